@@ -1,0 +1,239 @@
+/*
+ * rmqtt_gpu_router.h — C ABI of the MI355X-native publish-time topic matcher.
+ *
+ * Drop-in boundary for rmqtt's `Router::matches` hot path (and the RetainTree twin).
+ * The reference has no C ABI (it is in-process Rust); each entry point below names the
+ * reference interface it replaces.  A Rust `GpuRouter` plugin wraps `DefaultRouter`,
+ * delegates every `Router` method to it except `matches`, and mirrors `add`/`remove`
+ * into this table (INTEGRATION.md shows the binding).
+ *
+ *   reference interface                                         replaced by
+ *   ----------------------------------------------------------  --------------------------
+ *   DefaultRouter::new            rmqtt/src/router.rs:131-139    rgr_create
+ *   Router::add  (trie insert)    rmqtt/src/router.rs:434-453    rgr_filter_add + rgr_sub_add
+ *                                 rmqtt/src/trie.rs:113-126
+ *   Router::remove (trie prune)   rmqtt/src/router.rs:456-496    rgr_sub_remove + rgr_filter_remove
+ *                                 rmqtt/src/trie.rs:129-149
+ *   ClusterRouter restore loop    rmqtt-plugins/rmqtt-cluster-raft/src/router.rs:557-566
+ *                                                                rgr_subscribe_bulk
+ *   Router::matches / _matches    rmqtt/src/router.rs:499-501,   rgr_match_batch,
+ *     (Topic::from_str, TopicTree   174-265; topic.rs:379-394;   rgr_batch_* (windowed,
+ *      ::matches, relations walk)   trie.rs:157-159, 301-409      device-resident form)
+ *   _has_matches / _get_routes    rmqtt/src/router.rs:151-170    rgr_match_filters
+ *   RetainTree insert/remove      rmqtt/src/retain.rs:373-413    rgr_retain_topic_add/_remove
+ *   RetainTree::matches           rmqtt/src/retain.rs:450-526    rgr_retain_match_batch
+ *     (DefaultRetainStorage::get_message retain.rs:250-267,
+ *      rmqtt-retainer storage.rs:604-611)
+ *
+ * Conventions
+ *   - plain C99, no STL / torch types; every function returns an int32_t status
+ *     (RGR_OK == 0, negative = error) and never throws across the boundary;
+ *     rgr_last_error() returns a thread-local description of the last failure.
+ *   - strings are (ptr,len) byte ranges borrowed for the call only; batches are a
+ *     byte blob plus n+1 uint64 offsets.
+ *   - ownership: the caller (Rust) owns the subscription table objects; it assigns a
+ *     dense `sub_id` per (filter, client) relation.  `filter_id`s are assigned by the
+ *     library (one per distinct filter string).  The device side only ever sees ids.
+ *   - threading: handles are thread-safe.  Mutations are serialised internally and
+ *     become visible to matches at rgr_commit() (immutable epoch snapshot; matches in
+ *     flight keep the epoch they started with).  Match calls are re-entrant.
+ *   - result order (bit-exact contract): per topic the matched
+ *     filters appear in exactly TopicTree::matches' iteration order; within a filter
+ *     subscribers are ascending by sub_id.
+ *   - there is NO CPU fallback: if no HIP device is usable rgr_create fails with
+ *     RGR_EDEVICE.
+ */
+#ifndef RMQTT_GPU_ROUTER_H
+#define RMQTT_GPU_ROUTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------------ */
+enum {
+    RGR_OK = 0,
+    RGR_EOF = 1,              /* rgr_batch_next_window: no more windows               */
+    RGR_EINVAL = -1,          /* bad argument                                         */
+    RGR_EINVAL_TOPIC = -2,    /* topic / filter rejected by the parser (topic.rs Err) */
+    RGR_ENOMEM = -3,
+    RGR_EDEVICE = -4,         /* HIP error / no usable device                         */
+    RGR_ECAPACITY = -5,       /* a fixed capacity (window, arena) was exceeded        */
+    RGR_ENOENT = -6,          /* unknown filter_id / sub_id                           */
+    RGR_ESTATE = -7           /* call sequence error                                  */
+};
+
+/* per-topic status values in result/status arrays */
+enum {
+    RGR_TOPIC_OK = 0,
+    RGR_TOPIC_INVALID = -2    /* Topic::from_str would return Err => no subscribers
+                                 (rmqtt/src/shared.rs:774-777)                       */
+};
+
+/* subscription flag bits carried next to qos (opaque to the matcher) */
+enum {
+    RGR_SUB_V5 = 1u << 0,         /* SubscriptionOptions::V5 (types.rs:607-610)       */
+    RGR_SUB_NO_LOCAL = 1u << 1,   /* v5 No Local (router.rs:196-201, applied by host) */
+    RGR_SUB_SHARED = 1u << 2      /* member of a $share group (host post-filter)      */
+};
+
+typedef struct rgr_handle rgr_handle;
+typedef struct rgr_batch rgr_batch;
+
+typedef struct rgr_config {
+    int32_t device;             /* HIP device ordinal                                   */
+    uint32_t slot_cap;          /* matched-filter slots per topic before the overflow
+                                   arena is used (0 = default 32)                       */
+    uint64_t window_hits;       /* capacity of one expansion window in hits
+                                   (0 = default 2^28 => 3 GiB of tuples)                */
+    uint32_t chunk_topics;      /* topics walked per pass (0 = default 2^21)            */
+    uint32_t host_threads;      /* tokeniser threads (0 = hardware concurrency)         */
+    uint32_t collect_walk_stats;/* nonzero: count visited trie nodes in the walk kernel */
+    uint32_t reserved;
+} rgr_config;
+
+/* One emitted hit: exactly the (topic_idx, subscriber_id, qos) tuple of BASELINE.json. */
+typedef struct rgr_tuple {
+    uint32_t topic_idx;         /* index of the publish topic inside the batch          */
+    uint32_t sub_id;            /* caller-assigned relation id                          */
+    uint32_t qos_flags;         /* bits 0-7 qos, bits 8-15 RGR_SUB_* flags              */
+} rgr_tuple;
+
+/* Host-side result of rgr_match_batch (arrays owned by the library until
+ * rgr_result_free). */
+typedef struct rgr_result {
+    uint32_t n_topics;
+    uint64_t n_hits;
+    int32_t* status;            /* [n_topics] RGR_TOPIC_*                               */
+    uint64_t* hit_offsets;      /* [n_topics+1] CSR offsets into tuples                 */
+    rgr_tuple* tuples;          /* [n_hits] topic-major, filter order, sub_id ascending */
+    void* _owner;
+} rgr_result;
+
+/* Matched-filter view (TopicTree::matches items without the relation expansion). */
+typedef struct rgr_filters_result {
+    uint32_t n_topics;
+    uint64_t n_pairs;
+    int32_t* status;            /* [n_topics]                                           */
+    uint64_t* pair_offsets;     /* [n_topics+1]                                         */
+    uint32_t* filter_ids;       /* [n_pairs] in iteration order (duplicates preserved)  */
+    void* _owner;
+} rgr_filters_result;
+
+/* One expansion window of a device-resident batch. Pointers are DEVICE pointers valid
+ * until the next rgr_batch_next_window / rgr_batch_begin on the same batch.
+ * Hits of topic i (topic_begin <= i < topic_end) are
+ *   d_tuples[d_hit_offsets[i - topic_begin] - offsets_bias ..
+ *            d_hit_offsets[i - topic_begin + 1] - offsets_bias). */
+typedef struct rgr_window {
+    uint32_t topic_begin, topic_end;  /* topics [begin,end) of the batch                */
+    uint64_t n_hits;
+    uint64_t hit_base;                /* hits emitted by earlier windows of this pass   */
+    const rgr_tuple* d_tuples;        /* [n_hits]                                       */
+    const uint64_t* d_hit_offsets;    /* [topic_end-topic_begin+1]                      */
+    uint64_t offsets_bias;
+} rgr_window;
+
+typedef struct rgr_stats {
+    /* table */
+    uint64_t n_filters, n_subs, n_nodes, n_edge_slots, n_tokens, epoch;
+    uint64_t table_bytes_device;
+    /* cumulative since create / rgr_stats_reset */
+    uint64_t topics, invalid_topics, levels, pairs, hits, visited_nodes, overflow_topics;
+    uint64_t walk_launches, expand_launches;
+    double walk_ms, scan_ms, expand_ms, tokenize_ms, h2d_ms, d2h_ms;   /* HIP-event / wall */
+    /* algorithmic bytes of the work counted above */
+    uint64_t alg_bytes_walk, alg_bytes_expand;
+} rgr_stats;
+
+/* ---- lifecycle ----------------------------------------------------------------- */
+int32_t rgr_create(const rgr_config* cfg, rgr_handle** out);
+void rgr_destroy(rgr_handle* h);
+const char* rgr_last_error(void);
+const char* rgr_version(void);
+
+/* ---- subscription table (host-owned, mirrored to HBM at commit) ------------------- */
+/* Insert a filter path into the trie (idempotent): *filter_id receives the id of the
+ * (new or existing) filter.  RGR_EINVAL_TOPIC if Topic::from_str would fail. */
+int32_t rgr_filter_add(rgr_handle* h, const char* filter, uint32_t len, uint32_t* filter_id);
+/* Look up without inserting: RGR_ENOENT if absent. */
+int32_t rgr_filter_find(rgr_handle* h, const char* filter, uint32_t len, uint32_t* filter_id);
+/* Remove the filter (must have no subscriptions left) and prune empty trie nodes. */
+int32_t rgr_filter_remove(rgr_handle* h, uint32_t filter_id);
+int32_t rgr_sub_add(rgr_handle* h, uint32_t filter_id, uint32_t sub_id, uint8_t qos, uint8_t flags);
+int32_t rgr_sub_remove(rgr_handle* h, uint32_t filter_id, uint32_t sub_id);
+/* Restore/bulk path: for i in [0,n): filter_add(filter_i) + sub_add(fid, sub_ids ?
+ * sub_ids[i] : i, qos[i], flags ? flags[i] : 0).  filter_ids_out (optional, [n]).
+ * Returns RGR_OK and stores the number of rejected filters in *n_rejected. */
+int32_t rgr_subscribe_bulk(rgr_handle* h, const uint8_t* blob, const uint64_t* offsets, uint64_t n,
+                           const uint32_t* sub_ids, const uint8_t* qos, const uint8_t* flags,
+                           uint32_t* filter_ids_out, uint64_t* n_rejected);
+/* Publish the current host table as a new immutable device epoch. */
+int32_t rgr_commit(rgr_handle* h);
+
+/* ---- matching, host buffers in / host buffers out ------------------------------------ */
+int32_t rgr_match_batch(rgr_handle* h, const uint8_t* topics_blob, const uint64_t* topic_offsets, uint32_t n,
+                        rgr_result* out);
+void rgr_result_free(rgr_result* r);
+int32_t rgr_match_filters(rgr_handle* h, const uint8_t* topics_blob, const uint64_t* topic_offsets, uint32_t n,
+                          rgr_filters_result* out);
+void rgr_filters_result_free(rgr_filters_result* r);
+
+/* ---- matching, device-resident batches (bench / multi-GPU / streaming consumers) ------ */
+/* Parse + tokenise the topics against the current dictionary and leave the token
+ * arrays resident in HBM. */
+int32_t rgr_batch_create(rgr_handle* h, const uint8_t* topics_blob, const uint64_t* topic_offsets, uint32_t n,
+                         rgr_batch** out);
+void rgr_batch_destroy(rgr_batch* b);
+/* [n] statuses computed by the tokeniser (host pointer, valid for the batch lifetime) */
+const int32_t* rgr_batch_status(const rgr_batch* b);
+/* Start a pass over the batch (binds the current epoch, rewinds the window cursor). */
+int32_t rgr_batch_begin(rgr_batch* b);
+/* Walk (as needed) and expand the next window of topics.  RGR_EOF after the last. */
+int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w);
+/* Copy a window's tuples to host memory (blocking). */
+int32_t rgr_window_to_host(rgr_batch* b, const rgr_window* w, rgr_tuple* host_tuples, uint64_t* host_hit_offsets);
+/* One full pass: begin + every window (tuples stay on device, each window overwrites the
+ * previous one).  *n_hits / *n_windows are optional. */
+int32_t rgr_batch_run(rgr_batch* b, uint64_t* n_hits, uint32_t* n_windows);
+
+/* ---- retained-message twin (RetainTree) ----------------------------------------------- */
+/* Insert / replace a retained topic carrying caller value `topic_id`. */
+int32_t rgr_retain_topic_add(rgr_handle* h, const char* topic, uint32_t len, uint32_t topic_id);
+int32_t rgr_retain_topic_remove(rgr_handle* h, const char* topic, uint32_t len);
+int32_t rgr_retain_add_bulk(rgr_handle* h, const uint8_t* blob, const uint64_t* offsets, uint64_t n,
+                            const uint32_t* topic_ids, uint64_t* n_rejected);
+int32_t rgr_retain_commit(rgr_handle* h);
+typedef struct rgr_retain_result {
+    uint32_t n_filters;
+    uint64_t n_hits;
+    int32_t* status;            /* [n_filters]                                          */
+    uint64_t* hit_offsets;      /* [n_filters+1]                                        */
+    uint32_t* topic_ids;        /* [n_hits] per filter ascending by topic_id            */
+    void* _owner;
+} rgr_retain_result;
+int32_t rgr_retain_match_batch(rgr_handle* h, const uint8_t* filters_blob, const uint64_t* filter_offsets, uint32_t n,
+                               rgr_retain_result* out);
+void rgr_retain_result_free(rgr_retain_result* r);
+
+/* ---- multi-GPU sharding rule (host-side helper, no device work) -------------------------
+ * Table and publishes shard by a hash of the first TWO topic levels (a
+ * first-level-only hash is too skewed under Zipf level-0 tokens):
+ *   topic  -> shard = H(level0, level1 | none) mod n_shards
+ *   filter -> the same, unless level0 or level1 is a wildcard: then -1 = replicate on
+ *             every shard.  A topic's complete match set then lives on its owner shard.
+ * out[i] in [0,n_shards) or -1; invalid topics/filters get shard 0 (they match nothing). */
+int32_t rgr_shard_assign(const uint8_t* blob, const uint64_t* offsets, uint64_t n, uint32_t n_shards, int32_t is_filter,
+                         int32_t* out);
+
+/* ---- observability ------------------------------------------------------------------------ */
+int32_t rgr_stats_get(rgr_handle* h, rgr_stats* out);
+int32_t rgr_stats_reset(rgr_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RMQTT_GPU_ROUTER_H */

@@ -1,0 +1,454 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see oracle.hpp).  Non-template parts of the
+// restatement plus the ctypes-facing C API used by tests/ and bench.py's
+// cpu_baseline leg.
+#include "oracle.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+
+namespace orc {
+
+// rmqtt/src/topic.rs:357-377
+bool parse_level(std::string_view s, Level& out) {
+    if (s == "+") { out = Level{Kind::SingleWildcard, "+"}; return true; }
+    if (s == "#") { out = Level{Kind::MultiWildcard, "#"}; return true; }
+    if (s.empty()) { out = Level{Kind::Blank, ""}; return true; }
+    if (s.find_first_of("+#") != std::string_view::npos) return false;          // InvalidLevel
+    if (s[0] == '$') { out = Level{Kind::Metadata, std::string(s)}; return true; }   // topic.rs:66-68
+    out = Level{Kind::Normal, std::string(s)};
+    return true;
+}
+
+// rmqtt/src/topic.rs:379-394 (split on '/') + 231-243 (is_valid)
+bool parse_topic(std::string_view s, Topic& out) {
+    out.clear();
+    size_t start = 0;
+    for (;;) {
+        size_t pos = s.find('/', start);
+        std::string_view seg = s.substr(start, pos == std::string_view::npos ? std::string_view::npos : pos - start);
+        Level l;
+        if (!parse_level(seg, l)) return false;
+        out.push_back(std::move(l));
+        if (pos == std::string_view::npos) break;
+        start = pos + 1;
+    }
+    // Level::is_valid holds by construction of parse_level; positional rules:
+    for (size_t i = 0; i < out.size(); ++i) {
+        if (out[i].kind == Kind::MultiWildcard && i != out.size() - 1) return false;
+        if (out[i].kind == Kind::Metadata && i != 0) return false;
+    }
+    return true;
+}
+
+std::string join_levels(const std::vector<const Level*>& levels) {
+    std::string r;
+    for (size_t i = 0; i < levels.size(); ++i) { if (i) r.push_back('/'); r += levels[i]->s; }
+    return r;
+}
+
+std::string topic_to_string(const Topic& t) {
+    std::string r;
+    for (size_t i = 0; i < t.size(); ++i) { if (i) r.push_back('/'); r += t[i].s; }
+    return r;
+}
+
+// ------------------------------------------------------------ DefaultRouter
+bool DefaultRouter::add(std::string_view topic_filter, const Id& id, const SubscriptionOptions& opts, uint32_t rel_id) {
+    Topic topic;
+    if (!parse_topic(topic_filter, topic)) return false;       // router.rs:436 (`?`)
+    topics_.insert(topic, Unit{});                             // router.rs:438
+    auto it = relations_.find(std::string(topic_filter));
+    if (it == relations_.end()) {                              // router.rs:443-446
+        topics_count_++;
+        it = relations_.emplace(std::string(topic_filter), FilterEntry{next_filter_id_++, {}}).first;
+    }
+    auto& rels = it->second.rels;
+    auto old = rels.find(id.client_id);
+    if (old == rels.end()) { relations_count_++; rels.emplace(id.client_id, Rel{id, opts, rel_id}); }   // router.rs:447-450
+    else old->second = Rel{id, opts, rel_id};
+    return true;
+}
+
+int DefaultRouter::remove(std::string_view topic_filter, const Id& id) {
+    auto it = relations_.find(std::string(topic_filter));
+    if (it == relations_.end()) return 1;
+    auto& rels = it->second.rels;
+    auto r = rels.find(id.client_id);
+    if (r == rels.end() || !(r->second.id == id)) return 1;    // router.rs:460-467
+    rels.erase(r);
+    relations_count_--;
+    if (rels.empty()) {                                        // router.rs:484-490
+        relations_.erase(it);
+        topics_count_--;
+        Topic topic;
+        if (!parse_topic(topic_filter, topic)) return -1;
+        topics_.remove(topic, Unit{});
+    }
+    return 0;
+}
+
+uint32_t DefaultRouter::filter_id_of(const std::string& f) const {
+    auto it = relations_.find(f);
+    return it == relations_.end() ? 0xFFFFFFFFu : it->second.filter_id;
+}
+
+namespace {
+// types.rs:503-541
+struct Collector {
+    std::vector<SubRelation> v3_rels;
+    std::vector<std::string> v5_order;                       // deterministic stand-in for HashMap order
+    std::unordered_map<std::string, SubRelation> v5_rels;
+    void add(const std::string& filter, const std::string& client, const SubscriptionOptions& opts, uint32_t rel_id) {
+        if (opts.is_v3()) {
+            v3_rels.push_back(SubRelation{filter, client, opts, std::nullopt, rel_id});
+            return;
+        }
+        auto it = v5_rels.find(client);
+        if (it != v5_rels.end()) {                            // types.rs:526-534
+            if (opts.sub_ident) {
+                if (it->second.sub_ids) it->second.sub_ids->push_back(opts.sub_ident);
+                else it->second.sub_ids = std::vector<uint32_t>{opts.sub_ident};
+            }
+        } else {                                              // types.rs:535-538
+            SubRelation r{filter, client, opts, std::nullopt, rel_id};
+            if (opts.sub_ident) r.sub_ids = std::vector<uint32_t>{opts.sub_ident};
+            v5_rels.emplace(client, std::move(r));
+            v5_order.push_back(client);
+        }
+    }
+};
+}  // namespace
+
+bool DefaultRouter::matches(const Id& this_id, std::string_view topic_name, SubRelationsMap& out, WalkStats* st) const {
+    out.clear();
+    Topic topic;
+    if (!parse_topic(topic_name, topic)) { if (st) st->invalid++; return false; }   // router.rs:177
+    if (st) st->levels += topic.size();
+    std::map<NodeId, Collector> collector_map;
+    for (auto& item : topics_.matches(topic, st)) {             // router.rs:178
+        const std::string filter = join_levels(item.first);    // router.rs:179 (to_topic_filter)
+        auto rit = relations_.find(filter);                    // router.rs:194
+        if (rit == relations_.end()) continue;
+        // Reference iteration order over `rels` is unspecified (ahash RandomState);
+        // canonicalise by rel_id.
+        std::vector<const std::pair<const std::string, Rel>*> ordered;
+        for (auto& kv : rit->second.rels) ordered.push_back(&kv);
+        std::sort(ordered.begin(), ordered.end(), [](auto* a, auto* b) { return a->second.rel_id < b->second.rel_id; });
+        for (auto* kv : ordered) {
+            const Rel& rel = kv->second;
+            auto nl = rel.opts.opt_no_local();
+            if (nl && *nl && this_id == rel.id) continue;      // router.rs:196-201
+            collector_map[rel.id.node_id].add(filter, kv->first, rel.opts, rel.rel_id);   // router.rs:214-229
+            if (st) st->hits++;
+        }
+    }
+    for (auto& kv : collector_map) {                            // router.rs:258-261 + types.rs:488-497
+        auto& dst = out[kv.first];
+        dst = std::move(kv.second.v3_rels);
+        for (auto& c : kv.second.v5_order) dst.push_back(std::move(kv.second.v5_rels[c]));
+    }
+    return true;
+}
+
+bool DefaultRouter::match_flat(uint32_t topic_idx, std::string_view topic_name, std::vector<FlatHit>& out, WalkStats* st) const {
+    Topic topic;
+    if (!parse_topic(topic_name, topic)) { if (st) st->invalid++; return false; }
+    if (st) st->levels += topic.size();
+    std::vector<FlatHit> tmp;
+    for (auto& item : topics_.matches(topic, st)) {
+        auto rit = relations_.find(join_levels(item.first));
+        if (rit == relations_.end()) continue;
+        tmp.clear();
+        for (auto& kv : rit->second.rels) {
+            const Rel& r = kv.second;
+            uint8_t flags = uint8_t((r.opts.v5 ? 1 : 0) | (r.opts.no_local ? 2 : 0));
+            tmp.push_back(FlatHit{topic_idx, rit->second.filter_id, r.rel_id, r.opts.qos, flags});
+        }
+        std::sort(tmp.begin(), tmp.end(), [](const FlatHit& a, const FlatHit& b) { return a.sub_id < b.sub_id; });
+        out.insert(out.end(), tmp.begin(), tmp.end());
+        if (st) st->hits += tmp.size();
+    }
+    return true;
+}
+
+bool DefaultRouter::has_matches(std::string_view t) const {
+    Topic topic;
+    if (!parse_topic(t, topic)) return false;
+    return topics_.is_match(topic);
+}
+
+std::vector<std::string> DefaultRouter::get_routes(std::string_view t, bool* ok) const {
+    std::vector<std::string> r;
+    Topic topic;
+    *ok = parse_topic(t, topic);
+    if (!*ok) return r;
+    for (auto& item : topics_.matches(topic)) {                 // .unique(), router.rs:166
+        std::string f = join_levels(item.first);
+        if (std::find(r.begin(), r.end(), f) == r.end()) r.push_back(std::move(f));
+    }
+    return r;
+}
+
+}  // namespace orc
+
+// =====================================================================  C API
+using namespace orc;
+
+namespace {
+char* dup_str(const std::string& s) {
+    char* p = static_cast<char*>(std::malloc(s.size() + 1));
+    std::memcpy(p, s.data(), s.size());
+    p[s.size()] = 0;
+    return p;
+}
+template <class T> T* dup_vec(const std::vector<T>& v) {
+    T* p = static_cast<T*>(std::malloc(std::max<size_t>(1, v.size()) * sizeof(T)));
+    if (!v.empty()) std::memcpy(p, v.data(), v.size() * sizeof(T));
+    return p;
+}
+std::string esc(const std::string& s) {   // strings in canonical dumps are newline/tab free in practice
+    std::string r;
+    for (char c : s) { if (c == '\n') r += "\\n"; else if (c == '\t') r += "\\t"; else r.push_back(c); }
+    return r;
+}
+}  // namespace
+
+extern "C" {
+
+void orc_free(void* p) { std::free(p); }
+
+// ---- parser -------------------------------------------------------------
+// Returns number of levels, or -1 on Err.  kinds (if non-null) receives one byte per level.
+int orc_parse_topic(const char* s, uint64_t len, uint8_t* kinds, int cap) {
+    Topic t;
+    if (!parse_topic(std::string_view(s, len), t)) return -1;
+    for (size_t i = 0; i < t.size() && int(i) < cap; ++i) kinds[i] = uint8_t(t[i].kind);
+    return int(t.size());
+}
+
+// ---- TopicTree<u64> (golden vectors) --------------------------------------
+void* orc_tree_new() { return new TopicTree<uint64_t>(); }
+void orc_tree_free(void* t) { delete static_cast<TopicTree<uint64_t>*>(t); }
+int orc_tree_insert(void* t, const char* f, uint64_t len, uint64_t v) {
+    Topic tp;
+    if (!parse_topic(std::string_view(f, len), tp)) return -1;
+    return static_cast<TopicTree<uint64_t>*>(t)->insert(tp, v) ? 1 : 0;
+}
+int orc_tree_remove(void* t, const char* f, uint64_t len, uint64_t v) {
+    Topic tp;
+    if (!parse_topic(std::string_view(f, len), tp)) return -1;
+    return static_cast<TopicTree<uint64_t>*>(t)->remove(tp, v) ? 1 : 0;
+}
+uint64_t orc_tree_values_size(void* t) { return static_cast<TopicTree<uint64_t>*>(t)->values_size(); }
+uint64_t orc_tree_nodes_size(void* t) { return static_cast<TopicTree<uint64_t>*>(t)->nodes_size(); }
+// One line per yielded item, in iterator order: "<filter>\t<v1>,<v2>,...\n".  NULL on parse Err.
+char* orc_tree_matches(void* t, const char* topic, uint64_t len) {
+    Topic tp;
+    if (!parse_topic(std::string_view(topic, len), tp)) return nullptr;
+    std::string r;
+    for (auto& item : static_cast<TopicTree<uint64_t>*>(t)->matches(tp)) {
+        r += esc(join_levels(item.first));
+        r.push_back('\t');
+        for (size_t i = 0; i < item.second.size(); ++i) { if (i) r.push_back(','); r += std::to_string(*item.second[i]); }
+        r.push_back('\n');
+    }
+    return dup_str(r);
+}
+int orc_tree_is_match(void* t, const char* topic, uint64_t len) {
+    Topic tp;
+    if (!parse_topic(std::string_view(topic, len), tp)) return -1;
+    return static_cast<TopicTree<uint64_t>*>(t)->is_match(tp) ? 1 : 0;
+}
+
+// ---- RetainTree<i64> ------------------------------------------------------
+void* orc_retain_new() { return new RetainTree<int64_t>(); }
+void orc_retain_free(void* t) { delete static_cast<RetainTree<int64_t>*>(t); }
+int orc_retain_insert(void* t, const char* s, uint64_t len, int64_t v) {
+    Topic tp;
+    if (!parse_topic(std::string_view(s, len), tp)) return -1;
+    static_cast<RetainTree<int64_t>*>(t)->insert(tp, v);
+    return 0;
+}
+// 1 = removed (value in *v), 0 = nothing stored, -1 = parse Err
+int orc_retain_remove(void* t, const char* s, uint64_t len, int64_t* v) {
+    Topic tp;
+    if (!parse_topic(std::string_view(s, len), tp)) return -1;
+    auto r = static_cast<RetainTree<int64_t>*>(t)->remove(tp);
+    if (r && v) *v = *r;
+    return r ? 1 : 0;
+}
+// Removes every value < keep_from (test hook for retain(); mirrors retain.rs:420-447).
+uint64_t orc_retain_retain_ge(void* t, uint64_t max_limit, int64_t keep_from) {
+    return static_cast<RetainTree<int64_t>*>(t)->retain(size_t(max_limit), [&](int64_t& v) { return v >= keep_from; });
+}
+uint64_t orc_retain_values_size(void* t) { return static_cast<RetainTree<int64_t>*>(t)->values_size(); }
+uint64_t orc_retain_nodes_size(void* t) { return static_cast<RetainTree<int64_t>*>(t)->nodes_size(); }
+// One line per hit "<topic>\t<value>\n", sorted by topic string (canonical form, App. A.5).
+char* orc_retain_matches(void* t, const char* filter, uint64_t len) {
+    Topic tp;
+    if (!parse_topic(std::string_view(filter, len), tp)) return nullptr;
+    std::vector<std::pair<std::string, int64_t>> rows;
+    for (auto& kv : static_cast<RetainTree<int64_t>*>(t)->matches(tp)) rows.emplace_back(topic_to_string(kv.first), kv.second);
+    std::sort(rows.begin(), rows.end());
+    std::string r;
+    for (auto& row : rows) { r += esc(row.first); r.push_back('\t'); r += std::to_string(row.second); r.push_back('\n'); }
+    return dup_str(r);
+}
+// Batch form for the GPU parity tests: values per filter, each filter's list sorted ascending.
+// status[i] = 0 ok / -1 parse Err.  Returns total hits; *offsets (n+1) and *values are malloc'ed.
+uint64_t orc_retain_match_batch(void* t, const char* blob, const uint64_t* offs, uint64_t n, int32_t* status,
+                                uint64_t** offsets, int64_t** values, uint64_t* visited) {
+    auto* tree = static_cast<RetainTree<int64_t>*>(t);
+    std::vector<uint64_t> off(n + 1, 0);
+    std::vector<int64_t> vals;
+    WalkStats st;
+    for (uint64_t i = 0; i < n; ++i) {
+        Topic tp;
+        if (!parse_topic(std::string_view(blob + offs[i], offs[i + 1] - offs[i]), tp)) { status[i] = -1; off[i + 1] = vals.size(); continue; }
+        status[i] = 0;
+        size_t b = vals.size();
+        for (auto& kv : tree->matches(tp, &st)) vals.push_back(kv.second);
+        std::sort(vals.begin() + b, vals.end());
+        off[i + 1] = vals.size();
+    }
+    *offsets = dup_vec(off); *values = dup_vec(vals);
+    if (visited) *visited = st.visited;
+    return vals.size();
+}
+
+// ---- DefaultRouter ----------------------------------------------------------
+struct orc_id {
+    uint64_t node_id;
+    const char* client_id; uint32_t client_len;
+    int64_t create_time;
+    uint16_t lid;
+};
+static Id mk_id(const orc_id* i) {
+    Id id;
+    id.node_id = i->node_id; id.lid = i->lid; id.create_time = i->create_time;
+    id.client_id.assign(i->client_id, i->client_len);
+    return id;
+}
+struct orc_opts { uint8_t v5, qos, no_local, retain_as_published, retain_handling; uint32_t sub_ident; };
+static SubscriptionOptions mk_opts(const orc_opts* o) {
+    SubscriptionOptions s;
+    s.v5 = o->v5; s.qos = o->qos; s.no_local = o->no_local; s.retain_as_published = o->retain_as_published;
+    s.retain_handling = o->retain_handling; s.sub_ident = o->sub_ident;
+    return s;
+}
+
+void* orc_router_new() { return new DefaultRouter(); }
+void orc_router_free(void* r) { delete static_cast<DefaultRouter*>(r); }
+int orc_router_add(void* r, const char* f, uint64_t len, const orc_id* id, const orc_opts* o, uint32_t rel_id) {
+    return static_cast<DefaultRouter*>(r)->add(std::string_view(f, len), mk_id(id), mk_opts(o), rel_id) ? 0 : -1;
+}
+int orc_router_remove(void* r, const char* f, uint64_t len, const orc_id* id) {
+    return static_cast<DefaultRouter*>(r)->remove(std::string_view(f, len), mk_id(id));
+}
+int64_t orc_router_topics(void* r) { return static_cast<DefaultRouter*>(r)->topics_count(); }
+int64_t orc_router_routes(void* r) { return static_cast<DefaultRouter*>(r)->relations_count(); }
+uint64_t orc_router_topics_tree(void* r) { return static_cast<DefaultRouter*>(r)->topics_tree(); }
+uint32_t orc_router_filter_id(void* r, const char* f, uint64_t len) {
+    return static_cast<DefaultRouter*>(r)->filter_id_of(std::string(f, len));
+}
+
+// Bulk add used by the large parity tests / the bench: subscription i = (filter i,
+// client "c<client[i]>", node_id 1, v3 opts with qos[i]), rel_id = i.
+int orc_router_add_bulk(void* r, const char* blob, const uint64_t* offs, uint64_t n, const uint32_t* client, const uint8_t* qos) {
+    auto* rt = static_cast<DefaultRouter*>(r);
+    int bad = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        Id id; id.node_id = 1; id.client_id = "c" + std::to_string(client[i]);
+        SubscriptionOptions o; o.qos = qos[i];
+        if (!rt->add(std::string_view(blob + offs[i], offs[i + 1] - offs[i]), id, o, uint32_t(i))) ++bad;
+    }
+    return bad;
+}
+
+// Canonical dump of DefaultRouter::matches (App. A.5): per node id ascending,
+//   "N <node>\n" then "3 <filter>\t<client>\t<qos>\t<rel_id>\n" rows sorted, then
+//   "5 <client>\t<first filter>\t<qos>\t<nl>\t<sorted sub ids,>\n" rows sorted by client.
+// NULL => Err.
+char* orc_router_matches(void* r, const orc_id* this_id, const char* topic, uint64_t len) {
+    SubRelationsMap m;
+    if (!static_cast<DefaultRouter*>(r)->matches(mk_id(this_id), std::string_view(topic, len), m)) return nullptr;
+    std::string out;
+    for (auto& kv : m) {
+        out += "N " + std::to_string(kv.first) + "\n";
+        std::vector<std::string> v3, v5;
+        for (auto& s : kv.second) {
+            if (s.opts.is_v3()) {
+                v3.push_back("3 " + esc(s.topic_filter) + "\t" + esc(s.client_id) + "\t" + std::to_string(s.opts.qos) + "\t" + std::to_string(s.rel_id) + "\n");
+            } else {
+                std::string ids;
+                if (s.sub_ids) {
+                    auto v = *s.sub_ids; std::sort(v.begin(), v.end());
+                    for (size_t i = 0; i < v.size(); ++i) { if (i) ids.push_back(','); ids += std::to_string(v[i]); }
+                } else ids = "-";
+                v5.push_back("5 " + esc(s.client_id) + "\t" + esc(s.topic_filter) + "\t" + std::to_string(s.opts.qos) + "\t" + std::to_string(int(s.opts.no_local)) + "\t" + ids + "\n");
+            }
+        }
+        std::sort(v3.begin(), v3.end()); std::sort(v5.begin(), v5.end());
+        for (auto& s : v3) out += s;
+        for (auto& s : v5) out += s;
+    }
+    return dup_str(out);
+}
+
+struct orc_stats { uint64_t levels, visited, matched, hits, invalid; };
+
+// Flat id-level match of a batch (single thread): status[n] (0 / -1), hit_offsets[n+1],
+// and per hit filter_id / sub_id / qos / flags.  Arrays are malloc'ed (orc_free).
+uint64_t orc_router_match_flat(void* r, const char* blob, const uint64_t* offs, uint64_t n, int32_t* status,
+                               uint64_t** hit_offsets, uint32_t** filter_ids, uint32_t** sub_ids, uint8_t** qos,
+                               uint8_t** flags, orc_stats* stats) {
+    auto* rt = static_cast<DefaultRouter*>(r);
+    std::vector<FlatHit> hits;
+    std::vector<uint64_t> off(n + 1, 0);
+    WalkStats st;
+    for (uint64_t i = 0; i < n; ++i) {
+        bool ok = rt->match_flat(uint32_t(i), std::string_view(blob + offs[i], offs[i + 1] - offs[i]), hits, &st);
+        status[i] = ok ? 0 : -1;
+        off[i + 1] = hits.size();
+    }
+    std::vector<uint32_t> f(hits.size()), s(hits.size());
+    std::vector<uint8_t> q(hits.size()), fl(hits.size());
+    for (size_t i = 0; i < hits.size(); ++i) { f[i] = hits[i].filter_id; s[i] = hits[i].sub_id; q[i] = hits[i].qos; fl[i] = hits[i].flags; }
+    *hit_offsets = dup_vec(off); *filter_ids = dup_vec(f); *sub_ids = dup_vec(s); *qos = dup_vec(q); *flags = dup_vec(fl);
+    if (stats) *stats = orc_stats{st.levels, st.visited, st.matched, st.hits, st.invalid};
+    return hits.size();
+}
+
+// Timed multi-thread match (the cpu_baseline leg): topics statically partitioned over
+// `threads` threads sharing the read-only table (mirrors tokio tasks under the trie's
+// RwLock read guard, router.rs:178).  Includes per-topic parsing, as the reference does
+// (router.rs:177).  Hits are produced into per-thread vectors and discarded.
+double orc_router_match_timed(void* r, const char* blob, const uint64_t* offs, uint64_t n, int threads, orc_stats* stats) {
+    auto* rt = static_cast<DefaultRouter*>(r);
+    if (threads < 1) threads = 1;
+    std::vector<WalkStats> sts(threads);
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    for (int k = 0; k < threads; ++k) {
+        th.emplace_back([&, k] {
+            std::vector<FlatHit> hits;
+            uint64_t lo = n * k / threads, hi = n * (k + 1) / threads;
+            for (uint64_t i = lo; i < hi; ++i) {
+                hits.clear();
+                rt->match_flat(uint32_t(i), std::string_view(blob + offs[i], offs[i + 1] - offs[i]), hits, &sts[k]);
+            }
+        });
+    }
+    for (auto& t : th) t.join();
+    double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    WalkStats tot;
+    for (auto& s : sts) tot.add(s);
+    if (stats) *stats = orc_stats{tot.levels, tot.visited, tot.matched, tot.hits, tot.invalid};
+    return sec;
+}
+
+}  // extern "C"

@@ -1,0 +1,79 @@
+"""In-tree builds of the native pieces (no pip install, no JIT cache).
+
+  librmqtt_gpu_router.so  — the product: HIP kernels (gfx950) + host table compiler
+                            + the C ABI of include/rmqtt_gpu_router.h   (hipcc)
+  librmqtt_workload.so    — the seeded synthetic workload generator     (g++)
+
+The ``.so`` files are git-ignored but travel to the GPU box with the tree snapshot.
+"""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+ROOT = os.path.dirname(HERE)
+INCLUDE = os.path.join(ROOT, "include")
+
+GPU_LIB = os.path.join(HERE, "librmqtt_gpu_router.so")
+WL_LIB = os.path.join(HERE, "librmqtt_workload.so")
+HOST_LIB = os.path.join(HERE, "librmqtt_host_router.so")
+
+GPU_SRCS = ["c_abi.cpp", "table.cpp", "kernels.hip"]
+GPU_HDRS = ["table.hpp", "topic.hpp", "device.hpp", "kernels.hpp", "retain.hpp", "retain_abi.inc"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def hipcc():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def build_workload(force=False):
+    src = os.path.join(CSRC, "workload.cpp")
+    if force or _stale(WL_LIB, [src]):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", WL_LIB, src])
+    return WL_LIB
+
+
+def build_gpu(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, s) for s in GPU_SRCS]
+    deps = srcs + [os.path.join(CSRC, h) for h in GPU_HDRS] + [os.path.join(INCLUDE, "rmqtt_gpu_router.h")]
+    if force or _stale(GPU_LIB, deps):
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
+               "-Wall", "-Wno-unused-result", "-I", INCLUDE, "-I", CSRC, "-x", "hip"]
+        cmd += srcs + ["-o", GPU_LIB]
+        if verbose:
+            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        subprocess.check_call(cmd)
+    return GPU_LIB
+
+
+def build_host_router(force=False):
+    """C++ mirror of the reference's Router trait over the C ABI + its test shim."""
+    hdir = os.path.join(HERE, "host")
+    srcs = [os.path.join(hdir, "gpu_router.cpp"), os.path.join(hdir, "router_capi.cpp")]
+    deps = srcs + [os.path.join(hdir, "gpu_router.hpp"), os.path.join(INCLUDE, "rmqtt_gpu_router.h"), GPU_LIB]
+    if force or _stale(HOST_LIB, deps):
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I", INCLUDE, "-I", hdir] + srcs
+        cmd += ["-o", HOST_LIB, "-L", HERE, "-lrmqtt_gpu_router", "-Wl,-rpath,$ORIGIN"]
+        subprocess.check_call(cmd)
+    return HOST_LIB
+
+
+def build_all(force=False):
+    build_workload(force)
+    build_gpu(force)
+    if os.path.exists(os.path.join(HERE, "host", "gpu_router.cpp")):
+        build_host_router(force)
+
+
+if __name__ == "__main__":
+    import sys
+    build_all(force="--force" in sys.argv)
+    print("built:", GPU_LIB, WL_LIB)

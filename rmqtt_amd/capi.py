@@ -1,0 +1,333 @@
+"""ctypes view of the C ABI in include/rmqtt_gpu_router.h (tests, bench, smoke).
+
+No compute happens in Python: every call goes straight to librmqtt_gpu_router.so.
+Importing this module does not need a GPU; ``Router()`` (rgr_create) does and raises
+``RgrError`` with RGR_EDEVICE when none is usable — there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+RGR_OK, RGR_EOF = 0, 1
+RGR_EINVAL, RGR_EINVAL_TOPIC, RGR_ENOMEM, RGR_EDEVICE, RGR_ECAPACITY, RGR_ENOENT, RGR_ESTATE = -1, -2, -3, -4, -5, -6, -7
+RGR_TOPIC_OK, RGR_TOPIC_INVALID = 0, -2
+RGR_SUB_V5, RGR_SUB_NO_LOCAL, RGR_SUB_SHARED = 1, 2, 4
+
+TUPLE_DTYPE = np.dtype([("topic_idx", np.uint32), ("sub_id", np.uint32), ("qos_flags", np.uint32)])
+
+# every symbol include/rmqtt_gpu_router.h declares
+SYMBOLS = [
+    "rgr_create", "rgr_destroy", "rgr_last_error", "rgr_version",
+    "rgr_filter_add", "rgr_filter_find", "rgr_filter_remove", "rgr_sub_add", "rgr_sub_remove",
+    "rgr_subscribe_bulk", "rgr_commit",
+    "rgr_match_batch", "rgr_result_free", "rgr_match_filters", "rgr_filters_result_free",
+    "rgr_batch_create", "rgr_batch_destroy", "rgr_batch_status", "rgr_batch_begin", "rgr_batch_next_window",
+    "rgr_window_to_host", "rgr_batch_run",
+    "rgr_retain_topic_add", "rgr_retain_topic_remove", "rgr_retain_add_bulk", "rgr_retain_commit",
+    "rgr_retain_match_batch", "rgr_retain_result_free",
+    "rgr_shard_assign", "rgr_stats_get", "rgr_stats_reset",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [("device", C.c_int32), ("slot_cap", C.c_uint32), ("window_hits", C.c_uint64),
+                ("chunk_topics", C.c_uint32), ("host_threads", C.c_uint32), ("collect_walk_stats", C.c_uint32),
+                ("reserved", C.c_uint32)]
+
+
+class Result(C.Structure):
+    _fields_ = [("n_topics", C.c_uint32), ("n_hits", C.c_uint64), ("status", C.c_void_p),
+                ("hit_offsets", C.c_void_p), ("tuples", C.c_void_p), ("_owner", C.c_void_p)]
+
+
+class FiltersResult(C.Structure):
+    _fields_ = [("n_topics", C.c_uint32), ("n_pairs", C.c_uint64), ("status", C.c_void_p),
+                ("pair_offsets", C.c_void_p), ("filter_ids", C.c_void_p), ("_owner", C.c_void_p)]
+
+
+class RetainResult(C.Structure):
+    _fields_ = [("n_filters", C.c_uint32), ("n_hits", C.c_uint64), ("status", C.c_void_p),
+                ("hit_offsets", C.c_void_p), ("topic_ids", C.c_void_p), ("_owner", C.c_void_p)]
+
+
+class Window(C.Structure):
+    _fields_ = [("topic_begin", C.c_uint32), ("topic_end", C.c_uint32), ("n_hits", C.c_uint64),
+                ("hit_base", C.c_uint64), ("d_tuples", C.c_void_p), ("d_hit_offsets", C.c_void_p),
+                ("offsets_bias", C.c_uint64)]
+
+
+class Stats(C.Structure):
+    _fields_ = ([(n, C.c_uint64) for n in ("n_filters", "n_subs", "n_nodes", "n_edge_slots", "n_tokens", "epoch",
+                                           "table_bytes_device", "topics", "invalid_topics", "levels", "pairs", "hits",
+                                           "visited_nodes", "overflow_topics", "walk_launches", "expand_launches")] +
+                [(n, C.c_double) for n in ("walk_ms", "scan_ms", "expand_ms", "tokenize_ms", "h2d_ms", "d2h_ms")] +
+                [(n, C.c_uint64) for n in ("alg_bytes_walk", "alg_bytes_expand")])
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class RgrError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"rgr error {code}: {msg}")
+        self.code = code
+
+
+_LIB = None
+
+
+def lib():
+    """Load (building in-tree if stale) librmqtt_gpu_router.so.  Fails loudly if it cannot."""
+    global _LIB
+    if _LIB is None:
+        path = _build.build_gpu()
+        L = C.CDLL(path, mode=C.RTLD_GLOBAL)
+        vp, u32, u64, i32, u8 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int32, C.c_uint8
+        for name in SYMBOLS:
+            getattr(L, name)   # AttributeError if the .so misses a declared symbol
+        L.rgr_last_error.restype = C.c_char_p
+        L.rgr_version.restype = C.c_char_p
+        L.rgr_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+        L.rgr_destroy.argtypes = [vp]; L.rgr_destroy.restype = None
+        L.rgr_filter_add.argtypes = [vp, C.c_char_p, u32, C.POINTER(u32)]
+        L.rgr_filter_find.argtypes = [vp, C.c_char_p, u32, C.POINTER(u32)]
+        L.rgr_filter_remove.argtypes = [vp, u32]
+        L.rgr_sub_add.argtypes = [vp, u32, u32, u8, u8]
+        L.rgr_sub_remove.argtypes = [vp, u32, u32]
+        L.rgr_subscribe_bulk.argtypes = [vp, vp, vp, u64, vp, vp, vp, vp, C.POINTER(u64)]
+        L.rgr_commit.argtypes = [vp]
+        L.rgr_match_batch.argtypes = [vp, vp, vp, u32, C.POINTER(Result)]
+        L.rgr_result_free.argtypes = [C.POINTER(Result)]; L.rgr_result_free.restype = None
+        L.rgr_match_filters.argtypes = [vp, vp, vp, u32, C.POINTER(FiltersResult)]
+        L.rgr_filters_result_free.argtypes = [C.POINTER(FiltersResult)]; L.rgr_filters_result_free.restype = None
+        L.rgr_batch_create.argtypes = [vp, vp, vp, u32, C.POINTER(vp)]
+        L.rgr_batch_destroy.argtypes = [vp]; L.rgr_batch_destroy.restype = None
+        L.rgr_batch_status.argtypes = [vp]; L.rgr_batch_status.restype = vp
+        L.rgr_batch_begin.argtypes = [vp]
+        L.rgr_batch_next_window.argtypes = [vp, C.POINTER(Window)]
+        L.rgr_window_to_host.argtypes = [vp, C.POINTER(Window), vp, vp]
+        L.rgr_batch_run.argtypes = [vp, C.POINTER(u64), C.POINTER(u32)]
+        L.rgr_retain_topic_add.argtypes = [vp, C.c_char_p, u32, u32]
+        L.rgr_retain_topic_remove.argtypes = [vp, C.c_char_p, u32]
+        L.rgr_retain_add_bulk.argtypes = [vp, vp, vp, u64, vp, C.POINTER(u64)]
+        L.rgr_retain_commit.argtypes = [vp]
+        L.rgr_retain_match_batch.argtypes = [vp, vp, vp, u32, C.POINTER(RetainResult)]
+        L.rgr_retain_result_free.argtypes = [C.POINTER(RetainResult)]; L.rgr_retain_result_free.restype = None
+        L.rgr_shard_assign.argtypes = [vp, vp, u64, u32, i32, vp]
+        L.rgr_stats_get.argtypes = [vp, C.POINTER(Stats)]
+        L.rgr_stats_reset.argtypes = [vp]
+        _LIB = L
+    return _LIB
+
+
+def _check(rc):
+    if rc < 0:
+        raise RgrError(rc, lib().rgr_last_error().decode())
+    return rc
+
+
+def _b(s):
+    return s if isinstance(s, (bytes, bytearray)) else s.encode()
+
+
+def _blob_ptr(blob):
+    if isinstance(blob, np.ndarray):
+        return C.c_void_p(blob.ctypes.data), blob
+    b = bytes(blob)
+    return C.cast(C.c_char_p(b), C.c_void_p), b
+
+
+def _copy(ptr, n, dtype):
+    if not n:
+        return np.zeros(0, dtype=dtype)
+    nbytes = int(n) * np.dtype(dtype).itemsize
+    return np.frombuffer(C.string_at(ptr, nbytes), dtype=dtype).copy()
+
+
+def pack(strs):
+    bs = [_b(s) for s in strs]
+    offs = np.zeros(len(bs) + 1, dtype=np.uint64)
+    if bs:
+        offs[1:] = np.cumsum([len(b) for b in bs], dtype=np.uint64)
+    return np.frombuffer(b"".join(bs), dtype=np.uint8), offs
+
+
+class Router:
+    """One rgr_handle.  Thin: argument marshalling only."""
+
+    def __init__(self, device=0, slot_cap=0, window_hits=0, chunk_topics=0, host_threads=0, collect_walk_stats=True):
+        self._h = C.c_void_p()
+        cfg = Config(device, slot_cap, window_hits, chunk_topics, host_threads, int(collect_walk_stats), 0)
+        _check(lib().rgr_create(C.byref(cfg), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().rgr_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- table
+    def filter_add(self, f):
+        f = _b(f); fid = C.c_uint32()
+        _check(lib().rgr_filter_add(self._h, f, len(f), C.byref(fid)))
+        return fid.value
+
+    def filter_find(self, f):
+        f = _b(f); fid = C.c_uint32()
+        rc = lib().rgr_filter_find(self._h, f, len(f), C.byref(fid))
+        return fid.value if rc == RGR_OK else None
+
+    def filter_remove(self, fid):
+        return lib().rgr_filter_remove(self._h, fid)
+
+    def sub_add(self, fid, sub_id, qos=0, flags=0):
+        _check(lib().rgr_sub_add(self._h, fid, sub_id, qos, flags))
+
+    def sub_remove(self, fid, sub_id):
+        return lib().rgr_sub_remove(self._h, fid, sub_id)
+
+    def subscribe_bulk(self, blob, offsets, sub_ids=None, qos=None, flags=None, want_filter_ids=False):
+        n = len(offsets) - 1
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        keep = [offsets]
+        def p(a, dt):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dtype=dt); keep.append(a)
+            return C.c_void_p(a.ctypes.data)
+        fids = np.zeros(n, dtype=np.uint32) if want_filter_ids else None
+        rej = C.c_uint64(0)
+        bp, bk = _blob_ptr(blob)
+        _check(lib().rgr_subscribe_bulk(self._h, bp, offsets.ctypes.data, n, p(sub_ids, np.uint32), p(qos, np.uint8),
+                                        p(flags, np.uint8), C.c_void_p(fids.ctypes.data) if want_filter_ids else None,
+                                        C.byref(rej)))
+        return (int(rej.value), fids) if want_filter_ids else int(rej.value)
+
+    def commit(self):
+        _check(lib().rgr_commit(self._h))
+
+    # ---- matching
+    def match_batch(self, blob, offsets):
+        """-> dict(status int32[n], hit_offsets uint64[n+1], tuples TUPLE_DTYPE[n_hits])"""
+        n = len(offsets) - 1
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        r = Result()
+        bp, bk = _blob_ptr(blob)
+        _check(lib().rgr_match_batch(self._h, bp, offsets.ctypes.data, n, C.byref(r)))
+        try:
+            return dict(status=_copy(r.status, n, np.int32), hit_offsets=_copy(r.hit_offsets, n + 1, np.uint64),
+                        tuples=_copy(r.tuples, r.n_hits, TUPLE_DTYPE))
+        finally:
+            lib().rgr_result_free(C.byref(r))
+
+    def match_filters(self, blob, offsets):
+        n = len(offsets) - 1
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        r = FiltersResult()
+        bp, bk = _blob_ptr(blob)
+        _check(lib().rgr_match_filters(self._h, bp, offsets.ctypes.data, n, C.byref(r)))
+        try:
+            return dict(status=_copy(r.status, n, np.int32), pair_offsets=_copy(r.pair_offsets, n + 1, np.uint64),
+                        filter_ids=_copy(r.filter_ids, r.n_pairs, np.uint32))
+        finally:
+            lib().rgr_filters_result_free(C.byref(r))
+
+    def batch(self, blob, offsets):
+        return Batch(self, blob, offsets)
+
+    # ---- retain twin
+    def retain_add(self, topic, topic_id):
+        t = _b(topic)
+        return lib().rgr_retain_topic_add(self._h, t, len(t), topic_id)
+
+    def retain_remove(self, topic):
+        t = _b(topic)
+        return lib().rgr_retain_topic_remove(self._h, t, len(t))
+
+    def retain_add_bulk(self, blob, offsets, topic_ids=None):
+        n = len(offsets) - 1
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        ids = None if topic_ids is None else np.ascontiguousarray(topic_ids, dtype=np.uint32)
+        rej = C.c_uint64(0)
+        bp, bk = _blob_ptr(blob)
+        _check(lib().rgr_retain_add_bulk(self._h, bp, offsets.ctypes.data, n,
+                                         None if ids is None else C.c_void_p(ids.ctypes.data), C.byref(rej)))
+        return int(rej.value)
+
+    def retain_commit(self):
+        _check(lib().rgr_retain_commit(self._h))
+
+    def retain_match_batch(self, blob, offsets):
+        n = len(offsets) - 1
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        r = RetainResult()
+        bp, bk = _blob_ptr(blob)
+        _check(lib().rgr_retain_match_batch(self._h, bp, offsets.ctypes.data, n, C.byref(r)))
+        try:
+            return dict(status=_copy(r.status, n, np.int32), hit_offsets=_copy(r.hit_offsets, n + 1, np.uint64),
+                        topic_ids=_copy(r.topic_ids, r.n_hits, np.uint32))
+        finally:
+            lib().rgr_retain_result_free(C.byref(r))
+
+    # ---- stats
+    def stats(self):
+        s = Stats()
+        _check(lib().rgr_stats_get(self._h, C.byref(s)))
+        return s.as_dict()
+
+    def stats_reset(self):
+        _check(lib().rgr_stats_reset(self._h))
+
+
+class Batch:
+    """Device-resident tokenised batch (rgr_batch_*)."""
+
+    def __init__(self, router, blob, offsets):
+        self.router = router
+        self.n = len(offsets) - 1
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self._b = C.c_void_p()
+        bp, bk = _blob_ptr(blob)
+        _check(lib().rgr_batch_create(router._h, bp, offsets.ctypes.data, self.n, C.byref(self._b)))
+
+    def close(self):
+        if self._b:
+            lib().rgr_batch_destroy(self._b)
+            self._b = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def status(self):
+        return _copy(lib().rgr_batch_status(self._b), self.n, np.int32)
+
+    def run(self):
+        """One full pass; tuples stay on the device.  -> (n_hits, n_windows)"""
+        h, w = C.c_uint64(0), C.c_uint32(0)
+        _check(lib().rgr_batch_run(self._b, C.byref(h), C.byref(w)))
+        return int(h.value), int(w.value)
+
+    def begin(self):
+        _check(lib().rgr_batch_begin(self._b))
+
+    def next_window(self):
+        w = Window()
+        rc = _check(lib().rgr_batch_next_window(self._b, C.byref(w)))
+        return None if rc == RGR_EOF else w
+
+    def window_to_host(self, w):
+        tuples = np.zeros(int(w.n_hits), dtype=TUPLE_DTYPE)
+        offs = np.zeros(w.topic_end - w.topic_begin + 1, dtype=np.uint64)
+        _check(lib().rgr_window_to_host(self._b, C.byref(w), tuples.ctypes.data if w.n_hits else None, offs.ctypes.data))
+        return tuples, offs

@@ -1,0 +1,783 @@
+// C ABI of include/rmqtt_gpu_router.h: handle / epoch / batch orchestration.
+//
+// Pipeline per chunk of topics (all on the batch's own HIP stream):
+//   walk (+ overflow re-walk) -> count -> scan -> compact      [one host sync: sizes]
+//   then per window of topics: tiles -> expand                  [async]
+// Epochs are immutable device snapshots of the host table; a pass binds the epoch that
+// is current at rgr_batch_begin().
+#include <algorithm>
+#include <chrono>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <shared_mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "device.hpp"
+#include "kernels.hpp"
+#include "retain.hpp"
+#include "rmqtt_gpu_router.h"
+#include "table.hpp"
+
+using namespace rgr;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int32_t fail(int32_t code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+template <class Fn> int32_t guarded(Fn&& fn) {
+    try {
+        return fn();
+    } catch (const HipError& e) {
+        return fail(RGR_EDEVICE, e.what());
+    } catch (const std::bad_alloc&) {
+        return fail(RGR_ENOMEM, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(RGR_EINVAL, e.what());
+    }
+}
+
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct Epoch {
+    DevBuf edges, filt, subs;
+    TrieView view{};
+    uint64_t id = 0, n_filters = 0, n_subs = 0, n_nodes = 0, edge_slots = 0, max_filter_subs = 0, bytes = 0;
+};
+
+enum SpanKind { kSpanWalk = 0, kSpanScan = 1, kSpanExpand = 2 };
+
+}  // namespace
+
+struct rgr_handle {
+    rgr_config cfg{};
+    std::shared_mutex table_mu;     // HostTable: shared for tokenising, exclusive for mutation
+    HostTable table;
+    std::mutex epoch_mu;
+    std::shared_ptr<Epoch> epoch;
+    uint64_t epoch_counter = 0;
+    std::mutex stats_mu;
+    rgr_stats stats{};
+    RetainState retain;
+};
+
+struct rgr_batch {
+    rgr_handle* h = nullptr;
+    uint32_t n = 0;
+    std::vector<int32_t> status;
+    uint64_t total_tokens = 0, valid_levels = 0, valid_topics = 0;
+    DevBuf d_tokens, d_tok_off, d_tflags, d_path;
+    hipStream_t stream = nullptr;
+    // chunk work buffers
+    DevBuf slots, pair_cnt, hit_cnt, pair_live, hit_off, pair_base, ovf_list, ovf_base, scalars, arena;
+    DevBuf pair_src, pair_topic, pair_off, tile_first, out, scan_tmp;
+    PinnedBuf h_hit_off, h_pair_base, h_scalars;
+    uint64_t arena_cap = 0;
+    // pass state
+    std::shared_ptr<Epoch> epoch;
+    bool in_pass = false;
+    uint32_t chunk_begin = 0, chunk_n = 0;
+    bool chunk_ready = false;
+    uint32_t cursor = 0;
+    uint64_t hits_before = 0;        // hits emitted by earlier windows of this pass
+    // timing
+    struct Span { hipEvent_t a, b; int kind; };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> event_pool;
+    rgr_stats local{};               // accumulated over the pass, merged into the handle at the end
+
+    hipEvent_t get_event() {
+        if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
+        hipEvent_t e;
+        RGR_HIP(hipEventCreate(&e));
+        return e;
+    }
+    size_t span_begin(int kind) {
+        Span s{get_event(), get_event(), kind};
+        RGR_HIP(hipEventRecord(s.a, stream));
+        spans.push_back(s);
+        return spans.size() - 1;
+    }
+    void span_end(size_t i) { RGR_HIP(hipEventRecord(spans[i].b, stream)); }
+    void resolve_spans() {   // stream must be synchronised
+        for (auto& s : spans) {
+            float ms = 0;
+            RGR_HIP(hipEventElapsedTime(&ms, s.a, s.b));
+            if (s.kind == kSpanWalk) local.walk_ms += ms;
+            else if (s.kind == kSpanScan) local.scan_ms += ms;
+            else local.expand_ms += ms;
+            event_pool.push_back(s.a); event_pool.push_back(s.b);
+        }
+        spans.clear();
+    }
+    ~rgr_batch() {
+        for (auto& s : spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
+        for (auto e : event_pool) (void)hipEventDestroy(e);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+// scalars layout (device, 32 bytes): [0] u32 ovf_count, [1] u32 error, [2..3] u64 ovf_cursor, [4..5] u64 visited
+struct Scalars { uint32_t ovf_count, error; unsigned long long ovf_cursor, visited; };
+
+std::shared_ptr<Epoch> current_epoch(rgr_handle* h) {
+    std::lock_guard<std::mutex> g(h->epoch_mu);
+    return h->epoch;
+}
+
+void merge_stats(rgr_handle* h, rgr_stats& l) {
+    std::lock_guard<std::mutex> g(h->stats_mu);
+    rgr_stats& s = h->stats;
+    s.topics += l.topics; s.invalid_topics += l.invalid_topics; s.levels += l.levels; s.pairs += l.pairs; s.hits += l.hits;
+    s.visited_nodes += l.visited_nodes; s.overflow_topics += l.overflow_topics;
+    s.walk_launches += l.walk_launches; s.expand_launches += l.expand_launches;
+    s.walk_ms += l.walk_ms; s.scan_ms += l.scan_ms; s.expand_ms += l.expand_ms;
+    s.tokenize_ms += l.tokenize_ms; s.h2d_ms += l.h2d_ms; s.d2h_ms += l.d2h_ms;
+    s.alg_bytes_walk += l.alg_bytes_walk; s.alg_bytes_expand += l.alg_bytes_expand;
+    l = rgr_stats{};
+}
+
+void tokenize_batch(rgr_handle* h, rgr_batch* b, const uint8_t* blob, const uint64_t* offs, uint32_t n) {
+    const double t0 = now_ms();
+    unsigned nt = h->cfg.host_threads ? h->cfg.host_threads : std::max(1u, std::thread::hardware_concurrency());
+    nt = std::min<unsigned>(nt, std::max<uint32_t>(1, n / 4096));
+    struct Part { std::vector<uint32_t> toks; std::vector<uint32_t> lens; std::vector<uint8_t> flags; };
+    std::vector<Part> parts(nt);
+    {
+        std::shared_lock<std::shared_mutex> lk(h->table_mu);
+        auto work = [&](unsigned k) {
+            Part& p = parts[k];
+            const uint64_t lo = uint64_t(n) * k / nt, hi = uint64_t(n) * (k + 1) / nt;
+            p.lens.reserve(hi - lo); p.flags.reserve(hi - lo); p.toks.reserve((hi - lo) * 10);
+            for (uint64_t i = lo; i < hi; ++i) {
+                const size_t mark = p.toks.size();
+                const uint8_t fl = h->table.tokenize_topic(
+                    std::string_view(reinterpret_cast<const char*>(blob) + offs[i], offs[i + 1] - offs[i]), p.toks);
+                p.flags.push_back(fl);
+                p.lens.push_back(uint32_t(p.toks.size() - mark));
+            }
+        };
+        if (nt == 1) work(0);
+        else {
+            std::vector<std::thread> th;
+            for (unsigned k = 0; k < nt; ++k) th.emplace_back(work, k);
+            for (auto& t : th) t.join();
+        }
+    }
+    uint64_t total = 0;
+    for (auto& p : parts) total += p.toks.size();
+    std::vector<uint32_t> toks;
+    toks.reserve(total + 1);
+    std::vector<uint64_t> toff(size_t(n) + 1, 0);
+    std::vector<uint8_t> flags;
+    flags.reserve(n);
+    b->status.assign(n, RGR_TOPIC_OK);
+    uint64_t ti = 0;
+    for (auto& p : parts) {
+        toks.insert(toks.end(), p.toks.begin(), p.toks.end());
+        for (size_t j = 0; j < p.lens.size(); ++j, ++ti) {
+            toff[ti + 1] = toff[ti] + p.lens[j];
+            flags.push_back(p.flags[j]);
+            if (p.flags[j] & kTopicInvalid) b->status[ti] = RGR_TOPIC_INVALID;
+            else { b->valid_topics++; b->valid_levels += p.lens[j]; }
+        }
+    }
+    b->total_tokens = total;
+    b->local.tokenize_ms += now_ms() - t0;
+    const double t1 = now_ms();
+    b->d_tokens.ensure(std::max<uint64_t>(1, total) * 4);
+    b->d_tok_off.ensure((size_t(n) + 1) * 8);
+    b->d_tflags.ensure(std::max<uint32_t>(1, n));
+    b->d_path.ensure(std::max<uint64_t>(1, total) * 4);
+    if (total) RGR_HIP(hipMemcpyAsync(b->d_tokens.p, toks.data(), total * 4, hipMemcpyHostToDevice, b->stream));
+    RGR_HIP(hipMemcpyAsync(b->d_tok_off.p, toff.data(), (size_t(n) + 1) * 8, hipMemcpyHostToDevice, b->stream));
+    if (n) RGR_HIP(hipMemcpyAsync(b->d_tflags.p, flags.data(), n, hipMemcpyHostToDevice, b->stream));
+    RGR_HIP(hipStreamSynchronize(b->stream));
+    b->local.h2d_ms += now_ms() - t1;
+}
+
+WalkArgs make_walk_args(rgr_batch* b, uint32_t n) {
+    WalkArgs a{};
+    Scalars* sc = b->scalars.as<Scalars>();
+    a.tokens = b->d_tokens.as<uint32_t>();
+    a.tok_off = b->d_tok_off.as<uint64_t>();
+    a.tflags = b->d_tflags.as<uint8_t>();
+    a.topic_base = b->chunk_begin;
+    a.n = n;
+    a.slot_cap = b->h->cfg.slot_cap;
+    a.slots = b->slots.as<uint32_t>();
+    a.pair_cnt = b->pair_cnt.as<uint32_t>();
+    a.path_scratch = b->d_path.as<uint32_t>();
+    a.visited = b->h->cfg.collect_walk_stats ? &sc->visited : nullptr;
+    a.ovf_list = b->ovf_list.as<uint32_t>();
+    a.ovf_count = &sc->ovf_count;
+    a.ovf_base = b->ovf_base.as<uint64_t>();
+    a.ovf_cursor = &sc->ovf_cursor;
+    a.ovf_arena = b->arena.as<uint32_t>();
+    a.ovf_arena_cap = b->arena_cap;
+    return a;
+}
+
+ChunkArrays make_chunk_arrays(rgr_batch* b, uint32_t n) {
+    ChunkArrays c{};
+    Scalars* sc = b->scalars.as<Scalars>();
+    c.n = n;
+    c.slot_cap = b->h->cfg.slot_cap;
+    c.slots = b->slots.as<uint32_t>();
+    c.pair_cnt = b->pair_cnt.as<uint32_t>();
+    c.hit_cnt = b->hit_cnt.as<uint32_t>();
+    c.pair_live = b->pair_live.as<uint32_t>();
+    c.hit_off = b->hit_off.as<uint64_t>();
+    c.pair_base = b->pair_base.as<uint64_t>();
+    c.ovf_base = b->ovf_base.as<uint64_t>();
+    c.ovf_arena = b->arena.as<uint32_t>();
+    c.ovf_arena_cap = b->arena_cap;
+    c.error_flag = &sc->error;
+    c.pair_src = b->pair_src.as<uint32_t>();
+    c.pair_topic = b->pair_topic.as<uint32_t>();
+    c.pair_off = b->pair_off.as<uint64_t>();
+    return c;
+}
+
+void ensure_chunk_buffers(rgr_batch* b, uint32_t n) {
+    const uint32_t C = b->h->cfg.slot_cap;
+    b->slots.ensure(size_t(C) * n * 4);
+    b->pair_cnt.ensure(size_t(n) * 4);
+    b->hit_cnt.ensure(size_t(n) * 4);
+    b->pair_live.ensure(size_t(n) * 4);
+    b->hit_off.ensure((size_t(n) + 1) * 8);
+    b->pair_base.ensure((size_t(n) + 1) * 8);
+    b->ovf_list.ensure(size_t(n) * 4);
+    b->ovf_base.ensure(size_t(n) * 8);
+    b->scalars.ensure(sizeof(Scalars));
+    if (b->arena_cap == 0) { b->arena_cap = 1u << 20; b->arena.ensure(b->arena_cap * 4); }
+    const uint32_t nb = (n + scan_block_topics() - 1) / scan_block_topics();
+    b->scan_tmp.ensure((size_t(nb) + 1) * 16);
+    b->h_hit_off.ensure((size_t(n) + 1) * 8);
+    b->h_pair_base.ensure((size_t(n) + 1) * 8);
+    b->h_scalars.ensure(sizeof(Scalars));
+}
+
+// Walk the chunk starting at `begin`; on return the host has hit_off / pair_base and the
+// dense pair arrays are built.  With walk_only the pipeline stops after the walk passes.
+void prepare_chunk(rgr_batch* b, uint32_t begin, bool walk_only) {
+    rgr_handle* h = b->h;
+    const uint32_t n = std::min<uint32_t>(h->cfg.chunk_topics, b->n - begin);
+    b->chunk_begin = begin;
+    b->chunk_n = n;
+    ensure_chunk_buffers(b, n);
+    const TrieView& tv = b->epoch->view;
+    for (;;) {
+        RGR_HIP(hipMemsetAsync(b->scalars.p, 0, sizeof(Scalars), b->stream));
+        WalkArgs wa = make_walk_args(b, n);
+        size_t sp = b->span_begin(kSpanWalk);
+        launch_walk(tv, wa, false, b->stream);
+        launch_walk(tv, wa, true, b->stream);
+        b->span_end(sp);
+        b->local.walk_launches++;
+        RGR_HIP(hipGetLastError());
+        if (walk_only) {
+            RGR_HIP(hipMemcpyAsync(b->h_scalars.p, b->scalars.p, sizeof(Scalars), hipMemcpyDeviceToHost, b->stream));
+            RGR_HIP(hipStreamSynchronize(b->stream));
+            const Scalars* hs = b->h_scalars.as<Scalars>();
+            if (hs->ovf_cursor > b->arena_cap) {   // arena too small: grow and redo
+                b->arena_cap = hs->ovf_cursor * 2;
+                b->arena.ensure(b->arena_cap * 4);
+                b->resolve_spans();
+                continue;
+            }
+            b->resolve_spans();
+            b->chunk_ready = true;
+            return;
+        }
+        ChunkArrays ca = make_chunk_arrays(b, n);
+        sp = b->span_begin(kSpanScan);
+        launch_count(tv, ca, b->stream);
+        launch_scan(ca, b->scan_tmp.as<uint64_t>(), b->stream);
+        b->span_end(sp);
+        RGR_HIP(hipMemcpyAsync(b->h_scalars.p, b->scalars.p, sizeof(Scalars), hipMemcpyDeviceToHost, b->stream));
+        RGR_HIP(hipMemcpyAsync(b->h_hit_off.p, b->hit_off.p, (size_t(n) + 1) * 8, hipMemcpyDeviceToHost, b->stream));
+        RGR_HIP(hipMemcpyAsync(b->h_pair_base.p, b->pair_base.p, (size_t(n) + 1) * 8, hipMemcpyDeviceToHost, b->stream));
+        RGR_HIP(hipStreamSynchronize(b->stream));
+        RGR_HIP(hipGetLastError());
+        b->resolve_spans();
+        const Scalars* hs = b->h_scalars.as<Scalars>();
+        if (hs->error || hs->ovf_cursor > b->arena_cap) {
+            b->arena_cap = std::max<uint64_t>(b->arena_cap * 2, hs->ovf_cursor * 2);
+            b->arena.ensure(b->arena_cap * 4);
+            continue;
+        }
+        const uint64_t P = b->h_pair_base.as<uint64_t>()[n];
+        const uint64_t H = b->h_hit_off.as<uint64_t>()[n];
+        b->pair_src.ensure(std::max<uint64_t>(1, P) * 4);
+        b->pair_topic.ensure(std::max<uint64_t>(1, P) * 4);
+        b->pair_off.ensure((P + 1) * 8);
+        ca = make_chunk_arrays(b, n);
+        sp = b->span_begin(kSpanScan);
+        launch_compact(tv, ca, begin, b->stream);
+        b->span_end(sp);
+        // accounting
+        b->local.pairs += P;
+        b->local.hits += H;
+        b->local.visited_nodes += hs->visited;
+        b->local.overflow_topics += hs->ovf_count;
+        b->local.alg_bytes_walk += 24 * hs->visited + 8 * P;
+        b->local.alg_bytes_expand += 20 * H;
+        b->chunk_ready = true;
+        return;
+    }
+}
+
+}  // namespace
+
+// =============================================================================== C ABI
+extern "C" {
+
+const char* rgr_last_error(void) { return g_last_error.c_str(); }
+const char* rgr_version(void) { return "rmqtt_gpu_router 0.1 (gfx950)"; }
+
+int32_t rgr_create(const rgr_config* cfg, rgr_handle** out) {
+    return guarded([&]() -> int32_t {
+        if (!out) return fail(RGR_EINVAL, "rgr_create: out is NULL");
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev <= 0) return fail(RGR_EDEVICE, "rgr_create: no HIP device available (there is no CPU fallback)");
+        auto h = std::make_unique<rgr_handle>();
+        if (cfg) h->cfg = *cfg;
+        if (h->cfg.device < 0 || h->cfg.device >= ndev) return fail(RGR_EDEVICE, "rgr_create: bad device ordinal");
+        if (!h->cfg.slot_cap) h->cfg.slot_cap = 32;
+        if (!h->cfg.window_hits) h->cfg.window_hits = 1ull << 28;
+        if (!h->cfg.chunk_topics) h->cfg.chunk_topics = 1u << 21;
+        RGR_HIP(hipSetDevice(h->cfg.device));
+        // epoch 0: the empty table
+        *out = h.release();
+        int32_t rc = rgr_commit(*out);
+        if (rc != RGR_OK) { delete *out; *out = nullptr; }
+        return rc;
+    });
+}
+
+void rgr_destroy(rgr_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    delete h;
+}
+
+int32_t rgr_filter_add(rgr_handle* h, const char* filter, uint32_t len, uint32_t* filter_id) {
+    return guarded([&]() -> int32_t {
+        if (!h || !filter_id || (!filter && len)) return fail(RGR_EINVAL, "rgr_filter_add: bad argument");
+        std::unique_lock<std::shared_mutex> lk(h->table_mu);
+        int32_t rc = h->table.filter_add(std::string_view(filter, len), filter_id);
+        if (rc != RGR_OK) return fail(rc, "rgr_filter_add: invalid topic filter");
+        return RGR_OK;
+    });
+}
+
+int32_t rgr_filter_find(rgr_handle* h, const char* filter, uint32_t len, uint32_t* filter_id) {
+    return guarded([&]() -> int32_t {
+        if (!h || !filter_id) return fail(RGR_EINVAL, "rgr_filter_find: bad argument");
+        std::shared_lock<std::shared_mutex> lk(h->table_mu);
+        int32_t rc = h->table.filter_find(std::string_view(filter, len), filter_id);
+        if (rc != RGR_OK) return fail(rc, "rgr_filter_find: not found");
+        return RGR_OK;
+    });
+}
+
+int32_t rgr_filter_remove(rgr_handle* h, uint32_t filter_id) {
+    return guarded([&]() -> int32_t {
+        if (!h) return fail(RGR_EINVAL, "rgr_filter_remove: bad argument");
+        std::unique_lock<std::shared_mutex> lk(h->table_mu);
+        int32_t rc = h->table.filter_remove(filter_id);
+        if (rc == RGR_ESTATE) return fail(rc, "rgr_filter_remove: filter still has subscriptions");
+        if (rc != RGR_OK) return fail(rc, "rgr_filter_remove: unknown filter id");
+        return RGR_OK;
+    });
+}
+
+int32_t rgr_sub_add(rgr_handle* h, uint32_t filter_id, uint32_t sub_id, uint8_t qos, uint8_t flags) {
+    return guarded([&]() -> int32_t {
+        if (!h) return fail(RGR_EINVAL, "rgr_sub_add: bad argument");
+        std::unique_lock<std::shared_mutex> lk(h->table_mu);
+        int32_t rc = h->table.sub_add(filter_id, sub_id, qos, flags);
+        if (rc != RGR_OK) return fail(rc, "rgr_sub_add: unknown filter id");
+        return RGR_OK;
+    });
+}
+
+int32_t rgr_sub_remove(rgr_handle* h, uint32_t filter_id, uint32_t sub_id) {
+    return guarded([&]() -> int32_t {
+        if (!h) return fail(RGR_EINVAL, "rgr_sub_remove: bad argument");
+        std::unique_lock<std::shared_mutex> lk(h->table_mu);
+        int32_t rc = h->table.sub_remove(filter_id, sub_id);
+        if (rc != RGR_OK) return fail(rc, "rgr_sub_remove: unknown filter / subscription id");
+        return RGR_OK;
+    });
+}
+
+int32_t rgr_subscribe_bulk(rgr_handle* h, const uint8_t* blob, const uint64_t* offsets, uint64_t n, const uint32_t* sub_ids,
+                           const uint8_t* qos, const uint8_t* flags, uint32_t* filter_ids_out, uint64_t* n_rejected) {
+    return guarded([&]() -> int32_t {
+        if (!h || (n && (!blob || !offsets))) return fail(RGR_EINVAL, "rgr_subscribe_bulk: bad argument");
+        std::unique_lock<std::shared_mutex> lk(h->table_mu);
+        uint64_t levels = 0;
+        if (n) levels = (offsets[n] - offsets[0]) / 6 + n;      // rough: >= number of '/' separated levels
+        h->table.reserve(h->table.n_filters() + n, h->table.n_nodes() + levels);
+        uint64_t rejected = 0;
+        for (uint64_t i = 0; i < n; ++i) {
+            uint32_t fid = kNone;
+            int32_t rc = h->table.filter_add(std::string_view(reinterpret_cast<const char*>(blob) + offsets[i], offsets[i + 1] - offsets[i]), &fid);
+            if (rc != RGR_OK) { rejected++; if (filter_ids_out) filter_ids_out[i] = kNone; continue; }
+            h->table.sub_add(fid, sub_ids ? sub_ids[i] : uint32_t(i), qos ? qos[i] : 0, flags ? flags[i] : 0);
+            if (filter_ids_out) filter_ids_out[i] = fid;
+        }
+        if (n_rejected) *n_rejected = rejected;
+        return RGR_OK;
+    });
+}
+
+int32_t rgr_commit(rgr_handle* h) {
+    return guarded([&]() -> int32_t {
+        if (!h) return fail(RGR_EINVAL, "rgr_commit: bad argument");
+        RGR_HIP(hipSetDevice(h->cfg.device));
+        auto ep = std::make_shared<Epoch>();
+        {
+            std::shared_lock<std::shared_mutex> lk(h->table_mu);
+            const auto& edges = h->table.edges();
+            std::vector<FilterDesc> filt;
+            std::vector<SubEntry> subs;
+            h->table.flatten_filters(filt, subs);
+            ep->edges.ensure(edges.size() * sizeof(EdgeEntry));
+            ep->filt.ensure(std::max<size_t>(1, filt.size()) * sizeof(FilterDesc));
+            ep->subs.ensure(std::max<size_t>(1, subs.size()) * sizeof(SubEntry));
+            RGR_HIP(hipMemcpy(ep->edges.p, edges.data(), edges.size() * sizeof(EdgeEntry), hipMemcpyHostToDevice));
+            if (!filt.empty()) RGR_HIP(hipMemcpy(ep->filt.p, filt.data(), filt.size() * sizeof(FilterDesc), hipMemcpyHostToDevice));
+            if (!subs.empty()) RGR_HIP(hipMemcpy(ep->subs.p, subs.data(), subs.size() * sizeof(SubEntry), hipMemcpyHostToDevice));
+            ep->view.edges = ep->edges.as<EdgeEntry>();
+            ep->view.mask = uint32_t(edges.size() - 1);
+            ep->view.root = h->table.root_header();
+            ep->view.filt = ep->filt.as<FilterDesc>();
+            ep->view.subs = ep->subs.as<SubEntry>();
+            ep->n_filters = h->table.n_filters();
+            ep->n_subs = h->table.n_subs();
+            ep->n_nodes = h->table.n_nodes();
+            ep->edge_slots = edges.size();
+            ep->max_filter_subs = h->table.max_filter_subs();
+            ep->bytes = ep->edges.bytes + ep->filt.bytes + ep->subs.bytes;
+        }
+        std::lock_guard<std::mutex> g(h->epoch_mu);
+        ep->id = ++h->epoch_counter;
+        h->epoch = ep;
+        return RGR_OK;
+    });
+}
+
+// ------------------------------------------------------------------ device-resident batches
+int32_t rgr_batch_create(rgr_handle* h, const uint8_t* blob, const uint64_t* offs, uint32_t n, rgr_batch** out) {
+    return guarded([&]() -> int32_t {
+        if (!h || !out || (n && (!blob || !offs))) return fail(RGR_EINVAL, "rgr_batch_create: bad argument");
+        RGR_HIP(hipSetDevice(h->cfg.device));
+        auto b = std::make_unique<rgr_batch>();
+        b->h = h;
+        b->n = n;
+        RGR_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+        tokenize_batch(h, b.get(), blob, offs, n);
+        *out = b.release();
+        return RGR_OK;
+    });
+}
+
+void rgr_batch_destroy(rgr_batch* b) {
+    if (!b) return;
+    (void)hipSetDevice(b->h->cfg.device);
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    merge_stats(b->h, b->local);
+    delete b;
+}
+
+const int32_t* rgr_batch_status(const rgr_batch* b) { return b ? b->status.data() : nullptr; }
+
+int32_t rgr_batch_begin(rgr_batch* b) {
+    return guarded([&]() -> int32_t {
+        if (!b) return fail(RGR_EINVAL, "rgr_batch_begin: bad argument");
+        RGR_HIP(hipSetDevice(b->h->cfg.device));
+        b->epoch = current_epoch(b->h);
+        b->in_pass = true;
+        b->cursor = 0;
+        b->chunk_ready = false;
+        b->hits_before = 0;
+        b->local.topics += b->n;
+        b->local.invalid_topics += b->n - b->valid_topics;
+        b->local.levels += b->valid_levels;
+        b->local.alg_bytes_walk += 4 * (b->valid_levels + b->valid_topics);
+        return RGR_OK;
+    });
+}
+
+int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
+    return guarded([&]() -> int32_t {
+        if (!b || !w) return fail(RGR_EINVAL, "rgr_batch_next_window: bad argument");
+        if (!b->in_pass) return fail(RGR_ESTATE, "rgr_batch_next_window: call rgr_batch_begin first");
+        rgr_handle* h = b->h;
+        RGR_HIP(hipSetDevice(h->cfg.device));
+        if (b->cursor >= b->n) {
+            RGR_HIP(hipStreamSynchronize(b->stream));
+            RGR_HIP(hipGetLastError());
+            b->resolve_spans();
+            b->in_pass = false;
+            merge_stats(h, b->local);
+            return RGR_EOF;
+        }
+        if (!b->chunk_ready || b->cursor >= b->chunk_begin + b->chunk_n) {
+            b->chunk_ready = false;
+            prepare_chunk(b, b->cursor, false);
+        }
+        const uint32_t n = b->chunk_n;
+        const uint32_t lc = b->cursor - b->chunk_begin;
+        const uint64_t* ho = b->h_hit_off.as<uint64_t>();
+        const uint64_t* pb = b->h_pair_base.as<uint64_t>();
+        const uint64_t cap = h->cfg.window_hits;
+        uint32_t le;
+        if (ho[n] - ho[lc] <= cap) le = n;
+        else {
+            le = uint32_t(std::upper_bound(ho + lc, ho + n + 1, ho[lc] + cap) - ho) - 1;
+            if (le <= lc) le = lc + 1;       // a single topic larger than the window: give it its own window
+        }
+        const uint64_t hit_lo = ho[lc], hit_hi = ho[le], pair_lo = pb[lc], pair_hi = pb[le];
+        const uint64_t nh = hit_hi - hit_lo;
+        if (nh) {
+            const uint32_t T = expand_tile_hits();
+            b->out.ensure(nh * sizeof(Tuple));
+            b->tile_first.ensure(((nh + T - 1) / T) * 4);
+            ChunkArrays ca = make_chunk_arrays(b, n);
+            size_t sp = b->span_begin(kSpanScan);
+            launch_tiles(ca, pair_lo, pair_hi, hit_lo, b->tile_first.as<uint32_t>(), b->stream);
+            b->span_end(sp);
+            sp = b->span_begin(kSpanExpand);
+            launch_expand(b->epoch->view, ca, pair_lo, pair_hi, hit_lo, hit_hi, b->tile_first.as<uint32_t>(), b->out.as<Tuple>(), b->stream);
+            b->span_end(sp);
+            b->local.expand_launches++;
+        }
+        w->topic_begin = b->cursor;
+        w->topic_end = b->chunk_begin + le;
+        w->n_hits = nh;
+        w->hit_base = b->hits_before;
+        w->d_tuples = reinterpret_cast<const rgr_tuple*>(b->out.p);
+        w->d_hit_offsets = b->hit_off.as<uint64_t>() + lc;
+        w->offsets_bias = hit_lo;
+        b->hits_before += nh;
+        b->cursor = b->chunk_begin + le;
+        return RGR_OK;
+    });
+}
+
+int32_t rgr_window_to_host(rgr_batch* b, const rgr_window* w, rgr_tuple* host_tuples, uint64_t* host_hit_offsets) {
+    return guarded([&]() -> int32_t {
+        if (!b || !w) return fail(RGR_EINVAL, "rgr_window_to_host: bad argument");
+        RGR_HIP(hipSetDevice(b->h->cfg.device));
+        const double t0 = now_ms();
+        if (host_tuples && w->n_hits)
+            RGR_HIP(hipMemcpyAsync(host_tuples, w->d_tuples, w->n_hits * sizeof(rgr_tuple), hipMemcpyDeviceToHost, b->stream));
+        RGR_HIP(hipStreamSynchronize(b->stream));
+        if (host_hit_offsets) {
+            const uint64_t* ho = b->h_hit_off.as<uint64_t>() + (w->topic_begin - b->chunk_begin);
+            const uint32_t m = w->topic_end - w->topic_begin;
+            for (uint32_t i = 0; i <= m; ++i) host_hit_offsets[i] = ho[i] - w->offsets_bias;
+        }
+        b->local.d2h_ms += now_ms() - t0;
+        return RGR_OK;
+    });
+}
+
+int32_t rgr_batch_run(rgr_batch* b, uint64_t* n_hits, uint32_t* n_windows) {
+    int32_t rc = rgr_batch_begin(b);
+    if (rc != RGR_OK) return rc;
+    uint64_t hits = 0;
+    uint32_t nw = 0;
+    for (;;) {
+        rgr_window w;
+        rc = rgr_batch_next_window(b, &w);
+        if (rc == RGR_EOF) break;
+        if (rc != RGR_OK) return rc;
+        hits += w.n_hits;
+        nw++;
+    }
+    if (n_hits) *n_hits = hits;
+    if (n_windows) *n_windows = nw;
+    return RGR_OK;
+}
+
+// ------------------------------------------------------------------ host in / host out
+namespace {
+struct ResultOwner {
+    std::vector<int32_t> status;
+    std::vector<uint64_t> offsets;
+    std::vector<rgr_tuple> tuples;
+    std::vector<uint32_t> ids;
+};
+}  // namespace
+
+int32_t rgr_match_batch(rgr_handle* h, const uint8_t* blob, const uint64_t* offs, uint32_t n, rgr_result* out) {
+    if (!out) return fail(RGR_EINVAL, "rgr_match_batch: out is NULL");
+    std::memset(out, 0, sizeof *out);
+    rgr_batch* b = nullptr;
+    int32_t rc = rgr_batch_create(h, blob, offs, n, &b);
+    if (rc != RGR_OK) return rc;
+    rc = guarded([&]() -> int32_t {
+        auto own = std::make_unique<ResultOwner>();
+        own->status.assign(b->status.begin(), b->status.end());
+        own->offsets.assign(size_t(n) + 1, 0);
+        int32_t r = rgr_batch_begin(b);
+        if (r != RGR_OK) return r;
+        std::vector<uint64_t> tmp;
+        for (;;) {
+            rgr_window w;
+            r = rgr_batch_next_window(b, &w);
+            if (r == RGR_EOF) break;
+            if (r != RGR_OK) return r;
+            const size_t base = own->tuples.size();
+            own->tuples.resize(base + w.n_hits);
+            tmp.resize(size_t(w.topic_end - w.topic_begin) + 1);
+            r = rgr_window_to_host(b, &w, own->tuples.data() + base, tmp.data());
+            if (r != RGR_OK) return r;
+            for (uint32_t i = 0; i <= w.topic_end - w.topic_begin; ++i) own->offsets[w.topic_begin + i] = base + tmp[i];
+        }
+        out->n_topics = n;
+        out->n_hits = own->tuples.size();
+        out->status = own->status.data();
+        out->hit_offsets = own->offsets.data();
+        out->tuples = own->tuples.data();
+        out->_owner = own.release();
+        return RGR_OK;
+    });
+    rgr_batch_destroy(b);
+    return rc;
+}
+
+void rgr_result_free(rgr_result* r) {
+    if (!r || !r->_owner) return;
+    delete static_cast<ResultOwner*>(r->_owner);
+    std::memset(r, 0, sizeof *r);
+}
+
+int32_t rgr_match_filters(rgr_handle* h, const uint8_t* blob, const uint64_t* offs, uint32_t n, rgr_filters_result* out) {
+    if (!out) return fail(RGR_EINVAL, "rgr_match_filters: out is NULL");
+    std::memset(out, 0, sizeof *out);
+    rgr_batch* b = nullptr;
+    int32_t rc = rgr_batch_create(h, blob, offs, n, &b);
+    if (rc != RGR_OK) return rc;
+    rc = guarded([&]() -> int32_t {
+        auto own = std::make_unique<ResultOwner>();
+        own->status.assign(b->status.begin(), b->status.end());
+        own->offsets.assign(size_t(n) + 1, 0);
+        int32_t r = rgr_batch_begin(b);
+        if (r != RGR_OK) return r;
+        const uint32_t C = h->cfg.slot_cap;
+        std::vector<uint32_t> slots, cnt, arena;
+        std::vector<uint64_t> obase;
+        for (uint32_t begin = 0; begin < n; begin += b->chunk_n) {
+            prepare_chunk(b, begin, true);
+            const uint32_t cn = b->chunk_n;
+            slots.resize(size_t(C) * cn); cnt.resize(cn); obase.resize(cn);
+            const Scalars* hs = b->h_scalars.as<Scalars>();
+            arena.resize(hs->ovf_cursor);
+            RGR_HIP(hipMemcpy(slots.data(), b->slots.p, slots.size() * 4, hipMemcpyDeviceToHost));
+            RGR_HIP(hipMemcpy(cnt.data(), b->pair_cnt.p, size_t(cn) * 4, hipMemcpyDeviceToHost));
+            if (hs->ovf_count) {
+                RGR_HIP(hipMemcpy(obase.data(), b->ovf_base.p, size_t(cn) * 8, hipMemcpyDeviceToHost));
+                RGR_HIP(hipMemcpy(arena.data(), b->arena.p, arena.size() * 4, hipMemcpyDeviceToHost));
+            }
+            for (uint32_t t = 0; t < cn; ++t) {
+                for (uint32_t j = 0; j < cnt[t]; ++j)
+                    own->ids.push_back(cnt[t] <= C ? slots[size_t(j) * cn + t] : arena[obase[t] + j]);
+                own->offsets[begin + t + 1] = own->ids.size();
+            }
+            b->local.overflow_topics += hs->ovf_count;
+        }
+        RGR_HIP(hipStreamSynchronize(b->stream));
+        b->resolve_spans();
+        b->in_pass = false;
+        out->n_topics = n;
+        out->n_pairs = own->ids.size();
+        out->status = own->status.data();
+        out->pair_offsets = own->offsets.data();
+        out->filter_ids = own->ids.data();
+        out->_owner = own.release();
+        return RGR_OK;
+    });
+    rgr_batch_destroy(b);
+    return rc;
+}
+
+void rgr_filters_result_free(rgr_filters_result* r) {
+    if (!r || !r->_owner) return;
+    delete static_cast<ResultOwner*>(r->_owner);
+    std::memset(r, 0, sizeof *r);
+}
+
+// ------------------------------------------------------------------ sharding rule
+int32_t rgr_shard_assign(const uint8_t* blob, const uint64_t* offsets, uint64_t n, uint32_t n_shards, int32_t is_filter, int32_t* out) {
+    return guarded([&]() -> int32_t {
+        if ((n && (!blob || !offsets || !out)) || n_shards == 0) return fail(RGR_EINVAL, "rgr_shard_assign: bad argument");
+        for (uint64_t i = 0; i < n; ++i) {
+            const std::string_view s(reinterpret_cast<const char*>(blob) + offsets[i], offsets[i + 1] - offsets[i]);
+            const size_t p0 = s.find('/');
+            const std::string_view l0 = s.substr(0, p0);
+            std::string_view l1;
+            bool has1 = false;
+            if (p0 != std::string_view::npos) {
+                const size_t p1 = s.find('/', p0 + 1);
+                l1 = s.substr(p0 + 1, p1 == std::string_view::npos ? std::string_view::npos : p1 - p0 - 1);
+                has1 = true;
+            }
+            auto wild = [](std::string_view l) { return l == "+" || l == "#"; };
+            if (is_filter && (wild(l0) || (has1 && wild(l1)))) { out[i] = -1; continue; }
+            uint64_t h = 0xcbf29ce484222325ull;
+            for (unsigned char ch : l0) { h ^= ch; h *= 0x100000001b3ull; }
+            h ^= 0x2f; h *= 0x100000001b3ull;
+            if (has1) { for (unsigned char ch : l1) { h ^= ch; h *= 0x100000001b3ull; } h ^= 0x01; h *= 0x100000001b3ull; }
+            h ^= h >> 32; h *= 0xd6e8feb86659fd93ull; h ^= h >> 32;
+            out[i] = int32_t(h % n_shards);
+        }
+        return RGR_OK;
+    });
+}
+
+// ------------------------------------------------------------------ observability
+int32_t rgr_stats_get(rgr_handle* h, rgr_stats* out) {
+    return guarded([&]() -> int32_t {
+        if (!h || !out) return fail(RGR_EINVAL, "rgr_stats_get: bad argument");
+        {
+            std::lock_guard<std::mutex> g(h->stats_mu);
+            *out = h->stats;
+        }
+        auto ep = current_epoch(h);
+        out->n_filters = ep->n_filters; out->n_subs = ep->n_subs; out->n_nodes = ep->n_nodes;
+        out->n_edge_slots = ep->edge_slots; out->epoch = ep->id; out->table_bytes_device = ep->bytes;
+        std::shared_lock<std::shared_mutex> lk(h->table_mu);
+        out->n_tokens = h->table.n_tokens();
+        return RGR_OK;
+    });
+}
+
+int32_t rgr_stats_reset(rgr_handle* h) {
+    if (!h) return fail(RGR_EINVAL, "rgr_stats_reset: bad argument");
+    std::lock_guard<std::mutex> g(h->stats_mu);
+    h->stats = rgr_stats{};
+    return RGR_OK;
+}
+
+}  // extern "C"
+
+#include "retain_abi.inc"

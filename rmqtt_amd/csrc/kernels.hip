@@ -1,0 +1,300 @@
+// Hand-written HIP kernels for gfx950 (MI355X / CDNA4): publish-topic matching.
+//
+// Integer / indexing work only — HBM- and latency-bound, no MFMA.  Wave = 64 lanes.
+//
+//   walk_kernel     one lane per publish topic; depth-first walk of the subscription trie in
+//                   exactly TopicTree::matches' order (rmqtt/src/trie.rs:327-375): '#'-child
+//                   item, then the '+' subtree, then the exact-child subtree; at path end the
+//                   node's own filter, then its '#' child ("parent match").  '$'-topics skip
+//                   the wildcard steps at the root (trie.rs:342-346).  The block's '/'-tokenised
+//                   topics are staged into LDS with coalesced loads; the per-lane DFS stack
+//                   lives in a second LDS window addressed like the tokens (one word per
+//                   level) and spills to HBM scratch beyond the window, so topic depth is
+//                   unbounded.  One 32-byte edge record is read per visited trie node.
+//   count/scan/compact  per-topic hit counts -> exclusive scans -> dense list of
+//                   (topic, subscriber-run) pairs with their output offsets.
+//   tiles_kernel    for every output tile, the first pair that intersects it.
+//   expand_kernel   load-balanced expansion: each block owns kTile consecutive output
+//                   positions, finds the owning pair of each position by binary search in LDS
+//                   and streams (topic_idx, sub_id, qos) tuples out fully coalesced.
+#include <hip/hip_runtime.h>
+
+#include "kernels.hpp"
+#include "match_core.hpp"
+
+namespace rgr {
+
+namespace {
+
+constexpr int kWalkThreads = 256;
+constexpr int kWalkWindow = 2560;        // LDS words per array (tokens, stack): 2 x 10 KiB
+constexpr int kExpandThreads = 256;
+constexpr int kExpandPerThread = 8;
+constexpr int kTile = kExpandThreads * kExpandPerThread;   // 2048 hits = 24 KiB of tuples
+constexpr int kScanThreads = 256;
+constexpr int kScanPerThread = 8;
+constexpr int kScanBlock = kScanThreads * kScanPerThread;  // 2048 topics per scan block
+
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// --------------------------------------------------------------------------- walk
+template <bool OVF>
+__global__ __launch_bounds__(kWalkThreads) void walk_kernel(TrieView tv, WalkArgs a) {
+    __shared__ uint32_t s_tok[OVF ? 1 : kWalkWindow];
+    __shared__ uint32_t s_path[OVF ? 1 : kWalkWindow];
+
+    const int tid = threadIdx.x;
+    uint32_t tl;            // chunk-local topic index
+    bool active;
+    uint64_t win_base = 0;  // token index of the first staged token
+    uint32_t staged = 0;    // tokens held in LDS
+
+    if (OVF) {
+        const uint32_t i = blockIdx.x * kWalkThreads + tid;
+        active = i < min(*a.ovf_count, a.n);
+        tl = active ? a.ovf_list[i] : 0;
+    } else {
+        const uint32_t t0 = blockIdx.x * kWalkThreads;
+        tl = t0 + tid;
+        active = tl < a.n;
+        const uint32_t t1 = min(t0 + uint32_t(kWalkThreads), a.n);
+        win_base = a.tok_off[a.topic_base + t0];
+        const uint64_t win_end = a.tok_off[a.topic_base + t1];
+        const uint64_t span = win_end - win_base;
+        staged = span < uint64_t(kWalkWindow) ? uint32_t(span) : uint32_t(kWalkWindow);
+        for (uint32_t i = tid; i < staged; i += kWalkThreads) s_tok[i] = a.tokens[win_base + i];   // coalesced
+        __syncthreads();
+    }
+
+    uint32_t cnt = 0;
+    uint32_t visited = 0;
+    if (active) {
+        const uint32_t gt = a.topic_base + tl;
+        const uint64_t off0 = a.tok_off[gt];
+        const uint32_t L = uint32_t(a.tok_off[gt + 1] - off0);
+        const uint8_t fl = a.tflags[gt];
+        const uint64_t rel = off0 - win_base;          // position of level 0 inside the window
+        const uint64_t arena_base = OVF ? a.ovf_base[tl] : 0;
+
+        auto tok_at = [&](uint32_t d) -> uint32_t {
+            const uint64_t i = rel + d;
+            return (!OVF && i < staged) ? s_tok[i] : a.tokens[off0 + d];
+        };
+        auto path_get = [&](uint32_t d) -> uint32_t {
+            const uint64_t i = rel + d;
+            return (!OVF && i < staged) ? s_path[i] : a.path_scratch[off0 + d];
+        };
+        auto path_set = [&](uint32_t d, uint32_t v) {
+            const uint64_t i = rel + d;
+            if (!OVF && i < staged) s_path[i] = v; else a.path_scratch[off0 + d] = v;
+        };
+        auto emit = [&](uint32_t fid) {
+            if (OVF) { if (arena_base + cnt < a.ovf_arena_cap) a.ovf_arena[arena_base + cnt] = fid; }
+            else if (cnt < a.slot_cap) a.slots[uint64_t(cnt) * a.n + tl] = fid;
+            cnt++;
+        };
+
+        if (!(fl & kTopicInvalid)) {
+            const EdgeEntry* edges = tv.edges;
+            visited = walk_topic(
+                tv.root, tv.mask, L, (fl & kTopicMeta) != 0, tok_at, path_get, path_set, emit,
+                [&](uint32_t slot, U4& e0, U4& e1) {
+                    const uint4* ep = reinterpret_cast<const uint4*>(edges + slot);
+                    const uint4 a0 = ep[0], a1 = ep[1];
+                    e0 = U4{a0.x, a0.y, a0.z, a0.w};
+                    e1 = U4{a1.x, a1.y, a1.z, a1.w};
+                });
+        }
+        if (!OVF) {
+            a.pair_cnt[tl] = cnt;
+            if (cnt > a.slot_cap) {
+                const uint32_t i = atomicAdd(a.ovf_count, 1u);
+                a.ovf_list[i] = tl;
+                a.ovf_base[tl] = atomicAdd(a.ovf_cursor, (unsigned long long)cnt);
+            }
+        }
+    }
+    if (a.visited && !OVF) {
+        const unsigned long long v = wave_sum(visited);
+        if ((tid & 63) == 0 && v) atomicAdd(a.visited, v);
+    }
+}
+
+// --------------------------------------------------------------------------- count
+__global__ __launch_bounds__(256) void count_kernel(TrieView tv, ChunkArrays c) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t < c.n) count_topic(tv, c, t);
+}
+
+// --------------------------------------------------------------------------- scan
+// Exclusive scans of hit_cnt -> hit_off (u64) and pair_live -> pair_base (u64), three phases.
+struct U2 { unsigned long long a, b; };
+
+__device__ __forceinline__ U2 block_reduce2(unsigned long long a, unsigned long long b, U2* s_w) {
+    a = wave_sum(a); b = wave_sum(b);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_w[w].a = a; s_w[w].b = b; }
+    __syncthreads();
+    U2 r{0, 0};
+    for (int i = 0; i < kScanThreads / 64; ++i) { r.a += s_w[i].a; r.b += s_w[i].b; }
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(kScanThreads) void scan_reduce_kernel(ChunkArrays c, uint64_t* block_tmp) {
+    __shared__ U2 s_w[kScanThreads / 64];
+    const uint32_t base = blockIdx.x * kScanBlock + threadIdx.x * kScanPerThread;
+    unsigned long long a = 0, b = 0;
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; ++k) {
+        const uint32_t t = base + k;
+        if (t < c.n) { a += c.hit_cnt[t]; b += c.pair_live[t]; }
+    }
+    const U2 r = block_reduce2(a, b, s_w);
+    if (threadIdx.x == 0) { block_tmp[2 * blockIdx.x] = r.a; block_tmp[2 * blockIdx.x + 1] = r.b; }
+}
+
+__global__ void scan_spine_kernel(uint64_t* block_tmp, uint32_t nblocks) {   // <<<1,1>>>: nblocks is small
+    unsigned long long a = 0, b = 0;
+    for (uint32_t i = 0; i < nblocks; ++i) {
+        const unsigned long long x = block_tmp[2 * i], y = block_tmp[2 * i + 1];
+        block_tmp[2 * i] = a; block_tmp[2 * i + 1] = b;
+        a += x; b += y;
+    }
+    block_tmp[2 * nblocks] = a; block_tmp[2 * nblocks + 1] = b;
+}
+
+__global__ __launch_bounds__(kScanThreads) void scan_down_kernel(ChunkArrays c, const uint64_t* block_tmp, uint32_t nblocks) {
+    __shared__ U2 s_w[kScanThreads / 64];
+    __shared__ U2 s_pre[kScanThreads / 64];
+    const uint32_t base = blockIdx.x * kScanBlock + threadIdx.x * kScanPerThread;
+    unsigned long long la[kScanPerThread], lb[kScanPerThread];
+    unsigned long long a = 0, b = 0;
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; ++k) {
+        const uint32_t t = base + k;
+        la[k] = a; lb[k] = b;
+        if (t < c.n) { a += c.hit_cnt[t]; b += c.pair_live[t]; }
+    }
+    // exclusive scan of the per-thread totals across the block
+    unsigned long long xa = a, xb = b;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long ya = __shfl_up(xa, o, 64), yb = __shfl_up(xb, o, 64);
+        if (lane >= o) { xa += ya; xb += yb; }
+    }
+    if (lane == 63) { s_w[w].a = xa; s_w[w].b = xb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long pa = 0, pb = 0;
+        for (int i = 0; i < kScanThreads / 64; ++i) { s_pre[i].a = pa; s_pre[i].b = pb; pa += s_w[i].a; pb += s_w[i].b; }
+    }
+    __syncthreads();
+    const unsigned long long ta = block_tmp[2 * blockIdx.x] + s_pre[w].a + (xa - a);
+    const unsigned long long tb = block_tmp[2 * blockIdx.x + 1] + s_pre[w].b + (xb - b);
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; ++k) {
+        const uint32_t t = base + k;
+        if (t < c.n) { c.hit_off[t] = ta + la[k]; c.pair_base[t] = tb + lb[k]; }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { c.hit_off[c.n] = block_tmp[2 * nblocks]; c.pair_base[c.n] = block_tmp[2 * nblocks + 1]; }
+}
+
+// --------------------------------------------------------------------------- compact
+__global__ __launch_bounds__(256) void compact_kernel(TrieView tv, ChunkArrays c, uint32_t topic_base) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t < c.n) compact_topic(tv, c, topic_base, t);
+}
+
+// --------------------------------------------------------------------------- tiles
+__global__ __launch_bounds__(256) void tiles_kernel(const uint64_t* pair_off, uint64_t pair_lo, uint64_t pair_hi,
+                                                    uint64_t hit_lo, uint32_t* tile_first) {
+    const uint64_t p = pair_lo + uint64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (p < pair_hi) tiles_pair(pair_off, p, pair_lo, hit_lo, kTile, tile_first);
+}
+
+// --------------------------------------------------------------------------- expand
+__global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* __restrict__ subs, ChunkArrays c,
+                                                                uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo,
+                                                                uint64_t hit_hi, const uint32_t* __restrict__ tile_first,
+                                                                uint32_t ntiles, Tuple* __restrict__ out) {
+    __shared__ int32_t s_off[kTile + 2];
+    __shared__ uint32_t s_src[kTile + 2];
+    __shared__ uint32_t s_topic[kTile + 2];
+
+    const uint32_t tile = blockIdx.x;
+    const uint64_t base = hit_lo + uint64_t(tile) * kTile;
+    const uint32_t len = (hit_hi - base) < uint64_t(kTile) ? uint32_t(hit_hi - base) : uint32_t(kTile);
+    const uint64_t a = pair_lo + tile_first[tile];
+    const uint64_t b = (tile + 1 < ntiles) ? pair_lo + tile_first[tile + 1] + 1 : pair_hi;
+    const uint32_t np = uint32_t(b - a);
+    for (uint32_t i = threadIdx.x; i < np; i += kExpandThreads) tile_pair_view(c, a, i, base, s_off[i], s_src[i], s_topic[i]);
+    __syncthreads();
+    Tuple* o = out + (base - hit_lo);
+#pragma unroll
+    for (int j = 0; j < kExpandPerThread; ++j) {
+        const uint32_t pos = uint32_t(j) * kExpandThreads + threadIdx.x;
+        if (pos < len) {
+            const uint32_t i = locate_pair([&](uint32_t m) { return s_off[m]; }, np, int32_t(pos));
+            const SubEntry se = subs[uint64_t(s_src[i]) + uint32_t(int32_t(pos) - s_off[i])];
+            Tuple tp;
+            tp.topic_idx = s_topic[i]; tp.sub_id = se.sub_id; tp.qos_flags = se.qos_flags;
+            o[pos] = tp;
+        }
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------ launchers
+uint32_t expand_tile_hits() { return kTile; }
+uint32_t scan_block_topics() { return kScanBlock; }
+
+void launch_walk(const TrieView& t, const WalkArgs& a, bool overflow_pass, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (a.n == 0) return;
+    // The overflow pass does not know the overflow count on the host: it is launched over the
+    // whole chunk and every block beyond *ovf_count exits at once.
+    if (!overflow_pass) walk_kernel<false><<<(a.n + kWalkThreads - 1) / kWalkThreads, kWalkThreads, 0, s>>>(t, a);
+    else walk_kernel<true><<<(a.n + kWalkThreads - 1) / kWalkThreads, kWalkThreads, 0, s>>>(t, a);
+}
+
+void launch_count(const TrieView& t, const ChunkArrays& c, void* stream) {
+    if (c.n == 0) return;
+    count_kernel<<<(c.n + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(t, c);
+}
+
+void launch_scan(const ChunkArrays& c, uint64_t* block_tmp, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint32_t nb = (c.n + kScanBlock - 1) / kScanBlock;
+    if (nb == 0) return;
+    scan_reduce_kernel<<<nb, kScanThreads, 0, s>>>(c, block_tmp);
+    scan_spine_kernel<<<1, 1, 0, s>>>(block_tmp, nb);
+    scan_down_kernel<<<nb, kScanThreads, 0, s>>>(c, block_tmp, nb);
+}
+
+void launch_compact(const TrieView& t, const ChunkArrays& c, uint32_t topic_base, void* stream) {
+    if (c.n == 0) return;
+    compact_kernel<<<(c.n + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(t, c, topic_base);
+}
+
+void launch_tiles(const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint32_t* tile_first, void* stream) {
+    if (pair_hi <= pair_lo) return;
+    const uint64_t np = pair_hi - pair_lo;
+    tiles_kernel<<<uint32_t((np + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(c.pair_off, pair_lo, pair_hi, hit_lo, tile_first);
+}
+
+void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint64_t hit_hi,
+                   const uint32_t* tile_first, Tuple* out, void* stream) {
+    if (hit_hi <= hit_lo) return;
+    const uint32_t ntiles = uint32_t((hit_hi - hit_lo + kTile - 1) / kTile);
+    expand_kernel<<<ntiles, kExpandThreads, 0, static_cast<hipStream_t>(stream)>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first,
+                                                                                  ntiles, out);
+}
+
+}  // namespace rgr

@@ -1,0 +1,118 @@
+// Device-visible table layout + kernel launch prototypes (HIP, gfx950 only).
+//
+// HBM layout of one epoch of the subscription table:
+//   edges[cap]   open-addressed CSR edge table, 32-byte records keyed by (parent node,
+//                level token); a record carries the child's id *and* the child's header
+//                (its '+' edge slot, the filter id of "child/#", the filter id ending at
+//                child), so one 32 B read per visited trie node serves both the edge
+//                lookup and the node header.
+//   filt[nf]     per filter: [begin,count) of its subscriber run in subs[]
+//   subs[ns]     packed (sub_id, qos|flags<<8), grouped per filter, ascending sub_id
+#pragma once
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define RGR_HD __host__ __device__
+#else
+#define RGR_HD
+#endif
+
+namespace rgr {
+
+struct U4 { uint32_t x, y, z, w; };   // one 16-byte half of an edge record
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr uint32_t kTokPlus = 0;          // reserved token ids: "+" and "#"
+constexpr uint32_t kTokHash = 1;
+constexpr uint32_t kTokFirst = 2;
+constexpr uint32_t kTokUnknown = 0xFFFFFFFFu;   // level string absent from the dictionary
+constexpr uint32_t kEdgeEmpty = 0xFFFFFFFFu;
+constexpr uint32_t kEdgeTomb = 0xFFFFFFFEu;
+
+struct alignas(16) EdgeEntry {
+    uint32_t parent;      // parent node id | kEdgeEmpty | kEdgeTomb
+    uint32_t token;       // level token on this edge
+    uint32_t child;       // child node id
+    uint32_t plus_slot;   // slot of the child's '+' edge record, kNone if none
+    uint32_t hash_fid;    // filter id of "<child>/#", kNone if none
+    uint32_t term_fid;    // filter id ending at <child>, kNone if none
+    uint32_t pad0, pad1;
+};
+static_assert(sizeof(EdgeEntry) == 32, "edge record is one 32-byte sector");
+
+struct NodeHeader { uint32_t plus_slot, hash_fid, term_fid; };
+
+struct FilterDesc { uint32_t begin, count; };
+struct SubEntry { uint32_t sub_id, qos_flags; };
+struct Tuple { uint32_t topic_idx, sub_id, qos_flags; };   // == rgr_tuple
+
+// topic flag bits produced by the tokeniser
+constexpr uint8_t kTopicInvalid = 1;   // parser rejected it: zero matches
+constexpr uint8_t kTopicMeta = 2;      // first level starts with '$' (trie.rs:342-346)
+
+RGR_HD inline uint32_t edge_hash(uint32_t parent, uint32_t token) {
+    uint64_t x = (uint64_t(parent) << 32) | token;
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull;
+    x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull;
+    x ^= x >> 33;
+    return uint32_t(x);
+}
+
+struct TrieView {
+    const EdgeEntry* edges;
+    uint32_t mask;            // capacity - 1 (capacity is a power of two)
+    NodeHeader root;
+    const FilterDesc* filt;
+    const SubEntry* subs;
+};
+
+struct WalkArgs {
+    const uint32_t* tokens;      // CSR token ids of the batch
+    const uint64_t* tok_off;     // [n_batch+1]
+    const uint8_t* tflags;       // [n_batch]
+    uint32_t topic_base;         // first topic of this chunk
+    uint32_t n;                  // topics in this chunk
+    uint32_t slot_cap;           // C
+    uint32_t* slots;             // [C][n]  matched filter ids, j-major
+    uint32_t* pair_cnt;          // [n] matched filters per topic (true count, may exceed C)
+    uint32_t* path_scratch;      // [total tokens] spill of the DFS stack beyond the LDS window
+    unsigned long long* visited; // optional: sum of visited trie nodes
+    // overflow (count > C): main pass registers the topic, overflow pass re-walks it into the arena
+    uint32_t* ovf_list;          // [n] chunk-local topic indices
+    uint32_t* ovf_count;         // device scalar
+    uint64_t* ovf_base;          // [n] arena base per overflow topic
+    unsigned long long* ovf_cursor;
+    uint32_t* ovf_arena;
+    uint64_t ovf_arena_cap;
+};
+
+struct ChunkArrays {
+    uint32_t n;                  // topics in chunk
+    uint32_t slot_cap;
+    const uint32_t* slots;
+    const uint32_t* pair_cnt;
+    uint32_t* hit_cnt;           // [n]
+    uint32_t* pair_live;         // [n] matched filters with at least one subscriber
+    uint64_t* hit_off;           // [n+1] exclusive scan of hit_cnt (chunk-local)
+    uint64_t* pair_base;         // [n+1] exclusive scan of pair_live
+    const uint64_t* ovf_base;
+    const uint32_t* ovf_arena;
+    uint64_t ovf_arena_cap;
+    uint32_t* error_flag;
+    // dense (topic, subscriber-run) pairs
+    uint32_t* pair_src;          // [P] subs[] index of the run
+    uint32_t* pair_topic;        // [P] batch-global topic index
+    uint64_t* pair_off;          // [P+1] chunk-local output offset of the run
+};
+
+void launch_walk(const TrieView& t, const WalkArgs& a, bool overflow_pass, void* stream);
+void launch_count(const TrieView& t, const ChunkArrays& c, void* stream);
+void launch_scan(const ChunkArrays& c, uint64_t* block_tmp, void* stream);
+void launch_compact(const TrieView& t, const ChunkArrays& c, uint32_t topic_base, void* stream);
+void launch_tiles(const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint32_t* tile_first, void* stream);
+void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint64_t hit_hi,
+                   const uint32_t* tile_first, Tuple* out, void* stream);
+uint32_t expand_tile_hits();
+uint32_t scan_block_topics();
+
+}  // namespace rgr

@@ -1,0 +1,160 @@
+// Per-lane / per-item logic of the matching kernels, written once as host+device inline
+// functions.  kernels.hip instantiates them inside the HIP kernels (LDS / HBM accessors);
+// tests/emu instantiates the same code on the host to check the table compiler and the
+// index arithmetic without a GPU.  (The emulator is test infrastructure: nothing in the
+// product library calls these on the host.)
+#pragma once
+#include <cstdint>
+
+#include "kernels.hpp"
+
+namespace rgr {
+
+// Depth-first walk of the subscription trie for ONE publish topic, emitting matched filter
+// ids in exactly TopicTree::matches' iteration order (rmqtt/src/trie.rs:327-375;
+// SURVEY.md App. A.2):
+//   remaining path empty : node's own filter, then its '#' child ("parent match";
+//                          trie.rs:328-338 pushes them in the opposite order and pops LIFO)
+//   otherwise            : unless (root && first level is '$'-metadata, trie.rs:342-346):
+//                          the '#' child's filter, then the whole '+' subtree;
+//                          then the exact-child subtree.
+// The DFS stack is one word per level (`path`): the node whose exact-child lookup is still
+// pending at that depth, or kNone.  It is only written when a '+' branch is taken, and is
+// found again by scanning down from the depth where the walk died.
+//
+//   tok_at(d)        level token d of the topic
+//   path_get/set(d)  stack word of depth d
+//   emit(fid)        next matched filter id
+//   load(slot,e0,e1) read the 32-byte edge record `slot` as two 16-byte halves
+// Returns the number of trie nodes visited (= MatchedIter instantiations, the nV of
+// SURVEY.md §8(d)).
+template <class TokAt, class PathGet, class PathSet, class Emit, class Load>
+RGR_HD inline uint32_t walk_topic(const NodeHeader& root, uint32_t mask, uint32_t L, bool meta, TokAt tok_at,
+                                  PathGet path_get, PathSet path_set, Emit emit, Load load) {
+    enum : int { kArrive = 0, kPop = 1, kProbe = 2, kDirect = 3 };
+    uint32_t visited = 0;
+    uint32_t node = 0, d = 0;
+    NodeHeader h = root;
+    int mode = kArrive;
+    int64_t scan = -1;
+    uint32_t slot = 0, want_parent = 0, want_tok = 0;
+    for (;;) {
+        if (mode == kArrive) {
+            visited++;
+            if (d == L) {
+                if (h.term_fid != kNone) emit(h.term_fid);
+                if (h.hash_fid != kNone) emit(h.hash_fid);
+                mode = kPop; scan = int64_t(d) - 1;
+            } else {
+                const bool wild = !(d == 0 && meta);
+                if (wild && h.hash_fid != kNone) emit(h.hash_fid);      // trie.rs:349-355
+                const uint32_t tk = tok_at(d);
+                const bool ex = tk != kTokUnknown;
+                const bool pl = wild && h.plus_slot != kNone;
+                if (pl) {                                                // trie.rs:358-362
+                    path_set(d, ex ? node : kNone);                      // exact lookup deferred
+                    slot = h.plus_slot; mode = kDirect;
+                } else if (ex) {                                         // trie.rs:366-370
+                    path_set(d, kNone);
+                    want_parent = node; want_tok = tk;
+                    slot = edge_hash(node, tk) & mask; mode = kProbe;
+                } else {
+                    path_set(d, kNone);
+                    mode = kPop; scan = int64_t(d) - 1;
+                }
+            }
+        }
+        if (mode == kPop) {
+            uint32_t pn = kNone;
+            int64_t s = scan;
+            for (; s >= 0; --s) { pn = path_get(uint32_t(s)); if (pn != kNone) break; }
+            if (s < 0) break;                                            // walk finished
+            path_set(uint32_t(s), kNone);
+            d = uint32_t(s);
+            want_parent = pn; want_tok = tok_at(d);
+            slot = edge_hash(pn, want_tok) & mask; mode = kProbe;
+        }
+        U4 e0, e1;                                                       // one 32-byte record per step
+        load(slot, e0, e1);
+        if (mode == kProbe) {
+            if (e0.x == kEdgeEmpty) { mode = kPop; scan = int64_t(d) - 1; continue; }
+            if (e0.x != want_parent || e0.y != want_tok) { slot = (slot + 1) & mask; continue; }
+        }
+        node = e0.z;
+        h.plus_slot = e0.w; h.hash_fid = e1.x; h.term_fid = e1.y;
+        d += 1;
+        mode = kArrive;
+    }
+    return visited;
+}
+
+// j-th matched filter of chunk-local topic t (slots are j-major; topics whose count
+// exceeded the slot capacity live in the overflow arena).
+RGR_HD inline uint32_t pair_fid(const ChunkArrays& c, uint32_t t, uint32_t cnt, uint32_t j) {
+    return cnt <= c.slot_cap ? c.slots[uint64_t(j) * c.n + t] : c.ovf_arena[c.ovf_base[t] + j];
+}
+
+// Per-topic hit count and number of matched filters that have subscribers.
+RGR_HD inline void count_topic(const TrieView& tv, const ChunkArrays& c, uint32_t t) {
+    const uint32_t cnt = c.pair_cnt[t];
+    uint32_t hits = 0, live = 0;
+    if (cnt > c.slot_cap && c.ovf_base[t] + cnt > c.ovf_arena_cap) {
+        *c.error_flag = 1; c.hit_cnt[t] = 0; c.pair_live[t] = 0;
+        return;
+    }
+    for (uint32_t j = 0; j < cnt; ++j) {
+        const uint32_t n = tv.filt[pair_fid(c, t, cnt, j)].count;
+        hits += n; live += n != 0;
+    }
+    c.hit_cnt[t] = hits;
+    c.pair_live[t] = live;
+}
+
+// Dense (topic, subscriber-run) pairs of topic t with their chunk-local output offsets.
+RGR_HD inline void compact_topic(const TrieView& tv, const ChunkArrays& c, uint32_t topic_base, uint32_t t) {
+    const uint32_t cnt = c.pair_cnt[t];
+    uint64_t o = c.hit_off[t];
+    uint64_t p = c.pair_base[t];
+    if (c.pair_live[t]) {
+        for (uint32_t j = 0; j < cnt; ++j) {
+            const FilterDesc fd = tv.filt[pair_fid(c, t, cnt, j)];
+            if (fd.count) {
+                c.pair_src[p] = fd.begin;
+                c.pair_topic[p] = topic_base + t;
+                c.pair_off[p] = o;
+                ++p; o += fd.count;
+            }
+        }
+    }
+    if (t == c.n - 1) c.pair_off[p] = o;   // sentinel: total hits of the chunk
+}
+
+// Pair p covers output positions [pair_off[p], pair_off[p+1]); it owns every tile whose first
+// position falls inside that range.
+RGR_HD inline void tiles_pair(const uint64_t* pair_off, uint64_t p, uint64_t pair_lo, uint64_t hit_lo, uint32_t tile,
+                              uint32_t* tile_first) {
+    const uint64_t s = pair_off[p] - hit_lo, e = pair_off[p + 1] - hit_lo;
+    for (uint64_t k = (s + tile - 1) / tile; k * tile < e; ++k) tile_first[k] = uint32_t(p - pair_lo);
+}
+
+// Largest i in [0,np) with off[i] <= pos (off[0] <= pos is guaranteed by the caller).
+template <class OffAt> RGR_HD inline uint32_t locate_pair(OffAt off_at, uint32_t np, int32_t pos) {
+    uint32_t lo = 0, hi = np;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (off_at(mid) <= pos) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// Tile-local view of pair i of a tile starting at output position `base`: offset of the run
+// relative to the tile (0 for the first pair, whose skipped prefix is folded into src).
+RGR_HD inline void tile_pair_view(const ChunkArrays& c, uint64_t a, uint32_t i, uint64_t base, int32_t& off, uint32_t& src,
+                                  uint32_t& topic) {
+    const uint64_t po = c.pair_off[a + i];
+    off = i == 0 ? 0 : int32_t(po - base);
+    src = c.pair_src[a + i] + (i == 0 ? uint32_t(base - po) : 0u);
+    topic = c.pair_topic[a + i];
+}
+
+}  // namespace rgr

@@ -1,0 +1,284 @@
+// Host-side subscription table compiler — see table.hpp.
+#include "table.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+#include "rmqtt_gpu_router.h"
+#include "topic.hpp"
+
+namespace rgr {
+
+// ------------------------------------------------------------------ StringDict
+StringDict::StringDict() : slots_(1024, 0), mask_(1023) {}
+
+uint64_t StringDict::hash(std::string_view s) {
+    uint64_t h = 0xcbf29ce484222325ull;             // FNV-1a 64 + avalanche
+    for (unsigned char c : s) { h ^= c; h *= 0x100000001b3ull; }
+    h ^= h >> 32; h *= 0xd6e8feb86659fd93ull; h ^= h >> 32;
+    return h;
+}
+
+uint32_t StringDict::find(std::string_view s) const {
+    const uint64_t h = hash(s);
+    for (uint64_t i = h & mask_;; i = (i + 1) & mask_) {
+        const uint32_t v = slots_[i];
+        if (!v) return kTokUnknown;
+        const Entry& e = entries_[v - 1];
+        if (e.hash == h && e.len == s.size() && (e.len == 0 || std::memcmp(arena_.data() + e.off, s.data(), e.len) == 0))
+            return v - 1 + kTokFirst;
+    }
+}
+
+void StringDict::grow() {
+    std::vector<uint32_t> ns(slots_.size() * 2, 0);
+    const uint64_t nm = ns.size() - 1;
+    for (uint32_t v : slots_) {
+        if (!v) continue;
+        uint64_t i = entries_[v - 1].hash & nm;
+        while (ns[i]) i = (i + 1) & nm;
+        ns[i] = v;
+    }
+    slots_.swap(ns);
+    mask_ = nm;
+}
+
+uint32_t StringDict::intern(std::string_view s) {
+    uint32_t t = find(s);
+    if (t != kTokUnknown) return t;
+    if ((entries_.size() + 1) * 2 > slots_.size()) grow();
+    const uint64_t h = hash(s);
+    entries_.push_back(Entry{h, arena_.size(), uint32_t(s.size())});
+    arena_.insert(arena_.end(), s.begin(), s.end());
+    uint64_t i = h & mask_;
+    while (slots_[i]) i = (i + 1) & mask_;
+    slots_[i] = uint32_t(entries_.size());
+    return uint32_t(entries_.size()) - 1 + kTokFirst;
+}
+
+std::string_view StringDict::str(uint32_t tok) const {
+    const Entry& e = entries_[tok - kTokFirst];
+    return std::string_view(arena_.data() + e.off, e.len);
+}
+
+// ------------------------------------------------------------------ HostTable
+static EdgeEntry empty_edge() { return EdgeEntry{kEdgeEmpty, 0, kNone, kNone, kNone, kNone, 0, 0}; }
+
+HostTable::HostTable() {
+    nodes_.push_back(Node{kNone, 0, kNone, 0, kNone, kNone, kNone});   // root = node 0
+    edges_.assign(1024, empty_edge());
+}
+
+void HostTable::reserve(uint64_t n_filters_hint, uint64_t levels_hint) {
+    uint64_t want = 1024;
+    while (want < levels_hint * 2) want <<= 1;
+    if (want > edges_.size()) rehash(want);
+    filters_.reserve(n_filters_hint);
+    nodes_.reserve(levels_hint + 1);
+}
+
+bool HostTable::tokenize_filter(std::string_view f, std::vector<uint32_t>& toks) {
+    toks.clear();
+    // validate first so that rejected filters do not pollute the dictionary
+    int64_t n = for_each_level(f, [](int64_t, std::string_view, LevelKind) {});
+    if (n < 0) return false;
+    for_each_level(f, [&](int64_t, std::string_view seg, LevelKind k) {
+        if (k == LevelKind::Plus) toks.push_back(kTokPlus);
+        else if (k == LevelKind::Hash) toks.push_back(kTokHash);
+        else toks.push_back(dict_.intern(seg));
+    });
+    return true;
+}
+
+uint8_t HostTable::tokenize_topic(std::string_view t, std::vector<uint32_t>& toks) const {
+    const size_t mark = toks.size();
+    uint8_t flags = 0;
+    int64_t n = for_each_level(t, [&](int64_t idx, std::string_view seg, LevelKind k) {
+        if (idx == 0 && k == LevelKind::Metadata) flags |= kTopicMeta;
+        if (k == LevelKind::Plus) toks.push_back(kTokPlus);
+        else if (k == LevelKind::Hash) toks.push_back(kTokHash);
+        else toks.push_back(dict_.find(seg));
+    });
+    if (n < 0) { toks.resize(mark); return kTopicInvalid; }
+    return flags;
+}
+
+uint32_t HostTable::find_slot(uint32_t parent, uint32_t token) const {
+    const uint32_t mask = uint32_t(edges_.size() - 1);
+    for (uint32_t i = edge_hash(parent, token) & mask;; i = (i + 1) & mask) {
+        const EdgeEntry& e = edges_[i];
+        if (e.parent == kEdgeEmpty) return kNone;
+        if (e.parent == parent && e.token == token) return i;
+    }
+}
+
+void HostTable::rehash(uint64_t new_cap) {
+    std::vector<EdgeEntry> old;
+    old.swap(edges_);
+    edges_.assign(new_cap, empty_edge());
+    const uint32_t mask = uint32_t(new_cap - 1);
+    for (const EdgeEntry& e : old) {
+        if (e.parent == kEdgeEmpty || e.parent == kEdgeTomb) continue;
+        uint32_t i = edge_hash(e.parent, e.token) & mask;
+        while (edges_[i].parent != kEdgeEmpty) i = (i + 1) & mask;
+        edges_[i] = e;
+        nodes_[e.child].slot = i;
+    }
+    edge_used_ = edge_live_;
+    // slots moved: re-point every header's plus_slot
+    for (EdgeEntry& e : edges_) {
+        if (e.parent == kEdgeEmpty) continue;
+        const uint32_t pc = nodes_[e.child].plus_child;
+        e.plus_slot = pc == kNone ? kNone : nodes_[pc].slot;
+    }
+    const uint32_t rp = nodes_[0].plus_child;
+    root_hdr_.plus_slot = rp == kNone ? kNone : nodes_[rp].slot;
+}
+
+uint32_t HostTable::insert_edge(uint32_t parent, uint32_t token, uint32_t child) {
+    if ((edge_used_ + 1) * 2 > edges_.size())
+        rehash(edge_live_ * 4 > edges_.size() ? edges_.size() * 2 : edges_.size());
+    const uint32_t mask = uint32_t(edges_.size() - 1);
+    uint32_t i = edge_hash(parent, token) & mask;
+    while (edges_[i].parent != kEdgeEmpty && edges_[i].parent != kEdgeTomb) i = (i + 1) & mask;
+    if (edges_[i].parent == kEdgeEmpty) edge_used_++;
+    edges_[i] = EdgeEntry{parent, token, child, kNone, kNone, kNone, 0, 0};
+    edge_live_++;
+    return i;
+}
+
+uint32_t HostTable::new_node(uint32_t parent, uint32_t token) {
+    uint32_t id;
+    if (!free_nodes_.empty()) { id = free_nodes_.back(); free_nodes_.pop_back(); }
+    else { id = uint32_t(nodes_.size()); nodes_.push_back(Node{}); }
+    nodes_[id] = Node{parent, token, kNone, 0, kNone, kNone, kNone};
+    const uint32_t slot = insert_edge(parent, token, id);   // may rehash (fixes every other slot)
+    nodes_[id].slot = slot;
+    nodes_[parent].nchild++;
+    n_nodes_++;
+    if (token == kTokPlus) { nodes_[parent].plus_child = id; set_plus_slot(parent, slot); }
+    else if (token == kTokHash) nodes_[parent].hash_child = id;
+    return id;
+}
+
+void HostTable::set_plus_slot(uint32_t node, uint32_t slot) {
+    if (node == 0) root_hdr_.plus_slot = slot; else edges_[nodes_[node].slot].plus_slot = slot;
+}
+void HostTable::set_hash_fid(uint32_t node, uint32_t fid) {
+    if (node == 0) root_hdr_.hash_fid = fid; else edges_[nodes_[node].slot].hash_fid = fid;
+}
+void HostTable::set_term_fid(uint32_t node, uint32_t fid) {
+    nodes_[node].term_fid = fid;
+    if (node == 0) root_hdr_.term_fid = fid; else edges_[nodes_[node].slot].term_fid = fid;
+}
+
+uint32_t HostTable::walk_existing(const std::vector<uint32_t>& toks) const {
+    uint32_t cur = 0;
+    for (uint32_t t : toks) {
+        if (t == kTokUnknown) return kNone;
+        const uint32_t s = find_slot(cur, t);
+        if (s == kNone) return kNone;
+        cur = edges_[s].child;
+    }
+    return cur;
+}
+
+int32_t HostTable::filter_add(std::string_view f, uint32_t* fid) {
+    std::vector<uint32_t> toks;
+    if (!tokenize_filter(f, toks)) return RGR_EINVAL_TOPIC;
+    uint32_t cur = 0;
+    for (uint32_t t : toks) {
+        const uint32_t s = find_slot(cur, t);
+        cur = s != kNone ? edges_[s].child : new_node(cur, t);
+    }
+    if (nodes_[cur].term_fid != kNone) { *fid = nodes_[cur].term_fid; return RGR_OK; }
+    uint32_t id;
+    if (!free_fids_.empty()) { id = free_fids_.back(); free_fids_.pop_back(); }
+    else { id = uint32_t(filters_.size()); filters_.emplace_back(); }
+    filters_[id].node = cur;
+    filters_[id].subs.clear();
+    set_term_fid(cur, id);
+    if (nodes_[cur].token == kTokHash) set_hash_fid(nodes_[cur].parent, id);
+    n_filters_++;
+    *fid = id;
+    return RGR_OK;
+}
+
+int32_t HostTable::filter_find(std::string_view f, uint32_t* fid) const {
+    std::vector<uint32_t> toks;
+    int64_t n = for_each_level(f, [&](int64_t, std::string_view seg, LevelKind k) {
+        if (k == LevelKind::Plus) toks.push_back(kTokPlus);
+        else if (k == LevelKind::Hash) toks.push_back(kTokHash);
+        else toks.push_back(dict_.find(seg));
+    });
+    if (n < 0) return RGR_EINVAL_TOPIC;
+    const uint32_t node = walk_existing(toks);
+    if (node == kNone || nodes_[node].term_fid == kNone) return RGR_ENOENT;
+    *fid = nodes_[node].term_fid;
+    return RGR_OK;
+}
+
+int32_t HostTable::filter_remove(uint32_t fid) {
+    if (fid >= filters_.size() || filters_[fid].node == kNone) return RGR_ENOENT;
+    if (!filters_[fid].subs.empty()) return RGR_ESTATE;
+    uint32_t t = filters_[fid].node;
+    set_term_fid(t, kNone);
+    if (nodes_[t].token == kTokHash) set_hash_fid(nodes_[t].parent, kNone);
+    // trie.rs:141-143: prune children left with no values and no branches, bottom-up
+    while (t != 0 && nodes_[t].term_fid == kNone && nodes_[t].nchild == 0) {
+        const uint32_t p = nodes_[t].parent;
+        edges_[nodes_[t].slot].parent = kEdgeTomb;
+        edge_live_--;
+        if (nodes_[t].token == kTokPlus) { nodes_[p].plus_child = kNone; set_plus_slot(p, kNone); }
+        else if (nodes_[t].token == kTokHash) nodes_[p].hash_child = kNone;
+        nodes_[p].nchild--;
+        free_nodes_.push_back(t);
+        n_nodes_--;
+        t = p;
+    }
+    filters_[fid].node = kNone;
+    std::vector<SubEntry>().swap(filters_[fid].subs);
+    free_fids_.push_back(fid);
+    n_filters_--;
+    return RGR_OK;
+}
+
+int32_t HostTable::sub_add(uint32_t fid, uint32_t sub_id, uint8_t qos, uint8_t flags) {
+    if (fid >= filters_.size() || filters_[fid].node == kNone) return RGR_ENOENT;
+    auto& v = filters_[fid].subs;
+    const SubEntry e{sub_id, uint32_t(qos) | (uint32_t(flags) << 8)};
+    if (v.empty() || v.back().sub_id < sub_id) { v.push_back(e); n_subs_++; return RGR_OK; }
+    auto it = std::lower_bound(v.begin(), v.end(), sub_id, [](const SubEntry& a, uint32_t b) { return a.sub_id < b; });
+    if (it != v.end() && it->sub_id == sub_id) { *it = e; return RGR_OK; }   // re-subscribe: options replaced
+    v.insert(it, e);
+    n_subs_++;
+    return RGR_OK;
+}
+
+int32_t HostTable::sub_remove(uint32_t fid, uint32_t sub_id) {
+    if (fid >= filters_.size() || filters_[fid].node == kNone) return RGR_ENOENT;
+    auto& v = filters_[fid].subs;
+    auto it = std::lower_bound(v.begin(), v.end(), sub_id, [](const SubEntry& a, uint32_t b) { return a.sub_id < b; });
+    if (it == v.end() || it->sub_id != sub_id) return RGR_ENOENT;
+    v.erase(it);
+    n_subs_--;
+    return RGR_OK;
+}
+
+void HostTable::flatten_filters(std::vector<FilterDesc>& filt, std::vector<SubEntry>& subs) const {
+    filt.resize(filters_.size());
+    subs.clear();
+    subs.reserve(n_subs_);
+    for (size_t i = 0; i < filters_.size(); ++i) {
+        filt[i] = FilterDesc{uint32_t(subs.size()), uint32_t(filters_[i].subs.size())};
+        subs.insert(subs.end(), filters_[i].subs.begin(), filters_[i].subs.end());
+    }
+}
+
+uint64_t HostTable::max_filter_subs() const {
+    uint64_t m = 0;
+    for (auto& f : filters_) m = std::max<uint64_t>(m, f.subs.size());
+    return m;
+}
+
+}  // namespace rgr

@@ -1,0 +1,99 @@
+// Host-side subscription table compiler.
+//
+// Owns the mutable image of what the reference keeps in `TopicTree<()>` +
+// `AllRelationsMap` (rmqtt/src/router.rs:121-127, rmqtt/src/trie.rs:84-87), already in
+// the layout the kernels read: a token dictionary, an open-addressed edge table of
+// 32-byte records (kernels.hpp) and per-filter subscriber runs.  Mutations follow
+// trie.rs:113-149 (insert; remove + prune nodes left with no value and no branches).
+// rgr_commit() snapshots this image into HBM as an immutable epoch.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <string_view>
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace rgr {
+
+// Level-string -> token id dictionary (open addressing over an append-only byte arena).
+class StringDict {
+   public:
+    StringDict();
+    uint32_t find(std::string_view s) const;      // kTokUnknown if absent
+    uint32_t intern(std::string_view s);          // existing or new token id
+    uint32_t size() const { return uint32_t(entries_.size()); }
+    static uint64_t hash(std::string_view s);
+    std::string_view str(uint32_t tok) const;
+
+   private:
+    struct Entry { uint64_t hash; uint64_t off; uint32_t len; };
+    std::vector<char> arena_;
+    std::vector<Entry> entries_;       // index = token - kTokFirst
+    std::vector<uint32_t> slots_;      // token+1, 0 = empty
+    uint64_t mask_;
+    void grow();
+};
+
+class HostTable {
+   public:
+    HostTable();
+    // Parse a filter into tokens (interning new level strings).  false => invalid filter.
+    bool tokenize_filter(std::string_view f, std::vector<uint32_t>& toks);
+    // Tokenise a publish topic against the dictionary without mutating it.  Returns the
+    // topic flags (kTopicInvalid / kTopicMeta); appends tokens only for valid topics.
+    uint8_t tokenize_topic(std::string_view t, std::vector<uint32_t>& toks) const;
+
+    int32_t filter_add(std::string_view f, uint32_t* fid);
+    int32_t filter_find(std::string_view f, uint32_t* fid) const;
+    int32_t filter_remove(uint32_t fid);
+    int32_t sub_add(uint32_t fid, uint32_t sub_id, uint8_t qos, uint8_t flags);
+    int32_t sub_remove(uint32_t fid, uint32_t sub_id);
+
+    // Flattened image for the device.
+    const std::vector<EdgeEntry>& edges() const { return edges_; }
+    NodeHeader root_header() const { return root_hdr_; }
+    void flatten_filters(std::vector<FilterDesc>& filt, std::vector<SubEntry>& subs) const;
+
+    uint64_t n_filters() const { return n_filters_; }
+    uint64_t n_subs() const { return n_subs_; }
+    uint64_t n_nodes() const { return n_nodes_; }
+    uint64_t n_tokens() const { return dict_.size(); }
+    uint64_t max_filter_subs() const;
+    const StringDict& dict() const { return dict_; }
+    void reserve(uint64_t n_filters_hint, uint64_t levels_hint);
+
+   private:
+    struct Node {
+        uint32_t parent, token;
+        uint32_t slot;         // slot of this node's edge record (kNone for the root)
+        uint32_t nchild;
+        uint32_t term_fid;
+        uint32_t plus_child, hash_child;   // node ids
+    };
+    struct Filter {
+        uint32_t node = kNone;             // terminal node; kNone = free id
+        std::vector<SubEntry> subs;        // ascending sub_id
+    };
+    StringDict dict_;
+    std::vector<Node> nodes_;
+    std::vector<uint32_t> free_nodes_;
+    std::vector<EdgeEntry> edges_;
+    uint64_t edge_used_ = 0;               // live + tombstones
+    uint64_t edge_live_ = 0;
+    NodeHeader root_hdr_{kNone, kNone, kNone};
+    std::vector<Filter> filters_;
+    std::vector<uint32_t> free_fids_;
+    uint64_t n_filters_ = 0, n_subs_ = 0, n_nodes_ = 1;
+
+    uint32_t find_slot(uint32_t parent, uint32_t token) const;
+    uint32_t insert_edge(uint32_t parent, uint32_t token, uint32_t child);
+    void rehash(uint64_t new_cap);
+    uint32_t new_node(uint32_t parent, uint32_t token);
+    void set_plus_slot(uint32_t node, uint32_t slot);
+    void set_hash_fid(uint32_t node, uint32_t fid);
+    void set_term_fid(uint32_t node, uint32_t fid);
+    uint32_t walk_existing(const std::vector<uint32_t>& toks) const;
+};
+
+}  // namespace rgr

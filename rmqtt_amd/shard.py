@@ -1,0 +1,42 @@
+"""Multi-GPU sharding rule — host-side helpers over the C ABI.
+
+owner(topic)  = H(level0, level1|none) mod G
+owner(filter) = the same, or -1 (replicate on every shard) when level0 or level1 is a
+                wildcard.  A topic's full match set then lives on its owner alone, so the
+                data path needs no collective; ranks only exchange hit counts (and,
+                optionally, tuples: all-gatherv) afterwards.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .workload import take  # noqa: F401  (re-export: gather a subset of a string batch)
+
+
+def assign(blob, offsets, n_shards, is_filter):
+    blob = np.ascontiguousarray(blob, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n = len(offsets) - 1
+    out = np.zeros(n, dtype=np.int32)
+    rc = capi.lib().rgr_shard_assign(blob.ctypes.data, offsets.ctypes.data, n, n_shards, int(is_filter), out.ctypes.data)
+    if rc != 0:
+        raise capi.RgrError(rc, capi.lib().rgr_last_error().decode())
+    return out
+
+
+def allgatherv_tuples(local, world, rank, dist, device):
+    """all-gatherv of (topic_idx, sub_id, qos) tuples: local is an int32/uint32 tensor [n,3].
+    RCCL has no native allgatherv: gather the counts, then one padded all_gather; returns the
+    concatenation in rank order.  (world_size-2 gloo test: tests/test_distributed.py.)"""
+    import torch
+    cnt = torch.tensor([local.shape[0]], dtype=torch.int64, device=device)
+    counts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(counts, cnt)
+    counts = [int(x.item()) for x in counts]
+    mx = max(counts) if counts else 0
+    pad = torch.zeros((mx, 3), dtype=local.dtype, device=device)
+    pad[: local.shape[0]] = local
+    bufs = [torch.zeros_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad)
+    return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0), counts

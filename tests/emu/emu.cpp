@@ -1,0 +1,216 @@
+// TEST INFRASTRUCTURE ONLY — host emulator of the HIP matching pipeline.
+//
+// Runs the *same* per-lane / per-item functions the kernels run (rmqtt_amd/csrc/
+// match_core.hpp) and the same host table compiler (table.cpp), sequentially on the CPU,
+// with the same chunk / slot-overflow / window / tile orchestration as c_abi.cpp.  It lets
+// the `-m "not gpu"` suite check the compiled table and the index arithmetic against the
+// oracle without a GPU.  It is NOT a CPU fallback: the product library neither contains
+// nor links this file, and rgr_create fails without a HIP device.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <string_view>
+#include <vector>
+
+#include "match_core.hpp"
+#include "rmqtt_gpu_router.h"
+#include "table.hpp"
+
+using namespace rgr;
+
+namespace {
+struct Emu {
+    HostTable table;
+    uint32_t slot_cap = 32, chunk_topics = 1u << 21, lds_window = 2560, tile = 2048;
+    uint64_t window_hits = 1ull << 28;
+    uint64_t visited = 0, overflow_topics = 0, windows = 0, pairs = 0;
+};
+template <class T> T* dup(const std::vector<T>& v) {
+    T* p = static_cast<T*>(std::malloc(std::max<size_t>(1, v.size()) * sizeof(T)));
+    if (!v.empty()) std::memcpy(p, v.data(), v.size() * sizeof(T));
+    return p;
+}
+}  // namespace
+
+extern "C" {
+
+void* emu_new(uint32_t slot_cap, uint32_t chunk_topics, uint64_t window_hits, uint32_t lds_window, uint32_t tile) {
+    auto* e = new Emu();
+    if (slot_cap) e->slot_cap = slot_cap;
+    if (chunk_topics) e->chunk_topics = chunk_topics;
+    if (window_hits) e->window_hits = window_hits;
+    e->lds_window = lds_window;
+    if (tile) e->tile = tile;
+    return e;
+}
+void emu_free(void* e) { delete static_cast<Emu*>(e); }
+void emu_free_buf(void* p) { std::free(p); }
+
+int32_t emu_filter_add(void* e, const char* f, uint32_t len, uint32_t* fid) { return static_cast<Emu*>(e)->table.filter_add(std::string_view(f, len), fid); }
+int32_t emu_filter_find(void* e, const char* f, uint32_t len, uint32_t* fid) { return static_cast<Emu*>(e)->table.filter_find(std::string_view(f, len), fid); }
+int32_t emu_filter_remove(void* e, uint32_t fid) { return static_cast<Emu*>(e)->table.filter_remove(fid); }
+int32_t emu_sub_add(void* e, uint32_t fid, uint32_t sid, uint8_t qos, uint8_t flags) { return static_cast<Emu*>(e)->table.sub_add(fid, sid, qos, flags); }
+int32_t emu_sub_remove(void* e, uint32_t fid, uint32_t sid) { return static_cast<Emu*>(e)->table.sub_remove(fid, sid); }
+uint64_t emu_n_nodes(void* e) { return static_cast<Emu*>(e)->table.n_nodes(); }
+uint64_t emu_n_filters(void* e) { return static_cast<Emu*>(e)->table.n_filters(); }
+uint64_t emu_n_subs(void* e) { return static_cast<Emu*>(e)->table.n_subs(); }
+uint64_t emu_visited(void* e) { return static_cast<Emu*>(e)->visited; }
+uint64_t emu_overflow_topics(void* e) { return static_cast<Emu*>(e)->overflow_topics; }
+uint64_t emu_windows(void* e) { return static_cast<Emu*>(e)->windows; }
+
+int32_t emu_subscribe_bulk(void* ev, const uint8_t* blob, const uint64_t* offs, uint64_t n, const uint32_t* sub_ids,
+                           const uint8_t* qos, const uint8_t* flags, uint64_t* rejected) {
+    auto* e = static_cast<Emu*>(ev);
+    uint64_t rej = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        uint32_t fid;
+        if (e->table.filter_add(std::string_view(reinterpret_cast<const char*>(blob) + offs[i], offs[i + 1] - offs[i]), &fid) != RGR_OK) { rej++; continue; }
+        e->table.sub_add(fid, sub_ids ? sub_ids[i] : uint32_t(i), qos ? qos[i] : 0, flags ? flags[i] : 0);
+    }
+    if (rejected) *rejected = rej;
+    return RGR_OK;
+}
+
+// Same outputs as rgr_match_batch (+ the matched filter ids per topic).  Arrays malloc'ed.
+int32_t emu_match(void* ev, const uint8_t* blob, const uint64_t* offs, uint32_t n, int32_t* status, uint64_t** hit_offsets_out,
+                  rgr_tuple** tuples_out, uint64_t* n_hits_out, uint64_t** pair_offsets_out, uint32_t** pair_fids_out) {
+    auto* e = static_cast<Emu*>(ev);
+    const HostTable& tb = e->table;
+    // ---- tokenise
+    std::vector<uint32_t> tokens;
+    std::vector<uint64_t> tok_off(size_t(n) + 1, 0);
+    std::vector<uint8_t> tflags(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        tflags[i] = tb.tokenize_topic(std::string_view(reinterpret_cast<const char*>(blob) + offs[i], offs[i + 1] - offs[i]), tokens);
+        tok_off[i + 1] = tokens.size();
+        status[i] = (tflags[i] & kTopicInvalid) ? RGR_TOPIC_INVALID : RGR_TOPIC_OK;
+    }
+    tokens.push_back(0);
+    std::vector<uint32_t> path_scratch(tokens.size(), 0xDEADBEEF);
+    // ---- epoch view over host memory
+    std::vector<FilterDesc> filt;
+    std::vector<SubEntry> subs;
+    tb.flatten_filters(filt, subs);
+    filt.push_back(FilterDesc{0, 0}); subs.push_back(SubEntry{0, 0});
+    TrieView tv{tb.edges().data(), uint32_t(tb.edges().size() - 1), tb.root_header(), filt.data(), subs.data()};
+
+    std::vector<uint64_t> hit_offsets(size_t(n) + 1, 0), pair_offsets(size_t(n) + 1, 0);
+    std::vector<rgr_tuple> tuples;
+    std::vector<uint32_t> pair_fids;
+    const uint32_t C = e->slot_cap;
+
+    for (uint32_t begin = 0; begin < n; begin += e->chunk_topics) {
+        const uint32_t cn = std::min<uint32_t>(e->chunk_topics, n - begin);
+        std::vector<uint32_t> slots(size_t(C) * cn, 0xDEADBEEF), pair_cnt(cn, 0), hit_cnt(cn), pair_live(cn), ovf_list;
+        std::vector<uint64_t> hit_off(size_t(cn) + 1), pair_base(size_t(cn) + 1), ovf_base(cn, 0);
+        std::vector<uint32_t> arena;
+        uint64_t ovf_cursor = 0;
+        // ---- walk (main pass): blocks of 256 topics share one LDS window
+        std::vector<uint32_t> s_path(std::max<uint32_t>(1, e->lds_window));
+        auto walk = [&](uint32_t tl, bool ovf_pass) {
+            const uint32_t gt = begin + tl;
+            const uint64_t off0 = tok_off[gt];
+            const uint32_t L = uint32_t(tok_off[gt + 1] - off0);
+            const uint32_t t0 = tl / 256 * 256;
+            const uint64_t win_base = tok_off[begin + t0];
+            const uint64_t span = tok_off[begin + std::min(t0 + 256, cn)] - win_base;
+            const uint64_t staged = ovf_pass ? 0 : std::min<uint64_t>(span, e->lds_window);
+            const uint64_t rel = off0 - win_base;
+            uint32_t cnt = 0;
+            if (tflags[gt] & kTopicInvalid) { if (!ovf_pass) pair_cnt[tl] = 0; return; }
+            auto tok_at = [&](uint32_t d) { return tokens[off0 + d]; };
+            auto path_get = [&](uint32_t d) { return rel + d < staged ? s_path[rel + d] : path_scratch[off0 + d]; };
+            auto path_set = [&](uint32_t d, uint32_t v) { if (rel + d < staged) s_path[rel + d] = v; else path_scratch[off0 + d] = v; };
+            auto emit = [&](uint32_t fid) {
+                if (ovf_pass) arena[ovf_base[tl] + cnt] = fid;
+                else if (cnt < C) slots[size_t(cnt) * cn + tl] = fid;
+                cnt++;
+            };
+            const uint32_t v = walk_topic(tv.root, tv.mask, L, (tflags[gt] & kTopicMeta) != 0, tok_at, path_get, path_set, emit,
+                                          [&](uint32_t slot, U4& e0, U4& e1) {
+                                              const EdgeEntry& en = tv.edges[slot];
+                                              e0 = U4{en.parent, en.token, en.child, en.plus_slot};
+                                              e1 = U4{en.hash_fid, en.term_fid, en.pad0, en.pad1};
+                                          });
+            if (!ovf_pass) {
+                e->visited += v;
+                pair_cnt[tl] = cnt;
+                if (cnt > C) { ovf_list.push_back(tl); ovf_base[tl] = ovf_cursor; ovf_cursor += cnt; }
+            }
+        };
+        for (uint32_t tl = 0; tl < cn; ++tl) walk(tl, false);
+        arena.assign(ovf_cursor + 1, 0xDEADBEEF);
+        for (uint32_t tl : ovf_list) walk(tl, true);
+        e->overflow_topics += ovf_list.size();
+        // ---- count / scan / compact
+        uint32_t err = 0;
+        ChunkArrays ca{};
+        ca.n = cn; ca.slot_cap = C; ca.slots = slots.data(); ca.pair_cnt = pair_cnt.data(); ca.hit_cnt = hit_cnt.data();
+        ca.pair_live = pair_live.data(); ca.hit_off = hit_off.data(); ca.pair_base = pair_base.data();
+        ca.ovf_base = ovf_base.data(); ca.ovf_arena = arena.data(); ca.ovf_arena_cap = arena.size(); ca.error_flag = &err;
+        for (uint32_t t = 0; t < cn; ++t) count_topic(tv, ca, t);
+        if (err) return RGR_ECAPACITY;
+        hit_off[0] = pair_base[0] = 0;
+        for (uint32_t t = 0; t < cn; ++t) { hit_off[t + 1] = hit_off[t] + hit_cnt[t]; pair_base[t + 1] = pair_base[t] + pair_live[t]; }
+        const uint64_t P = pair_base[cn], H = hit_off[cn];
+        std::vector<uint32_t> pair_src(P + 1), pair_topic(P + 1);
+        std::vector<uint64_t> pair_off(P + 2, ~0ull);
+        ca.pair_src = pair_src.data(); ca.pair_topic = pair_topic.data(); ca.pair_off = pair_off.data();
+        for (uint32_t t = 0; t < cn; ++t) compact_topic(tv, ca, begin, t);
+        e->pairs += P;
+        // matched-filter view
+        for (uint32_t t = 0; t < cn; ++t) {
+            for (uint32_t j = 0; j < pair_cnt[t]; ++j) pair_fids.push_back(pair_fid(ca, t, pair_cnt[t], j));
+            pair_offsets[begin + t + 1] = pair_fids.size();
+        }
+        // ---- windows: tiles + expand
+        const size_t out_base = tuples.size();
+        tuples.resize(out_base + H);
+        uint32_t lc = 0;
+        while (lc < cn) {
+            uint32_t le;
+            if (hit_off[cn] - hit_off[lc] <= e->window_hits) le = cn;
+            else {
+                le = uint32_t(std::upper_bound(hit_off.begin() + lc, hit_off.end(), hit_off[lc] + e->window_hits) - hit_off.begin()) - 1;
+                if (le <= lc) le = lc + 1;
+            }
+            const uint64_t hit_lo = hit_off[lc], hit_hi = hit_off[le], pair_lo = pair_base[lc], pair_hi = pair_base[le];
+            const uint64_t nh = hit_hi - hit_lo;
+            e->windows++;
+            if (nh) {
+                const uint32_t T = e->tile;
+                const uint32_t ntiles = uint32_t((nh + T - 1) / T);
+                std::vector<uint32_t> tile_first(ntiles, 0xDEADBEEF);
+                for (uint64_t p = pair_lo; p < pair_hi; ++p) tiles_pair(pair_off.data(), p, pair_lo, hit_lo, T, tile_first.data());
+                std::vector<int32_t> s_off(T + 2);
+                std::vector<uint32_t> s_src(T + 2), s_topic(T + 2);
+                rgr_tuple* out = tuples.data() + out_base + hit_lo;
+                for (uint32_t tile = 0; tile < ntiles; ++tile) {
+                    const uint64_t base = hit_lo + uint64_t(tile) * T;
+                    const uint32_t len = uint32_t(std::min<uint64_t>(T, hit_hi - base));
+                    if (tile_first[tile] == 0xDEADBEEF) return RGR_EINVAL;
+                    const uint64_t a = pair_lo + tile_first[tile];
+                    const uint64_t b = (tile + 1 < ntiles) ? pair_lo + tile_first[tile + 1] + 1 : pair_hi;
+                    const uint32_t np = uint32_t(b - a);
+                    if (np > T + 1) return RGR_EINVAL;
+                    for (uint32_t i = 0; i < np; ++i) tile_pair_view(ca, a, i, base, s_off[i], s_src[i], s_topic[i]);
+                    for (uint32_t pos = 0; pos < len; ++pos) {
+                        const uint32_t i = locate_pair([&](uint32_t m) { return s_off[m]; }, np, int32_t(pos));
+                        const SubEntry se = tv.subs[uint64_t(s_src[i]) + uint32_t(int32_t(pos) - s_off[i])];
+                        out[(base - hit_lo) + pos] = rgr_tuple{s_topic[i], se.sub_id, se.qos_flags};
+                    }
+                }
+            }
+            lc = le;
+        }
+        for (uint32_t t = 0; t <= cn; ++t) hit_offsets[begin + t] = out_base + hit_off[t];
+    }
+    *hit_offsets_out = dup(hit_offsets);
+    *tuples_out = dup(tuples);
+    *n_hits_out = tuples.size();
+    if (pair_offsets_out) *pair_offsets_out = dup(pair_offsets);
+    if (pair_fids_out) *pair_fids_out = dup(pair_fids);
+    return RGR_OK;
+}
+
+}  // extern "C"

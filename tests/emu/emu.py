@@ -1,0 +1,132 @@
+"""ctypes binding of tests/emu/emu.cpp — TEST INFRASTRUCTURE ONLY (host emulation of the
+HIP pipeline over the product's own table compiler + match_core.hpp)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+_LIB = None
+
+TUPLE_DTYPE = np.dtype([("topic_idx", np.uint32), ("sub_id", np.uint32), ("qos_flags", np.uint32)])
+
+
+def build():
+    so = os.path.join(HERE, "libemu.so")
+    csrc = os.path.join(ROOT, "rmqtt_amd", "csrc")
+    deps = [os.path.join(HERE, "emu.cpp")] + [os.path.join(csrc, f) for f in
+                                               ("table.cpp", "table.hpp", "match_core.hpp", "kernels.hpp", "topic.hpp")]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"), "-I", csrc,
+                               os.path.join(HERE, "emu.cpp"), os.path.join(csrc, "table.cpp"), "-o", so])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        vp, u32, u64, u8 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_uint8
+        L.emu_new.argtypes = [u32, u32, u64, u32, u32]; L.emu_new.restype = vp
+        L.emu_free.argtypes = [vp]; L.emu_free_buf.argtypes = [vp]
+        L.emu_filter_add.argtypes = [vp, C.c_char_p, u32, C.POINTER(u32)]
+        L.emu_filter_find.argtypes = [vp, C.c_char_p, u32, C.POINTER(u32)]
+        L.emu_filter_remove.argtypes = [vp, u32]
+        L.emu_sub_add.argtypes = [vp, u32, u32, u8, u8]
+        L.emu_sub_remove.argtypes = [vp, u32, u32]
+        for f in ("emu_n_nodes", "emu_n_filters", "emu_n_subs", "emu_visited", "emu_overflow_topics", "emu_windows"):
+            getattr(L, f).argtypes = [vp]; getattr(L, f).restype = u64
+        L.emu_subscribe_bulk.argtypes = [vp, vp, vp, u64, vp, vp, vp, C.POINTER(u64)]
+        L.emu_match.argtypes = [vp, vp, vp, u32, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), C.POINTER(vp), C.POINTER(vp)]
+        _LIB = L
+    return _LIB
+
+
+def _b(s):
+    return s if isinstance(s, (bytes, bytearray)) else s.encode()
+
+
+def _take(p, n, dtype):
+    if n:
+        a = np.frombuffer(C.string_at(p, int(n) * np.dtype(dtype).itemsize), dtype=dtype).copy()
+    else:
+        a = np.zeros(0, dtype=dtype)
+    lib().emu_free_buf(p)
+    return a
+
+
+class EmuRouter:
+    """Same surface as rmqtt_amd.capi.Router for the calls the parity tests use."""
+
+    def __init__(self, slot_cap=0, chunk_topics=0, window_hits=0, lds_window=2560, tile=0):
+        self._h = lib().emu_new(slot_cap, chunk_topics, window_hits, lds_window, tile)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().emu_free(self._h); self._h = None
+
+    def filter_add(self, f):
+        f = _b(f); fid = C.c_uint32()
+        rc = lib().emu_filter_add(self._h, f, len(f), C.byref(fid))
+        if rc != 0:
+            raise ValueError(rc)
+        return fid.value
+
+    def filter_find(self, f):
+        f = _b(f); fid = C.c_uint32()
+        return fid.value if lib().emu_filter_find(self._h, f, len(f), C.byref(fid)) == 0 else None
+
+    def filter_remove(self, fid):
+        return lib().emu_filter_remove(self._h, fid)
+
+    def sub_add(self, fid, sub_id, qos=0, flags=0):
+        assert lib().emu_sub_add(self._h, fid, sub_id, qos, flags) == 0
+
+    def sub_remove(self, fid, sub_id):
+        return lib().emu_sub_remove(self._h, fid, sub_id)
+
+    def subscribe_bulk(self, blob, offsets, sub_ids=None, qos=None, flags=None):
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        blob = np.ascontiguousarray(np.frombuffer(bytes(blob), dtype=np.uint8) if not isinstance(blob, np.ndarray) else blob)
+        keep = []
+        def p(a, dt):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dtype=dt); keep.append(a)
+            return C.c_void_p(a.ctypes.data)
+        rej = C.c_uint64(0)
+        lib().emu_subscribe_bulk(self._h, blob.ctypes.data, offsets.ctypes.data, len(offsets) - 1, p(sub_ids, np.uint32),
+                                 p(qos, np.uint8), p(flags, np.uint8), C.byref(rej))
+        return int(rej.value)
+
+    def commit(self):
+        pass
+
+    def _match(self, blob, offsets):
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        blob = np.ascontiguousarray(np.frombuffer(bytes(blob), dtype=np.uint8) if not isinstance(blob, np.ndarray) else blob)
+        n = len(offsets) - 1
+        status = np.zeros(n, dtype=np.int32)
+        ho, tp, po, pf = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        nh = C.c_uint64(0)
+        rc = lib().emu_match(self._h, blob.ctypes.data if len(blob) else None, offsets.ctypes.data, n, status.ctypes.data,
+                             C.byref(ho), C.byref(tp), C.byref(nh), C.byref(po), C.byref(pf))
+        assert rc == 0, rc
+        hit_offsets = _take(ho, n + 1, np.uint64)
+        tuples = _take(tp, nh.value, TUPLE_DTYPE)
+        pair_offsets = _take(po, n + 1, np.uint64)
+        fids = _take(pf, int(pair_offsets[-1]), np.uint32)
+        return status, hit_offsets, tuples, pair_offsets, fids
+
+    def match_batch(self, blob, offsets):
+        s, ho, tp, _, _ = self._match(blob, offsets)
+        return dict(status=s, hit_offsets=ho, tuples=tp)
+
+    def match_filters(self, blob, offsets):
+        s, _, _, po, pf = self._match(blob, offsets)
+        return dict(status=s, pair_offsets=po, filter_ids=pf)
+
+    def counters(self):
+        return {k: int(getattr(lib(), "emu_" + k)(self._h)) for k in ("n_nodes", "n_filters", "n_subs", "visited", "overflow_topics", "windows")}
