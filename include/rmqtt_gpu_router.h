@@ -212,11 +212,17 @@ typedef struct rgr_retain_result {
     uint64_t n_hits;
     int32_t* status;            /* [n_filters]                                          */
     uint64_t* hit_offsets;      /* [n_filters+1]                                        */
-    uint32_t* topic_ids;        /* [n_hits] per filter ascending by topic_id            */
+    uint32_t* topic_ids;        /* [n_hits] per filter, deterministic (trie preorder); the
+                                   reference's own order is hash-map order: compare as sets */
     void* _owner;
 } rgr_retain_result;
 int32_t rgr_retain_match_batch(rgr_handle* h, const uint8_t* filters_blob, const uint64_t* filter_offsets, uint32_t n,
                                rgr_retain_result* out);
+/* Device-resident form: a batch of SUBSCRIBE filters; drive it with rgr_batch_begin /
+ * rgr_batch_next_window / rgr_batch_run exactly like a publish batch.  In its windows
+ * rgr_tuple.topic_idx is the filter index and rgr_tuple.sub_id the retained topic_id. */
+int32_t rgr_retain_batch_create(rgr_handle* h, const uint8_t* filters_blob, const uint64_t* filter_offsets, uint32_t n,
+                                rgr_batch** out);
 void rgr_retain_result_free(rgr_retain_result* r);
 
 /* ---- multi-GPU sharding rule (host-side helper, no device work) -------------------------

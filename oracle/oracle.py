@@ -198,7 +198,7 @@ class RetainTree:
         po, pv = C.c_void_p(), C.c_void_p()
         visited = C.c_uint64(0)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
-        tot = lib().orc_retain_match_batch(self._h, blob, offsets.ctypes.data, n, status.ctypes.data,
+        tot = lib().orc_retain_match_batch(self._h, _ptr(blob), offsets.ctypes.data, n, status.ctypes.data,
                                            C.byref(po), C.byref(pv), C.byref(visited))
         return status, _take_arr(po, n + 1, np.uint64), _take_arr(pv, tot, np.int64), int(visited.value)
 

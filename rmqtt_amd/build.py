@@ -19,8 +19,8 @@ GPU_LIB = os.path.join(HERE, "librmqtt_gpu_router.so")
 WL_LIB = os.path.join(HERE, "librmqtt_workload.so")
 HOST_LIB = os.path.join(HERE, "librmqtt_host_router.so")
 
-GPU_SRCS = ["c_abi.cpp", "table.cpp", "kernels.hip"]
-GPU_HDRS = ["table.hpp", "topic.hpp", "device.hpp", "kernels.hpp", "retain.hpp", "retain_abi.inc"]
+GPU_SRCS = ["c_abi.cpp", "table.cpp", "retain.cpp", "kernels.hip"]
+GPU_HDRS = ["table.hpp", "topic.hpp", "device.hpp", "kernels.hpp", "retain.hpp", "retain_abi.inc", "match_core.hpp"]
 
 
 def _stale(target, deps):

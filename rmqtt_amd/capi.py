@@ -27,7 +27,7 @@ SYMBOLS = [
     "rgr_batch_create", "rgr_batch_destroy", "rgr_batch_status", "rgr_batch_begin", "rgr_batch_next_window",
     "rgr_window_to_host", "rgr_batch_run",
     "rgr_retain_topic_add", "rgr_retain_topic_remove", "rgr_retain_add_bulk", "rgr_retain_commit",
-    "rgr_retain_match_batch", "rgr_retain_result_free",
+    "rgr_retain_match_batch", "rgr_retain_result_free", "rgr_retain_batch_create",
     "rgr_shard_assign", "rgr_stats_get", "rgr_stats_reset",
 ]
 
@@ -116,6 +116,7 @@ def lib():
         L.rgr_retain_commit.argtypes = [vp]
         L.rgr_retain_match_batch.argtypes = [vp, vp, vp, u32, C.POINTER(RetainResult)]
         L.rgr_retain_result_free.argtypes = [C.POINTER(RetainResult)]; L.rgr_retain_result_free.restype = None
+        L.rgr_retain_batch_create.argtypes = [vp, vp, vp, u32, C.POINTER(vp)]
         L.rgr_shard_assign.argtypes = [vp, vp, u64, u32, i32, vp]
         L.rgr_stats_get.argtypes = [vp, C.POINTER(Stats)]
         L.rgr_stats_reset.argtypes = [vp]
@@ -243,6 +244,9 @@ class Router:
     def batch(self, blob, offsets):
         return Batch(self, blob, offsets)
 
+    def retain_batch(self, blob, offsets):
+        return Batch(self, blob, offsets, retain=True)
+
     # ---- retain twin
     def retain_add(self, topic, topic_id):
         t = _b(topic)
@@ -290,13 +294,14 @@ class Router:
 class Batch:
     """Device-resident tokenised batch (rgr_batch_*)."""
 
-    def __init__(self, router, blob, offsets):
+    def __init__(self, router, blob, offsets, retain=False):
         self.router = router
         self.n = len(offsets) - 1
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         self._b = C.c_void_p()
         bp, bk = _blob_ptr(blob)
-        _check(lib().rgr_batch_create(router._h, bp, offsets.ctypes.data, self.n, C.byref(self._b)))
+        create = lib().rgr_retain_batch_create if retain else lib().rgr_batch_create
+        _check(create(router._h, bp, offsets.ctypes.data, self.n, C.byref(self._b)))
 
     def close(self):
         if self._b:

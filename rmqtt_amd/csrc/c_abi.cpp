@@ -55,6 +55,13 @@ struct Epoch {
     uint64_t id = 0, n_filters = 0, n_subs = 0, n_nodes = 0, edge_slots = 0, max_filter_subs = 0, bytes = 0;
 };
 
+struct RetainEpoch {
+    DevBuf edges, child_off, child_ids, desc, vals;
+    RetainView view{};
+    TrieView tv{};       // filt = run descriptors, subs = values: what count/compact/expand read
+    uint64_t id = 0, n_topics = 0, n_nodes = 0, bytes = 0;
+};
+
 enum SpanKind { kSpanWalk = 0, kSpanScan = 1, kSpanExpand = 2 };
 
 }  // namespace
@@ -68,7 +75,10 @@ struct rgr_handle {
     uint64_t epoch_counter = 0;
     std::mutex stats_mu;
     rgr_stats stats{};
-    RetainState retain;
+    // RetainTree twin
+    std::shared_mutex retain_mu;
+    RetainTable retain_table;
+    std::shared_ptr<RetainEpoch> retain_epoch;
 };
 
 struct rgr_batch {
@@ -84,7 +94,9 @@ struct rgr_batch {
     PinnedBuf h_hit_off, h_pair_base, h_scalars;
     uint64_t arena_cap = 0;
     // pass state
+    bool retain = false;             // batch of SUBSCRIBE filters against the retained-topic trie
     std::shared_ptr<Epoch> epoch;
+    std::shared_ptr<RetainEpoch> repoch;
     bool in_pass = false;
     uint32_t chunk_begin = 0, chunk_n = 0;
     bool chunk_ready = false;
@@ -149,6 +161,8 @@ void merge_stats(rgr_handle* h, rgr_stats& l) {
     l = rgr_stats{};
 }
 
+const TrieView& batch_view(const rgr_batch* b) { return b->retain ? b->repoch->tv : b->epoch->view; }
+
 void tokenize_batch(rgr_handle* h, rgr_batch* b, const uint8_t* blob, const uint64_t* offs, uint32_t n) {
     const double t0 = now_ms();
     unsigned nt = h->cfg.host_threads ? h->cfg.host_threads : std::max(1u, std::thread::hardware_concurrency());
@@ -156,15 +170,15 @@ void tokenize_batch(rgr_handle* h, rgr_batch* b, const uint8_t* blob, const uint
     struct Part { std::vector<uint32_t> toks; std::vector<uint32_t> lens; std::vector<uint8_t> flags; };
     std::vector<Part> parts(nt);
     {
-        std::shared_lock<std::shared_mutex> lk(h->table_mu);
+        std::shared_lock<std::shared_mutex> lk(b->retain ? h->retain_mu : h->table_mu);
         auto work = [&](unsigned k) {
             Part& p = parts[k];
             const uint64_t lo = uint64_t(n) * k / nt, hi = uint64_t(n) * (k + 1) / nt;
             p.lens.reserve(hi - lo); p.flags.reserve(hi - lo); p.toks.reserve((hi - lo) * 10);
             for (uint64_t i = lo; i < hi; ++i) {
                 const size_t mark = p.toks.size();
-                const uint8_t fl = h->table.tokenize_topic(
-                    std::string_view(reinterpret_cast<const char*>(blob) + offs[i], offs[i + 1] - offs[i]), p.toks);
+                const std::string_view sv(reinterpret_cast<const char*>(blob) + offs[i], offs[i + 1] - offs[i]);
+                const uint8_t fl = b->retain ? h->retain_table.tokenize_filter(sv, p.toks) : h->table.tokenize_topic(sv, p.toks);
                 p.flags.push_back(fl);
                 p.lens.push_back(uint32_t(p.toks.size() - mark));
             }
@@ -200,7 +214,7 @@ void tokenize_batch(rgr_handle* h, rgr_batch* b, const uint8_t* blob, const uint
     b->d_tokens.ensure(std::max<uint64_t>(1, total) * 4);
     b->d_tok_off.ensure((size_t(n) + 1) * 8);
     b->d_tflags.ensure(std::max<uint32_t>(1, n));
-    b->d_path.ensure(std::max<uint64_t>(1, total) * 4);
+    b->d_path.ensure(std::max<uint64_t>(1, total) * (b->retain ? 8 : 4));
     if (total) RGR_HIP(hipMemcpyAsync(b->d_tokens.p, toks.data(), total * 4, hipMemcpyHostToDevice, b->stream));
     RGR_HIP(hipMemcpyAsync(b->d_tok_off.p, toff.data(), (size_t(n) + 1) * 8, hipMemcpyHostToDevice, b->stream));
     if (n) RGR_HIP(hipMemcpyAsync(b->d_tflags.p, flags.data(), n, hipMemcpyHostToDevice, b->stream));
@@ -278,13 +292,18 @@ void prepare_chunk(rgr_batch* b, uint32_t begin, bool walk_only) {
     b->chunk_begin = begin;
     b->chunk_n = n;
     ensure_chunk_buffers(b, n);
-    const TrieView& tv = b->epoch->view;
+    const TrieView& tv = batch_view(b);
     for (;;) {
         RGR_HIP(hipMemsetAsync(b->scalars.p, 0, sizeof(Scalars), b->stream));
         WalkArgs wa = make_walk_args(b, n);
         size_t sp = b->span_begin(kSpanWalk);
-        launch_walk(tv, wa, false, b->stream);
-        launch_walk(tv, wa, true, b->stream);
+        if (b->retain) {
+            launch_retain_walk(b->repoch->view, wa, false, b->stream);
+            launch_retain_walk(b->repoch->view, wa, true, b->stream);
+        } else {
+            launch_walk(tv, wa, false, b->stream);
+            launch_walk(tv, wa, true, b->stream);
+        }
         b->span_end(sp);
         b->local.walk_launches++;
         RGR_HIP(hipGetLastError());
@@ -484,18 +503,23 @@ int32_t rgr_commit(rgr_handle* h) {
 }
 
 // ------------------------------------------------------------------ device-resident batches
-int32_t rgr_batch_create(rgr_handle* h, const uint8_t* blob, const uint64_t* offs, uint32_t n, rgr_batch** out) {
+static int32_t batch_create_impl(rgr_handle* h, const uint8_t* blob, const uint64_t* offs, uint32_t n, bool retain, rgr_batch** out) {
     return guarded([&]() -> int32_t {
         if (!h || !out || (n && (!blob || !offs))) return fail(RGR_EINVAL, "rgr_batch_create: bad argument");
         RGR_HIP(hipSetDevice(h->cfg.device));
         auto b = std::make_unique<rgr_batch>();
         b->h = h;
         b->n = n;
+        b->retain = retain;
         RGR_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
         tokenize_batch(h, b.get(), blob, offs, n);
         *out = b.release();
         return RGR_OK;
     });
+}
+
+int32_t rgr_batch_create(rgr_handle* h, const uint8_t* blob, const uint64_t* offs, uint32_t n, rgr_batch** out) {
+    return batch_create_impl(h, blob, offs, n, false, out);
 }
 
 void rgr_batch_destroy(rgr_batch* b) {
@@ -512,7 +536,13 @@ int32_t rgr_batch_begin(rgr_batch* b) {
     return guarded([&]() -> int32_t {
         if (!b) return fail(RGR_EINVAL, "rgr_batch_begin: bad argument");
         RGR_HIP(hipSetDevice(b->h->cfg.device));
-        b->epoch = current_epoch(b->h);
+        if (b->retain) {
+            std::lock_guard<std::mutex> g(b->h->epoch_mu);
+            b->repoch = b->h->retain_epoch;
+            if (!b->repoch) return fail(RGR_ESTATE, "rgr_batch_begin: rgr_retain_commit has not been called");
+        } else {
+            b->epoch = current_epoch(b->h);
+        }
         b->in_pass = true;
         b->cursor = 0;
         b->chunk_ready = false;
@@ -565,7 +595,7 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
             launch_tiles(ca, pair_lo, pair_hi, hit_lo, b->tile_first.as<uint32_t>(), b->stream);
             b->span_end(sp);
             sp = b->span_begin(kSpanExpand);
-            launch_expand(b->epoch->view, ca, pair_lo, pair_hi, hit_lo, hit_hi, b->tile_first.as<uint32_t>(), b->out.as<Tuple>(), b->stream);
+            launch_expand(batch_view(b), ca, pair_lo, pair_hi, hit_lo, hit_hi, b->tile_first.as<uint32_t>(), b->out.as<Tuple>(), b->stream);
             b->span_end(sp);
             b->local.expand_launches++;
         }

@@ -124,6 +124,63 @@ __global__ __launch_bounds__(kWalkThreads) void walk_kernel(TrieView tv, WalkArg
     }
 }
 
+// --------------------------------------------------------------------------- retain walk
+// RetainTree::matches: one lane per SUBSCRIBE filter walking the preorder-numbered trie of
+// retained topics (match_core.hpp: retain_walk_filter).  Emits run-descriptor indices into
+// the same slot / overflow structures as walk_kernel; the downstream count / scan / compact /
+// tiles / expand kernels are shared.  The '+' stack (cursor,end per level) lives in HBM
+// scratch shaped like the token array.
+template <bool OVF>
+__global__ __launch_bounds__(kWalkThreads) void retain_walk_kernel(RetainView rv, WalkArgs a) {
+    const uint32_t i = blockIdx.x * kWalkThreads + threadIdx.x;
+    uint32_t tl;
+    bool active;
+    if (OVF) { active = i < min(*a.ovf_count, a.n); tl = active ? a.ovf_list[i] : 0; }
+    else { tl = i; active = tl < a.n; }
+    uint32_t cnt = 0, visited = 0;
+    if (active) {
+        const uint32_t gt = a.topic_base + tl;
+        const uint64_t off0 = a.tok_off[gt];
+        const uint32_t L = uint32_t(a.tok_off[gt + 1] - off0);
+        const uint64_t arena_base = OVF ? a.ovf_base[tl] : 0;
+        if (!(a.tflags[gt] & kTopicInvalid)) {
+            const REdge* edges = rv.edges;
+            const uint32_t mask = rv.mask;
+            visited = retain_walk_filter(
+                rv, L, [&](uint32_t d) { return a.tokens[off0 + d]; },
+                [&](uint32_t d, uint32_t& cur, uint32_t& end) {
+                    const uint2 v = *reinterpret_cast<const uint2*>(a.path_scratch + 2 * (off0 + d));
+                    cur = v.x; end = v.y;
+                },
+                [&](uint32_t d, uint32_t cur, uint32_t end) { *reinterpret_cast<uint2*>(a.path_scratch + 2 * (off0 + d)) = make_uint2(cur, end); },
+                [&](uint32_t desc) {
+                    if (OVF) { if (arena_base + cnt < a.ovf_arena_cap) a.ovf_arena[arena_base + cnt] = desc; }
+                    else if (cnt < a.slot_cap) a.slots[uint64_t(cnt) * a.n + tl] = desc;
+                    cnt++;
+                },
+                [&](uint32_t parent, uint32_t token) -> uint32_t {
+                    for (uint32_t s = edge_hash(parent, token) & mask;; s = (s + 1) & mask) {
+                        const uint4 e = *reinterpret_cast<const uint4*>(edges + s);
+                        if (e.x == kEdgeEmpty) return kNone;
+                        if (e.x == parent && e.y == token) return e.z;
+                    }
+                });
+        }
+        if (!OVF) {
+            a.pair_cnt[tl] = cnt;
+            if (cnt > a.slot_cap) {
+                const uint32_t k = atomicAdd(a.ovf_count, 1u);
+                a.ovf_list[k] = tl;
+                a.ovf_base[tl] = atomicAdd(a.ovf_cursor, (unsigned long long)cnt);
+            }
+        }
+    }
+    if (a.visited && !OVF) {
+        const unsigned long long v = wave_sum(visited);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(a.visited, v);
+    }
+}
+
 // --------------------------------------------------------------------------- count
 __global__ __launch_bounds__(256) void count_kernel(TrieView tv, ChunkArrays c) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
@@ -262,6 +319,13 @@ void launch_walk(const TrieView& t, const WalkArgs& a, bool overflow_pass, void*
     // whole chunk and every block beyond *ovf_count exits at once.
     if (!overflow_pass) walk_kernel<false><<<(a.n + kWalkThreads - 1) / kWalkThreads, kWalkThreads, 0, s>>>(t, a);
     else walk_kernel<true><<<(a.n + kWalkThreads - 1) / kWalkThreads, kWalkThreads, 0, s>>>(t, a);
+}
+
+void launch_retain_walk(const RetainView& t, const WalkArgs& a, bool overflow_pass, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (a.n == 0) return;
+    if (!overflow_pass) retain_walk_kernel<false><<<(a.n + kWalkThreads - 1) / kWalkThreads, kWalkThreads, 0, s>>>(t, a);
+    else retain_walk_kernel<true><<<(a.n + kWalkThreads - 1) / kWalkThreads, kWalkThreads, 0, s>>>(t, a);
 }
 
 void launch_count(const TrieView& t, const ChunkArrays& c, void* stream) {

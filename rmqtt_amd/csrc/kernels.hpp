@@ -66,6 +66,23 @@ struct TrieView {
     const SubEntry* subs;
 };
 
+// ---- RetainTree twin (rmqtt/src/retain.rs): trie of concrete retained topics, nodes numbered
+// in DFS preorder so that "every valued node in the subtree of p" is ONE contiguous run of
+// vals[]; '+' enumerates a node's children through a CSR child list.
+struct alignas(16) REdge { uint32_t parent, token, child, pad; };   // open-addressed (parent,token)->child
+struct RetainView {
+    const REdge* edges;
+    uint32_t mask;
+    const uint32_t* child_off;   // [N+1] CSR into child_ids (children in preorder order)
+    const uint32_t* child_ids;
+    uint32_t root_nonmeta;       // root's children that are not '$'-metadata come first
+    uint32_t n_nodes;
+    // run descriptors (FilterDesc) the downstream kernels expand: index 2p = p's own value,
+    // 2p+1 = every value in subtree(p) (p included), 2N = every value outside '$' subtrees
+    const FilterDesc* desc;
+    const SubEntry* vals;        // {topic_id, 0} of valued nodes in preorder
+};
+
 struct WalkArgs {
     const uint32_t* tokens;      // CSR token ids of the batch
     const uint64_t* tok_off;     // [n_batch+1]
@@ -106,6 +123,7 @@ struct ChunkArrays {
 };
 
 void launch_walk(const TrieView& t, const WalkArgs& a, bool overflow_pass, void* stream);
+void launch_retain_walk(const RetainView& t, const WalkArgs& a, bool overflow_pass, void* stream);
 void launch_count(const TrieView& t, const ChunkArrays& c, void* stream);
 void launch_scan(const ChunkArrays& c, uint64_t* block_tmp, void* stream);
 void launch_compact(const TrieView& t, const ChunkArrays& c, uint32_t topic_base, void* stream);

@@ -1,0 +1,213 @@
+// RetainTree twin — host table + snapshot compiler (see retain.hpp).
+#include "retain.hpp"
+
+#include <algorithm>
+
+#include "rmqtt_gpu_router.h"
+#include "topic.hpp"
+
+namespace rgr {
+
+static REdge empty_redge() { return REdge{kEdgeEmpty, 0, kNone, 0}; }
+
+RetainTable::RetainTable() {
+    nodes_.push_back(Node{kNone, 0, kNone, 0, kNone, false});
+    edges_.assign(1024, empty_redge());
+}
+
+uint32_t RetainTable::find(uint32_t parent, uint32_t token) const {
+    const uint32_t mask = uint32_t(edges_.size() - 1);
+    for (uint32_t i = edge_hash(parent, token) & mask;; i = (i + 1) & mask) {
+        const REdge& e = edges_[i];
+        if (e.parent == kEdgeEmpty) return kNone;
+        if (e.parent == parent && e.token == token) return i;
+    }
+}
+
+void RetainTable::rehash(uint64_t cap) {
+    std::vector<REdge> old;
+    old.swap(edges_);
+    edges_.assign(cap, empty_redge());
+    const uint32_t mask = uint32_t(cap - 1);
+    for (const REdge& e : old) {
+        if (e.parent == kEdgeEmpty || e.parent == kEdgeTomb) continue;
+        uint32_t i = edge_hash(e.parent, e.token) & mask;
+        while (edges_[i].parent != kEdgeEmpty) i = (i + 1) & mask;
+        edges_[i] = e;
+        nodes_[e.child].slot = i;
+    }
+    edge_used_ = edge_live_;
+}
+
+uint32_t RetainTable::insert_edge(uint32_t parent, uint32_t token, uint32_t child) {
+    if ((edge_used_ + 1) * 2 > edges_.size()) rehash(edge_live_ * 4 > edges_.size() ? edges_.size() * 2 : edges_.size());
+    const uint32_t mask = uint32_t(edges_.size() - 1);
+    uint32_t i = edge_hash(parent, token) & mask;
+    while (edges_[i].parent != kEdgeEmpty && edges_[i].parent != kEdgeTomb) i = (i + 1) & mask;
+    if (edges_[i].parent == kEdgeEmpty) edge_used_++;
+    edges_[i] = REdge{parent, token, child, 0};
+    edge_live_++;
+    return i;
+}
+
+bool RetainTable::tokenize(std::string_view s, std::vector<uint32_t>& toks, bool intern, bool* first_meta) {
+    toks.clear();
+    if (for_each_level(s, [](int64_t, std::string_view, LevelKind) {}) < 0) return false;
+    for_each_level(s, [&](int64_t idx, std::string_view seg, LevelKind k) {
+        if (idx == 0 && first_meta) *first_meta = k == LevelKind::Metadata;
+        if (k == LevelKind::Plus) toks.push_back(kTokPlus);
+        else if (k == LevelKind::Hash) toks.push_back(kTokHash);
+        else toks.push_back(intern ? dict_.intern(seg) : dict_.find(seg));
+    });
+    return true;
+}
+
+uint8_t RetainTable::tokenize_filter(std::string_view f, std::vector<uint32_t>& toks) const {
+    const size_t mark = toks.size();
+    int64_t n = for_each_level(f, [&](int64_t, std::string_view seg, LevelKind k) {
+        if (k == LevelKind::Plus) toks.push_back(kTokPlus);
+        else if (k == LevelKind::Hash) toks.push_back(kTokHash);
+        else toks.push_back(dict_.find(seg));
+    });
+    if (n < 0) { toks.resize(mark); return kTopicInvalid; }
+    return 0;
+}
+
+int32_t RetainTable::topic_add(std::string_view topic, uint32_t topic_id) {
+    std::vector<uint32_t> toks;
+    bool meta = false;
+    if (!tokenize(topic, toks, true, &meta)) return RGR_EINVAL_TOPIC;
+    uint32_t cur = 0;
+    for (size_t l = 0; l < toks.size(); ++l) {
+        const uint32_t s = find(cur, toks[l]);
+        if (s != kNone) { cur = edges_[s].child; continue; }
+        uint32_t id;
+        if (!free_nodes_.empty()) { id = free_nodes_.back(); free_nodes_.pop_back(); }
+        else { id = uint32_t(nodes_.size()); nodes_.push_back(Node{}); }
+        nodes_[id] = Node{cur, toks[l], kNone, 0, kNone, l == 0 && meta};
+        const uint32_t slot = insert_edge(cur, toks[l], id);
+        nodes_[id].slot = slot;
+        nodes_[cur].nchild++;
+        n_nodes_++;
+        cur = id;
+    }
+    if (nodes_[cur].value == kNone) n_values_++;
+    nodes_[cur].value = topic_id;                    // value.replace(), retain.rs:384
+    return RGR_OK;
+}
+
+int32_t RetainTable::topic_remove(std::string_view topic) {
+    std::vector<uint32_t> toks;
+    if (!tokenize(topic, toks, false, nullptr)) return RGR_EINVAL_TOPIC;
+    uint32_t cur = 0;
+    for (uint32_t t : toks) {
+        if (t == kTokUnknown) return RGR_ENOENT;
+        const uint32_t s = find(cur, t);
+        if (s == kNone) return RGR_ENOENT;
+        cur = edges_[s].child;
+    }
+    if (nodes_[cur].value == kNone) return RGR_ENOENT;
+    nodes_[cur].value = kNone;
+    n_values_--;
+    while (cur != 0 && nodes_[cur].value == kNone && nodes_[cur].nchild == 0) {   // retain.rs:405-407
+        const uint32_t p = nodes_[cur].parent;
+        edges_[nodes_[cur].slot].parent = kEdgeTomb;
+        edge_live_--;
+        nodes_[p].nchild--;
+        free_nodes_.push_back(cur);
+        n_nodes_--;
+        cur = p;
+    }
+    return RGR_OK;
+}
+
+void RetainTable::compile(RetainImage& out) const {
+    const uint32_t total = uint32_t(nodes_.size());
+    // children lists of the mutable ids (counting sort by parent), ordered by token; the
+    // root's non-'$' children first (retain.rs:486-490, 505-509 skip '$' children at the root)
+    std::vector<uint32_t> cnt(size_t(total) + 1, 0), kids;
+    for (const REdge& e : edges_)
+        if (e.parent != kEdgeEmpty && e.parent != kEdgeTomb) cnt[e.parent + 1]++;
+    for (uint32_t i = 0; i < total; ++i) cnt[i + 1] += cnt[i];
+    kids.resize(cnt[total]);
+    {
+        std::vector<uint32_t> pos(cnt.begin(), cnt.end() - 1);
+        for (const REdge& e : edges_)
+            if (e.parent != kEdgeEmpty && e.parent != kEdgeTomb) kids[pos[e.parent]++] = e.child;
+    }
+    for (uint32_t p = 0; p < total; ++p) {
+        auto b = kids.begin() + cnt[p], e = kids.begin() + cnt[p + 1];
+        if (e - b < 2) continue;
+        if (p == 0)
+            std::sort(b, e, [&](uint32_t x, uint32_t y) {
+                if (nodes_[x].meta != nodes_[y].meta) return !nodes_[x].meta;
+                return nodes_[x].token < nodes_[y].token;
+            });
+        else
+            std::sort(b, e, [&](uint32_t x, uint32_t y) { return nodes_[x].token < nodes_[y].token; });
+    }
+    // iterative DFS: preorder ids + subtree ends
+    const uint32_t N = uint32_t(n_nodes_);
+    std::vector<uint32_t> pre(total, kNone), order;   // order[preorder id] = mutable id
+    order.reserve(N);
+    std::vector<uint32_t> sub_end(N, 0);
+    {
+        std::vector<std::pair<uint32_t, uint32_t>> st;   // (node, next child index)
+        pre[0] = 0;
+        order.push_back(0);
+        st.emplace_back(0u, cnt[0]);
+        while (!st.empty()) {
+            auto& top = st.back();
+            if (top.second < cnt[top.first + 1]) {
+                const uint32_t c = kids[top.second++];
+                pre[c] = uint32_t(order.size());
+                order.push_back(c);
+                st.emplace_back(c, cnt[c]);
+            } else {
+                sub_end[pre[top.first]] = uint32_t(order.size());
+                st.pop_back();
+            }
+        }
+    }
+    out.n_nodes = N;
+    out.child_off.assign(size_t(N) + 1, 0);
+    out.child_ids.clear();
+    out.child_ids.reserve(N);
+    out.vals.clear();
+    std::vector<uint32_t> val_rank(size_t(N) + 1, 0);
+    for (uint32_t p = 0; p < N; ++p) {
+        const uint32_t m = order[p];
+        out.child_off[p] = uint32_t(out.child_ids.size());
+        for (uint32_t k = cnt[m]; k < cnt[m + 1]; ++k) out.child_ids.push_back(pre[kids[k]]);
+        val_rank[p] = uint32_t(out.vals.size());
+        if (nodes_[m].value != kNone) out.vals.push_back(SubEntry{nodes_[m].value, 0});
+    }
+    out.child_off[N] = uint32_t(out.child_ids.size());
+    val_rank[N] = uint32_t(out.vals.size());
+    out.root_nonmeta = 0;
+    for (uint32_t k = cnt[0]; k < cnt[1]; ++k) out.root_nonmeta += !nodes_[kids[k]].meta;
+    out.desc.assign(2 * size_t(N) + 1, FilterDesc{0, 0});
+    for (uint32_t p = 0; p < N; ++p) {
+        const bool has = nodes_[order[p]].value != kNone;
+        out.desc[2 * size_t(p)] = FilterDesc{val_rank[p], has ? 1u : 0u};
+        out.desc[2 * size_t(p) + 1] = FilterDesc{val_rank[p], val_rank[sub_end[p]] - val_rank[p]};
+    }
+    // everything outside the root's '$' subtrees: the non-meta children come first in preorder
+    uint32_t first_meta_pre = N;
+    if (out.root_nonmeta < cnt[1] - cnt[0]) first_meta_pre = pre[kids[cnt[0] + out.root_nonmeta]];
+    out.desc[2 * size_t(N)] = FilterDesc{0, val_rank[first_meta_pre]};
+    // edge table over preorder ids
+    uint64_t cap = 1024;
+    while (cap < uint64_t(N) * 2) cap <<= 1;
+    out.edges.assign(cap, empty_redge());
+    const uint32_t mask = uint32_t(cap - 1);
+    for (const REdge& e : edges_) {
+        if (e.parent == kEdgeEmpty || e.parent == kEdgeTomb) continue;
+        const uint32_t pp = pre[e.parent], pc = pre[e.child];
+        uint32_t i = edge_hash(pp, e.token) & mask;
+        while (out.edges[i].parent != kEdgeEmpty) i = (i + 1) & mask;
+        out.edges[i] = REdge{pp, e.token, pc, 0};
+    }
+}
+
+}  // namespace rgr

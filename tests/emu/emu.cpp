@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "match_core.hpp"
+#include "retain.hpp"
 #include "rmqtt_gpu_router.h"
 #include "table.hpp"
 
@@ -21,6 +22,7 @@ using namespace rgr;
 namespace {
 struct Emu {
     HostTable table;
+    RetainTable retain;
     uint32_t slot_cap = 32, chunk_topics = 1u << 21, lds_window = 2560, tile = 2048;
     uint64_t window_hits = 1ull << 28;
     uint64_t visited = 0, overflow_topics = 0, windows = 0, pairs = 0;
@@ -71,67 +73,41 @@ int32_t emu_subscribe_bulk(void* ev, const uint8_t* blob, const uint64_t* offs, 
     return RGR_OK;
 }
 
-// Same outputs as rgr_match_batch (+ the matched filter ids per topic).  Arrays malloc'ed.
-int32_t emu_match(void* ev, const uint8_t* blob, const uint64_t* offs, uint32_t n, int32_t* status, uint64_t** hit_offsets_out,
-                  rgr_tuple** tuples_out, uint64_t* n_hits_out, uint64_t** pair_offsets_out, uint32_t** pair_fids_out) {
-    auto* e = static_cast<Emu*>(ev);
-    const HostTable& tb = e->table;
-    // ---- tokenise
-    std::vector<uint32_t> tokens;
-    std::vector<uint64_t> tok_off(size_t(n) + 1, 0);
-    std::vector<uint8_t> tflags(n);
-    for (uint32_t i = 0; i < n; ++i) {
-        tflags[i] = tb.tokenize_topic(std::string_view(reinterpret_cast<const char*>(blob) + offs[i], offs[i + 1] - offs[i]), tokens);
-        tok_off[i + 1] = tokens.size();
-        status[i] = (tflags[i] & kTopicInvalid) ? RGR_TOPIC_INVALID : RGR_TOPIC_OK;
-    }
-    tokens.push_back(0);
-    std::vector<uint32_t> path_scratch(tokens.size(), 0xDEADBEEF);
-    // ---- epoch view over host memory
-    std::vector<FilterDesc> filt;
-    std::vector<SubEntry> subs;
-    tb.flatten_filters(filt, subs);
-    filt.push_back(FilterDesc{0, 0}); subs.push_back(SubEntry{0, 0});
-    TrieView tv{tb.edges().data(), uint32_t(tb.edges().size() - 1), tb.root_header(), filt.data(), subs.data()};
+}  // extern "C" (helpers below are C++)
 
+namespace {
+// The chunk / overflow / window / tile orchestration of c_abi.cpp, sequential on the host.
+// walk_one(gt, ovf_pass, staged_words, rel, s_path, emit) runs the per-lane walk of topic gt.
+template <class WalkOne>
+int32_t run_pipeline(Emu* e, uint32_t n, const std::vector<uint64_t>& tok_off, const std::vector<uint8_t>& tflags, const TrieView& tv,
+                     WalkOne walk_one, uint64_t** hit_offsets_out, rgr_tuple** tuples_out, uint64_t* n_hits_out,
+                     uint64_t** pair_offsets_out, uint32_t** pair_fids_out) {
     std::vector<uint64_t> hit_offsets(size_t(n) + 1, 0), pair_offsets(size_t(n) + 1, 0);
     std::vector<rgr_tuple> tuples;
     std::vector<uint32_t> pair_fids;
     const uint32_t C = e->slot_cap;
-
     for (uint32_t begin = 0; begin < n; begin += e->chunk_topics) {
         const uint32_t cn = std::min<uint32_t>(e->chunk_topics, n - begin);
         std::vector<uint32_t> slots(size_t(C) * cn, 0xDEADBEEF), pair_cnt(cn, 0), hit_cnt(cn), pair_live(cn), ovf_list;
         std::vector<uint64_t> hit_off(size_t(cn) + 1), pair_base(size_t(cn) + 1), ovf_base(cn, 0);
         std::vector<uint32_t> arena;
         uint64_t ovf_cursor = 0;
-        // ---- walk (main pass): blocks of 256 topics share one LDS window
         std::vector<uint32_t> s_path(std::max<uint32_t>(1, e->lds_window));
         auto walk = [&](uint32_t tl, bool ovf_pass) {
             const uint32_t gt = begin + tl;
-            const uint64_t off0 = tok_off[gt];
-            const uint32_t L = uint32_t(tok_off[gt + 1] - off0);
             const uint32_t t0 = tl / 256 * 256;
             const uint64_t win_base = tok_off[begin + t0];
             const uint64_t span = tok_off[begin + std::min(t0 + 256, cn)] - win_base;
             const uint64_t staged = ovf_pass ? 0 : std::min<uint64_t>(span, e->lds_window);
-            const uint64_t rel = off0 - win_base;
+            const uint64_t rel = tok_off[gt] - win_base;
             uint32_t cnt = 0;
             if (tflags[gt] & kTopicInvalid) { if (!ovf_pass) pair_cnt[tl] = 0; return; }
-            auto tok_at = [&](uint32_t d) { return tokens[off0 + d]; };
-            auto path_get = [&](uint32_t d) { return rel + d < staged ? s_path[rel + d] : path_scratch[off0 + d]; };
-            auto path_set = [&](uint32_t d, uint32_t v) { if (rel + d < staged) s_path[rel + d] = v; else path_scratch[off0 + d] = v; };
             auto emit = [&](uint32_t fid) {
                 if (ovf_pass) arena[ovf_base[tl] + cnt] = fid;
                 else if (cnt < C) slots[size_t(cnt) * cn + tl] = fid;
                 cnt++;
             };
-            const uint32_t v = walk_topic(tv.root, tv.mask, L, (tflags[gt] & kTopicMeta) != 0, tok_at, path_get, path_set, emit,
-                                          [&](uint32_t slot, U4& e0, U4& e1) {
-                                              const EdgeEntry& en = tv.edges[slot];
-                                              e0 = U4{en.parent, en.token, en.child, en.plus_slot};
-                                              e1 = U4{en.hash_fid, en.term_fid, en.pad0, en.pad1};
-                                          });
+            const uint32_t v = walk_one(gt, staged, rel, s_path, emit);
             if (!ovf_pass) {
                 e->visited += v;
                 pair_cnt[tl] = cnt;
@@ -142,7 +118,6 @@ int32_t emu_match(void* ev, const uint8_t* blob, const uint64_t* offs, uint32_t 
         arena.assign(ovf_cursor + 1, 0xDEADBEEF);
         for (uint32_t tl : ovf_list) walk(tl, true);
         e->overflow_topics += ovf_list.size();
-        // ---- count / scan / compact
         uint32_t err = 0;
         ChunkArrays ca{};
         ca.n = cn; ca.slot_cap = C; ca.slots = slots.data(); ca.pair_cnt = pair_cnt.data(); ca.hit_cnt = hit_cnt.data();
@@ -158,12 +133,10 @@ int32_t emu_match(void* ev, const uint8_t* blob, const uint64_t* offs, uint32_t 
         ca.pair_src = pair_src.data(); ca.pair_topic = pair_topic.data(); ca.pair_off = pair_off.data();
         for (uint32_t t = 0; t < cn; ++t) compact_topic(tv, ca, begin, t);
         e->pairs += P;
-        // matched-filter view
         for (uint32_t t = 0; t < cn; ++t) {
             for (uint32_t j = 0; j < pair_cnt[t]; ++j) pair_fids.push_back(pair_fid(ca, t, pair_cnt[t], j));
             pair_offsets[begin + t + 1] = pair_fids.size();
         }
-        // ---- windows: tiles + expand
         const size_t out_base = tuples.size();
         tuples.resize(out_base + H);
         uint32_t lc = 0;
@@ -211,6 +184,99 @@ int32_t emu_match(void* ev, const uint8_t* blob, const uint64_t* offs, uint32_t 
     if (pair_offsets_out) *pair_offsets_out = dup(pair_offsets);
     if (pair_fids_out) *pair_fids_out = dup(pair_fids);
     return RGR_OK;
+}
+}  // namespace
+
+extern "C" {
+
+// Same outputs as rgr_match_batch (+ the matched filter ids per topic).  Arrays malloc'ed.
+int32_t emu_match(void* ev, const uint8_t* blob, const uint64_t* offs, uint32_t n, int32_t* status, uint64_t** hit_offsets_out,
+                  rgr_tuple** tuples_out, uint64_t* n_hits_out, uint64_t** pair_offsets_out, uint32_t** pair_fids_out) {
+    auto* e = static_cast<Emu*>(ev);
+    const HostTable& tb = e->table;
+    std::vector<uint32_t> tokens;
+    std::vector<uint64_t> tok_off(size_t(n) + 1, 0);
+    std::vector<uint8_t> tflags(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        tflags[i] = tb.tokenize_topic(std::string_view(reinterpret_cast<const char*>(blob) + offs[i], offs[i + 1] - offs[i]), tokens);
+        tok_off[i + 1] = tokens.size();
+        status[i] = (tflags[i] & kTopicInvalid) ? RGR_TOPIC_INVALID : RGR_TOPIC_OK;
+    }
+    tokens.push_back(0);
+    std::vector<uint32_t> path_scratch(tokens.size(), 0xDEADBEEF);
+    std::vector<FilterDesc> filt;
+    std::vector<SubEntry> subs;
+    tb.flatten_filters(filt, subs);
+    filt.push_back(FilterDesc{0, 0}); subs.push_back(SubEntry{0, 0});
+    TrieView tv{tb.edges().data(), uint32_t(tb.edges().size() - 1), tb.root_header(), filt.data(), subs.data()};
+    auto walk_one = [&](uint32_t gt, uint64_t staged, uint64_t rel, std::vector<uint32_t>& s_path, auto& emit) {
+        const uint64_t off0 = tok_off[gt];
+        const uint32_t L = uint32_t(tok_off[gt + 1] - off0);
+        return walk_topic(
+            tv.root, tv.mask, L, (tflags[gt] & kTopicMeta) != 0, [&](uint32_t d) { return tokens[off0 + d]; },
+            [&](uint32_t d) { return rel + d < staged ? s_path[rel + d] : path_scratch[off0 + d]; },
+            [&](uint32_t d, uint32_t v) { if (rel + d < staged) s_path[rel + d] = v; else path_scratch[off0 + d] = v; }, emit,
+            [&](uint32_t slot, U4& e0, U4& e1) {
+                const EdgeEntry& en = tv.edges[slot];
+                e0 = U4{en.parent, en.token, en.child, en.plus_slot};
+                e1 = U4{en.hash_fid, en.term_fid, en.pad0, en.pad1};
+            });
+    };
+    return run_pipeline(e, n, tok_off, tflags, tv, walk_one, hit_offsets_out, tuples_out, n_hits_out, pair_offsets_out, pair_fids_out);
+}
+
+// ---- RetainTree twin -----------------------------------------------------------------
+int32_t emu_retain_add(void* e, const char* t, uint32_t len, uint32_t id) { return static_cast<Emu*>(e)->retain.topic_add(std::string_view(t, len), id); }
+int32_t emu_retain_remove(void* e, const char* t, uint32_t len) { return static_cast<Emu*>(e)->retain.topic_remove(std::string_view(t, len)); }
+uint64_t emu_retain_topics(void* e) { return static_cast<Emu*>(e)->retain.n_topics(); }
+uint64_t emu_retain_nodes(void* e) { return static_cast<Emu*>(e)->retain.n_nodes(); }
+int32_t emu_retain_add_bulk(void* ev, const uint8_t* blob, const uint64_t* offs, uint64_t n, const uint32_t* ids, uint64_t* rejected) {
+    auto* e = static_cast<Emu*>(ev);
+    uint64_t rej = 0;
+    for (uint64_t i = 0; i < n; ++i)
+        if (e->retain.topic_add(std::string_view(reinterpret_cast<const char*>(blob) + offs[i], offs[i + 1] - offs[i]), ids ? ids[i] : uint32_t(i)) != RGR_OK) rej++;
+    if (rejected) *rejected = rej;
+    return RGR_OK;
+}
+
+// Same outputs as rgr_retain_match_batch, as tuples (topic_idx = filter index, sub_id = topic id).
+int32_t emu_retain_match(void* ev, const uint8_t* blob, const uint64_t* offs, uint32_t n, int32_t* status, uint64_t** hit_offsets_out,
+                         rgr_tuple** tuples_out, uint64_t* n_hits_out) {
+    auto* e = static_cast<Emu*>(ev);
+    std::vector<uint32_t> tokens;
+    std::vector<uint64_t> tok_off(size_t(n) + 1, 0);
+    std::vector<uint8_t> tflags(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        tflags[i] = e->retain.tokenize_filter(std::string_view(reinterpret_cast<const char*>(blob) + offs[i], offs[i + 1] - offs[i]), tokens);
+        tok_off[i + 1] = tokens.size();
+        status[i] = (tflags[i] & kTopicInvalid) ? RGR_TOPIC_INVALID : RGR_TOPIC_OK;
+    }
+    tokens.push_back(0);
+    std::vector<uint32_t> stack(2 * tokens.size(), 0xDEADBEEF);
+    RetainImage img;
+    e->retain.compile(img);
+    img.vals.push_back(SubEntry{0, 0});
+    img.child_ids.push_back(0);
+    RetainView rv{img.edges.data(), uint32_t(img.edges.size() - 1), img.child_off.data(), img.child_ids.data(), img.root_nonmeta,
+                  img.n_nodes, img.desc.data(), img.vals.data()};
+    TrieView tv{};
+    tv.filt = rv.desc; tv.subs = rv.vals;
+    auto walk_one = [&](uint32_t gt, uint64_t, uint64_t, std::vector<uint32_t>&, auto& emit) {
+        const uint64_t off0 = tok_off[gt];
+        const uint32_t L = uint32_t(tok_off[gt + 1] - off0);
+        return retain_walk_filter(
+            rv, L, [&](uint32_t d) { return tokens[off0 + d]; },
+            [&](uint32_t d, uint32_t& cur, uint32_t& end) { cur = stack[2 * (off0 + d)]; end = stack[2 * (off0 + d) + 1]; },
+            [&](uint32_t d, uint32_t cur, uint32_t end) { stack[2 * (off0 + d)] = cur; stack[2 * (off0 + d) + 1] = end; }, emit,
+            [&](uint32_t parent, uint32_t token) -> uint32_t {
+                for (uint32_t s = edge_hash(parent, token) & rv.mask;; s = (s + 1) & rv.mask) {
+                    const REdge& en = rv.edges[s];
+                    if (en.parent == kEdgeEmpty) return kNone;
+                    if (en.parent == parent && en.token == token) return en.child;
+                }
+            });
+    };
+    return run_pipeline(e, n, tok_off, tflags, tv, walk_one, hit_offsets_out, tuples_out, n_hits_out, nullptr, nullptr);
 }
 
 }  // extern "C"

@@ -17,10 +17,10 @@ def build():
     so = os.path.join(HERE, "libemu.so")
     csrc = os.path.join(ROOT, "rmqtt_amd", "csrc")
     deps = [os.path.join(HERE, "emu.cpp")] + [os.path.join(csrc, f) for f in
-                                               ("table.cpp", "table.hpp", "match_core.hpp", "kernels.hpp", "topic.hpp")]
+                                               ("table.cpp", "table.hpp", "retain.cpp", "retain.hpp", "match_core.hpp", "kernels.hpp", "topic.hpp")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"), "-I", csrc,
-                               os.path.join(HERE, "emu.cpp"), os.path.join(csrc, "table.cpp"), "-o", so])
+                               os.path.join(HERE, "emu.cpp"), os.path.join(csrc, "table.cpp"), os.path.join(csrc, "retain.cpp"), "-o", so])
     return so
 
 
@@ -40,6 +40,12 @@ def lib():
             getattr(L, f).argtypes = [vp]; getattr(L, f).restype = u64
         L.emu_subscribe_bulk.argtypes = [vp, vp, vp, u64, vp, vp, vp, C.POINTER(u64)]
         L.emu_match.argtypes = [vp, vp, vp, u32, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), C.POINTER(vp), C.POINTER(vp)]
+        L.emu_retain_add.argtypes = [vp, C.c_char_p, u32, u32]
+        L.emu_retain_remove.argtypes = [vp, C.c_char_p, u32]
+        L.emu_retain_topics.argtypes = [vp]; L.emu_retain_topics.restype = u64
+        L.emu_retain_nodes.argtypes = [vp]; L.emu_retain_nodes.restype = u64
+        L.emu_retain_add_bulk.argtypes = [vp, vp, vp, u64, vp, C.POINTER(u64)]
+        L.emu_retain_match.argtypes = [vp, vp, vp, u32, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
         _LIB = L
     return _LIB
 
@@ -127,6 +133,39 @@ class EmuRouter:
     def match_filters(self, blob, offsets):
         s, _, _, po, pf = self._match(blob, offsets)
         return dict(status=s, pair_offsets=po, filter_ids=pf)
+
+    # ---- retain twin (same surface as capi.Router)
+    def retain_add(self, topic, topic_id):
+        t = _b(topic); return lib().emu_retain_add(self._h, t, len(t), topic_id)
+
+    def retain_remove(self, topic):
+        t = _b(topic); return lib().emu_retain_remove(self._h, t, len(t))
+
+    def retain_add_bulk(self, blob, offsets, topic_ids=None):
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        blob = np.ascontiguousarray(np.frombuffer(bytes(blob), dtype=np.uint8) if not isinstance(blob, np.ndarray) else blob)
+        ids = None if topic_ids is None else np.ascontiguousarray(topic_ids, dtype=np.uint32)
+        rej = C.c_uint64(0)
+        lib().emu_retain_add_bulk(self._h, blob.ctypes.data, offsets.ctypes.data, len(offsets) - 1,
+                                  None if ids is None else C.c_void_p(ids.ctypes.data), C.byref(rej))
+        return int(rej.value)
+
+    def retain_commit(self):
+        pass
+
+    def retain_match_batch(self, blob, offsets):
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        blob = np.ascontiguousarray(np.frombuffer(bytes(blob), dtype=np.uint8) if not isinstance(blob, np.ndarray) else blob)
+        n = len(offsets) - 1
+        status = np.zeros(n, dtype=np.int32)
+        ho, tp = C.c_void_p(), C.c_void_p()
+        nh = C.c_uint64(0)
+        rc = lib().emu_retain_match(self._h, blob.ctypes.data if len(blob) else None, offsets.ctypes.data, n, status.ctypes.data,
+                                    C.byref(ho), C.byref(tp), C.byref(nh))
+        assert rc == 0, rc
+        hit_offsets = _take(ho, n + 1, np.uint64)
+        tuples = _take(tp, nh.value, TUPLE_DTYPE)
+        return dict(status=status, hit_offsets=hit_offsets, topic_ids=tuples["sub_id"].copy(), filter_idx=tuples["topic_idx"].copy())
 
     def counters(self):
         return {k: int(getattr(lib(), "emu_" + k)(self._h)) for k in ("n_nodes", "n_filters", "n_subs", "visited", "overflow_topics", "windows")}

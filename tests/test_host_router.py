@@ -1,0 +1,130 @@
+"""The C++ mirror of the reference's Router trait (rmqtt_amd/host/gpu_router.*), driven
+through its ctypes shim, against the oracle's DefaultRouter: full SubRelationsMap semantics
+(No-Local, v3 one-row-per-filter, v5 first-filter + sub-id accumulation, remove rules,
+get/unique, counters).  These read like the reference's own router behaviour because the
+method names and error behaviour are the trait's (rmqtt/src/router.rs:65-112)."""
+import ctypes as C
+import random
+import re
+
+import pytest
+
+from oracle import oracle as orc
+from rmqtt_amd import build
+
+pytestmark = pytest.mark.gpu
+
+
+class HrId(C.Structure):
+    _fields_ = [("node_id", C.c_uint64), ("client_id", C.c_char_p), ("client_len", C.c_uint32), ("create_time", C.c_int64),
+                ("lid", C.c_uint16)]
+
+
+class HrOpts(C.Structure):
+    _fields_ = [("v5", C.c_uint8), ("qos", C.c_uint8), ("no_local", C.c_uint8), ("rap", C.c_uint8), ("rh", C.c_uint8),
+                ("sub_ident", C.c_uint32)]
+
+
+@pytest.fixture(scope="module")
+def hr():
+    build.build_gpu()
+    L = C.CDLL(build.build_host_router())
+    vp = C.c_void_p
+    L.hr_new.restype = vp; L.hr_new.argtypes = [C.c_uint64, C.c_int]
+    L.hr_free.argtypes = [vp]; L.hr_free_str.argtypes = [vp]
+    L.hr_add.argtypes = [vp, C.c_char_p, C.c_uint32, C.POINTER(HrId), C.POINTER(HrOpts)]
+    L.hr_remove.argtypes = [vp, C.c_char_p, C.c_uint32, C.POINTER(HrId)]
+    L.hr_matches.argtypes = [vp, C.POINTER(HrId), C.c_char_p, C.c_uint32]; L.hr_matches.restype = vp
+    L.hr_get.argtypes = [vp, C.c_char_p, C.c_uint32]; L.hr_get.restype = vp
+    for f in ("hr_topics", "hr_routes"):
+        getattr(L, f).argtypes = [vp]; getattr(L, f).restype = C.c_int64
+    L.hr_topics_tree.argtypes = [vp]; L.hr_topics_tree.restype = C.c_uint64
+    return L
+
+
+def _id(node, client, ct=0):
+    c = client.encode()
+    return HrId(node, c, len(c), ct, 0), orc.mk_id(node, client, ct)
+
+
+def _take(L, p):
+    if not p:
+        return None
+    s = C.string_at(p).decode()
+    L.hr_free_str(p)
+    return s
+
+
+def _strip_rel(s):   # oracle v3 rows carry a test-only rel_id column
+    return None if s is None else re.sub(r"^(3 [^\n]*)\t\d+$", r"\1", s, flags=re.M)
+
+
+def test_router_mirror_matches_oracle(hr):
+    g = hr.hr_new(1, 0)
+    assert g
+    o = orc.DefaultRouter()
+    rng = random.Random(7)
+    levels = ["a", "b", "c", "", "$SYS"]
+
+    def rand_filter():
+        n = rng.randint(1, 4)
+        lv = [rng.choice(levels if i == 0 else levels[:4] + ["+"]) for i in range(n)]
+        if rng.random() < 0.25:
+            lv.append("#")
+        return "/".join(lv)
+
+    subs = []
+    for i in range(600):
+        f = rand_filter()
+        client = f"cl{rng.randint(0, 80)}"
+        node = rng.choice([1, 1, 2, 3])
+        v5 = rng.random() < 0.5
+        opts = dict(qos=rng.randint(0, 2), v5=v5, no_local=v5 and rng.random() < 0.5, sub_ident=rng.randint(0, 5) if v5 else 0)
+        hid, oid = _id(node, client, ct=rng.randint(0, 1))
+        ho = HrOpts(int(opts["v5"]), opts["qos"], int(opts["no_local"]), 0, 0, opts["sub_ident"])
+        ra = hr.hr_add(g, f.encode(), len(f.encode()), C.byref(hid), C.byref(ho))
+        rb = o.add(f, oid, orc.mk_opts(**opts), rel_id=i)
+        assert ra == rb
+        subs.append((f, node, client))
+    assert hr.hr_topics(g) == o.topics() and hr.hr_routes(g) == o.routes() and hr.hr_topics_tree(g) == o.topics_tree()
+    assert hr.hr_add(g, b"a/#/b", 5, C.byref(_id(1, "x")[0]), C.byref(HrOpts())) == -1      # Err like Topic::from_str
+
+    def check_all():
+        for _ in range(300):
+            n = rng.randint(1, 5)
+            t = "/".join(rng.choice(levels if i == 0 else levels[:4]) for i in range(n))
+            if rng.random() < 0.05:
+                t += "/$bad"
+            f, node, client = rng.choice(subs)
+            hid, oid = _id(node, client, ct=rng.randint(0, 1))
+            got = _take(hr, hr.hr_matches(g, C.byref(hid), t.encode(), len(t.encode())))
+            exp = _strip_rel(o.matches(oid, t))
+            assert got == exp, t
+            routes = _take(hr, hr.hr_get(g, t.encode(), len(t.encode())))
+            if exp is None:
+                assert routes is None
+
+    check_all()
+    # remove: wrong Id (create_time) is refused, right Id removes, last relation prunes the filter
+    removed = 0
+    for f, node, client in subs[::2]:
+        for ct in (5, 0, 1):
+            hid, oid = _id(node, client, ct=ct)
+            ra = hr.hr_remove(g, f.encode(), len(f.encode()), C.byref(hid))
+            rb = o.remove(f, oid)
+            assert ra == rb, (f, client, ct)
+            removed += ra == 0
+    assert removed > 50
+    assert hr.hr_topics(g) == o.topics() and hr.hr_routes(g) == o.routes() and hr.hr_topics_tree(g) == o.topics_tree()
+    check_all()
+    hr.hr_free(g)
+
+
+def test_get_routes_unique(hr):   # router.rs:157-170: .unique() hides the wildcard-in-topic duplicate
+    g = hr.hr_new(9, 0)
+    for f in ["test/+", "test/#", "#"]:
+        hid, _ = _id(9, "c")
+        assert hr.hr_add(g, f.encode(), len(f), C.byref(hid), C.byref(HrOpts())) == 0
+    got = _take(hr, hr.hr_get(g, b"test/+", 6))
+    assert got.split("\n")[:-1] == ["#", "test/#", "test/+"]
+    hr.hr_free(g)

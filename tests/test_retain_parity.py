@@ -1,0 +1,137 @@
+"""RetainTree::matches parity (rmqtt/src/retain.rs:450-526; config 5 of BASELINE.json):
+SUBSCRIBE filters against the trie of retained topics.  The reference's result order is
+hash-map iteration order, so results compare as sorted sets per filter (App. A.5).
+Backends as in test_parity.py: emu (CPU, host logic + index math) and hip (`-m gpu`)."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle import brute
+from oracle import oracle as orc
+from rmqtt_amd import workload as wl
+from tests.parity import make_backend, pack
+
+BACKENDS = ["emu", pytest.param("hip", marks=pytest.mark.gpu)]
+
+
+@pytest.fixture(params=BACKENDS)
+def kind(request):
+    return request.param
+
+
+def per_filter(res):
+    ho = res["hit_offsets"]
+    return [sorted(res["topic_ids"][int(a):int(b)].tolist()) for a, b in zip(ho[:-1], ho[1:])]
+
+
+def check(backend, tree, filters):
+    got = backend.retain_match_batch(*pack(filters))
+    blob, offs = pack(filters)
+    st, eo, ev, _ = tree.match_batch(blob, offs)
+    assert np.array_equal(got["status"] < 0, st < 0)
+    exp = [sorted(ev[int(a):int(b)].tolist()) for a, b in zip(eo[:-1], eo[1:])]
+    assert per_filter(got) == exp
+    return exp
+
+
+def test_reference_retain_vectors(kind):   # retain.rs:609-634
+    b = make_backend(kind)
+    t = orc.RetainTree()
+    vec = [("/iot/b/x", 1), ("/iot/b/y", 2), ("/iot/b/z", 3), ("/iot/b", 123), ("/x/y/z", 4), ("/xx/yy", 9), ("/xx/yy/", 0),
+           ("/xx/yy/1", 11), ("/xx/yy/2", 12), ("/xx/yy/3", 13), ("/xx/yy/3/4", 14), ("/xx/yy/3/4/5", 15)]
+    for s, v in vec:
+        assert b.retain_add(s, v) == 0
+        t.insert(s, v)
+    b.retain_commit()
+    exp = check(b, t, ["/iot/b/y", "/iot/b/+", "/x/y/z", "/xx/yy/+", "/xx/yy/3/+", "/xx/yy/3/4/+", "/xx/yy/1/+", "#", "+/#", "/xx/#",
+                       "/xx/yy/#", "/+/+/#", "a/#/b", "", "/"])
+    assert exp[:7] == [[2], [1, 2, 3], [4], [0, 11, 12, 13], [14], [15], []]
+    assert exp[7] == sorted(v for _, v in vec)
+
+
+def test_semantics_and_mutation(kind):   # retain.rs:393-413 (remove + prune), 476-481, 502-524, '$' isolation
+    b = make_backend(kind)
+    t = orc.RetainTree()
+    topics = ["a", "a/b", "a/b/c", "a/x", "b", "$SYS/up", "$SYS", "/lead", "a/", "$SYS/a/b", "deep/" + "/".join(["q"] * 60)]
+    for i, s in enumerate(topics):
+        b.retain_add(s, i); t.insert(s, i)
+    b.retain_commit()
+    filters = ["a/#", "#", "+", "$SYS/#", "+/#", "a/+", "a/b/c", "$SYS/+", "+/up", "+/+/c", "a/+/c", "a/b/#", "nope/#", "a/b/c/#",
+               "deep/" + "/".join(["+"] * 60), "deep/" + "/".join(["q"] * 59) + "/#", "a/b/c/d"]
+    exp = check(b, t, filters)
+    assert exp[0] == [0, 1, 2, 3, 8] and exp[1] == [0, 1, 2, 3, 4, 7, 8, 10] and exp[2] == [0, 4]
+    # replace a value, remove topics (pruning), re-check
+    b.retain_add("a/b", 77); t.insert("a/b", 77)
+    for s in ["a/b/c", "b", "$SYS/up"]:
+        assert b.retain_remove(s) == 0
+        assert t.remove(s)[0] == 1
+    assert b.retain_remove("a/b/c") != 0 and b.retain_remove("zz/unknown") != 0
+    b.retain_commit()
+    exp = check(b, t, filters)
+    assert exp[0] == [0, 3, 8, 77]
+
+
+def test_wildcard_levels_stored_in_tree(kind):
+    """A retained topic name may syntactically carry '+' / '#' levels (Topic::from_str accepts
+    them); the exact-key-first else-if chain of retain.rs:472/483/502 must be reproduced."""
+    b = make_backend(kind)
+    t = orc.RetainTree()
+    for i, s in enumerate(["x/+", "x/y", "x/z", "x/+/k", "x/y/k", "w/#", "w/v", "w/v/u", "#", "p", "+", "+/q", "p/q"]):
+        b.retain_add(s, i); t.insert(s, i)
+    b.retain_commit()
+    check(b, t, ["x/+", "x/+/k", "x/#", "w/#", "w/+", "#", "+", "+/q", "+/#", "x/+/#"])
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(slot_cap=1, chunk_topics=100, window_hits=50, tile=8), dict(slot_cap=2, window_hits=1)])
+def test_random_retain_tables(kind, opts):
+    rng = random.Random(5)
+    alpha = ["a", "b", "c", "d", "", "$s", "ee"]
+
+    def rand(wild, maxd=6):
+        n = rng.randint(1, maxd)
+        lv = []
+        for i in range(n):
+            x = rng.random()
+            if wild and x < 0.25:
+                lv.append("+")
+            elif wild and x < 0.45 and i == n - 1:
+                lv.append("#")
+            else:
+                lv.append(rng.choice(alpha if i == 0 else [a for a in alpha if a != "$s"]))
+        return "/".join(lv)
+
+    b = make_backend(kind, **opts)
+    t = orc.RetainTree()
+    topics = sorted({rand(False) for _ in range(1500)})
+    for i, s in enumerate(topics):
+        b.retain_add(s, i); t.insert(s, i)
+    b.retain_commit()
+    filters = [rand(True) for _ in range(800)]
+    exp = check(b, t, filters)
+    for f, e in list(zip(filters, exp))[:300]:     # independent brute-force cross-check
+        assert e == [i for i, s in enumerate(topics) if brute.filter_matches(f, s)], f
+    for s in topics[::3]:
+        assert b.retain_remove(s) == 0 and t.remove(s)[0] == 1
+    b.retain_commit()
+    check(b, t, filters)
+
+
+def test_seeded_config5_small(kind):
+    """BASELINE.json configs[4] shape at oracle-friendly size: retained topics from the publish
+    generator (distinct), filters from the config-3 filter generator forced to hold a wildcard."""
+    tb, to = wl.gen_topics(40_000, wl.PUB_SEED + 5, 0.01, 0.01)
+    topics = sorted(s for s in set(wl.strings(tb, to)) if brute.valid(s))   # the generator emits a few invalid names ("/$SYS/..")
+    fb, fo, _, _ = wl.gen_subs(3_000, wl.SUB_SEED + 5, 0.028, 0.10, 0.005, force_wildcard=True)
+    b = make_backend(kind, chunk_topics=1024, window_hits=100_000)
+    t = orc.RetainTree()
+    blob, offs = pack(topics)
+    assert b.retain_add_bulk(blob, offs) == 0
+    for i, s in enumerate(topics):
+        t.insert(s, i)
+    b.retain_commit()
+    got = b.retain_match_batch(fb, fo)
+    st, eo, ev, _ = t.match_batch(fb, fo)
+    assert np.array_equal(got["hit_offsets"], eo)
+    assert per_filter(got) == [sorted(ev[int(a):int(b_)].tolist()) for a, b_ in zip(eo[:-1], eo[1:])]
+    assert eo[-1] > 10_000
