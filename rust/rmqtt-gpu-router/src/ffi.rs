@@ -1,0 +1,67 @@
+//! Raw bindings of include/rmqtt_gpu_router.h (hand-written; identical to what bindgen emits).
+#![allow(non_camel_case_types, dead_code)]
+use std::os::raw::{c_char, c_void};
+
+pub const RGR_OK: i32 = 0;
+pub const RGR_EOF: i32 = 1;
+pub const RGR_TOPIC_OK: i32 = 0;
+pub const RGR_SUB_V5: u8 = 1;
+pub const RGR_SUB_NO_LOCAL: u8 = 2;
+pub const RGR_SUB_SHARED: u8 = 4;
+
+#[repr(C)]
+pub struct rgr_handle { _p: [u8; 0] }
+
+#[repr(C)]
+#[derive(Default, Clone, Copy)]
+pub struct rgr_config {
+    pub device: i32,
+    pub slot_cap: u32,
+    pub window_hits: u64,
+    pub chunk_topics: u32,
+    pub host_threads: u32,
+    pub collect_walk_stats: u32,
+    pub reserved: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct rgr_tuple { pub topic_idx: u32, pub sub_id: u32, pub qos_flags: u32 }
+
+#[repr(C)]
+pub struct rgr_result {
+    pub n_topics: u32,
+    pub n_hits: u64,
+    pub status: *mut i32,
+    pub hit_offsets: *mut u64,
+    pub tuples: *mut rgr_tuple,
+    pub _owner: *mut c_void,
+}
+
+#[repr(C)]
+pub struct rgr_retain_result {
+    pub n_filters: u32,
+    pub n_hits: u64,
+    pub status: *mut i32,
+    pub hit_offsets: *mut u64,
+    pub topic_ids: *mut u32,
+    pub _owner: *mut c_void,
+}
+
+extern "C" {
+    pub fn rgr_create(cfg: *const rgr_config, out: *mut *mut rgr_handle) -> i32;
+    pub fn rgr_destroy(h: *mut rgr_handle);
+    pub fn rgr_last_error() -> *const c_char;
+    pub fn rgr_filter_add(h: *mut rgr_handle, filter: *const c_char, len: u32, filter_id: *mut u32) -> i32;
+    pub fn rgr_filter_remove(h: *mut rgr_handle, filter_id: u32) -> i32;
+    pub fn rgr_sub_add(h: *mut rgr_handle, filter_id: u32, sub_id: u32, qos: u8, flags: u8) -> i32;
+    pub fn rgr_sub_remove(h: *mut rgr_handle, filter_id: u32, sub_id: u32) -> i32;
+    pub fn rgr_commit(h: *mut rgr_handle) -> i32;
+    pub fn rgr_match_batch(h: *mut rgr_handle, blob: *const u8, offsets: *const u64, n: u32, out: *mut rgr_result) -> i32;
+    pub fn rgr_result_free(r: *mut rgr_result);
+    pub fn rgr_retain_topic_add(h: *mut rgr_handle, topic: *const c_char, len: u32, topic_id: u32) -> i32;
+    pub fn rgr_retain_topic_remove(h: *mut rgr_handle, topic: *const c_char, len: u32) -> i32;
+    pub fn rgr_retain_commit(h: *mut rgr_handle) -> i32;
+    pub fn rgr_retain_match_batch(h: *mut rgr_handle, blob: *const u8, offsets: *const u64, n: u32, out: *mut rgr_retain_result) -> i32;
+    pub fn rgr_retain_result_free(r: *mut rgr_retain_result);
+}

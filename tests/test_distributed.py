@@ -1,0 +1,31 @@
+"""N>1 path on CPU: world_size-2 gloo run of the sharded matcher + all-gatherv of tuples,
+checked against the oracle over the unsharded table (tests/dist_worker.py)."""
+import os
+import subprocess
+import sys
+
+from rmqtt_amd import shard
+from tests.conftest import ROOT
+from tests.parity import pack
+
+
+def test_shard_rule_properties():
+    filters = ["a/b/c", "a/b", "a/b/#", "a/+/c", "a/#", "+/b", "#", "a", "$SYS/x/y", "/x", "", "a/", "+"]
+    topics = ["a/b/c", "a/b", "a", "$SYS/x", "/x", "", "a/"]
+    for world in (1, 2, 8):
+        fo = shard.assign(*pack(filters), world, True)
+        to = shard.assign(*pack(topics), world, False)
+        assert list(fo < 0) == [False, False, False, True, True, True, True, False, False, False, False, False, True]
+        assert ((to >= 0) & (to < world)).all()
+        # a filter with two literal leading levels lives where every topic it can match lives
+        assert fo[0] == fo[1] == fo[2] == to[0] == to[1]
+        assert fo[7] == to[2] and fo[9] == to[4] and fo[10] == to[5] and fo[11] == to[6]
+
+
+def test_two_rank_gloo_sharded_match():
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(ROOT, "tests", "dist_worker.py")]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert "rank0:" in p.stdout
