@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--window-hits", type=int, default=0)
     ap.add_argument("--d2h", action="store_true", help="also report the PCIe-inclusive rate (copies every window to host)")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo lets the N>1 logic be exercised on one GPU")
     args = ap.parse_args()
 
     import torch
@@ -62,10 +63,16 @@ def main():
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if args.dist_backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()       # several ranks may share a GPU under gloo
     torch.cuda.set_device(local_rank)
+    cdev = "cuda" if args.dist_backend == "nccl" else "cpu"        # device of the collective tensors
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
 
     from rmqtt_amd import capi, shard
     from rmqtt_amd import workload as wl
@@ -75,12 +82,22 @@ def main():
     n_sub = max(1, int(c["n_sub"] * args.scale))
     n_pub = max(1, int(c["n_pub"] * args.scale))
 
+    retain = cfg == 5
     # ---- synthetic inputs (identical on every rank: seeded)
-    log(f"config {cfg}: generating {n_sub} subscriptions / {n_pub} publish topics", rank)
-    blob, offs, client, qos = wl.gen_subs(n_sub, wl.SUB_SEED + cfg, c["p_plus"], c["p_hash"], c["p_sys"], 0, c["fixed_depth"])
-    tb, to = wl.gen_topics(n_pub, wl.PUB_SEED + cfg, 0.01 if cfg != 1 else 0.0, c["p_blank"], c["fixed_depth"])
+    if retain:
+        # config 5: table = n_sub DISTINCT retained topics (publish generator), queries = n_pub wildcard SUBSCRIBE filters
+        log(f"config 5: generating {n_sub} retained topics / {n_pub} wildcard filters", rank)
+        blob, offs = wl.gen_topics(n_sub, wl.PUB_SEED + cfg, 0.01, c["p_blank"], c["fixed_depth"], distinct=True)
+        client = qos = None
+        tb, to, _, _ = wl.gen_subs(n_pub, wl.SUB_SEED + cfg, c["p_plus"], c["p_hash"], c["p_sys"], 0, c["fixed_depth"], force_wildcard=True)
+    else:
+        log(f"config {cfg}: generating {n_sub} subscriptions / {n_pub} publish topics", rank)
+        blob, offs, client, qos = wl.gen_subs(n_sub, wl.SUB_SEED + cfg, c["p_plus"], c["p_hash"], c["p_sys"], 0, c["fixed_depth"])
+        tb, to = wl.gen_topics(n_pub, wl.PUB_SEED + cfg, 0.01 if cfg != 1 else 0.0, c["p_blank"], c["fixed_depth"])
 
     sub_ids = np.arange(n_sub, dtype=np.uint32)
+    if world > 1 and retain:
+        raise SystemExit("config 5 (retained path) is a single-GPU config")
     if world > 1:
         f_owner = shard.assign(blob, offs, world, is_filter=True)
         t_owner = shard.assign(tb, to, world, is_filter=False)
@@ -96,14 +113,21 @@ def main():
     # ---- table build + device-resident batch
     r = capi.Router(device=local_rank, window_hits=args.window_hits, collect_walk_stats=True)
     t = time.time()
-    rej = r.subscribe_bulk(blob_r, offs_r, sub_ids_r, qos_r)
-    r.commit()
+    if retain:
+        rej = r.retain_add_bulk(blob_r, offs_r)
+        r.retain_commit()
+    else:
+        rej = r.subscribe_bulk(blob_r, offs_r, sub_ids_r, qos_r)
+        r.commit()
     build_s = time.time() - t
     st0 = r.stats()
-    log(f"table: {st0['n_filters']} filters, {st0['n_subs']} subs, {st0['n_nodes']} trie nodes, "
-        f"{st0['table_bytes_device'] / 2**30:.2f} GiB in HBM, built in {build_s:.1f}s (rejected {rej})", rank)
+    if retain:
+        log(f"retain table: {n_sub - rej} topics ({rej} names rejected by the parser), built in {build_s:.1f}s", rank)
+    else:
+        log(f"table: {st0['n_filters']} filters, {st0['n_subs']} subs, {st0['n_nodes']} trie nodes, "
+            f"{st0['table_bytes_device'] / 2**30:.2f} GiB in HBM, built in {build_s:.1f}s (rejected {rej})", rank)
     t = time.time()
-    batch = r.batch(tb_r, to_r)
+    batch = r.retain_batch(tb_r, to_r) if retain else r.batch(tb_r, to_r)
     log(f"batch: {my_topics} topics tokenised + uploaded in {time.time() - t:.1f}s", rank)
 
     def barrier():
@@ -111,10 +135,38 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    class _DevTuples:   # zero-copy torch view of a window's device tuples
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n, 3), "typestr": "<i4", "data": (ptr, True), "version": 2}
+
+    def step_gather_tuples():
+        """all-gatherv of every window's tuples (RCCL has no allgatherv: counts + padded all_gather)."""
+        hits = nwin = 0
+        batch.begin()
+        finished = False
+        while True:
+            w = None if finished else batch.next_window()
+            finished = w is None
+            done = torch.tensor([1 if w is None else 0], dtype=torch.int64, device=cdev)
+            dist.all_reduce(done, op=dist.ReduceOp.MIN)      # ranks own different window counts
+            if int(done.item()) == 1:
+                break
+            n = 0 if w is None else int(w.n_hits)
+            torch.cuda.synchronize()
+            local = torch.as_tensor(_DevTuples(w.d_tuples, n), device="cuda") if n else torch.zeros((0, 3), dtype=torch.int32, device="cuda")
+            if cdev == "cpu":
+                local = local.cpu()
+            shard.allgatherv_tuples(local, world, rank, dist, cdev)
+            hits += n
+            nwin += 1
+        return hits, nwin
+
     def step():
+        if world > 1 and args.gather == "tuples":
+            return step_gather_tuples()
         hits, nwin = batch.run()      # synchronises the library's stream at the end of the pass
         if world > 1 and args.gather != "none":
-            cnt = torch.tensor([hits], dtype=torch.int64, device="cuda")
+            cnt = torch.tensor([hits], dtype=torch.int64, device=cdev)
             allc = [torch.zeros_like(cnt) for _ in range(world)]
             dist.all_gather(allc, cnt)
         return hits, nwin
@@ -130,10 +182,10 @@ def main():
     barrier()
     elapsed = time.time() - t_start
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        tot = torch.tensor([hits, my_topics], dtype=torch.int64, device="cuda")
+        tot = torch.tensor([hits, my_topics], dtype=torch.int64, device=cdev)
         dist.all_reduce(tot)
         total_hits, total_topics = int(tot[0].item()), int(tot[1].item())
     else:
@@ -180,11 +232,15 @@ def main():
         from oracle import oracle as orc
         cores = args.cpu_threads or os.cpu_count() or 1
         t = time.time()
-        o = orc.DefaultRouter()
-        o.add_bulk(blob, offs, client, qos)
+        if retain:
+            o = orc.RetainTree()
+            o.insert_bulk(blob, offs)
+        else:
+            o = orc.DefaultRouter()
+            o.add_bulk(blob, offs, client, qos)
         log(f"cpu_baseline: oracle table built in {time.time() - t:.1f}s; timing on {cores} threads", 0)
         hits_per_topic = max(1.0, total_hits / max(1, total_topics))
-        n_s = args.cpu_sample if args.cpu_sample > 0 else int(min(n_pub, max(2000, 2.0e8 * cores / 8 / hits_per_topic)))
+        n_s = args.cpu_sample if args.cpu_sample > 0 else int(min(n_pub, max(2000, (2.0e7 if retain else 2.0e8) * cores / 8 / hits_per_topic)))
         sb, so = shard.take(tb, to, np.arange(n_s))
         sec, ost = o.match_timed(sb, so, cores)
         cpu = {"value": round(n_s / sec, 1), "unit": "publish-topic matches/s", "cores": cores, "kind": "port",
@@ -193,8 +249,10 @@ def main():
                "hits_per_s": round(ost["hits"] / sec, 1)}
 
     out = {
-        "metric": "publish-topic matches/sec @10M subs" if cfg in (3, 4) and args.scale == 1.0 else f"publish-topic matches/sec (config {cfg}, scale {args.scale})",
-        "value": round(value, 1), "unit": "publish-topic matches/s",
+        "metric": "publish-topic matches/sec @10M subs" if cfg in (3, 4) and args.scale == 1.0 else
+                  (f"retained-path SUBSCRIBE-filter matches/sec (config 5, scale {args.scale})" if retain else
+                   f"publish-topic matches/sec (config {cfg}, scale {args.scale})"),
+        "value": round(value, 1), "unit": "SUBSCRIBE-filter matches/s" if retain else "publish-topic matches/s",
         "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / K, 3),
         "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
         "dtype": "u32", "data": "synthetic",

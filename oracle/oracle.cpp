@@ -320,6 +320,45 @@ uint64_t orc_retain_match_batch(void* t, const char* blob, const uint64_t* offs,
     return vals.size();
 }
 
+// Bulk insert: topic i -> value ids ? ids[i] : i.  Returns the number of rejected names.
+uint64_t orc_retain_insert_bulk(void* t, const char* blob, const uint64_t* offs, uint64_t n, const uint32_t* ids) {
+    auto* tree = static_cast<RetainTree<int64_t>*>(t);
+    uint64_t bad = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        Topic tp;
+        if (!parse_topic(std::string_view(blob + offs[i], offs[i + 1] - offs[i]), tp)) { ++bad; continue; }
+        tree->insert(tp, ids ? int64_t(ids[i]) : int64_t(i));
+    }
+    return bad;
+}
+// Timed multi-thread RetainTree::matches over a batch of filters (cpu_baseline, config 5):
+// filters statically partitioned over threads sharing the read-only tree; results discarded.
+double orc_retain_match_timed(void* t, const char* blob, const uint64_t* offs, uint64_t n, int threads, uint64_t* hits, uint64_t* visited) {
+    auto* tree = static_cast<RetainTree<int64_t>*>(t);
+    if (threads < 1) threads = 1;
+    std::vector<WalkStats> sts(threads);
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    for (int k = 0; k < threads; ++k) {
+        th.emplace_back([&, k] {
+            uint64_t lo = n * k / threads, hi = n * (k + 1) / threads;
+            for (uint64_t i = lo; i < hi; ++i) {
+                Topic tp;
+                if (!parse_topic(std::string_view(blob + offs[i], offs[i + 1] - offs[i]), tp)) continue;
+                auto v = tree->matches(tp, &sts[k]);
+                (void)v;
+            }
+        });
+    }
+    for (auto& x : th) x.join();
+    double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    WalkStats tot;
+    for (auto& s : sts) tot.add(s);
+    if (hits) *hits = tot.hits;
+    if (visited) *visited = tot.visited;
+    return sec;
+}
+
 // ---- DefaultRouter ----------------------------------------------------------
 struct orc_id {
     uint64_t node_id;

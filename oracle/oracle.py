@@ -63,6 +63,9 @@ def lib():
         L.orc_retain_matches.argtypes = [vp, cp, u64]; L.orc_retain_matches.restype = vp
         L.orc_retain_match_batch.argtypes = [vp, vp, vp, u64, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
         L.orc_retain_match_batch.restype = u64
+        L.orc_retain_insert_bulk.argtypes = [vp, vp, vp, u64, vp]; L.orc_retain_insert_bulk.restype = u64
+        L.orc_retain_match_timed.argtypes = [vp, vp, vp, u64, C.c_int, C.POINTER(u64), C.POINTER(u64)]
+        L.orc_retain_match_timed.restype = C.c_double
         L.orc_router_new.restype = vp
         L.orc_router_free.argtypes = [vp]
         L.orc_router_add.argtypes = [vp, cp, u64, C.POINTER(OrcId), C.POINTER(OrcOpts), C.c_uint32]
@@ -191,6 +194,18 @@ class RetainTree:
             t, v = line.rsplit("\t", 1)
             out.append((t, int(v)))
         return out
+
+    def insert_bulk(self, blob, offsets, ids=None):
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        ids = None if ids is None else np.ascontiguousarray(ids, dtype=np.uint32)
+        return int(lib().orc_retain_insert_bulk(self._h, _ptr(blob), offsets.ctypes.data, len(offsets) - 1,
+                                                None if ids is None else C.c_void_p(ids.ctypes.data)))
+
+    def match_timed(self, blob, offsets, threads=1):
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        h, v = C.c_uint64(0), C.c_uint64(0)
+        sec = lib().orc_retain_match_timed(self._h, _ptr(blob), offsets.ctypes.data, len(offsets) - 1, threads, C.byref(h), C.byref(v))
+        return float(sec), dict(hits=int(h.value), visited=int(v.value))
 
     def match_batch(self, blob, offsets):
         n = len(offsets) - 1

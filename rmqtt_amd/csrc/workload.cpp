@@ -132,6 +132,8 @@ struct wl_params {
     uint64_t n_clients;    // client population (filters); 0 -> n/4 (min 1)
     int32_t fixed_depth;   // >0: every item has exactly this many levels
     int32_t force_wildcard;  // filters: re-draw until the filter has '+' or '#'
+    int32_t distinct;        // topics: re-draw repeated topic strings
+    int32_t reserved;
 };
 
 // Subscriptions: filter strings + client index + qos.
@@ -189,7 +191,9 @@ int wl_gen_topics(const wl_params* p, char** blob, uint64_t** offsets) {
     b.bytes.reserve(p->n * 56);
     b.offsets.reserve(p->n + 1);
     std::string t;
-    for (uint64_t i = 0; i < p->n; ++i) {
+    std::unordered_set<uint64_t> seen;
+    if (p->distinct) seen.reserve(p->n * 2);
+    for (uint64_t i = 0; i < p->n;) {
         t.clear();
         const int L = draw_depth(r, p->fixed_depth);
         const bool sys = p->p_sys > 0 && r.uniform() < p->p_sys;
@@ -202,7 +206,13 @@ int wl_gen_topics(const wl_params* p, char** blob, uint64_t** offsets) {
             if (l == 0 && sys) t += "$SYS"; else append_token(t, l, k);
         }
         if (blank == 2) t.push_back('/');
+        if (p->distinct) {
+            uint64_t h = 1469598103934665603ull;
+            for (unsigned char ch : t) { h ^= ch; h *= 1099511628211ull; }
+            if (!seen.insert(h).second) continue;
+        }
         b.push(t);
+        ++i;
     }
     *blob = dup_bytes(b.bytes); *offsets = dup(b.offsets);
     return 0;

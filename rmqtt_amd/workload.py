@@ -16,7 +16,7 @@ _LIB = None
 class _Params(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("n", C.c_uint64), ("p_plus", C.c_double), ("p_hash", C.c_double),
                 ("p_sys", C.c_double), ("p_blank", C.c_double), ("n_clients", C.c_uint64),
-                ("fixed_depth", C.c_int32), ("force_wildcard", C.c_int32)]
+                ("fixed_depth", C.c_int32), ("force_wildcard", C.c_int32), ("distinct", C.c_int32), ("reserved", C.c_int32)]
 
 
 def _lib():
@@ -54,7 +54,7 @@ PUB_SEED = 0x9B1C0000
 
 def gen_subs(n, seed, p_plus=0.028, p_hash=0.0, p_sys=0.0, n_clients=0, fixed_depth=0, force_wildcard=False):
     """-> (blob uint8[], offsets uint64[n+1], client uint32[n], qos uint8[n])"""
-    p = _Params(seed, n, p_plus, p_hash, p_sys, 0.0, n_clients, fixed_depth, int(force_wildcard))
+    p = _Params(seed, n, p_plus, p_hash, p_sys, 0.0, n_clients, fixed_depth, int(force_wildcard), 0, 0)
     ps = [C.c_void_p() for _ in range(4)]
     rc = _lib().wl_gen_subs(C.byref(p), *[C.byref(x) for x in ps])
     assert rc == 0
@@ -63,9 +63,9 @@ def gen_subs(n, seed, p_plus=0.028, p_hash=0.0, p_sys=0.0, n_clients=0, fixed_de
     return blob, offs, _take(ps[2], n, np.uint32), _take(ps[3], n, np.uint8)
 
 
-def gen_topics(n, seed, p_sys=0.01, p_blank=0.01, fixed_depth=0):
+def gen_topics(n, seed, p_sys=0.01, p_blank=0.01, fixed_depth=0, distinct=False):
     """-> (blob uint8[], offsets uint64[n+1])"""
-    p = _Params(seed, n, 0.0, 0.0, p_sys, p_blank, 0, fixed_depth, 0)
+    p = _Params(seed, n, 0.0, 0.0, p_sys, p_blank, 0, fixed_depth, 0, int(distinct), 0)
     ps = [C.c_void_p() for _ in range(2)]
     rc = _lib().wl_gen_topics(C.byref(p), *[C.byref(x) for x in ps])
     assert rc == 0
