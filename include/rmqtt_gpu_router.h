@@ -92,7 +92,8 @@ typedef struct rgr_config {
     uint32_t chunk_topics;      /* topics walked per pass (0 = default 2^21)            */
     uint32_t host_threads;      /* tokeniser threads (0 = hardware concurrency)         */
     uint32_t collect_walk_stats;/* nonzero: count visited trie nodes in the walk kernel */
-    uint32_t reserved;
+    uint32_t host_tokenize;     /* nonzero: tokenise topics on the host (threads above) instead
+                                   of with the device tokeniser kernels                  */
 } rgr_config;
 
 /* One emitted hit: exactly the (topic_idx, subscriber_id, qos) tuple of BASELINE.json. */

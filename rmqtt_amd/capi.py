@@ -35,7 +35,7 @@ SYMBOLS = [
 class Config(C.Structure):
     _fields_ = [("device", C.c_int32), ("slot_cap", C.c_uint32), ("window_hits", C.c_uint64),
                 ("chunk_topics", C.c_uint32), ("host_threads", C.c_uint32), ("collect_walk_stats", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("host_tokenize", C.c_uint32)]
 
 
 class Result(C.Structure):
@@ -159,9 +159,10 @@ def pack(strs):
 class Router:
     """One rgr_handle.  Thin: argument marshalling only."""
 
-    def __init__(self, device=0, slot_cap=0, window_hits=0, chunk_topics=0, host_threads=0, collect_walk_stats=True):
+    def __init__(self, device=0, slot_cap=0, window_hits=0, chunk_topics=0, host_threads=0, collect_walk_stats=True,
+                 host_tokenize=False):
         self._h = C.c_void_p()
-        cfg = Config(device, slot_cap, window_hits, chunk_topics, host_threads, int(collect_walk_stats), 0)
+        cfg = Config(device, slot_cap, window_hits, chunk_topics, host_threads, int(collect_walk_stats), int(host_tokenize))
         _check(lib().rgr_create(C.byref(cfg), C.byref(self._h)))
 
     def close(self):

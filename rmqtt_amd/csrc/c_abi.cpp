@@ -49,13 +49,34 @@ double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+struct DictImage {   // device copy of a StringDict for the device tokeniser
+    DevBuf slots, entries, arena;
+    DictView view{};
+    uint64_t n_tokens = 0;
+    void upload(const StringDict& sd) {
+        slots.ensure(sd.slots().size() * 4);
+        entries.ensure(std::max<size_t>(1, sd.entries().size()) * sizeof(DictEntry));
+        arena.ensure(std::max<size_t>(1, sd.arena().size()));
+        RGR_HIP(hipMemcpy(slots.p, sd.slots().data(), sd.slots().size() * 4, hipMemcpyHostToDevice));
+        if (!sd.entries().empty()) RGR_HIP(hipMemcpy(entries.p, sd.entries().data(), sd.entries().size() * sizeof(DictEntry), hipMemcpyHostToDevice));
+        if (!sd.arena().empty()) RGR_HIP(hipMemcpy(arena.p, sd.arena().data(), sd.arena().size(), hipMemcpyHostToDevice));
+        view.slots = slots.as<uint32_t>();
+        view.mask = sd.slots().size() - 1;
+        view.entries = entries.as<DictEntry>();
+        view.arena = arena.as<char>();
+        n_tokens = sd.size();
+    }
+};
+
 struct Epoch {
+    DictImage dict;
     DevBuf edges, filt, subs;
     TrieView view{};
     uint64_t id = 0, n_filters = 0, n_subs = 0, n_nodes = 0, edge_slots = 0, max_filter_subs = 0, bytes = 0;
 };
 
 struct RetainEpoch {
+    DictImage dict;
     DevBuf edges, child_off, child_ids, desc, vals;
     RetainView view{};
     TrieView tv{};       // filt = run descriptors, subs = values: what count/compact/expand read
@@ -87,6 +108,10 @@ struct rgr_batch {
     std::vector<int32_t> status;
     uint64_t total_tokens = 0, valid_levels = 0, valid_topics = 0;
     DevBuf d_tokens, d_tok_off, d_tflags, d_path;
+    DevBuf d_blob, d_offs, d_level_cnt;   // raw topics (device tokeniser)
+    std::vector<uint8_t> h_blob;          // raw topics kept on the host (host tokeniser only)
+    std::vector<uint64_t> h_offs;
+    uint64_t dict_tokens = ~0ull;         // dictionary size the batch was tokenised against
     hipStream_t stream = nullptr;
     // chunk work buffers
     DevBuf slots, pair_cnt, hit_cnt, pair_live, hit_off, pair_base, ovf_list, ovf_base, scalars, arena;
@@ -198,6 +223,7 @@ void tokenize_batch(rgr_handle* h, rgr_batch* b, const uint8_t* blob, const uint
     std::vector<uint8_t> flags;
     flags.reserve(n);
     b->status.assign(n, RGR_TOPIC_OK);
+    b->valid_topics = 0; b->valid_levels = 0;
     uint64_t ti = 0;
     for (auto& p : parts) {
         toks.insert(toks.end(), p.toks.begin(), p.toks.end());
@@ -209,6 +235,10 @@ void tokenize_batch(rgr_handle* h, rgr_batch* b, const uint8_t* blob, const uint
         }
     }
     b->total_tokens = total;
+    {
+        std::shared_lock<std::shared_mutex> lk(b->retain ? h->retain_mu : h->table_mu);
+        b->dict_tokens = b->retain ? h->retain_table.dict().size() : h->table.n_tokens();
+    }
     b->local.tokenize_ms += now_ms() - t0;
     const double t1 = now_ms();
     b->d_tokens.ensure(std::max<uint64_t>(1, total) * 4);
@@ -220,6 +250,39 @@ void tokenize_batch(rgr_handle* h, rgr_batch* b, const uint8_t* blob, const uint
     if (n) RGR_HIP(hipMemcpyAsync(b->d_tflags.p, flags.data(), n, hipMemcpyHostToDevice, b->stream));
     RGR_HIP(hipStreamSynchronize(b->stream));
     b->local.h2d_ms += now_ms() - t1;
+}
+
+// Device tokeniser: Topic::from_str + dictionary lookup on the GPU against `dict`.
+void tokenize_batch_device(rgr_batch* b, const DictImage& dict) {
+    const double t0 = now_ms();
+    const uint32_t n = b->n;
+    b->d_level_cnt.ensure(std::max<uint32_t>(1, n) * 4);
+    b->d_tflags.ensure(std::max<uint32_t>(1, n));
+    b->d_tok_off.ensure((size_t(n) + 1) * 8);
+    b->scan_tmp.ensure((size_t(n) / scan_block_topics() + 3) * 16);
+    const uint8_t* blob = b->d_blob.as<uint8_t>();
+    const uint64_t* offs = b->d_offs.as<uint64_t>();
+    launch_tok_count(blob, offs, n, b->d_level_cnt.as<uint32_t>(), b->d_tflags.as<uint8_t>(), b->stream);
+    launch_scan_u32(b->d_level_cnt.as<uint32_t>(), b->d_tok_off.as<uint64_t>(), n, b->scan_tmp.as<uint64_t>(), b->stream);
+    uint64_t total = 0;
+    std::vector<uint8_t> flags(n);
+    RGR_HIP(hipMemcpyAsync(&total, b->d_tok_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
+    if (n) RGR_HIP(hipMemcpyAsync(flags.data(), b->d_tflags.p, n, hipMemcpyDeviceToHost, b->stream));
+    RGR_HIP(hipStreamSynchronize(b->stream));
+    b->d_tokens.ensure(std::max<uint64_t>(1, total) * 4);
+    b->d_path.ensure(std::max<uint64_t>(1, total) * (b->retain ? 8 : 4));
+    launch_tok_fill(dict.view, blob, offs, n, b->d_tok_off.as<uint64_t>(), b->d_tflags.as<uint8_t>(), b->d_tokens.as<uint32_t>(), b->stream);
+    RGR_HIP(hipStreamSynchronize(b->stream));
+    RGR_HIP(hipGetLastError());
+    b->status.assign(n, RGR_TOPIC_OK);
+    b->valid_topics = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (flags[i] & kTopicInvalid) b->status[i] = RGR_TOPIC_INVALID; else b->valid_topics++;
+    }
+    b->total_tokens = total;
+    b->valid_levels = total;
+    b->dict_tokens = dict.n_tokens;
+    b->local.tokenize_ms += now_ms() - t0;
 }
 
 WalkArgs make_walk_args(rgr_batch* b, uint32_t n) {
@@ -477,6 +540,7 @@ int32_t rgr_commit(rgr_handle* h) {
             std::vector<FilterDesc> filt;
             std::vector<SubEntry> subs;
             h->table.flatten_filters(filt, subs);
+            ep->dict.upload(h->table.dict());
             ep->edges.ensure(edges.size() * sizeof(EdgeEntry));
             ep->filt.ensure(std::max<size_t>(1, filt.size()) * sizeof(FilterDesc));
             ep->subs.ensure(std::max<size_t>(1, subs.size()) * sizeof(SubEntry));
@@ -512,7 +576,30 @@ static int32_t batch_create_impl(rgr_handle* h, const uint8_t* blob, const uint6
         b->n = n;
         b->retain = retain;
         RGR_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
-        tokenize_batch(h, b.get(), blob, offs, n);
+        if (h->cfg.host_tokenize) {
+            if (n) { b->h_blob.assign(blob + offs[0], blob + offs[n]); b->h_offs.assign(offs, offs + n + 1); for (auto& o : b->h_offs) o -= offs[0]; }
+            else b->h_offs.assign(1, 0);
+            tokenize_batch(h, b.get(), b->h_blob.data(), b->h_offs.data(), n);
+        } else {
+            const double t1 = now_ms();
+            const uint64_t nbytes = n ? offs[n] - offs[0] : 0;
+            std::vector<uint64_t> rel(size_t(n) + 1, 0);
+            for (uint32_t i = 0; i <= n && n; ++i) rel[i] = offs[i] - offs[0];
+            b->d_blob.ensure(std::max<uint64_t>(16, nbytes + 16));
+            b->d_offs.ensure((size_t(n) + 1) * 8);
+            if (nbytes) RGR_HIP(hipMemcpyAsync(b->d_blob.p, blob + offs[0], nbytes, hipMemcpyHostToDevice, b->stream));
+            RGR_HIP(hipMemcpyAsync(b->d_offs.p, rel.data(), (size_t(n) + 1) * 8, hipMemcpyHostToDevice, b->stream));
+            RGR_HIP(hipStreamSynchronize(b->stream));
+            b->local.h2d_ms += now_ms() - t1;
+            if (retain) {
+                std::shared_ptr<RetainEpoch> ep;
+                { std::lock_guard<std::mutex> g(h->epoch_mu); ep = h->retain_epoch; }
+                if (!ep) return fail(RGR_ESTATE, "rgr_retain_batch_create: rgr_retain_commit has not been called");
+                tokenize_batch_device(b.get(), ep->dict);
+            } else {
+                tokenize_batch_device(b.get(), current_epoch(h)->dict);
+            }
+        }
         *out = b.release();
         return RGR_OK;
     });
@@ -542,6 +629,11 @@ int32_t rgr_batch_begin(rgr_batch* b) {
             if (!b->repoch) return fail(RGR_ESTATE, "rgr_batch_begin: rgr_retain_commit has not been called");
         } else {
             b->epoch = current_epoch(b->h);
+        }
+        const uint64_t want = b->retain ? b->repoch->dict.n_tokens : b->epoch->dict.n_tokens;
+        if (want != b->dict_tokens) {      // the dictionary grew since this batch was tokenised
+            if (b->h->cfg.host_tokenize) tokenize_batch(b->h, b, b->h_blob.data(), b->h_offs.data(), b->n);
+            else tokenize_batch_device(b, b->retain ? b->repoch->dict : b->epoch->dict);
         }
         b->in_pass = true;
         b->cursor = 0;

@@ -41,6 +41,64 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
     return v;
 }
 
+// --------------------------------------------------------------------------- tokeniser
+// Device-side Topic::from_str + dictionary lookup: one lane per topic, one pass over its bytes
+// per kernel (count, then fill after the exclusive scan of the level counts).
+__global__ __launch_bounds__(256) void tok_count_kernel(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offs, uint32_t n,
+                                                        uint32_t* __restrict__ level_cnt, uint8_t* __restrict__ tflags) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    uint8_t fl;
+    level_cnt[t] = topic_level_count(blob + offs[t], offs[t + 1] - offs[t], &fl);
+    tflags[t] = fl;
+}
+
+__global__ __launch_bounds__(256) void tok_fill_kernel(DictView d, const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offs,
+                                                       uint32_t n, const uint64_t* __restrict__ tok_off,
+                                                       const uint8_t* __restrict__ tflags, uint32_t* __restrict__ tokens) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n || (tflags[t] & kTopicInvalid)) return;
+    topic_tokens(d, blob + offs[t], offs[t + 1] - offs[t], tokens + tok_off[t]);
+}
+
+// exclusive scan u32 -> u64 (three phases, same block shape as the chunk scan)
+__global__ __launch_bounds__(kScanThreads) void scan1_reduce_kernel(const uint32_t* __restrict__ in, uint32_t n, uint64_t* block_tmp) {
+    __shared__ unsigned long long s_w[kScanThreads / 64];
+    const uint32_t base = blockIdx.x * kScanBlock + threadIdx.x * kScanPerThread;
+    unsigned long long a = 0;
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; ++k) if (base + k < n) a += in[base + k];
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) { unsigned long long r = 0; for (int i = 0; i < kScanThreads / 64; ++i) r += s_w[i]; block_tmp[blockIdx.x] = r; }
+}
+__global__ void scan1_spine_kernel(uint64_t* block_tmp, uint32_t nblocks) {
+    unsigned long long a = 0;
+    for (uint32_t i = 0; i < nblocks; ++i) { const unsigned long long x = block_tmp[i]; block_tmp[i] = a; a += x; }
+    block_tmp[nblocks] = a;
+}
+__global__ __launch_bounds__(kScanThreads) void scan1_down_kernel(const uint32_t* __restrict__ in, uint64_t* __restrict__ out, uint32_t n,
+                                                                  const uint64_t* block_tmp, uint32_t nblocks) {
+    __shared__ unsigned long long s_w[kScanThreads / 64];
+    const uint32_t base = blockIdx.x * kScanBlock + threadIdx.x * kScanPerThread;
+    unsigned long long la[kScanPerThread], a = 0;
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; ++k) { la[k] = a; if (base + k < n) a += in[base + k]; }
+    unsigned long long xa = a;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const unsigned long long y = __shfl_up(xa, o, 64); if (lane >= o) xa += y; }
+    if (lane == 63) s_w[w] = xa;
+    __syncthreads();
+    unsigned long long pre = 0;
+    for (int i = 0; i < w; ++i) pre += s_w[i];
+    const unsigned long long t0 = block_tmp[blockIdx.x] + pre + (xa - a);
+#pragma unroll
+    for (int k = 0; k < kScanPerThread; ++k) if (base + k < n) out[base + k] = t0 + la[k];
+    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = block_tmp[nblocks];
+}
+
 // --------------------------------------------------------------------------- walk
 template <bool OVF>
 __global__ __launch_bounds__(kWalkThreads) void walk_kernel(TrieView tv, WalkArgs a) {
@@ -293,14 +351,32 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* 
     for (uint32_t i = threadIdx.x; i < np; i += kExpandThreads) tile_pair_view(c, a, i, base, s_off[i], s_src[i], s_topic[i]);
     __syncthreads();
     Tuple* o = out + (base - hit_lo);
+    // three phases so that the 8 subscriber loads of a lane are all in flight before the first
+    // store: (1) owner pair of each strided position (LDS binary search; free when one run
+    // covers the whole tile), (2) 8-byte subscriber loads, (3) 12-byte tuple stores — a wave
+    // stores 768 contiguous bytes per instruction.
+    uint32_t topic[kExpandPerThread];
+    const SubEntry* src[kExpandPerThread];
+#pragma unroll
+    for (int j = 0; j < kExpandPerThread; ++j) {
+        const uint32_t pos = uint32_t(j) * kExpandThreads + threadIdx.x;
+        const bool live = pos < len;
+        const uint32_t i = (np == 1 || !live) ? 0u : locate_pair([&](uint32_t m) { return s_off[m]; }, np, int32_t(pos));
+        topic[j] = s_topic[i];
+        // dead tail positions read (and discard) the tile's first entry: keeps the loads branch-free
+        src[j] = subs + (uint64_t(s_src[i]) + (live ? uint32_t(int32_t(pos) - s_off[i]) : 0u));
+    }
+    SubEntry se[kExpandPerThread];
+#pragma unroll
+    for (int j = 0; j < kExpandPerThread; ++j) {
+        se[j] = *src[j];
+    }
 #pragma unroll
     for (int j = 0; j < kExpandPerThread; ++j) {
         const uint32_t pos = uint32_t(j) * kExpandThreads + threadIdx.x;
         if (pos < len) {
-            const uint32_t i = locate_pair([&](uint32_t m) { return s_off[m]; }, np, int32_t(pos));
-            const SubEntry se = subs[uint64_t(s_src[i]) + uint32_t(int32_t(pos) - s_off[i])];
             Tuple tp;
-            tp.topic_idx = s_topic[i]; tp.sub_id = se.sub_id; tp.qos_flags = se.qos_flags;
+            tp.topic_idx = topic[j]; tp.sub_id = se[j].sub_id; tp.qos_flags = se[j].qos_flags;
             o[pos] = tp;
         }
     }
@@ -311,6 +387,24 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* 
 // ------------------------------------------------------------------------------ launchers
 uint32_t expand_tile_hits() { return kTile; }
 uint32_t scan_block_topics() { return kScanBlock; }
+
+void launch_tok_count(const uint8_t* blob, const uint64_t* offs, uint32_t n, uint32_t* level_cnt, uint8_t* tflags, void* stream) {
+    if (n) tok_count_kernel<<<(n + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(blob, offs, n, level_cnt, tflags);
+}
+
+void launch_scan_u32(const uint32_t* in, uint64_t* out, uint32_t n, uint64_t* block_tmp, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint32_t nb = (n + kScanBlock - 1) / kScanBlock;
+    if (nb == 0) { hipMemsetAsync(out, 0, 8, s); return; }
+    scan1_reduce_kernel<<<nb, kScanThreads, 0, s>>>(in, n, block_tmp);
+    scan1_spine_kernel<<<1, 1, 0, s>>>(block_tmp, nb);
+    scan1_down_kernel<<<nb, kScanThreads, 0, s>>>(in, out, n, block_tmp, nb);
+}
+
+void launch_tok_fill(const DictView& d, const uint8_t* blob, const uint64_t* offs, uint32_t n, const uint64_t* tok_off,
+                     const uint8_t* tflags, uint32_t* tokens, void* stream) {
+    if (n) tok_fill_kernel<<<(n + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(d, blob, offs, n, tok_off, tflags, tokens);
+}
 
 void launch_walk(const TrieView& t, const WalkArgs& a, bool overflow_pass, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);

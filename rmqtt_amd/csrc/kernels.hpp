@@ -36,15 +36,25 @@ struct alignas(16) EdgeEntry {
     uint32_t plus_slot;   // slot of the child's '+' edge record, kNone if none
     uint32_t hash_fid;    // filter id of "<child>/#", kNone if none
     uint32_t term_fid;    // filter id ending at <child>, kNone if none
-    uint32_t pad0, pad1;
+    uint32_t lit_cnt;     // number of literal (non-wildcard) edges leaving <child>
+    uint32_t lit_xor;     // XOR of their tokens: the sole literal edge's token when lit_cnt == 1
 };
 static_assert(sizeof(EdgeEntry) == 32, "edge record is one 32-byte sector");
 
-struct NodeHeader { uint32_t plus_slot, hash_fid, term_fid; };
+struct NodeHeader { uint32_t plus_slot, hash_fid, term_fid, lit_cnt, lit_xor; };
 
 struct FilterDesc { uint32_t begin, count; };
 struct SubEntry { uint32_t sub_id, qos_flags; };
 struct Tuple { uint32_t topic_idx, sub_id, qos_flags; };   // == rgr_tuple
+
+// Level-string dictionary image (host: table.cpp StringDict; device: one copy per epoch).
+struct DictEntry { uint64_t hash; uint64_t off; uint32_t len; uint32_t pad; };
+struct DictView {
+    const uint32_t* slots;      // open addressing: token - kTokFirst + 1, 0 = empty
+    uint64_t mask;
+    const DictEntry* entries;   // index = token - kTokFirst
+    const char* arena;          // level strings, back to back
+};
 
 // topic flag bits produced by the tokeniser
 constexpr uint8_t kTopicInvalid = 1;   // parser rejected it: zero matches
@@ -122,6 +132,11 @@ struct ChunkArrays {
     uint64_t* pair_off;          // [P+1] chunk-local output offset of the run
 };
 
+// device tokeniser: blob/offsets -> per-topic level counts + flags, then token ids
+void launch_tok_count(const uint8_t* blob, const uint64_t* offs, uint32_t n, uint32_t* level_cnt, uint8_t* tflags, void* stream);
+void launch_scan_u32(const uint32_t* in, uint64_t* out, uint32_t n, uint64_t* block_tmp, void* stream);   // out[n] = total
+void launch_tok_fill(const DictView& d, const uint8_t* blob, const uint64_t* offs, uint32_t n, const uint64_t* tok_off,
+                     const uint8_t* tflags, uint32_t* tokens, void* stream);
 void launch_walk(const TrieView& t, const WalkArgs& a, bool overflow_pass, void* stream);
 void launch_retain_walk(const RetainView& t, const WalkArgs& a, bool overflow_pass, void* stream);
 void launch_count(const TrieView& t, const ChunkArrays& c, void* stream);

@@ -10,6 +10,70 @@
 
 namespace rgr {
 
+// ---- tokeniser (rmqtt/src/topic.rs:357-394, 231-243), one topic per call ------------------
+// FNV-1a 64 + avalanche; must equal StringDict::hash (table.cpp).
+RGR_HD inline uint64_t dict_hash_finish(uint64_t h) { h ^= h >> 32; h *= 0xd6e8feb86659fd93ull; h ^= h >> 32; return h; }
+constexpr uint64_t kFnvBasis = 0xcbf29ce484222325ull, kFnvPrime = 0x100000001b3ull;
+
+RGR_HD inline uint32_t dict_find(const DictView& d, const uint8_t* s, uint32_t len, uint64_t h) {
+    for (uint64_t i = h & d.mask;; i = (i + 1) & d.mask) {
+        const uint32_t v = d.slots[i];
+        if (!v) return kTokUnknown;
+        const DictEntry e = d.entries[v - 1];
+        if (e.hash == h && e.len == len) {
+            const char* a = d.arena + e.off;
+            bool eq = true;
+            for (uint32_t k = 0; k < len; ++k) if (uint8_t(a[k]) != s[k]) { eq = false; break; }
+            if (eq) return v - 1 + kTokFirst;
+        }
+    }
+}
+
+// One pass over the bytes of a topic.  on_level(index, token_or_hash_state...) is called per
+// level with (seg_ptr, seg_len, fnv_hash_of_segment, kind) where kind: 0 literal, 1 '+', 2 '#'.
+// Returns the level count, or -1 when Topic::from_str would fail; *meta = first level starts
+// with '$' (Level::Metadata).
+template <class OnLevel> RGR_HD inline int64_t scan_topic(const uint8_t* s, uint64_t len, bool* meta, OnLevel on_level) {
+    int64_t levels = 0;
+    uint64_t seg = 0, h = kFnvBasis;
+    bool hash_seen = false, seg_wild = false;
+    *meta = false;
+    for (uint64_t i = 0; i <= len; ++i) {
+        if (i == len || s[i] == '/') {
+            if (hash_seen) return -1;                               // '#' was not the last level
+            const uint64_t sl = i - seg;
+            int kind = 0;
+            if (sl == 1 && s[seg] == '+') kind = 1;
+            else if (sl == 1 && s[seg] == '#') { kind = 2; hash_seen = true; }
+            else if (seg_wild) return -1;                           // level merely contains '+'/'#'
+            else if (sl > 0 && s[seg] == '$') { if (levels != 0) return -1; *meta = true; }
+            on_level(levels, s + seg, uint32_t(sl), dict_hash_finish(h), kind);
+            ++levels;
+            seg = i + 1; h = kFnvBasis; seg_wild = false;
+        } else {
+            const uint8_t c = s[i];
+            if (c == '+' || c == '#') seg_wild = true;
+            h ^= c; h *= kFnvPrime;
+        }
+    }
+    return levels;
+}
+
+RGR_HD inline uint32_t topic_level_count(const uint8_t* s, uint64_t len, uint8_t* flags) {
+    bool meta;
+    const int64_t n = scan_topic(s, len, &meta, [](int64_t, const uint8_t*, uint32_t, uint64_t, int) {});
+    if (n < 0) { *flags = kTopicInvalid; return 0; }
+    *flags = meta ? kTopicMeta : 0;
+    return uint32_t(n);
+}
+
+RGR_HD inline void topic_tokens(const DictView& d, const uint8_t* s, uint64_t len, uint32_t* out) {
+    bool meta;
+    scan_topic(s, len, &meta, [&](int64_t idx, const uint8_t* seg, uint32_t sl, uint64_t h, int kind) {
+        out[idx] = kind == 1 ? kTokPlus : kind == 2 ? kTokHash : dict_find(d, seg, sl, h);
+    });
+}
+
 // Depth-first walk of the subscription trie for ONE publish topic, emitting matched filter
 // ids in exactly TopicTree::matches' iteration order (rmqtt/src/trie.rs:327-375;
 // SURVEY.md App. A.2):
@@ -49,7 +113,11 @@ RGR_HD inline uint32_t walk_topic(const NodeHeader& root, uint32_t mask, uint32_
                 const bool wild = !(d == 0 && meta);
                 if (wild && h.hash_fid != kNone) emit(h.hash_fid);      // trie.rs:349-355
                 const uint32_t tk = tok_at(d);
-                const bool ex = tk != kTokUnknown;
+                // miss filter: the header knows how many literal edges leave this node and, when
+                // there is exactly one, its token — most dead-end probes are skipped.  Wildcard
+                // tokens in a publish topic (tk < kTokFirst) always probe (App. A.4 quirk).
+                const bool ex = tk != kTokUnknown &&
+                                (tk < kTokFirst || (h.lit_cnt != 0 && (h.lit_cnt != 1 || h.lit_xor == tk)));
                 const bool pl = wild && h.plus_slot != kNone;
                 if (pl) {                                                // trie.rs:358-362
                     path_set(d, ex ? node : kNone);                      // exact lookup deferred
@@ -81,7 +149,7 @@ RGR_HD inline uint32_t walk_topic(const NodeHeader& root, uint32_t mask, uint32_
             if (e0.x != want_parent || e0.y != want_tok) { slot = (slot + 1) & mask; continue; }
         }
         node = e0.z;
-        h.plus_slot = e0.w; h.hash_fid = e1.x; h.term_fid = e1.y;
+        h.plus_slot = e0.w; h.hash_fid = e1.x; h.term_fid = e1.y; h.lit_cnt = e1.z; h.lit_xor = e1.w;
         d += 1;
         mode = kArrive;
     }

@@ -34,6 +34,7 @@ class RetainTable {
     // Tokenise a filter against the dictionary (read-only): flags as HostTable::tokenize_topic.
     uint8_t tokenize_filter(std::string_view f, std::vector<uint32_t>& toks) const;
     void compile(RetainImage& out) const;
+    const StringDict& dict() const { return dict_; }
     uint64_t n_topics() const { return n_values_; }
     uint64_t n_nodes() const { return n_nodes_; }
 

@@ -48,7 +48,7 @@ uint32_t StringDict::intern(std::string_view s) {
     if (t != kTokUnknown) return t;
     if ((entries_.size() + 1) * 2 > slots_.size()) grow();
     const uint64_t h = hash(s);
-    entries_.push_back(Entry{h, arena_.size(), uint32_t(s.size())});
+    entries_.push_back(Entry{h, arena_.size(), uint32_t(s.size()), 0});
     arena_.insert(arena_.end(), s.begin(), s.end());
     uint64_t i = h & mask_;
     while (slots_[i]) i = (i + 1) & mask_;
@@ -158,6 +158,7 @@ uint32_t HostTable::new_node(uint32_t parent, uint32_t token) {
     n_nodes_++;
     if (token == kTokPlus) { nodes_[parent].plus_child = id; set_plus_slot(parent, slot); }
     else if (token == kTokHash) nodes_[parent].hash_child = id;
+    else literal_edge(parent, token, +1);
     return id;
 }
 
@@ -166,6 +167,12 @@ void HostTable::set_plus_slot(uint32_t node, uint32_t slot) {
 }
 void HostTable::set_hash_fid(uint32_t node, uint32_t fid) {
     if (node == 0) root_hdr_.hash_fid = fid; else edges_[nodes_[node].slot].hash_fid = fid;
+}
+void HostTable::literal_edge(uint32_t node, uint32_t token, int delta) {
+    uint32_t& cnt = node == 0 ? root_hdr_.lit_cnt : edges_[nodes_[node].slot].lit_cnt;
+    uint32_t& x = node == 0 ? root_hdr_.lit_xor : edges_[nodes_[node].slot].lit_xor;
+    cnt += uint32_t(delta);
+    x ^= token;
 }
 void HostTable::set_term_fid(uint32_t node, uint32_t fid) {
     nodes_[node].term_fid = fid;
@@ -231,6 +238,7 @@ int32_t HostTable::filter_remove(uint32_t fid) {
         edge_live_--;
         if (nodes_[t].token == kTokPlus) { nodes_[p].plus_child = kNone; set_plus_slot(p, kNone); }
         else if (nodes_[t].token == kTokHash) nodes_[p].hash_child = kNone;
+        else literal_edge(p, nodes_[t].token, -1);
         nodes_[p].nchild--;
         free_nodes_.push_back(t);
         n_nodes_--;

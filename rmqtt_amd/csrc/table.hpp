@@ -25,9 +25,13 @@ class StringDict {
     uint32_t size() const { return uint32_t(entries_.size()); }
     static uint64_t hash(std::string_view s);
     std::string_view str(uint32_t tok) const;
+    // raw image for the device tokeniser (kernels.hpp DictView)
+    const std::vector<char>& arena() const { return arena_; }
+    const std::vector<DictEntry>& entries() const { return entries_; }
+    const std::vector<uint32_t>& slots() const { return slots_; }
 
    private:
-    struct Entry { uint64_t hash; uint64_t off; uint32_t len; };
+    using Entry = DictEntry;
     std::vector<char> arena_;
     std::vector<Entry> entries_;       // index = token - kTokFirst
     std::vector<uint32_t> slots_;      // token+1, 0 = empty
@@ -81,7 +85,7 @@ class HostTable {
     std::vector<EdgeEntry> edges_;
     uint64_t edge_used_ = 0;               // live + tombstones
     uint64_t edge_live_ = 0;
-    NodeHeader root_hdr_{kNone, kNone, kNone};
+    NodeHeader root_hdr_{kNone, kNone, kNone, 0, 0};
     std::vector<Filter> filters_;
     std::vector<uint32_t> free_fids_;
     uint64_t n_filters_ = 0, n_subs_ = 0, n_nodes_ = 1;
@@ -93,6 +97,7 @@ class HostTable {
     void set_plus_slot(uint32_t node, uint32_t slot);
     void set_hash_fid(uint32_t node, uint32_t fid);
     void set_term_fid(uint32_t node, uint32_t fid);
+    void literal_edge(uint32_t node, uint32_t token, int delta);
     uint32_t walk_existing(const std::vector<uint32_t>& toks) const;
 };
 

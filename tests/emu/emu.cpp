@@ -202,6 +202,21 @@ int32_t emu_match(void* ev, const uint8_t* blob, const uint64_t* offs, uint32_t 
         tok_off[i + 1] = tokens.size();
         status[i] = (tflags[i] & kTopicInvalid) ? RGR_TOPIC_INVALID : RGR_TOPIC_OK;
     }
+    {   // cross-check: the device tokeniser's code (match_core.hpp) must agree with the host tokeniser
+        const StringDict& sd = tb.dict();
+        DictView dv{sd.slots().data(), sd.slots().size() - 1, sd.entries().data(), sd.arena().data()};
+        std::vector<uint32_t> tk2;
+        for (uint32_t i = 0; i < n; ++i) {
+            const uint8_t* p = blob + offs[i];
+            const uint64_t len = offs[i + 1] - offs[i];
+            uint8_t fl;
+            const uint32_t L = topic_level_count(p, len, &fl);
+            if (fl != tflags[i] || L != tok_off[i + 1] - tok_off[i]) return RGR_ESTATE;
+            tk2.assign(L + 1, 0xDEADBEEF);
+            if (!(fl & kTopicInvalid)) topic_tokens(dv, p, len, tk2.data());
+            for (uint32_t d = 0; d < L; ++d) if (tk2[d] != tokens[tok_off[i] + d]) return RGR_ESTATE;
+        }
+    }
     tokens.push_back(0);
     std::vector<uint32_t> path_scratch(tokens.size(), 0xDEADBEEF);
     std::vector<FilterDesc> filt;
@@ -219,7 +234,7 @@ int32_t emu_match(void* ev, const uint8_t* blob, const uint64_t* offs, uint32_t 
             [&](uint32_t slot, U4& e0, U4& e1) {
                 const EdgeEntry& en = tv.edges[slot];
                 e0 = U4{en.parent, en.token, en.child, en.plus_slot};
-                e1 = U4{en.hash_fid, en.term_fid, en.pad0, en.pad1};
+                e1 = U4{en.hash_fid, en.term_fid, en.lit_cnt, en.lit_xor};
             });
     };
     return run_pipeline(e, n, tok_off, tflags, tv, walk_one, hit_offsets_out, tuples_out, n_hits_out, pair_offsets_out, pair_fids_out);
