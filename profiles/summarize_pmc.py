@@ -13,7 +13,7 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         for row in csv.DictReader(open(f)):
             if row.get("Counter_Name") != counter:
                 continue
-            k = row["Kernel_Name"].split("(")[0][-40:]
+            k = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:40]
             res[k][counter][0] += 1
             res[k][counter][1] += float(row["Counter_Value"])
 print("%-42s %8s %18s %18s   (values are the counters' native unit: KiB; per dispatch = total/dispatches)" % ("kernel", "disp", "FETCH_SIZE total", "WRITE_SIZE total"))

@@ -116,6 +116,7 @@ struct rgr_batch {
     // chunk work buffers
     DevBuf slots, pair_cnt, hit_cnt, pair_live, hit_off, pair_base, ovf_list, ovf_base, scalars, arena;
     DevBuf pair_src, pair_topic, pair_off, tile_first, out, scan_tmp;
+    DevBuf rf_filter[2], rf_node[2], r_cnt, r_payload, r_ecnt, r_e0, r_e1, r_out_off, r_epos, r_big;   // retain frontier rounds
     PinnedBuf h_hit_off, h_pair_base, h_scalars;
     uint64_t arena_cap = 0;
     // pass state
@@ -167,7 +168,7 @@ struct rgr_batch {
 namespace {
 
 // scalars layout (device, 32 bytes): [0] u32 ovf_count, [1] u32 error, [2..3] u64 ovf_cursor, [4..5] u64 visited
-struct Scalars { uint32_t ovf_count, error; unsigned long long ovf_cursor, visited; };
+struct Scalars { uint32_t ovf_count, error; unsigned long long ovf_cursor, visited; uint32_t big_count, pad; };
 
 std::shared_ptr<Epoch> current_epoch(rgr_handle* h) {
     std::lock_guard<std::mutex> g(h->epoch_mu);
@@ -293,7 +294,7 @@ WalkArgs make_walk_args(rgr_batch* b, uint32_t n) {
     a.tflags = b->d_tflags.as<uint8_t>();
     a.topic_base = b->chunk_begin;
     a.n = n;
-    a.slot_cap = b->h->cfg.slot_cap;
+    a.slot_cap = b->retain ? 0 : b->h->cfg.slot_cap;
     a.slots = b->slots.as<uint32_t>();
     a.pair_cnt = b->pair_cnt.as<uint32_t>();
     a.path_scratch = b->d_path.as<uint32_t>();
@@ -311,7 +312,7 @@ ChunkArrays make_chunk_arrays(rgr_batch* b, uint32_t n) {
     ChunkArrays c{};
     Scalars* sc = b->scalars.as<Scalars>();
     c.n = n;
-    c.slot_cap = b->h->cfg.slot_cap;
+    c.slot_cap = b->retain ? 0 : b->h->cfg.slot_cap;   // retain descriptor lists always live in the arena
     c.slots = b->slots.as<uint32_t>();
     c.pair_cnt = b->pair_cnt.as<uint32_t>();
     c.hit_cnt = b->hit_cnt.as<uint32_t>();
@@ -329,8 +330,8 @@ ChunkArrays make_chunk_arrays(rgr_batch* b, uint32_t n) {
 }
 
 void ensure_chunk_buffers(rgr_batch* b, uint32_t n) {
-    const uint32_t C = b->h->cfg.slot_cap;
-    b->slots.ensure(size_t(C) * n * 4);
+    const uint32_t C = b->retain ? 0 : b->h->cfg.slot_cap;
+    b->slots.ensure(std::max<size_t>(16, size_t(C) * n * 4));
     b->pair_cnt.ensure(size_t(n) * 4);
     b->hit_cnt.ensure(size_t(n) * 4);
     b->pair_live.ensure(size_t(n) * 4);
@@ -347,6 +348,59 @@ void ensure_chunk_buffers(rgr_batch* b, uint32_t n) {
     b->h_scalars.ensure(sizeof(Scalars));
 }
 
+// RetainTree::matches for the chunk's filters: level-synchronous frontier rounds (kernels.hip).
+// Fills the arena with every filter's run descriptors (in trie preorder), ovf_base / pair_cnt.
+void retain_rounds(rgr_batch* b, uint32_t begin, uint32_t n) {
+    const RetainView& rv = b->repoch->view;
+    Scalars* sc = b->scalars.as<Scalars>();
+    RGR_HIP(hipMemsetAsync(b->pair_cnt.p, 0, size_t(n) * 4, b->stream));
+    uint64_t g_total = 0, m = n, visited = 0;
+    int cur = 0;
+    for (uint32_t d = 0; m > 0; ++d) {
+        if (m > (1ull << 31)) throw std::runtime_error("retain frontier exceeds 2^31 items");
+        const uint32_t mm = uint32_t(m);
+        for (DevBuf* p : {&b->r_cnt, &b->r_payload, &b->r_ecnt, &b->r_e0, &b->r_e1, &b->r_big}) p->ensure(size_t(mm) * 4);
+        b->r_out_off.ensure((size_t(mm) + 1) * 8);
+        b->r_epos.ensure((size_t(mm) + 1) * 8);
+        b->scan_tmp.ensure((size_t(mm) / scan_block_topics() + 3) * 16);
+        RetainRound r{};
+        r.tokens = b->d_tokens.as<uint32_t>(); r.tok_off = b->d_tok_off.as<uint64_t>(); r.tflags = b->d_tflags.as<uint8_t>();
+        r.topic_base = begin; r.d = d; r.m = mm;
+        r.f_filter = d == 0 ? nullptr : b->rf_filter[cur].as<uint32_t>();
+        r.f_node = d == 0 ? nullptr : b->rf_node[cur].as<uint32_t>();
+        r.cnt = b->r_cnt.as<uint32_t>(); r.payload = b->r_payload.as<uint32_t>();
+        r.ecnt = b->r_ecnt.as<uint32_t>(); r.e0 = b->r_e0.as<uint32_t>(); r.e1 = b->r_e1.as<uint32_t>();
+        launch_retain_step(rv, r, b->stream);
+        launch_scan_u32(r.cnt, b->r_out_off.as<uint64_t>(), mm, b->scan_tmp.as<uint64_t>(), b->stream);
+        launch_scan_u32(r.ecnt, b->r_epos.as<uint64_t>(), mm, b->scan_tmp.as<uint64_t>(), b->stream);
+        uint64_t tot[2] = {0, 0};
+        RGR_HIP(hipMemcpyAsync(&tot[0], b->r_out_off.as<uint64_t>() + mm, 8, hipMemcpyDeviceToHost, b->stream));
+        RGR_HIP(hipMemcpyAsync(&tot[1], b->r_epos.as<uint64_t>() + mm, 8, hipMemcpyDeviceToHost, b->stream));
+        RGR_HIP(hipStreamSynchronize(b->stream));
+        const uint64_t m_next = tot[0], e_r = tot[1];
+        if (g_total + e_r > b->arena_cap) {
+            b->arena_cap = (g_total + e_r) * 2;
+            b->arena.ensure_preserve(b->arena_cap * 4, g_total * 4);
+        }
+        launch_retain_emit(r, b->r_epos.as<uint64_t>(), g_total, b->arena.as<uint32_t>(), b->ovf_base.as<uint64_t>(),
+                           b->pair_cnt.as<uint32_t>(), b->stream);
+        g_total += e_r;
+        if (m_next) {
+            b->rf_filter[cur ^ 1].ensure(m_next * 4);
+            b->rf_node[cur ^ 1].ensure(m_next * 4);
+            RGR_HIP(hipMemsetAsync(&sc->big_count, 0, 4, b->stream));
+            launch_retain_next(rv, r, b->r_out_off.as<uint64_t>(), b->rf_filter[cur ^ 1].as<uint32_t>(), b->rf_node[cur ^ 1].as<uint32_t>(),
+                               b->r_big.as<uint32_t>(), &sc->big_count, b->stream);
+        }
+        visited += m;
+        cur ^= 1;
+        m = m_next;
+    }
+    RGR_HIP(hipGetLastError());
+    b->local.visited_nodes += visited;
+    b->local.alg_bytes_walk += 24 * visited;
+}
+
 // Walk the chunk starting at `begin`; on return the host has hit_off / pair_base and the
 // dense pair arrays are built.  With walk_only the pipeline stops after the walk passes.
 void prepare_chunk(rgr_batch* b, uint32_t begin, bool walk_only) {
@@ -361,8 +415,7 @@ void prepare_chunk(rgr_batch* b, uint32_t begin, bool walk_only) {
         WalkArgs wa = make_walk_args(b, n);
         size_t sp = b->span_begin(kSpanWalk);
         if (b->retain) {
-            launch_retain_walk(b->repoch->view, wa, false, b->stream);
-            launch_retain_walk(b->repoch->view, wa, true, b->stream);
+            retain_rounds(b, begin, n);
         } else {
             launch_walk(tv, wa, false, b->stream);
             launch_walk(tv, wa, true, b->stream);

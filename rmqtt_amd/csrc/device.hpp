@@ -40,6 +40,18 @@ struct DevBuf {
         RGR_HIP(hipMalloc(&p, want));
         bytes = want;
     }
+    // Ensure capacity keeping the first `keep` bytes.
+    void ensure_preserve(size_t n, size_t keep) {
+        if (n <= bytes) return;
+        void* old = p;
+        const size_t want = n + n / 2 + 256;
+        void* np = nullptr;
+        RGR_HIP(hipMalloc(&np, want));
+        if (old && keep) RGR_HIP(hipMemcpy(np, old, keep, hipMemcpyDeviceToDevice));
+        if (old) (void)hipFree(old);
+        p = np;
+        bytes = want;
+    }
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 

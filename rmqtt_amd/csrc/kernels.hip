@@ -182,61 +182,92 @@ __global__ __launch_bounds__(kWalkThreads) void walk_kernel(TrieView tv, WalkArg
     }
 }
 
-// --------------------------------------------------------------------------- retain walk
-// RetainTree::matches: one lane per SUBSCRIBE filter walking the preorder-numbered trie of
-// retained topics (match_core.hpp: retain_walk_filter).  Emits run-descriptor indices into
-// the same slot / overflow structures as walk_kernel; the downstream count / scan / compact /
-// tiles / expand kernels are shared.  The '+' stack (cursor,end per level) lives in HBM
-// scratch shaped like the token array.
-template <bool OVF>
-__global__ __launch_bounds__(kWalkThreads) void retain_walk_kernel(RetainView rv, WalkArgs a) {
-    const uint32_t i = blockIdx.x * kWalkThreads + threadIdx.x;
-    uint32_t tl;
-    bool active;
-    if (OVF) { active = i < min(*a.ovf_count, a.n); tl = active ? a.ovf_list[i] : 0; }
-    else { tl = i; active = tl < a.n; }
-    uint32_t cnt = 0, visited = 0;
-    if (active) {
-        const uint32_t gt = a.topic_base + tl;
-        const uint64_t off0 = a.tok_off[gt];
-        const uint32_t L = uint32_t(a.tok_off[gt + 1] - off0);
-        const uint64_t arena_base = OVF ? a.ovf_base[tl] : 0;
-        if (!(a.tflags[gt] & kTopicInvalid)) {
-            const REdge* edges = rv.edges;
-            const uint32_t mask = rv.mask;
-            visited = retain_walk_filter(
-                rv, L, [&](uint32_t d) { return a.tokens[off0 + d]; },
-                [&](uint32_t d, uint32_t& cur, uint32_t& end) {
-                    const uint2 v = *reinterpret_cast<const uint2*>(a.path_scratch + 2 * (off0 + d));
-                    cur = v.x; end = v.y;
-                },
-                [&](uint32_t d, uint32_t cur, uint32_t end) { *reinterpret_cast<uint2*>(a.path_scratch + 2 * (off0 + d)) = make_uint2(cur, end); },
-                [&](uint32_t desc) {
-                    if (OVF) { if (arena_base + cnt < a.ovf_arena_cap) a.ovf_arena[arena_base + cnt] = desc; }
-                    else if (cnt < a.slot_cap) a.slots[uint64_t(cnt) * a.n + tl] = desc;
-                    cnt++;
-                },
-                [&](uint32_t parent, uint32_t token) -> uint32_t {
-                    for (uint32_t s = edge_hash(parent, token) & mask;; s = (s + 1) & mask) {
-                        const uint4 e = *reinterpret_cast<const uint4*>(edges + s);
-                        if (e.x == kEdgeEmpty) return kNone;
-                        if (e.x == parent && e.y == token) return e.z;
-                    }
-                });
-        }
-        if (!OVF) {
-            a.pair_cnt[tl] = cnt;
-            if (cnt > a.slot_cap) {
-                const uint32_t k = atomicAdd(a.ovf_count, 1u);
-                a.ovf_list[k] = tl;
-                a.ovf_base[tl] = atomicAdd(a.ovf_cursor, (unsigned long long)cnt);
-            }
-        }
+// --------------------------------------------------------------------------- retain (RetainTree::matches)
+// Level-synchronous, load-balanced frontier expansion over the preorder-numbered trie of retained
+// topics.  Per level: retain_step_kernel (one lane per frontier item: probe / child-range /
+// descriptors), exclusive scans, retain_expand_kernel (every block owns kTile consecutive slots
+// of the NEXT frontier and finds their producing item by binary search in LDS — a '+' over a
+// 65 k-child node is spread over many blocks instead of serialising one lane), and
+// retain_emit_kernel (descriptors appended per filter, in order).  The emitted descriptor lists
+// feed the shared count / scan / compact / tiles / expand kernels.
+__device__ __forceinline__ uint32_t retain_probe(const REdge* edges, uint32_t mask, uint32_t parent, uint32_t token) {
+    for (uint32_t s = edge_hash(parent, token) & mask;; s = (s + 1) & mask) {
+        const uint4 e = *reinterpret_cast<const uint4*>(edges + s);
+        if (e.x == kEdgeEmpty) return kNone;
+        if (e.x == parent && e.y == token) return e.z;
     }
-    if (a.visited && !OVF) {
-        const unsigned long long v = wave_sum(visited);
-        if ((threadIdx.x & 63) == 0 && v) atomicAdd(a.visited, v);
+}
+
+__global__ __launch_bounds__(256) void retain_step_kernel(RetainView rv, RetainRound r) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= r.m) return;
+    const uint32_t f = r.f_filter ? r.f_filter[i] : i;
+    const uint32_t node = r.f_filter ? r.f_node[i] : 0u;
+    const uint32_t gt = r.topic_base + f;
+    RetainStep st{0, 0, kNone, kNone};
+    if (!(r.tflags[gt] & kTopicInvalid)) {
+        const uint64_t off0 = r.tok_off[gt];
+        const uint32_t L = uint32_t(r.tok_off[gt + 1] - off0);
+        const uint32_t tok = r.d < L ? r.tokens[off0 + r.d] : 0u;
+        const REdge* edges = rv.edges;
+        const uint32_t mask = rv.mask;
+        st = retain_step(rv, node, r.d, L, tok, [&](uint32_t p, uint32_t t) { return retain_probe(edges, mask, p, t); });
     }
+    r.cnt[i] = st.cnt; r.payload[i] = st.payload;
+    r.e0[i] = st.e0; r.e1[i] = st.e1;
+    r.ecnt[i] = (st.e0 != kNone) + (st.e1 != kNone);
+}
+
+constexpr uint32_t kRetainSmall = 32;   // expansions up to this size are written by their own lane
+
+// Next frontier, part 1: every item writes its own contribution at out_off[i] when it is small;
+// big expansions ('+' over a node with many children) are queued for retain_big_kernel.
+__global__ __launch_bounds__(256) void retain_scatter_kernel(RetainView rv, RetainRound r, const uint64_t* __restrict__ out_off,
+                                                             uint32_t* __restrict__ nf_filter, uint32_t* __restrict__ nf_node,
+                                                             uint32_t* __restrict__ big_list, uint32_t* __restrict__ big_count) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= r.m) return;
+    const uint32_t c = r.cnt[i];
+    if (!c) return;
+    if (c > kRetainSmall) { big_list[atomicAdd(big_count, 1u)] = i; return; }
+    const uint32_t f = r.f_filter ? r.f_filter[i] : i;
+    const uint32_t pay = r.payload[i];
+    const uint64_t o = out_off[i];
+    for (uint32_t k = 0; k < c; ++k) { nf_filter[o + k] = f; nf_node[o + k] = retain_child(rv, pay, k); }
+}
+
+// Next frontier, part 2: one block per queued big expansion, coalesced copy of its child list.
+// Every big item owns the slot range [out_off[i], out_off[i]+cnt) so the result does not depend
+// on the queue order.
+__global__ __launch_bounds__(256) void retain_big_kernel(RetainView rv, RetainRound r, const uint64_t* __restrict__ out_off,
+                                                         uint32_t* __restrict__ nf_filter, uint32_t* __restrict__ nf_node,
+                                                         const uint32_t* __restrict__ big_list, const uint32_t* __restrict__ big_count) {
+    const uint32_t nb = *big_count;
+    for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+        const uint32_t i = big_list[b];
+        const uint32_t c = r.cnt[i], pay = r.payload[i];
+        const uint32_t f = r.f_filter ? r.f_filter[i] : i;
+        const uint64_t o = out_off[i];
+        for (uint32_t k = threadIdx.x; k < c; k += 256) { nf_filter[o + k] = f; nf_node[o + k] = rv.child_ids[pay + k]; }
+    }
+}
+
+// Descriptors of this round appended to the arena in item order.  A filter's items are
+// contiguous in the frontier and it emits only in its final round, so the exclusive scan value
+// of its first item is the base of its descriptor list.
+__global__ __launch_bounds__(256) void retain_emit_kernel(RetainRound r, const uint64_t* __restrict__ epos, uint64_t g_base,
+                                                          uint32_t* __restrict__ arena, uint64_t* __restrict__ ovf_base,
+                                                          uint32_t* __restrict__ pair_cnt) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= r.m) return;
+    const uint32_t f = r.f_filter ? r.f_filter[i] : i;
+    uint64_t p = g_base + epos[i];
+    if (i == 0 || (r.f_filter ? r.f_filter[i - 1] : i - 1) != f) ovf_base[f] = p;
+    const uint32_t n = r.ecnt[i];
+    if (!n) return;
+    if (r.e0[i] != kNone) arena[p++] = r.e0[i];
+    if (r.e1[i] != kNone) arena[p++] = r.e1[i];
+    atomicAdd(&pair_cnt[f], n);
 }
 
 // --------------------------------------------------------------------------- count
@@ -415,11 +446,21 @@ void launch_walk(const TrieView& t, const WalkArgs& a, bool overflow_pass, void*
     else walk_kernel<true><<<(a.n + kWalkThreads - 1) / kWalkThreads, kWalkThreads, 0, s>>>(t, a);
 }
 
-void launch_retain_walk(const RetainView& t, const WalkArgs& a, bool overflow_pass, void* stream) {
+void launch_retain_step(const RetainView& t, const RetainRound& r, void* stream) {
+    if (r.m) retain_step_kernel<<<(r.m + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(t, r);
+}
+
+void launch_retain_next(const RetainView& t, const RetainRound& r, const uint64_t* out_off, uint32_t* nf_filter, uint32_t* nf_node,
+                        uint32_t* big_list, uint32_t* big_count, void* stream) {
+    if (!r.m) return;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (a.n == 0) return;
-    if (!overflow_pass) retain_walk_kernel<false><<<(a.n + kWalkThreads - 1) / kWalkThreads, kWalkThreads, 0, s>>>(t, a);
-    else retain_walk_kernel<true><<<(a.n + kWalkThreads - 1) / kWalkThreads, kWalkThreads, 0, s>>>(t, a);
+    retain_scatter_kernel<<<(r.m + 255) / 256, 256, 0, s>>>(t, r, out_off, nf_filter, nf_node, big_list, big_count);
+    retain_big_kernel<<<1024, 256, 0, s>>>(t, r, out_off, nf_filter, nf_node, big_list, big_count);
+}
+
+void launch_retain_emit(const RetainRound& r, const uint64_t* epos, uint64_t g_base, uint32_t* arena, uint64_t* ovf_base,
+                        uint32_t* pair_cnt, void* stream) {
+    if (r.m) retain_emit_kernel<<<(r.m + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(r, epos, g_base, arena, ovf_base, pair_cnt);
 }
 
 void launch_count(const TrieView& t, const ChunkArrays& c, void* stream) {

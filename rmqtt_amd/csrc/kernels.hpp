@@ -138,7 +138,23 @@ void launch_scan_u32(const uint32_t* in, uint64_t* out, uint32_t n, uint64_t* bl
 void launch_tok_fill(const DictView& d, const uint8_t* blob, const uint64_t* offs, uint32_t n, const uint64_t* tok_off,
                      const uint8_t* tflags, uint32_t* tokens, void* stream);
 void launch_walk(const TrieView& t, const WalkArgs& a, bool overflow_pass, void* stream);
-void launch_retain_walk(const RetainView& t, const WalkArgs& a, bool overflow_pass, void* stream);
+// RetainTree twin: level-synchronous frontier expansion
+struct RetainRound {
+    const uint32_t* tokens; const uint64_t* tok_off; const uint8_t* tflags;
+    uint32_t topic_base;        // first filter of the chunk
+    uint32_t d;                 // level processed this round
+    uint32_t m;                 // frontier size
+    const uint32_t* f_filter;   // [m] chunk-local filter index (null in round 0: item i = filter i at the root)
+    const uint32_t* f_node;     // [m]
+    uint32_t* cnt; uint32_t* payload;       // [m] contribution to the next frontier
+    uint32_t* ecnt; uint32_t* e0; uint32_t* e1;   // [m] emitted descriptors
+};
+void launch_retain_step(const RetainView& t, const RetainRound& r, void* stream);
+void launch_retain_next(const RetainView& t, const RetainRound& r, const uint64_t* out_off, uint32_t* nf_filter, uint32_t* nf_node,
+                        uint32_t* big_list, uint32_t* big_count, void* stream);
+void launch_retain_emit(const RetainRound& r, const uint64_t* epos, uint64_t g_base, uint32_t* arena, uint64_t* ovf_base,
+                        uint32_t* pair_cnt, void* stream);
+
 void launch_count(const TrieView& t, const ChunkArrays& c, void* stream);
 void launch_scan(const ChunkArrays& c, uint64_t* block_tmp, void* stream);
 void launch_compact(const TrieView& t, const ChunkArrays& c, uint32_t topic_base, void* stream);

@@ -156,76 +156,54 @@ RGR_HD inline uint32_t walk_topic(const NodeHeader& root, uint32_t mask, uint32_
     return visited;
 }
 
-// RetainTree::matches for ONE filter (rmqtt/src/retain.rs:457-526): the
-// filter walks a trie of concrete topics.  Emits run-descriptor indices (RetainView::desc):
-//   path exhausted at node p            -> 2p   (p's own value, retain.rs:465-470)
-//   next level is the trailing '#' at p -> 2p+1 (p itself = "parent match" retain.rs:476-481 /
-//                                          494-499, plus every descendant retain.rs:502-524),
-//                                          or 2N at the root (no '$' subtrees, retain.rs:505-509)
-// '+' iterates the children (the root skips '$' children, retain.rs:486-490) depth-first in
-// child-list order, so descriptors come out in ascending preorder.  An exact key equal to a
-// wildcard token takes precedence over the wildcard meaning (the else-if chain at
-// retain.rs:472/483/502).  stk_get/stk_set hold (cursor,end) of the open '+' level d.
-template <class TokAt, class StkGet, class StkSet, class Emit, class Probe>
-RGR_HD inline uint32_t retain_walk_filter(const RetainView& rv, uint32_t L, TokAt tok_at, StkGet stk_get, StkSet stk_set, Emit emit,
-                                          Probe probe) {
-    uint32_t visited = 0;
-    uint32_t node = 0, d = 0;
-    int64_t top = -1;                    // deepest '+' level that may still have children left
-    for (;;) {
-        bool back = false;
-        visited++;
-        if (d == L) {
-            emit(2 * node);
-            back = true;
+// RetainTree::matches (rmqtt/src/retain.rs:457-526), one frontier item at a
+// time.  The filter batch is matched level-synchronously: the frontier of level d holds
+// (filter, node) items; retain_step() says what one item does at its filter's level d:
+//   cnt / payload  how many items it contributes to level d+1: 0 (dead end), 1 (exact child:
+//                  payload = child | kLitFlag) or the node's whole child list (payload = first
+//                  index into child_ids; the root skips '$' children, retain.rs:486-490)
+//   e0 / e1        run descriptors it emits (RetainView::desc indices), kNone if none:
+//     path exhausted at node p             -> 2p   (p's own value, retain.rs:465-470)
+//     next level is the trailing '#' at p  -> 2p+1 (p itself = "parent match" retain.rs:476-481
+//                                             / 494-499, plus every descendant retain.rs:502-524)
+//                                             or 2N at the root (no '$' subtrees, retain.rs:505-509)
+// An exact key equal to a wildcard token takes precedence over the wildcard meaning (the
+// else-if chain at retain.rs:472/483/502).  Expansion keeps items in order, so every filter's
+// descriptors come out in ascending trie preorder — deterministic.
+constexpr uint32_t kLitFlag = 0x80000000u;
+struct RetainStep { uint32_t cnt, payload, e0, e1; };
+
+template <class Probe>
+RGR_HD inline RetainStep retain_step(const RetainView& rv, uint32_t node, uint32_t d, uint32_t L, uint32_t tok, Probe probe) {
+    RetainStep r{0, 0, kNone, kNone};
+    if (d == L) { r.e0 = 2 * node; return r; }
+    if (tok == kTokHash) {                               // trailing '#'
+        const uint32_t c = probe(node, kTokHash);
+        if (c != kNone) {                                // a literal "#" level stored in the tree wins
+            if (node != 0) r.e0 = 2 * node;              // parent match of the node we stand on
+            r.e1 = 2 * c;
         } else {
-            const uint32_t t = tok_at(d);
-            if (t == kTokHash) {                         // trailing '#'
-                const uint32_t c = probe(node, kTokHash);
-                if (c != kNone) {                        // a literal "#" level stored in the tree wins
-                    if (node != 0) emit(2 * node);       // parent match of the node we stand on
-                    emit(2 * c);
-                } else {
-                    emit(node == 0 ? 2 * rv.n_nodes : 2 * node + 1);
-                }
-                back = true;
-            } else if (t == kTokPlus) {
-                const uint32_t c = probe(node, kTokPlus);
-                if (c != kNone) { stk_set(d, 0, 0); if (int64_t(d) > top) top = d; node = c; d++; continue; }
-                const uint32_t b = rv.child_off[node];
-                const uint32_t e = node == 0 ? b + rv.root_nonmeta : rv.child_off[node + 1];
-                if (int64_t(d) > top) top = d;
-                if (b == e) { stk_set(d, 0, 0); back = true; }
-                else {
-                    stk_set(d, b + 1, e);
-                    node = rv.child_ids[b]; d++;
-                    continue;
-                }
-            } else {
-                const uint32_t c = t == kTokUnknown ? kNone : probe(node, t);
-                if (c != kNone) { node = c; d++; continue; }
-                back = true;
-            }
+            r.e0 = node == 0 ? 2 * rv.n_nodes : 2 * node + 1;
         }
-        if (back) {
-            // resume the deepest '+' level that still has children.  Every '+' level at or
-            // below `top` has been initialised on arrival (pushed, or zeroed when not pushed).
-            bool found = false;
-            for (int64_t s = top; s >= 0; --s) {
-                if (tok_at(uint32_t(s)) != kTokPlus) continue;
-                uint32_t cur, end;
-                stk_get(uint32_t(s), cur, end);
-                if (cur < end) {
-                    stk_set(uint32_t(s), cur + 1, end);
-                    node = rv.child_ids[cur]; d = uint32_t(s) + 1; top = s;
-                    found = true;
-                    break;
-                }
-            }
-            if (!found) break;
-        }
+        return r;
     }
-    return visited;
+    if (tok == kTokPlus) {
+        const uint32_t c = probe(node, kTokPlus);
+        if (c != kNone) { r.cnt = 1; r.payload = c | kLitFlag; return r; }
+        const uint32_t b = rv.child_off[node];
+        const uint32_t e = node == 0 ? b + rv.root_nonmeta : rv.child_off[node + 1];
+        r.cnt = e - b; r.payload = b;
+        return r;
+    }
+    if (tok == kTokUnknown) return r;
+    const uint32_t c = probe(node, tok);
+    if (c != kNone) { r.cnt = 1; r.payload = c | kLitFlag; }
+    return r;
+}
+
+// k-th item an expansion (cnt, payload) contributes to the next frontier.
+RGR_HD inline uint32_t retain_child(const RetainView& rv, uint32_t payload, uint32_t k) {
+    return (payload & kLitFlag) ? (payload & ~kLitFlag) : rv.child_ids[payload + k];
 }
 
 // j-th matched filter of chunk-local topic t (slots are j-major; topics whose count

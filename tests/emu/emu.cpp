@@ -78,14 +78,16 @@ int32_t emu_subscribe_bulk(void* ev, const uint8_t* blob, const uint64_t* offs, 
 namespace {
 // The chunk / overflow / window / tile orchestration of c_abi.cpp, sequential on the host.
 // walk_one(gt, ovf_pass, staged_words, rel, s_path, emit) runs the per-lane walk of topic gt.
-template <class WalkOne>
+// With prefill != nullptr the walk is skipped and prefill(begin, cn, pair_cnt, ovf_base, arena)
+// provides every item's descriptor list in the arena (slot capacity 0), as the retain rounds do.
+template <class WalkOne, class Prefill>
 int32_t run_pipeline(Emu* e, uint32_t n, const std::vector<uint64_t>& tok_off, const std::vector<uint8_t>& tflags, const TrieView& tv,
-                     WalkOne walk_one, uint64_t** hit_offsets_out, rgr_tuple** tuples_out, uint64_t* n_hits_out,
+                     WalkOne walk_one, Prefill prefill, bool use_prefill, uint64_t** hit_offsets_out, rgr_tuple** tuples_out, uint64_t* n_hits_out,
                      uint64_t** pair_offsets_out, uint32_t** pair_fids_out) {
     std::vector<uint64_t> hit_offsets(size_t(n) + 1, 0), pair_offsets(size_t(n) + 1, 0);
     std::vector<rgr_tuple> tuples;
     std::vector<uint32_t> pair_fids;
-    const uint32_t C = e->slot_cap;
+    const uint32_t C = use_prefill ? 0 : e->slot_cap;
     for (uint32_t begin = 0; begin < n; begin += e->chunk_topics) {
         const uint32_t cn = std::min<uint32_t>(e->chunk_topics, n - begin);
         std::vector<uint32_t> slots(size_t(C) * cn, 0xDEADBEEF), pair_cnt(cn, 0), hit_cnt(cn), pair_live(cn), ovf_list;
@@ -114,10 +116,15 @@ int32_t run_pipeline(Emu* e, uint32_t n, const std::vector<uint64_t>& tok_off, c
                 if (cnt > C) { ovf_list.push_back(tl); ovf_base[tl] = ovf_cursor; ovf_cursor += cnt; }
             }
         };
-        for (uint32_t tl = 0; tl < cn; ++tl) walk(tl, false);
-        arena.assign(ovf_cursor + 1, 0xDEADBEEF);
-        for (uint32_t tl : ovf_list) walk(tl, true);
-        e->overflow_topics += ovf_list.size();
+        if (use_prefill) {
+            prefill(begin, cn, pair_cnt, ovf_base, arena);
+            arena.push_back(0xDEADBEEF);
+        } else {
+            for (uint32_t tl = 0; tl < cn; ++tl) walk(tl, false);
+            arena.assign(ovf_cursor + 1, 0xDEADBEEF);
+            for (uint32_t tl : ovf_list) walk(tl, true);
+            e->overflow_topics += ovf_list.size();
+        }
         uint32_t err = 0;
         ChunkArrays ca{};
         ca.n = cn; ca.slot_cap = C; ca.slots = slots.data(); ca.pair_cnt = pair_cnt.data(); ca.hit_cnt = hit_cnt.data();
@@ -237,7 +244,8 @@ int32_t emu_match(void* ev, const uint8_t* blob, const uint64_t* offs, uint32_t 
                 e1 = U4{en.hash_fid, en.term_fid, en.lit_cnt, en.lit_xor};
             });
     };
-    return run_pipeline(e, n, tok_off, tflags, tv, walk_one, hit_offsets_out, tuples_out, n_hits_out, pair_offsets_out, pair_fids_out);
+    auto no_prefill = [](uint32_t, uint32_t, std::vector<uint32_t>&, std::vector<uint64_t>&, std::vector<uint32_t>&) {};
+    return run_pipeline(e, n, tok_off, tflags, tv, walk_one, no_prefill, false, hit_offsets_out, tuples_out, n_hits_out, pair_offsets_out, pair_fids_out);
 }
 
 // ---- RetainTree twin -----------------------------------------------------------------
@@ -267,7 +275,6 @@ int32_t emu_retain_match(void* ev, const uint8_t* blob, const uint64_t* offs, ui
         status[i] = (tflags[i] & kTopicInvalid) ? RGR_TOPIC_INVALID : RGR_TOPIC_OK;
     }
     tokens.push_back(0);
-    std::vector<uint32_t> stack(2 * tokens.size(), 0xDEADBEEF);
     RetainImage img;
     e->retain.compile(img);
     img.vals.push_back(SubEntry{0, 0});
@@ -276,22 +283,44 @@ int32_t emu_retain_match(void* ev, const uint8_t* blob, const uint64_t* offs, ui
                   img.n_nodes, img.desc.data(), img.vals.data()};
     TrieView tv{};
     tv.filt = rv.desc; tv.subs = rv.vals;
-    auto walk_one = [&](uint32_t gt, uint64_t, uint64_t, std::vector<uint32_t>&, auto& emit) {
-        const uint64_t off0 = tok_off[gt];
-        const uint32_t L = uint32_t(tok_off[gt + 1] - off0);
-        return retain_walk_filter(
-            rv, L, [&](uint32_t d) { return tokens[off0 + d]; },
-            [&](uint32_t d, uint32_t& cur, uint32_t& end) { cur = stack[2 * (off0 + d)]; end = stack[2 * (off0 + d) + 1]; },
-            [&](uint32_t d, uint32_t cur, uint32_t end) { stack[2 * (off0 + d)] = cur; stack[2 * (off0 + d) + 1] = end; }, emit,
-            [&](uint32_t parent, uint32_t token) -> uint32_t {
-                for (uint32_t s = edge_hash(parent, token) & rv.mask;; s = (s + 1) & rv.mask) {
-                    const REdge& en = rv.edges[s];
-                    if (en.parent == kEdgeEmpty) return kNone;
-                    if (en.parent == parent && en.token == token) return en.child;
-                }
-            });
+    auto probe = [&](uint32_t parent, uint32_t token) -> uint32_t {
+        for (uint32_t s = edge_hash(parent, token) & rv.mask;; s = (s + 1) & rv.mask) {
+            const REdge& en = rv.edges[s];
+            if (en.parent == kEdgeEmpty) return kNone;
+            if (en.parent == parent && en.token == token) return en.child;
+        }
     };
-    return run_pipeline(e, n, tok_off, tflags, tv, walk_one, hit_offsets_out, tuples_out, n_hits_out, nullptr, nullptr);
+    // the level-synchronous frontier rounds of c_abi.cpp::retain_rounds, sequentially
+    auto prefill = [&](uint32_t begin, uint32_t cn, std::vector<uint32_t>& pair_cnt, std::vector<uint64_t>& ovf_base, std::vector<uint32_t>& arena) {
+        std::vector<uint32_t> ff(cn), fn(cn, 0);
+        for (uint32_t i = 0; i < cn; ++i) ff[i] = i;
+        arena.clear();
+        for (uint32_t d = 0; !ff.empty(); ++d) {
+            const size_t m = ff.size();
+            std::vector<RetainStep> st(m);
+            for (size_t i = 0; i < m; ++i) {
+                const uint32_t gt = begin + ff[i];
+                st[i] = RetainStep{0, 0, kNone, kNone};
+                if (tflags[gt] & kTopicInvalid) continue;
+                const uint64_t off0 = tok_off[gt];
+                const uint32_t L = uint32_t(tok_off[gt + 1] - off0);
+                st[i] = retain_step(rv, fn[i], d, L, d < L ? tokens[off0 + d] : 0u, probe);
+            }
+            e->visited += m;
+            // emit (item order) + next frontier (scatter at the exclusive scan of cnt)
+            std::vector<uint32_t> nf, nn;
+            for (size_t i = 0; i < m; ++i) {
+                const uint32_t f = ff[i];
+                if (i == 0 || ff[i - 1] != f) ovf_base[f] = arena.size();
+                if (st[i].e0 != kNone) { arena.push_back(st[i].e0); pair_cnt[f]++; }
+                if (st[i].e1 != kNone) { arena.push_back(st[i].e1); pair_cnt[f]++; }
+                for (uint32_t k = 0; k < st[i].cnt; ++k) { nf.push_back(f); nn.push_back(retain_child(rv, st[i].payload, k)); }
+            }
+            ff.swap(nf); fn.swap(nn);
+        }
+    };
+    auto no_walk = [](uint32_t, uint64_t, uint64_t, std::vector<uint32_t>&, auto&) { return 0u; };
+    return run_pipeline(e, n, tok_off, tflags, tv, no_walk, prefill, true, hit_offsets_out, tuples_out, n_hits_out, nullptr, nullptr);
 }
 
 }  // extern "C"
