@@ -323,6 +323,8 @@ ChunkArrays make_chunk_arrays(rgr_batch* b, uint32_t n) {
     c.ovf_arena = b->arena.as<uint32_t>();
     c.ovf_arena_cap = b->arena_cap;
     c.error_flag = &sc->error;
+    c.big_list = b->r_big.as<uint32_t>();
+    c.big_count = &sc->big_count;
     c.pair_src = b->pair_src.as<uint32_t>();
     c.pair_topic = b->pair_topic.as<uint32_t>();
     c.pair_off = b->pair_off.as<uint64_t>();
@@ -340,6 +342,7 @@ void ensure_chunk_buffers(rgr_batch* b, uint32_t n) {
     b->ovf_list.ensure(size_t(n) * 4);
     b->ovf_base.ensure(size_t(n) * 8);
     b->scalars.ensure(sizeof(Scalars));
+    b->r_big.ensure(size_t(n) * 4);
     if (b->arena_cap == 0) { b->arena_cap = 1u << 20; b->arena.ensure(b->arena_cap * 4); }
     const uint32_t nb = (n + scan_block_topics() - 1) / scan_block_topics();
     b->scan_tmp.ensure((size_t(nb) + 1) * 16);

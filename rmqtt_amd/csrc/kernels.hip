@@ -273,7 +273,37 @@ __global__ __launch_bounds__(256) void retain_emit_kernel(RetainRound r, const u
 // --------------------------------------------------------------------------- count
 __global__ __launch_bounds__(256) void count_kernel(TrieView tv, ChunkArrays c) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t < c.n) count_topic(tv, c, t);
+    if (t >= c.n) return;
+    if (c.pair_cnt[t] > kBigPairs) { c.big_list[atomicAdd(c.big_count, 1u)] = t; return; }   // -> count_big_kernel
+    count_topic(tv, c, t);
+}
+
+// Long pair lists (a retained-path '+' over a wide node emits one descriptor per child; a hot
+// publish topic can match hundreds of filters): one block per topic instead of one lane.
+__global__ __launch_bounds__(256) void count_big_kernel(TrieView tv, ChunkArrays c) {
+    __shared__ unsigned long long s_a[4], s_b[4];
+    const uint32_t nb = *c.big_count;
+    for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+        const uint32_t t = c.big_list[b];
+        const uint32_t cnt = c.pair_cnt[t];
+        if (c.ovf_base[t] + cnt > c.ovf_arena_cap && cnt > c.slot_cap) {
+            if (threadIdx.x == 0) { *c.error_flag = 1; c.hit_cnt[t] = 0; c.pair_live[t] = 0; }
+            continue;
+        }
+        unsigned long long hits = 0, live = 0;
+        for (uint32_t j = threadIdx.x; j < cnt; j += 256) {
+            const uint32_t n = tv.filt[pair_fid(c, t, cnt, j)].count;
+            hits += n; live += n != 0;
+        }
+        hits = wave_sum(hits); live = wave_sum(live);
+        if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = hits; s_b[threadIdx.x >> 6] = live; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            c.hit_cnt[t] = uint32_t(s_a[0] + s_a[1] + s_a[2] + s_a[3]);
+            c.pair_live[t] = uint32_t(s_b[0] + s_b[1] + s_b[2] + s_b[3]);
+        }
+        __syncthreads();
+    }
 }
 
 // --------------------------------------------------------------------------- scan
@@ -354,7 +384,49 @@ __global__ __launch_bounds__(kScanThreads) void scan_down_kernel(ChunkArrays c, 
 // --------------------------------------------------------------------------- compact
 __global__ __launch_bounds__(256) void compact_kernel(TrieView tv, ChunkArrays c, uint32_t topic_base) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t < c.n) compact_topic(tv, c, topic_base, t);
+    if (t >= c.n) return;
+    if (c.pair_cnt[t] > kBigPairs) {                       // -> compact_big_kernel (list built by count_kernel)
+        if (t == c.n - 1) c.pair_off[c.pair_base[c.n]] = c.hit_off[c.n];
+        return;
+    }
+    compact_topic(tv, c, topic_base, t);
+}
+
+// Order-preserving compaction of one long pair list by a whole block: 256 pairs per step, block
+// exclusive scan of (live, count), carried across steps.
+__global__ __launch_bounds__(256) void compact_big_kernel(TrieView tv, ChunkArrays c, uint32_t topic_base) {
+    __shared__ unsigned long long s_l[4], s_c[4];
+    const uint32_t nb = *c.big_count;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
+        const uint32_t t = c.big_list[b];
+        const uint32_t cnt = c.pair_cnt[t];
+        uint64_t p0 = c.pair_base[t], o0 = c.hit_off[t];
+        for (uint32_t j0 = 0; j0 < cnt; j0 += 256) {
+            const uint32_t j = j0 + threadIdx.x;
+            FilterDesc fd{0, 0};
+            if (j < cnt) fd = tv.filt[pair_fid(c, t, cnt, j)];
+            unsigned long long xl = fd.count != 0, xc = fd.count;
+            const unsigned long long ml = xl, mc = xc;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned long long yl = __shfl_up(xl, o, 64), yc = __shfl_up(xc, o, 64);
+                if (lane >= o) { xl += yl; xc += yc; }
+            }
+            if (lane == 63) { s_l[w] = xl; s_c[w] = xc; }
+            __syncthreads();
+            unsigned long long pl = 0, pc = 0, tl = 0, tc = 0;
+            for (int i = 0; i < 4; ++i) { if (i < w) { pl += s_l[i]; pc += s_c[i]; } tl += s_l[i]; tc += s_c[i]; }
+            if (ml) {
+                const uint64_t p = p0 + pl + (xl - ml);
+                c.pair_src[p] = fd.begin;
+                c.pair_topic[p] = topic_base + t;
+                c.pair_off[p] = o0 + pc + (xc - mc);
+            }
+            p0 += tl; o0 += tc;
+            __syncthreads();
+        }
+    }
 }
 
 // --------------------------------------------------------------------------- tiles
@@ -465,7 +537,10 @@ void launch_retain_emit(const RetainRound& r, const uint64_t* epos, uint64_t g_b
 
 void launch_count(const TrieView& t, const ChunkArrays& c, void* stream) {
     if (c.n == 0) return;
-    count_kernel<<<(c.n + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(t, c);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipMemsetAsync(c.big_count, 0, 4, s);
+    count_kernel<<<(c.n + 255) / 256, 256, 0, s>>>(t, c);
+    count_big_kernel<<<512, 256, 0, s>>>(t, c);
 }
 
 void launch_scan(const ChunkArrays& c, uint64_t* block_tmp, void* stream) {
@@ -479,7 +554,9 @@ void launch_scan(const ChunkArrays& c, uint64_t* block_tmp, void* stream) {
 
 void launch_compact(const TrieView& t, const ChunkArrays& c, uint32_t topic_base, void* stream) {
     if (c.n == 0) return;
-    compact_kernel<<<(c.n + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(t, c, topic_base);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    compact_kernel<<<(c.n + 255) / 256, 256, 0, s>>>(t, c, topic_base);
+    compact_big_kernel<<<512, 256, 0, s>>>(t, c, topic_base);
 }
 
 void launch_tiles(const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint32_t* tile_first, void* stream) {

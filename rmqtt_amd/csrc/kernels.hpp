@@ -28,6 +28,7 @@ constexpr uint32_t kTokFirst = 2;
 constexpr uint32_t kTokUnknown = 0xFFFFFFFFu;   // level string absent from the dictionary
 constexpr uint32_t kEdgeEmpty = 0xFFFFFFFFu;
 constexpr uint32_t kEdgeTomb = 0xFFFFFFFEu;
+constexpr uint32_t kBigPairs = 64;           // per-topic pair lists longer than this get a whole block
 
 struct alignas(16) EdgeEntry {
     uint32_t parent;      // parent node id | kEdgeEmpty | kEdgeTomb
@@ -126,6 +127,9 @@ struct ChunkArrays {
     const uint32_t* ovf_arena;
     uint64_t ovf_arena_cap;
     uint32_t* error_flag;
+    // topics with more than kBigPairs matched filters are counted / compacted by a whole block
+    uint32_t* big_list;          // [n]
+    uint32_t* big_count;         // device scalar (zeroed before the count kernel)
     // dense (topic, subscriber-run) pairs
     uint32_t* pair_src;          // [P] subs[] index of the run
     uint32_t* pair_topic;        // [P] batch-global topic index

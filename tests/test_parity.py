@@ -124,6 +124,27 @@ def test_random_tables_all_paths(kind, opts):
     p.check(*pack(topics), what=str(opts) + " after churn")
 
 
+def test_long_pair_lists(kind):
+    """A topic matched by hundreds of filters (every '+' pattern over 8 levels = 256 filters, plus
+    their '#' truncations): exercises slot overflow and the block-cooperative count/compact."""
+    import itertools
+    p = Pair(kind)
+    sub = 0
+    for mask in itertools.product([0, 1], repeat=8):
+        f = "/".join("+" if m else "a" for m in mask)
+        for k in range(1 + (sub % 3)):
+            p.add(f, f"c{sub}", sub, qos=sub % 3)
+            sub += 1
+        if sum(mask) <= 2:
+            for d in range(1, 8):
+                p.add("/".join(f.split("/")[:d]) + "/#", f"h{sub}", sub)
+                sub += 1
+    p.commit()
+    topics = ["a/a/a/a/a/a/a/a", "a/a/a/a/a/a/a/b", "b/a/a/a/a/a/a/a", "a/a/a/a", "a/a/a/a/a/a/a/a/a", "$a/a/a/a/a/a/a/a"] * 3
+    exp, got = p.check(*pack(topics))
+    assert exp["hit_offsets"][1] > 600          # the first topic really has a long list
+
+
 def test_matched_filter_order(kind):   # TopicTree::matches order incl. duplicates (App. A.2 / A.4)
     p = Pair(kind)
     fl = ["a/b", "a/#", "a/+", "+/b", "#", "+/#", "a/b/#", "+/+", "a/+/#", "test/+", "test/#"]

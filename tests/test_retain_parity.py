@@ -83,6 +83,23 @@ def test_wildcard_levels_stored_in_tree(kind):
     check(b, t, ["x/+", "x/+/k", "x/#", "w/#", "w/+", "#", "+", "+/q", "+/#", "x/+/#"])
 
 
+def test_wide_nodes_long_descriptor_lists(kind):
+    """'+' over nodes with hundreds / thousands of children: big frontier expansions and
+    descriptor lists far beyond 64 entries per filter (block-cooperative count/compact)."""
+    b = make_backend(kind)
+    t = orc.RetainTree()
+    i = 0
+    for a in range(3):
+        for k in range(1500 if a == 0 else 40):
+            for leaf in (["x"] if k % 3 else ["x", "y/z"]):
+                s = f"r{a}/k{k}/{leaf}"
+                b.retain_add(s, i); t.insert(s, i); i += 1
+        b.retain_add(f"r{a}", i); t.insert(f"r{a}", i); i += 1
+    b.retain_commit()
+    exp = check(b, t, ["r0/+/x", "r0/+", "r0/+/#", "+/+/x", "+/+/+", "+/+/y/z", "r0/+/y/+", "r1/+/x", "+/k7/x", "#", "r0/#", "+/+/#", "+/#"])
+    assert len(exp[0]) == 1500 and len(exp[3]) == 1580
+
+
 @pytest.mark.parametrize("opts", [dict(), dict(slot_cap=1, chunk_topics=100, window_hits=50, tile=8), dict(slot_cap=2, window_hits=1)])
 def test_random_retain_tables(kind, opts):
     rng = random.Random(5)
