@@ -137,7 +137,7 @@ def main():
 
     class _DevTuples:   # zero-copy torch view of a window's device tuples
         def __init__(self, ptr, n):
-            self.__cuda_array_interface__ = {"shape": (n, 3), "typestr": "<i4", "data": (ptr, True), "version": 2}
+            self.__cuda_array_interface__ = {"shape": (n, 3), "typestr": "<i4", "data": (ptr, False), "version": 2}
 
     def step_gather_tuples():
         """all-gatherv of every window's tuples (RCCL has no allgatherv: counts + padded all_gather)."""
