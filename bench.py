@@ -220,8 +220,20 @@ def main():
     ach = exp_gbs if dominant == "expand_kernel" else walk_gbs
     launches = st["expand_launches"] if dominant == "expand_kernel" else st["walk_launches"]
     dom_s = exp_s if dominant == "expand_kernel" else walk_s
+    # HBM traffic per launch from the PMC passes of profiles/collect_pmc.sh (FETCH_SIZE / WRITE_SIZE are
+    # collected in separate rocprofv3 runs, so they cannot be measured inside this process): measured
+    # bytes per hit x hits per launch.  null until a calibration file for this kernel exists.
+    traffic = None
+    try:
+        cal = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[dominant]
+        if dominant == "expand_kernel" and launches:
+            traffic = int((cal["write_bytes_per_hit"] + cal["fetch_bytes_per_hit"]) * st["hits"] / launches)
+        elif launches:
+            traffic = int(cal["bytes_per_topic"] * st["topics"] / launches)
+    except (OSError, KeyError, ValueError):
+        pass
     roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "launches": int(launches), "avg_launch_ms": round(dom_s * 1e3 / max(1, launches), 4),
                 "alg_bytes_per_launch": int((st["alg_bytes_expand"] if dominant == "expand_kernel" else st["alg_bytes_walk"]) / max(1, launches)),
                 "walk_GBps": round(walk_gbs, 1), "expand_GBps": round(exp_gbs, 1)}
