@@ -7,7 +7,7 @@ A "step" is one pass of the hot path (trie walk + subscriber expansion into
 (topic_idx, sub_id, qos) tuples) over one batch of publish topics whose '/'-tokenised
 form is already resident in HBM.  Workload at N=1: BASELINE.json configs[2] — 10 M
 subscriptions with mixed '+'/'#' (seeded generator of SURVEY.md §8(d)), 10 M publishes,
-1x MI355X.  N>1: the same table hash-sharded by the first two topic levels, publishes
+1x MI355X.  N>1: the same table hash-sharded by the first three topic levels, publishes
 routed to their owner rank (strong scaling: total work fixed); ranks exchange per-rank
 hit counts (all-gather over RCCL), tuples stay on the owning GPU unless --gather tuples.
 
@@ -238,9 +238,9 @@ def main():
                 "alg_bytes_per_launch": int((st["alg_bytes_expand"] if dominant == "expand_kernel" else st["alg_bytes_walk"]) / max(1, launches)),
                 "walk_GBps": round(walk_gbs, 1), "expand_GBps": round(exp_gbs, 1)}
 
-    # ---- CPU baseline: the oracle ("port"), bounded sample of the same workload, this host's cores
+    # ---- CPU baseline: the oracle ("port"), bounded sample of the same workload, this host's cores (N=1 only)
     cpu = None
-    if args.cpu_sample != 0:
+    if args.cpu_sample != 0 and world == 1:
         from oracle import oracle as orc
         cores = args.cpu_threads or os.cpu_count() or 1
         t = time.time()
@@ -272,7 +272,7 @@ def main():
         "dtype": "u32", "data": "synthetic",
         "config": {"workload": f"BASELINE.json configs[{cfg - 1}]: {n_sub} subscriptions (p_plus/level {c['p_plus']}, p_hash {c['p_hash']}, "
                                f"Zipf tokens s=1.1, Zipf clients s=1.0), {n_pub} publish topics, seeds 0x{wl.SUB_SEED + cfg:X}/0x{wl.PUB_SEED + cfg:X}",
-                   "subscriptions": n_sub, "publishes": n_pub, "sharding": f"first-two-level hash x{world}" if world > 1 else "none",
+                   "subscriptions": n_sub, "publishes": n_pub, "sharding": f"hash of the first {shard.KEY_LEVELS} levels x{world}" if world > 1 else "none",
                    "gather": args.gather if world > 1 else "n/a", "windows_per_step": int(nwin)},
         "hits_per_step": int(total_hits), "hits_per_s": round(total_hits * K / elapsed, 1),
         "mean_hits_per_topic": round(total_hits / max(1, total_topics), 2),

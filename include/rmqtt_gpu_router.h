@@ -227,14 +227,17 @@ int32_t rgr_retain_batch_create(rgr_handle* h, const uint8_t* filters_blob, cons
 void rgr_retain_result_free(rgr_retain_result* r);
 
 /* ---- multi-GPU sharding rule (host-side helper, no device work) -------------------------
- * Table and publishes shard by a hash of the first TWO topic levels (a
- * first-level-only hash is too skewed under Zipf level-0 tokens):
- *   topic  -> shard = H(level0, level1 | none) mod n_shards
- *   filter -> the same, unless level0 or level1 is a wildcard: then -1 = replicate on
- *             every shard.  A topic's complete match set then lives on its owner shard.
- * out[i] in [0,n_shards) or -1; invalid topics/filters get shard 0 (they match nothing). */
+ * Table and publishes shard by a hash of the first `key_levels` topic levels (SURVEY.md §8(e):
+ * a first-level-only hash is far too skewed under Zipf level-0 tokens; 3 levels keep the
+ * hottest shard key near 1 % of the hits):
+ *   topic  -> shard = H(level0 .. level_{k-1} | shorter topics hash what they have) mod n_shards
+ *   filter -> the same, unless one of its first `key_levels` levels is a wildcard: then -1 =
+ *             replicate on every shard.  A topic's complete match set then lives on its owner
+ *             shard, so the data path needs no collective.
+ * out[i] in [0,n_shards) or -1; invalid topics/filters get a shard too (they match nothing).
+ * key_levels: 1..8 (0 = default 3). */
 int32_t rgr_shard_assign(const uint8_t* blob, const uint64_t* offsets, uint64_t n, uint32_t n_shards, int32_t is_filter,
-                         int32_t* out);
+                         uint32_t key_levels, int32_t* out);
 
 /* ---- observability ------------------------------------------------------------------------ */
 int32_t rgr_stats_get(rgr_handle* h, rgr_stats* out);

@@ -117,7 +117,7 @@ def lib():
         L.rgr_retain_match_batch.argtypes = [vp, vp, vp, u32, C.POINTER(RetainResult)]
         L.rgr_retain_result_free.argtypes = [C.POINTER(RetainResult)]; L.rgr_retain_result_free.restype = None
         L.rgr_retain_batch_create.argtypes = [vp, vp, vp, u32, C.POINTER(vp)]
-        L.rgr_shard_assign.argtypes = [vp, vp, u64, u32, i32, vp]
+        L.rgr_shard_assign.argtypes = [vp, vp, u64, u32, i32, u32, vp]
         L.rgr_stats_get.argtypes = [vp, C.POINTER(Stats)]
         L.rgr_stats_reset.argtypes = [vp]
         _LIB = L

@@ -116,7 +116,7 @@ struct rgr_batch {
     // chunk work buffers
     DevBuf slots, pair_cnt, hit_cnt, pair_live, hit_off, pair_base, ovf_list, ovf_base, scalars, arena;
     DevBuf pair_src, pair_topic, pair_off, tile_first, out, scan_tmp;
-    DevBuf rf_filter[2], rf_node[2], r_cnt, r_payload, r_ecnt, r_e0, r_e1, r_out_off, r_epos, r_big;   // retain frontier rounds
+    DevBuf rf_filter[2], rf_node[2], r_cnt, r_payload, r_ecnt, r_e0, r_e1, r_out_off, r_epos, r_big, r_end;   // retain frontier rounds
     PinnedBuf h_hit_off, h_pair_base, h_scalars;
     uint64_t arena_cap = 0;
     // pass state
@@ -356,7 +356,7 @@ void ensure_chunk_buffers(rgr_batch* b, uint32_t n) {
 void retain_rounds(rgr_batch* b, uint32_t begin, uint32_t n) {
     const RetainView& rv = b->repoch->view;
     Scalars* sc = b->scalars.as<Scalars>();
-    RGR_HIP(hipMemsetAsync(b->pair_cnt.p, 0, size_t(n) * 4, b->stream));
+    b->r_end.ensure(size_t(n) * 8);
     uint64_t g_total = 0, m = n, visited = 0;
     int cur = 0;
     for (uint32_t d = 0; m > 0; ++d) {
@@ -386,7 +386,7 @@ void retain_rounds(rgr_batch* b, uint32_t begin, uint32_t n) {
             b->arena.ensure_preserve(b->arena_cap * 4, g_total * 4);
         }
         launch_retain_emit(r, b->r_epos.as<uint64_t>(), g_total, b->arena.as<uint32_t>(), b->ovf_base.as<uint64_t>(),
-                           b->pair_cnt.as<uint32_t>(), b->stream);
+                           b->r_end.as<uint64_t>(), b->stream);
         g_total += e_r;
         if (m_next) {
             b->rf_filter[cur ^ 1].ensure(m_next * 4);
@@ -399,6 +399,7 @@ void retain_rounds(rgr_batch* b, uint32_t begin, uint32_t n) {
         cur ^= 1;
         m = m_next;
     }
+    launch_retain_finish(n, b->ovf_base.as<uint64_t>(), b->r_end.as<uint64_t>(), b->pair_cnt.as<uint32_t>(), b->stream);
     RGR_HIP(hipGetLastError());
     b->local.visited_nodes += visited;
     b->local.alg_bytes_walk += 24 * visited;
@@ -905,26 +906,26 @@ void rgr_filters_result_free(rgr_filters_result* r) {
 }
 
 // ------------------------------------------------------------------ sharding rule
-int32_t rgr_shard_assign(const uint8_t* blob, const uint64_t* offsets, uint64_t n, uint32_t n_shards, int32_t is_filter, int32_t* out) {
+int32_t rgr_shard_assign(const uint8_t* blob, const uint64_t* offsets, uint64_t n, uint32_t n_shards, int32_t is_filter,
+                         uint32_t key_levels, int32_t* out) {
     return guarded([&]() -> int32_t {
-        if ((n && (!blob || !offsets || !out)) || n_shards == 0) return fail(RGR_EINVAL, "rgr_shard_assign: bad argument");
+        if ((n && (!blob || !offsets || !out)) || n_shards == 0 || key_levels > 8) return fail(RGR_EINVAL, "rgr_shard_assign: bad argument");
+        const uint32_t K = key_levels ? key_levels : 3;
         for (uint64_t i = 0; i < n; ++i) {
             const std::string_view s(reinterpret_cast<const char*>(blob) + offsets[i], offsets[i + 1] - offsets[i]);
-            const size_t p0 = s.find('/');
-            const std::string_view l0 = s.substr(0, p0);
-            std::string_view l1;
-            bool has1 = false;
-            if (p0 != std::string_view::npos) {
-                const size_t p1 = s.find('/', p0 + 1);
-                l1 = s.substr(p0 + 1, p1 == std::string_view::npos ? std::string_view::npos : p1 - p0 - 1);
-                has1 = true;
-            }
-            auto wild = [](std::string_view l) { return l == "+" || l == "#"; };
-            if (is_filter && (wild(l0) || (has1 && wild(l1)))) { out[i] = -1; continue; }
             uint64_t h = 0xcbf29ce484222325ull;
-            for (unsigned char ch : l0) { h ^= ch; h *= 0x100000001b3ull; }
-            h ^= 0x2f; h *= 0x100000001b3ull;
-            if (has1) { for (unsigned char ch : l1) { h ^= ch; h *= 0x100000001b3ull; } h ^= 0x01; h *= 0x100000001b3ull; }
+            bool replicate = false;
+            size_t start = 0;
+            for (uint32_t l = 0; l < K; ++l) {
+                const size_t pos = s.find('/', start);
+                const std::string_view lv = s.substr(start, pos == std::string_view::npos ? std::string_view::npos : pos - start);
+                if (is_filter && (lv == "+" || lv == "#")) { replicate = true; break; }
+                for (unsigned char ch : lv) { h ^= ch; h *= 0x100000001b3ull; }
+                h ^= 0x2f; h *= 0x100000001b3ull;                 // level terminator
+                if (pos == std::string_view::npos) break;          // shorter than K levels
+                start = pos + 1;
+            }
+            if (replicate) { out[i] = -1; continue; }
             h ^= h >> 32; h *= 0xd6e8feb86659fd93ull; h ^= h >> 32;
             out[i] = int32_t(h % n_shards);
         }

@@ -73,11 +73,6 @@ __global__ __launch_bounds__(kScanThreads) void scan1_reduce_kernel(const uint32
     __syncthreads();
     if (threadIdx.x == 0) { unsigned long long r = 0; for (int i = 0; i < kScanThreads / 64; ++i) r += s_w[i]; block_tmp[blockIdx.x] = r; }
 }
-__global__ void scan1_spine_kernel(uint64_t* block_tmp, uint32_t nblocks) {
-    unsigned long long a = 0;
-    for (uint32_t i = 0; i < nblocks; ++i) { const unsigned long long x = block_tmp[i]; block_tmp[i] = a; a += x; }
-    block_tmp[nblocks] = a;
-}
 __global__ __launch_bounds__(kScanThreads) void scan1_down_kernel(const uint32_t* __restrict__ in, uint64_t* __restrict__ out, uint32_t n,
                                                                   const uint64_t* block_tmp, uint32_t nblocks) {
     __shared__ unsigned long long s_w[kScanThreads / 64];
@@ -254,20 +249,27 @@ __global__ __launch_bounds__(256) void retain_big_kernel(RetainView rv, RetainRo
 
 // Descriptors of this round appended to the arena in item order.  A filter's items are
 // contiguous in the frontier and it emits only in its final round, so the exclusive scan value
-// of its first item is the base of its descriptor list.
+// at its first item is the base of its descriptor list and the value after its last item the
+// end: no atomics.  Earlier rounds write base == end; the final round overwrites both.
 __global__ __launch_bounds__(256) void retain_emit_kernel(RetainRound r, const uint64_t* __restrict__ epos, uint64_t g_base,
                                                           uint32_t* __restrict__ arena, uint64_t* __restrict__ ovf_base,
-                                                          uint32_t* __restrict__ pair_cnt) {
+                                                          uint64_t* __restrict__ ovf_end) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= r.m) return;
     const uint32_t f = r.f_filter ? r.f_filter[i] : i;
     uint64_t p = g_base + epos[i];
-    if (i == 0 || (r.f_filter ? r.f_filter[i - 1] : i - 1) != f) ovf_base[f] = p;
     const uint32_t n = r.ecnt[i];
+    if (i == 0 || (r.f_filter ? r.f_filter[i - 1] : i - 1) != f) ovf_base[f] = p;
+    if (i == r.m - 1 || (r.f_filter ? r.f_filter[i + 1] : i + 1) != f) ovf_end[f] = p + n;
     if (!n) return;
     if (r.e0[i] != kNone) arena[p++] = r.e0[i];
     if (r.e1[i] != kNone) arena[p++] = r.e1[i];
-    atomicAdd(&pair_cnt[f], n);
+}
+
+__global__ __launch_bounds__(256) void retain_finish_kernel(uint32_t n, const uint64_t* __restrict__ ovf_base,
+                                                            const uint64_t* __restrict__ ovf_end, uint32_t* __restrict__ pair_cnt) {
+    const uint32_t f = blockIdx.x * 256 + threadIdx.x;
+    if (f < n) pair_cnt[f] = uint32_t(ovf_end[f] - ovf_base[f]);
 }
 
 // --------------------------------------------------------------------------- count
@@ -334,14 +336,43 @@ __global__ __launch_bounds__(kScanThreads) void scan_reduce_kernel(ChunkArrays c
     if (threadIdx.x == 0) { block_tmp[2 * blockIdx.x] = r.a; block_tmp[2 * blockIdx.x + 1] = r.b; }
 }
 
-__global__ void scan_spine_kernel(uint64_t* block_tmp, uint32_t nblocks) {   // <<<1,1>>>: nblocks is small
-    unsigned long long a = 0, b = 0;
-    for (uint32_t i = 0; i < nblocks; ++i) {
-        const unsigned long long x = block_tmp[2 * i], y = block_tmp[2 * i + 1];
-        block_tmp[2 * i] = a; block_tmp[2 * i + 1] = b;
-        a += x; b += y;
+// Exclusive scan of the per-block sums by ONE block of 1024 threads (each thread owns a contiguous
+// slice; block-wide scan of the slice totals).  `stride` interleaved sequences are scanned at once.
+template <int STRIDE>
+__global__ __launch_bounds__(1024) void scan_spine_kernel(uint64_t* block_tmp, uint32_t nblocks) {
+    __shared__ unsigned long long s_w[STRIDE][16];
+    const uint32_t per = (nblocks + 1023) / 1024;
+    const uint32_t lo = min(threadIdx.x * per, nblocks), hi = min(lo + per, nblocks);
+    unsigned long long tot[STRIDE];
+#pragma unroll
+    for (int k = 0; k < STRIDE; ++k) tot[k] = 0;
+    for (uint32_t i = lo; i < hi; ++i)
+#pragma unroll
+        for (int k = 0; k < STRIDE; ++k) tot[k] += block_tmp[STRIDE * i + k];
+    unsigned long long x[STRIDE];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < STRIDE; ++k) {
+        x[k] = tot[k];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned long long y = __shfl_up(x[k], o, 64); if (lane >= o) x[k] += y; }
+        if (lane == 63) s_w[k][w] = x[k];
     }
-    block_tmp[2 * nblocks] = a; block_tmp[2 * nblocks + 1] = b;
+    __syncthreads();
+    unsigned long long run[STRIDE], all[STRIDE];
+#pragma unroll
+    for (int k = 0; k < STRIDE; ++k) {
+        unsigned long long pre = 0, sum = 0;
+        for (int i = 0; i < 16; ++i) { if (i < w) pre += s_w[k][i]; sum += s_w[k][i]; }
+        run[k] = pre + (x[k] - tot[k]);
+        all[k] = sum;
+    }
+    for (uint32_t i = lo; i < hi; ++i)
+#pragma unroll
+        for (int k = 0; k < STRIDE; ++k) { const unsigned long long v = block_tmp[STRIDE * i + k]; block_tmp[STRIDE * i + k] = run[k]; run[k] += v; }
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int k = 0; k < STRIDE; ++k) block_tmp[STRIDE * nblocks + k] = all[k];
 }
 
 __global__ __launch_bounds__(kScanThreads) void scan_down_kernel(ChunkArrays c, const uint64_t* block_tmp, uint32_t nblocks) {
@@ -500,7 +531,7 @@ void launch_scan_u32(const uint32_t* in, uint64_t* out, uint32_t n, uint64_t* bl
     const uint32_t nb = (n + kScanBlock - 1) / kScanBlock;
     if (nb == 0) { hipMemsetAsync(out, 0, 8, s); return; }
     scan1_reduce_kernel<<<nb, kScanThreads, 0, s>>>(in, n, block_tmp);
-    scan1_spine_kernel<<<1, 1, 0, s>>>(block_tmp, nb);
+    scan_spine_kernel<1><<<1, 1024, 0, s>>>(block_tmp, nb);
     scan1_down_kernel<<<nb, kScanThreads, 0, s>>>(in, out, n, block_tmp, nb);
 }
 
@@ -531,8 +562,12 @@ void launch_retain_next(const RetainView& t, const RetainRound& r, const uint64_
 }
 
 void launch_retain_emit(const RetainRound& r, const uint64_t* epos, uint64_t g_base, uint32_t* arena, uint64_t* ovf_base,
-                        uint32_t* pair_cnt, void* stream) {
-    if (r.m) retain_emit_kernel<<<(r.m + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(r, epos, g_base, arena, ovf_base, pair_cnt);
+                        uint64_t* ovf_end, void* stream) {
+    if (r.m) retain_emit_kernel<<<(r.m + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(r, epos, g_base, arena, ovf_base, ovf_end);
+}
+
+void launch_retain_finish(uint32_t n, const uint64_t* ovf_base, const uint64_t* ovf_end, uint32_t* pair_cnt, void* stream) {
+    if (n) retain_finish_kernel<<<(n + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(n, ovf_base, ovf_end, pair_cnt);
 }
 
 void launch_count(const TrieView& t, const ChunkArrays& c, void* stream) {
@@ -548,7 +583,7 @@ void launch_scan(const ChunkArrays& c, uint64_t* block_tmp, void* stream) {
     const uint32_t nb = (c.n + kScanBlock - 1) / kScanBlock;
     if (nb == 0) return;
     scan_reduce_kernel<<<nb, kScanThreads, 0, s>>>(c, block_tmp);
-    scan_spine_kernel<<<1, 1, 0, s>>>(block_tmp, nb);
+    scan_spine_kernel<2><<<1, 1024, 0, s>>>(block_tmp, nb);
     scan_down_kernel<<<nb, kScanThreads, 0, s>>>(c, block_tmp, nb);
 }
 

@@ -157,7 +157,8 @@ void launch_retain_step(const RetainView& t, const RetainRound& r, void* stream)
 void launch_retain_next(const RetainView& t, const RetainRound& r, const uint64_t* out_off, uint32_t* nf_filter, uint32_t* nf_node,
                         uint32_t* big_list, uint32_t* big_count, void* stream);
 void launch_retain_emit(const RetainRound& r, const uint64_t* epos, uint64_t g_base, uint32_t* arena, uint64_t* ovf_base,
-                        uint32_t* pair_cnt, void* stream);
+                        uint64_t* ovf_end, void* stream);
+void launch_retain_finish(uint32_t n, const uint64_t* ovf_base, const uint64_t* ovf_end, uint32_t* pair_cnt, void* stream);
 
 void launch_count(const TrieView& t, const ChunkArrays& c, void* stream);
 void launch_scan(const ChunkArrays& c, uint64_t* block_tmp, void* stream);

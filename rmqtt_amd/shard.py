@@ -1,8 +1,8 @@
 """Multi-GPU sharding rule — host-side helpers over the C ABI.
 
-owner(topic)  = H(level0, level1|none) mod G
-owner(filter) = the same, or -1 (replicate on every shard) when level0 or level1 is a
-                wildcard.  A topic's full match set then lives on its owner alone, so the
+owner(topic)  = H(first KEY_LEVELS levels) mod G
+owner(filter) = the same, or -1 (replicate on every shard) when one of its first KEY_LEVELS
+                levels is a wildcard.  A topic's full match set then lives on its owner alone, so the
                 data path needs no collective; ranks only exchange hit counts (and,
                 optionally, tuples: all-gatherv) afterwards.
 """
@@ -14,12 +14,15 @@ from . import capi
 from .workload import take  # noqa: F401  (re-export: gather a subset of a string batch)
 
 
-def assign(blob, offsets, n_shards, is_filter):
+KEY_LEVELS = 3
+
+
+def assign(blob, offsets, n_shards, is_filter, key_levels=KEY_LEVELS):
     blob = np.ascontiguousarray(blob, dtype=np.uint8)
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
     n = len(offsets) - 1
     out = np.zeros(n, dtype=np.int32)
-    rc = capi.lib().rgr_shard_assign(blob.ctypes.data, offsets.ctypes.data, n, n_shards, int(is_filter), out.ctypes.data)
+    rc = capi.lib().rgr_shard_assign(blob.ctypes.data, offsets.ctypes.data, n, n_shards, int(is_filter), key_levels, out.ctypes.data)
     if rc != 0:
         raise capi.RgrError(rc, capi.lib().rgr_last_error().decode())
     return out

@@ -10,16 +10,20 @@ from tests.parity import pack
 
 
 def test_shard_rule_properties():
-    filters = ["a/b/c", "a/b", "a/b/#", "a/+/c", "a/#", "+/b", "#", "a", "$SYS/x/y", "/x", "", "a/", "+"]
-    topics = ["a/b/c", "a/b", "a", "$SYS/x", "/x", "", "a/"]
+    filters = ["a/b/c", "a/b", "a/b/#", "a/+/c", "a/#", "+/b", "#", "a", "$SYS/x/y", "/x", "", "a/", "+", "a/b/c/#", "a/b/c/+/e"]
+    topics = ["a/b/c", "a/b", "a", "$SYS/x", "/x", "", "a/", "a/b/c/d", "a/b/c/d/e"]
     for world in (1, 2, 8):
         fo = shard.assign(*pack(filters), world, True)
         to = shard.assign(*pack(topics), world, False)
-        assert list(fo < 0) == [False, False, False, True, True, True, True, False, False, False, False, False, True]
+        # a wildcard inside the first three levels => replicated everywhere
+        assert list(fo < 0) == [False, False, True, True, True, True, True, False, False, False, False, False, True, False, False]
         assert ((to >= 0) & (to < world)).all()
-        # a filter with two literal leading levels lives where every topic it can match lives
-        assert fo[0] == fo[1] == fo[2] == to[0] == to[1]
-        assert fo[7] == to[2] and fo[9] == to[4] and fo[10] == to[5] and fo[11] == to[6]
+        # a filter lives where every topic it can match lives
+        assert fo[0] == to[0] == to[7] == to[8] == fo[13] == fo[14]      # a/b/c, a/b/c/#, a/b/c/+/e with a/b/c[/..]
+        assert fo[1] == to[1] and fo[7] == to[2] and fo[9] == to[4] and fo[10] == to[5] and fo[11] == to[6]
+        # two-level keys (the SURVEY variant) still work
+        f2 = shard.assign(*pack(filters), world, True, key_levels=2)
+        assert list(f2 < 0) == [False, False, False, True, True, True, True, False, False, False, False, False, True, False, False]
 
 
 def test_two_rank_gloo_sharded_match():
