@@ -96,6 +96,9 @@ struct rgr_handle {
     uint64_t epoch_counter = 0;
     std::mutex stats_mu;
     rgr_stats stats{};
+    // recycled batch workspaces (stream + grow-only device buffers) for the one-shot entry points
+    std::mutex pool_mu;
+    std::vector<rgr_batch*> pool;
     // RetainTree twin
     std::shared_mutex retain_mu;
     RetainTable retain_table;
@@ -511,6 +514,7 @@ int32_t rgr_create(const rgr_config* cfg, rgr_handle** out) {
 void rgr_destroy(rgr_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
+    for (rgr_batch* b : h->pool) delete b;
     delete h;
 }
 
@@ -624,15 +628,28 @@ int32_t rgr_commit(rgr_handle* h) {
 }
 
 // ------------------------------------------------------------------ device-resident batches
-static int32_t batch_create_impl(rgr_handle* h, const uint8_t* blob, const uint64_t* offs, uint32_t n, bool retain, rgr_batch** out) {
+// `recycle`: take the workspace from the handle's pool (one-shot entry points); it goes back with
+// batch_release().  Public rgr_batch_create always builds a fresh one owned by the caller.
+static int32_t batch_create_impl(rgr_handle* h, const uint8_t* blob, const uint64_t* offs, uint32_t n, bool retain, rgr_batch** out,
+                                 bool recycle = false) {
     return guarded([&]() -> int32_t {
         if (!h || !out || (n && (!blob || !offs))) return fail(RGR_EINVAL, "rgr_batch_create: bad argument");
         RGR_HIP(hipSetDevice(h->cfg.device));
-        auto b = std::make_unique<rgr_batch>();
+        std::unique_ptr<rgr_batch> b;
+        if (recycle) {
+            std::lock_guard<std::mutex> g(h->pool_mu);
+            if (!h->pool.empty()) { b.reset(h->pool.back()); h->pool.pop_back(); }
+        }
+        if (!b) {
+            b = std::make_unique<rgr_batch>();
+            RGR_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+        }
         b->h = h;
         b->n = n;
         b->retain = retain;
-        RGR_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+        b->in_pass = false; b->chunk_ready = false; b->cursor = 0; b->hits_before = 0;
+        b->dict_tokens = ~0ull;
+        b->epoch.reset(); b->repoch.reset();
         if (h->cfg.host_tokenize) {
             if (n) { b->h_blob.assign(blob + offs[0], blob + offs[n]); b->h_offs.assign(offs, offs + n + 1); for (auto& o : b->h_offs) o -= offs[0]; }
             else b->h_offs.assign(1, 0);
@@ -664,6 +681,25 @@ static int32_t batch_create_impl(rgr_handle* h, const uint8_t* blob, const uint6
 
 int32_t rgr_batch_create(rgr_handle* h, const uint8_t* blob, const uint64_t* offs, uint32_t n, rgr_batch** out) {
     return batch_create_impl(h, blob, offs, n, false, out);
+}
+
+// Return a recycled workspace to the pool (bounded; extras are destroyed).
+static void batch_release(rgr_batch* b) {
+    if (!b) return;
+    rgr_handle* h = b->h;
+    (void)hipSetDevice(h->cfg.device);
+    if (b->stream) (void)hipStreamSynchronize(b->stream);
+    try { b->resolve_spans(); } catch (...) {
+        for (auto& sp : b->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+        b->spans.clear();
+    }
+    merge_stats(h, b->local);
+    b->epoch.reset(); b->repoch.reset();
+    {
+        std::lock_guard<std::mutex> g(h->pool_mu);
+        if (h->pool.size() < 16) { h->pool.push_back(b); return; }
+    }
+    delete b;
 }
 
 void rgr_batch_destroy(rgr_batch* b) {
@@ -811,7 +847,7 @@ int32_t rgr_match_batch(rgr_handle* h, const uint8_t* blob, const uint64_t* offs
     if (!out) return fail(RGR_EINVAL, "rgr_match_batch: out is NULL");
     std::memset(out, 0, sizeof *out);
     rgr_batch* b = nullptr;
-    int32_t rc = rgr_batch_create(h, blob, offs, n, &b);
+    int32_t rc = batch_create_impl(h, blob, offs, n, false, &b, true);
     if (rc != RGR_OK) return rc;
     rc = guarded([&]() -> int32_t {
         auto own = std::make_unique<ResultOwner>();
@@ -840,7 +876,7 @@ int32_t rgr_match_batch(rgr_handle* h, const uint8_t* blob, const uint64_t* offs
         out->_owner = own.release();
         return RGR_OK;
     });
-    rgr_batch_destroy(b);
+    batch_release(b);
     return rc;
 }
 
@@ -854,7 +890,7 @@ int32_t rgr_match_filters(rgr_handle* h, const uint8_t* blob, const uint64_t* of
     if (!out) return fail(RGR_EINVAL, "rgr_match_filters: out is NULL");
     std::memset(out, 0, sizeof *out);
     rgr_batch* b = nullptr;
-    int32_t rc = rgr_batch_create(h, blob, offs, n, &b);
+    int32_t rc = batch_create_impl(h, blob, offs, n, false, &b, true);
     if (rc != RGR_OK) return rc;
     rc = guarded([&]() -> int32_t {
         auto own = std::make_unique<ResultOwner>();
@@ -895,7 +931,7 @@ int32_t rgr_match_filters(rgr_handle* h, const uint8_t* blob, const uint64_t* of
         out->_owner = own.release();
         return RGR_OK;
     });
-    rgr_batch_destroy(b);
+    batch_release(b);
     return rc;
 }
 

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Per-call latency of the host-buffer entry point (rgr_match_batch) for small batches — the
+shape a broker's micro-batcher would issue — and the PCIe-inclusive throughput for big ones."""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from rmqtt_amd import capi, workload as wl
+
+cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+scale = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
+c = wl.CONFIGS[cfg]
+n_sub = int(c["n_sub"] * scale)
+blob, offs, client, qos = wl.gen_subs(n_sub, wl.SUB_SEED + cfg, c["p_plus"], c["p_hash"], c["p_sys"])
+tb, to = wl.gen_topics(200_000, wl.PUB_SEED + cfg, 0.01, c["p_blank"])
+r = capi.Router(device=0)
+r.subscribe_bulk(blob, offs, None, qos); r.commit()
+for bs in (1, 16, 256, 4096, 65536, 200_000):
+    reps = max(3, min(300, 200_000 // bs))
+    batches = [wl.take(tb, to, np.arange(i * bs, (i + 1) * bs) % 200_000) for i in range(min(reps, 8))]
+    r.match_batch(*batches[0])
+    t0 = time.time(); hits = 0
+    for i in range(reps):
+        res = r.match_batch(*batches[i % len(batches)]); hits += len(res["tuples"])
+    dt = (time.time() - t0) / reps
+    print(f"config {cfg} x{scale}: batch {bs:7d}: {dt * 1e3:9.3f} ms/call  {bs / dt:14.0f} topics/s  {hits / reps / max(dt, 1e-9) / 1e6:10.1f} M tuples/s  (host blob in, host tuples out)")
