@@ -144,8 +144,9 @@ def _blob_ptr(blob):
 def _copy(ptr, n, dtype):
     if not n:
         return np.zeros(0, dtype=dtype)
-    nbytes = int(n) * np.dtype(dtype).itemsize
-    return np.frombuffer(C.string_at(ptr, nbytes), dtype=dtype).copy()
+    out = np.empty(int(n), dtype=dtype)
+    C.memmove(out.ctypes.data, ptr, out.nbytes)      # (string_at is limited to 2 GiB)
+    return out
 
 
 def pack(strs):
