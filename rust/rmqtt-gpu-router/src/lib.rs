@@ -1,6 +1,7 @@
 //! rmqtt-gpu-router plugin: installs `GpuRouter` into `extends.router` at start(), the same way
 //! rmqtt-cluster-broadcast/src/lib.rs:141-142 and rmqtt-cluster-raft/src/lib.rs:384 install theirs.
 //! Source only — see Cargo.toml.
+mod batcher;
 mod ffi;
 mod router;
 
