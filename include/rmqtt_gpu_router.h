@@ -148,6 +148,8 @@ typedef struct rgr_stats {
     double walk_ms, scan_ms, expand_ms, tokenize_ms, h2d_ms, d2h_ms;   /* HIP-event / wall */
     /* algorithmic bytes of the work counted above */
     uint64_t alg_bytes_walk, alg_bytes_expand;
+    /* rgr_commit: epochs published by a full image upload vs by patching the delta */
+    uint64_t commits_full, commits_delta;
 } rgr_stats;
 
 /* ---- lifecycle ----------------------------------------------------------------- */

@@ -64,7 +64,7 @@ class Stats(C.Structure):
                                            "table_bytes_device", "topics", "invalid_topics", "levels", "pairs", "hits",
                                            "visited_nodes", "overflow_topics", "walk_launches", "expand_launches")] +
                 [(n, C.c_double) for n in ("walk_ms", "scan_ms", "expand_ms", "tokenize_ms", "h2d_ms", "d2h_ms")] +
-                [(n, C.c_uint64) for n in ("alg_bytes_walk", "alg_bytes_expand")])
+                [(n, C.c_uint64) for n in ("alg_bytes_walk", "alg_bytes_expand", "commits_full", "commits_delta")])
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

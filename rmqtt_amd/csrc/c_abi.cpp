@@ -68,11 +68,21 @@ struct DictImage {   // device copy of a StringDict for the device tokeniser
     }
 };
 
+// Device images an epoch is made of.  Edge table and filter descriptors are ping-ponged between
+// two images patched in place by the scatter kernels; subscriber runs live in an append-only pool
+// (a run is never overwritten, so older epochs stay valid).  shared_ptr keeps whatever an
+// in-flight pass still reads alive.
+struct EdgeImage { DevBuf buf; uint64_t cap = 0; std::vector<uint32_t> pending; bool need_full = true; };
+struct FiltImage { DevBuf buf; uint64_t cap = 0; std::vector<uint32_t> pending; bool need_full = true; };
+struct SubsPool { DevBuf buf; uint64_t used = 0, cap = 0; };
+
 struct Epoch {
-    DictImage dict;
-    DevBuf edges, filt, subs;
+    std::shared_ptr<DictImage> dict;
+    std::shared_ptr<EdgeImage> edges;
+    std::shared_ptr<FiltImage> filt;
+    std::shared_ptr<SubsPool> subs;
     TrieView view{};
-    uint64_t id = 0, n_filters = 0, n_subs = 0, n_nodes = 0, edge_slots = 0, max_filter_subs = 0, bytes = 0;
+    uint64_t id = 0, n_filters = 0, n_subs = 0, n_nodes = 0, edge_slots = 0, bytes = 0;
 };
 
 struct RetainEpoch {
@@ -94,6 +104,15 @@ struct rgr_handle {
     std::mutex epoch_mu;
     std::shared_ptr<Epoch> epoch;
     uint64_t epoch_counter = 0;
+    // incremental-commit state (guarded by commit_mu)
+    std::mutex commit_mu;
+    std::shared_ptr<EdgeImage> edge_img[2];
+    std::shared_ptr<FiltImage> filt_img[2];
+    std::shared_ptr<SubsPool> sub_pool;
+    std::vector<FilterDesc> host_desc;     // per filter id: its run in the pool
+    uint64_t pool_garbage = 0;
+    int cur_img = 1;
+    uint64_t commits_full = 0, commits_delta = 0;
     std::mutex stats_mu;
     rgr_stats stats{};
     // recycled batch workspaces (stream + grow-only device buffers) for the one-shot entry points
@@ -594,31 +613,120 @@ int32_t rgr_commit(rgr_handle* h) {
     return guarded([&]() -> int32_t {
         if (!h) return fail(RGR_EINVAL, "rgr_commit: bad argument");
         RGR_HIP(hipSetDevice(h->cfg.device));
+        std::lock_guard<std::mutex> cg(h->commit_mu);
+        auto prev = current_epoch(h);
         auto ep = std::make_shared<Epoch>();
         {
             std::shared_lock<std::shared_mutex> lk(h->table_mu);
+            HostTable::Delta delta;
+            h->table.take_delta(delta);              // (mutators hold table_mu exclusively; this is the only reader of the delta)
             const auto& edges = h->table.edges();
-            std::vector<FilterDesc> filt;
-            std::vector<SubEntry> subs;
-            h->table.flatten_filters(filt, subs);
-            ep->dict.upload(h->table.dict());
-            ep->edges.ensure(edges.size() * sizeof(EdgeEntry));
-            ep->filt.ensure(std::max<size_t>(1, filt.size()) * sizeof(FilterDesc));
-            ep->subs.ensure(std::max<size_t>(1, subs.size()) * sizeof(SubEntry));
-            RGR_HIP(hipMemcpy(ep->edges.p, edges.data(), edges.size() * sizeof(EdgeEntry), hipMemcpyHostToDevice));
-            if (!filt.empty()) RGR_HIP(hipMemcpy(ep->filt.p, filt.data(), filt.size() * sizeof(FilterDesc), hipMemcpyHostToDevice));
-            if (!subs.empty()) RGR_HIP(hipMemcpy(ep->subs.p, subs.data(), subs.size() * sizeof(SubEntry), hipMemcpyHostToDevice));
-            ep->view.edges = ep->edges.as<EdgeEntry>();
+            // ---- dictionary: append-only; re-uploaded only when it grew
+            if (prev && prev->dict && prev->dict->n_tokens == h->table.n_tokens()) ep->dict = prev->dict;
+            else { ep->dict = std::make_shared<DictImage>(); ep->dict->upload(h->table.dict()); }
+            // ---- every image accumulates the delta; the one not serving the current epoch is patched
+            for (int k = 0; k < 2; ++k) {
+                if (!h->edge_img[k]) h->edge_img[k] = std::make_shared<EdgeImage>();
+                if (!h->filt_img[k]) h->filt_img[k] = std::make_shared<FiltImage>();
+                if (delta.relocated) h->edge_img[k]->need_full = true;
+                else h->edge_img[k]->pending.insert(h->edge_img[k]->pending.end(), delta.slots.begin(), delta.slots.end());
+                h->filt_img[k]->pending.insert(h->filt_img[k]->pending.end(), delta.fids.begin(), delta.fids.end());
+            }
+            const int tgt = h->cur_img ^ 1;
+            // an in-flight pass may still read the target image through an older epoch: give it a fresh one
+            if (h->edge_img[tgt].use_count() > 1) h->edge_img[tgt] = std::make_shared<EdgeImage>();
+            if (h->filt_img[tgt].use_count() > 1) h->filt_img[tgt] = std::make_shared<FiltImage>();
+            EdgeImage& ei = *h->edge_img[tgt];
+            bool full = false;
+            if (ei.need_full || ei.cap != edges.size() || ei.pending.size() > edges.size() / 8) {
+                ei.buf.ensure(edges.size() * sizeof(EdgeEntry));
+                RGR_HIP(hipMemcpy(ei.buf.p, edges.data(), edges.size() * sizeof(EdgeEntry), hipMemcpyHostToDevice));
+                ei.cap = edges.size();
+                full = true;
+            } else if (!ei.pending.empty()) {
+                std::sort(ei.pending.begin(), ei.pending.end());
+                ei.pending.erase(std::unique(ei.pending.begin(), ei.pending.end()), ei.pending.end());
+                std::vector<EdgeEntry> recs(ei.pending.size());
+                for (size_t i = 0; i < recs.size(); ++i) recs[i] = edges[ei.pending[i]];
+                DevBuf d_slots, d_recs;
+                d_slots.ensure(recs.size() * 4); d_recs.ensure(recs.size() * sizeof(EdgeEntry));
+                RGR_HIP(hipMemcpy(d_slots.p, ei.pending.data(), recs.size() * 4, hipMemcpyHostToDevice));
+                RGR_HIP(hipMemcpy(d_recs.p, recs.data(), recs.size() * sizeof(EdgeEntry), hipMemcpyHostToDevice));
+                launch_scatter_edges(ei.buf.as<EdgeEntry>(), d_slots.as<uint32_t>(), d_recs.as<EdgeEntry>(), uint32_t(recs.size()), nullptr);
+                RGR_HIP(hipDeviceSynchronize());
+            }
+            ei.pending.clear(); ei.need_full = false;
+            // ---- subscriber runs: dirty filters get a fresh run appended to the pool
+            const uint64_t nf = h->table.filter_capacity();
+            if (h->host_desc.size() < nf) h->host_desc.resize(nf, FilterDesc{0, 0});
+            std::vector<uint32_t> fids = delta.fids;
+            std::sort(fids.begin(), fids.end());
+            fids.erase(std::unique(fids.begin(), fids.end()), fids.end());
+            uint64_t add = 0;
+            for (uint32_t f : fids) { const auto* v = h->table.filter_subs(f); add += v ? v->size() : 0; }
+            bool rebuild = !h->sub_pool || h->sub_pool->used + add > h->sub_pool->cap || h->sub_pool->used + add > 0xFFFFFF00ull ||
+                           h->pool_garbage > h->table.n_subs() + (1u << 16);
+            if (rebuild) {
+                std::vector<FilterDesc> filt;
+                std::vector<SubEntry> subs;
+                h->table.flatten_filters(filt, subs);
+                auto np = std::make_shared<SubsPool>();
+                np->cap = subs.size() + subs.size() / 2 + (1u << 16);      // head-room for appended runs
+                np->buf.ensure(np->cap * sizeof(SubEntry));
+                if (!subs.empty()) RGR_HIP(hipMemcpy(np->buf.p, subs.data(), subs.size() * sizeof(SubEntry), hipMemcpyHostToDevice));
+                np->used = subs.size();
+                h->sub_pool = np;
+                h->host_desc = filt;
+                if (h->host_desc.size() < nf) h->host_desc.resize(nf, FilterDesc{0, 0});
+                h->pool_garbage = 0;
+                for (int k = 0; k < 2; ++k) h->filt_img[k]->need_full = true;
+            } else if (!fids.empty()) {
+                std::vector<SubEntry> stage;
+                stage.reserve(add);
+                for (uint32_t f : fids) {
+                    const auto* v = h->table.filter_subs(f);
+                    h->pool_garbage += h->host_desc[f].count;
+                    h->host_desc[f] = FilterDesc{uint32_t(h->sub_pool->used + stage.size()), v ? uint32_t(v->size()) : 0u};
+                    if (v) stage.insert(stage.end(), v->begin(), v->end());
+                }
+                if (!stage.empty())
+                    RGR_HIP(hipMemcpy(h->sub_pool->buf.as<SubEntry>() + h->sub_pool->used, stage.data(), stage.size() * sizeof(SubEntry), hipMemcpyHostToDevice));
+                h->sub_pool->used += stage.size();
+            }
+            FiltImage& fi = *h->filt_img[tgt];
+            if (fi.need_full || fi.cap < nf || fi.pending.size() > nf / 4) {
+                fi.cap = nf + nf / 4 + 1024;
+                fi.buf.ensure(fi.cap * sizeof(FilterDesc));
+                if (nf) RGR_HIP(hipMemcpy(fi.buf.p, h->host_desc.data(), nf * sizeof(FilterDesc), hipMemcpyHostToDevice));
+                full = true;
+            } else if (!fi.pending.empty()) {
+                std::sort(fi.pending.begin(), fi.pending.end());
+                fi.pending.erase(std::unique(fi.pending.begin(), fi.pending.end()), fi.pending.end());
+                std::vector<FilterDesc> recs(fi.pending.size());
+                for (size_t i = 0; i < recs.size(); ++i) recs[i] = h->host_desc[fi.pending[i]];
+                DevBuf d_f, d_r;
+                d_f.ensure(recs.size() * 4); d_r.ensure(recs.size() * sizeof(FilterDesc));
+                RGR_HIP(hipMemcpy(d_f.p, fi.pending.data(), recs.size() * 4, hipMemcpyHostToDevice));
+                RGR_HIP(hipMemcpy(d_r.p, recs.data(), recs.size() * sizeof(FilterDesc), hipMemcpyHostToDevice));
+                launch_scatter_desc(fi.buf.as<FilterDesc>(), d_f.as<uint32_t>(), d_r.as<FilterDesc>(), uint32_t(recs.size()), nullptr);
+                RGR_HIP(hipDeviceSynchronize());
+            }
+            fi.pending.clear(); fi.need_full = false;
+            (full ? h->commits_full : h->commits_delta)++;
+            h->cur_img = tgt;
+            ep->edges = h->edge_img[tgt];
+            ep->filt = h->filt_img[tgt];
+            ep->subs = h->sub_pool;
+            ep->view.edges = ei.buf.as<EdgeEntry>();
             ep->view.mask = uint32_t(edges.size() - 1);
             ep->view.root = h->table.root_header();
-            ep->view.filt = ep->filt.as<FilterDesc>();
-            ep->view.subs = ep->subs.as<SubEntry>();
+            ep->view.filt = fi.buf.as<FilterDesc>();
+            ep->view.subs = h->sub_pool->buf.as<SubEntry>();
             ep->n_filters = h->table.n_filters();
             ep->n_subs = h->table.n_subs();
             ep->n_nodes = h->table.n_nodes();
             ep->edge_slots = edges.size();
-            ep->max_filter_subs = h->table.max_filter_subs();
-            ep->bytes = ep->edges.bytes + ep->filt.bytes + ep->subs.bytes;
+            ep->bytes = ei.buf.bytes + fi.buf.bytes + h->sub_pool->buf.bytes;
         }
         std::lock_guard<std::mutex> g(h->epoch_mu);
         ep->id = ++h->epoch_counter;
@@ -671,7 +779,7 @@ static int32_t batch_create_impl(rgr_handle* h, const uint8_t* blob, const uint6
                 if (!ep) return fail(RGR_ESTATE, "rgr_retain_batch_create: rgr_retain_commit has not been called");
                 tokenize_batch_device(b.get(), ep->dict);
             } else {
-                tokenize_batch_device(b.get(), current_epoch(h)->dict);
+                tokenize_batch_device(b.get(), *current_epoch(h)->dict);
             }
         }
         *out = b.release();
@@ -723,10 +831,10 @@ int32_t rgr_batch_begin(rgr_batch* b) {
         } else {
             b->epoch = current_epoch(b->h);
         }
-        const uint64_t want = b->retain ? b->repoch->dict.n_tokens : b->epoch->dict.n_tokens;
+        const uint64_t want = b->retain ? b->repoch->dict.n_tokens : b->epoch->dict->n_tokens;
         if (want != b->dict_tokens) {      // the dictionary grew since this batch was tokenised
             if (b->h->cfg.host_tokenize) tokenize_batch(b->h, b, b->h_blob.data(), b->h_offs.data(), b->n);
-            else tokenize_batch_device(b, b->retain ? b->repoch->dict : b->epoch->dict);
+            else tokenize_batch_device(b, b->retain ? b->repoch->dict : *b->epoch->dict);
         }
         b->in_pass = true;
         b->cursor = 0;
@@ -980,6 +1088,10 @@ int32_t rgr_stats_get(rgr_handle* h, rgr_stats* out) {
         auto ep = current_epoch(h);
         out->n_filters = ep->n_filters; out->n_subs = ep->n_subs; out->n_nodes = ep->n_nodes;
         out->n_edge_slots = ep->edge_slots; out->epoch = ep->id; out->table_bytes_device = ep->bytes;
+        {
+            std::lock_guard<std::mutex> cg(h->commit_mu);
+            out->commits_full = h->commits_full; out->commits_delta = h->commits_delta;
+        }
         std::shared_lock<std::shared_mutex> lk(h->table_mu);
         out->n_tokens = h->table.n_tokens();
         return RGR_OK;

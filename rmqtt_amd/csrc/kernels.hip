@@ -41,6 +41,21 @@ __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
     return v;
 }
 
+// --------------------------------------------------------------------------- epoch delta
+__global__ __launch_bounds__(256) void scatter_edges_kernel(EdgeEntry* __restrict__ dst, const uint32_t* __restrict__ slots,
+                                                            const EdgeEntry* __restrict__ recs, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint4* s = reinterpret_cast<const uint4*>(recs + i);
+    uint4* d = reinterpret_cast<uint4*>(dst + slots[i]);
+    d[0] = s[0]; d[1] = s[1];
+}
+__global__ __launch_bounds__(256) void scatter_desc_kernel(FilterDesc* __restrict__ dst, const uint32_t* __restrict__ fids,
+                                                           const FilterDesc* __restrict__ recs, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[fids[i]] = recs[i];
+}
+
 // --------------------------------------------------------------------------- tokeniser
 // Device-side Topic::from_str + dictionary lookup: one lane per topic, one pass over its bytes
 // per kernel (count, then fill after the exclusive scan of the level counts).
@@ -521,6 +536,13 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* 
 // ------------------------------------------------------------------------------ launchers
 uint32_t expand_tile_hits() { return kTile; }
 uint32_t scan_block_topics() { return kScanBlock; }
+
+void launch_scatter_edges(EdgeEntry* dst, const uint32_t* slots, const EdgeEntry* recs, uint32_t n, void* stream) {
+    if (n) scatter_edges_kernel<<<(n + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(dst, slots, recs, n);
+}
+void launch_scatter_desc(FilterDesc* dst, const uint32_t* fids, const FilterDesc* recs, uint32_t n, void* stream) {
+    if (n) scatter_desc_kernel<<<(n + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(dst, fids, recs, n);
+}
 
 void launch_tok_count(const uint8_t* blob, const uint64_t* offs, uint32_t n, uint32_t* level_cnt, uint8_t* tflags, void* stream) {
     if (n) tok_count_kernel<<<(n + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(blob, offs, n, level_cnt, tflags);

@@ -136,6 +136,9 @@ struct ChunkArrays {
     uint64_t* pair_off;          // [P+1] chunk-local output offset of the run
 };
 
+// incremental epoch update: patch `n` edge records / filter descriptors of a device image
+void launch_scatter_edges(EdgeEntry* dst, const uint32_t* slots, const EdgeEntry* recs, uint32_t n, void* stream);
+void launch_scatter_desc(FilterDesc* dst, const uint32_t* fids, const FilterDesc* recs, uint32_t n, void* stream);
 // device tokeniser: blob/offsets -> per-topic level counts + flags, then token ids
 void launch_tok_count(const uint8_t* blob, const uint64_t* offs, uint32_t n, uint32_t* level_cnt, uint8_t* tflags, void* stream);
 void launch_scan_u32(const uint32_t* in, uint64_t* out, uint32_t n, uint64_t* block_tmp, void* stream);   // out[n] = total

@@ -125,6 +125,7 @@ void HostTable::rehash(uint64_t new_cap) {
         nodes_[e.child].slot = i;
     }
     edge_used_ = edge_live_;
+    delta_.relocated = true;
     // slots moved: re-point every header's plus_slot
     for (EdgeEntry& e : edges_) {
         if (e.parent == kEdgeEmpty) continue;
@@ -144,6 +145,7 @@ uint32_t HostTable::insert_edge(uint32_t parent, uint32_t token, uint32_t child)
     if (edges_[i].parent == kEdgeEmpty) edge_used_++;
     edges_[i] = EdgeEntry{parent, token, child, kNone, kNone, kNone, 0, 0};
     edge_live_++;
+    touch(i);
     return i;
 }
 
@@ -163,20 +165,27 @@ uint32_t HostTable::new_node(uint32_t parent, uint32_t token) {
 }
 
 void HostTable::set_plus_slot(uint32_t node, uint32_t slot) {
-    if (node == 0) root_hdr_.plus_slot = slot; else edges_[nodes_[node].slot].plus_slot = slot;
+    if (node == 0) root_hdr_.plus_slot = slot; else { edges_[nodes_[node].slot].plus_slot = slot; touch(nodes_[node].slot); }
 }
 void HostTable::set_hash_fid(uint32_t node, uint32_t fid) {
-    if (node == 0) root_hdr_.hash_fid = fid; else edges_[nodes_[node].slot].hash_fid = fid;
+    if (node == 0) root_hdr_.hash_fid = fid; else { edges_[nodes_[node].slot].hash_fid = fid; touch(nodes_[node].slot); }
 }
 void HostTable::literal_edge(uint32_t node, uint32_t token, int delta) {
     uint32_t& cnt = node == 0 ? root_hdr_.lit_cnt : edges_[nodes_[node].slot].lit_cnt;
     uint32_t& x = node == 0 ? root_hdr_.lit_xor : edges_[nodes_[node].slot].lit_xor;
     cnt += uint32_t(delta);
     x ^= token;
+    if (node != 0) touch(nodes_[node].slot);
 }
 void HostTable::set_term_fid(uint32_t node, uint32_t fid) {
     nodes_[node].term_fid = fid;
-    if (node == 0) root_hdr_.term_fid = fid; else edges_[nodes_[node].slot].term_fid = fid;
+    if (node == 0) root_hdr_.term_fid = fid; else { edges_[nodes_[node].slot].term_fid = fid; touch(nodes_[node].slot); }
+}
+void HostTable::take_delta(Delta& d) {
+    d.slots.swap(delta_.slots);
+    d.fids.swap(delta_.fids);
+    d.relocated = delta_.relocated;
+    delta_ = Delta{};
 }
 
 uint32_t HostTable::walk_existing(const std::vector<uint32_t>& toks) const {
@@ -204,6 +213,7 @@ int32_t HostTable::filter_add(std::string_view f, uint32_t* fid) {
     else { id = uint32_t(filters_.size()); filters_.emplace_back(); }
     filters_[id].node = cur;
     filters_[id].subs.clear();
+    delta_.fids.push_back(id);
     set_term_fid(cur, id);
     if (nodes_[cur].token == kTokHash) set_hash_fid(nodes_[cur].parent, id);
     n_filters_++;
@@ -235,6 +245,7 @@ int32_t HostTable::filter_remove(uint32_t fid) {
     while (t != 0 && nodes_[t].term_fid == kNone && nodes_[t].nchild == 0) {
         const uint32_t p = nodes_[t].parent;
         edges_[nodes_[t].slot].parent = kEdgeTomb;
+        touch(nodes_[t].slot);
         edge_live_--;
         if (nodes_[t].token == kTokPlus) { nodes_[p].plus_child = kNone; set_plus_slot(p, kNone); }
         else if (nodes_[t].token == kTokHash) nodes_[p].hash_child = kNone;
@@ -245,6 +256,7 @@ int32_t HostTable::filter_remove(uint32_t fid) {
         t = p;
     }
     filters_[fid].node = kNone;
+    delta_.fids.push_back(fid);
     std::vector<SubEntry>().swap(filters_[fid].subs);
     free_fids_.push_back(fid);
     n_filters_--;
@@ -254,6 +266,7 @@ int32_t HostTable::filter_remove(uint32_t fid) {
 int32_t HostTable::sub_add(uint32_t fid, uint32_t sub_id, uint8_t qos, uint8_t flags) {
     if (fid >= filters_.size() || filters_[fid].node == kNone) return RGR_ENOENT;
     auto& v = filters_[fid].subs;
+    delta_.fids.push_back(fid);
     const SubEntry e{sub_id, uint32_t(qos) | (uint32_t(flags) << 8)};
     if (v.empty() || v.back().sub_id < sub_id) { v.push_back(e); n_subs_++; return RGR_OK; }
     auto it = std::lower_bound(v.begin(), v.end(), sub_id, [](const SubEntry& a, uint32_t b) { return a.sub_id < b; });
@@ -269,6 +282,7 @@ int32_t HostTable::sub_remove(uint32_t fid, uint32_t sub_id) {
     auto it = std::lower_bound(v.begin(), v.end(), sub_id, [](const SubEntry& a, uint32_t b) { return a.sub_id < b; });
     if (it == v.end() || it->sub_id != sub_id) return RGR_ENOENT;
     v.erase(it);
+    delta_.fids.push_back(fid);
     n_subs_--;
     return RGR_OK;
 }

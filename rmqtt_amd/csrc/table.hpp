@@ -58,6 +58,17 @@ class HostTable {
     const std::vector<EdgeEntry>& edges() const { return edges_; }
     NodeHeader root_header() const { return root_hdr_; }
     void flatten_filters(std::vector<FilterDesc>& filt, std::vector<SubEntry>& subs) const;
+    // Incremental commits: what changed since the last take_delta().
+    struct Delta {
+        std::vector<uint32_t> slots;     // edge records written (may repeat)
+        std::vector<uint32_t> fids;      // filters whose subscriber run / existence changed (may repeat)
+        bool relocated = false;          // the edge table was rehashed: every slot moved
+    };
+    void take_delta(Delta& d);
+    uint64_t filter_capacity() const { return filters_.size(); }
+    const std::vector<SubEntry>* filter_subs(uint32_t fid) const {
+        return fid < filters_.size() && filters_[fid].node != kNone ? &filters_[fid].subs : nullptr;
+    }
 
     uint64_t n_filters() const { return n_filters_; }
     uint64_t n_subs() const { return n_subs_; }
@@ -89,6 +100,8 @@ class HostTable {
     std::vector<Filter> filters_;
     std::vector<uint32_t> free_fids_;
     uint64_t n_filters_ = 0, n_subs_ = 0, n_nodes_ = 1;
+    Delta delta_;
+    void touch(uint32_t slot) { delta_.slots.push_back(slot); }
 
     uint32_t find_slot(uint32_t parent, uint32_t token) const;
     uint32_t insert_edge(uint32_t parent, uint32_t token, uint32_t child);
