@@ -23,3 +23,21 @@ for bs in (1, 16, 256, 4096, 65536, 200_000):
         res = r.match_batch(*batches[i % len(batches)]); hits += len(res["tuples"])
     dt = (time.time() - t0) / reps
     print(f"config {cfg} x{scale}: batch {bs:7d}: {dt * 1e3:9.3f} ms/call  {bs / dt:14.0f} topics/s  {hits / reps / max(dt, 1e-9) / 1e6:10.1f} M tuples/s  (host blob in, host tuples out)")
+
+# ---- commit latency: a burst of SUBSCRIBEs followed by rgr_commit (delta path)
+rng = np.random.default_rng(0)
+fb, fo, _, fq = wl.gen_subs(64 * 40, 777, c["p_plus"], c["p_hash"], c["p_sys"])
+next_id = n_sub
+for burst in (1, 64):
+    ts = []
+    for it in range(20):
+        idx = np.arange(it * burst, (it + 1) * burst)
+        bb, bo = wl.take(fb, fo, idx)
+        t0 = time.time()
+        r.subscribe_bulk(bb, bo, np.arange(next_id, next_id + burst, dtype=np.uint32), fq[idx])
+        r.commit()
+        ts.append(time.time() - t0)
+        next_id += burst
+    st = r.stats()
+    print(f"config {cfg} x{scale}: {burst:3d} new subscriptions + rgr_commit: median {np.median(ts) * 1e3:8.3f} ms  "
+          f"(commits so far: {st['commits_full']} full, {st['commits_delta']} delta; table {st['n_subs']} subs)")
