@@ -47,6 +47,7 @@ def build_gpu(force=False, verbose=False):
     if force or _stale(GPU_LIB, deps):
         cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
                "-Wall", "-Wno-unused-result", "-I", INCLUDE, "-I", CSRC, "-x", "hip"]
+        cmd += os.environ.get("RGR_EXTRA_FLAGS", "").split()      # tuning sweeps: -DRGR_EXPAND_THREADS=... etc.
         cmd += srcs + ["-o", GPU_LIB]
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")

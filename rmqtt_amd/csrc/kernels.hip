@@ -28,8 +28,17 @@ namespace {
 
 constexpr int kWalkThreads = 256;
 constexpr int kWalkWindow = 2560;        // LDS words per array (tokens, stack): 2 x 10 KiB
-constexpr int kExpandThreads = 256;
-constexpr int kExpandPerThread = 8;
+#ifndef RGR_EXPAND_THREADS
+#define RGR_EXPAND_THREADS 256
+#endif
+#ifndef RGR_EXPAND_PER_THREAD
+#define RGR_EXPAND_PER_THREAD 8
+#endif
+#ifndef RGR_EXPAND_NT
+#define RGR_EXPAND_NT 0          // 1: nontemporal tuple stores
+#endif
+constexpr int kExpandThreads = RGR_EXPAND_THREADS;
+constexpr int kExpandPerThread = RGR_EXPAND_PER_THREAD;
 constexpr int kTile = kExpandThreads * kExpandPerThread;   // 2048 hits = 24 KiB of tuples
 constexpr int kScanThreads = 256;
 constexpr int kScanPerThread = 8;
@@ -148,13 +157,26 @@ __global__ __launch_bounds__(kWalkThreads) void walk_kernel(TrieView tv, WalkArg
         const uint64_t rel = off0 - win_base;          // position of level 0 inside the window
         const uint64_t arena_base = OVF ? a.ovf_base[tl] : 0;
 
+        // LDS window first, HBM only beyond it.  Written as an unconditional ds_read (clamped index)
+        // plus a branch-guarded global load: a ?: over the two pointers makes hipcc emit flat_load,
+        // which sends LDS-resident reads through the vector-memory path.
         auto tok_at = [&](uint32_t d) -> uint32_t {
+            if (OVF) return a.tokens[off0 + d];
             const uint64_t i = rel + d;
-            return (!OVF && i < staged) ? s_tok[i] : a.tokens[off0 + d];
+            const bool in = i < staged;
+            uint32_t v = s_tok[in ? uint32_t(i) : 0u];
+            asm volatile("" : "+v"(v));          // keep the ds_read: no pointer-select + flat_load
+            if (!in) v = a.tokens[off0 + d];
+            return v;
         };
         auto path_get = [&](uint32_t d) -> uint32_t {
+            if (OVF) return a.path_scratch[off0 + d];
             const uint64_t i = rel + d;
-            return (!OVF && i < staged) ? s_path[i] : a.path_scratch[off0 + d];
+            const bool in = i < staged;
+            uint32_t v = s_path[in ? uint32_t(i) : 0u];
+            asm volatile("" : "+v"(v));
+            if (!in) v = a.path_scratch[off0 + d];
+            return v;
         };
         auto path_set = [&](uint32_t d, uint32_t v) {
             const uint64_t i = rel + d;
@@ -524,9 +546,15 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* 
     for (int j = 0; j < kExpandPerThread; ++j) {
         const uint32_t pos = uint32_t(j) * kExpandThreads + threadIdx.x;
         if (pos < len) {
+#if RGR_EXPAND_NT
+            __builtin_nontemporal_store(topic[j], &o[pos].topic_idx);
+            __builtin_nontemporal_store(se[j].sub_id, &o[pos].sub_id);
+            __builtin_nontemporal_store(se[j].qos_flags, &o[pos].qos_flags);
+#else
             Tuple tp;
             tp.topic_idx = topic[j]; tp.sub_id = se[j].sub_id; tp.qos_flags = se[j].qos_flags;
             o[pos] = tp;
+#endif
         }
     }
 }
