@@ -1,0 +1,89 @@
+// GpuRetainStorage — see gpu_retain.hpp.  Uses nothing but the C ABI.
+#include "gpu_retain.hpp"
+
+namespace rmqtt {
+
+GpuRetainStorage::GpuRetainStorage(int device) {
+    rgr_config cfg{};
+    cfg.device = device;
+    if (rgr_create(&cfg, &h_) != RGR_OK) h_ = nullptr;
+}
+GpuRetainStorage::~GpuRetainStorage() { if (h_) rgr_destroy(h_); }
+
+// retain.rs:229-247: remove the old value; a non-empty payload stores the new one.
+Result<bool> GpuRetainStorage::set(const TopicName& topic, const Retain& retain, int64_t expiry_ms, int64_t now_ms) {
+    if (!h_) return Result<bool>::Err("no device");
+    std::lock_guard<std::mutex> g(mu_);
+    auto it = ids_.find(topic);
+    const bool had = it != ids_.end();
+    if (retain.payload.empty()) {
+        if (had) {
+            if (rgr_retain_topic_remove(h_, topic.data(), uint32_t(topic.size())) != RGR_OK) return Result<bool>::Err(rgr_last_error());
+            slab_[it->second] = Entry{};
+            free_.push_back(it->second);
+            ids_.erase(it);
+            retaineds_.dec();
+            dirty_ = true;
+        } else {
+            // still has to be a valid topic name (Topic::from_str, retain.rs:235)
+            uint32_t probe_id = 0xFFFFFFF0u;
+            if (rgr_retain_topic_add(h_, topic.data(), uint32_t(topic.size()), probe_id) != RGR_OK) return Result<bool>::Err("invalid topic");
+            rgr_retain_topic_remove(h_, topic.data(), uint32_t(topic.size()));
+        }
+        return Result<bool>::Ok(true);
+    }
+    uint32_t id;
+    if (had) id = it->second;
+    else if (!free_.empty()) { id = free_.back(); free_.pop_back(); }
+    else { id = uint32_t(slab_.size()); slab_.emplace_back(); }
+    if (rgr_retain_topic_add(h_, topic.data(), uint32_t(topic.size()), id) != RGR_OK) {
+        if (!had) free_.push_back(id);
+        return Result<bool>::Err(std::string("invalid topic: ") + rgr_last_error());
+    }
+    slab_[id] = Entry{topic, retain, expiry_ms ? now_ms + expiry_ms : 0, true};
+    if (!had) { ids_.emplace(topic, id); retaineds_.inc(); }
+    dirty_ = true;
+    return Result<bool>::Ok(true);
+}
+
+// retain.rs:250-267
+Result<std::vector<std::pair<TopicName, Retain>>> GpuRetainStorage::get(const TopicFilter& f, int64_t now_ms) {
+    using R = Result<std::vector<std::pair<TopicName, Retain>>>;
+    if (!h_) return R::Err("no device");
+    std::lock_guard<std::mutex> g(mu_);
+    if (dirty_) { if (rgr_retain_commit(h_) != RGR_OK) return R::Err(rgr_last_error()); dirty_ = false; }
+    const uint64_t offs[2] = {0, f.size()};
+    rgr_retain_result res{};
+    if (rgr_retain_match_batch(h_, reinterpret_cast<const uint8_t*>(f.data()), offs, 1, &res) != RGR_OK) return R::Err(rgr_last_error());
+    std::vector<std::pair<TopicName, Retain>> out;
+    const bool bad = res.status[0] != RGR_TOPIC_OK;
+    for (uint64_t k = 0; !bad && k < res.n_hits; ++k) {
+        const Entry& e = slab_[res.topic_ids[k]];
+        if (!e.live || (e.expire_at && now_ms >= e.expire_at)) continue;      // TimedValue::is_expired
+        out.emplace_back(e.topic, e.retain);
+    }
+    rgr_retain_result_free(&res);
+    if (bad) return R::Err("invalid topic filter `" + f + "`");
+    return R::Ok(std::move(out));
+}
+
+// retain.rs:216-226 — RetainTree::retain(usize::MAX, |tv| !tv.is_expired())
+size_t GpuRetainStorage::remove_expired_messages(int64_t now_ms) {
+    if (!h_) return 0;
+    std::lock_guard<std::mutex> g(mu_);
+    size_t removed = 0;
+    for (uint32_t id = 0; id < slab_.size(); ++id) {
+        Entry& e = slab_[id];
+        if (!e.live || !e.expire_at || now_ms < e.expire_at) continue;
+        rgr_retain_topic_remove(h_, e.topic.data(), uint32_t(e.topic.size()));
+        ids_.erase(e.topic);
+        e = Entry{};
+        free_.push_back(id);
+        retaineds_.dec();
+        ++removed;
+        dirty_ = true;
+    }
+    return removed;
+}
+
+}  // namespace rmqtt

@@ -1,0 +1,49 @@
+// C++ host-side mirror of rmqtt's `RetainStorage` surface over the C ABI (retain twin).
+//
+// Mirrors DefaultRetainStorage (rmqtt/src/retain.rs:198-301) / the retainer plugin's storage
+// (rmqtt-plugins/rmqtt-retainer/src/storage.rs:576-641): the messages stay on the host keyed by a
+// dense topic_id; only the in-memory topic index (`RetainTree<TimedValue<..>>`) is replaced by
+// the device table.  Same method names / semantics as the trait (retain.rs:100-186):
+//   set(topic, retain, expiry)   empty payload deletes (retain.rs:229-247)
+//   get(topic_filter)            wildcard match + drop expired (retain.rs:250-267)
+//   count() / max()
+//   remove_expired_messages()    RetainTree::retain(|tv| !tv.is_expired()) (retain.rs:216-226)
+#pragma once
+#include <cstdint>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "gpu_router.hpp"
+
+namespace rmqtt {
+
+struct Retain {                // types.rs `Retain`: the fields the index path carries
+    std::string payload;
+    uint8_t qos = 0;
+};
+
+class GpuRetainStorage {
+   public:
+    explicit GpuRetainStorage(int device = 0);
+    ~GpuRetainStorage();
+    bool usable() const { return h_ != nullptr; }
+    // `now_ms` / `expiry_ms` make TimedValue::is_expired (types.rs:2308-2338) testable: 0 = never expires.
+    Result<bool> set(const TopicName& topic, const Retain& retain, int64_t expiry_ms = 0, int64_t now_ms = 0);
+    Result<std::vector<std::pair<TopicName, Retain>>> get(const TopicFilter& topic_filter, int64_t now_ms = 0);
+    size_t remove_expired_messages(int64_t now_ms);
+    Counter count_max() const { return retaineds_; }
+
+   private:
+    struct Entry { TopicName topic; Retain retain; int64_t expire_at = 0; bool live = false; };
+    rgr_handle* h_ = nullptr;
+    std::mutex mu_;
+    std::unordered_map<TopicName, uint32_t> ids_;
+    std::vector<Entry> slab_;
+    std::vector<uint32_t> free_;
+    Counter retaineds_;
+    bool dirty_ = false;
+};
+
+}  // namespace rmqtt

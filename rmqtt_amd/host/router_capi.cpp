@@ -6,6 +6,7 @@
 #include <cstring>
 #include <string>
 
+#include "gpu_retain.hpp"
 #include "gpu_router.hpp"
 
 using namespace rmqtt;
@@ -76,6 +77,31 @@ char* hr_get(void* r, const char* topic, uint32_t len) {
     for (auto& rt : *res.value) { s += rt.topic; s.push_back('\n'); }
     return dup_str(s);
 }
+// ---- GpuRetainStorage shim -------------------------------------------------------------------
+void* hs_new(int device) {
+    auto* s = new GpuRetainStorage(device);
+    if (!s->usable()) { delete s; return nullptr; }
+    return s;
+}
+void hs_free(void* s) { delete static_cast<GpuRetainStorage*>(s); }
+int hs_set(void* s, const char* t, uint32_t tl, const char* payload, uint32_t pl, int64_t expiry_ms, int64_t now_ms) {
+    return static_cast<GpuRetainStorage*>(s)->set(std::string(t, tl), Retain{std::string(payload, pl), 0}, expiry_ms, now_ms).ok() ? 0 : -1;
+}
+// "topic\tpayload\n" rows sorted by topic; NULL on Err
+char* hs_get(void* s, const char* f, uint32_t fl, int64_t now_ms) {
+    auto r = static_cast<GpuRetainStorage*>(s)->get(std::string(f, fl), now_ms);
+    if (!r.ok()) return nullptr;
+    std::vector<std::string> rows;
+    for (auto& kv : *r.value) rows.push_back(kv.first + "\t" + kv.second.payload + "\n");
+    std::sort(rows.begin(), rows.end());
+    std::string out;
+    for (auto& x : rows) out += x;
+    return dup_str(out);
+}
+uint64_t hs_remove_expired(void* s, int64_t now_ms) { return static_cast<GpuRetainStorage*>(s)->remove_expired_messages(now_ms); }
+int64_t hs_count(void* s) { return static_cast<GpuRetainStorage*>(s)->count_max().count; }
+int64_t hs_max(void* s) { return static_cast<GpuRetainStorage*>(s)->count_max().max; }
+
 int64_t hr_topics(void* r) { return static_cast<GpuRouter*>(r)->topics().count; }
 int64_t hr_routes(void* r) { return static_cast<GpuRouter*>(r)->routes().count; }
 uint64_t hr_topics_tree(void* r) { return static_cast<GpuRouter*>(r)->topics_tree(); }

@@ -39,6 +39,13 @@ def hr():
     for f in ("hr_topics", "hr_routes"):
         getattr(L, f).argtypes = [vp]; getattr(L, f).restype = C.c_int64
     L.hr_topics_tree.argtypes = [vp]; L.hr_topics_tree.restype = C.c_uint64
+    L.hs_new.restype = vp; L.hs_new.argtypes = [C.c_int]
+    L.hs_free.argtypes = [vp]
+    L.hs_set.argtypes = [vp, C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint32, C.c_int64, C.c_int64]
+    L.hs_get.argtypes = [vp, C.c_char_p, C.c_uint32, C.c_int64]; L.hs_get.restype = vp
+    L.hs_remove_expired.argtypes = [vp, C.c_int64]; L.hs_remove_expired.restype = C.c_uint64
+    for f in ("hs_count", "hs_max"):
+        getattr(L, f).argtypes = [vp]; getattr(L, f).restype = C.c_int64
     return L
 
 
@@ -128,3 +135,55 @@ def test_get_routes_unique(hr):   # router.rs:157-170: .unique() hides the wildc
     got = _take(hr, hr.hr_get(g, b"test/+", 6))
     assert got.split("\n")[:-1] == ["#", "test/#", "test/+"]
     hr.hr_free(g)
+
+
+def test_retain_storage_mirror(hr):
+    """GpuRetainStorage (RetainStorage surface: set / get / expiry / counters) vs the oracle's
+    RetainTree holding the same topics — DefaultRetainStorage semantics, retain.rs:229-267."""
+    s = hr.hs_new(0)
+    assert s
+    t = orc.RetainTree()
+    model = {}
+    rng = random.Random(3)
+    levels = ["a", "b", "c", "", "$SYS"]
+
+    def rand_topic():
+        n = rng.randint(1, 4)
+        return "/".join(rng.choice(levels if i == 0 else levels[:4]) for i in range(n))
+
+    def put(topic, payload, expiry=0, now=0):
+        tb, pb = topic.encode(), payload.encode()
+        assert hr.hs_set(s, tb, len(tb), pb, len(pb), expiry, now) == 0
+        if payload:
+            if topic not in model:
+                model[topic] = len(model) + 1000
+            t.insert(topic, model[topic])
+        elif topic in model:
+            t.remove(topic); del model[topic]
+
+    payloads = {}
+    for i in range(300):
+        tp = rand_topic()
+        pl = f"m{i}" if rng.random() < 0.85 else ""       # empty payload deletes the retained message
+        put(tp, pl)
+        if pl:
+            payloads[tp] = pl
+        else:
+            payloads.pop(tp, None)
+    assert hr.hs_count(s) == len(model) == t.values_size()
+    assert hr.hs_set(s, b"a/#/b", 5, b"x", 1, 0, 0) == -1            # invalid topic name -> Err
+    for f in ["#", "+", "a/#", "+/+", "a/+/c", "$SYS/#", "+/b/#", "a/b", "nope/#", "/+"]:
+        got = _take(hr, hr.hs_get(s, f.encode(), len(f.encode()), 0))
+        exp = "".join(f"{tp}\t{payloads[tp]}\n" for tp, _ in t.matches(f))
+        assert got == exp, f
+    assert hr.hs_get(s, b"a/#/b", 5, 0) is None
+    # expiry: TimedValue::is_expired filters at get(); remove_expired_messages prunes
+    put("exp/one", "e1", expiry=100, now=1000)
+    put("exp/two", "e2", expiry=500, now=1000)
+    assert _take(hr, hr.hs_get(s, b"exp/+", 5, 1050)) == "exp/one\te1\nexp/two\te2\n"
+    assert _take(hr, hr.hs_get(s, b"exp/+", 5, 1200)) == "exp/two\te2\n"
+    n0 = hr.hs_count(s)
+    assert hr.hs_remove_expired(s, 1200) == 1 and hr.hs_count(s) == n0 - 1
+    assert _take(hr, hr.hs_get(s, b"exp/#", 5, 1200)) == "exp/two\te2\n"
+    assert hr.hs_max(s) >= hr.hs_count(s)
+    hr.hs_free(s)
