@@ -943,10 +943,35 @@ int32_t rgr_batch_run(rgr_batch* b, uint64_t* n_hits, uint32_t* n_windows) {
 
 // ------------------------------------------------------------------ host in / host out
 namespace {
+// Tuple storage of a host result: pinned (hipHostMalloc) once it is large, so that the D2H copies
+// run at PCIe speed instead of through the driver's pageable-memory staging.
+struct TupleStore {
+    rgr_tuple* p = nullptr;
+    size_t n = 0, cap = 0;
+    bool pinned = false;
+    ~TupleStore() { release(); }
+    void release() {
+        if (!p) return;
+        if (pinned) (void)hipHostFree(p); else std::free(p);
+        p = nullptr; n = cap = 0;
+    }
+    void grow(size_t want) {       // keeps contents
+        if (want <= cap) return;
+        const size_t ncap = std::max(want, cap * 2);
+        const bool pin = ncap * sizeof(rgr_tuple) >= (4u << 20);
+        rgr_tuple* np = nullptr;
+        if (pin) { RGR_HIP(hipHostMalloc(reinterpret_cast<void**>(&np), ncap * sizeof(rgr_tuple), hipHostMallocDefault)); }
+        else { np = static_cast<rgr_tuple*>(std::malloc(std::max<size_t>(1, ncap) * sizeof(rgr_tuple))); if (!np) throw std::bad_alloc(); }
+        if (n) std::memcpy(np, p, n * sizeof(rgr_tuple));
+        const size_t keep = n;
+        release();
+        p = np; n = keep; cap = ncap; pinned = pin;
+    }
+};
 struct ResultOwner {
     std::vector<int32_t> status;
     std::vector<uint64_t> offsets;
-    std::vector<rgr_tuple> tuples;
+    TupleStore tuples;
     std::vector<uint32_t> ids;
 };
 }  // namespace
@@ -969,18 +994,20 @@ int32_t rgr_match_batch(rgr_handle* h, const uint8_t* blob, const uint64_t* offs
             r = rgr_batch_next_window(b, &w);
             if (r == RGR_EOF) break;
             if (r != RGR_OK) return r;
-            const size_t base = own->tuples.size();
-            own->tuples.resize(base + w.n_hits);
+            const size_t base = own->tuples.n;
+            if (base == 0 && w.topic_end == n) own->tuples.grow(w.n_hits);            // single window: exact size
+            else own->tuples.grow(base + w.n_hits);
+            own->tuples.n = base + w.n_hits;
             tmp.resize(size_t(w.topic_end - w.topic_begin) + 1);
-            r = rgr_window_to_host(b, &w, own->tuples.data() + base, tmp.data());
+            r = rgr_window_to_host(b, &w, own->tuples.p + base, tmp.data());
             if (r != RGR_OK) return r;
             for (uint32_t i = 0; i <= w.topic_end - w.topic_begin; ++i) own->offsets[w.topic_begin + i] = base + tmp[i];
         }
         out->n_topics = n;
-        out->n_hits = own->tuples.size();
+        out->n_hits = own->tuples.n;
         out->status = own->status.data();
         out->hit_offsets = own->offsets.data();
-        out->tuples = own->tuples.data();
+        out->tuples = own->tuples.p;
         out->_owner = own.release();
         return RGR_OK;
     });
