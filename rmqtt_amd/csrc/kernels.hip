@@ -29,13 +29,13 @@ namespace {
 constexpr int kWalkThreads = 256;
 constexpr int kWalkWindow = 2560;        // LDS words per array (tokens, stack): 2 x 10 KiB
 #ifndef RGR_EXPAND_THREADS
-#define RGR_EXPAND_THREADS 256
+#define RGR_EXPAND_THREADS 512
 #endif
 #ifndef RGR_EXPAND_PER_THREAD
-#define RGR_EXPAND_PER_THREAD 8
+#define RGR_EXPAND_PER_THREAD 4
 #endif
 #ifndef RGR_EXPAND_NT
-#define RGR_EXPAND_NT 0          // 1: nontemporal tuple stores
+#define RGR_EXPAND_NT 1          // nontemporal tuple stores: the output is write-once, keep L2 for the subscriber runs
 #endif
 constexpr int kExpandThreads = RGR_EXPAND_THREADS;
 constexpr int kExpandPerThread = RGR_EXPAND_PER_THREAD;
@@ -160,23 +160,15 @@ __global__ __launch_bounds__(kWalkThreads) void walk_kernel(TrieView tv, WalkArg
         // LDS window first, HBM only beyond it.  Written as an unconditional ds_read (clamped index)
         // plus a branch-guarded global load: a ?: over the two pointers makes hipcc emit flat_load,
         // which sends LDS-resident reads through the vector-memory path.
+        // (hipcc lowers the LDS-or-HBM select below to flat_load; an explicit ds_read + guarded
+        // global_load variant miscompared on small batches and was dropped — see DESIGN.md §10.)
         auto tok_at = [&](uint32_t d) -> uint32_t {
-            if (OVF) return a.tokens[off0 + d];
             const uint64_t i = rel + d;
-            const bool in = i < staged;
-            uint32_t v = s_tok[in ? uint32_t(i) : 0u];
-            asm volatile("" : "+v"(v));          // keep the ds_read: no pointer-select + flat_load
-            if (!in) v = a.tokens[off0 + d];
-            return v;
+            return (!OVF && i < staged) ? s_tok[i] : a.tokens[off0 + d];
         };
         auto path_get = [&](uint32_t d) -> uint32_t {
-            if (OVF) return a.path_scratch[off0 + d];
             const uint64_t i = rel + d;
-            const bool in = i < staged;
-            uint32_t v = s_path[in ? uint32_t(i) : 0u];
-            asm volatile("" : "+v"(v));
-            if (!in) v = a.path_scratch[off0 + d];
-            return v;
+            return (!OVF && i < staged) ? s_path[i] : a.path_scratch[off0 + d];
         };
         auto path_set = [&](uint32_t d, uint32_t v) {
             const uint64_t i = rel + d;
