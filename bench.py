@@ -253,7 +253,7 @@ def main():
         log(f"cpu_baseline: oracle table built in {time.time() - t:.1f}s; timing on {cores} threads", 0)
         hits_per_topic = max(1.0, total_hits / max(1, total_topics))
         # bounded sample: about 20 s of CPU work at the oracle's measured rates
-        budget_hits = (6.0e7 if retain else 3.0e9) * cores / 256
+        budget_hits = (3.5e7 if retain else 3.0e9) * cores / 256
         n_s = args.cpu_sample if args.cpu_sample > 0 else int(min(n_pub, max(200 if retain else 2000, budget_hits / hits_per_topic)))
         sb, so = shard.take(tb, to, np.arange(n_s))
         sec, ost = o.match_timed(sb, so, cores)

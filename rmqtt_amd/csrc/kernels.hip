@@ -26,8 +26,14 @@ namespace rgr {
 
 namespace {
 
-constexpr int kWalkThreads = 256;
-constexpr int kWalkWindow = 2560;        // LDS words per array (tokens, stack): 2 x 10 KiB
+#ifndef RGR_WALK_THREADS
+#define RGR_WALK_THREADS 256
+#endif
+#ifndef RGR_WALK_WINDOW
+#define RGR_WALK_WINDOW 2560             // LDS words per array (tokens, stack): 2 x 10 KiB per 256 topics
+#endif
+constexpr int kWalkThreads = RGR_WALK_THREADS;
+constexpr int kWalkWindow = RGR_WALK_WINDOW;
 #ifndef RGR_EXPAND_THREADS
 #define RGR_EXPAND_THREADS 512
 #endif
