@@ -577,7 +577,7 @@ void launch_tok_count(const uint8_t* blob, const uint64_t* offs, uint32_t n, uin
 void launch_scan_u32(const uint32_t* in, uint64_t* out, uint32_t n, uint64_t* block_tmp, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint32_t nb = (n + kScanBlock - 1) / kScanBlock;
-    if (nb == 0) { hipMemsetAsync(out, 0, 8, s); return; }
+    if (nb == 0) { (void)hipMemsetAsync(out, 0, 8, s); return; }
     scan1_reduce_kernel<<<nb, kScanThreads, 0, s>>>(in, n, block_tmp);
     scan_spine_kernel<1><<<1, 1024, 0, s>>>(block_tmp, nb);
     scan1_down_kernel<<<nb, kScanThreads, 0, s>>>(in, out, n, block_tmp, nb);
@@ -621,7 +621,7 @@ void launch_retain_finish(uint32_t n, const uint64_t* ovf_base, const uint64_t* 
 void launch_count(const TrieView& t, const ChunkArrays& c, void* stream) {
     if (c.n == 0) return;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    hipMemsetAsync(c.big_count, 0, 4, s);
+    (void)hipMemsetAsync(c.big_count, 0, 4, s);
     count_kernel<<<(c.n + 255) / 256, 256, 0, s>>>(t, c);
     count_big_kernel<<<512, 256, 0, s>>>(t, c);
 }

@@ -1,0 +1,67 @@
+"""Property-based parity (hypothesis): arbitrary filter sets / topics over a hostile alphabet —
+multi-byte UTF-8 levels, '$' in every position, empty levels, wildcards in publish topics,
+near-duplicate filters — through the host emulator (the kernels' own per-lane code + the
+product's table compiler) against the oracle and the brute-force matcher.  CPU only."""
+import numpy as np
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+from oracle import brute
+from oracle import oracle as orc
+from tests.emu import emu
+from tests.parity import compare_flat, pack
+
+LEVELS = st.sampled_from(["a", "b", "", "$", "$SYS", "é", "日本", "a b", "A", "+", "#", "a+", "#x", "x$"])
+TOPIC = st.lists(LEVELS, min_size=1, max_size=6).map("/".join)
+
+
+@settings(max_examples=600, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(filters=st.lists(TOPIC, min_size=0, max_size=25), topics=st.lists(TOPIC, min_size=1, max_size=25),
+       slot_cap=st.sampled_from([0, 1, 2]), window=st.sampled_from([0, 1, 7]), lds=st.sampled_from([0, 3, 2560]))
+def test_router_parity_property(filters, topics, slot_cap, window, lds):
+    o = orc.DefaultRouter()
+    e = emu.EmuRouter(slot_cap=slot_cap, window_hits=window, lds_window=lds, tile=4)
+    sub = 0
+    for f in filters:
+        ok = o.add(f, orc.mk_id(1, f"c{sub}"), orc.mk_opts(qos=sub % 3), rel_id=sub) == 0
+        try:
+            fid = e.filter_add(f)
+            assert ok, f"emu accepted a filter the reference rejects: {f!r}"
+            e.sub_add(fid, sub, sub % 3)
+        except ValueError:
+            assert not ok, f"emu rejected a filter the reference accepts: {f!r}"
+        sub += 1
+    blob, offs = pack(topics)
+    exp = o.match_flat(blob, offs)
+    got = e.match_batch(blob, offs)
+    compare_flat(got, exp)
+    # independent cross-check on wildcard-free valid topics
+    valid_filters = [(i, f) for i, f in enumerate(filters) if brute.valid(f)]
+    for ti, t in enumerate(topics):
+        if not brute.valid(t) or any(l in ("+", "#") for l in t.split("/")):
+            continue
+        ids = sorted(got["tuples"]["sub_id"][int(got["hit_offsets"][ti]):int(got["hit_offsets"][ti + 1])].tolist())
+        assert ids == sorted(i for i, f in valid_filters if brute.filter_matches(f, t)), (t, filters)
+
+
+@settings(max_examples=600, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(topics=st.lists(TOPIC, min_size=0, max_size=25, unique=True), filters=st.lists(TOPIC, min_size=1, max_size=20),
+       removes=st.lists(st.integers(0, 24), max_size=6))
+def test_retain_parity_property(topics, filters, removes):
+    t = orc.RetainTree()
+    e = emu.EmuRouter(window_hits=3, tile=4)
+    for i, s in enumerate(topics):
+        ok = t.insert(s, i) == 0
+        assert (e.retain_add(s, i) == 0) == ok, s
+    for r in removes:
+        if r < len(topics):
+            a = t.remove(topics[r])[0]
+            b = e.retain_remove(topics[r])
+            assert (a == 1) == (b == 0), topics[r]
+    blob, offs = pack(filters)
+    got = e.retain_match_batch(blob, offs)
+    st_, eo, ev, _ = t.match_batch(blob, offs)
+    assert np.array_equal(got["status"] < 0, st_ < 0)
+    assert np.array_equal(got["hit_offsets"], eo)
+    for a, b_ in zip(eo[:-1], eo[1:]):
+        assert sorted(got["topic_ids"][int(a):int(b_)].tolist()) == sorted(ev[int(a):int(b_)].tolist())
