@@ -11,12 +11,18 @@
 //                   lives in a second LDS window addressed like the tokens (one word per
 //                   level) and spills to HBM scratch beyond the window, so topic depth is
 //                   unbounded.  One 32-byte edge record is read per visited trie node.
+//   tok_count/tok_fill  device tokeniser: Topic::from_str + dictionary lookup, lane per topic.
+//   retain_*        RetainTree::matches as level-synchronous, load-balanced frontier rounds
+//                   over a preorder-numbered trie of retained topics.
 //   count/scan/compact  per-topic hit counts -> exclusive scans -> dense list of
-//                   (topic, subscriber-run) pairs with their output offsets.
+//                   (topic, subscriber-run) pairs with their output offsets (block-cooperative
+//                   for pair lists longer than kBigPairs).
 //   tiles_kernel    for every output tile, the first pair that intersects it.
 //   expand_kernel   load-balanced expansion: each block owns kTile consecutive output
 //                   positions, finds the owning pair of each position by binary search in LDS
-//                   and streams (topic_idx, sub_id, qos) tuples out fully coalesced.
+//                   and streams (topic_idx, sub_id, qos) tuples out fully coalesced with
+//                   nontemporal 12-byte stores.
+//   scatter_*       incremental epoch update: patch dirty edge records / filter descriptors.
 #include <hip/hip_runtime.h>
 
 #include "kernels.hpp"
