@@ -21,7 +21,7 @@ pub struct rgr_config {
     pub chunk_topics: u32,
     pub host_threads: u32,
     pub collect_walk_stats: u32,
-    pub reserved: u32,
+    pub host_tokenize: u32,
 }
 
 #[repr(C)]
@@ -64,4 +64,8 @@ extern "C" {
     pub fn rgr_retain_commit(h: *mut rgr_handle) -> i32;
     pub fn rgr_retain_match_batch(h: *mut rgr_handle, blob: *const u8, offsets: *const u64, n: u32, out: *mut rgr_retain_result) -> i32;
     pub fn rgr_retain_result_free(r: *mut rgr_retain_result);
+    pub fn rgr_subscribe_bulk(h: *mut rgr_handle, blob: *const u8, offsets: *const u64, n: u64, sub_ids: *const u32,
+                              qos: *const u8, flags: *const u8, filter_ids_out: *mut u32, n_rejected: *mut u64) -> i32;
+    pub fn rgr_shard_assign(blob: *const u8, offsets: *const u64, n: u64, n_shards: u32, is_filter: i32, key_levels: u32,
+                            out: *mut i32) -> i32;
 }
