@@ -87,7 +87,7 @@ struct Epoch {
 
 struct RetainEpoch {
     DictImage dict;
-    DevBuf edges, child_off, child_ids, desc, vals;
+    DevBuf edges, child_off, child_ids, desc, vals, gc_edges, gc_ids;
     RetainView view{};
     TrieView tv{};       // filt = run descriptors, subs = values: what count/compact/expand read
     uint64_t id = 0, n_topics = 0, n_nodes = 0, bytes = 0;
@@ -138,7 +138,7 @@ struct rgr_batch {
     // chunk work buffers
     DevBuf slots, pair_cnt, hit_cnt, pair_live, hit_off, pair_base, ovf_list, ovf_base, scalars, arena;
     DevBuf pair_src, pair_topic, pair_off, tile_first, out, scan_tmp;
-    DevBuf rf_filter[2], rf_node[2], r_cnt, r_payload, r_ecnt, r_e0, r_e1, r_out_off, r_epos, r_big, r_end;   // retain frontier rounds
+    DevBuf rf_filter[2], rf_node[2], r_cnt, r_payload, r_ecnt, r_e0, r_e1, r_out_off, r_epos, r_big, r_end, r_depth;   // retain frontier rounds
     PinnedBuf h_hit_off, h_pair_base, h_scalars;
     uint64_t arena_cap = 0;
     // pass state
@@ -379,6 +379,8 @@ void retain_rounds(rgr_batch* b, uint32_t begin, uint32_t n) {
     const RetainView& rv = b->repoch->view;
     Scalars* sc = b->scalars.as<Scalars>();
     b->r_end.ensure(size_t(n) * 8);
+    b->r_depth.ensure(std::max<size_t>(1, n) * 4);
+    RGR_HIP(hipMemsetAsync(b->r_depth.p, 0, size_t(n) * 4, b->stream));
     uint64_t g_total = 0, m = n, visited = 0;
     int cur = 0;
     for (uint32_t d = 0; m > 0; ++d) {
@@ -390,7 +392,7 @@ void retain_rounds(rgr_batch* b, uint32_t begin, uint32_t n) {
         b->scan_tmp.ensure((size_t(mm) / scan_block_topics() + 3) * 16);
         RetainRound r{};
         r.tokens = b->d_tokens.as<uint32_t>(); r.tok_off = b->d_tok_off.as<uint64_t>(); r.tflags = b->d_tflags.as<uint8_t>();
-        r.topic_base = begin; r.d = d; r.m = mm;
+        r.topic_base = begin; r.fdepth = b->r_depth.as<uint32_t>(); r.m = mm;
         r.f_filter = d == 0 ? nullptr : b->rf_filter[cur].as<uint32_t>();
         r.f_node = d == 0 ? nullptr : b->rf_node[cur].as<uint32_t>();
         r.cnt = b->r_cnt.as<uint32_t>(); r.payload = b->r_payload.as<uint32_t>();
@@ -417,6 +419,7 @@ void retain_rounds(rgr_batch* b, uint32_t begin, uint32_t n) {
             launch_retain_next(rv, r, b->r_out_off.as<uint64_t>(), b->rf_filter[cur ^ 1].as<uint32_t>(), b->rf_node[cur ^ 1].as<uint32_t>(),
                                b->r_big.as<uint32_t>(), &sc->big_count, b->stream);
         }
+        launch_retain_advance(r, n, b->r_depth.as<uint32_t>(), b->stream);
         visited += m;
         cur ^= 1;
         m = m_next;

@@ -244,10 +244,22 @@ __global__ __launch_bounds__(256) void retain_step_kernel(RetainView rv, RetainR
     if (!(r.tflags[gt] & kTopicInvalid)) {
         const uint64_t off0 = r.tok_off[gt];
         const uint32_t L = uint32_t(r.tok_off[gt + 1] - off0);
-        const uint32_t tok = r.d < L ? r.tokens[off0 + r.d] : 0u;
+        const uint32_t d = r.fdepth[f];
+        const uint32_t tok = d < L ? r.tokens[off0 + d] : 0u;
+        const uint32_t tok_next = d + 1 < L ? r.tokens[off0 + d + 1] : 0u;
         const REdge* edges = rv.edges;
         const uint32_t mask = rv.mask;
-        st = retain_step(rv, node, r.d, L, tok, [&](uint32_t p, uint32_t t) { return retain_probe(edges, mask, p, t); });
+        const GcEdge* gc = rv.gc_edges;
+        const uint32_t gmask = rv.gc_mask;
+        st = retain_step(
+            rv, node, d, L, tok, tok_next, [&](uint32_t p, uint32_t t) { return retain_probe(edges, mask, p, t); },
+            [&](uint32_t g, uint32_t t, uint32_t& begin, uint32_t& count) {
+                for (uint32_t s = edge_hash(g, t) & gmask;; s = (s + 1) & gmask) {
+                    const uint4 e = *reinterpret_cast<const uint4*>(gc + s);
+                    if (e.x == kEdgeEmpty) { begin = 0; count = 0; return; }
+                    if (e.x == g && e.y == t) { begin = e.z; count = e.w; return; }
+                }
+            });
     }
     r.cnt[i] = st.cnt; r.payload[i] = st.payload;
     r.e0[i] = st.e0; r.e1[i] = st.e1;
@@ -284,7 +296,7 @@ __global__ __launch_bounds__(256) void retain_big_kernel(RetainView rv, RetainRo
         const uint32_t c = r.cnt[i], pay = r.payload[i];
         const uint32_t f = r.f_filter ? r.f_filter[i] : i;
         const uint64_t o = out_off[i];
-        for (uint32_t k = threadIdx.x; k < c; k += 256) { nf_filter[o + k] = f; nf_node[o + k] = rv.child_ids[pay + k]; }
+        for (uint32_t k = threadIdx.x; k < c; k += 256) { nf_filter[o + k] = f; nf_node[o + k] = retain_child(rv, pay, k); }
     }
 }
 
@@ -305,6 +317,20 @@ __global__ __launch_bounds__(256) void retain_emit_kernel(RetainRound r, const u
     if (!n) return;
     if (r.e0[i] != kNone) arena[p++] = r.e0[i];
     if (r.e1[i] != kNone) arena[p++] = r.e1[i];
+}
+
+__global__ __launch_bounds__(256) void retain_advance_kernel(RetainRound r, uint32_t n, uint32_t* __restrict__ fdepth) {
+    const uint32_t f = blockIdx.x * 256 + threadIdx.x;
+    if (f >= n) return;
+    const uint32_t gt = r.topic_base + f;
+    const uint64_t off0 = r.tok_off[gt];
+    const uint32_t L = uint32_t(r.tok_off[gt + 1] - off0);
+    const uint32_t d = fdepth[f];
+    if (d > L) return;                                  // finished long ago
+    bool jump = false;
+    if (d < L && !(r.tflags[gt] & kTopicInvalid))
+        jump = retain_jumps(r.tokens[off0 + d], d + 1 < L, d + 1 < L ? r.tokens[off0 + d + 1] : 0u);
+    fdepth[f] = d + (jump ? 2u : 1u);
 }
 
 __global__ __launch_bounds__(256) void retain_finish_kernel(uint32_t n, const uint64_t* __restrict__ ovf_base,
@@ -605,6 +631,10 @@ void launch_walk(const TrieView& t, const WalkArgs& a, bool overflow_pass, void*
 
 void launch_retain_step(const RetainView& t, const RetainRound& r, void* stream) {
     if (r.m) retain_step_kernel<<<(r.m + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(t, r);
+}
+
+void launch_retain_advance(const RetainRound& r, uint32_t n, uint32_t* fdepth, void* stream) {
+    if (n) retain_advance_kernel<<<(n + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(r, n, fdepth);
 }
 
 void launch_retain_next(const RetainView& t, const RetainRound& r, const uint64_t* out_off, uint32_t* nf_filter, uint32_t* nf_node,

@@ -81,9 +81,17 @@ struct TrieView {
 // in DFS preorder so that "every valued node in the subtree of p" is ONE contiguous run of
 // vals[]; '+' enumerates a node's children through a CSR child list.
 struct alignas(16) REdge { uint32_t parent, token, child, pad; };   // open-addressed (parent,token)->child
+// grandchild index: (node g, literal token t) -> the run gc_ids[begin, begin+count) of all nodes x
+// with token t whose grandparent is g (under the root: only via non-'$' children).  Lets a '+'
+// level followed by a literal level jump two levels with ONE probe instead of enumerating every
+// child of g and probing each.
+struct alignas(16) GcEdge { uint32_t gparent, token, begin, count; };
 struct RetainView {
     const REdge* edges;
     uint32_t mask;
+    const GcEdge* gc_edges;
+    uint32_t gc_mask;
+    const uint32_t* gc_ids;
     const uint32_t* child_off;   // [N+1] CSR into child_ids (children in preorder order)
     const uint32_t* child_ids;
     uint32_t root_nonmeta;       // root's children that are not '$'-metadata come first
@@ -149,7 +157,7 @@ void launch_walk(const TrieView& t, const WalkArgs& a, bool overflow_pass, void*
 struct RetainRound {
     const uint32_t* tokens; const uint64_t* tok_off; const uint8_t* tflags;
     uint32_t topic_base;        // first filter of the chunk
-    uint32_t d;                 // level processed this round
+    const uint32_t* fdepth;     // [n] level each filter's items stand at this round
     uint32_t m;                 // frontier size
     const uint32_t* f_filter;   // [m] chunk-local filter index (null in round 0: item i = filter i at the root)
     const uint32_t* f_node;     // [m]
@@ -157,6 +165,8 @@ struct RetainRound {
     uint32_t* ecnt; uint32_t* e0; uint32_t* e1;   // [m] emitted descriptors
 };
 void launch_retain_step(const RetainView& t, const RetainRound& r, void* stream);
+// after a round: fdepth[f] += 1, or 2 where the level was a '+' followed by a literal level
+void launch_retain_advance(const RetainRound& r, uint32_t n, uint32_t* fdepth, void* stream);
 void launch_retain_next(const RetainView& t, const RetainRound& r, const uint64_t* out_off, uint32_t* nf_filter, uint32_t* nf_node,
                         uint32_t* big_list, uint32_t* big_count, void* stream);
 void launch_retain_emit(const RetainRound& r, const uint64_t* epos, uint64_t g_base, uint32_t* arena, uint64_t* ovf_base,

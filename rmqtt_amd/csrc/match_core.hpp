@@ -170,11 +170,19 @@ RGR_HD inline uint32_t walk_topic(const NodeHeader& root, uint32_t mask, uint32_
 // An exact key equal to a wildcard token takes precedence over the wildcard meaning (the
 // else-if chain at retain.rs:472/483/502).  Expansion keeps items in order, so every filter's
 // descriptors come out in ascending trie preorder — deterministic.
-constexpr uint32_t kLitFlag = 0x80000000u;
+constexpr uint32_t kLitFlag = 0x80000000u;   // payload = one node id
+constexpr uint32_t kGcFlag = 0x40000000u;    // payload = first index of a gc_ids run
 struct RetainStep { uint32_t cnt, payload, e0, e1; };
 
-template <class Probe>
-RGR_HD inline RetainStep retain_step(const RetainView& rv, uint32_t node, uint32_t d, uint32_t L, uint32_t tok, Probe probe) {
+// A '+' level followed by a literal level is taken in one jump of two levels (grandchild index).
+// Depends on the filter's tokens only, so all items of a filter always stand at the same level.
+RGR_HD inline bool retain_jumps(uint32_t tok, bool has_next, uint32_t tok_next) {
+    return tok == kTokPlus && has_next && tok_next >= kTokFirst;
+}
+
+template <class Probe, class ProbeGc>
+RGR_HD inline RetainStep retain_step(const RetainView& rv, uint32_t node, uint32_t d, uint32_t L, uint32_t tok, uint32_t tok_next,
+                                     Probe probe, ProbeGc probe_gc) {
     RetainStep r{0, 0, kNone, kNone};
     if (d == L) { r.e0 = 2 * node; return r; }
     if (tok == kTokHash) {                               // trailing '#'
@@ -188,8 +196,21 @@ RGR_HD inline RetainStep retain_step(const RetainView& rv, uint32_t node, uint32
         return r;
     }
     if (tok == kTokPlus) {
+        const bool jump = retain_jumps(tok, d + 1 < L, tok_next);
         const uint32_t c = probe(node, kTokPlus);
-        if (c != kNone) { r.cnt = 1; r.payload = c | kLitFlag; return r; }
+        if (c != kNone) {                                // literal "+" key: exact-first (retain.rs:472)
+            if (!jump) { r.cnt = 1; r.payload = c | kLitFlag; return r; }
+            const uint32_t c2 = tok_next == kTokUnknown ? kNone : probe(c, tok_next);   // both levels in this round
+            if (c2 != kNone) { r.cnt = 1; r.payload = c2 | kLitFlag; }
+            return r;
+        }
+        if (jump) {                                      // all grandchildren carrying tok_next, one probe
+            if (tok_next == kTokUnknown) return r;
+            uint32_t begin = 0, count = 0;
+            probe_gc(node, tok_next, begin, count);
+            r.cnt = count; r.payload = begin | kGcFlag;
+            return r;
+        }
         const uint32_t b = rv.child_off[node];
         const uint32_t e = node == 0 ? b + rv.root_nonmeta : rv.child_off[node + 1];
         r.cnt = e - b; r.payload = b;
@@ -203,7 +224,9 @@ RGR_HD inline RetainStep retain_step(const RetainView& rv, uint32_t node, uint32
 
 // k-th item an expansion (cnt, payload) contributes to the next frontier.
 RGR_HD inline uint32_t retain_child(const RetainView& rv, uint32_t payload, uint32_t k) {
-    return (payload & kLitFlag) ? (payload & ~kLitFlag) : rv.child_ids[payload + k];
+    if (payload & kLitFlag) return payload & ~kLitFlag;
+    if (payload & kGcFlag) return rv.gc_ids[(payload & ~kGcFlag) + k];
+    return rv.child_ids[payload + k];
 }
 
 // j-th matched filter of chunk-local topic t (slots are j-major; topics whose count

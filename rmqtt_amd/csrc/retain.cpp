@@ -196,6 +196,40 @@ void RetainTable::compile(RetainImage& out) const {
     uint32_t first_meta_pre = N;
     if (out.root_nonmeta < cnt[1] - cnt[0]) first_meta_pre = pre[kids[cnt[0] + out.root_nonmeta]];
     out.desc[2 * size_t(N)] = FilterDesc{0, val_rank[first_meta_pre]};
+    // grandchild index: (grandparent g, literal token t) -> run of nodes x (preorder ascending)
+    {
+        struct Tri { uint32_t g, tok, x; };
+        std::vector<Tri> tri;
+        tri.reserve(N);
+        for (uint32_t m = 1; m < total; ++m) {
+            if (pre[m] == kNone) continue;                       // freed slot
+            const Node& nx = nodes_[m];
+            if (nx.token < kTokFirst || nx.parent == 0) continue;   // wildcard-token levels and depth-1 nodes are not indexed
+            const uint32_t p = nx.parent, g = nodes_[p].parent;
+            if (g == 0 && nodes_[p].meta) continue;              // a '+' at the root skips '$' children (retain.rs:486-490)
+            tri.push_back(Tri{pre[g], nx.token, pre[m]});
+        }
+        std::sort(tri.begin(), tri.end(), [](const Tri& a, const Tri& b) {
+            if (a.g != b.g) return a.g < b.g;
+            if (a.tok != b.tok) return a.tok < b.tok;
+            return a.x < b.x;
+        });
+        out.gc_ids.resize(tri.size());
+        size_t runs = 0;
+        for (size_t i = 0; i < tri.size(); ++i) { out.gc_ids[i] = tri[i].x; runs += i == 0 || tri[i].g != tri[i - 1].g || tri[i].tok != tri[i - 1].tok; }
+        uint64_t gcap = 1024;
+        while (gcap < runs * 2) gcap <<= 1;
+        out.gc_edges.assign(gcap, GcEdge{kEdgeEmpty, 0, 0, 0});
+        const uint32_t gmask = uint32_t(gcap - 1);
+        for (size_t i = 0; i < tri.size();) {
+            size_t j = i;
+            while (j < tri.size() && tri[j].g == tri[i].g && tri[j].tok == tri[i].tok) ++j;
+            uint32_t s = edge_hash(tri[i].g, tri[i].tok) & gmask;
+            while (out.gc_edges[s].gparent != kEdgeEmpty) s = (s + 1) & gmask;
+            out.gc_edges[s] = GcEdge{tri[i].g, tri[i].tok, uint32_t(i), uint32_t(j - i)};
+            i = j;
+        }
+    }
     // edge table over preorder ids
     uint64_t cap = 1024;
     while (cap < uint64_t(N) * 2) cap <<= 1;

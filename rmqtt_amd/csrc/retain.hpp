@@ -19,6 +19,8 @@ namespace rgr {
 
 struct RetainImage {   // host copy of one snapshot, preorder-numbered
     std::vector<REdge> edges;
+    std::vector<GcEdge> gc_edges;          // grandchild index (kernels.hpp)
+    std::vector<uint32_t> gc_ids;
     std::vector<uint32_t> child_off, child_ids;
     std::vector<FilterDesc> desc;
     std::vector<SubEntry> vals;

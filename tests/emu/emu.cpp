@@ -279,8 +279,12 @@ int32_t emu_retain_match(void* ev, const uint8_t* blob, const uint64_t* offs, ui
     e->retain.compile(img);
     img.vals.push_back(SubEntry{0, 0});
     img.child_ids.push_back(0);
-    RetainView rv{img.edges.data(), uint32_t(img.edges.size() - 1), img.child_off.data(), img.child_ids.data(), img.root_nonmeta,
-                  img.n_nodes, img.desc.data(), img.vals.data()};
+    img.gc_ids.push_back(0);
+    RetainView rv{};
+    rv.edges = img.edges.data(); rv.mask = uint32_t(img.edges.size() - 1);
+    rv.gc_edges = img.gc_edges.data(); rv.gc_mask = uint32_t(img.gc_edges.size() - 1); rv.gc_ids = img.gc_ids.data();
+    rv.child_off = img.child_off.data(); rv.child_ids = img.child_ids.data(); rv.root_nonmeta = img.root_nonmeta;
+    rv.n_nodes = img.n_nodes; rv.desc = img.desc.data(); rv.vals = img.vals.data();
     TrieView tv{};
     tv.filt = rv.desc; tv.subs = rv.vals;
     auto probe = [&](uint32_t parent, uint32_t token) -> uint32_t {
@@ -291,11 +295,18 @@ int32_t emu_retain_match(void* ev, const uint8_t* blob, const uint64_t* offs, ui
         }
     };
     // the level-synchronous frontier rounds of c_abi.cpp::retain_rounds, sequentially
+    auto probe_gc = [&](uint32_t g, uint32_t t, uint32_t& b0, uint32_t& c0) {
+        for (uint32_t s = edge_hash(g, t) & rv.gc_mask;; s = (s + 1) & rv.gc_mask) {
+            const GcEdge& en = rv.gc_edges[s];
+            if (en.gparent == kEdgeEmpty) { b0 = 0; c0 = 0; return; }
+            if (en.gparent == g && en.token == t) { b0 = en.begin; c0 = en.count; return; }
+        }
+    };
     auto prefill = [&](uint32_t begin, uint32_t cn, std::vector<uint32_t>& pair_cnt, std::vector<uint64_t>& ovf_base, std::vector<uint32_t>& arena) {
-        std::vector<uint32_t> ff(cn), fn(cn, 0);
+        std::vector<uint32_t> ff(cn), fn(cn, 0), fdepth(cn, 0);
         for (uint32_t i = 0; i < cn; ++i) ff[i] = i;
         arena.clear();
-        for (uint32_t d = 0; !ff.empty(); ++d) {
+        while (!ff.empty()) {
             const size_t m = ff.size();
             std::vector<RetainStep> st(m);
             for (size_t i = 0; i < m; ++i) {
@@ -304,7 +315,17 @@ int32_t emu_retain_match(void* ev, const uint8_t* blob, const uint64_t* offs, ui
                 if (tflags[gt] & kTopicInvalid) continue;
                 const uint64_t off0 = tok_off[gt];
                 const uint32_t L = uint32_t(tok_off[gt + 1] - off0);
-                st[i] = retain_step(rv, fn[i], d, L, d < L ? tokens[off0 + d] : 0u, probe);
+                const uint32_t d = fdepth[ff[i]];
+                st[i] = retain_step(rv, fn[i], d, L, d < L ? tokens[off0 + d] : 0u, d + 1 < L ? tokens[off0 + d + 1] : 0u, probe, probe_gc);
+            }
+            for (uint32_t f = 0; f < cn; ++f) {          // retain_advance_kernel
+                const uint32_t gt = begin + f;
+                const uint64_t off0 = tok_off[gt];
+                const uint32_t L = uint32_t(tok_off[gt + 1] - off0), d = fdepth[f];
+                if (d > L) continue;
+                bool jump = false;
+                if (d < L && !(tflags[gt] & kTopicInvalid)) jump = retain_jumps(tokens[off0 + d], d + 1 < L, d + 1 < L ? tokens[off0 + d + 1] : 0u);
+                fdepth[f] = d + (jump ? 2u : 1u);
             }
             e->visited += m;
             // emit (item order) + next frontier (scatter at the exclusive scan of cnt)
