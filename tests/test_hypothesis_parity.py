@@ -1,8 +1,10 @@
 """Property-based parity (hypothesis): arbitrary filter sets / topics over a hostile alphabet —
 multi-byte UTF-8 levels, '$' in every position, empty levels, wildcards in publish topics,
 near-duplicate filters — through the host emulator (the kernels' own per-lane code + the
-product's table compiler) against the oracle and the brute-force matcher.  CPU only."""
+product's table compiler; CPU) and through the HIP path (`-m gpu`, fewer examples) against the
+oracle and the brute-force matcher."""
 import numpy as np
+import pytest
 from hypothesis import HealthCheck, given, settings
 from hypothesis import strategies as st
 
@@ -65,3 +67,38 @@ def test_retain_parity_property(topics, filters, removes):
     assert np.array_equal(got["hit_offsets"], eo)
     for a, b_ in zip(eo[:-1], eo[1:]):
         assert sorted(got["topic_ids"][int(a):int(b_)].tolist()) == sorted(ev[int(a):int(b_)].tolist())
+
+
+@pytest.mark.gpu
+@settings(max_examples=80, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(filters=st.lists(TOPIC, min_size=0, max_size=25), topics=st.lists(TOPIC, min_size=1, max_size=25),
+       retained=st.lists(TOPIC, min_size=0, max_size=20, unique=True), slot_cap=st.sampled_from([0, 1, 2]))
+def test_hip_parity_property(filters, topics, retained, slot_cap):
+    """The same properties through the real kernels and the C ABI (device tokeniser included)."""
+    from rmqtt_amd import capi
+    o = orc.DefaultRouter()
+    r = capi.Router(device=0, slot_cap=slot_cap, window_hits=7)
+    sub = 0
+    for f in filters:
+        ok = o.add(f, orc.mk_id(1, f"c{sub}"), orc.mk_opts(qos=sub % 3), rel_id=sub) == 0
+        try:
+            fid = r.filter_add(f)
+            assert ok
+            r.sub_add(fid, sub, sub % 3)
+        except capi.RgrError:
+            assert not ok
+        sub += 1
+    r.commit()
+    blob, offs = pack(topics)
+    compare_flat(r.match_batch(blob, offs), o.match_flat(blob, offs))
+    t = orc.RetainTree()
+    for i, s_ in enumerate(retained):
+        ok = t.insert(s_, i) == 0
+        assert (r.retain_add(s_, i) == 0) == ok
+    r.retain_commit()
+    got = r.retain_match_batch(blob, offs)
+    st_, eo, ev, _ = t.match_batch(blob, offs)
+    assert np.array_equal(got["status"] < 0, st_ < 0) and np.array_equal(got["hit_offsets"], eo)
+    for a, b_ in zip(eo[:-1], eo[1:]):
+        assert sorted(got["topic_ids"][int(a):int(b_)].tolist()) == sorted(ev[int(a):int(b_)].tolist())
+    r.close()
