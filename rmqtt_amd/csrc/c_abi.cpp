@@ -596,18 +596,7 @@ int32_t rgr_subscribe_bulk(rgr_handle* h, const uint8_t* blob, const uint64_t* o
     return guarded([&]() -> int32_t {
         if (!h || (n && (!blob || !offsets))) return fail(RGR_EINVAL, "rgr_subscribe_bulk: bad argument");
         std::unique_lock<std::shared_mutex> lk(h->table_mu);
-        uint64_t levels = 0;
-        if (n) levels = (offsets[n] - offsets[0]) / 6 + n;      // rough: >= number of '/' separated levels
-        h->table.reserve(h->table.n_filters() + n, h->table.n_nodes() + levels);
-        uint64_t rejected = 0;
-        for (uint64_t i = 0; i < n; ++i) {
-            uint32_t fid = kNone;
-            int32_t rc = h->table.filter_add(std::string_view(reinterpret_cast<const char*>(blob) + offsets[i], offsets[i + 1] - offsets[i]), &fid);
-            if (rc != RGR_OK) { rejected++; if (filter_ids_out) filter_ids_out[i] = kNone; continue; }
-            h->table.sub_add(fid, sub_ids ? sub_ids[i] : uint32_t(i), qos ? qos[i] : 0, flags ? flags[i] : 0);
-            if (filter_ids_out) filter_ids_out[i] = fid;
-        }
-        if (n_rejected) *n_rejected = rejected;
+        h->table.subscribe_bulk(blob, offsets, n, sub_ids, qos, flags, filter_ids_out, n_rejected, h->cfg.host_threads);
         return RGR_OK;
     });
 }

@@ -3,6 +3,8 @@
 
 #include <algorithm>
 #include <cstring>
+#include <thread>
+#include <unordered_set>
 
 #include "rmqtt_gpu_router.h"
 #include "topic.hpp"
@@ -285,6 +287,132 @@ int32_t HostTable::sub_remove(uint32_t fid, uint32_t sub_id) {
     delta_.fids.push_back(fid);
     n_subs_--;
     return RGR_OK;
+}
+
+void HostTable::subscribe_bulk(const uint8_t* blob, const uint64_t* offs, uint64_t n, const uint32_t* sub_ids, const uint8_t* qos,
+                               const uint8_t* flags, uint32_t* fids_out, uint64_t* n_rejected, unsigned threads) {
+    if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
+    threads = unsigned(std::min<uint64_t>(threads, std::max<uint64_t>(1, n / 8192)));
+    auto sv = [&](uint64_t i) { return std::string_view(reinterpret_cast<const char*>(blob) + offs[i], offs[i + 1] - offs[i]); };
+    auto run = [&](auto&& fn) {
+        if (threads == 1) { fn(0u); return; }
+        std::vector<std::thread> th;
+        for (unsigned k = 0; k < threads; ++k) th.emplace_back(fn, k);
+        for (auto& t : th) t.join();
+    };
+    // ---- A: parallel parse against the current dictionary; unknown level strings are collected
+    struct Part { std::vector<uint32_t> toks; std::vector<uint32_t> lens; std::vector<std::pair<uint64_t, std::string_view>> fix;
+                  std::unordered_set<std::string_view> fresh; };
+    std::vector<Part> parts(threads);
+    run([&](unsigned k) {
+        Part& p = parts[k];
+        const uint64_t lo = n * k / threads, hi = n * (k + 1) / threads;
+        p.lens.reserve(hi - lo); p.toks.reserve((hi - lo) * 9);
+        for (uint64_t i = lo; i < hi; ++i) {
+            const size_t mark = p.toks.size();
+            int64_t L = for_each_level(sv(i), [&](int64_t, std::string_view seg, LevelKind kd) {
+                if (kd == LevelKind::Plus) p.toks.push_back(kTokPlus);
+                else if (kd == LevelKind::Hash) p.toks.push_back(kTokHash);
+                else {
+                    const uint32_t t = dict_.find(seg);
+                    if (t == kTokUnknown) { p.fix.emplace_back(p.toks.size(), seg); p.fresh.insert(seg); }
+                    p.toks.push_back(t);
+                }
+            });
+            if (L < 0) {                                    // invalid filter: drop its partial tokens / fix-ups
+                while (!p.fix.empty() && p.fix.back().first >= mark) p.fix.pop_back();
+                p.toks.resize(mark);
+                p.lens.push_back(kNone);
+            } else p.lens.push_back(uint32_t(L));
+        }
+    });
+    // ---- B: intern the new level strings (single thread), C: patch the unknown tokens
+    for (auto& p : parts) for (auto& s : p.fresh) dict_.intern(s);
+    run([&](unsigned k) { for (auto& f : parts[k].fix) parts[k].toks[f.first] = dict_.find(f.second); });
+    // flat token arrays
+    std::vector<uint64_t> toff(n + 1, 0);
+    std::vector<uint8_t> valid(n, 1);
+    uint64_t rejected = 0;
+    {
+        uint64_t i = 0;
+        for (auto& p : parts) for (uint32_t L : p.lens) { valid[i] = L != kNone; rejected += L == kNone; toff[i + 1] = toff[i] + (L == kNone ? 0 : L); ++i; }
+    }
+    std::vector<uint32_t> toks(toff[n]);
+    {
+        uint64_t at = 0;
+        for (auto& p : parts) { std::copy(p.toks.begin(), p.toks.end(), toks.begin() + at); at += p.toks.size(); std::vector<uint32_t>().swap(p.toks); }
+    }
+    // ---- order: lexicographic by token sequence (ties by arrival index: stable ids)
+    std::vector<uint32_t> idx;
+    idx.reserve(n - rejected);
+    for (uint64_t i = 0; i < n; ++i) if (valid[i]) idx.push_back(uint32_t(i));
+    auto less = [&](uint32_t a, uint32_t b) {
+        const uint32_t* pa = toks.data() + toff[a]; const uint32_t* pb = toks.data() + toff[b];
+        const uint64_t la = toff[a + 1] - toff[a], lb = toff[b + 1] - toff[b];
+        const uint64_t m = std::min(la, lb);
+        for (uint64_t k = 0; k < m; ++k) if (pa[k] != pb[k]) return pa[k] < pb[k];
+        if (la != lb) return la < lb;
+        return a < b;
+    };
+    {
+        const size_t m = idx.size();
+        std::vector<size_t> cut(threads + 1);
+        for (unsigned k = 0; k <= threads; ++k) cut[k] = m * k / threads;
+        run([&](unsigned k) { std::sort(idx.begin() + cut[k], idx.begin() + cut[k + 1], less); });
+        for (unsigned width = 1; width < threads; width *= 2) {         // pairwise merges, parallel per round
+            std::vector<std::thread> th;
+            for (unsigned k = 0; k + width < threads; k += 2 * width)
+                th.emplace_back([&, k] { std::inplace_merge(idx.begin() + cut[k], idx.begin() + cut[k + width], idx.begin() + cut[std::min(threads, k + 2 * width)], less); });
+            for (auto& t : th) t.join();
+        }
+    }
+    // ---- insert in sorted order: only the levels past the common prefix with the predecessor.
+    // The sorted order also gives the exact number of trie nodes the batch can add, so the edge
+    // table is sized once, to what is needed (no rehash while inserting).
+    {
+        uint64_t new_nodes = 0;
+        const uint32_t* pv = nullptr; uint64_t pl = 0;
+        for (uint32_t i : idx) {
+            const uint32_t* cu = toks.data() + toff[i];
+            const uint64_t L = toff[i + 1] - toff[i];
+            uint64_t lcp = 0;
+            while (lcp < L && lcp < pl && cu[lcp] == pv[lcp]) ++lcp;
+            new_nodes += L - lcp;
+            pv = cu; pl = L;
+        }
+        reserve(n_filters_ + idx.size(), n_nodes_ + new_nodes);
+    }
+    std::vector<uint32_t> path{0};                   // path[l] = node reached after l levels of the previous filter
+    const uint32_t* prev = nullptr; uint64_t prev_len = 0;
+    for (uint32_t i : idx) {
+        const uint32_t* cur = toks.data() + toff[i];
+        const uint64_t L = toff[i + 1] - toff[i];
+        uint64_t lcp = 0;
+        while (lcp < L && lcp < prev_len && cur[lcp] == prev[lcp]) ++lcp;
+        path.resize(lcp + 1);
+        uint32_t node = path[lcp];
+        for (uint64_t l = lcp; l < L; ++l) {
+            const uint32_t s = find_slot(node, cur[l]);
+            node = s != kNone ? edges_[s].child : new_node(node, cur[l]);
+            path.push_back(node);
+        }
+        prev = cur; prev_len = L;
+        uint32_t fid = nodes_[node].term_fid;
+        if (fid == kNone) {
+            if (!free_fids_.empty()) { fid = free_fids_.back(); free_fids_.pop_back(); }
+            else { fid = uint32_t(filters_.size()); filters_.emplace_back(); }
+            filters_[fid].node = node;
+            filters_[fid].subs.clear();
+            delta_.fids.push_back(fid);
+            set_term_fid(node, fid);
+            if (nodes_[node].token == kTokHash) set_hash_fid(nodes_[node].parent, fid);
+            n_filters_++;
+        }
+        sub_add(fid, sub_ids ? sub_ids[i] : i, qos ? qos[i] : 0, flags ? flags[i] : 0);
+        if (fids_out) fids_out[i] = fid;
+    }
+    if (fids_out) for (uint64_t i = 0; i < n; ++i) if (!valid[i]) fids_out[i] = kNone;
+    if (n_rejected) *n_rejected = rejected;
 }
 
 void HostTable::flatten_filters(std::vector<FilterDesc>& filt, std::vector<SubEntry>& subs) const {

@@ -53,6 +53,13 @@ class HostTable {
     int32_t filter_remove(uint32_t fid);
     int32_t sub_add(uint32_t fid, uint32_t sub_id, uint8_t qos, uint8_t flags);
     int32_t sub_remove(uint32_t fid, uint32_t sub_id);
+    // Restore / bulk path (rmqtt-cluster-raft/src/router.rs:557-566 re-inserts every filter after a
+    // snapshot): filter_add + sub_add for n subscriptions.  Tokenises on `threads` threads, sorts the
+    // filters by token sequence and inserts them in that order so that each filter only creates the
+    // trie levels it does not share with its predecessor.  Result is identical to n single calls
+    // (filter ids are assigned in sorted order instead of arrival order).
+    void subscribe_bulk(const uint8_t* blob, const uint64_t* offs, uint64_t n, const uint32_t* sub_ids, const uint8_t* qos,
+                        const uint8_t* flags, uint32_t* fids_out, uint64_t* n_rejected, unsigned threads);
 
     // Flattened image for the device.
     const std::vector<EdgeEntry>& edges() const { return edges_; }

@@ -63,13 +63,7 @@ uint64_t emu_windows(void* e) { return static_cast<Emu*>(e)->windows; }
 int32_t emu_subscribe_bulk(void* ev, const uint8_t* blob, const uint64_t* offs, uint64_t n, const uint32_t* sub_ids,
                            const uint8_t* qos, const uint8_t* flags, uint64_t* rejected) {
     auto* e = static_cast<Emu*>(ev);
-    uint64_t rej = 0;
-    for (uint64_t i = 0; i < n; ++i) {
-        uint32_t fid;
-        if (e->table.filter_add(std::string_view(reinterpret_cast<const char*>(blob) + offs[i], offs[i + 1] - offs[i]), &fid) != RGR_OK) { rej++; continue; }
-        e->table.sub_add(fid, sub_ids ? sub_ids[i] : uint32_t(i), qos ? qos[i] : 0, flags ? flags[i] : 0);
-    }
-    if (rejected) *rejected = rej;
+    e->table.subscribe_bulk(blob, offs, n, sub_ids, qos, flags, nullptr, rejected, 3);
     return RGR_OK;
 }
 
