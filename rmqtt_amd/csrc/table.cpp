@@ -3,6 +3,9 @@
 
 #include <algorithm>
 #include <cstring>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <thread>
 #include <unordered_set>
 
@@ -293,6 +296,10 @@ void HostTable::subscribe_bulk(const uint8_t* blob, const uint64_t* offs, uint64
                                const uint8_t* flags, uint32_t* fids_out, uint64_t* n_rejected, unsigned threads) {
     if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
     threads = unsigned(std::min<uint64_t>(threads, std::max<uint64_t>(1, n / 8192)));
+    const bool prof = std::getenv("RGR_BULK_PROFILE") != nullptr;
+    auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = tnow();
+    auto lap = [&](const char* what) { if (prof) { const double t = tnow(); std::fprintf(stderr, "[bulk] %-12s %.3f s\n", what, t - t_prev); t_prev = t; } };
     auto sv = [&](uint64_t i) { return std::string_view(reinterpret_cast<const char*>(blob) + offs[i], offs[i + 1] - offs[i]); };
     auto run = [&](auto&& fn) {
         if (threads == 1) { fn(0u); return; }
@@ -329,6 +336,7 @@ void HostTable::subscribe_bulk(const uint8_t* blob, const uint64_t* offs, uint64
     // ---- B: intern the new level strings (single thread), C: patch the unknown tokens
     for (auto& p : parts) for (auto& s : p.fresh) dict_.intern(s);
     run([&](unsigned k) { for (auto& f : parts[k].fix) parts[k].toks[f.first] = dict_.find(f.second); });
+    lap("tokenise");
     // flat token arrays
     std::vector<uint64_t> toff(n + 1, 0);
     std::vector<uint8_t> valid(n, 1);
@@ -366,9 +374,11 @@ void HostTable::subscribe_bulk(const uint8_t* blob, const uint64_t* offs, uint64
             for (auto& t : th) t.join();
         }
     }
+    lap("sort");
     // ---- insert in sorted order: only the levels past the common prefix with the predecessor.
     // The sorted order also gives the exact number of trie nodes the batch can add, so the edge
-    // table is sized once, to what is needed (no rehash while inserting).
+    // table is sized once (no rehash while inserting).
+    uint64_t new_nodes_total = 0;
     {
         uint64_t new_nodes = 0;
         const uint32_t* pv = nullptr; uint64_t pl = 0;
@@ -380,8 +390,37 @@ void HostTable::subscribe_bulk(const uint8_t* blob, const uint64_t* offs, uint64
             new_nodes += L - lcp;
             pv = cu; pl = L;
         }
-        reserve(n_filters_ + idx.size(), n_nodes_ + new_nodes);
+        new_nodes_total = new_nodes;
     }
+    // Empty table (the restore case): in sorted order a child exists iff it lies on the previous
+    // filter's path, so no hash probe is needed while creating nodes; the edge table is
+    // materialised once at the end (sequential pass with software prefetch) instead of 2 random
+    // DRAM accesses per created node.
+    const bool deferred = n_nodes_ == 1 && edge_live_ == 0;
+    std::vector<uint32_t> lit_cnt, lit_xor;
+    if (deferred) {
+        lit_cnt.assign(nodes_.size(), 0); lit_xor.assign(nodes_.size(), 0);
+        nodes_.reserve(nodes_.size() + new_nodes_total);
+        lit_cnt.reserve(nodes_.size() + new_nodes_total); lit_xor.reserve(nodes_.size() + new_nodes_total);
+        filters_.reserve(n_filters_ + idx.size());
+    } else {
+        reserve(n_filters_ + idx.size(), n_nodes_ + 2 * new_nodes_total);
+    }
+    auto child_of = [&](uint32_t parent, uint32_t tok) -> uint32_t {
+        if (!deferred) {
+            const uint32_t s = find_slot(parent, tok);
+            return s != kNone ? edges_[s].child : new_node(parent, tok);
+        }
+        const uint32_t id = uint32_t(nodes_.size());
+        nodes_.push_back(Node{parent, tok, kNone, 0, kNone, kNone, kNone});
+        lit_cnt.push_back(0); lit_xor.push_back(0);
+        nodes_[parent].nchild++;
+        n_nodes_++;
+        if (tok == kTokPlus) nodes_[parent].plus_child = id;
+        else if (tok == kTokHash) nodes_[parent].hash_child = id;
+        else { lit_cnt[parent]++; lit_xor[parent] ^= tok; }
+        return id;
+    };
     std::vector<uint32_t> path{0};                   // path[l] = node reached after l levels of the previous filter
     const uint32_t* prev = nullptr; uint64_t prev_len = 0;
     for (uint32_t i : idx) {
@@ -392,8 +431,7 @@ void HostTable::subscribe_bulk(const uint8_t* blob, const uint64_t* offs, uint64
         path.resize(lcp + 1);
         uint32_t node = path[lcp];
         for (uint64_t l = lcp; l < L; ++l) {
-            const uint32_t s = find_slot(node, cur[l]);
-            node = s != kNone ? edges_[s].child : new_node(node, cur[l]);
+            node = child_of(node, cur[l]);
             path.push_back(node);
         }
         prev = cur; prev_len = L;
@@ -404,15 +442,69 @@ void HostTable::subscribe_bulk(const uint8_t* blob, const uint64_t* offs, uint64
             filters_[fid].node = node;
             filters_[fid].subs.clear();
             delta_.fids.push_back(fid);
-            set_term_fid(node, fid);
-            if (nodes_[node].token == kTokHash) set_hash_fid(nodes_[node].parent, fid);
+            if (deferred) nodes_[node].term_fid = fid;          // headers are written by materialize_edges()
+            else {
+                set_term_fid(node, fid);
+                if (nodes_[node].token == kTokHash) set_hash_fid(nodes_[node].parent, fid);
+            }
             n_filters_++;
         }
         sub_add(fid, sub_ids ? sub_ids[i] : i, qos ? qos[i] : 0, flags ? flags[i] : 0);
         if (fids_out) fids_out[i] = fid;
     }
+    lap("insert");
+    if (deferred) materialize_edges(lit_cnt, lit_xor);
+    lap("materialise");
     if (fids_out) for (uint64_t i = 0; i < n; ++i) if (!valid[i]) fids_out[i] = kNone;
     if (n_rejected) *n_rejected = rejected;
+}
+
+// Build the whole edge table from the node array (bulk restore into an empty table).
+void HostTable::materialize_edges(const std::vector<uint32_t>& lit_cnt, const std::vector<uint32_t>& lit_xor) {
+    uint64_t cap = 1024;
+    while (cap < n_nodes_ * 4) cap <<= 1;            // load <= 0.25: short probe sequences for the walk kernel
+    const bool prof = std::getenv("RGR_BULK_PROFILE") != nullptr;
+    auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = tnow();
+    auto lap = [&](const char* what) { if (prof) { const double t = tnow(); std::fprintf(stderr, "[bulk]   mat.%-8s %.3f s\n", what, t - t_prev); t_prev = t; } };
+    edges_.assign(cap, empty_edge());
+    lap("assign");
+    const uint32_t mask = uint32_t(cap - 1);
+    const uint32_t total = uint32_t(nodes_.size());
+    std::vector<uint8_t> dead(total, 0);
+    for (uint32_t f : free_nodes_) dead[f] = 1;
+    auto hdr_hash_fid = [&](uint32_t id) { const uint32_t hc = nodes_[id].hash_child; return hc == kNone ? kNone : nodes_[hc].term_fid; };
+    // Cache-friendly placement: bucket the nodes by the high bits of their home slot (counting
+    // sort), then fill bucket after bucket — every bucket spans 256 KiB of the table, so the random
+    // probes of a bucket stay in cache / TLB instead of touching a different page per node.
+    const uint32_t bucket_shift = cap > (1u << 13) ? uint32_t(__builtin_ctzll(cap)) - 13 : 0;   // 8192 slots per bucket
+    const uint32_t nbuckets = uint32_t(cap >> bucket_shift);
+    std::vector<uint32_t> bstart(size_t(nbuckets) + 1, 0), order(n_nodes_ ? n_nodes_ - 1 : 0);
+    for (uint32_t id = 1; id < total; ++id)
+        if (!dead[id]) bstart[((edge_hash(nodes_[id].parent, nodes_[id].token) & mask) >> bucket_shift) + 1]++;
+    for (uint32_t b = 0; b < nbuckets; ++b) bstart[b + 1] += bstart[b];
+    {
+        std::vector<uint32_t> pos(bstart.begin(), bstart.end() - 1);
+        for (uint32_t id = 1; id < total; ++id)
+            if (!dead[id]) order[pos[(edge_hash(nodes_[id].parent, nodes_[id].token) & mask) >> bucket_shift]++] = id;
+    }
+    lap("bucket");
+    for (uint32_t id : order) {
+        Node& nd = nodes_[id];
+        uint32_t i = edge_hash(nd.parent, nd.token) & mask;
+        while (edges_[i].parent != kEdgeEmpty) i = (i + 1) & mask;
+        edges_[i] = EdgeEntry{nd.parent, nd.token, id, kNone, hdr_hash_fid(id), nd.term_fid, lit_cnt[id], lit_xor[id]};
+        nd.slot = i;
+    }
+    lap("fill");
+    for (uint32_t id = 1; id < total; ++id) {         // '+' edge slots are known only now
+        if (dead[id] || nodes_[id].plus_child == kNone) continue;
+        edges_[nodes_[id].slot].plus_slot = nodes_[nodes_[id].plus_child].slot;
+    }
+    root_hdr_ = NodeHeader{nodes_[0].plus_child == kNone ? kNone : nodes_[nodes_[0].plus_child].slot, hdr_hash_fid(0), nodes_[0].term_fid,
+                           lit_cnt[0], lit_xor[0]};
+    edge_live_ = edge_used_ = n_nodes_ - 1;
+    delta_.relocated = true;
 }
 
 void HostTable::flatten_filters(std::vector<FilterDesc>& filt, std::vector<SubEntry>& subs) const {
