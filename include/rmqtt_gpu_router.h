@@ -203,6 +203,14 @@ int32_t rgr_window_to_host(rgr_batch* b, const rgr_window* w, rgr_tuple* host_tu
  * previous one).  *n_hits / *n_windows are optional. */
 int32_t rgr_batch_run(rgr_batch* b, uint64_t* n_hits, uint32_t* n_windows);
 
+/* One full pass whose windows are streamed to the HOST: every window is expanded into one of two
+ * device buffers and copied (asynchronously, overlapping the next window's expansion) into a
+ * library-owned pinned staging ring; `consume` (optional) is called with each window's host tuples
+ * before its staging slot is reused.  This is the PCIe-inclusive form of rgr_batch_run. */
+typedef void (*rgr_window_consumer)(void* user, uint32_t topic_begin, uint32_t topic_end, const rgr_tuple* host_tuples,
+                                    uint64_t n_hits);
+int32_t rgr_batch_run_to_host(rgr_batch* b, rgr_window_consumer consume, void* user, uint64_t* n_hits, uint32_t* n_windows);
+
 /* ---- retained-message twin (RetainTree) ----------------------------------------------- */
 /* Insert / replace a retained topic carrying caller value `topic_id`. */
 int32_t rgr_retain_topic_add(rgr_handle* h, const char* topic, uint32_t len, uint32_t topic_id);

@@ -25,7 +25,7 @@ SYMBOLS = [
     "rgr_subscribe_bulk", "rgr_commit",
     "rgr_match_batch", "rgr_result_free", "rgr_match_filters", "rgr_filters_result_free",
     "rgr_batch_create", "rgr_batch_destroy", "rgr_batch_status", "rgr_batch_begin", "rgr_batch_next_window",
-    "rgr_window_to_host", "rgr_batch_run",
+    "rgr_window_to_host", "rgr_batch_run", "rgr_batch_run_to_host",
     "rgr_retain_topic_add", "rgr_retain_topic_remove", "rgr_retain_add_bulk", "rgr_retain_commit",
     "rgr_retain_match_batch", "rgr_retain_result_free", "rgr_retain_batch_create",
     "rgr_shard_assign", "rgr_stats_get", "rgr_stats_reset",
@@ -110,6 +110,7 @@ def lib():
         L.rgr_batch_next_window.argtypes = [vp, C.POINTER(Window)]
         L.rgr_window_to_host.argtypes = [vp, C.POINTER(Window), vp, vp]
         L.rgr_batch_run.argtypes = [vp, C.POINTER(u64), C.POINTER(u32)]
+        L.rgr_batch_run_to_host.argtypes = [vp, vp, vp, C.POINTER(u64), C.POINTER(u32)]
         L.rgr_retain_topic_add.argtypes = [vp, C.c_char_p, u32, u32]
         L.rgr_retain_topic_remove.argtypes = [vp, C.c_char_p, u32]
         L.rgr_retain_add_bulk.argtypes = [vp, vp, vp, u64, vp, C.POINTER(u64)]
@@ -323,6 +324,12 @@ class Batch:
         """One full pass; tuples stay on the device.  -> (n_hits, n_windows)"""
         h, w = C.c_uint64(0), C.c_uint32(0)
         _check(lib().rgr_batch_run(self._b, C.byref(h), C.byref(w)))
+        return int(h.value), int(w.value)
+
+    def run_to_host(self):
+        """One full pass streaming every window into pinned host staging (PCIe-inclusive).  -> (n_hits, n_windows)"""
+        h, w = C.c_uint64(0), C.c_uint32(0)
+        _check(lib().rgr_batch_run_to_host(self._b, None, None, C.byref(h), C.byref(w)))
         return int(h.value), int(w.value)
 
     def begin(self):

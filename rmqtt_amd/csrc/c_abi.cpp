@@ -138,6 +138,9 @@ struct rgr_batch {
     // chunk work buffers
     DevBuf slots, pair_cnt, hit_cnt, pair_live, hit_off, pair_base, ovf_list, ovf_base, scalars, arena;
     DevBuf pair_src, pair_topic, pair_off, tile_first, out, scan_tmp;
+    DevBuf out2;                         // second window buffer (rgr_batch_run_to_host double-buffers)
+    PinnedBuf h_ring[2];                 // pinned staging for streamed windows
+    bool alt_out = false;                // next_window expands into out2 instead of out
     DevBuf rf_filter[2], rf_node[2], r_cnt, r_payload, r_ecnt, r_e0, r_e1, r_out_off, r_epos, r_big, r_end, r_depth;   // retain frontier rounds
     PinnedBuf h_hit_off, h_pair_base, h_scalars;
     uint64_t arena_cap = 0;
@@ -873,14 +876,15 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
         const uint64_t nh = hit_hi - hit_lo;
         if (nh) {
             const uint32_t T = expand_tile_hits();
-            b->out.ensure(nh * sizeof(Tuple));
+            DevBuf& outbuf = b->alt_out ? b->out2 : b->out;
+            outbuf.ensure(nh * sizeof(Tuple));
             b->tile_first.ensure(((nh + T - 1) / T) * 4);
             ChunkArrays ca = make_chunk_arrays(b, n);
             size_t sp = b->span_begin(kSpanScan);
             launch_tiles(ca, pair_lo, pair_hi, hit_lo, b->tile_first.as<uint32_t>(), b->stream);
             b->span_end(sp);
             sp = b->span_begin(kSpanExpand);
-            launch_expand(batch_view(b), ca, pair_lo, pair_hi, hit_lo, hit_hi, b->tile_first.as<uint32_t>(), b->out.as<Tuple>(), b->stream);
+            launch_expand(batch_view(b), ca, pair_lo, pair_hi, hit_lo, hit_hi, b->tile_first.as<uint32_t>(), outbuf.as<Tuple>(), b->stream);
             b->span_end(sp);
             b->local.expand_launches++;
         }
@@ -888,7 +892,7 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
         w->topic_end = b->chunk_begin + le;
         w->n_hits = nh;
         w->hit_base = b->hits_before;
-        w->d_tuples = reinterpret_cast<const rgr_tuple*>(b->out.p);
+        w->d_tuples = reinterpret_cast<const rgr_tuple*>(b->alt_out ? b->out2.p : b->out.p);
         w->d_hit_offsets = b->hit_off.as<uint64_t>() + lc;
         w->offsets_bias = hit_lo;
         b->hits_before += nh;
@@ -931,6 +935,53 @@ int32_t rgr_batch_run(rgr_batch* b, uint64_t* n_hits, uint32_t* n_windows) {
     if (n_hits) *n_hits = hits;
     if (n_windows) *n_windows = nw;
     return RGR_OK;
+}
+
+int32_t rgr_batch_run_to_host(rgr_batch* b, rgr_window_consumer consume, void* user, uint64_t* n_hits, uint32_t* n_windows) {
+    int32_t rc = rgr_batch_begin(b);
+    if (rc != RGR_OK) return rc;
+    return guarded([&]() -> int32_t {
+        hipStream_t copy_stream;
+        RGR_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+        hipEvent_t expanded[2], copied[2];
+        for (int k = 0; k < 2; ++k) { RGR_HIP(hipEventCreate(&expanded[k])); RGR_HIP(hipEventCreate(&copied[k])); }
+        struct Pending { bool live = false; uint32_t t0 = 0, t1 = 0; uint64_t n = 0; } pend[2];
+        uint64_t hits = 0;
+        uint32_t nw = 0;
+        int32_t r = RGR_OK;
+        const double t0 = now_ms();
+        auto drain = [&](int k) {
+            if (!pend[k].live) return;
+            RGR_HIP(hipEventSynchronize(copied[k]));
+            if (consume) consume(user, pend[k].t0, pend[k].t1, b->h_ring[k].as<rgr_tuple>(), pend[k].n);
+            pend[k].live = false;
+        };
+        for (int k = 0;; k ^= 1) {
+            drain(k);                                   // slot k (device buffer + staging) is free again
+            b->alt_out = k == 1;
+            // the expansion into buffer k must not start before its previous copy finished: drain() waited
+            rgr_window w;
+            r = rgr_batch_next_window(b, &w);
+            if (r != RGR_OK) break;
+            RGR_HIP(hipEventRecord(expanded[k], b->stream));
+            b->h_ring[k].ensure(std::max<uint64_t>(1, w.n_hits) * sizeof(rgr_tuple));
+            RGR_HIP(hipStreamWaitEvent(copy_stream, expanded[k], 0));
+            if (w.n_hits) RGR_HIP(hipMemcpyAsync(b->h_ring[k].p, w.d_tuples, w.n_hits * sizeof(rgr_tuple), hipMemcpyDeviceToHost, copy_stream));
+            RGR_HIP(hipEventRecord(copied[k], copy_stream));
+            pend[k] = Pending{true, w.topic_begin, w.topic_end, w.n_hits};
+            hits += w.n_hits;
+            nw++;
+        }
+        b->alt_out = false;
+        drain(0); drain(1);
+        for (int k = 0; k < 2; ++k) { (void)hipEventDestroy(expanded[k]); (void)hipEventDestroy(copied[k]); }
+        (void)hipStreamDestroy(copy_stream);
+        b->local.d2h_ms += now_ms() - t0;
+        if (r != RGR_EOF) return r;
+        if (n_hits) *n_hits = hits;
+        if (n_windows) *n_windows = nw;
+        return RGR_OK;
+    });
 }
 
 // ------------------------------------------------------------------ host in / host out

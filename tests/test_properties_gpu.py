@@ -137,3 +137,38 @@ def test_concurrent_batches_and_epochs():
     new = r.match_batch(tb, to)
     assert len(new["tuples"]) > len(ref["tuples"])                   # the next pass sees the new epoch
     b.close(); r.close()
+
+
+def test_streamed_to_host_pass_equals_host_result():
+    """rgr_batch_run_to_host (double-buffered expansion + async D2H into a pinned ring, consumer
+    callback per window) delivers exactly the tuples rgr_match_batch returns."""
+    import ctypes as C
+    cfg = 3
+    c = wl.CONFIGS[cfg]
+    blob, offs, client, qos = wl.gen_subs(60_000, wl.SUB_SEED + cfg, c["p_plus"], c["p_hash"], c["p_sys"])
+    tb, to = wl.gen_topics(20_000, wl.PUB_SEED + cfg, 0.01, c["p_blank"])
+    r = capi.Router(device=0, window_hits=150_000, chunk_topics=6000)
+    r.subscribe_bulk(blob, offs, None, qos)
+    r.commit()
+    ref = r.match_batch(tb, to)
+    parts, ranges = [], []
+    CB = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64)
+
+    def consume(_user, t0, t1, ptr, n):
+        a = np.empty(int(n), dtype=capi.TUPLE_DTYPE)
+        if n:
+            C.memmove(a.ctypes.data, ptr, a.nbytes)
+        parts.append(a); ranges.append((t0, t1))
+
+    cb = CB(consume)
+    b = r.batch(tb, to)
+    h, w = C.c_uint64(0), C.c_uint32(0)
+    for _ in range(2):                                   # twice: the staging ring is reused
+        parts.clear(); ranges.clear()
+        rc = capi.lib().rgr_batch_run_to_host(b._b, C.cast(cb, C.c_void_p), None, C.byref(h), C.byref(w))
+        assert rc == 0 and w.value == len(parts) > 10
+        got = np.concatenate(parts)
+        assert h.value == len(got) == len(ref["tuples"])
+        assert np.array_equal(got, ref["tuples"])
+        assert ranges[0][0] == 0 and ranges[-1][1] == 20_000 and all(a[1] == b_[0] for a, b_ in zip(ranges, ranges[1:]))
+    b.close(); r.close()
