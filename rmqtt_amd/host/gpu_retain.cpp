@@ -1,6 +1,8 @@
 // GpuRetainStorage — see gpu_retain.hpp.  Uses nothing but the C ABI.
 #include "gpu_retain.hpp"
 
+#include <algorithm>
+
 namespace rmqtt {
 
 GpuRetainStorage::GpuRetainStorage(int device) {
@@ -84,6 +86,75 @@ size_t GpuRetainStorage::remove_expired_messages(int64_t now_ms) {
         dirty_ = true;
     }
     return removed;
+}
+
+// ---- GpuMessageIndex (rmqtt-message-storage/src/ram.rs) ---------------------------------------
+GpuMessageIndex::GpuMessageIndex(int device) {
+    rgr_config cfg{};
+    cfg.device = device;
+    if (rgr_create(&cfg, &h_) != RGR_OK) h_ = nullptr;
+}
+GpuMessageIndex::~GpuMessageIndex() { if (h_) rgr_destroy(h_); }
+
+namespace {
+// Topic::push(Level::Normal(msg_id.to_string())) in string form: one more '/'-separated level.
+std::string with_msg_level(const TopicName& topic, MsgID id) { return topic + "/" + std::to_string(id); }
+}  // namespace
+
+// ram.rs:333-334 + :351/:361
+Result<bool> GpuMessageIndex::set(const TopicName& topic, MsgID msg_id) {
+    if (!h_) return Result<bool>::Err("no device");
+    std::lock_guard<std::mutex> g(mu_);
+    const std::string key = with_msg_level(topic, msg_id);
+    auto it = ids_.find(msg_id);
+    uint32_t id;
+    const bool had = it != ids_.end();
+    if (had) id = it->second;
+    else if (!free_.empty()) { id = free_.back(); free_.pop_back(); }
+    else { id = uint32_t(slab_.size()); slab_.push_back(0); }
+    if (rgr_retain_topic_add(h_, key.data(), uint32_t(key.size()), id) != RGR_OK) {
+        if (!had) free_.push_back(id);
+        return Result<bool>::Err(std::string("invalid topic: ") + rgr_last_error());
+    }
+    slab_[id] = msg_id;
+    if (!had) { ids_.emplace(msg_id, id); ++live_; }
+    dirty_ = true;
+    return Result<bool>::Ok(true);
+}
+
+// ram.rs:226-233
+Result<bool> GpuMessageIndex::remove(const TopicName& topic, MsgID msg_id) {
+    if (!h_) return Result<bool>::Err("no device");
+    std::lock_guard<std::mutex> g(mu_);
+    const std::string key = with_msg_level(topic, msg_id);
+    const int32_t rc = rgr_retain_topic_remove(h_, key.data(), uint32_t(key.size()));
+    if (rc == RGR_ENOENT) return Result<bool>::Ok(false);
+    if (rc != RGR_OK) return Result<bool>::Err(rgr_last_error());
+    auto it = ids_.find(msg_id);
+    if (it != ids_.end()) { free_.push_back(it->second); ids_.erase(it); --live_; }
+    dirty_ = true;
+    return Result<bool>::Ok(true);
+}
+
+// ram.rs:381-394
+Result<std::vector<MsgID>> GpuMessageIndex::get(const TopicFilter& f) {
+    using R = Result<std::vector<MsgID>>;
+    if (!h_) return R::Err("no device");
+    std::lock_guard<std::mutex> g(mu_);
+    if (dirty_) { if (rgr_retain_commit(h_) != RGR_OK) return R::Err(rgr_last_error()); dirty_ = false; }
+    // last level `#`  <=>  the string is "#" or ends in "/#" (levels are the '/'-separated pieces)
+    const bool multi = f == "#" || (f.size() >= 2 && f.compare(f.size() - 2, 2, "/#") == 0);
+    const std::string q = multi ? f : f + "/+";
+    const uint64_t offs[2] = {0, q.size()};
+    rgr_retain_result res{};
+    if (rgr_retain_match_batch(h_, reinterpret_cast<const uint8_t*>(q.data()), offs, 1, &res) != RGR_OK) return R::Err(rgr_last_error());
+    const bool bad = res.status[0] != RGR_TOPIC_OK;
+    std::vector<MsgID> out;
+    for (uint64_t k = 0; !bad && k < res.n_hits; ++k) out.push_back(slab_[res.topic_ids[k]]);
+    rgr_retain_result_free(&res);
+    if (bad) return R::Err("invalid topic filter `" + f + "`");
+    std::sort(out.begin(), out.end());
+    return R::Ok(std::move(out));
 }
 
 }  // namespace rmqtt

@@ -46,4 +46,38 @@ class GpuRetainStorage {
     bool dirty_ = false;
 };
 
+// the message-storage topic index.  rmqtt-message-storage keeps
+// `topic_tree: RwLock<RetainTree<MsgID>>` (rmqtt-plugins/rmqtt-message-storage/src/ram.rs:158):
+//   _set  (ram.rs:333-334,351,361): Topic::from_str(publish.topic) + push(Level::Normal(msg_id.to_string()))
+//                                   -> topic_tree.insert(&topic, msg_id)
+//   _get  (ram.rs:381-394): Topic::from_str(filter); push(Level::SingleWildcard) unless the last
+//                           level is `#`; topic_tree.matches(&topic) -> msg ids
+//   remove (ram.rs:232): topic_tree.remove(&topic) with the same msg-id level appended
+// (One divergence, unreachable from the broker: a PUBLISH topic ending in `#` would be indexed by
+// the reference because it validates before pushing the id level; here it is an Err.  PUBLISH
+// topic names with wildcards are rejected before they get this far.)
+// Same structure and query shape as the retained path, so it binds the same rgr_retain_* calls;
+// the stored messages, expiries heap and forwardeds map stay host-side as in the reference.
+using MsgID = uint64_t;
+
+class GpuMessageIndex {
+   public:
+    explicit GpuMessageIndex(int device = 0);
+    ~GpuMessageIndex();
+    bool usable() const { return h_ != nullptr; }
+    Result<bool> set(const TopicName& topic, MsgID msg_id);
+    Result<bool> remove(const TopicName& topic, MsgID msg_id);        // Ok(false): nothing stored there
+    Result<std::vector<MsgID>> get(const TopicFilter& topic_filter);  // ids in ascending order
+    size_t values_size() const { return live_; }
+
+   private:
+    rgr_handle* h_ = nullptr;
+    std::mutex mu_;
+    std::vector<MsgID> slab_;            // dense topic_id -> MsgID
+    std::vector<uint32_t> free_;
+    std::unordered_map<MsgID, uint32_t> ids_;
+    size_t live_ = 0;
+    bool dirty_ = false;
+};
+
 }  // namespace rmqtt

@@ -102,6 +102,31 @@ uint64_t hs_remove_expired(void* s, int64_t now_ms) { return static_cast<GpuReta
 int64_t hs_count(void* s) { return static_cast<GpuRetainStorage*>(s)->count_max().count; }
 int64_t hs_max(void* s) { return static_cast<GpuRetainStorage*>(s)->count_max().max; }
 
+// ---- GpuMessageIndex shim ---------------------------------------------------------------------
+void* hm_new(int device) {
+    auto* s = new GpuMessageIndex(device);
+    if (!s->usable()) { delete s; return nullptr; }
+    return s;
+}
+void hm_free(void* s) { delete static_cast<GpuMessageIndex*>(s); }
+int hm_set(void* s, const char* t, uint32_t tl, uint64_t msg_id) {
+    return static_cast<GpuMessageIndex*>(s)->set(std::string(t, tl), msg_id).ok() ? 0 : -1;
+}
+// 0 removed, 1 nothing there, -1 error
+int hm_remove(void* s, const char* t, uint32_t tl, uint64_t msg_id) {
+    auto r = static_cast<GpuMessageIndex*>(s)->remove(std::string(t, tl), msg_id);
+    return !r.ok() ? -1 : (*r.value ? 0 : 1);
+}
+// decimal ids joined by ','; NULL on Err
+char* hm_get(void* s, const char* f, uint32_t fl) {
+    auto r = static_cast<GpuMessageIndex*>(s)->get(std::string(f, fl));
+    if (!r.ok()) return nullptr;
+    std::string out;
+    for (auto id : *r.value) { out += std::to_string(id); out.push_back(','); }
+    return dup_str(out);
+}
+uint64_t hm_values_size(void* s) { return static_cast<GpuMessageIndex*>(s)->values_size(); }
+
 int64_t hr_topics(void* r) { return static_cast<GpuRouter*>(r)->topics().count; }
 int64_t hr_routes(void* r) { return static_cast<GpuRouter*>(r)->routes().count; }
 uint64_t hr_topics_tree(void* r) { return static_cast<GpuRouter*>(r)->topics_tree(); }

@@ -46,6 +46,12 @@ def hr():
     L.hs_remove_expired.argtypes = [vp, C.c_int64]; L.hs_remove_expired.restype = C.c_uint64
     for f in ("hs_count", "hs_max"):
         getattr(L, f).argtypes = [vp]; getattr(L, f).restype = C.c_int64
+    L.hm_new.restype = vp; L.hm_new.argtypes = [C.c_int]
+    L.hm_free.argtypes = [vp]
+    L.hm_set.argtypes = [vp, C.c_char_p, C.c_uint32, C.c_uint64]
+    L.hm_remove.argtypes = [vp, C.c_char_p, C.c_uint32, C.c_uint64]
+    L.hm_get.argtypes = [vp, C.c_char_p, C.c_uint32]; L.hm_get.restype = vp
+    L.hm_values_size.argtypes = [vp]; L.hm_values_size.restype = C.c_uint64
     return L
 
 
@@ -187,3 +193,39 @@ def test_retain_storage_mirror(hr):
     assert _take(hr, hr.hs_get(s, b"exp/#", 5, 1200)) == "exp/two\te2\n"
     assert hr.hs_max(s) >= hr.hs_count(s)
     hr.hs_free(s)
+
+
+def test_message_index_mirror(hr):
+    """GpuMessageIndex vs the oracle's RetainTree driven exactly as
+    rmqtt-message-storage drives its `RetainTree<MsgID>`: _set appends the msg id as one more
+    level (ram.rs:333-334), _get appends `+` unless the filter ends in `#` (ram.rs:381-384)."""
+    m = hr.hm_new(0)
+    assert m
+    t = orc.RetainTree()
+    rng = random.Random(11)
+    levels = ["a", "b", "c", "", "$SYS"]
+    stored = {}                                   # msg_id -> topic
+    for msg_id in range(1, 401):
+        n = rng.randint(1, 4)
+        topic = "/".join(rng.choice(levels if i == 0 else levels[:4]) for i in range(n))
+        tb = topic.encode()
+        assert hr.hm_set(m, tb, len(tb), msg_id) == 0
+        t.insert(f"{topic}/{msg_id}", msg_id)
+        stored[msg_id] = topic
+        if rng.random() < 0.25:                   # expiry / forwarded-to-all removal (ram.rs:226-233)
+            victim = rng.choice(sorted(stored))
+            vt = stored.pop(victim).encode()
+            assert hr.hm_remove(m, vt, len(vt), victim) == 0
+            assert hr.hm_remove(m, vt, len(vt), victim) == 1
+            t.remove(f"{vt.decode()}/{victim}")
+    assert hr.hm_values_size(m) == len(stored) == t.values_size()
+    assert hr.hm_set(m, b"a/#/b", 5, 9999) == -1                      # Topic::from_str Err (ram.rs:333)
+    for f in ["#", "+", "a", "a/b", "a/#", "+/+", "a/+/c", "$SYS/#", "$SYS", "+/b/#", "nope", "", "/", "a//b", "/#"]:
+        fb = f.encode()
+        q = f if (f == "#" or f.endswith("/#")) else f + "/+"
+        exp = sorted(v for _, v in t.matches(q))
+        got = _take(hr, hr.hm_get(m, fb, len(fb)))
+        assert got is not None, f
+        assert [int(x) for x in got.split(",") if x] == exp, f
+    assert hr.hm_get(m, b"a/#/b", 5) is None
+    hr.hm_free(m)
