@@ -49,6 +49,9 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--window-hits", type=int, default=0)
     ap.add_argument("--d2h", action="store_true", help="also report the PCIe-inclusive rate (copies every window to host)")
+    ap.add_argument("--deliver", type=float, default=-1.0, metavar="V5FRAC",
+                    help="also run the delivery stage (SURVEY 8(f)-1): this fraction of the subscriptions is MQTT v5 "
+                         "(No Local / RAP / per-client dedup); 0 = v3 only. Not the headline metric.")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo lets the N>1 logic be exercised on one GPU")
     args = ap.parse_args()
 
@@ -117,7 +120,16 @@ def main():
         rej = r.retain_add_bulk(blob_r, offs_r)
         r.retain_commit()
     else:
-        rej = r.subscribe_bulk(blob_r, offs_r, sub_ids_r, qos_r)
+        deliver = args.deliver >= 0 and world == 1
+        flags_r = None
+        if deliver:
+            drng = np.random.default_rng(11)
+            is5 = drng.random(n_sub) < args.deliver
+            flags_r = (is5 * capi.RGR_SUB_V5 | (is5 & (drng.random(n_sub) < 0.3)) * capi.RGR_SUB_NO_LOCAL |
+                       (is5 & (drng.random(n_sub) < 0.5)) * capi.RGR_SUB_RAP).astype(np.uint8)
+        rej = r.subscribe_bulk(blob_r, offs_r, sub_ids_r, qos_r, flags_r)
+        if deliver:
+            r.sub_attrs_bulk(client.astype(np.uint32), client.astype(np.uint32))     # one Id per client
         r.commit()
     build_s = time.time() - t
     st0 = r.stats()
@@ -129,6 +141,12 @@ def main():
     t = time.time()
     batch = r.retain_batch(tb_r, to_r) if retain else r.batch(tb_r, to_r)
     log(f"batch: {my_topics} topics tokenised + uploaded in {time.time() - t:.1f}s", rank)
+    if not retain and args.deliver >= 0 and world == 1:
+        pa = np.zeros(my_topics, dtype=capi.PUBLISH_ATTR_DTYPE)
+        prng = np.random.default_rng(12)
+        pa["from_id"] = prng.choice(client.astype(np.uint32), size=my_topics)
+        pa["qos_retain"] = prng.integers(0, 3, size=my_topics) | (prng.integers(0, 2, size=my_topics) << 2)
+        batch.set_publish_attrs(pa)
 
     def barrier():
         if world > 1:
@@ -259,7 +277,9 @@ def main():
                "hits_per_s": round(ost["hits"] / sec, 1)}
 
     out = {
-        "metric": "publish-topic matches/sec @10M subs" if cfg in (3, 4) and args.scale == 1.0 else
+        "metric": f"publish-topic matches/sec with delivery stage (config {cfg}, scale {args.scale}, v5 fraction {args.deliver})"
+                  if (args.deliver >= 0 and not retain and world == 1) else
+                  "publish-topic matches/sec @10M subs" if cfg in (3, 4) and args.scale == 1.0 else
                   (f"retained-path SUBSCRIBE-filter matches/sec (config 5, scale {args.scale})" if retain else
                    f"publish-topic matches/sec (config {cfg}, scale {args.scale})"),
         "value": round(value, 1), "unit": "SUBSCRIBE-filter matches/s" if retain else "publish-topic matches/s",
@@ -280,6 +300,10 @@ def main():
                   "hbm_bytes": int(st0["table_bytes_device"]), "host_build_s": round(build_s, 1)},
         "roofline": roofline, "cpu_baseline": cpu,
     }
+    if args.deliver >= 0 and not retain and world == 1:
+        out["delivery_stage"] = {"v5_fraction": args.deliver, "dedup_ms_per_step": round(st["dedup_ms"] / K, 3),
+                                 "dedup_candidates_per_step": int(st["dedup_candidates"] / K),
+                                 "dedup_launches_per_step": int(st["dedup_launches"] / K)}
     if pcie is not None:
         out["pcie_inclusive_matches_per_s"] = round(pcie, 1)
     print(json.dumps(out), flush=True)

@@ -77,8 +77,26 @@ enum {
 enum {
     RGR_SUB_V5 = 1u << 0,         /* SubscriptionOptions::V5 (types.rs:607-610)       */
     RGR_SUB_NO_LOCAL = 1u << 1,   /* v5 No Local (router.rs:196-201, applied by host) */
-    RGR_SUB_SHARED = 1u << 2      /* member of a $share group (host post-filter)      */
+    RGR_SUB_SHARED = 1u << 2,     /* member of a $share group (host post-filter)      */
+    RGR_SUB_RAP = 1u << 3         /* v5 Retain As Published (shared.rs:889-897)       */
 };
+
+/* Delivery word: what rgr_tuple.qos_flags holds for a batch that carries publish
+ * attributes (rgr_batch_set_publish_attrs / rgr_match_batch_deliver) — the per-hit part of
+ * DefaultRouter::_matches + forwards_to done on the device:
+ *   bits 0-1   delivery qos = min(publish qos, subscription qos)   (shared.rs:902)
+ *   bit  2     deliver with retain=1: v5 Retain-As-Published && publish.retain (shared.rs:889-897)
+ *   bit  3     dropped by v5 No Local: subscriber Id == publisher Id (router.rs:196-201)
+ *   bit  4     later v5 hit of a client already collected for this topic: only its
+ *              subscription identifier is appended to the first one (types.rs:526-534)
+ *   bits 8-15  RGR_SUB_* flags, bits 16-31 node_idx — as without publish attributes     */
+enum {
+    RGR_HIT_QOS_MASK = 3u,
+    RGR_HIT_RETAIN = 1u << 2,
+    RGR_HIT_NO_LOCAL = 1u << 3,
+    RGR_HIT_V5_DUP = 1u << 4
+};
+#define RGR_ID_NONE 0xFFFFFFFFu
 
 typedef struct rgr_handle rgr_handle;
 typedef struct rgr_batch rgr_batch;
@@ -100,8 +118,18 @@ typedef struct rgr_config {
 typedef struct rgr_tuple {
     uint32_t topic_idx;         /* index of the publish topic inside the batch          */
     uint32_t sub_id;            /* caller-assigned relation id                          */
-    uint32_t qos_flags;         /* bits 0-7 qos, bits 8-15 RGR_SUB_* flags              */
+    uint32_t qos_flags;         /* bits 0-7 qos, bits 8-15 RGR_SUB_* flags, bits 16-31
+                                   node_idx (rgr_sub_add_ex); a delivery word (above)
+                                   when the batch carries publish attributes             */
 } rgr_tuple;
+
+/* Per-publish attributes of a batch (one per topic): who published it and with what
+ * qos / retain bit — `from.id`, `publish.qos`, `publish.retain` of shared.rs:772,880-902. */
+typedef struct rgr_publish_attr {
+    uint32_t from_id;           /* owner_id (rgr_sub_add_ex) of the publisher's Id, or
+                                   RGR_ID_NONE when it holds no subscription            */
+    uint32_t qos_retain;        /* bits 0-1 publish qos, bit 2 publish retain            */
+} rgr_publish_attr;
 
 /* Host-side result of rgr_match_batch (arrays owned by the library until
  * rgr_result_free). */
@@ -150,6 +178,9 @@ typedef struct rgr_stats {
     uint64_t alg_bytes_walk, alg_bytes_expand;
     /* rgr_commit: epochs published by a full image upload vs by patching the delta */
     uint64_t commits_full, commits_delta;
+    /* delivery stage (batches with publish attributes): v5 per-client dedup */
+    uint64_t dedup_candidates, dedup_launches;
+    double dedup_ms;
 } rgr_stats;
 
 /* ---- lifecycle ----------------------------------------------------------------- */
@@ -167,6 +198,16 @@ int32_t rgr_filter_find(rgr_handle* h, const char* filter, uint32_t len, uint32_
 /* Remove the filter (must have no subscriptions left) and prune empty trie nodes. */
 int32_t rgr_filter_remove(rgr_handle* h, uint32_t filter_id);
 int32_t rgr_sub_add(rgr_handle* h, uint32_t filter_id, uint32_t sub_id, uint8_t qos, uint8_t flags);
+/* rgr_sub_add plus what the delivery stage needs to know about the subscriber: its node
+ * (dense index of Id::node_id, returned in bits 16-31 of every tuple so the consumer can group
+ * by node like SubscriptioRelationsCollectorMap, router.rs:176), a dense id of its `Id` object
+ * (No Local compares whole Ids, router.rs:198) and a dense id of its ClientId (the v5
+ * collector is keyed by client, types.rs:524). */
+int32_t rgr_sub_add_ex(rgr_handle* h, uint32_t filter_id, uint32_t sub_id, uint8_t qos, uint8_t flags,
+                       uint16_t node_idx, uint32_t owner_id, uint32_t client_idx);
+/* Bulk form for subscriptions added with rgr_subscribe_bulk: owner / client ids per sub_id. */
+int32_t rgr_sub_attrs_bulk(rgr_handle* h, const uint32_t* sub_ids, const uint32_t* owner_ids,
+                           const uint32_t* client_idx, uint64_t n);
 int32_t rgr_sub_remove(rgr_handle* h, uint32_t filter_id, uint32_t sub_id);
 /* Restore/bulk path: for i in [0,n): filter_add(filter_i) + sub_add(fid, sub_ids ?
  * sub_ids[i] : i, qos[i], flags ? flags[i] : 0).  filter_ids_out (optional, [n]).
@@ -180,6 +221,9 @@ int32_t rgr_commit(rgr_handle* h);
 /* ---- matching, host buffers in / host buffers out ------------------------------------ */
 int32_t rgr_match_batch(rgr_handle* h, const uint8_t* topics_blob, const uint64_t* topic_offsets, uint32_t n,
                         rgr_result* out);
+/* Same, with the delivery stage: tuples carry delivery words (RGR_HIT_*). attrs: [n]. */
+int32_t rgr_match_batch_deliver(rgr_handle* h, const uint8_t* topics_blob, const uint64_t* topic_offsets, uint32_t n,
+                                const rgr_publish_attr* attrs, rgr_result* out);
 void rgr_result_free(rgr_result* r);
 int32_t rgr_match_filters(rgr_handle* h, const uint8_t* topics_blob, const uint64_t* topic_offsets, uint32_t n,
                           rgr_filters_result* out);
@@ -193,6 +237,10 @@ int32_t rgr_batch_create(rgr_handle* h, const uint8_t* topics_blob, const uint64
 void rgr_batch_destroy(rgr_batch* b);
 /* [n] statuses computed by the tokeniser (host pointer, valid for the batch lifetime) */
 const int32_t* rgr_batch_status(const rgr_batch* b);
+/* Attach publish attributes ([n], host memory, copied) to a router batch: every later pass
+ * runs the delivery stage and emits delivery words (RGR_HIT_*) in rgr_tuple.qos_flags.
+ * NULL detaches them.  RGR_ESTATE inside a pass or on a retain batch. */
+int32_t rgr_batch_set_publish_attrs(rgr_batch* b, const rgr_publish_attr* attrs);
 /* Start a pass over the batch (binds the current epoch, rewinds the window cursor). */
 int32_t rgr_batch_begin(rgr_batch* b);
 /* Walk (as needed) and expand the next window of topics.  RGR_EOF after the last. */

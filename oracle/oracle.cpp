@@ -438,6 +438,33 @@ char* orc_router_matches(void* r, const orc_id* this_id, const char* topic, uint
     return dup_str(out);
 }
 
+// forwards_to (rmqtt/src/shared.rs:876-903) applied to the SubRelationsMap of one publish: what
+// each recipient is sent.  Per relation: retain = opts.retain_as_published() (Some only for v5,
+// types.rs) ? (rap && publish.retain) : false (shared.rs:886-897); qos = publish.qos.less_value(
+// opts.qos()) (shared.rs:902); subscription_ids = the collector's list (shared.rs:904-908).
+//   "N <node>\n" then "<client>\t<filter>\t<qos'>\t<retain'>\t<sub ids in collected order,|->\n" rows sorted.
+// NULL => Err (callers use an empty map, shared.rs:774-777).
+char* orc_router_forwards(void* r, const orc_id* this_id, const char* topic, uint64_t len, uint8_t pub_qos, uint8_t pub_retain) {
+    SubRelationsMap m;
+    if (!static_cast<DefaultRouter*>(r)->matches(mk_id(this_id), std::string_view(topic, len), m)) return nullptr;
+    std::string out;
+    for (auto& kv : m) {
+        out += "N " + std::to_string(kv.first) + "\n";
+        std::vector<std::string> rows;
+        for (auto& s : kv.second) {
+            const bool retain = s.opts.v5 ? (s.opts.retain_as_published && pub_retain) : false;
+            const uint8_t qos = std::min<uint8_t>(pub_qos, s.opts.qos);
+            std::string ids;
+            if (s.sub_ids) { for (size_t i = 0; i < s.sub_ids->size(); ++i) { if (i) ids.push_back(','); ids += std::to_string((*s.sub_ids)[i]); } }
+            else ids = "-";
+            rows.push_back(esc(s.client_id) + "\t" + esc(s.topic_filter) + "\t" + std::to_string(qos) + "\t" + std::to_string(int(retain)) + "\t" + ids + "\n");
+        }
+        std::sort(rows.begin(), rows.end());
+        for (auto& x : rows) out += x;
+    }
+    return dup_str(out);
+}
+
 struct orc_stats { uint64_t levels, visited, matched, hits, invalid; };
 
 // Flat id-level match of a batch (single thread): status[n] (0 / -1), hit_offsets[n+1],

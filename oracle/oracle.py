@@ -76,6 +76,7 @@ def lib():
         L.orc_router_filter_id.argtypes = [vp, cp, u64]; L.orc_router_filter_id.restype = C.c_uint32
         L.orc_router_add_bulk.argtypes = [vp, vp, vp, u64, vp, vp]
         L.orc_router_matches.argtypes = [vp, C.POINTER(OrcId), cp, u64]; L.orc_router_matches.restype = vp
+        L.orc_router_forwards.argtypes = [vp, C.POINTER(OrcId), cp, u64, C.c_uint8, C.c_uint8]; L.orc_router_forwards.restype = vp
         L.orc_router_match_flat.argtypes = [vp, vp, vp, u64, vp] + [C.POINTER(vp)] * 5 + [C.POINTER(OrcStats)]
         L.orc_router_match_flat.restype = u64
         L.orc_router_match_timed.argtypes = [vp, vp, vp, u64, C.c_int, C.POINTER(OrcStats)]
@@ -268,6 +269,11 @@ class DefaultRouter:
         """Canonical text dump of the SubRelationsMap, or None on Err."""
         t = _b(topic)
         return _take_str(lib().orc_router_matches(self._h, C.byref(this_id), t, len(t)))
+
+    def forwards(self, this_id, topic, pub_qos=0, pub_retain=False):
+        """What forwards_to would send per node (text dump), or None on Err."""
+        t = _b(topic)
+        return _take_str(lib().orc_router_forwards(self._h, C.byref(this_id), t, len(t), pub_qos, 1 if pub_retain else 0))
 
     def match_flat(self, blob, offsets):
         n = len(offsets) - 1

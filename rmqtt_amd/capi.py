@@ -14,17 +14,21 @@ from . import build as _build
 RGR_OK, RGR_EOF = 0, 1
 RGR_EINVAL, RGR_EINVAL_TOPIC, RGR_ENOMEM, RGR_EDEVICE, RGR_ECAPACITY, RGR_ENOENT, RGR_ESTATE = -1, -2, -3, -4, -5, -6, -7
 RGR_TOPIC_OK, RGR_TOPIC_INVALID = 0, -2
-RGR_SUB_V5, RGR_SUB_NO_LOCAL, RGR_SUB_SHARED = 1, 2, 4
+RGR_SUB_V5, RGR_SUB_NO_LOCAL, RGR_SUB_SHARED, RGR_SUB_RAP = 1, 2, 4, 8
+RGR_HIT_QOS_MASK, RGR_HIT_RETAIN, RGR_HIT_NO_LOCAL, RGR_HIT_V5_DUP = 3, 4, 8, 16
+ID_NONE = 0xFFFFFFFF
 
 TUPLE_DTYPE = np.dtype([("topic_idx", np.uint32), ("sub_id", np.uint32), ("qos_flags", np.uint32)])
+PUBLISH_ATTR_DTYPE = np.dtype([("from_id", np.uint32), ("qos_retain", np.uint32)])
 
 # every symbol include/rmqtt_gpu_router.h declares
 SYMBOLS = [
     "rgr_create", "rgr_destroy", "rgr_last_error", "rgr_version",
-    "rgr_filter_add", "rgr_filter_find", "rgr_filter_remove", "rgr_sub_add", "rgr_sub_remove",
-    "rgr_subscribe_bulk", "rgr_commit",
-    "rgr_match_batch", "rgr_result_free", "rgr_match_filters", "rgr_filters_result_free",
-    "rgr_batch_create", "rgr_batch_destroy", "rgr_batch_status", "rgr_batch_begin", "rgr_batch_next_window",
+    "rgr_filter_add", "rgr_filter_find", "rgr_filter_remove", "rgr_sub_add", "rgr_sub_add_ex", "rgr_sub_attrs_bulk",
+    "rgr_sub_remove", "rgr_subscribe_bulk", "rgr_commit",
+    "rgr_match_batch", "rgr_match_batch_deliver", "rgr_result_free", "rgr_match_filters", "rgr_filters_result_free",
+    "rgr_batch_create", "rgr_batch_destroy", "rgr_batch_status", "rgr_batch_set_publish_attrs",
+    "rgr_batch_begin", "rgr_batch_next_window",
     "rgr_window_to_host", "rgr_batch_run", "rgr_batch_run_to_host",
     "rgr_retain_topic_add", "rgr_retain_topic_remove", "rgr_retain_add_bulk", "rgr_retain_commit",
     "rgr_retain_match_batch", "rgr_retain_result_free", "rgr_retain_batch_create",
@@ -64,7 +68,9 @@ class Stats(C.Structure):
                                            "table_bytes_device", "topics", "invalid_topics", "levels", "pairs", "hits",
                                            "visited_nodes", "overflow_topics", "walk_launches", "expand_launches")] +
                 [(n, C.c_double) for n in ("walk_ms", "scan_ms", "expand_ms", "tokenize_ms", "h2d_ms", "d2h_ms")] +
-                [(n, C.c_uint64) for n in ("alg_bytes_walk", "alg_bytes_expand", "commits_full", "commits_delta")])
+                [(n, C.c_uint64) for n in ("alg_bytes_walk", "alg_bytes_expand", "commits_full", "commits_delta",
+                                           "dedup_candidates", "dedup_launches")] +
+                [("dedup_ms", C.c_double)])
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -96,6 +102,10 @@ def lib():
         L.rgr_filter_find.argtypes = [vp, C.c_char_p, u32, C.POINTER(u32)]
         L.rgr_filter_remove.argtypes = [vp, u32]
         L.rgr_sub_add.argtypes = [vp, u32, u32, u8, u8]
+        L.rgr_sub_add_ex.argtypes = [vp, u32, u32, u8, u8, C.c_uint16, u32, u32]
+        L.rgr_sub_attrs_bulk.argtypes = [vp, vp, vp, vp, u64]
+        L.rgr_match_batch_deliver.argtypes = [vp, vp, vp, u32, vp, C.POINTER(Result)]
+        L.rgr_batch_set_publish_attrs.argtypes = [vp, vp]
         L.rgr_sub_remove.argtypes = [vp, u32, u32]
         L.rgr_subscribe_bulk.argtypes = [vp, vp, vp, u64, vp, vp, vp, vp, C.POINTER(u64)]
         L.rgr_commit.argtypes = [vp]
@@ -195,6 +205,15 @@ class Router:
     def sub_add(self, fid, sub_id, qos=0, flags=0):
         _check(lib().rgr_sub_add(self._h, fid, sub_id, qos, flags))
 
+    def sub_add_ex(self, fid, sub_id, qos=0, flags=0, node_idx=0, owner_id=ID_NONE, client_idx=ID_NONE):
+        _check(lib().rgr_sub_add_ex(self._h, fid, sub_id, qos, flags, node_idx, owner_id, client_idx))
+
+    def sub_attrs_bulk(self, owner_ids, client_idx, sub_ids=None):
+        o = np.ascontiguousarray(owner_ids, dtype=np.uint32)
+        c = np.ascontiguousarray(client_idx, dtype=np.uint32)
+        s_ = None if sub_ids is None else np.ascontiguousarray(sub_ids, dtype=np.uint32)
+        _check(lib().rgr_sub_attrs_bulk(self._h, None if s_ is None else s_.ctypes.data, o.ctypes.data, c.ctypes.data, len(o)))
+
     def sub_remove(self, fid, sub_id):
         return lib().rgr_sub_remove(self._h, fid, sub_id)
 
@@ -226,6 +245,22 @@ class Router:
         r = Result()
         bp, bk = _blob_ptr(blob)
         _check(lib().rgr_match_batch(self._h, bp, offsets.ctypes.data, n, C.byref(r)))
+        try:
+            return dict(status=_copy(r.status, n, np.int32), hit_offsets=_copy(r.hit_offsets, n + 1, np.uint64),
+                        tuples=_copy(r.tuples, r.n_hits, TUPLE_DTYPE))
+        finally:
+            lib().rgr_result_free(C.byref(r))
+
+    def match_batch_deliver(self, blob, offsets, publish_attrs):
+        """match_batch with the delivery stage: tuples carry delivery words (RGR_HIT_*).
+        publish_attrs: PUBLISH_ATTR_DTYPE[n] (from_id, qos_retain)."""
+        n = len(offsets) - 1
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        pa = np.ascontiguousarray(publish_attrs, dtype=PUBLISH_ATTR_DTYPE)
+        assert len(pa) == n
+        r = Result()
+        bp, bk = _blob_ptr(blob)
+        _check(lib().rgr_match_batch_deliver(self._h, bp, offsets.ctypes.data, n, pa.ctypes.data, C.byref(r)))
         try:
             return dict(status=_copy(r.status, n, np.int32), hit_offsets=_copy(r.hit_offsets, n + 1, np.uint64),
                         tuples=_copy(r.tuples, r.n_hits, TUPLE_DTYPE))
@@ -319,6 +354,14 @@ class Batch:
 
     def status(self):
         return _copy(lib().rgr_batch_status(self._b), self.n, np.int32)
+
+    def set_publish_attrs(self, publish_attrs):
+        if publish_attrs is None:
+            _check(lib().rgr_batch_set_publish_attrs(self._b, None))
+            return
+        pa = np.ascontiguousarray(publish_attrs, dtype=PUBLISH_ATTR_DTYPE)
+        assert len(pa) == self.n
+        _check(lib().rgr_batch_set_publish_attrs(self._b, pa.ctypes.data))
 
     def run(self):
         """One full pass; tuples stay on the device.  -> (n_hits, n_windows)"""

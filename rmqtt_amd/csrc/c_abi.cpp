@@ -74,7 +74,7 @@ struct DictImage {   // device copy of a StringDict for the device tokeniser
 // in-flight pass still reads alive.
 struct EdgeImage { DevBuf buf; uint64_t cap = 0; std::vector<uint32_t> pending; bool need_full = true; };
 struct FiltImage { DevBuf buf; uint64_t cap = 0; std::vector<uint32_t> pending; bool need_full = true; };
-struct SubsPool { DevBuf buf; uint64_t used = 0, cap = 0; };
+struct SubsPool { DevBuf buf, attr_buf; uint64_t used = 0, cap = 0; bool has_attrs = false; };   // attr_buf: SubAttr parallel to buf
 
 struct Epoch {
     std::shared_ptr<DictImage> dict;
@@ -82,7 +82,7 @@ struct Epoch {
     std::shared_ptr<FiltImage> filt;
     std::shared_ptr<SubsPool> subs;
     TrieView view{};
-    uint64_t id = 0, n_filters = 0, n_subs = 0, n_nodes = 0, edge_slots = 0, bytes = 0;
+    uint64_t id = 0, n_filters = 0, n_subs = 0, n_nodes = 0, edge_slots = 0, bytes = 0, n_v5 = 0;
 };
 
 struct RetainEpoch {
@@ -93,7 +93,7 @@ struct RetainEpoch {
     uint64_t id = 0, n_topics = 0, n_nodes = 0, bytes = 0;
 };
 
-enum SpanKind { kSpanWalk = 0, kSpanScan = 1, kSpanExpand = 2 };
+enum SpanKind { kSpanWalk = 0, kSpanScan = 1, kSpanExpand = 2, kSpanDedup = 3 };
 
 }  // namespace
 
@@ -141,6 +141,10 @@ struct rgr_batch {
     DevBuf out2;                         // second window buffer (rgr_batch_run_to_host double-buffers)
     PinnedBuf h_ring[2];                 // pinned staging for streamed windows
     bool alt_out = false;                // next_window expands into out2 instead of out
+    // delivery stage (rgr_batch_set_publish_attrs)
+    bool deliver = false;
+    DevBuf d_pub, cand, cand_count, dedup_tab;
+    PinnedBuf h_cand_count;
     DevBuf rf_filter[2], rf_node[2], r_cnt, r_payload, r_ecnt, r_e0, r_e1, r_out_off, r_epos, r_big, r_end, r_depth;   // retain frontier rounds
     PinnedBuf h_hit_off, h_pair_base, h_scalars;
     uint64_t arena_cap = 0;
@@ -178,6 +182,7 @@ struct rgr_batch {
             RGR_HIP(hipEventElapsedTime(&ms, s.a, s.b));
             if (s.kind == kSpanWalk) local.walk_ms += ms;
             else if (s.kind == kSpanScan) local.scan_ms += ms;
+            else if (s.kind == kSpanDedup) local.dedup_ms += ms;
             else local.expand_ms += ms;
             event_pool.push_back(s.a); event_pool.push_back(s.b);
         }
@@ -209,6 +214,7 @@ void merge_stats(rgr_handle* h, rgr_stats& l) {
     s.walk_ms += l.walk_ms; s.scan_ms += l.scan_ms; s.expand_ms += l.expand_ms;
     s.tokenize_ms += l.tokenize_ms; s.h2d_ms += l.h2d_ms; s.d2h_ms += l.d2h_ms;
     s.alg_bytes_walk += l.alg_bytes_walk; s.alg_bytes_expand += l.alg_bytes_expand;
+    s.dedup_candidates += l.dedup_candidates; s.dedup_launches += l.dedup_launches; s.dedup_ms += l.dedup_ms;
     l = rgr_stats{};
 }
 
@@ -584,6 +590,28 @@ int32_t rgr_sub_add(rgr_handle* h, uint32_t filter_id, uint32_t sub_id, uint8_t 
     });
 }
 
+int32_t rgr_sub_add_ex(rgr_handle* h, uint32_t filter_id, uint32_t sub_id, uint8_t qos, uint8_t flags, uint16_t node_idx,
+                       uint32_t owner_id, uint32_t client_idx) {
+    return guarded([&]() -> int32_t {
+        if (!h) return fail(RGR_EINVAL, "rgr_sub_add_ex: bad argument");
+        std::unique_lock<std::shared_mutex> lk(h->table_mu);
+        int32_t rc = h->table.sub_add(filter_id, sub_id, qos, flags, node_idx);
+        if (rc != RGR_OK) return fail(rc, "rgr_sub_add_ex: unknown filter id");
+        h->table.sub_set_attr(sub_id, owner_id, client_idx);
+        return RGR_OK;
+    });
+}
+
+int32_t rgr_sub_attrs_bulk(rgr_handle* h, const uint32_t* sub_ids, const uint32_t* owner_ids, const uint32_t* client_idx, uint64_t n) {
+    return guarded([&]() -> int32_t {
+        if (!h || (n && (!owner_ids || !client_idx))) return fail(RGR_EINVAL, "rgr_sub_attrs_bulk: bad argument");
+        std::unique_lock<std::shared_mutex> lk(h->table_mu);
+        for (uint64_t i = 0; i < n; ++i) h->table.sub_set_attr(sub_ids ? sub_ids[i] : uint32_t(i), owner_ids[i], client_idx[i]);
+        if (n) h->table.mark_attrs_all_dirty();
+        return RGR_OK;
+    });
+}
+
 int32_t rgr_sub_remove(rgr_handle* h, uint32_t filter_id, uint32_t sub_id) {
     return guarded([&]() -> int32_t {
         if (!h) return fail(RGR_EINVAL, "rgr_sub_remove: bad argument");
@@ -659,8 +687,15 @@ int32_t rgr_commit(rgr_handle* h) {
             fids.erase(std::unique(fids.begin(), fids.end()), fids.end());
             uint64_t add = 0;
             for (uint32_t f : fids) { const auto* v = h->table.filter_subs(f); add += v ? v->size() : 0; }
+            const bool want_attrs = h->table.has_attrs();
+            const bool attrs_dirty = h->table.take_attrs_all_dirty();     // (same single-reader rule as the delta)
+            auto gather_attrs = [&](const std::vector<SubEntry>& run) {
+                std::vector<SubAttr> at(run.size());
+                for (size_t i = 0; i < run.size(); ++i) at[i] = h->table.sub_attr(run[i].sub_id);
+                return at;
+            };
             bool rebuild = !h->sub_pool || h->sub_pool->used + add > h->sub_pool->cap || h->sub_pool->used + add > 0xFFFFFF00ull ||
-                           h->pool_garbage > h->table.n_subs() + (1u << 16);
+                           h->pool_garbage > h->table.n_subs() + (1u << 16) || attrs_dirty || (want_attrs && !h->sub_pool->has_attrs);
             if (rebuild) {
                 std::vector<FilterDesc> filt;
                 std::vector<SubEntry> subs;
@@ -670,6 +705,12 @@ int32_t rgr_commit(rgr_handle* h) {
                 np->buf.ensure(np->cap * sizeof(SubEntry));
                 if (!subs.empty()) RGR_HIP(hipMemcpy(np->buf.p, subs.data(), subs.size() * sizeof(SubEntry), hipMemcpyHostToDevice));
                 np->used = subs.size();
+                if (want_attrs) {
+                    np->attr_buf.ensure(np->cap * sizeof(SubAttr));
+                    const auto at = gather_attrs(subs);
+                    if (!at.empty()) RGR_HIP(hipMemcpy(np->attr_buf.p, at.data(), at.size() * sizeof(SubAttr), hipMemcpyHostToDevice));
+                    np->has_attrs = true;
+                }
                 h->sub_pool = np;
                 h->host_desc = filt;
                 if (h->host_desc.size() < nf) h->host_desc.resize(nf, FilterDesc{0, 0});
@@ -686,6 +727,10 @@ int32_t rgr_commit(rgr_handle* h) {
                 }
                 if (!stage.empty())
                     RGR_HIP(hipMemcpy(h->sub_pool->buf.as<SubEntry>() + h->sub_pool->used, stage.data(), stage.size() * sizeof(SubEntry), hipMemcpyHostToDevice));
+                if (!stage.empty() && h->sub_pool->has_attrs) {
+                    const auto at = gather_attrs(stage);
+                    RGR_HIP(hipMemcpy(h->sub_pool->attr_buf.as<SubAttr>() + h->sub_pool->used, at.data(), at.size() * sizeof(SubAttr), hipMemcpyHostToDevice));
+                }
                 h->sub_pool->used += stage.size();
             }
             FiltImage& fi = *h->filt_img[tgt];
@@ -717,11 +762,13 @@ int32_t rgr_commit(rgr_handle* h) {
             ep->view.root = h->table.root_header();
             ep->view.filt = fi.buf.as<FilterDesc>();
             ep->view.subs = h->sub_pool->buf.as<SubEntry>();
+            ep->view.attrs = h->sub_pool->has_attrs ? h->sub_pool->attr_buf.as<SubAttr>() : nullptr;
+            ep->n_v5 = h->table.n_v5_subs();
             ep->n_filters = h->table.n_filters();
             ep->n_subs = h->table.n_subs();
             ep->n_nodes = h->table.n_nodes();
             ep->edge_slots = edges.size();
-            ep->bytes = ei.buf.bytes + fi.buf.bytes + h->sub_pool->buf.bytes;
+            ep->bytes = ei.buf.bytes + fi.buf.bytes + h->sub_pool->buf.bytes + h->sub_pool->attr_buf.bytes;
         }
         std::lock_guard<std::mutex> g(h->epoch_mu);
         ep->id = ++h->epoch_counter;
@@ -750,6 +797,7 @@ static int32_t batch_create_impl(rgr_handle* h, const uint8_t* blob, const uint6
         b->h = h;
         b->n = n;
         b->retain = retain;
+        b->deliver = false;
         b->in_pass = false; b->chunk_ready = false; b->cursor = 0; b->hits_before = 0;
         b->dict_tokens = ~0ull;
         b->epoch.reset(); b->repoch.reset();
@@ -814,6 +862,22 @@ void rgr_batch_destroy(rgr_batch* b) {
 }
 
 const int32_t* rgr_batch_status(const rgr_batch* b) { return b ? b->status.data() : nullptr; }
+
+int32_t rgr_batch_set_publish_attrs(rgr_batch* b, const rgr_publish_attr* attrs) {
+    return guarded([&]() -> int32_t {
+        if (!b) return fail(RGR_EINVAL, "rgr_batch_set_publish_attrs: bad argument");
+        if (b->in_pass) return fail(RGR_ESTATE, "rgr_batch_set_publish_attrs: inside a pass");
+        if (b->retain) return fail(RGR_ESTATE, "rgr_batch_set_publish_attrs: not a publish batch");
+        if (!attrs) { b->deliver = false; return RGR_OK; }
+        RGR_HIP(hipSetDevice(b->h->cfg.device));
+        static_assert(sizeof(rgr_publish_attr) == sizeof(PublishAttr), "rgr_publish_attr layout");
+        b->d_pub.ensure(std::max<size_t>(1, b->n) * sizeof(PublishAttr));
+        if (b->n) RGR_HIP(hipMemcpyAsync(b->d_pub.p, attrs, size_t(b->n) * sizeof(PublishAttr), hipMemcpyHostToDevice, b->stream));
+        RGR_HIP(hipStreamSynchronize(b->stream));
+        b->deliver = true;
+        return RGR_OK;
+    });
+}
 
 int32_t rgr_batch_begin(rgr_batch* b) {
     return guarded([&]() -> int32_t {
@@ -883,10 +947,47 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
             size_t sp = b->span_begin(kSpanScan);
             launch_tiles(ca, pair_lo, pair_hi, hit_lo, b->tile_first.as<uint32_t>(), b->stream);
             b->span_end(sp);
+            // delivery stage: fused into the expansion; v5 hits additionally go through the per-client dedup
+            DeliverArgs da{};
+            const bool dedup = b->deliver && !b->retain && b->epoch->n_v5 > 0 && b->epoch->view.attrs != nullptr;
+            if (b->deliver && !b->retain) {
+                if (nh > 0xFFFFFFFFull) return fail(RGR_ECAPACITY, "delivery stage: window larger than 2^32 hits");
+                da.pub = b->d_pub.as<PublishAttr>();
+                da.attrs = b->epoch->view.attrs;
+                if (dedup) {
+                    // every v5 subscription can be hit at most once per matched-filter occurrence of a topic
+                    const uint64_t bound = std::min<uint64_t>(nh, 2 * b->epoch->n_v5 * uint64_t(le - lc));
+                    b->cand.ensure(std::max<uint64_t>(1, bound) * sizeof(Cand));
+                    b->cand_count.ensure(4);
+                    b->h_cand_count.ensure(4);
+                    RGR_HIP(hipMemsetAsync(b->cand_count.p, 0, 4, b->stream));
+                    da.cand = b->cand.as<Cand>();
+                    da.cand_count = b->cand_count.as<uint32_t>();
+                }
+            }
             sp = b->span_begin(kSpanExpand);
-            launch_expand(batch_view(b), ca, pair_lo, pair_hi, hit_lo, hit_hi, b->tile_first.as<uint32_t>(), outbuf.as<Tuple>(), b->stream);
+            launch_expand(batch_view(b), ca, pair_lo, pair_hi, hit_lo, hit_hi, b->tile_first.as<uint32_t>(), outbuf.as<Tuple>(), b->stream,
+                          (b->deliver && !b->retain) ? &da : nullptr);
             b->span_end(sp);
             b->local.expand_launches++;
+            if (dedup) {
+                // the table is sized by the candidate count: one stream sync per window, only in this mode
+                RGR_HIP(hipMemcpyAsync(b->h_cand_count.p, b->cand_count.p, 4, hipMemcpyDeviceToHost, b->stream));
+                RGR_HIP(hipStreamSynchronize(b->stream));
+                const uint32_t nc = *b->h_cand_count.as<uint32_t>();
+                if (nc) {
+                    uint64_t capn = 1024;
+                    while (capn < 2 * uint64_t(nc)) capn <<= 1;
+                    b->dedup_tab.ensure(capn * 12);
+                    sp = b->span_begin(kSpanDedup);
+                    RGR_HIP(hipMemsetAsync(b->dedup_tab.p, 0xFF, capn * 12, b->stream));
+                    launch_dedup(b->cand.as<Cand>(), nc, outbuf.as<Tuple>(), b->dedup_tab.as<unsigned long long>(),
+                                 reinterpret_cast<uint32_t*>(b->dedup_tab.as<unsigned long long>() + capn), capn, b->stream);
+                    b->span_end(sp);
+                    b->local.dedup_candidates += nc;
+                    b->local.dedup_launches++;
+                }
+            }
         }
         w->topic_begin = b->cursor;
         w->topic_end = b->chunk_begin + le;
@@ -1019,7 +1120,8 @@ struct ResultOwner {
 };
 }  // namespace
 
-int32_t rgr_match_batch(rgr_handle* h, const uint8_t* blob, const uint64_t* offs, uint32_t n, rgr_result* out) {
+static int32_t match_batch_impl(rgr_handle* h, const uint8_t* blob, const uint64_t* offs, uint32_t n, const rgr_publish_attr* attrs,
+                                rgr_result* out) {
     if (!out) return fail(RGR_EINVAL, "rgr_match_batch: out is NULL");
     std::memset(out, 0, sizeof *out);
     rgr_batch* b = nullptr;
@@ -1029,7 +1131,9 @@ int32_t rgr_match_batch(rgr_handle* h, const uint8_t* blob, const uint64_t* offs
         auto own = std::make_unique<ResultOwner>();
         own->status.assign(b->status.begin(), b->status.end());
         own->offsets.assign(size_t(n) + 1, 0);
-        int32_t r = rgr_batch_begin(b);
+        int32_t r = attrs ? rgr_batch_set_publish_attrs(b, attrs) : RGR_OK;
+        if (r != RGR_OK) return r;
+        r = rgr_batch_begin(b);
         if (r != RGR_OK) return r;
         std::vector<uint64_t> tmp;
         for (;;) {
@@ -1056,6 +1160,16 @@ int32_t rgr_match_batch(rgr_handle* h, const uint8_t* blob, const uint64_t* offs
     });
     batch_release(b);
     return rc;
+}
+
+int32_t rgr_match_batch(rgr_handle* h, const uint8_t* blob, const uint64_t* offs, uint32_t n, rgr_result* out) {
+    return match_batch_impl(h, blob, offs, n, nullptr, out);
+}
+
+int32_t rgr_match_batch_deliver(rgr_handle* h, const uint8_t* blob, const uint64_t* offs, uint32_t n, const rgr_publish_attr* attrs,
+                                rgr_result* out) {
+    if (n && !attrs) return fail(RGR_EINVAL, "rgr_match_batch_deliver: attrs is NULL");
+    return match_batch_impl(h, blob, offs, n, attrs, out);
 }
 
 void rgr_result_free(rgr_result* r) {

@@ -535,13 +535,19 @@ __global__ __launch_bounds__(256) void tiles_kernel(const uint64_t* pair_off, ui
 }
 
 // --------------------------------------------------------------------------- expand
+// kDeliver: the delivery stage fused into the expansion — the tuple's third word becomes the
+// delivery word (deliver_word, match_core.hpp) and v5 hits that may be per-client duplicates are
+// appended to the window's candidate list (one global atomic per block that has any).
+template <bool kDeliver>
 __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* __restrict__ subs, ChunkArrays c,
                                                                 uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo,
                                                                 uint64_t hit_hi, const uint32_t* __restrict__ tile_first,
-                                                                uint32_t ntiles, Tuple* __restrict__ out) {
+                                                                uint32_t ntiles, Tuple* __restrict__ out, DeliverArgs da) {
     __shared__ int32_t s_off[kTile + 2];
     __shared__ uint32_t s_src[kTile + 2];
     __shared__ uint32_t s_topic[kTile + 2];
+    __shared__ uint32_t s_ncand, s_cbase;
+    if (kDeliver && threadIdx.x == 0) s_ncand = 0;
 
     const uint32_t tile = blockIdx.x;
     const uint64_t base = hit_lo + uint64_t(tile) * kTile;
@@ -572,6 +578,29 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* 
     for (int j = 0; j < kExpandPerThread; ++j) {
         se[j] = *src[j];
     }
+    if (kDeliver) {
+        uint32_t cslot[kExpandPerThread], cclient[kExpandPerThread];
+#pragma unroll
+        for (int j = 0; j < kExpandPerThread; ++j) {
+            const uint32_t pos = uint32_t(j) * kExpandThreads + threadIdx.x;
+            cslot[j] = kNone; cclient[j] = kNone;
+            if (pos < len) {
+                const PublishAttr pa = da.pub[topic[j]];                 // shared by every hit of the topic: L1/L2 hits
+                SubAttr at{kNone, kNone};
+                if (((se[j].qos_flags >> 8) & kSubV5) && da.attrs) at = da.attrs[src[j] - subs];   // v3 hits never need it
+                bool cand;
+                se[j].qos_flags = deliver_word(se[j].qos_flags, pa, at, cand);
+                if (cand && da.cand && at.client_idx != kNone) { cslot[j] = atomicAdd(&s_ncand, 1u); cclient[j] = at.client_idx; }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 && s_ncand) s_cbase = atomicAdd(da.cand_count, s_ncand);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kExpandPerThread; ++j)
+            if (cslot[j] != kNone)
+                da.cand[s_cbase + cslot[j]] = Cand{uint32_t(base - hit_lo) + uint32_t(j) * kExpandThreads + threadIdx.x, cclient[j]};
+    }
 #pragma unroll
     for (int j = 0; j < kExpandPerThread; ++j) {
         const uint32_t pos = uint32_t(j) * kExpandThreads + threadIdx.x;
@@ -586,6 +615,37 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* 
             o[pos] = tp;
 #endif
         }
+    }
+}
+
+// --------------------------------------------------------------------------- v5 per-client dedup
+// types.rs:524-539: of a topic's v5 hits for one client the FIRST (in filter order = position
+// order) keeps filter + options, later ones only contribute their subscription identifier.
+// Pass 1 records the minimum position per (topic, client) in an open-addressed table, pass 2
+// flags every candidate that is not that minimum.
+constexpr unsigned long long kDedupEmpty = ~0ull;
+__global__ __launch_bounds__(256) void dedup_insert_kernel(const Cand* __restrict__ cand, uint32_t n, const Tuple* __restrict__ tuples,
+                                                           unsigned long long* keys, uint32_t* vals, uint64_t mask) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const Cand c = cand[i];
+    const unsigned long long key = (static_cast<unsigned long long>(tuples[c.pos].topic_idx) << 32) | c.client_idx;
+    for (uint64_t s = dedup_hash(key) & mask;; s = (s + 1) & mask) {
+        const unsigned long long prev = atomicCAS(&keys[s], kDedupEmpty, key);
+        if (prev == kDedupEmpty || prev == key) { atomicMin(&vals[s], c.pos); return; }
+    }
+}
+__global__ __launch_bounds__(256) void dedup_flag_kernel(const Cand* __restrict__ cand, uint32_t n, Tuple* __restrict__ tuples,
+                                                         const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                         uint64_t mask) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const Cand c = cand[i];
+    const unsigned long long key = (static_cast<unsigned long long>(tuples[c.pos].topic_idx) << 32) | c.client_idx;
+    for (uint64_t s = dedup_hash(key) & mask;; s = (s + 1) & mask) {
+        const unsigned long long k = keys[s];
+        if (k == key) { if (vals[s] != c.pos) tuples[c.pos].qos_flags |= kHitV5Dup; return; }
+        if (k == kDedupEmpty) return;   // unreachable: every candidate was inserted
     }
 }
 
@@ -685,11 +745,19 @@ void launch_tiles(const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint
 }
 
 void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint64_t hit_hi,
-                   const uint32_t* tile_first, Tuple* out, void* stream) {
+                   const uint32_t* tile_first, Tuple* out, void* stream, const DeliverArgs* deliver) {
     if (hit_hi <= hit_lo) return;
     const uint32_t ntiles = uint32_t((hit_hi - hit_lo + kTile - 1) / kTile);
-    expand_kernel<<<ntiles, kExpandThreads, 0, static_cast<hipStream_t>(stream)>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first,
-                                                                                  ntiles, out);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (deliver) expand_kernel<true><<<ntiles, kExpandThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, *deliver);
+    else expand_kernel<false><<<ntiles, kExpandThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, DeliverArgs{});
+}
+
+void launch_dedup(const Cand* cand, uint32_t n, Tuple* tuples, unsigned long long* keys, uint32_t* vals, uint64_t cap, void* stream) {
+    if (!n) return;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    dedup_insert_kernel<<<(n + 255) / 256, 256, 0, s>>>(cand, n, tuples, keys, vals, cap - 1);
+    dedup_flag_kernel<<<(n + 255) / 256, 256, 0, s>>>(cand, n, tuples, keys, vals, cap - 1);
 }
 
 }  // namespace rgr

@@ -47,6 +47,19 @@ struct NodeHeader { uint32_t plus_slot, hash_fid, term_fid, lit_cnt, lit_xor; };
 struct FilterDesc { uint32_t begin, count; };
 struct SubEntry { uint32_t sub_id, qos_flags; };
 struct Tuple { uint32_t topic_idx, sub_id, qos_flags; };   // == rgr_tuple
+// Delivery stage: per-subscription attributes parallel to subs[] (same index),
+// per-publish attributes parallel to the batch's topics.
+struct SubAttr { uint32_t owner_id, client_idx; };
+struct PublishAttr { uint32_t from_id, qos_retain; };       // == rgr_publish_attr
+struct Cand { uint32_t pos, client_idx; };                  // v5 hit that may be a per-client duplicate (window-relative position)
+constexpr uint32_t kSubV5 = 1u << 0, kSubNoLocal = 1u << 1, kSubShared = 1u << 2, kSubRap = 1u << 3;   // RGR_SUB_*
+constexpr uint32_t kHitRetain = 1u << 2, kHitNoLocal = 1u << 3, kHitV5Dup = 1u << 4;                    // RGR_HIT_*
+struct DeliverArgs {
+    const PublishAttr* pub;      // [n_batch]
+    const SubAttr* attrs;        // parallel to TrieView::subs, may be null (no ids registered)
+    Cand* cand;                  // dedup candidates of this window, unordered; null = none wanted
+    uint32_t* cand_count;
+};
 
 // Level-string dictionary image (host: table.cpp StringDict; device: one copy per epoch).
 struct DictEntry { uint64_t hash; uint64_t off; uint32_t len; uint32_t pad; };
@@ -75,6 +88,7 @@ struct TrieView {
     NodeHeader root;
     const FilterDesc* filt;
     const SubEntry* subs;
+    const SubAttr* attrs = nullptr;   // parallel to subs (delivery stage), null when no ids were registered
 };
 
 // ---- RetainTree twin (rmqtt/src/retain.rs): trie of concrete retained topics, nodes numbered
@@ -178,7 +192,11 @@ void launch_scan(const ChunkArrays& c, uint64_t* block_tmp, void* stream);
 void launch_compact(const TrieView& t, const ChunkArrays& c, uint32_t topic_base, void* stream);
 void launch_tiles(const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint32_t* tile_first, void* stream);
 void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint64_t hit_hi,
-                   const uint32_t* tile_first, Tuple* out, void* stream);
+                   const uint32_t* tile_first, Tuple* out, void* stream, const DeliverArgs* deliver = nullptr);
+// v5 per-client dedup over a window's candidates: first position per (topic, client) wins, every
+// other candidate gets kHitV5Dup.  keys/vals: open-addressed table of `cap` (power of two) slots,
+// pre-filled with 0xFF bytes.
+void launch_dedup(const Cand* cand, uint32_t n, Tuple* tuples, unsigned long long* keys, uint32_t* vals, uint64_t cap, void* stream);
 uint32_t expand_tile_hits();
 uint32_t scan_block_topics();
 

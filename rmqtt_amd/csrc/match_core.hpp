@@ -298,4 +298,28 @@ RGR_HD inline void tile_pair_view(const ChunkArrays& c, uint64_t a, uint32_t i, 
     topic = c.pair_topic[a + i];
 }
 
+// ---- delivery stage --------------------------------------------------------
+// The per-hit part of DefaultRouter::_matches (router.rs:194-201) and forwards_to
+// (shared.rs:886-903): qos downgrade, Retain-As-Published, No Local.  `candidate` = the hit goes
+// through the v5 collector keyed by client (types.rs:524-539): v5, not a $share member (those go
+// through SharedSubscription::choice on the host, router.rs:202-255), not dropped.
+RGR_HD inline uint32_t deliver_word(uint32_t qos_flags, PublishAttr pa, SubAttr at, bool& candidate) {
+    const uint32_t fl = (qos_flags >> 8) & 0xFFu;
+    const uint32_t sq = qos_flags & 0xFFu, pq = pa.qos_retain & 3u;
+    uint32_t w = (qos_flags & 0xFFFFFF00u) | (sq < pq ? sq : pq);
+    const bool v5 = (fl & kSubV5) != 0;
+    if (v5 && (fl & kSubRap) && (pa.qos_retain & 4u)) w |= kHitRetain;
+    const bool dropped = v5 && (fl & kSubNoLocal) && pa.from_id != kNone && at.owner_id == pa.from_id;
+    if (dropped) w |= kHitNoLocal;
+    candidate = v5 && !(fl & kSubShared) && !dropped;
+    return w;
+}
+
+RGR_HD inline uint64_t dedup_hash(uint64_t key) {
+    key ^= key >> 33; key *= 0xff51afd7ed558ccdull;
+    key ^= key >> 33; key *= 0xc4ceb9fe1a85ec53ull;
+    key ^= key >> 33;
+    return key;
+}
+
 }  // namespace rgr

@@ -268,17 +268,30 @@ int32_t HostTable::filter_remove(uint32_t fid) {
     return RGR_OK;
 }
 
-int32_t HostTable::sub_add(uint32_t fid, uint32_t sub_id, uint8_t qos, uint8_t flags) {
+int32_t HostTable::sub_add(uint32_t fid, uint32_t sub_id, uint8_t qos, uint8_t flags, uint16_t node_idx) {
     if (fid >= filters_.size() || filters_[fid].node == kNone) return RGR_ENOENT;
     auto& v = filters_[fid].subs;
     delta_.fids.push_back(fid);
-    const SubEntry e{sub_id, uint32_t(qos) | (uint32_t(flags) << 8)};
-    if (v.empty() || v.back().sub_id < sub_id) { v.push_back(e); n_subs_++; return RGR_OK; }
+    const SubEntry e{sub_id, uint32_t(qos) | (uint32_t(flags) << 8) | (uint32_t(node_idx) << 16)};
+    const uint64_t is_v5 = (flags & kSubV5) ? 1 : 0;
+    if (v.empty() || v.back().sub_id < sub_id) { v.push_back(e); n_subs_++; n_v5_ += is_v5; return RGR_OK; }
     auto it = std::lower_bound(v.begin(), v.end(), sub_id, [](const SubEntry& a, uint32_t b) { return a.sub_id < b; });
-    if (it != v.end() && it->sub_id == sub_id) { *it = e; return RGR_OK; }   // re-subscribe: options replaced
+    if (it != v.end() && it->sub_id == sub_id) {                             // re-subscribe: options replaced
+        n_v5_ += is_v5;
+        n_v5_ -= ((it->qos_flags >> 8) & kSubV5) ? 1 : 0;
+        *it = e;
+        return RGR_OK;
+    }
     v.insert(it, e);
     n_subs_++;
+    n_v5_ += is_v5;
     return RGR_OK;
+}
+
+void HostTable::sub_set_attr(uint32_t sub_id, uint32_t owner_id, uint32_t client_idx) {
+    if (sub_id >= attrs_.size()) attrs_.resize(size_t(sub_id) + 1 + attrs_.size() / 2, SubAttr{kNone, kNone});
+    attrs_[sub_id] = SubAttr{owner_id, client_idx};
+    has_attrs_ = true;
 }
 
 int32_t HostTable::sub_remove(uint32_t fid, uint32_t sub_id) {
@@ -286,6 +299,7 @@ int32_t HostTable::sub_remove(uint32_t fid, uint32_t sub_id) {
     auto& v = filters_[fid].subs;
     auto it = std::lower_bound(v.begin(), v.end(), sub_id, [](const SubEntry& a, uint32_t b) { return a.sub_id < b; });
     if (it == v.end() || it->sub_id != sub_id) return RGR_ENOENT;
+    n_v5_ -= ((it->qos_flags >> 8) & kSubV5) ? 1 : 0;
     v.erase(it);
     delta_.fids.push_back(fid);
     n_subs_--;

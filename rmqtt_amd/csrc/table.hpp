@@ -51,7 +51,17 @@ class HostTable {
     int32_t filter_add(std::string_view f, uint32_t* fid);
     int32_t filter_find(std::string_view f, uint32_t* fid) const;
     int32_t filter_remove(uint32_t fid);
-    int32_t sub_add(uint32_t fid, uint32_t sub_id, uint8_t qos, uint8_t flags);
+    int32_t sub_add(uint32_t fid, uint32_t sub_id, uint8_t qos, uint8_t flags, uint16_t node_idx = 0);
+    // Delivery-stage attributes of a subscription (kernels.hpp SubAttr), indexed by sub_id.  They
+    // ride in a run parallel to the subscriber run, so setting them marks nothing dirty by itself:
+    // call it right before/after the sub_add that (re)writes the run, or use attrs_all_dirty().
+    void sub_set_attr(uint32_t sub_id, uint32_t owner_id, uint32_t client_idx);
+    bool has_attrs() const { return has_attrs_; }
+    SubAttr sub_attr(uint32_t sub_id) const { return sub_id < attrs_.size() ? attrs_[sub_id] : SubAttr{kNone, kNone}; }
+    // set by the bulk attribute call: every run must be rebuilt at the next commit
+    bool take_attrs_all_dirty() { const bool d = attrs_all_dirty_; attrs_all_dirty_ = false; return d; }
+    void mark_attrs_all_dirty() { attrs_all_dirty_ = true; }
+    uint64_t n_v5_subs() const { return n_v5_; }
     int32_t sub_remove(uint32_t fid, uint32_t sub_id);
     // Restore / bulk path (rmqtt-cluster-raft/src/router.rs:557-566 re-inserts every filter after a
     // snapshot): filter_add + sub_add for n subscriptions.  Tokenises on `threads` threads, sorts the
@@ -106,7 +116,9 @@ class HostTable {
     NodeHeader root_hdr_{kNone, kNone, kNone, 0, 0};
     std::vector<Filter> filters_;
     std::vector<uint32_t> free_fids_;
-    uint64_t n_filters_ = 0, n_subs_ = 0, n_nodes_ = 1;
+    uint64_t n_filters_ = 0, n_subs_ = 0, n_nodes_ = 1, n_v5_ = 0;
+    std::vector<SubAttr> attrs_;
+    bool has_attrs_ = false, attrs_all_dirty_ = false;
     Delta delta_;
     void touch(uint32_t slot) { delta_.slots.push_back(slot); }
 

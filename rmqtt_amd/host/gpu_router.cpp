@@ -6,29 +6,35 @@
 namespace rmqtt {
 
 namespace {
-// types.rs:503-541
-struct Collector {
-    SubRelations v3_rels;
-    std::vector<ClientId> v5_order;
-    std::unordered_map<ClientId, SubRelation> v5_rels;
-    void add(const TopicFilter& filter, const ClientId& client, const SubscriptionOptions& opts) {
-        if (opts.is_v3()) { v3_rels.push_back(SubRelation{filter, client, opts, std::nullopt}); return; }
-        auto it = v5_rels.find(client);
-        if (it != v5_rels.end()) {                                  // types.rs:526-534
-            if (opts.subscription_identifier) {
-                if (it->second.sub_ids) it->second.sub_ids->push_back(opts.subscription_identifier);
-                else it->second.sub_ids = std::vector<uint32_t>{opts.subscription_identifier};
-            }
-        } else {                                                    // types.rs:535-538
-            SubRelation r{filter, client, opts, std::nullopt};
-            if (opts.subscription_identifier) r.sub_ids = std::vector<uint32_t>{opts.subscription_identifier};
-            v5_rels.emplace(client, std::move(r));
-            v5_order.push_back(client);
-        }
-    }
-};
-uint8_t flags_of(const SubscriptionOptions& o) { return uint8_t((o.v5 ? RGR_SUB_V5 : 0) | (o.no_local ? RGR_SUB_NO_LOCAL : 0)); }
+uint8_t flags_of(const SubscriptionOptions& o) {
+    return uint8_t((o.v5 ? RGR_SUB_V5 : 0) | (o.v5 && o.no_local ? RGR_SUB_NO_LOCAL : 0) | (o.v5 && o.retain_as_published ? RGR_SUB_RAP : 0));
+}
+// Every field Id equality looks at (types.rs:1841-1851), unambiguously joined.
+std::string id_key(const Id& id) {
+    std::string k = std::to_string(id.node_id) + '|' + std::to_string(id.lid) + '|' + std::to_string(id.create_time);
+    for (const std::string* f : {&id.local_addr, &id.remote_addr, &id.client_id, &id.username}) { k += '|'; k += std::to_string(f->size()); k += ':'; k += *f; }
+    return k;
+}
+std::string client_key(NodeId node, const ClientId& c) { return std::to_string(node) + '|' + c; }
 }  // namespace
+
+uint32_t GpuRouter::Dense::acquire(const std::string& k) {
+    auto it = ids.find(k);
+    if (it != ids.end()) { it->second.second++; return it->second.first; }
+    uint32_t id;
+    if (!free.empty()) { id = free.back(); free.pop_back(); } else id = next++;
+    ids.emplace(k, std::make_pair(id, 1u));
+    return id;
+}
+void GpuRouter::Dense::release(const std::string& k) {
+    auto it = ids.find(k);
+    if (it == ids.end()) return;
+    if (--it->second.second == 0) { free.push_back(it->second.first); ids.erase(it); }
+}
+uint32_t GpuRouter::Dense::find(const std::string& k) const {
+    auto it = ids.find(k);
+    return it == ids.end() ? RGR_ID_NONE : it->second.first;
+}
 
 GpuRouter::GpuRouter(NodeId this_node, int device) : this_node_(this_node) {
     rgr_config cfg{};
@@ -61,17 +67,27 @@ Result<bool> GpuRouter::add(const std::string& topic_filter, const Id& id, const
     auto& rels = it->second.rels;
     auto old = rels.find(id.client_id);
     uint32_t sub_id;
+    const uint32_t owner_id = owners_.acquire(id_key(id));
     if (old == rels.end()) {
         relations_count_.inc();
         if (!free_sub_ids_.empty()) { sub_id = free_sub_ids_.back(); free_sub_ids_.pop_back(); }
         else { sub_id = uint32_t(slab_.size()); slab_.emplace_back(); }
-        old = rels.emplace(id.client_id, Rel{id, opts, sub_id}).first;
+        old = rels.emplace(id.client_id, Rel{id, opts, sub_id, owner_id}).first;
     } else {
         sub_id = old->second.sub_id;
-        old->second = Rel{id, opts, sub_id};                        // HashMap::insert replaces (router.rs:447)
+        owners_.release(id_key(old->second.id));
+        clients_.release(client_key(old->second.id.node_id, old->second.id.client_id));
+        old->second = Rel{id, opts, sub_id, owner_id};              // HashMap::insert replaces (router.rs:447)
+    }
+    const uint32_t client_idx = clients_.acquire(client_key(id.node_id, id.client_id));
+    auto ni = node_idx_.find(id.node_id);
+    if (ni == node_idx_.end()) {
+        if (nodes_.size() >= 0xFFFF) return Result<bool>::Err("more than 65535 distinct node ids");
+        ni = node_idx_.emplace(id.node_id, uint16_t(nodes_.size())).first;
+        nodes_.push_back(id.node_id);
     }
     slab_[sub_id] = Slot{&it->first, &old->second};
-    rc = rgr_sub_add(h_, fid, sub_id, opts.qos, flags_of(opts));
+    rc = rgr_sub_add_ex(h_, fid, sub_id, opts.qos, flags_of(opts), ni->second, owner_id, client_idx);
     if (rc != RGR_OK) return Result<bool>::Err(rgr_last_error());
     dirty_ = true;
     return Result<bool>::Ok(true);
@@ -90,6 +106,8 @@ Result<bool> GpuRouter::remove(const std::string& topic_filter, const Id& id) {
     if (rgr_sub_remove(h_, fid, sub_id) != RGR_OK) return Result<bool>::Err(rgr_last_error());
     slab_[sub_id] = Slot{};
     free_sub_ids_.push_back(sub_id);
+    owners_.release(id_key(r->second.id));
+    clients_.release(client_key(r->second.id.node_id, r->second.id.client_id));
     rels.erase(r);
     relations_count_.dec();
     if (rels.empty()) {                                              // router.rs:484-490
@@ -111,26 +129,41 @@ Result<bool> GpuRouter::matches_batch(const std::vector<Id>& ids, const std::vec
     std::string blob;
     std::vector<uint64_t> offs(topics.size() + 1, 0);
     for (size_t i = 0; i < topics.size(); ++i) { blob += topics[i]; offs[i + 1] = blob.size(); }
+    // publish attributes: who publishes (for No Local); qos 2 / retain 0 leave the subscription's own qos in the word
+    std::vector<rgr_publish_attr> attrs(topics.size());
+    for (size_t i = 0; i < topics.size(); ++i) attrs[i] = rgr_publish_attr{owners_.find(id_key(ids[i])), 2u};
     rgr_result res{};
-    if (rgr_match_batch(h_, reinterpret_cast<const uint8_t*>(blob.data()), offs.data(), uint32_t(topics.size()), &res) != RGR_OK)
+    if (rgr_match_batch_deliver(h_, reinterpret_cast<const uint8_t*>(blob.data()), offs.data(), uint32_t(topics.size()), attrs.data(), &res) != RGR_OK)
         return Result<bool>::Err(rgr_last_error());
     out.assign(topics.size(), std::nullopt);
     for (size_t t = 0; t < topics.size(); ++t) {
         if (res.status[t] != RGR_TOPIC_OK) continue;                 // Topic::from_str Err (router.rs:177)
-        std::map<NodeId, Collector> collector_map;
+        SubRelationsMap m;                                           // collector_map (router.rs:176) + router.rs:258-261
+        std::map<NodeId, SubRelations> v5;                           // types.rs:488-497: v3 rows first, then the v5 map's rows
         for (uint64_t k = res.hit_offsets[t]; k < res.hit_offsets[t + 1]; ++k) {
+            const uint32_t w = res.tuples[k].qos_flags;
+            if (w & RGR_HIT_NO_LOCAL) continue;                      // router.rs:196-201, decided on the device
             const Slot& s = slab_[res.tuples[k].sub_id];
             const Rel& rel = *s.rel;
-            auto nl = rel.opts.opt_no_local();
-            if (nl && *nl && ids[t] == rel.id) continue;             // router.rs:196-201
-            collector_map[rel.id.node_id].add(*s.filter, rel.id.client_id, rel.opts);
+            const NodeId node = nodes_[w >> 16];
+            if (rel.opts.is_v3()) { m[node].push_back(SubRelation{*s.filter, rel.id.client_id, rel.opts, std::nullopt}); continue; }
+            auto& rows = v5[node];
+            m[node];                                                  // the node has a collector even if only v5 rows follow
+            if (w & RGR_HIT_V5_DUP) {                                // types.rs:526-534: only the subscription identifier is kept
+                if (!rel.opts.subscription_identifier) continue;
+                for (auto& r : rows) {
+                    if (r.client_id != rel.id.client_id) continue;
+                    if (r.sub_ids) r.sub_ids->push_back(rel.opts.subscription_identifier);
+                    else r.sub_ids = std::vector<uint32_t>{rel.opts.subscription_identifier};
+                    break;
+                }
+            } else {                                                 // types.rs:535-538
+                SubRelation r{*s.filter, rel.id.client_id, rel.opts, std::nullopt};
+                if (rel.opts.subscription_identifier) r.sub_ids = std::vector<uint32_t>{rel.opts.subscription_identifier};
+                rows.push_back(std::move(r));
+            }
         }
-        SubRelationsMap m;
-        for (auto& kv : collector_map) {                             // router.rs:258-261 + types.rs:488-497
-            auto& dst = m[kv.first];
-            dst = std::move(kv.second.v3_rels);
-            for (auto& c : kv.second.v5_order) dst.push_back(std::move(kv.second.v5_rels[c]));
-        }
+        for (auto& kv : v5) { auto& dst = m[kv.first]; for (auto& r : kv.second) dst.push_back(std::move(r)); }
         out[t] = std::move(m);
     }
     rgr_result_free(&res);

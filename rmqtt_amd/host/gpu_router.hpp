@@ -11,10 +11,13 @@
 // keyed by the filter string (router.rs:121-127, types.rs:476) — and mirrors every add/remove
 // into the device table through rgr_filter_add/rgr_sub_add/...  Only `matches` changes: the
 // trie walk + relation expansion run on the GPU and come back as (topic_idx, sub_id, qos)
-// tuples, which are mapped back through a sub_id slab; No-Local (router.rs:196-201) and the
-// v3/v5 collector (types.rs:513-540) are applied here because they need `Id` equality and the
-// per-client map.  Shared-group choice (router.rs:236-255) needs live session state and is not
-// modelled (flagged RGR_SUB_SHARED for the Rust glue).
+// tuples, which are mapped back through a sub_id slab.  The per-hit decisions of _matches —
+// No Local (router.rs:196-201: whole-`Id` equality) and the v5 collector's first-hit-per-client
+// rule (types.rs:524-539) — are taken by the device's delivery stage (rgr_match_batch_deliver):
+// every relation is registered with a dense id of its `Id`, of its (node, ClientId) and of its
+// node (rgr_sub_add_ex), and `matches` only reads the RGR_HIT_* flags.  Shared-group choice
+// (router.rs:236-255) needs live session state and is not modelled (flagged RGR_SUB_SHARED for
+// the Rust glue).
 #pragma once
 #include <cstdint>
 #include <map>
@@ -126,7 +129,15 @@ class GpuRouter final : public Router {
     std::vector<std::string> list_topics(size_t top) override;
 
    private:
-    struct Rel { Id id; SubscriptionOptions opts; uint32_t sub_id; };
+    struct Rel { Id id; SubscriptionOptions opts; uint32_t sub_id; uint32_t owner_id; };
+    struct Dense {                       // string key -> dense u32 id with reference counts
+        std::unordered_map<std::string, std::pair<uint32_t, uint32_t>> ids;   // key -> (id, refs)
+        std::vector<uint32_t> free;
+        uint32_t next = 0;
+        uint32_t acquire(const std::string& k);
+        void release(const std::string& k);
+        uint32_t find(const std::string& k) const;                             // RGR_ID_NONE if absent
+    };
     struct FilterEntry { uint32_t filter_id; std::unordered_map<ClientId, Rel> rels; };
     struct Slot { const std::string* filter = nullptr; const Rel* rel = nullptr; };
 
@@ -138,6 +149,9 @@ class GpuRouter final : public Router {
     std::vector<Slot> slab_;           // sub_id -> relation
     std::vector<uint32_t> free_sub_ids_;
     std::unordered_map<uint32_t, const std::string*> filter_names_;   // filter_id -> filter string
+    Dense owners_, clients_;             // Id -> owner_id, (node, ClientId) -> client_idx
+    std::vector<NodeId> nodes_;          // node_idx -> NodeId
+    std::unordered_map<NodeId, uint16_t> node_idx_;
     Counter topics_count_, relations_count_;
     bool dirty_ = false;
 

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string_view>
 #include <vector>
 
@@ -52,6 +53,12 @@ int32_t emu_filter_add(void* e, const char* f, uint32_t len, uint32_t* fid) { re
 int32_t emu_filter_find(void* e, const char* f, uint32_t len, uint32_t* fid) { return static_cast<Emu*>(e)->table.filter_find(std::string_view(f, len), fid); }
 int32_t emu_filter_remove(void* e, uint32_t fid) { return static_cast<Emu*>(e)->table.filter_remove(fid); }
 int32_t emu_sub_add(void* e, uint32_t fid, uint32_t sid, uint8_t qos, uint8_t flags) { return static_cast<Emu*>(e)->table.sub_add(fid, sid, qos, flags); }
+int32_t emu_sub_add_ex(void* e, uint32_t fid, uint32_t sid, uint8_t qos, uint8_t flags, uint16_t node, uint32_t owner, uint32_t client) {
+    auto& t = static_cast<Emu*>(e)->table;
+    const int32_t rc = t.sub_add(fid, sid, qos, flags, node);
+    if (rc == RGR_OK) t.sub_set_attr(sid, owner, client);
+    return rc;
+}
 int32_t emu_sub_remove(void* e, uint32_t fid, uint32_t sid) { return static_cast<Emu*>(e)->table.sub_remove(fid, sid); }
 uint64_t emu_n_nodes(void* e) { return static_cast<Emu*>(e)->table.n_nodes(); }
 uint64_t emu_n_filters(void* e) { return static_cast<Emu*>(e)->table.n_filters(); }
@@ -77,7 +84,7 @@ namespace {
 template <class WalkOne, class Prefill>
 int32_t run_pipeline(Emu* e, uint32_t n, const std::vector<uint64_t>& tok_off, const std::vector<uint8_t>& tflags, const TrieView& tv,
                      WalkOne walk_one, Prefill prefill, bool use_prefill, uint64_t** hit_offsets_out, rgr_tuple** tuples_out, uint64_t* n_hits_out,
-                     uint64_t** pair_offsets_out, uint32_t** pair_fids_out) {
+                     uint64_t** pair_offsets_out, uint32_t** pair_fids_out, const PublishAttr* pub = nullptr) {
     std::vector<uint64_t> hit_offsets(size_t(n) + 1, 0), pair_offsets(size_t(n) + 1, 0);
     std::vector<rgr_tuple> tuples;
     std::vector<uint32_t> pair_fids;
@@ -159,6 +166,7 @@ int32_t run_pipeline(Emu* e, uint32_t n, const std::vector<uint64_t>& tok_off, c
                 std::vector<int32_t> s_off(T + 2);
                 std::vector<uint32_t> s_src(T + 2), s_topic(T + 2);
                 rgr_tuple* out = tuples.data() + out_base + hit_lo;
+                std::vector<Cand> cand;
                 for (uint32_t tile = 0; tile < ntiles; ++tile) {
                     const uint64_t base = hit_lo + uint64_t(tile) * T;
                     const uint32_t len = uint32_t(std::min<uint64_t>(T, hit_hi - base));
@@ -170,9 +178,39 @@ int32_t run_pipeline(Emu* e, uint32_t n, const std::vector<uint64_t>& tok_off, c
                     for (uint32_t i = 0; i < np; ++i) tile_pair_view(ca, a, i, base, s_off[i], s_src[i], s_topic[i]);
                     for (uint32_t pos = 0; pos < len; ++pos) {
                         const uint32_t i = locate_pair([&](uint32_t m) { return s_off[m]; }, np, int32_t(pos));
-                        const SubEntry se = tv.subs[uint64_t(s_src[i]) + uint32_t(int32_t(pos) - s_off[i])];
+                        const uint64_t src = uint64_t(s_src[i]) + uint32_t(int32_t(pos) - s_off[i]);
+                        SubEntry se = tv.subs[src];
+                        if (pub) {   // expand_kernel<true>
+                            SubAttr at{kNone, kNone};
+                            if (((se.qos_flags >> 8) & kSubV5) && tv.attrs) at = tv.attrs[src];
+                            bool is_cand;
+                            se.qos_flags = deliver_word(se.qos_flags, pub[s_topic[i]], at, is_cand);
+                            if (is_cand && at.client_idx != kNone) cand.push_back(Cand{uint32_t(base - hit_lo) + pos, at.client_idx});
+                        }
                         out[(base - hit_lo) + pos] = rgr_tuple{s_topic[i], se.sub_id, se.qos_flags};
                     }
+                }
+                if (!cand.empty()) {   // launch_dedup: the same open-addressed table, sequentially; candidates reversed
+                    std::reverse(cand.begin(), cand.end());          // (their order on the device is arbitrary)
+                    uint64_t cap = 1024;
+                    while (cap < 2 * cand.size()) cap <<= 1;
+                    std::vector<uint64_t> keys(cap, ~0ull);
+                    std::vector<uint32_t> vals(cap, 0xFFFFFFFFu);
+                    auto key_of = [&](const Cand& c) { return (uint64_t(out[c.pos].topic_idx) << 32) | c.client_idx; };
+                    for (const Cand& c : cand)
+                        for (uint64_t sl = dedup_hash(key_of(c)) & (cap - 1);; sl = (sl + 1) & (cap - 1))
+                            if (keys[sl] == ~0ull || keys[sl] == key_of(c)) { keys[sl] = key_of(c); vals[sl] = std::min(vals[sl], c.pos); break; }
+                    std::map<uint64_t, uint32_t> first;                // independent statement of types.rs:524-539
+                    for (const Cand& c : cand) { auto it = first.find(key_of(c)); if (it == first.end() || c.pos < it->second) first[key_of(c)] = c.pos; }
+                    for (const Cand& c : cand)
+                        for (uint64_t sl = dedup_hash(key_of(c)) & (cap - 1);; sl = (sl + 1) & (cap - 1)) {
+                            if (keys[sl] == key_of(c)) {
+                                if ((vals[sl] != c.pos) != (first[key_of(c)] != c.pos)) return RGR_ESTATE;
+                                if (vals[sl] != c.pos) out[c.pos].qos_flags |= kHitV5Dup;
+                                break;
+                            }
+                            if (keys[sl] == ~0ull) return RGR_ESTATE;
+                        }
                 }
             }
             lc = le;
@@ -191,8 +229,16 @@ int32_t run_pipeline(Emu* e, uint32_t n, const std::vector<uint64_t>& tok_off, c
 extern "C" {
 
 // Same outputs as rgr_match_batch (+ the matched filter ids per topic).  Arrays malloc'ed.
+int32_t emu_match_deliver(void* ev, const uint8_t* blob, const uint64_t* offs, uint32_t n, const rgr_publish_attr* pub_attrs, int32_t* status,
+                          uint64_t** hit_offsets_out, rgr_tuple** tuples_out, uint64_t* n_hits_out, uint64_t** pair_offsets_out,
+                          uint32_t** pair_fids_out);
 int32_t emu_match(void* ev, const uint8_t* blob, const uint64_t* offs, uint32_t n, int32_t* status, uint64_t** hit_offsets_out,
                   rgr_tuple** tuples_out, uint64_t* n_hits_out, uint64_t** pair_offsets_out, uint32_t** pair_fids_out) {
+    return emu_match_deliver(ev, blob, offs, n, nullptr, status, hit_offsets_out, tuples_out, n_hits_out, pair_offsets_out, pair_fids_out);
+}
+int32_t emu_match_deliver(void* ev, const uint8_t* blob, const uint64_t* offs, uint32_t n, const rgr_publish_attr* pub_attrs, int32_t* status,
+                          uint64_t** hit_offsets_out, rgr_tuple** tuples_out, uint64_t* n_hits_out, uint64_t** pair_offsets_out,
+                          uint32_t** pair_fids_out) {
     auto* e = static_cast<Emu*>(ev);
     const HostTable& tb = e->table;
     std::vector<uint32_t> tokens;
@@ -225,6 +271,10 @@ int32_t emu_match(void* ev, const uint8_t* blob, const uint64_t* offs, uint32_t 
     tb.flatten_filters(filt, subs);
     filt.push_back(FilterDesc{0, 0}); subs.push_back(SubEntry{0, 0});
     TrieView tv{tb.edges().data(), uint32_t(tb.edges().size() - 1), tb.root_header(), filt.data(), subs.data()};
+    std::vector<SubAttr> attrs(subs.size());
+    for (size_t i = 0; i < subs.size(); ++i) attrs[i] = tb.sub_attr(subs[i].sub_id);
+    if (tb.has_attrs()) tv.attrs = attrs.data();
+    static_assert(sizeof(rgr_publish_attr) == sizeof(PublishAttr), "layout");
     auto walk_one = [&](uint32_t gt, uint64_t staged, uint64_t rel, std::vector<uint32_t>& s_path, auto& emit) {
         const uint64_t off0 = tok_off[gt];
         const uint32_t L = uint32_t(tok_off[gt + 1] - off0);
@@ -239,7 +289,8 @@ int32_t emu_match(void* ev, const uint8_t* blob, const uint64_t* offs, uint32_t 
             });
     };
     auto no_prefill = [](uint32_t, uint32_t, std::vector<uint32_t>&, std::vector<uint64_t>&, std::vector<uint32_t>&) {};
-    return run_pipeline(e, n, tok_off, tflags, tv, walk_one, no_prefill, false, hit_offsets_out, tuples_out, n_hits_out, pair_offsets_out, pair_fids_out);
+    return run_pipeline(e, n, tok_off, tflags, tv, walk_one, no_prefill, false, hit_offsets_out, tuples_out, n_hits_out, pair_offsets_out, pair_fids_out,
+                        reinterpret_cast<const PublishAttr*>(pub_attrs));
 }
 
 // ---- RetainTree twin -----------------------------------------------------------------

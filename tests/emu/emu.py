@@ -35,6 +35,8 @@ def lib():
         L.emu_filter_find.argtypes = [vp, C.c_char_p, u32, C.POINTER(u32)]
         L.emu_filter_remove.argtypes = [vp, u32]
         L.emu_sub_add.argtypes = [vp, u32, u32, u8, u8]
+        L.emu_sub_add_ex.argtypes = [vp, u32, u32, u8, u8, C.c_uint16, u32, u32]
+        L.emu_match_deliver.argtypes = [vp, vp, vp, u32, vp, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), C.POINTER(vp), C.POINTER(vp)]
         L.emu_sub_remove.argtypes = [vp, u32, u32]
         for f in ("emu_n_nodes", "emu_n_filters", "emu_n_subs", "emu_visited", "emu_overflow_topics", "emu_windows"):
             getattr(L, f).argtypes = [vp]; getattr(L, f).restype = u64
@@ -90,6 +92,9 @@ class EmuRouter:
     def sub_add(self, fid, sub_id, qos=0, flags=0):
         assert lib().emu_sub_add(self._h, fid, sub_id, qos, flags) == 0
 
+    def sub_add_ex(self, fid, sub_id, qos=0, flags=0, node_idx=0, owner_id=0xFFFFFFFF, client_idx=0xFFFFFFFF):
+        assert lib().emu_sub_add_ex(self._h, fid, sub_id, qos, flags, node_idx, owner_id, client_idx) == 0
+
     def sub_remove(self, fid, sub_id):
         return lib().emu_sub_remove(self._h, fid, sub_id)
 
@@ -110,15 +115,20 @@ class EmuRouter:
     def commit(self):
         pass
 
-    def _match(self, blob, offsets):
+    def _match(self, blob, offsets, publish_attrs=None):
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         blob = np.ascontiguousarray(np.frombuffer(bytes(blob), dtype=np.uint8) if not isinstance(blob, np.ndarray) else blob)
         n = len(offsets) - 1
         status = np.zeros(n, dtype=np.int32)
         ho, tp, po, pf = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
         nh = C.c_uint64(0)
-        rc = lib().emu_match(self._h, blob.ctypes.data if len(blob) else None, offsets.ctypes.data, n, status.ctypes.data,
-                             C.byref(ho), C.byref(tp), C.byref(nh), C.byref(po), C.byref(pf))
+        pa = None
+        if publish_attrs is not None:
+            pa = np.ascontiguousarray(publish_attrs, dtype=np.dtype([("from_id", np.uint32), ("qos_retain", np.uint32)]))
+            assert len(pa) == n
+        rc = lib().emu_match_deliver(self._h, blob.ctypes.data if len(blob) else None, offsets.ctypes.data, n,
+                                     None if pa is None else pa.ctypes.data, status.ctypes.data,
+                                     C.byref(ho), C.byref(tp), C.byref(nh), C.byref(po), C.byref(pf))
         assert rc == 0, rc
         hit_offsets = _take(ho, n + 1, np.uint64)
         tuples = _take(tp, nh.value, TUPLE_DTYPE)
@@ -128,6 +138,10 @@ class EmuRouter:
 
     def match_batch(self, blob, offsets):
         s, ho, tp, _, _ = self._match(blob, offsets)
+        return dict(status=s, hit_offsets=ho, tuples=tp)
+
+    def match_batch_deliver(self, blob, offsets, publish_attrs):
+        s, ho, tp, _, _ = self._match(blob, offsets, publish_attrs)
         return dict(status=s, hit_offsets=ho, tuples=tp)
 
     def match_filters(self, blob, offsets):

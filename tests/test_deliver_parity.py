@@ -1,0 +1,196 @@
+"""Delivery stage vs the oracle.
+
+The oracle side is `DefaultRouter::_matches` (router.rs:174-265: No Local, per-node collectors),
+the v3/v5 collector (types.rs:510-540) and forwards_to's per-recipient transform
+(shared.rs:886-908: Retain-As-Published, qos downgrade, subscription identifiers), dumped by
+oracle `forwards`.  The backend side is rgr_match_batch_deliver: tuples whose third word is the
+delivery word; the test folds them back into the same dump using only what the Rust glue would
+hold (sub_id -> relation) and compares text for text.
+"""
+import random
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from rmqtt_amd import capi
+from tests.parity import make_backend, pack
+
+BACKENDS = ["emu", pytest.param("hip", marks=pytest.mark.gpu)]
+
+FILTERS = ["a/b", "a/+", "a/#", "#", "+/b", "a/b/c", "a/+/c", "+/+", "+/+/+", "$SYS/#", "$SYS/+", "+/#", "a/b/#", "x", "a//b", "/+", "a/b/+"]
+TOPICS = ["a/b", "a/b/c", "a/x", "x", "$SYS/y", "a", "a//b", "+/b", "a/+", "a/#/b", "", "/b", "a/b/c/d", "q/r/s"]
+
+
+class World:
+    """Same subscription table in the oracle and in a backend, plus the id maps the glue keeps."""
+
+    def __init__(self, kind, seed, **kw):
+        self.rng = random.Random(seed)
+        self.oracle = orc.DefaultRouter()
+        self.backend = make_backend(kind, **kw)
+        self.nodes = [1, 2, 7]
+        self.clients = [f"c{i}" for i in range(24)]
+        self.client_node = {c: self.rng.choice(self.nodes) for c in self.clients}
+        self.owner_ids = {}            # (node, client, create_time) -> dense owner id
+        self.client_idx = {}           # (node, client) -> dense client idx
+        self.rels = {}                 # sub_id -> dict(filter, client, node, ident)
+        self.sub_of = {}               # (filter, client) -> sub_id
+        self.fids, self.refs = {}, {}
+        self.next_sub = 0
+
+    def owner(self, node, client, ct):
+        return self.owner_ids.setdefault((node, client, ct), len(self.owner_ids))
+
+    def add(self, filt, client, ct, qos, v5, no_local, rap, ident, shared=False):
+        node = self.client_node[client]
+        o = self.oracle.add(filt, orc.mk_id(node, client, ct), orc.mk_opts(qos=qos, v5=v5, no_local=no_local, sub_ident=ident, rap=rap),
+                            rel_id=0)
+        assert o == 0
+        key = (filt, client)
+        if key not in self.sub_of:
+            self.sub_of[key] = self.next_sub
+            self.next_sub += 1
+            self.refs[filt] = self.refs.get(filt, 0) + 1
+        sid = self.sub_of[key]
+        fid = self.backend.filter_add(filt)
+        self.fids[filt] = fid
+        flags = (capi.RGR_SUB_V5 if v5 else 0) | (capi.RGR_SUB_NO_LOCAL if v5 and no_local else 0) | (capi.RGR_SUB_RAP if v5 and rap else 0)
+        cidx = self.client_idx.setdefault((node, client), len(self.client_idx))
+        self.backend.sub_add_ex(fid, sid, qos, flags, self.nodes.index(node), self.owner(node, client, ct), cidx)
+        self.rels[sid] = dict(filter=filt, client=client, node=node, ident=ident if v5 else 0, v5=v5)
+
+    def remove(self, filt, client, ct):
+        node = self.client_node[client]
+        rc = self.oracle.remove(filt, orc.mk_id(node, client, ct))
+        assert rc in (0, 1)
+        if rc != 0:
+            return False                  # stored Id differs (router.rs:460-467): nothing removed
+        sid = self.sub_of.pop((filt, client))
+        assert self.backend.sub_remove(self.fids[filt], sid) == 0
+        del self.rels[sid]
+        self.refs[filt] -= 1
+        if self.refs[filt] == 0:
+            assert self.backend.filter_remove(self.fids[filt]) == 0
+            del self.fids[filt], self.refs[filt]
+        return True
+
+    def random_sub(self):
+        r = self.rng
+        v5 = r.random() < 0.55
+        return dict(filt=r.choice(FILTERS), client=r.choice(self.clients), ct=r.choice([0, 0, 0, 5]), qos=r.randrange(3), v5=v5,
+                    no_local=v5 and r.random() < 0.4, rap=v5 and r.random() < 0.5, ident=r.randrange(1, 90) if v5 and r.random() < 0.6 else 0)
+
+    # ---- one batch of publishes through both sides
+    def check(self, n_pub=60):
+        r = self.rng
+        known = list(self.owner_ids)
+        pubs = []
+        for _ in range(n_pub):
+            topic = r.choice(TOPICS)
+            if known and r.random() < 0.7:
+                node, client, ct = r.choice(known)
+            else:
+                node, client, ct = r.choice(self.nodes), "stranger", 0
+            pubs.append((topic, node, client, ct, r.randrange(3), r.random() < 0.5))
+        blob, offs = pack([p[0] for p in pubs])
+        attrs = np.zeros(len(pubs), dtype=capi.PUBLISH_ATTR_DTYPE)
+        for i, (_, node, client, ct, q, ret) in enumerate(pubs):
+            attrs[i] = (self.owner_ids.get((node, client, ct), capi.ID_NONE), q | (4 if ret else 0))
+        self.backend.commit()
+        got = self.backend.match_batch_deliver(blob, offs, attrs)
+        plain = self.backend.match_batch(blob, offs)
+        assert np.array_equal(plain["hit_offsets"], got["hit_offsets"]) and np.array_equal(plain["tuples"]["sub_id"], got["tuples"]["sub_id"])
+        for i, (topic, node, client, ct, q, ret) in enumerate(pubs):
+            exp = self.oracle.forwards(orc.mk_id(node, client, ct), topic, q, ret)
+            lo, hi = int(got["hit_offsets"][i]), int(got["hit_offsets"][i + 1])
+            if exp is None:
+                assert got["status"][i] < 0 and lo == hi
+                continue
+            assert got["status"][i] == 0
+            assert self.fold(got["tuples"][lo:hi], i) == exp, (topic, client, ct)
+
+    def fold(self, tuples, topic_idx):
+        """Delivery words -> the oracle's dump format, as the glue would build its SubRelationsMap."""
+        per_node = {}
+        v5_rows = {}
+        for tp in tuples:
+            assert tp["topic_idx"] == topic_idx
+            w = int(tp["qos_flags"])
+            rel = self.rels[int(tp["sub_id"])]
+            assert self.nodes[w >> 16] == rel["node"]
+            assert bool((w >> 8) & capi.RGR_SUB_V5) == rel["v5"]
+            if w & capi.RGR_HIT_NO_LOCAL:
+                continue
+            rows = per_node.setdefault(rel["node"], [])
+            if not rel["v5"]:
+                assert not (w & (capi.RGR_HIT_V5_DUP | capi.RGR_HIT_RETAIN))
+                rows.append([rel["client"], rel["filter"], w & 3, 0, None])
+            elif w & capi.RGR_HIT_V5_DUP:
+                row = v5_rows[(rel["node"], rel["client"])]
+                if rel["ident"]:
+                    row[4] = (row[4] or []) + [rel["ident"]]
+            else:
+                assert (rel["node"], rel["client"]) not in v5_rows
+                row = [rel["client"], rel["filter"], w & 3, 1 if w & capi.RGR_HIT_RETAIN else 0, [rel["ident"]] if rel["ident"] else None]
+                v5_rows[(rel["node"], rel["client"])] = row
+                rows.append(row)
+        out = ""
+        for node in sorted(per_node):
+            if not per_node[node]:
+                continue
+            out += f"N {node}\n"
+            out += "".join(sorted(f"{c}\t{f}\t{q}\t{rt}\t{','.join(map(str, ids)) if ids else '-'}\n" for c, f, q, rt, ids in per_node[node]))
+        return out
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+@pytest.mark.parametrize("seed,kw", [(1, {}), (2, dict(window_hits=64, chunk_topics=16)), (3, dict(slot_cap=2, window_hits=1))])
+def test_delivery_stage_matches_oracle_forwards(kind, seed, kw):
+    w = World(kind, seed, **kw)
+    for _ in range(160):
+        w.add(**w.random_sub())
+    w.check()
+    # churn: re-subscribes (options replaced, possibly with a new Id), removals, new subscriptions;
+    # on the HIP backend these go through the incremental commit with the attribute runs
+    for rnd in range(4):
+        for _ in range(25):
+            if w.sub_of and w.rng.random() < 0.45:
+                filt, client = w.rng.choice(sorted(w.sub_of))
+                w.remove(filt, client, w.rng.choice([0, 0, 5]))
+            else:
+                w.add(**w.random_sub())
+        w.check(40)
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_v5_dedup_many_candidates(kind):
+    """One topic matched by many overlapping filters, every client v5 on all of them: a few
+    thousand dedup candidates in one window, first filter in TopicTree::matches order wins."""
+    w = World(kind, 9)
+    w.clients = [f"k{i}" for i in range(300)]
+    w.client_node = {c: w.nodes[i % 3] for i, c in enumerate(w.clients)}
+    filters = ["a/b/c", "a/b/+", "a/+/c", "+/b/c", "a/b/#", "a/#", "#", "+/+/+", "+/#"]
+    for i, c in enumerate(w.clients):
+        for j, f in enumerate(filters):
+            if (i + j) % 4 != 3:
+                w.add(f, c, 0, (i + j) % 3, True, (i % 5) == 0, (j % 2) == 0, (i * 9 + j) % 200)
+    w.check(8)
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_delivery_without_registered_ids(kind):
+    """Plain rgr_sub_add (no owner / client ids): qos downgrade and RAP still apply, No Local
+    and the v5 dedup cannot (nothing to compare) and every hit is delivered unflagged."""
+    b = make_backend(kind)
+    fid = b.filter_add("t/+")
+    b.sub_add(fid, 0, 2, 0)
+    b.sub_add(fid, 1, 1, capi.RGR_SUB_V5 | capi.RGR_SUB_RAP | capi.RGR_SUB_NO_LOCAL)
+    fid2 = b.filter_add("t/#")
+    b.sub_add(fid2, 2, 2, capi.RGR_SUB_V5)
+    b.commit()
+    blob, offs = pack(["t/x", "t/y"])
+    attrs = np.array([(capi.ID_NONE, 1 | 4), (5, 0)], dtype=capi.PUBLISH_ATTR_DTYPE)
+    got = b.match_batch_deliver(blob, offs, attrs)
+    words = {(int(t["topic_idx"]), int(t["sub_id"])): int(t["qos_flags"]) & 0xFF for t in got["tuples"]}
+    assert words == {(0, 2): 1, (0, 0): 1, (0, 1): 1 | capi.RGR_HIT_RETAIN, (1, 2): 0, (1, 0): 0, (1, 1): 0}

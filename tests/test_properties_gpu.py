@@ -172,3 +172,66 @@ def test_streamed_to_host_pass_equals_host_result():
         assert np.array_equal(got, ref["tuples"])
         assert ranges[0][0] == 0 and ranges[-1][1] == 20_000 and all(a[1] == b_[0] for a, b_ in zip(ranges, ranges[1:]))
     b.close(); r.close()
+
+
+def test_delivery_stage_properties_at_scale():
+    """Delivery stage at config-3 shape (scaled): size-independent properties of the delivery
+    words against a numpy restatement of the per-hit rules (deliver_word + first-per-client),
+    window by window — the oracle's forwards() pins the same rules at small sizes
+    (tests/test_deliver_parity.py)."""
+    cfg = 3
+    c = wl.CONFIGS[cfg]
+    s = min(SCALE, 0.1) * 0.3
+    n_sub, n_pub = int(c["n_sub"] * s), int(c["n_pub"] * s * 0.2)
+    blob, offs, client, qos = wl.gen_subs(n_sub, wl.SUB_SEED + cfg, c["p_plus"], c["p_hash"], c["p_sys"])
+    tb, to = wl.gen_topics(n_pub, wl.PUB_SEED + cfg, 0.01, c["p_blank"])
+    rng = np.random.default_rng(7)
+    v5 = rng.random(n_sub) < 0.3
+    flags = (v5 * capi.RGR_SUB_V5 | (v5 & (rng.random(n_sub) < 0.3)) * capi.RGR_SUB_NO_LOCAL |
+             (v5 & (rng.random(n_sub) < 0.5)) * capi.RGR_SUB_RAP).astype(np.uint8)
+    client = client.astype(np.uint32)
+    owner = client                                            # one Id per client
+    r = capi.Router(device=0, window_hits=1 << 24)
+    assert r.subscribe_bulk(blob, offs, None, qos, flags) == 0
+    r.sub_attrs_bulk(owner, client)
+    r.commit()
+    attrs = np.zeros(n_pub, dtype=capi.PUBLISH_ATTR_DTYPE)
+    attrs["from_id"] = rng.choice(client, size=n_pub)         # publishers are subscribers too: No Local fires
+    attrs["qos_retain"] = rng.integers(0, 8, size=n_pub) & 7
+    attrs["qos_retain"][attrs["qos_retain"] & 3 == 3] -= 1
+    batch = r.batch(tb, to)
+    plain = []
+    batch.begin()
+    while (w := batch.next_window()) is not None:
+        plain.append(batch.window_to_host(w)[0])
+    batch.set_publish_attrs(attrs)
+    batch.begin()
+    wi = n_dup = n_drop = 0
+    while (w := batch.next_window()) is not None:
+        tup, ho = batch.window_to_host(w)
+        p = plain[wi]; wi += 1
+        assert np.array_equal(tup["topic_idx"], p["topic_idx"]) and np.array_equal(tup["sub_id"], p["sub_id"])
+        sid, t = tup["sub_id"], tup["topic_idx"]
+        fl = flags[sid].astype(np.uint32)
+        pq = attrs["qos_retain"][t]
+        is5 = (fl & capi.RGR_SUB_V5) != 0
+        exp = (fl << 8) | np.minimum(qos[sid].astype(np.uint32), pq & 3)
+        exp |= np.where(is5 & ((fl & capi.RGR_SUB_RAP) != 0) & ((pq & 4) != 0), capi.RGR_HIT_RETAIN, 0).astype(np.uint32)
+        drop = is5 & ((fl & capi.RGR_SUB_NO_LOCAL) != 0) & (owner[sid] == attrs["from_id"][t])
+        exp |= np.where(drop, capi.RGR_HIT_NO_LOCAL, 0).astype(np.uint32)
+        cand = np.nonzero(is5 & ~drop)[0]
+        key = (t[cand].astype(np.uint64) << np.uint64(32)) | client[sid[cand]].astype(np.uint64)
+        _, first = np.unique(key, return_index=True)           # first occurrence per (topic, client) in position order
+        dup = np.ones(len(cand), dtype=bool); dup[first] = False
+        exp[cand[dup]] |= capi.RGR_HIT_V5_DUP
+        assert np.array_equal(tup["qos_flags"], exp)
+        n_dup += int(dup.sum()); n_drop += int(drop.sum())
+    assert wi == len(plain) and wi > 1
+    assert n_dup > 0 and n_drop > 0
+    st = r.stats()
+    assert st["dedup_candidates"] > 0 and st["dedup_launches"] > 0
+    # detaching the attributes restores the plain tuples
+    batch.set_publish_attrs(None)
+    batch.begin()
+    w = batch.next_window()
+    assert np.array_equal(batch.window_to_host(w)[0]["qos_flags"], plain[0]["qos_flags"])
