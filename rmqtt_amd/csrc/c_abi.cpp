@@ -143,7 +143,7 @@ struct rgr_batch {
     bool alt_out = false;                // next_window expands into out2 instead of out
     // delivery stage (rgr_batch_set_publish_attrs)
     bool deliver = false;
-    DevBuf d_pub, cand, cand_count, dedup_tab;
+    DevBuf d_pub, cand, cand_count, dedup_tab, topic_cand, cand_off, dedup_tmp;
     PinnedBuf h_cand_count;
     DevBuf rf_filter[2], rf_node[2], r_cnt, r_payload, r_ecnt, r_e0, r_e1, r_out_off, r_epos, r_big, r_end, r_depth;   // retain frontier rounds
     PinnedBuf h_hit_off, h_pair_base, h_scalars;
@@ -956,13 +956,20 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
                 da.attrs = b->epoch->view.attrs;
                 if (dedup) {
                     // every v5 subscription can be hit at most once per matched-filter occurrence of a topic
-                    const uint64_t bound = std::min<uint64_t>(nh, 2 * b->epoch->n_v5 * uint64_t(le - lc));
+                    const uint32_t nt = le - lc;
+                    const uint64_t bound = std::min<uint64_t>(nh, 2 * b->epoch->n_v5 * uint64_t(nt));
                     b->cand.ensure(std::max<uint64_t>(1, bound) * sizeof(Cand));
                     b->cand_count.ensure(4);
-                    b->h_cand_count.ensure(4);
+                    b->h_cand_count.ensure(8);
+                    b->topic_cand.ensure((size_t(nt) + 1) * 4);
+                    b->cand_off.ensure((size_t(nt) + 2) * 8);
+                    b->dedup_tmp.ensure((size_t(nt) / scan_block_topics() + 3) * 16);
                     RGR_HIP(hipMemsetAsync(b->cand_count.p, 0, 4, b->stream));
+                    RGR_HIP(hipMemsetAsync(b->topic_cand.p, 0, (size_t(nt) + 1) * 4, b->stream));
                     da.cand = b->cand.as<Cand>();
                     da.cand_count = b->cand_count.as<uint32_t>();
+                    da.topic_cand = b->topic_cand.as<uint32_t>();
+                    da.topic_lo = b->chunk_begin + lc;
                 }
             }
             sp = b->span_begin(kSpanExpand);
@@ -971,18 +978,21 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
             b->span_end(sp);
             b->local.expand_launches++;
             if (dedup) {
-                // the table is sized by the candidate count: one stream sync per window, only in this mode
-                RGR_HIP(hipMemcpyAsync(b->h_cand_count.p, b->cand_count.p, 4, hipMemcpyDeviceToHost, b->stream));
+                // the table is partitioned by topic and sized by the candidate counts: one stream sync per
+                // window, only in this mode
+                const uint32_t nt = le - lc;
+                sp = b->span_begin(kSpanDedup);
+                launch_scan_u32(b->topic_cand.as<uint32_t>(), b->cand_off.as<uint64_t>(), nt, b->dedup_tmp.as<uint64_t>(), b->stream);
+                b->span_end(sp);
+                RGR_HIP(hipMemcpyAsync(b->h_cand_count.p, b->cand_off.as<uint64_t>() + nt, 8, hipMemcpyDeviceToHost, b->stream));
                 RGR_HIP(hipStreamSynchronize(b->stream));
-                const uint32_t nc = *b->h_cand_count.as<uint32_t>();
+                const uint64_t nc = *b->h_cand_count.as<uint64_t>();
                 if (nc) {
-                    uint64_t capn = 1024;
-                    while (capn < 2 * uint64_t(nc)) capn <<= 1;
-                    b->dedup_tab.ensure(capn * 12);
+                    b->dedup_tab.ensure(2 * nc * 8);
                     sp = b->span_begin(kSpanDedup);
-                    RGR_HIP(hipMemsetAsync(b->dedup_tab.p, 0xFF, capn * 12, b->stream));
-                    launch_dedup(b->cand.as<Cand>(), nc, outbuf.as<Tuple>(), b->dedup_tab.as<unsigned long long>(),
-                                 reinterpret_cast<uint32_t*>(b->dedup_tab.as<unsigned long long>() + capn), capn, b->stream);
+                    RGR_HIP(hipMemsetAsync(b->dedup_tab.p, 0xFF, 2 * nc * 8, b->stream));
+                    launch_dedup(b->cand.as<Cand>(), uint32_t(nc), outbuf.as<Tuple>(), b->chunk_begin + lc, b->cand_off.as<uint64_t>(),
+                                 b->dedup_tab.as<unsigned long long>(), b->stream);
                     b->span_end(sp);
                     b->local.dedup_candidates += nc;
                     b->local.dedup_launches++;

@@ -547,6 +547,8 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* 
     __shared__ uint32_t s_src[kTile + 2];
     __shared__ uint32_t s_topic[kTile + 2];
     __shared__ uint32_t s_ncand, s_cbase;
+    __shared__ uint32_t s_pc[kDeliver ? kTile + 2 : 1];   // dedup candidates per staged pair
+    __shared__ uint8_t s_qr[kDeliver ? kTile + 2 : 1];    // publish qos | retain<<2 of the pair's topic
     if (kDeliver && threadIdx.x == 0) s_ncand = 0;
 
     const uint32_t tile = blockIdx.x;
@@ -555,7 +557,10 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* 
     const uint64_t a = pair_lo + tile_first[tile];
     const uint64_t b = (tile + 1 < ntiles) ? pair_lo + tile_first[tile + 1] + 1 : pair_hi;
     const uint32_t np = uint32_t(b - a);
-    for (uint32_t i = threadIdx.x; i < np; i += kExpandThreads) tile_pair_view(c, a, i, base, s_off[i], s_src[i], s_topic[i]);
+    for (uint32_t i = threadIdx.x; i < np; i += kExpandThreads) {
+        tile_pair_view(c, a, i, base, s_off[i], s_src[i], s_topic[i]);
+        if (kDeliver) { s_qr[i] = uint8_t(da.pub[s_topic[i]].qos_retain); s_pc[i] = 0; }
+    }
     __syncthreads();
     Tuple* o = out + (base - hit_lo);
     // three phases so that the 8 subscriber loads of a lane are all in flight before the first
@@ -563,6 +568,7 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* 
     // covers the whole tile), (2) 8-byte subscriber loads, (3) 12-byte tuple stores — a wave
     // stores 768 contiguous bytes per instruction.
     uint32_t topic[kExpandPerThread];
+    uint32_t pidx[kExpandPerThread];
     const SubEntry* src[kExpandPerThread];
 #pragma unroll
     for (int j = 0; j < kExpandPerThread; ++j) {
@@ -570,6 +576,7 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* 
         const bool live = pos < len;
         const uint32_t i = (np == 1 || !live) ? 0u : locate_pair([&](uint32_t m) { return s_off[m]; }, np, int32_t(pos));
         topic[j] = s_topic[i];
+        pidx[j] = i;
         // dead tail positions read (and discard) the tile's first entry: keeps the loads branch-free
         src[j] = subs + (uint64_t(s_src[i]) + (live ? uint32_t(int32_t(pos) - s_off[i]) : 0u));
     }
@@ -585,16 +592,26 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* 
             const uint32_t pos = uint32_t(j) * kExpandThreads + threadIdx.x;
             cslot[j] = kNone; cclient[j] = kNone;
             if (pos < len) {
-                const PublishAttr pa = da.pub[topic[j]];                 // shared by every hit of the topic: L1/L2 hits
+                const uint32_t fl = se[j].qos_flags >> 8;
+                PublishAttr pa{kNone, s_qr[pidx[j]]};
                 SubAttr at{kNone, kNone};
-                if (((se[j].qos_flags >> 8) & kSubV5) && da.attrs) at = da.attrs[src[j] - subs];   // v3 hits never need it
+                if ((fl & kSubV5) && da.attrs) {                         // v3 hits need neither
+                    at = da.attrs[src[j] - subs];
+                    if (fl & kSubNoLocal) pa.from_id = da.pub[topic[j]].from_id;
+                }
                 bool cand;
                 se[j].qos_flags = deliver_word(se[j].qos_flags, pa, at, cand);
-                if (cand && da.cand && at.client_idx != kNone) { cslot[j] = atomicAdd(&s_ncand, 1u); cclient[j] = at.client_idx; }
+                if (cand && da.cand && at.client_idx != kNone) {
+                    cslot[j] = atomicAdd(&s_ncand, 1u); cclient[j] = at.client_idx;
+                    atomicAdd(&s_pc[pidx[j]], 1u);
+                }
             }
         }
         __syncthreads();
         if (threadIdx.x == 0 && s_ncand) s_cbase = atomicAdd(da.cand_count, s_ncand);
+        if (s_ncand)
+            for (uint32_t i = threadIdx.x; i < np; i += kExpandThreads)
+                if (s_pc[i]) atomicAdd(&da.topic_cand[s_topic[i] - da.topic_lo], s_pc[i]);
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < kExpandPerThread; ++j)
@@ -625,27 +642,32 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* 
 // flags every candidate that is not that minimum.
 constexpr unsigned long long kDedupEmpty = ~0ull;
 __global__ __launch_bounds__(256) void dedup_insert_kernel(const Cand* __restrict__ cand, uint32_t n, const Tuple* __restrict__ tuples,
-                                                           unsigned long long* keys, uint32_t* vals, uint64_t mask) {
+                                                           uint32_t topic_lo, const uint64_t* __restrict__ cand_off,
+                                                           unsigned long long* table) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const Cand c = cand[i];
-    const unsigned long long key = (static_cast<unsigned long long>(tuples[c.pos].topic_idx) << 32) | c.client_idx;
-    for (uint64_t s = dedup_hash(key) & mask;; s = (s + 1) & mask) {
-        const unsigned long long prev = atomicCAS(&keys[s], kDedupEmpty, key);
-        if (prev == kDedupEmpty || prev == key) { atomicMin(&vals[s], c.pos); return; }
+    const uint32_t t = tuples[c.pos].topic_idx - topic_lo;
+    const uint64_t b = 2 * cand_off[t], len = 2 * (cand_off[t + 1] - cand_off[t]);
+    const unsigned long long mine = (static_cast<unsigned long long>(c.client_idx) << 32) | c.pos;
+    for (uint64_t s = dedup_slot(c.client_idx, len);; s = (s + 1 == len) ? 0 : s + 1) {
+        const unsigned long long prev = atomicCAS(&table[b + s], kDedupEmpty, mine);
+        if (prev == kDedupEmpty) return;
+        if (uint32_t(prev >> 32) == c.client_idx) { atomicMin(&table[b + s], mine); return; }   // same client: smaller position wins
     }
 }
 __global__ __launch_bounds__(256) void dedup_flag_kernel(const Cand* __restrict__ cand, uint32_t n, Tuple* __restrict__ tuples,
-                                                         const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                         uint64_t mask) {
+                                                         uint32_t topic_lo, const uint64_t* __restrict__ cand_off,
+                                                         const unsigned long long* __restrict__ table) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const Cand c = cand[i];
-    const unsigned long long key = (static_cast<unsigned long long>(tuples[c.pos].topic_idx) << 32) | c.client_idx;
-    for (uint64_t s = dedup_hash(key) & mask;; s = (s + 1) & mask) {
-        const unsigned long long k = keys[s];
-        if (k == key) { if (vals[s] != c.pos) tuples[c.pos].qos_flags |= kHitV5Dup; return; }
-        if (k == kDedupEmpty) return;   // unreachable: every candidate was inserted
+    const uint32_t t = tuples[c.pos].topic_idx - topic_lo;
+    const uint64_t b = 2 * cand_off[t], len = 2 * (cand_off[t + 1] - cand_off[t]);
+    for (uint64_t s = dedup_slot(c.client_idx, len);; s = (s + 1 == len) ? 0 : s + 1) {
+        const unsigned long long e = table[b + s];
+        if (uint32_t(e >> 32) == c.client_idx && e != kDedupEmpty) { if (uint32_t(e) != c.pos) tuples[c.pos].qos_flags |= kHitV5Dup; return; }
+        if (e == kDedupEmpty) return;   // unreachable: every candidate was inserted
     }
 }
 
@@ -753,11 +775,12 @@ void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, ui
     else expand_kernel<false><<<ntiles, kExpandThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, DeliverArgs{});
 }
 
-void launch_dedup(const Cand* cand, uint32_t n, Tuple* tuples, unsigned long long* keys, uint32_t* vals, uint64_t cap, void* stream) {
+void launch_dedup(const Cand* cand, uint32_t n, Tuple* tuples, uint32_t topic_lo, const uint64_t* cand_off, unsigned long long* table,
+                  void* stream) {
     if (!n) return;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    dedup_insert_kernel<<<(n + 255) / 256, 256, 0, s>>>(cand, n, tuples, keys, vals, cap - 1);
-    dedup_flag_kernel<<<(n + 255) / 256, 256, 0, s>>>(cand, n, tuples, keys, vals, cap - 1);
+    dedup_insert_kernel<<<(n + 255) / 256, 256, 0, s>>>(cand, n, tuples, topic_lo, cand_off, table);
+    dedup_flag_kernel<<<(n + 255) / 256, 256, 0, s>>>(cand, n, tuples, topic_lo, cand_off, table);
 }
 
 }  // namespace rgr

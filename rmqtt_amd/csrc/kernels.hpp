@@ -59,6 +59,8 @@ struct DeliverArgs {
     const SubAttr* attrs;        // parallel to TrieView::subs, may be null (no ids registered)
     Cand* cand;                  // dedup candidates of this window, unordered; null = none wanted
     uint32_t* cand_count;
+    uint32_t* topic_cand;        // [topics in window] candidates per topic (zeroed by the caller)
+    uint32_t topic_lo;           // first topic of the window (batch-global index)
 };
 
 // Level-string dictionary image (host: table.cpp StringDict; device: one copy per epoch).
@@ -194,9 +196,11 @@ void launch_tiles(const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint
 void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint64_t hit_hi,
                    const uint32_t* tile_first, Tuple* out, void* stream, const DeliverArgs* deliver = nullptr);
 // v5 per-client dedup over a window's candidates: first position per (topic, client) wins, every
-// other candidate gets kHitV5Dup.  keys/vals: open-addressed table of `cap` (power of two) slots,
-// pre-filled with 0xFF bytes.
-void launch_dedup(const Cand* cand, uint32_t n, Tuple* tuples, unsigned long long* keys, uint32_t* vals, uint64_t cap, void* stream);
+// other candidate gets kHitV5Dup.  `table` (pre-filled with 0xFF bytes) is partitioned by topic:
+// topic t of the window owns slots [2*cand_off[t], 2*cand_off[t+1]) — twice its candidate count
+// (cand_off = exclusive scan of DeliverArgs::topic_cand) — and a slot holds (client_idx << 32 | pos).
+void launch_dedup(const Cand* cand, uint32_t n, Tuple* tuples, uint32_t topic_lo, const uint64_t* cand_off, unsigned long long* table,
+                  void* stream);
 uint32_t expand_tile_hits();
 uint32_t scan_block_topics();
 

@@ -315,11 +315,13 @@ RGR_HD inline uint32_t deliver_word(uint32_t qos_flags, PublishAttr pa, SubAttr 
     return w;
 }
 
-RGR_HD inline uint64_t dedup_hash(uint64_t key) {
-    key ^= key >> 33; key *= 0xff51afd7ed558ccdull;
-    key ^= key >> 33; key *= 0xc4ceb9fe1a85ec53ull;
-    key ^= key >> 33;
-    return key;
+// Slot of `client` inside a topic's region of `len` (>= 2) dedup-table slots.
+RGR_HD inline uint64_t dedup_slot(uint32_t client, uint64_t len) {
+    uint64_t x = client;
+    x ^= x >> 16; x *= 0x7feb352dull; x &= 0xFFFFFFFFull;
+    x ^= x >> 15; x *= 0x846ca68bull; x &= 0xFFFFFFFFull;
+    x ^= x >> 16;
+    return len <= 0xFFFFFFFFull ? (x * len) >> 32 : x % len;
 }
 
 }  // namespace rgr

@@ -181,36 +181,54 @@ int32_t run_pipeline(Emu* e, uint32_t n, const std::vector<uint64_t>& tok_off, c
                         const uint64_t src = uint64_t(s_src[i]) + uint32_t(int32_t(pos) - s_off[i]);
                         SubEntry se = tv.subs[src];
                         if (pub) {   // expand_kernel<true>
+                            const uint32_t fl = se.qos_flags >> 8;
+                            PublishAttr pa{kNone, uint8_t(pub[s_topic[i]].qos_retain)};     // s_qr
                             SubAttr at{kNone, kNone};
-                            if (((se.qos_flags >> 8) & kSubV5) && tv.attrs) at = tv.attrs[src];
+                            if ((fl & kSubV5) && tv.attrs) {
+                                at = tv.attrs[src];
+                                if (fl & kSubNoLocal) pa.from_id = pub[s_topic[i]].from_id;
+                            }
                             bool is_cand;
-                            se.qos_flags = deliver_word(se.qos_flags, pub[s_topic[i]], at, is_cand);
+                            se.qos_flags = deliver_word(se.qos_flags, pa, at, is_cand);
                             if (is_cand && at.client_idx != kNone) cand.push_back(Cand{uint32_t(base - hit_lo) + pos, at.client_idx});
                         }
                         out[(base - hit_lo) + pos] = rgr_tuple{s_topic[i], se.sub_id, se.qos_flags};
                     }
                 }
-                if (!cand.empty()) {   // launch_dedup: the same open-addressed table, sequentially; candidates reversed
+                if (!cand.empty()) {   // launch_dedup: the same topic-partitioned table, sequentially; candidates reversed
                     std::reverse(cand.begin(), cand.end());          // (their order on the device is arbitrary)
-                    uint64_t cap = 1024;
-                    while (cap < 2 * cand.size()) cap <<= 1;
-                    std::vector<uint64_t> keys(cap, ~0ull);
-                    std::vector<uint32_t> vals(cap, 0xFFFFFFFFu);
-                    auto key_of = [&](const Cand& c) { return (uint64_t(out[c.pos].topic_idx) << 32) | c.client_idx; };
-                    for (const Cand& c : cand)
-                        for (uint64_t sl = dedup_hash(key_of(c)) & (cap - 1);; sl = (sl + 1) & (cap - 1))
-                            if (keys[sl] == ~0ull || keys[sl] == key_of(c)) { keys[sl] = key_of(c); vals[sl] = std::min(vals[sl], c.pos); break; }
-                    std::map<uint64_t, uint32_t> first;                // independent statement of types.rs:524-539
-                    for (const Cand& c : cand) { auto it = first.find(key_of(c)); if (it == first.end() || c.pos < it->second) first[key_of(c)] = c.pos; }
-                    for (const Cand& c : cand)
-                        for (uint64_t sl = dedup_hash(key_of(c)) & (cap - 1);; sl = (sl + 1) & (cap - 1)) {
-                            if (keys[sl] == key_of(c)) {
-                                if ((vals[sl] != c.pos) != (first[key_of(c)] != c.pos)) return RGR_ESTATE;
-                                if (vals[sl] != c.pos) out[c.pos].qos_flags |= kHitV5Dup;
-                                break;
-                            }
-                            if (keys[sl] == ~0ull) return RGR_ESTATE;
+                    const uint32_t topic_lo = begin + lc, nt = le - lc;
+                    std::vector<uint64_t> cand_off(size_t(nt) + 1, 0);
+                    for (const Cand& c : cand) cand_off[out[c.pos].topic_idx - topic_lo + 1]++;      // DeliverArgs::topic_cand + scan
+                    for (uint32_t t = 0; t < nt; ++t) cand_off[t + 1] += cand_off[t];
+                    std::vector<uint64_t> table(2 * cand.size(), ~0ull);
+                    auto region = [&](const Cand& c, uint64_t& b, uint64_t& len) {
+                        const uint32_t t = out[c.pos].topic_idx - topic_lo;
+                        b = 2 * cand_off[t]; len = 2 * (cand_off[t + 1] - cand_off[t]);
+                    };
+                    for (const Cand& c : cand) {                      // dedup_insert_kernel
+                        uint64_t b, len; region(c, b, len);
+                        const uint64_t mine = (uint64_t(c.client_idx) << 32) | c.pos;
+                        for (uint64_t sl = dedup_slot(c.client_idx, len);; sl = (sl + 1 == len) ? 0 : sl + 1) {
+                            uint64_t& e = table[b + sl];
+                            if (e == ~0ull) { e = mine; break; }
+                            if (uint32_t(e >> 32) == c.client_idx) { e = std::min(e, mine); break; }
                         }
+                    }
+                    std::map<uint64_t, uint32_t> first;                // independent statement of types.rs:524-539
+                    auto key_of = [&](const Cand& c) { return (uint64_t(out[c.pos].topic_idx) << 32) | c.client_idx; };
+                    for (const Cand& c : cand) { auto it = first.find(key_of(c)); if (it == first.end() || c.pos < it->second) first[key_of(c)] = c.pos; }
+                    for (const Cand& c : cand) {                      // dedup_flag_kernel
+                        uint64_t b, len; region(c, b, len);
+                        for (uint64_t sl = dedup_slot(c.client_idx, len);; sl = (sl + 1 == len) ? 0 : sl + 1) {
+                            const uint64_t e = table[b + sl];
+                            if (e == ~0ull) return RGR_ESTATE;
+                            if (uint32_t(e >> 32) != c.client_idx) continue;
+                            if ((uint32_t(e) != c.pos) != (first[key_of(c)] != c.pos)) return RGR_ESTATE;
+                            if (uint32_t(e) != c.pos) out[c.pos].qos_flags |= kHitV5Dup;
+                            break;
+                        }
+                    }
                 }
             }
             lc = le;
