@@ -585,8 +585,8 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* 
     for (int j = 0; j < kExpandPerThread; ++j) {
         se[j] = *src[j];
     }
+    uint32_t cslot[kDeliver ? kExpandPerThread : 1], cclient[kDeliver ? kExpandPerThread : 1];
     if (kDeliver) {
-        uint32_t cslot[kExpandPerThread], cclient[kExpandPerThread];
 #pragma unroll
         for (int j = 0; j < kExpandPerThread; ++j) {
             const uint32_t pos = uint32_t(j) * kExpandThreads + threadIdx.x;
@@ -607,16 +607,6 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* 
                 }
             }
         }
-        __syncthreads();
-        if (threadIdx.x == 0 && s_ncand) s_cbase = atomicAdd(da.cand_count, s_ncand);
-        if (s_ncand)
-            for (uint32_t i = threadIdx.x; i < np; i += kExpandThreads)
-                if (s_pc[i]) atomicAdd(&da.topic_cand[s_topic[i] - da.topic_lo], s_pc[i]);
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < kExpandPerThread; ++j)
-            if (cslot[j] != kNone)
-                da.cand[s_cbase + cslot[j]] = Cand{uint32_t(base - hit_lo) + uint32_t(j) * kExpandThreads + threadIdx.x, cclient[j]};
     }
 #pragma unroll
     for (int j = 0; j < kExpandPerThread; ++j) {
@@ -632,6 +622,20 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* 
             o[pos] = tp;
 #endif
         }
+    }
+    // candidate bookkeeping after the tuple stores are in flight; the whole part is skipped (block-
+    // uniformly) when the epoch holds no v5 subscription
+    if (kDeliver && da.cand) {
+        __syncthreads();
+        if (threadIdx.x == 0 && s_ncand) s_cbase = atomicAdd(da.cand_count, s_ncand);
+        if (s_ncand)
+            for (uint32_t i = threadIdx.x; i < np; i += kExpandThreads)
+                if (s_pc[i]) atomicAdd(&da.topic_cand[s_topic[i] - da.topic_lo], s_pc[i]);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < kExpandPerThread; ++j)
+            if (cslot[j] != kNone)
+                da.cand[s_cbase + cslot[j]] = Cand{uint32_t(base - hit_lo) + uint32_t(j) * kExpandThreads + threadIdx.x, cclient[j]};
     }
 }
 

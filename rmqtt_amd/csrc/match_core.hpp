@@ -185,14 +185,13 @@ RGR_HD inline RetainStep retain_step(const RetainView& rv, uint32_t node, uint32
                                      Probe probe, ProbeGc probe_gc) {
     RetainStep r{0, 0, kNone, kNone};
     if (d == L) { r.e0 = 2 * node; return r; }
-    if (tok == kTokHash) {                               // trailing '#'
-        const uint32_t c = probe(node, kTokHash);
-        if (c != kNone) {                                // a literal "#" level stored in the tree wins
-            if (node != 0) r.e0 = 2 * node;              // parent match of the node we stand on
-            r.e1 = 2 * c;
-        } else {
-            r.e0 = node == 0 ? 2 * rv.n_nodes : 2 * node + 1;
-        }
+    if (tok == kTokHash) {
+        // trailing '#': the node's own value ("parent match", retain.rs:476-481/494-499) + everything
+        // `node._matches(["#"])` yields (retain.rs:502-524).  The second run is laid out by
+        // RetainTable::compile, including the reference's exact-first rule (retain.rs:472): below a
+        // node that stores a literal "#" level only that child's value is visible.
+        if (node != 0) r.e0 = 2 * node;
+        r.e1 = node == 0 ? 2 * rv.n_nodes : 2 * node + 1;
         return r;
     }
     if (tok == kTokPlus) {

@@ -174,28 +174,79 @@ void RetainTable::compile(RetainImage& out) const {
     out.child_ids.clear();
     out.child_ids.reserve(N);
     out.vals.clear();
-    std::vector<uint32_t> val_rank(size_t(N) + 1, 0);
     for (uint32_t p = 0; p < N; ++p) {
         const uint32_t m = order[p];
         out.child_off[p] = uint32_t(out.child_ids.size());
         for (uint32_t k = cnt[m]; k < cnt[m + 1]; ++k) out.child_ids.push_back(pre[kids[k]]);
-        val_rank[p] = uint32_t(out.vals.size());
-        if (nodes_[m].value != kNone) out.vals.push_back(SubEntry{nodes_[m].value, 0});
     }
     out.child_off[N] = uint32_t(out.child_ids.size());
-    val_rank[N] = uint32_t(out.vals.size());
     out.root_nonmeta = 0;
     for (uint32_t k = cnt[0]; k < cnt[1]; ++k) out.root_nonmeta += !nodes_[kids[k]].meta;
+    // ---- value layout.  desc[2p] = p's own value; desc[2p+1] = H(p) = what `p._matches(["#"])`
+    // yields (retain.rs:502-524): every value below p — EXCEPT that a node y storing a literal "#"
+    // level (child c) answers through the exact-first branch (retain.rs:472-483): below y only c's
+    // own value is visible from y or from above.  Values are placed by a DFS that stops at such a
+    // y after placing y's and c's values; the rest of subtree(y) goes to a deferred area of its
+    // own (still contiguous for every start inside it).  With no literal "#" levels stored this is
+    // plain preorder.
+    std::vector<uint32_t> own_pos(total, 0), hp_b(total, 0), hp_e(total, 0);
+    auto hash_child = [&](uint32_t m) -> uint32_t {
+        for (uint32_t k = cnt[m]; k < cnt[m + 1]; ++k) if (nodes_[kids[k]].token == kTokHash) return kids[k];
+        return kNone;
+    };
+    auto place_value = [&](uint32_t m) { own_pos[m] = uint32_t(out.vals.size()); if (nodes_[m].value != kNone) out.vals.push_back(SubEntry{nodes_[m].value, 0}); };
+    std::vector<uint32_t> deferred;                       // barrier nodes whose hidden part is still to be placed
+    uint32_t first_meta_pos = kNone;
+    // DFS below `m` (its own value is already placed): fills hp_b/hp_e of m and of everything visited
+    auto place_below = [&](uint32_t m0) {
+        std::vector<std::pair<uint32_t, uint32_t>> st;   // (node, next child index)
+        auto enter = [&](uint32_t m) {
+            hp_b[m] = uint32_t(out.vals.size());
+            const uint32_t c = hash_child(m);
+            if (c != kNone) {                             // barrier: only c's own value is visible below m
+                place_value(c);
+                hp_e[m] = uint32_t(out.vals.size());
+                deferred.push_back(m);
+                return;
+            }
+            st.emplace_back(m, cnt[m]);
+        };
+        enter(m0);
+        while (!st.empty()) {
+            auto& top = st.back();
+            if (top.second < cnt[top.first + 1]) {
+                if (top.first == 0 && top.second == cnt[0] + out.root_nonmeta) first_meta_pos = uint32_t(out.vals.size());
+                const uint32_t k = kids[top.second++];
+                place_value(k);
+                enter(k);
+            } else {
+                hp_e[top.first] = uint32_t(out.vals.size());
+                st.pop_back();
+            }
+        }
+    };
+    place_value(0);
+    place_below(0);
+    const bool root_barrier = hash_child(0) != kNone;
+    if (first_meta_pos == kNone) first_meta_pos = hp_e[0];
+    const FilterDesc root_desc = root_barrier ? FilterDesc{hp_b[0], hp_e[0] - hp_b[0]} : FilterDesc{hp_b[0], first_meta_pos - hp_b[0]};
+    for (size_t di = 0; di < deferred.size(); ++di) {     // (grows while we iterate)
+        const uint32_t y = deferred[di], c = hash_child(y);
+        for (uint32_t k = cnt[y]; k < cnt[y + 1]; ++k) {
+            const uint32_t ch = kids[k];
+            if (ch != c) place_value(ch);                 // c's own value sits next to y's
+            place_below(ch);
+        }
+    }
     out.desc.assign(2 * size_t(N) + 1, FilterDesc{0, 0});
     for (uint32_t p = 0; p < N; ++p) {
-        const bool has = nodes_[order[p]].value != kNone;
-        out.desc[2 * size_t(p)] = FilterDesc{val_rank[p], has ? 1u : 0u};
-        out.desc[2 * size_t(p) + 1] = FilterDesc{val_rank[p], val_rank[sub_end[p]] - val_rank[p]};
+        const uint32_t m = order[p];
+        out.desc[2 * size_t(p)] = FilterDesc{own_pos[m], nodes_[m].value != kNone ? 1u : 0u};
+        out.desc[2 * size_t(p) + 1] = FilterDesc{hp_b[m], hp_e[m] - hp_b[m]};
     }
-    // everything outside the root's '$' subtrees: the non-meta children come first in preorder
-    uint32_t first_meta_pre = N;
-    if (out.root_nonmeta < cnt[1] - cnt[0]) first_meta_pre = pre[kids[cnt[0] + out.root_nonmeta]];
-    out.desc[2 * size_t(N)] = FilterDesc{0, val_rank[first_meta_pre]};
+    // root '#': everything outside the root's '$' subtrees (the non-meta children come first), or the
+    // literal "#" topic alone when one is stored
+    out.desc[2 * size_t(N)] = root_desc;
     // grandchild index: (grandparent g, literal token t) -> run of nodes x (preorder ascending)
     {
         struct Tri { uint32_t g, tok, x; };

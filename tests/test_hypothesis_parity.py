@@ -21,6 +21,22 @@ TOPIC = st.lists(LEVELS, min_size=1, max_size=6).map("/".join)
 @given(filters=st.lists(TOPIC, min_size=0, max_size=25), topics=st.lists(TOPIC, min_size=1, max_size=25),
        slot_cap=st.sampled_from([0, 1, 2]), window=st.sampled_from([0, 1, 7]), lds=st.sampled_from([0, 3, 2560]))
 def test_router_parity_property(filters, topics, slot_cap, window, lds):
+    _router_property(filters, topics, slot_cap, window, lds)
+
+
+WILD = st.lists(st.sampled_from(["a", "b", "+", "#", "$s", ""]), min_size=1, max_size=5).map("/".join)
+
+
+@settings(max_examples=500, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(filters=st.lists(WILD, min_size=0, max_size=30), topics=st.lists(WILD, min_size=1, max_size=25),
+       slot_cap=st.sampled_from([0, 1, 2]), window=st.sampled_from([0, 1, 7]), lds=st.sampled_from([0, 3, 2560]))
+def test_router_parity_property_wildcard_heavy(filters, topics, slot_cap, window, lds):
+    """Dense wildcard alphabet: overlapping filters, wildcard levels inside PUBLISH topics (the
+    double-visit quirk of trie.rs:327-375), '$' and blank levels in every position."""
+    _router_property(filters, topics, slot_cap, window, lds)
+
+
+def _router_property(filters, topics, slot_cap, window, lds):
     o = orc.DefaultRouter()
     e = emu.EmuRouter(slot_cap=slot_cap, window_hits=window, lds_window=lds, tile=4)
     sub = 0
@@ -50,6 +66,22 @@ def test_router_parity_property(filters, topics, slot_cap, window, lds):
 @given(topics=st.lists(TOPIC, min_size=0, max_size=25, unique=True), filters=st.lists(TOPIC, min_size=1, max_size=20),
        removes=st.lists(st.integers(0, 24), max_size=6))
 def test_retain_parity_property(topics, filters, removes):
+    _retain_property(topics, filters, removes)
+
+
+# a small alphabet dominated by wildcard levels: literal "+" / "#" levels stored in the tree and the
+# exact-first branch of retain.rs:472 (also inside the '#' recursion) come up in most examples
+WILD_TOPIC = st.lists(st.sampled_from(["a", "b", "+", "#", "$s", ""]), min_size=1, max_size=5).map("/".join)
+
+
+@settings(max_examples=500, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(topics=st.lists(WILD_TOPIC, min_size=0, max_size=30, unique=True), filters=st.lists(WILD_TOPIC, min_size=1, max_size=20),
+       removes=st.lists(st.integers(0, 29), max_size=6))
+def test_retain_parity_property_wildcard_heavy(topics, filters, removes):
+    _retain_property(topics, filters, removes)
+
+
+def _retain_property(topics, filters, removes):
     t = orc.RetainTree()
     e = emu.EmuRouter(window_hits=3, tile=4)
     for i, s in enumerate(topics):

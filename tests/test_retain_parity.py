@@ -83,6 +83,32 @@ def test_wildcard_levels_stored_in_tree(kind):
     check(b, t, ["x/+", "x/+/k", "x/#", "w/#", "w/+", "#", "+", "+/q", "+/#", "x/+/#"])
 
 
+def test_literal_hash_level_shadows_its_siblings_from_above(kind):
+    """retain.rs:472-483 is also hit *during* the '#' recursion (retain.rs:521 recurses with the same
+    path): a node storing a literal "#" level answers `["#"]` through the exact branch, so from that
+    node or from anywhere above it only the "#" child's value is visible below it — 'a/a' is NOT
+    returned for the filter '#' once 'a/#' is stored.  (Found by the hypothesis suite.)"""
+    b = make_backend(kind)
+    t = orc.RetainTree()
+    names = ["a/a", "a/#", "a", "a/b/c", "a/b/#", "a/b/d/e", "x/y", "x/y/z", "x/y/#", "x/q", "$SYS/u", "$SYS/#", "$SYS/u/v",
+             "m/n/o/p", "m/n/#", "m/n/o/#", "m/k"]
+    for i, s in enumerate(names):
+        assert b.retain_add(s, i) == 0
+        t.insert(s, i)
+    b.retain_commit()
+    filters = ["#", "a/#", "a/b/#", "a/b/d/#", "+/#", "a/+/#", "+/+/#", "x/#", "x/y/#", "x/+", "$SYS/#", "$SYS/+/#", "m/#", "m/n/#",
+               "m/n/o/#", "m/+/#", "+/n/#", "a/a", "a/b/c", "+/+", "a/+", "m/n/o/p"]
+    exp = check(b, t, filters)
+    assert exp[0] == sorted(names.index(s) for s in ["a", "a/#", "x/y", "x/q", "x/y/#", "m/k", "m/n/#"])   # hand-derived
+    # removing the literal "#" topics un-shadows their siblings
+    for s in ["a/#", "m/n/#"]:
+        assert b.retain_remove(s) == 0
+        t.remove(s)
+    b.retain_commit()
+    exp = check(b, t, filters)
+    assert names.index("a/a") in exp[0] and names.index("m/n/o/#") in exp[0] and names.index("m/n/o/p") not in exp[0]
+
+
 def test_wide_nodes_long_descriptor_lists(kind):
     """'+' over nodes with hundreds / thousands of children: big frontier expansions and
     descriptor lists far beyond 64 entries per filter (block-cooperative count/compact)."""
