@@ -143,7 +143,7 @@ struct rgr_batch {
     bool alt_out = false;                // next_window expands into out2 instead of out
     // delivery stage (rgr_batch_set_publish_attrs)
     bool deliver = false;
-    DevBuf d_pub, cand, cand_count, dedup_tab, topic_cand, cand_off, dedup_tmp;
+    DevBuf d_pub, pair_qr, cand, cand_count, dedup_tab, topic_cand, cand_off, dedup_tmp;
     PinnedBuf h_cand_count;
     DevBuf rf_filter[2], rf_node[2], r_cnt, r_payload, r_ecnt, r_e0, r_e1, r_out_off, r_epos, r_big, r_end, r_depth;   // retain frontier rounds
     PinnedBuf h_hit_off, h_pair_base, h_scalars;
@@ -359,6 +359,7 @@ ChunkArrays make_chunk_arrays(rgr_batch* b, uint32_t n) {
     c.pair_src = b->pair_src.as<uint32_t>();
     c.pair_topic = b->pair_topic.as<uint32_t>();
     c.pair_off = b->pair_off.as<uint64_t>();
+    if (b->deliver && !b->retain) { c.pub = b->d_pub.as<PublishAttr>(); c.pair_qr = b->pair_qr.as<uint8_t>(); }
     return c;
 }
 
@@ -497,6 +498,7 @@ void prepare_chunk(rgr_batch* b, uint32_t begin, bool walk_only) {
         b->pair_src.ensure(std::max<uint64_t>(1, P) * 4);
         b->pair_topic.ensure(std::max<uint64_t>(1, P) * 4);
         b->pair_off.ensure((P + 1) * 8);
+        if (b->deliver && !b->retain) b->pair_qr.ensure(std::max<uint64_t>(1, P));
         ca = make_chunk_arrays(b, n);
         sp = b->span_begin(kSpanScan);
         launch_compact(tv, ca, begin, b->stream);

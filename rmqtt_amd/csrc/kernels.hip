@@ -519,6 +519,7 @@ __global__ __launch_bounds__(256) void compact_big_kernel(TrieView tv, ChunkArra
                 const uint64_t p = p0 + pl + (xl - ml);
                 c.pair_src[p] = fd.begin;
                 c.pair_topic[p] = topic_base + t;
+                if (c.pair_qr) c.pair_qr[p] = uint8_t(c.pub[topic_base + t].qos_retain);
                 c.pair_off[p] = o0 + pc + (xc - mc);
             }
             p0 += tl; o0 += tc;
@@ -559,7 +560,7 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* 
     const uint32_t np = uint32_t(b - a);
     for (uint32_t i = threadIdx.x; i < np; i += kExpandThreads) {
         tile_pair_view(c, a, i, base, s_off[i], s_src[i], s_topic[i]);
-        if (kDeliver) { s_qr[i] = uint8_t(da.pub[s_topic[i]].qos_retain); s_pc[i] = 0; }
+        if (kDeliver) { s_qr[i] = c.pair_qr[a + i]; s_pc[i] = 0; }
     }
     __syncthreads();
     Tuple* o = out + (base - hit_lo);

@@ -158,6 +158,10 @@ struct ChunkArrays {
     uint32_t* pair_src;          // [P] subs[] index of the run
     uint32_t* pair_topic;        // [P] batch-global topic index
     uint64_t* pair_off;          // [P+1] chunk-local output offset of the run
+    // delivery stage only (null otherwise): publish qos|retain<<2 of the pair's topic, copied next to
+    // the pair at compaction so that the expansion's prologue has no dependent load for it
+    const PublishAttr* pub;      // [n_batch]
+    uint8_t* pair_qr;            // [P]
 };
 
 // incremental epoch update: patch `n` edge records / filter descriptors of a device image

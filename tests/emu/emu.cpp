@@ -139,6 +139,8 @@ int32_t run_pipeline(Emu* e, uint32_t n, const std::vector<uint64_t>& tok_off, c
         std::vector<uint32_t> pair_src(P + 1), pair_topic(P + 1);
         std::vector<uint64_t> pair_off(P + 2, ~0ull);
         ca.pair_src = pair_src.data(); ca.pair_topic = pair_topic.data(); ca.pair_off = pair_off.data();
+        std::vector<uint8_t> pair_qr(P + 1, 0xEE);
+        if (pub) { ca.pub = pub; ca.pair_qr = pair_qr.data(); }
         for (uint32_t t = 0; t < cn; ++t) compact_topic(tv, ca, begin, t);
         e->pairs += P;
         for (uint32_t t = 0; t < cn; ++t) {
@@ -182,7 +184,7 @@ int32_t run_pipeline(Emu* e, uint32_t n, const std::vector<uint64_t>& tok_off, c
                         SubEntry se = tv.subs[src];
                         if (pub) {   // expand_kernel<true>
                             const uint32_t fl = se.qos_flags >> 8;
-                            PublishAttr pa{kNone, uint8_t(pub[s_topic[i]].qos_retain)};     // s_qr
+                            PublishAttr pa{kNone, ca.pair_qr[a + i]};                       // s_qr
                             SubAttr at{kNone, kNone};
                             if ((fl & kSubV5) && tv.attrs) {
                                 at = tv.attrs[src];
