@@ -602,9 +602,30 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* 
                 }
                 bool cand;
                 se[j].qos_flags = deliver_word(se[j].qos_flags, pa, at, cand);
-                if (cand && da.cand && at.client_idx != kNone) {
-                    cslot[j] = atomicAdd(&s_ncand, 1u); cclient[j] = at.client_idx;
-                    atomicAdd(&s_pc[pidx[j]], 1u);
+                if (cand && da.cand && at.client_idx != kNone) cclient[j] = at.client_idx;
+            }
+        }
+        if (da.cand) {
+            // slots in the block's candidate list and per-pair counts, one LDS atomic per wave and
+            // per pair present in the wave instead of one per lane
+            const int lane = threadIdx.x & 63;
+#pragma unroll
+            for (int j = 0; j < kExpandPerThread; ++j) {
+                const bool is = cclient[j] != kNone;
+                const unsigned long long m = __ballot(is);
+                if (!m) continue;
+                const int leader = __ffsll(static_cast<long long>(m)) - 1;
+                uint32_t wbase = 0;
+                if (lane == leader) wbase = atomicAdd(&s_ncand, uint32_t(__popcll(m)));
+                wbase = __shfl(wbase, leader, 64);
+                if (is) cslot[j] = wbase + uint32_t(__popcll(m & ((1ull << lane) - 1ull)));
+                unsigned long long rest = m;
+                while (rest) {                                           // usually one or two pairs per wave
+                    const int l0 = __ffsll(static_cast<long long>(rest)) - 1;
+                    const uint32_t p0 = __shfl(pidx[j], l0, 64);
+                    const unsigned long long same = __ballot(is && pidx[j] == p0);
+                    if (lane == l0) atomicAdd(&s_pc[p0], uint32_t(__popcll(same)));
+                    rest &= ~same;
                 }
             }
         }
@@ -636,7 +657,8 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* 
 #pragma unroll
         for (int j = 0; j < kExpandPerThread; ++j)
             if (cslot[j] != kNone)
-                da.cand[s_cbase + cslot[j]] = Cand{uint32_t(base - hit_lo) + uint32_t(j) * kExpandThreads + threadIdx.x, cclient[j]};
+                da.cand[s_cbase + cslot[j]] = Cand{uint32_t(base - hit_lo) + uint32_t(j) * kExpandThreads + threadIdx.x, cclient[j],
+                                                   topic[j] - da.topic_lo};
     }
 }
 
@@ -649,10 +671,11 @@ constexpr unsigned long long kDedupEmpty = ~0ull;
 __global__ __launch_bounds__(256) void dedup_insert_kernel(const Cand* __restrict__ cand, uint32_t n, const Tuple* __restrict__ tuples,
                                                            uint32_t topic_lo, const uint64_t* __restrict__ cand_off,
                                                            unsigned long long* table) {
+    (void)tuples; (void)topic_lo;
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const Cand c = cand[i];
-    const uint32_t t = tuples[c.pos].topic_idx - topic_lo;
+    const uint32_t t = c.topic;
     const uint64_t b = 2 * cand_off[t], len = 2 * (cand_off[t + 1] - cand_off[t]);
     const unsigned long long mine = (static_cast<unsigned long long>(c.client_idx) << 32) | c.pos;
     for (uint64_t s = dedup_slot(c.client_idx, len);; s = (s + 1 == len) ? 0 : s + 1) {
@@ -667,7 +690,7 @@ __global__ __launch_bounds__(256) void dedup_flag_kernel(const Cand* __restrict_
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const Cand c = cand[i];
-    const uint32_t t = tuples[c.pos].topic_idx - topic_lo;
+    const uint32_t t = c.topic;
     const uint64_t b = 2 * cand_off[t], len = 2 * (cand_off[t + 1] - cand_off[t]);
     for (uint64_t s = dedup_slot(c.client_idx, len);; s = (s + 1 == len) ? 0 : s + 1) {
         const unsigned long long e = table[b + s];

@@ -192,7 +192,7 @@ int32_t run_pipeline(Emu* e, uint32_t n, const std::vector<uint64_t>& tok_off, c
                             }
                             bool is_cand;
                             se.qos_flags = deliver_word(se.qos_flags, pa, at, is_cand);
-                            if (is_cand && at.client_idx != kNone) cand.push_back(Cand{uint32_t(base - hit_lo) + pos, at.client_idx});
+                            if (is_cand && at.client_idx != kNone) cand.push_back(Cand{uint32_t(base - hit_lo) + pos, at.client_idx, s_topic[i] - (begin + lc)});
                         }
                         out[(base - hit_lo) + pos] = rgr_tuple{s_topic[i], se.sub_id, se.qos_flags};
                     }
@@ -201,11 +201,14 @@ int32_t run_pipeline(Emu* e, uint32_t n, const std::vector<uint64_t>& tok_off, c
                     std::reverse(cand.begin(), cand.end());          // (their order on the device is arbitrary)
                     const uint32_t topic_lo = begin + lc, nt = le - lc;
                     std::vector<uint64_t> cand_off(size_t(nt) + 1, 0);
-                    for (const Cand& c : cand) cand_off[out[c.pos].topic_idx - topic_lo + 1]++;      // DeliverArgs::topic_cand + scan
+                    for (const Cand& c : cand) {
+                        if (c.topic != out[c.pos].topic_idx - topic_lo) return RGR_ESTATE;
+                        cand_off[c.topic + 1]++;                      // DeliverArgs::topic_cand + scan
+                    }
                     for (uint32_t t = 0; t < nt; ++t) cand_off[t + 1] += cand_off[t];
                     std::vector<uint64_t> table(2 * cand.size(), ~0ull);
                     auto region = [&](const Cand& c, uint64_t& b, uint64_t& len) {
-                        const uint32_t t = out[c.pos].topic_idx - topic_lo;
+                        const uint32_t t = c.topic;
                         b = 2 * cand_off[t]; len = 2 * (cand_off[t + 1] - cand_off[t]);
                     };
                     for (const Cand& c : cand) {                      // dedup_insert_kernel
