@@ -8,6 +8,13 @@ pub const RGR_TOPIC_OK: i32 = 0;
 pub const RGR_SUB_V5: u8 = 1;
 pub const RGR_SUB_NO_LOCAL: u8 = 2;
 pub const RGR_SUB_SHARED: u8 = 4;
+pub const RGR_SUB_RAP: u8 = 8;
+// delivery word bits (rgr_tuple.qos_flags of batches that carry publish attributes)
+pub const RGR_HIT_QOS_MASK: u32 = 3;
+pub const RGR_HIT_RETAIN: u32 = 1 << 2;
+pub const RGR_HIT_NO_LOCAL: u32 = 1 << 3;
+pub const RGR_HIT_V5_DUP: u32 = 1 << 4;
+pub const RGR_ID_NONE: u32 = 0xFFFF_FFFF;
 
 #[repr(C)]
 pub struct rgr_handle { _p: [u8; 0] }
@@ -27,6 +34,9 @@ pub struct rgr_config {
 #[repr(C)]
 #[derive(Clone, Copy)]
 pub struct rgr_tuple { pub topic_idx: u32, pub sub_id: u32, pub qos_flags: u32 }
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct rgr_publish_attr { pub from_id: u32, pub qos_retain: u32 }
 
 #[repr(C)]
 pub struct rgr_result {
@@ -55,9 +65,13 @@ extern "C" {
     pub fn rgr_filter_add(h: *mut rgr_handle, filter: *const c_char, len: u32, filter_id: *mut u32) -> i32;
     pub fn rgr_filter_remove(h: *mut rgr_handle, filter_id: u32) -> i32;
     pub fn rgr_sub_add(h: *mut rgr_handle, filter_id: u32, sub_id: u32, qos: u8, flags: u8) -> i32;
+    pub fn rgr_sub_add_ex(h: *mut rgr_handle, filter_id: u32, sub_id: u32, qos: u8, flags: u8, node_idx: u16, owner_id: u32,
+                          client_idx: u32) -> i32;
     pub fn rgr_sub_remove(h: *mut rgr_handle, filter_id: u32, sub_id: u32) -> i32;
     pub fn rgr_commit(h: *mut rgr_handle) -> i32;
     pub fn rgr_match_batch(h: *mut rgr_handle, blob: *const u8, offsets: *const u64, n: u32, out: *mut rgr_result) -> i32;
+    pub fn rgr_match_batch_deliver(h: *mut rgr_handle, blob: *const u8, offsets: *const u64, n: u32, attrs: *const rgr_publish_attr,
+                                   out: *mut rgr_result) -> i32;
     pub fn rgr_result_free(r: *mut rgr_result);
     pub fn rgr_retain_topic_add(h: *mut rgr_handle, topic: *const c_char, len: u32, topic_id: u32) -> i32;
     pub fn rgr_retain_topic_remove(h: *mut rgr_handle, topic: *const c_char, len: u32) -> i32;
