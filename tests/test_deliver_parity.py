@@ -194,3 +194,43 @@ def test_delivery_without_registered_ids(kind):
     got = b.match_batch_deliver(blob, offs, attrs)
     words = {(int(t["topic_idx"]), int(t["sub_id"])): int(t["qos_flags"]) & 0xFF for t in got["tuples"]}
     assert words == {(0, 2): 1, (0, 0): 1, (0, 1): 1 | capi.RGR_HIT_RETAIN, (1, 2): 0, (1, 0): 0, (1, 1): 0}
+
+
+# ---- property-based: arbitrary small worlds through the emulator (CPU) --------------------------
+from hypothesis import HealthCheck, given, settings  # noqa: E402
+from hypothesis import strategies as st  # noqa: E402
+
+_LV = st.sampled_from(["a", "b", "+", "#", "$s", ""])
+_NAME = st.lists(_LV, min_size=1, max_size=4).map("/".join)
+_SUB = st.tuples(_NAME, st.integers(0, 5), st.sampled_from([0, 0, 9]), st.integers(0, 2), st.booleans(), st.booleans(), st.booleans(),
+                 st.integers(0, 3))
+_PUB = st.tuples(_NAME, st.integers(0, 6), st.sampled_from([0, 0, 9]), st.integers(0, 2), st.booleans())
+
+
+@settings(max_examples=300, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(subs=st.lists(_SUB, min_size=0, max_size=30), pubs=st.lists(_PUB, min_size=1, max_size=12),
+       window=st.sampled_from([0, 1, 5]), slot_cap=st.sampled_from([0, 1, 2]))
+def test_delivery_stage_property(subs, pubs, window, slot_cap):
+    w = World("emu", 0, window_hits=window, slot_cap=slot_cap, tile=4)
+    w.clients = [f"c{i}" for i in range(7)]
+    w.client_node = {c: w.nodes[i % 3] for i, c in enumerate(w.clients)}
+    for filt, ci, ct, qos, v5, nl, rap, ident in subs:
+        if orc.parse_topic(filt) is None:
+            continue
+        w.add(filt, w.clients[ci], ct, qos, v5, v5 and nl, v5 and rap, ident if v5 else 0)
+    blob, offs = pack([p[0] for p in pubs])
+    attrs = np.zeros(len(pubs), dtype=capi.PUBLISH_ATTR_DTYPE)
+    ids = []
+    for i, (_, ci, ct, q, ret) in enumerate(pubs):
+        client = w.clients[ci]
+        node = w.client_node[client]
+        ids.append((node, client, ct))
+        attrs[i] = (w.owner_ids.get((node, client, ct), capi.ID_NONE), q | (4 if ret else 0))
+    got = w.backend.match_batch_deliver(blob, offs, attrs)
+    for i, (topic, _, _, q, ret) in enumerate(pubs):
+        exp = w.oracle.forwards(orc.mk_id(*ids[i]), topic, q, ret)
+        lo, hi = int(got["hit_offsets"][i]), int(got["hit_offsets"][i + 1])
+        if exp is None:
+            assert got["status"][i] < 0 and lo == hi
+        else:
+            assert w.fold(got["tuples"][lo:hi], i) == exp, (topic, ids[i])
