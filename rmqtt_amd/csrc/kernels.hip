@@ -650,9 +650,14 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* 
     if (kDeliver && da.cand) {
         __syncthreads();
         if (threadIdx.x == 0 && s_ncand) s_cbase = atomicAdd(da.cand_count, s_ncand);
-        if (s_ncand)
-            for (uint32_t i = threadIdx.x; i < np; i += kExpandThreads)
-                if (s_pc[i]) atomicAdd(&da.topic_cand[s_topic[i] - da.topic_lo], s_pc[i]);
+        if (s_ncand)   // per-topic candidate counts: the tile's pairs of one topic are adjacent, their first pair's lane sums them
+            for (uint32_t i = threadIdx.x; i < np; i += kExpandThreads) {
+                const uint32_t tp = s_topic[i];
+                if (i != 0 && s_topic[i - 1] == tp) continue;
+                uint32_t sum = 0;
+                for (uint32_t k = i; k < np && s_topic[k] == tp; ++k) sum += s_pc[k];
+                if (sum) atomicAdd(&da.topic_cand[tp - da.topic_lo], sum);
+            }
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < kExpandPerThread; ++j)
