@@ -957,19 +957,19 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
                 da.pub = b->d_pub.as<PublishAttr>();
                 da.attrs = b->epoch->view.attrs;
                 if (dedup) {
-                    // every v5 subscription can be hit at most once per matched-filter occurrence of a topic
+                    // every tile owns a tile-sized slice of the candidate list (no global cursor): sized for the
+                    // worst case, touched only where candidates exist
                     const uint32_t nt = le - lc;
-                    const uint64_t bound = std::min<uint64_t>(nh, 2 * b->epoch->n_v5 * uint64_t(nt));
-                    b->cand.ensure(std::max<uint64_t>(1, bound) * sizeof(Cand));
-                    b->cand_count.ensure(4);
+                    const uint64_t ntl = (nh + T - 1) / T;
+                    b->cand.ensure(ntl * T * sizeof(Cand));
+                    b->cand_count.ensure(ntl * 4);                       // per-tile counts (every tile writes its own)
                     b->h_cand_count.ensure(8);
                     b->topic_cand.ensure((size_t(nt) + 1) * 4);
                     b->cand_off.ensure((size_t(nt) + 2) * 8);
                     b->dedup_tmp.ensure((size_t(nt) / scan_block_topics() + 3) * 16);
-                    RGR_HIP(hipMemsetAsync(b->cand_count.p, 0, 4, b->stream));
                     RGR_HIP(hipMemsetAsync(b->topic_cand.p, 0, (size_t(nt) + 1) * 4, b->stream));
                     da.cand = b->cand.as<Cand>();
-                    da.cand_count = b->cand_count.as<uint32_t>();
+                    da.tile_ncand = b->cand_count.as<uint32_t>();
                     da.topic_cand = b->topic_cand.as<uint32_t>();
                     da.topic_lo = b->chunk_begin + lc;
                 }
@@ -993,8 +993,8 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
                     b->dedup_tab.ensure(2 * nc * 8);
                     sp = b->span_begin(kSpanDedup);
                     RGR_HIP(hipMemsetAsync(b->dedup_tab.p, 0xFF, 2 * nc * 8, b->stream));
-                    launch_dedup(b->cand.as<Cand>(), uint32_t(nc), outbuf.as<Tuple>(), b->chunk_begin + lc, b->cand_off.as<uint64_t>(),
-                                 b->dedup_tab.as<unsigned long long>(), b->stream);
+                    launch_dedup(b->cand.as<Cand>(), b->cand_count.as<uint32_t>(), uint32_t((nh + T - 1) / T), outbuf.as<Tuple>(),
+                                 b->cand_off.as<uint64_t>(), b->dedup_tab.as<unsigned long long>(), b->stream);
                     b->span_end(sp);
                     b->local.dedup_candidates += nc;
                     b->local.dedup_launches++;

@@ -547,7 +547,7 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* 
     __shared__ int32_t s_off[kTile + 2];
     __shared__ uint32_t s_src[kTile + 2];
     __shared__ uint32_t s_topic[kTile + 2];
-    __shared__ uint32_t s_ncand, s_cbase;
+    __shared__ uint32_t s_ncand;
     __shared__ uint32_t s_pc[kDeliver ? kTile + 2 : 1];   // dedup candidates per staged pair
     __shared__ uint8_t s_qr[kDeliver ? kTile + 2 : 1];    // publish qos | retain<<2 of the pair's topic
     if (kDeliver && threadIdx.x == 0) s_ncand = 0;
@@ -649,7 +649,7 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* 
     // uniformly) when the epoch holds no v5 subscription
     if (kDeliver && da.cand) {
         __syncthreads();
-        if (threadIdx.x == 0 && s_ncand) s_cbase = atomicAdd(da.cand_count, s_ncand);
+        if (threadIdx.x == 0) da.tile_ncand[tile] = s_ncand;
         if (s_ncand)   // per-topic candidate counts: the tile's pairs of one topic are adjacent, their first pair's lane sums them
             for (uint32_t i = threadIdx.x; i < np; i += kExpandThreads) {
                 const uint32_t tp = s_topic[i];
@@ -658,12 +658,12 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* 
                 for (uint32_t k = i; k < np && s_topic[k] == tp; ++k) sum += s_pc[k];
                 if (sum) atomicAdd(&da.topic_cand[tp - da.topic_lo], sum);
             }
-        __syncthreads();
+        // the tile's candidates go to the tile's own slice of the list: no global cursor
+        Cand* mine = da.cand + uint64_t(tile) * kTile;
 #pragma unroll
         for (int j = 0; j < kExpandPerThread; ++j)
             if (cslot[j] != kNone)
-                da.cand[s_cbase + cslot[j]] = Cand{uint32_t(base - hit_lo) + uint32_t(j) * kExpandThreads + threadIdx.x, cclient[j],
-                                                   topic[j] - da.topic_lo};
+                mine[cslot[j]] = Cand{uint32_t(base - hit_lo) + uint32_t(j) * kExpandThreads + threadIdx.x, cclient[j], topic[j] - da.topic_lo};
     }
 }
 
@@ -673,34 +673,36 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* 
 // Pass 1 records the minimum position per (topic, client) in an open-addressed table, pass 2
 // flags every candidate that is not that minimum.
 constexpr unsigned long long kDedupEmpty = ~0ull;
-__global__ __launch_bounds__(256) void dedup_insert_kernel(const Cand* __restrict__ cand, uint32_t n, const Tuple* __restrict__ tuples,
-                                                           uint32_t topic_lo, const uint64_t* __restrict__ cand_off,
-                                                           unsigned long long* table) {
-    (void)tuples; (void)topic_lo;
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const Cand c = cand[i];
-    const uint32_t t = c.topic;
-    const uint64_t b = 2 * cand_off[t], len = 2 * (cand_off[t + 1] - cand_off[t]);
-    const unsigned long long mine = (static_cast<unsigned long long>(c.client_idx) << 32) | c.pos;
-    for (uint64_t s = dedup_slot(c.client_idx, len);; s = (s + 1 == len) ? 0 : s + 1) {
-        const unsigned long long prev = atomicCAS(&table[b + s], kDedupEmpty, mine);
-        if (prev == kDedupEmpty) return;
-        if (uint32_t(prev >> 32) == c.client_idx) { atomicMin(&table[b + s], mine); return; }   // same client: smaller position wins
+__global__ __launch_bounds__(256) void dedup_insert_kernel(const Cand* __restrict__ cand, const uint32_t* __restrict__ tile_ncand,
+                                                           const uint64_t* __restrict__ cand_off, unsigned long long* table) {
+    const uint32_t n = tile_ncand[blockIdx.x];
+    const Cand* mine_list = cand + uint64_t(blockIdx.x) * kTile;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const Cand c = mine_list[i];
+        const uint32_t t = c.topic;
+        const uint64_t b = 2 * cand_off[t], len = 2 * (cand_off[t + 1] - cand_off[t]);
+        const unsigned long long mine = (static_cast<unsigned long long>(c.client_idx) << 32) | c.pos;
+        for (uint64_t s = dedup_slot(c.client_idx, len);; s = (s + 1 == len) ? 0 : s + 1) {
+            const unsigned long long prev = atomicCAS(&table[b + s], kDedupEmpty, mine);
+            if (prev == kDedupEmpty) break;
+            if (uint32_t(prev >> 32) == c.client_idx) { atomicMin(&table[b + s], mine); break; }   // same client: smaller position wins
+        }
     }
 }
-__global__ __launch_bounds__(256) void dedup_flag_kernel(const Cand* __restrict__ cand, uint32_t n, Tuple* __restrict__ tuples,
-                                                         uint32_t topic_lo, const uint64_t* __restrict__ cand_off,
+__global__ __launch_bounds__(256) void dedup_flag_kernel(const Cand* __restrict__ cand, const uint32_t* __restrict__ tile_ncand,
+                                                         Tuple* __restrict__ tuples, const uint64_t* __restrict__ cand_off,
                                                          const unsigned long long* __restrict__ table) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const Cand c = cand[i];
-    const uint32_t t = c.topic;
-    const uint64_t b = 2 * cand_off[t], len = 2 * (cand_off[t + 1] - cand_off[t]);
-    for (uint64_t s = dedup_slot(c.client_idx, len);; s = (s + 1 == len) ? 0 : s + 1) {
-        const unsigned long long e = table[b + s];
-        if (uint32_t(e >> 32) == c.client_idx && e != kDedupEmpty) { if (uint32_t(e) != c.pos) tuples[c.pos].qos_flags |= kHitV5Dup; return; }
-        if (e == kDedupEmpty) return;   // unreachable: every candidate was inserted
+    const uint32_t n = tile_ncand[blockIdx.x];
+    const Cand* mine_list = cand + uint64_t(blockIdx.x) * kTile;
+    for (uint32_t i = threadIdx.x; i < n; i += 256) {
+        const Cand c = mine_list[i];
+        const uint32_t t = c.topic;
+        const uint64_t b = 2 * cand_off[t], len = 2 * (cand_off[t + 1] - cand_off[t]);
+        for (uint64_t s = dedup_slot(c.client_idx, len);; s = (s + 1 == len) ? 0 : s + 1) {
+            const unsigned long long e = table[b + s];
+            if (uint32_t(e >> 32) == c.client_idx && e != kDedupEmpty) { if (uint32_t(e) != c.pos) tuples[c.pos].qos_flags |= kHitV5Dup; break; }
+            if (e == kDedupEmpty) break;   // unreachable: every candidate was inserted
+        }
     }
 }
 
@@ -808,12 +810,12 @@ void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, ui
     else expand_kernel<false><<<ntiles, kExpandThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, DeliverArgs{});
 }
 
-void launch_dedup(const Cand* cand, uint32_t n, Tuple* tuples, uint32_t topic_lo, const uint64_t* cand_off, unsigned long long* table,
-                  void* stream) {
-    if (!n) return;
+void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, uint32_t ntiles, Tuple* tuples, const uint64_t* cand_off,
+                  unsigned long long* table, void* stream) {
+    if (!ntiles) return;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    dedup_insert_kernel<<<(n + 255) / 256, 256, 0, s>>>(cand, n, tuples, topic_lo, cand_off, table);
-    dedup_flag_kernel<<<(n + 255) / 256, 256, 0, s>>>(cand, n, tuples, topic_lo, cand_off, table);
+    dedup_insert_kernel<<<ntiles, 256, 0, s>>>(cand, tile_ncand, cand_off, table);
+    dedup_flag_kernel<<<ntiles, 256, 0, s>>>(cand, tile_ncand, tuples, cand_off, table);
 }
 
 }  // namespace rgr

@@ -57,8 +57,8 @@ constexpr uint32_t kHitRetain = 1u << 2, kHitNoLocal = 1u << 3, kHitV5Dup = 1u <
 struct DeliverArgs {
     const PublishAttr* pub;      // [n_batch]
     const SubAttr* attrs;        // parallel to TrieView::subs, may be null (no ids registered)
-    Cand* cand;                  // dedup candidates of this window, unordered; null = none wanted
-    uint32_t* cand_count;
+    Cand* cand;                  // dedup candidates of this window: tile i owns cand[i*tile_hits ..], null = none wanted
+    uint32_t* tile_ncand;        // [tiles] candidates each tile wrote
     uint32_t* topic_cand;        // [topics in window] candidates per topic (zeroed by the caller)
     uint32_t topic_lo;           // first topic of the window (batch-global index)
 };
@@ -203,8 +203,8 @@ void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, ui
 // other candidate gets kHitV5Dup.  `table` (pre-filled with 0xFF bytes) is partitioned by topic:
 // topic t of the window owns slots [2*cand_off[t], 2*cand_off[t+1]) — twice its candidate count
 // (cand_off = exclusive scan of DeliverArgs::topic_cand) — and a slot holds (client_idx << 32 | pos).
-void launch_dedup(const Cand* cand, uint32_t n, Tuple* tuples, uint32_t topic_lo, const uint64_t* cand_off, unsigned long long* table,
-                  void* stream);
+void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, uint32_t ntiles, Tuple* tuples, const uint64_t* cand_off,
+                  unsigned long long* table, void* stream);
 uint32_t expand_tile_hits();
 uint32_t scan_block_topics();
 
