@@ -215,6 +215,14 @@ int32_t rgr_sub_remove(rgr_handle* h, uint32_t filter_id, uint32_t sub_id);
 int32_t rgr_subscribe_bulk(rgr_handle* h, const uint8_t* blob, const uint64_t* offsets, uint64_t n,
                            const uint32_t* sub_ids, const uint8_t* qos, const uint8_t* flags,
                            uint32_t* filter_ids_out, uint64_t* n_rejected);
+/* Snapshot file of the compiled host table (dictionary, trie, edge table, subscriber runs,
+ * delivery attributes; flat arrays + checksum): a cold start becomes one read + one full
+ * upload instead of re-inserting every subscription as the reference's restore does
+ * (rmqtt-cluster-raft/src/router.rs:557-566).  filter_id / sub_id values are preserved.
+ * load replaces the host table (nothing changes on a failed load) and must be followed by
+ * rgr_commit; batches created earlier stay usable (they are re-tokenised). */
+int32_t rgr_snapshot_save(rgr_handle* h, const char* path);
+int32_t rgr_snapshot_load(rgr_handle* h, const char* path);
 /* Publish the current host table as a new immutable device epoch. */
 int32_t rgr_commit(rgr_handle* h);
 

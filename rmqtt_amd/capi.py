@@ -25,7 +25,7 @@ PUBLISH_ATTR_DTYPE = np.dtype([("from_id", np.uint32), ("qos_retain", np.uint32)
 SYMBOLS = [
     "rgr_create", "rgr_destroy", "rgr_last_error", "rgr_version",
     "rgr_filter_add", "rgr_filter_find", "rgr_filter_remove", "rgr_sub_add", "rgr_sub_add_ex", "rgr_sub_attrs_bulk",
-    "rgr_sub_remove", "rgr_subscribe_bulk", "rgr_commit",
+    "rgr_sub_remove", "rgr_subscribe_bulk", "rgr_snapshot_save", "rgr_snapshot_load", "rgr_commit",
     "rgr_match_batch", "rgr_match_batch_deliver", "rgr_result_free", "rgr_match_filters", "rgr_filters_result_free",
     "rgr_batch_create", "rgr_batch_destroy", "rgr_batch_status", "rgr_batch_set_publish_attrs",
     "rgr_batch_begin", "rgr_batch_next_window",
@@ -109,6 +109,8 @@ def lib():
         L.rgr_sub_remove.argtypes = [vp, u32, u32]
         L.rgr_subscribe_bulk.argtypes = [vp, vp, vp, u64, vp, vp, vp, vp, C.POINTER(u64)]
         L.rgr_commit.argtypes = [vp]
+        L.rgr_snapshot_save.argtypes = [vp, C.c_char_p]
+        L.rgr_snapshot_load.argtypes = [vp, C.c_char_p]
         L.rgr_match_batch.argtypes = [vp, vp, vp, u32, C.POINTER(Result)]
         L.rgr_result_free.argtypes = [C.POINTER(Result)]; L.rgr_result_free.restype = None
         L.rgr_match_filters.argtypes = [vp, vp, vp, u32, C.POINTER(FiltersResult)]
@@ -236,6 +238,13 @@ class Router:
 
     def commit(self):
         _check(lib().rgr_commit(self._h))
+
+    def snapshot_save(self, path):
+        _check(lib().rgr_snapshot_save(self._h, os.fsencode(path)))
+
+    def snapshot_load(self, path):
+        """Replace the host table by a snapshot file; raises RgrError (table untouched) on a bad file."""
+        _check(lib().rgr_snapshot_load(self._h, os.fsencode(path)))
 
     # ---- matching
     def match_batch(self, blob, offsets):

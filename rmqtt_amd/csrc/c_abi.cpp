@@ -53,7 +53,7 @@ struct DictImage {   // device copy of a StringDict for the device tokeniser
     DevBuf slots, entries, arena;
     DictView view{};
     uint64_t n_tokens = 0;
-    void upload(const StringDict& sd) {
+    void upload(const StringDict& sd, uint64_t stamp = ~0ull) {
         slots.ensure(sd.slots().size() * 4);
         entries.ensure(std::max<size_t>(1, sd.entries().size()) * sizeof(DictEntry));
         arena.ensure(std::max<size_t>(1, sd.arena().size()));
@@ -64,7 +64,7 @@ struct DictImage {   // device copy of a StringDict for the device tokeniser
         view.mask = sd.slots().size() - 1;
         view.entries = entries.as<DictEntry>();
         view.arena = arena.as<char>();
-        n_tokens = sd.size();
+        n_tokens = stamp == ~0ull ? sd.size() : stamp;     // identifies the dictionary a batch was tokenised against
     }
 };
 
@@ -269,7 +269,7 @@ void tokenize_batch(rgr_handle* h, rgr_batch* b, const uint8_t* blob, const uint
     b->total_tokens = total;
     {
         std::shared_lock<std::shared_mutex> lk(b->retain ? h->retain_mu : h->table_mu);
-        b->dict_tokens = b->retain ? h->retain_table.dict().size() : h->table.n_tokens();
+        b->dict_tokens = b->retain ? h->retain_table.dict().size() : h->table.dict_stamp();
     }
     b->local.tokenize_ms += now_ms() - t0;
     const double t1 = now_ms();
@@ -634,6 +634,32 @@ int32_t rgr_subscribe_bulk(rgr_handle* h, const uint8_t* blob, const uint64_t* o
     });
 }
 
+int32_t rgr_snapshot_save(rgr_handle* h, const char* path) {
+    return guarded([&]() -> int32_t {
+        if (!h || !path) return fail(RGR_EINVAL, "rgr_snapshot_save: bad argument");
+        std::shared_lock<std::shared_mutex> lk(h->table_mu);
+        std::string err;
+        if (!h->table.save(path, &err)) return fail(RGR_EINVAL, "rgr_snapshot_save: " + err);
+        return RGR_OK;
+    });
+}
+
+int32_t rgr_snapshot_load(rgr_handle* h, const char* path) {
+    return guarded([&]() -> int32_t {
+        if (!h || !path) return fail(RGR_EINVAL, "rgr_snapshot_load: bad argument");
+        std::lock_guard<std::mutex> cg(h->commit_mu);
+        std::unique_lock<std::shared_mutex> lk(h->table_mu);
+        std::string err;
+        if (!h->table.load(path, &err)) return fail(RGR_EINVAL, "rgr_snapshot_load: " + err);
+        // every device image is rebuilt by the next commit; epochs still pinned by passes keep theirs alive
+        for (int k = 0; k < 2; ++k) { h->edge_img[k].reset(); h->filt_img[k].reset(); }
+        h->sub_pool.reset();
+        h->host_desc.clear();
+        h->pool_garbage = 0;
+        return RGR_OK;
+    });
+}
+
 int32_t rgr_commit(rgr_handle* h) {
     return guarded([&]() -> int32_t {
         if (!h) return fail(RGR_EINVAL, "rgr_commit: bad argument");
@@ -647,8 +673,8 @@ int32_t rgr_commit(rgr_handle* h) {
             h->table.take_delta(delta);              // (mutators hold table_mu exclusively; this is the only reader of the delta)
             const auto& edges = h->table.edges();
             // ---- dictionary: append-only; re-uploaded only when it grew
-            if (prev && prev->dict && prev->dict->n_tokens == h->table.n_tokens()) ep->dict = prev->dict;
-            else { ep->dict = std::make_shared<DictImage>(); ep->dict->upload(h->table.dict()); }
+            if (prev && prev->dict && prev->dict->n_tokens == h->table.dict_stamp()) ep->dict = prev->dict;
+            else { ep->dict = std::make_shared<DictImage>(); ep->dict->upload(h->table.dict(), h->table.dict_stamp()); }
             // ---- every image accumulates the delta; the one not serving the current epoch is patched
             for (int k = 0; k < 2; ++k) {
                 if (!h->edge_img[k]) h->edge_img[k] = std::make_shared<EdgeImage>();

@@ -6,6 +6,8 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <new>
+#include <sys/mman.h>
 #include <thread>
 #include <unordered_set>
 
@@ -13,6 +15,32 @@
 #include "topic.hpp"
 
 namespace rgr {
+
+// ------------------------------------------------------------------ EdgeArray
+void EdgeArray::release() {
+    std::free(p_);
+    p_ = nullptr; n_ = 0;
+}
+
+void EdgeArray::assign(uint64_t n, const EdgeEntry& v) {
+    release();
+    if (!n) return;
+    void* mem = nullptr;
+    const size_t bytes = size_t(n) * sizeof(EdgeEntry);
+    if (posix_memalign(&mem, bytes >= (2u << 20) ? (2u << 20) : 64, bytes) != 0) throw std::bad_alloc();
+#ifdef MADV_HUGEPAGE
+    if (bytes >= (2u << 20)) (void)madvise(mem, bytes, MADV_HUGEPAGE);   // fewer first-touch faults
+#endif
+    p_ = static_cast<EdgeEntry*>(mem);
+    n_ = n;
+    unsigned nt = unsigned(std::min<uint64_t>(std::max(1u, std::thread::hardware_concurrency()), n / (1u << 20)));
+    if (nt <= 1) { std::fill(p_, p_ + n, v); return; }
+    nt = std::min(nt, 64u);
+    std::vector<std::thread> th;
+    for (unsigned k = 0; k < nt; ++k)
+        th.emplace_back([=] { std::fill(p_ + n * k / nt, p_ + n * (k + 1) / nt, v); });
+    for (auto& t : th) t.join();
+}
 
 // ------------------------------------------------------------------ StringDict
 StringDict::StringDict() : slots_(1024, 0), mask_(1023) {}
@@ -118,7 +146,7 @@ uint32_t HostTable::find_slot(uint32_t parent, uint32_t token) const {
 }
 
 void HostTable::rehash(uint64_t new_cap) {
-    std::vector<EdgeEntry> old;
+    EdgeArray old;
     old.swap(edges_);
     edges_.assign(new_cap, empty_edge());
     const uint32_t mask = uint32_t(new_cap - 1);
@@ -535,6 +563,179 @@ uint64_t HostTable::max_filter_subs() const {
     uint64_t m = 0;
     for (auto& f : filters_) m = std::max<uint64_t>(m, f.subs.size());
     return m;
+}
+
+// ------------------------------------------------------------------------------ snapshot file
+namespace {
+constexpr char kSnapMagic[8] = {'R', 'G', 'R', 'S', 'N', 'A', 'P', '1'};
+struct SnapWriter {
+    std::FILE* f;
+    uint64_t sum = 0xcbf29ce484222325ull;
+    bool ok = true;
+    void raw(const void* p, size_t n) {
+        if (!n) return;
+        const unsigned char* b = static_cast<const unsigned char*>(p);
+        // checksum: FNV-1a over 8-byte words (tail bytewise) — a corruption check, not a MAC
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8) { uint64_t w; std::memcpy(&w, b + i, 8); sum ^= w; sum *= 0x100000001b3ull; }
+        for (; i < n; ++i) { sum ^= b[i]; sum *= 0x100000001b3ull; }
+        if (ok && std::fwrite(p, 1, n, f) != n) ok = false;
+    }
+    template <class T> void pod(const T& v) { raw(&v, sizeof v); }
+    template <class T> void vec(const std::vector<T>& v) { const uint64_t n = v.size(); pod(n); raw(v.data(), n * sizeof(T)); }
+};
+struct SnapReader {
+    std::FILE* f;
+    uint64_t sum = 0xcbf29ce484222325ull, left;
+    bool raw(void* p, size_t n) {
+        if (!n) return true;
+        if (n > left || std::fread(p, 1, n, f) != n) return false;
+        left -= n;
+        const unsigned char* b = static_cast<const unsigned char*>(p);
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8) { uint64_t w; std::memcpy(&w, b + i, 8); sum ^= w; sum *= 0x100000001b3ull; }
+        for (; i < n; ++i) { sum ^= b[i]; sum *= 0x100000001b3ull; }
+        return true;
+    }
+    template <class T> bool pod(T& v) { return raw(&v, sizeof v); }
+    template <class T> bool vec(std::vector<T>& v) {
+        uint64_t n = 0;
+        if (!pod(n) || n > left / sizeof(T)) return false;      // a length that cannot fit in the file: corrupt
+        v.resize(n);
+        return raw(v.data(), n * sizeof(T));
+    }
+};
+struct SnapHeader {
+    char magic[8];
+    uint32_t version, edge_bytes, node_bytes, sub_bytes;
+    uint64_t n_filters, n_subs, n_nodes, n_v5, edge_used, edge_live;
+};
+}  // namespace
+
+bool HostTable::save(const std::string& path, std::string* err) const {
+    std::FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f) { if (err) *err = "cannot open " + path + " for writing"; return false; }
+    SnapWriter w{f};
+    SnapHeader h{};
+    std::memcpy(h.magic, kSnapMagic, 8);
+    h.version = 1; h.edge_bytes = sizeof(EdgeEntry); h.node_bytes = sizeof(Node); h.sub_bytes = sizeof(SubEntry);
+    h.n_filters = n_filters_; h.n_subs = n_subs_; h.n_nodes = n_nodes_; h.n_v5 = n_v5_; h.edge_used = edge_used_; h.edge_live = edge_live_;
+    w.pod(h);
+    dict_.save(w);
+    w.vec(nodes_); w.vec(free_nodes_);
+    {   // the edge table is mostly empty slots (load <= 0.25): only occupied slots (tombstones included) are stored
+        const uint64_t cap = edges_.size();
+        std::vector<uint32_t> idx;
+        std::vector<EdgeEntry> recs;
+        idx.reserve(edge_used_); recs.reserve(edge_used_);
+        for (uint64_t i = 0; i < cap; ++i)
+            if (edges_[i].parent != kEdgeEmpty) { idx.push_back(uint32_t(i)); recs.push_back(edges_[i]); }
+        w.pod(cap); w.vec(idx); w.vec(recs);
+    }
+    w.pod(root_hdr_);
+    std::vector<uint32_t> fnode(filters_.size());
+    std::vector<FilterDesc> fdesc;
+    std::vector<SubEntry> subs;
+    for (size_t i = 0; i < filters_.size(); ++i) fnode[i] = filters_[i].node;
+    flatten_filters(fdesc, subs);
+    w.vec(fnode); w.vec(fdesc); w.vec(subs); w.vec(free_fids_);
+    const uint8_t ha = has_attrs_ ? 1 : 0;
+    w.pod(ha);
+    w.vec(attrs_);
+    const uint64_t sum = w.sum;
+    if (w.ok && std::fwrite(&sum, 1, 8, f) != 8) w.ok = false;
+    if (std::fclose(f) != 0) w.ok = false;
+    if (!w.ok && err) *err = "write error on " + path;
+    return w.ok;
+}
+
+bool HostTable::load(const std::string& path, std::string* err) {
+    auto bad = [&](const char* what) { if (err) *err = path + ": " + what; return false; };
+    std::FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return bad("cannot open");
+    struct Closer { std::FILE* f; ~Closer() { std::fclose(f); } } closer{f};
+    if (std::fseek(f, 0, SEEK_END) != 0) return bad("cannot seek");
+    const long size = std::ftell(f);
+    if (size < long(sizeof(SnapHeader) + 8)) return bad("not a snapshot (too short)");
+    std::rewind(f);
+    SnapReader r{f};
+    r.left = uint64_t(size) - 8;
+    SnapHeader h{};
+    if (!r.pod(h) || std::memcmp(h.magic, kSnapMagic, 8) != 0) return bad("not a snapshot (bad magic)");
+    if (h.version != 1 || h.edge_bytes != sizeof(EdgeEntry) || h.node_bytes != sizeof(Node) || h.sub_bytes != sizeof(SubEntry))
+        return bad("snapshot of an incompatible build");
+    const bool prof = std::getenv("RGR_BULK_PROFILE") != nullptr;
+    auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = tnow();
+    auto lap = [&](const char* what) { if (prof) { const double tn = tnow(); std::fprintf(stderr, "[snapshot] %-12s %.3f s\n", what, tn - t_prev); t_prev = tn; } };
+    HostTable t;                                   // parsed on the side: *this is untouched unless everything checks out
+    std::vector<uint32_t> fnode;
+    std::vector<FilterDesc> fdesc;
+    std::vector<SubEntry> subs;
+    uint8_t ha = 0;
+    uint64_t ecap = 0;
+    std::vector<uint32_t> eidx;
+    std::vector<EdgeEntry> erecs;
+    if (!t.dict_.load(r) || !r.vec(t.nodes_) || !r.vec(t.free_nodes_) || !r.pod(ecap) || !r.vec(eidx) || !r.vec(erecs) || !r.pod(t.root_hdr_) || !r.vec(fnode) ||
+        !r.vec(fdesc) || !r.vec(subs) || !r.vec(t.free_fids_) || !r.pod(ha) || !r.vec(t.attrs_))
+        return bad("truncated or corrupt");
+    lap("read");
+    uint64_t sum = 0;
+    if (r.left != 0 || std::fread(&sum, 1, 8, f) != 8 || sum != r.sum) return bad("checksum mismatch");
+    if (ecap < 2 || ecap > (1ull << 32) || (ecap & (ecap - 1)) || eidx.size() != erecs.size() || eidx.size() > ecap) return bad("inconsistent edge table");
+    t.edges_.assign(ecap, empty_edge());
+    for (size_t i = 0; i < eidx.size(); ++i) {
+        if (eidx[i] >= ecap || (i && eidx[i] <= eidx[i - 1])) return bad("edge slots out of order");
+        t.edges_[eidx[i]] = erecs[i];
+    }
+    std::vector<uint32_t>().swap(eidx);
+    std::vector<EdgeEntry>().swap(erecs);
+    lap("edge table");
+    // structural checks: everything the kernels index with must be in range
+    if (t.edges_.size() < 2 || (t.edges_.size() & (t.edges_.size() - 1)) || t.nodes_.empty() || fdesc.size() != fnode.size())
+        return bad("inconsistent arrays");
+    const uint64_t nf = fnode.size();
+    for (const EdgeEntry& e : t.edges_) {
+        if (e.parent == kEdgeEmpty || e.parent == kEdgeTomb) continue;
+        if (e.parent >= t.nodes_.size() || e.child >= t.nodes_.size() || (e.plus_slot != kNone && e.plus_slot >= t.edges_.size()) ||
+            (e.hash_fid != kNone && e.hash_fid >= nf) || (e.term_fid != kNone && e.term_fid >= nf))
+            return bad("edge record out of range");
+    }
+    if ((t.root_hdr_.plus_slot != kNone && t.root_hdr_.plus_slot >= t.edges_.size()) || (t.root_hdr_.hash_fid != kNone && t.root_hdr_.hash_fid >= nf) ||
+        (t.root_hdr_.term_fid != kNone && t.root_hdr_.term_fid >= nf))
+        return bad("root header out of range");
+    for (const Node& nd : t.nodes_) {
+        auto in = [](uint32_t v, uint64_t lim) { return v == kNone || v < lim; };
+        if (!in(nd.parent, t.nodes_.size()) || !in(nd.slot, t.edges_.size()) || !in(nd.term_fid, nf) || !in(nd.plus_child, t.nodes_.size()) ||
+            !in(nd.hash_child, t.nodes_.size()))
+            return bad("trie node out of range");
+    }
+    for (uint32_t v : t.free_nodes_) if (v >= t.nodes_.size()) return bad("free list out of range");
+    for (uint32_t v : t.free_fids_) if (v >= nf) return bad("free list out of range");
+    uint64_t total = 0;
+    for (uint64_t i = 0; i < nf; ++i) {
+        if (fdesc[i].begin != total || uint64_t(fdesc[i].begin) + fdesc[i].count > subs.size()) return bad("subscriber runs out of range");
+        if (fnode[i] != kNone && fnode[i] >= t.nodes_.size()) return bad("filter node out of range");
+        total += fdesc[i].count;
+    }
+    if (total != subs.size() || total != h.n_subs) return bad("subscriber count mismatch");
+    lap("checks");
+    t.filters_.resize(nf);
+    for (uint64_t i = 0; i < nf; ++i) {
+        t.filters_[i].node = fnode[i];
+        t.filters_[i].subs.assign(subs.begin() + fdesc[i].begin, subs.begin() + fdesc[i].begin + fdesc[i].count);
+    }
+    t.n_filters_ = h.n_filters; t.n_subs_ = h.n_subs; t.n_nodes_ = h.n_nodes; t.n_v5_ = h.n_v5;
+    t.edge_used_ = h.edge_used; t.edge_live_ = h.edge_live;
+    t.has_attrs_ = ha != 0;
+    t.dict_gen_ = dict_gen_ + 1;
+    t.delta_ = Delta{};
+    t.delta_.relocated = true;                     // every device image must be rebuilt
+    t.attrs_all_dirty_ = true;
+    lap("filters");
+    *this = std::move(t);
+    lap("swap");
+    return true;
 }
 
 }  // namespace rgr

@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <string>
 #include <string_view>
+#include <utility>
 #include <vector>
 
 #include "kernels.hpp"
@@ -30,6 +31,17 @@ class StringDict {
     const std::vector<DictEntry>& entries() const { return entries_; }
     const std::vector<uint32_t>& slots() const { return slots_; }
 
+    // snapshot (table.cpp: SnapWriter / SnapReader)
+    template <class W> void save(W& w) const { w.vec(arena_); w.vec(entries_); w.vec(slots_); }
+    template <class R> bool load(R& r) {
+        if (!r.vec(arena_) || !r.vec(entries_) || !r.vec(slots_)) return false;
+        if (slots_.size() < 2 || (slots_.size() & (slots_.size() - 1))) return false;
+        for (uint32_t v : slots_) if (v > entries_.size()) return false;
+        for (const Entry& e : entries_) if (e.off > arena_.size() || e.len > arena_.size() - e.off) return false;
+        mask_ = slots_.size() - 1;
+        return true;
+    }
+
    private:
     using Entry = DictEntry;
     std::vector<char> arena_;
@@ -37,6 +49,35 @@ class StringDict {
     std::vector<uint32_t> slots_;      // token+1, 0 = empty
     uint64_t mask_;
     void grow();
+};
+
+// The open-addressed edge table: a flat array that is (re)filled in parallel — at 10 M
+// subscriptions it is 8 GiB of mostly empty slots and a single-threaded first touch of those
+// pages dominated both the bulk build and the snapshot load.
+class EdgeArray {
+   public:
+    EdgeArray() = default;
+    EdgeArray(const EdgeArray&) = delete;
+    EdgeArray& operator=(const EdgeArray&) = delete;
+    EdgeArray(EdgeArray&& o) noexcept : p_(o.p_), n_(o.n_) { o.p_ = nullptr; o.n_ = 0; }
+    EdgeArray& operator=(EdgeArray&& o) noexcept { if (this != &o) { release(); p_ = o.p_; n_ = o.n_; o.p_ = nullptr; o.n_ = 0; } return *this; }
+    ~EdgeArray() { release(); }
+    void assign(uint64_t n, const EdgeEntry& v);      // discard contents, n copies of v (parallel fill)
+    void swap(EdgeArray& o) noexcept { std::swap(p_, o.p_); std::swap(n_, o.n_); }
+    uint64_t size() const { return n_; }
+    const EdgeEntry* data() const { return p_; }
+    EdgeEntry* data() { return p_; }
+    const EdgeEntry& operator[](uint64_t i) const { return p_[i]; }
+    EdgeEntry& operator[](uint64_t i) { return p_[i]; }
+    const EdgeEntry* begin() const { return p_; }
+    const EdgeEntry* end() const { return p_ + n_; }
+    EdgeEntry* begin() { return p_; }
+    EdgeEntry* end() { return p_ + n_; }
+
+   private:
+    EdgeEntry* p_ = nullptr;
+    uint64_t n_ = 0;
+    void release();
 };
 
 class HostTable {
@@ -72,7 +113,7 @@ class HostTable {
                         const uint8_t* flags, uint32_t* fids_out, uint64_t* n_rejected, unsigned threads);
 
     // Flattened image for the device.
-    const std::vector<EdgeEntry>& edges() const { return edges_; }
+    const EdgeArray& edges() const { return edges_; }
     NodeHeader root_header() const { return root_hdr_; }
     void flatten_filters(std::vector<FilterDesc>& filt, std::vector<SubEntry>& subs) const;
     // Incremental commits: what changed since the last take_delta().
@@ -86,6 +127,17 @@ class HostTable {
     const std::vector<SubEntry>* filter_subs(uint32_t fid) const {
         return fid < filters_.size() && filters_[fid].node != kNone ? &filters_[fid].subs : nullptr;
     }
+
+    // Snapshot file (the format adjacent to the table).  The whole compiled host
+    // image — dictionary, trie nodes, edge table, filters, subscriber runs, delivery attributes — as
+    // flat arrays, so a cold start is a read + one full device upload instead of re-inserting every
+    // subscription (rmqtt-cluster-raft/src/router.rs:557-566 re-inserts one by one).  load() replaces
+    // the table; false + *err on I/O errors, a foreign / truncated / corrupt file (checksummed).
+    bool save(const std::string& path, std::string* err) const;
+    bool load(const std::string& path, std::string* err);
+    // distinguishes dictionaries of equal size across a load(): batches tokenised against an older
+    // dictionary are re-tokenised
+    uint64_t dict_stamp() const { return uint64_t(dict_.size()) | (dict_gen_ << 40); }
 
     uint64_t n_filters() const { return n_filters_; }
     uint64_t n_subs() const { return n_subs_; }
@@ -110,7 +162,7 @@ class HostTable {
     StringDict dict_;
     std::vector<Node> nodes_;
     std::vector<uint32_t> free_nodes_;
-    std::vector<EdgeEntry> edges_;
+    EdgeArray edges_;
     uint64_t edge_used_ = 0;               // live + tombstones
     uint64_t edge_live_ = 0;
     NodeHeader root_hdr_{kNone, kNone, kNone, 0, 0};
@@ -119,6 +171,7 @@ class HostTable {
     uint64_t n_filters_ = 0, n_subs_ = 0, n_nodes_ = 1, n_v5_ = 0;
     std::vector<SubAttr> attrs_;
     bool has_attrs_ = false, attrs_all_dirty_ = false;
+    uint64_t dict_gen_ = 0;
     Delta delta_;
     void touch(uint32_t slot) { delta_.slots.push_back(slot); }
 

@@ -67,6 +67,9 @@ uint64_t emu_visited(void* e) { return static_cast<Emu*>(e)->visited; }
 uint64_t emu_overflow_topics(void* e) { return static_cast<Emu*>(e)->overflow_topics; }
 uint64_t emu_windows(void* e) { return static_cast<Emu*>(e)->windows; }
 
+int32_t emu_snapshot_save(void* e, const char* path) { return static_cast<Emu*>(e)->table.save(path, nullptr) ? RGR_OK : RGR_EINVAL; }
+int32_t emu_snapshot_load(void* e, const char* path) { return static_cast<Emu*>(e)->table.load(path, nullptr) ? RGR_OK : RGR_EINVAL; }
+
 int32_t emu_subscribe_bulk(void* ev, const uint8_t* blob, const uint64_t* offs, uint64_t n, const uint32_t* sub_ids,
                            const uint8_t* qos, const uint8_t* flags, uint64_t* rejected) {
     auto* e = static_cast<Emu*>(ev);

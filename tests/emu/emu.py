@@ -38,6 +38,8 @@ def lib():
         L.emu_sub_add_ex.argtypes = [vp, u32, u32, u8, u8, C.c_uint16, u32, u32]
         L.emu_match_deliver.argtypes = [vp, vp, vp, u32, vp, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64), C.POINTER(vp), C.POINTER(vp)]
         L.emu_sub_remove.argtypes = [vp, u32, u32]
+        L.emu_snapshot_save.argtypes = [vp, C.c_char_p]
+        L.emu_snapshot_load.argtypes = [vp, C.c_char_p]
         for f in ("emu_n_nodes", "emu_n_filters", "emu_n_subs", "emu_visited", "emu_overflow_topics", "emu_windows"):
             getattr(L, f).argtypes = [vp]; getattr(L, f).restype = u64
         L.emu_subscribe_bulk.argtypes = [vp, vp, vp, u64, vp, vp, vp, C.POINTER(u64)]
@@ -114,6 +116,13 @@ class EmuRouter:
 
     def commit(self):
         pass
+
+    def snapshot_save(self, path):
+        assert lib().emu_snapshot_save(self._h, os.fsencode(path)) == 0
+
+    def snapshot_load(self, path):
+        if lib().emu_snapshot_load(self._h, os.fsencode(path)) != 0:
+            raise ValueError("bad snapshot")
 
     def _match(self, blob, offsets, publish_attrs=None):
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)

@@ -1,0 +1,104 @@
+"""Snapshot file of the compiled table: save -> load into a fresh table gives the
+same matches (bit-exact against the oracle), the table stays mutable afterwards, and foreign /
+truncated / bit-flipped files are rejected without touching the table."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from rmqtt_amd import capi
+from tests.parity import Pair, compare_flat, make_backend, pack, workload
+
+BACKENDS = ["emu", pytest.param("hip", marks=pytest.mark.gpu)]
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_snapshot_roundtrip_and_mutation_after_load(kind, tmp_path):
+    (blob, offs, client, qos), (tb, to) = workload(3, 20_000, 3_000)
+    a = Pair(kind)
+    a.add_bulk(blob, offs, client, qos)
+    exp, _ = a.check(tb, to, "before save")
+    path = str(tmp_path / "table.rgrsnap")
+    a.backend.snapshot_save(path)
+    assert os.path.getsize(path) > 100_000
+
+    b = make_backend(kind)
+    fid0 = b.filter_add("only/in/the/old/table")             # replaced wholesale by the load
+    b.sub_add(fid0, 7, 1)
+    b.commit()
+    b.snapshot_load(path)
+    b.commit()
+    compare_flat(b.match_batch(tb, to), exp, "after load")
+    assert b.filter_find("only/in/the/old/table") is None
+    # ids survive: the glue's filter_id / sub_id maps stay valid
+    some = orc.pack_strings([bytes(blob[int(offs[i]):int(offs[i + 1])]).decode() for i in (0, 17, 4242)])
+    for i in (0, 17, 4242):
+        f = bytes(blob[int(offs[i]):int(offs[i + 1])]).decode()
+        assert b.filter_find(f) == a.backend.filter_find(f)
+    # the loaded table is a normal table: mutate it on both sides and compare again
+    a.backend = b
+    a.fids = {}
+    a.refs = {}
+    a.add("sport/+/player1", "late-client", 5_000_000, qos=2)
+    a.add("#", "late-client", 5_000_001, qos=1)
+    a.commit()
+    tb2, to2 = pack(["sport/tennis/player1", "a/b", "$SYS/x"])
+    a.check(tb2, to2, "mutated after load")
+    a.check(tb, to, "mutated after load, seeded topics")
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_snapshot_keeps_delivery_attributes(kind, tmp_path):
+    b = make_backend(kind)
+    f1, f2 = b.filter_add("t/+"), b.filter_add("t/#")
+    b.sub_add_ex(f1, 0, 1, capi.RGR_SUB_V5 | capi.RGR_SUB_NO_LOCAL, 2, 11, 3)
+    b.sub_add_ex(f2, 1, 2, capi.RGR_SUB_V5, 2, 11, 3)
+    b.sub_add_ex(f2, 2, 0, 0, 1, 12, 4)
+    b.commit()
+    blob, offs = pack(["t/x", "t/y"])
+    attrs = np.array([(11, 2), (capi.ID_NONE, 1 | 4)], dtype=capi.PUBLISH_ATTR_DTYPE)
+    exp = b.match_batch_deliver(blob, offs, attrs)
+    path = str(tmp_path / "attrs.rgrsnap")
+    b.snapshot_save(path)
+    c = make_backend(kind)
+    c.snapshot_load(path)
+    c.commit()
+    got = c.match_batch_deliver(blob, offs, attrs)
+    assert np.array_equal(got["tuples"], exp["tuples"]) and np.array_equal(got["hit_offsets"], exp["hit_offsets"])
+    words = {(int(t["topic_idx"]), int(t["sub_id"])): int(t["qos_flags"]) for t in got["tuples"]}
+    assert words[(0, 0)] & capi.RGR_HIT_NO_LOCAL and words[(0, 1)] >> 16 == 2 and words[(1, 2)] >> 16 == 1
+    assert words[(1, 1)] & capi.RGR_HIT_V5_DUP or words[(1, 0)] & capi.RGR_HIT_V5_DUP      # same client on both filters
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_bad_snapshots_are_rejected_and_leave_the_table_alone(kind, tmp_path):
+    b = make_backend(kind)
+    fid = b.filter_add("keep/me")
+    b.sub_add(fid, 1, 1)
+    for i in range(300):
+        b.sub_add(b.filter_add(f"x/{i}/+"), 10 + i, i % 3)
+    b.commit()
+    good = str(tmp_path / "good.rgrsnap")
+    b.snapshot_save(good)
+    data = open(good, "rb").read()
+    cases = {"empty": b"", "garbage": b"not a snapshot at all" * 10, "truncated": data[:len(data) // 2], "short-tail": data[:-3],
+             "extra-tail": data + b"\0\0\0\0\0\0\0\0"}
+    for off in (40, len(data) // 3, len(data) - 20):                 # single bit flips: header, payload, near the checksum
+        d = bytearray(data); d[off] ^= 0x10
+        cases[f"flip@{off}"] = bytes(d)
+    blob, offs = pack(["keep/me", "x/5/y"])
+    before = b.match_batch(blob, offs)
+    for name, content in cases.items():
+        p = str(tmp_path / f"{name}.rgrsnap")
+        open(p, "wb").write(content)
+        with pytest.raises((capi.RgrError, ValueError)):
+            b.snapshot_load(p)
+        b.commit()
+        after = b.match_batch(blob, offs)
+        assert np.array_equal(after["tuples"], before["tuples"]), name
+    with pytest.raises((capi.RgrError, ValueError)):
+        b.snapshot_load(str(tmp_path / "does-not-exist"))
+    b.snapshot_load(good)                                            # and the good one still loads
+    b.commit()
+    assert np.array_equal(b.match_batch(blob, offs)["tuples"], before["tuples"])
