@@ -275,6 +275,13 @@ def main():
                "sample": f"first {n_s} publish topics of the same batch against the full {n_sub}-subscription table, "
                          f"{ost['hits']} hits, {sec:.2f}s wall",
                "hits_per_s": round(ost["hits"] / sec, 1)}
+        # SURVEY 8(d) also asks for the single-thread figure: a ~3 s prefix of the same sample on one core
+        if cores > 1:
+            n1 = max(20, min(n_s, int(n_s / cores * 0.15)))
+            s1b, s1o = shard.take(tb, to, np.arange(n1))
+            sec1, ost1 = o.match_timed(s1b, s1o, 1)
+            cpu["single_thread"] = {"value": round(n1 / sec1, 1), "hits_per_s": round(ost1["hits"] / sec1, 1),
+                                    "sample": f"first {n1} topics, {sec1:.2f}s wall"}
 
     out = {
         "metric": f"publish-topic matches/sec with delivery stage (config {cfg}, scale {args.scale}, v5 fraction {args.deliver})"
