@@ -179,6 +179,8 @@ def main():
             nwin += 1
         return hits, nwin
 
+    rank_hits = []          # per-rank hit counts of the last step (N>1, --gather counts): the shard imbalance
+
     def step():
         if world > 1 and args.gather == "tuples":
             return step_gather_tuples()
@@ -187,6 +189,7 @@ def main():
             cnt = torch.tensor([hits], dtype=torch.int64, device=cdev)
             allc = [torch.zeros_like(cnt) for _ in range(world)]
             dist.all_gather(allc, cnt)
+            rank_hits[:] = [int(x.item()) for x in allc]
         return hits, nwin
 
     for _ in range(args.warmup):
@@ -307,6 +310,12 @@ def main():
                   "hbm_bytes": int(st0["table_bytes_device"]), "host_build_s": round(build_s, 1)},
         "roofline": roofline, "cpu_baseline": cpu,
     }
+    try:
+        if world > 1 and rank_hits and sum(rank_hits) > 0:
+            out["shard_hits"] = rank_hits
+            out["shard_imbalance_max_over_mean"] = round(max(rank_hits) * len(rank_hits) / sum(rank_hits), 3)
+    except Exception as e:      # reporting only: never fail the bench line over it
+        log(f"shard imbalance not reported: {e}", 0)
     if args.deliver >= 0 and not retain and world == 1:
         out["delivery_stage"] = {"v5_fraction": args.deliver, "dedup_ms_per_step": round(st["dedup_ms"] / K, 3),
                                  "dedup_candidates_per_step": int(st["dedup_candidates"] / K),
