@@ -90,7 +90,7 @@ struct RetainEpoch {
     DevBuf edges, child_off, child_ids, desc, vals, gc_edges, gc_ids;
     RetainView view{};
     TrieView tv{};       // filt = run descriptors, subs = values: what count/compact/expand read
-    uint64_t id = 0, n_topics = 0, n_nodes = 0, bytes = 0;
+    uint64_t id = 0, n_topics = 0, n_nodes = 0, bytes = 0, table_version = 0;
 };
 
 enum SpanKind { kSpanWalk = 0, kSpanScan = 1, kSpanExpand = 2, kSpanDedup = 3 };

@@ -2,6 +2,9 @@
 #include "retain.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 #include "rmqtt_gpu_router.h"
 #include "topic.hpp"
@@ -92,6 +95,7 @@ int32_t RetainTable::topic_add(std::string_view topic, uint32_t topic_id) {
         cur = id;
     }
     if (nodes_[cur].value == kNone) n_values_++;
+    if (nodes_[cur].value != topic_id) version_++;   // re-publishing a retained topic under the same id changes nothing on the device
     nodes_[cur].value = topic_id;                    // value.replace(), retain.rs:384
     return RGR_OK;
 }
@@ -109,6 +113,7 @@ int32_t RetainTable::topic_remove(std::string_view topic) {
     if (nodes_[cur].value == kNone) return RGR_ENOENT;
     nodes_[cur].value = kNone;
     n_values_--;
+    version_++;
     while (cur != 0 && nodes_[cur].value == kNone && nodes_[cur].nchild == 0) {   // retain.rs:405-407
         const uint32_t p = nodes_[cur].parent;
         edges_[nodes_[cur].slot].parent = kEdgeTomb;
@@ -122,6 +127,10 @@ int32_t RetainTable::topic_remove(std::string_view topic) {
 }
 
 void RetainTable::compile(RetainImage& out) const {
+    const bool prof = std::getenv("RGR_BULK_PROFILE") != nullptr;
+    auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = tnow();
+    auto lap = [&](const char* what) { if (prof) { const double tn = tnow(); std::fprintf(stderr, "[retain.compile] %-12s %.3f s\n", what, tn - t_prev); t_prev = tn; } };
     const uint32_t total = uint32_t(nodes_.size());
     // children lists of the mutable ids (counting sort by parent), ordered by token; the
     // root's non-'$' children first (retain.rs:486-490, 505-509 skip '$' children at the root)
@@ -146,6 +155,7 @@ void RetainTable::compile(RetainImage& out) const {
         else
             std::sort(b, e, [&](uint32_t x, uint32_t y) { return nodes_[x].token < nodes_[y].token; });
     }
+    lap("children");
     // iterative DFS: preorder ids + subtree ends
     const uint32_t N = uint32_t(n_nodes_);
     std::vector<uint32_t> pre(total, kNone), order;   // order[preorder id] = mutable id
@@ -169,6 +179,7 @@ void RetainTable::compile(RetainImage& out) const {
             }
         }
     }
+    lap("preorder");
     out.n_nodes = N;
     out.child_off.assign(size_t(N) + 1, 0);
     out.child_ids.clear();
@@ -190,10 +201,13 @@ void RetainTable::compile(RetainImage& out) const {
     // own (still contiguous for every start inside it).  With no literal "#" levels stored this is
     // plain preorder.
     std::vector<uint32_t> own_pos(total, 0), hp_b(total, 0), hp_e(total, 0);
-    auto hash_child = [&](uint32_t m) -> uint32_t {
-        for (uint32_t k = cnt[m]; k < cnt[m + 1]; ++k) if (nodes_[kids[k]].token == kTokHash) return kids[k];
-        return kNone;
-    };
+    std::vector<uint32_t> hash_kid;                       // node -> its literal "#" child (rare: allocated on first use)
+    for (const REdge& e : edges_)
+        if (e.parent != kEdgeEmpty && e.parent != kEdgeTomb && e.token == kTokHash) {
+            if (hash_kid.empty()) hash_kid.assign(total, kNone);
+            hash_kid[e.parent] = e.child;
+        }
+    auto hash_child = [&](uint32_t m) -> uint32_t { return hash_kid.empty() ? kNone : hash_kid[m]; };
     auto place_value = [&](uint32_t m) { own_pos[m] = uint32_t(out.vals.size()); if (nodes_[m].value != kNone) out.vals.push_back(SubEntry{nodes_[m].value, 0}); };
     std::vector<uint32_t> deferred;                       // barrier nodes whose hidden part is still to be placed
     uint32_t first_meta_pos = kNone;
@@ -247,6 +261,7 @@ void RetainTable::compile(RetainImage& out) const {
     // root '#': everything outside the root's '$' subtrees (the non-meta children come first), or the
     // literal "#" topic alone when one is stored
     out.desc[2 * size_t(N)] = root_desc;
+    lap("values");
     // grandchild index: (grandparent g, literal token t) -> run of nodes x (preorder ascending)
     {
         struct Tri { uint32_t g, tok, x; };
@@ -260,11 +275,20 @@ void RetainTable::compile(RetainImage& out) const {
             if (g == 0 && nodes_[p].meta) continue;              // a '+' at the root skips '$' children (retain.rs:486-490)
             tri.push_back(Tri{pre[g], nx.token, pre[m]});
         }
-        std::sort(tri.begin(), tri.end(), [](const Tri& a, const Tri& b) {
-            if (a.g != b.g) return a.g < b.g;
-            if (a.tok != b.tok) return a.tok < b.tok;
-            return a.x < b.x;
-        });
+        {   // order by (g, tok, x): counting sort on the grandparent, then each (small) group by (tok, x)
+            std::vector<uint32_t> goff(size_t(N) + 1, 0);
+            for (const Tri& t : tri) goff[t.g + 1]++;
+            for (uint32_t i = 0; i < N; ++i) goff[i + 1] += goff[i];
+            std::vector<Tri> sorted(tri.size());
+            {
+                std::vector<uint32_t> pos(goff.begin(), goff.end() - 1);
+                for (const Tri& t : tri) sorted[pos[t.g]++] = t;
+            }
+            tri.swap(sorted);
+            for (uint32_t g = 0; g < N; ++g)
+                if (goff[g + 1] - goff[g] > 1)
+                    std::sort(tri.begin() + goff[g], tri.begin() + goff[g + 1], [](const Tri& a, const Tri& b) { return a.tok != b.tok ? a.tok < b.tok : a.x < b.x; });
+        }
         out.gc_ids.resize(tri.size());
         size_t runs = 0;
         for (size_t i = 0; i < tri.size(); ++i) { out.gc_ids[i] = tri[i].x; runs += i == 0 || tri[i].g != tri[i - 1].g || tri[i].tok != tri[i - 1].tok; }
@@ -281,6 +305,7 @@ void RetainTable::compile(RetainImage& out) const {
             i = j;
         }
     }
+    lap("gc index");
     // edge table over preorder ids
     uint64_t cap = 1024;
     while (cap < uint64_t(N) * 2) cap <<= 1;
@@ -293,6 +318,7 @@ void RetainTable::compile(RetainImage& out) const {
         while (out.edges[i].parent != kEdgeEmpty) i = (i + 1) & mask;
         out.edges[i] = REdge{pp, e.token, pc, 0};
     }
+    lap("edge table");
 }
 
 }  // namespace rgr

@@ -39,6 +39,8 @@ class RetainTable {
     const StringDict& dict() const { return dict_; }
     uint64_t n_topics() const { return n_values_; }
     uint64_t n_nodes() const { return n_nodes_; }
+    // bumped by every mutation that changes what compile() would emit
+    uint64_t version() const { return version_; }
 
    private:
     struct Node { uint32_t parent, token, slot, nchild, value; bool meta; };
@@ -46,7 +48,7 @@ class RetainTable {
     std::vector<Node> nodes_;
     std::vector<uint32_t> free_nodes_;
     std::vector<REdge> edges_;     // (parent,token)->child over the mutable node ids
-    uint64_t edge_used_ = 0, edge_live_ = 0, n_values_ = 0, n_nodes_ = 1;
+    uint64_t edge_used_ = 0, edge_live_ = 0, n_values_ = 0, n_nodes_ = 1, version_ = 1;
     uint32_t find(uint32_t parent, uint32_t token) const;
     uint32_t insert_edge(uint32_t parent, uint32_t token, uint32_t child);
     void rehash(uint64_t cap);
