@@ -181,6 +181,9 @@ typedef struct rgr_stats {
     /* delivery stage (batches with publish attributes): v5 per-client dedup */
     uint64_t dedup_candidates, dedup_launches;
     double dedup_ms;
+    /* retained-topic twin: id of the current retain epoch (0 = none; unchanged by a
+     * rgr_retain_commit that found nothing to do) and its topic count */
+    uint64_t retain_epoch, retain_topics;
 } rgr_stats;
 
 /* ---- lifecycle ----------------------------------------------------------------- */

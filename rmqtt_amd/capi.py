@@ -70,7 +70,7 @@ class Stats(C.Structure):
                 [(n, C.c_double) for n in ("walk_ms", "scan_ms", "expand_ms", "tokenize_ms", "h2d_ms", "d2h_ms")] +
                 [(n, C.c_uint64) for n in ("alg_bytes_walk", "alg_bytes_expand", "commits_full", "commits_delta",
                                            "dedup_candidates", "dedup_launches")] +
-                [("dedup_ms", C.c_double)])
+                [("dedup_ms", C.c_double), ("retain_epoch", C.c_uint64), ("retain_topics", C.c_uint64)])
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

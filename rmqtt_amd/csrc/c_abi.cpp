@@ -1311,6 +1311,11 @@ int32_t rgr_stats_get(rgr_handle* h, rgr_stats* out) {
         out->n_filters = ep->n_filters; out->n_subs = ep->n_subs; out->n_nodes = ep->n_nodes;
         out->n_edge_slots = ep->edge_slots; out->epoch = ep->id; out->table_bytes_device = ep->bytes;
         {
+            std::lock_guard<std::mutex> g(h->epoch_mu);
+            out->retain_epoch = h->retain_epoch ? h->retain_epoch->id : 0;
+            out->retain_topics = h->retain_epoch ? h->retain_epoch->n_topics : 0;
+        }
+        {
             std::lock_guard<std::mutex> cg(h->commit_mu);
             out->commits_full = h->commits_full; out->commits_delta = h->commits_delta;
         }

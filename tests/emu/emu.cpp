@@ -322,6 +322,7 @@ int32_t emu_match_deliver(void* ev, const uint8_t* blob, const uint64_t* offs, u
 // ---- RetainTree twin -----------------------------------------------------------------
 int32_t emu_retain_add(void* e, const char* t, uint32_t len, uint32_t id) { return static_cast<Emu*>(e)->retain.topic_add(std::string_view(t, len), id); }
 int32_t emu_retain_remove(void* e, const char* t, uint32_t len) { return static_cast<Emu*>(e)->retain.topic_remove(std::string_view(t, len)); }
+uint64_t emu_retain_version(void* e) { return static_cast<Emu*>(e)->retain.version(); }
 uint64_t emu_retain_topics(void* e) { return static_cast<Emu*>(e)->retain.n_topics(); }
 uint64_t emu_retain_nodes(void* e) { return static_cast<Emu*>(e)->retain.n_nodes(); }
 int32_t emu_retain_add_bulk(void* ev, const uint8_t* blob, const uint64_t* offs, uint64_t n, const uint32_t* ids, uint64_t* rejected) {

@@ -47,6 +47,7 @@ def lib():
         L.emu_retain_add.argtypes = [vp, C.c_char_p, u32, u32]
         L.emu_retain_remove.argtypes = [vp, C.c_char_p, u32]
         L.emu_retain_topics.argtypes = [vp]; L.emu_retain_topics.restype = u64
+        L.emu_retain_version.argtypes = [vp]; L.emu_retain_version.restype = u64
         L.emu_retain_nodes.argtypes = [vp]; L.emu_retain_nodes.restype = u64
         L.emu_retain_add_bulk.argtypes = [vp, vp, vp, u64, vp, C.POINTER(u64)]
         L.emu_retain_match.argtypes = [vp, vp, vp, u32, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
@@ -160,6 +161,9 @@ class EmuRouter:
     # ---- retain twin (same surface as capi.Router)
     def retain_add(self, topic, topic_id):
         t = _b(topic); return lib().emu_retain_add(self._h, t, len(t), topic_id)
+
+    def retain_version(self):
+        return int(lib().emu_retain_version(self._h))
 
     def retain_remove(self, topic):
         t = _b(topic); return lib().emu_retain_remove(self._h, t, len(t))

@@ -178,3 +178,40 @@ def test_seeded_config5_small(kind):
     assert np.array_equal(got["hit_offsets"], eo)
     assert per_filter(got) == [sorted(ev[int(a):int(b_)].tolist()) for a, b_ in zip(eo[:-1], eo[1:])]
     assert eo[-1] > 10_000
+
+
+def test_table_version_tracks_effective_changes_only():
+    """rgr_retain_commit skips the recompile when RetainTable::version() did not move: re-publishing
+    a retained topic under its id is not a change; a new id, a new topic or a removal is."""
+    from tests.emu import emu
+    e = emu.EmuRouter()
+    v0 = e.retain_version()
+    assert e.retain_add("a/b", 1) == 0
+    v1 = e.retain_version()
+    assert v1 != v0
+    assert e.retain_add("a/b", 1) == 0 and e.retain_version() == v1          # same topic, same id
+    assert e.retain_add("a/#/b", 2) != 0 and e.retain_version() == v1        # rejected name
+    assert e.retain_add("a/b", 5) == 0 and e.retain_version() != v1          # value replaced (retain.rs:384)
+    v2 = e.retain_version()
+    assert e.retain_remove("nope") != 0 and e.retain_version() == v2
+    assert e.retain_remove("a/b") == 0 and e.retain_version() != v2
+
+
+@pytest.mark.gpu
+def test_commit_without_changes_keeps_the_epoch():
+    from rmqtt_amd import capi
+    r = capi.Router(device=0)
+    assert r.retain_add("s/t", 3) == 0 and r.retain_add("s/u", 4) == 0
+    r.retain_commit()
+    e1 = r.stats()["retain_epoch"]
+    assert e1 != 0 and r.stats()["retain_topics"] == 2
+    r.retain_commit()                                        # nothing changed
+    assert r.retain_add("s/t", 3) == 0                       # retained message re-published, same id
+    r.retain_commit()
+    assert r.stats()["retain_epoch"] == e1
+    got = r.retain_match_batch(*pack(["s/+"]))
+    assert sorted(got["topic_ids"].tolist()) == [3, 4]
+    assert r.retain_add("s/v", 9) == 0
+    r.retain_commit()
+    assert r.stats()["retain_epoch"] != e1 and r.stats()["retain_topics"] == 3
+    assert sorted(r.retain_match_batch(*pack(["s/+"]))["topic_ids"].tolist()) == [3, 4, 9]
