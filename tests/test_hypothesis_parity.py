@@ -17,7 +17,7 @@ LEVELS = st.sampled_from(["a", "b", "", "$", "$SYS", "é", "日本", "a b", "A",
 TOPIC = st.lists(LEVELS, min_size=1, max_size=6).map("/".join)
 
 
-@settings(max_examples=600, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@settings(max_examples=600, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.too_slow])
 @given(filters=st.lists(TOPIC, min_size=0, max_size=25), topics=st.lists(TOPIC, min_size=1, max_size=25),
        slot_cap=st.sampled_from([0, 1, 2]), window=st.sampled_from([0, 1, 7]), lds=st.sampled_from([0, 3, 2560]))
 def test_router_parity_property(filters, topics, slot_cap, window, lds):
@@ -27,7 +27,7 @@ def test_router_parity_property(filters, topics, slot_cap, window, lds):
 WILD = st.lists(st.sampled_from(["a", "b", "+", "#", "$s", ""]), min_size=1, max_size=5).map("/".join)
 
 
-@settings(max_examples=500, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@settings(max_examples=500, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.too_slow])
 @given(filters=st.lists(WILD, min_size=0, max_size=30), topics=st.lists(WILD, min_size=1, max_size=25),
        slot_cap=st.sampled_from([0, 1, 2]), window=st.sampled_from([0, 1, 7]), lds=st.sampled_from([0, 3, 2560]))
 def test_router_parity_property_wildcard_heavy(filters, topics, slot_cap, window, lds):
@@ -62,7 +62,7 @@ def _router_property(filters, topics, slot_cap, window, lds):
         assert ids == sorted(i for i, f in valid_filters if brute.filter_matches(f, t)), (t, filters)
 
 
-@settings(max_examples=600, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@settings(max_examples=600, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.too_slow])
 @given(topics=st.lists(TOPIC, min_size=0, max_size=25, unique=True), filters=st.lists(TOPIC, min_size=1, max_size=20),
        removes=st.lists(st.integers(0, 24), max_size=6))
 def test_retain_parity_property(topics, filters, removes):
@@ -74,7 +74,7 @@ def test_retain_parity_property(topics, filters, removes):
 WILD_TOPIC = st.lists(st.sampled_from(["a", "b", "+", "#", "$s", ""]), min_size=1, max_size=5).map("/".join)
 
 
-@settings(max_examples=500, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@settings(max_examples=500, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.too_slow])
 @given(topics=st.lists(WILD_TOPIC, min_size=0, max_size=30, unique=True), filters=st.lists(WILD_TOPIC, min_size=1, max_size=20),
        removes=st.lists(st.integers(0, 29), max_size=6))
 def test_retain_parity_property_wildcard_heavy(topics, filters, removes):
@@ -102,7 +102,7 @@ def _retain_property(topics, filters, removes):
 
 
 @pytest.mark.gpu
-@settings(max_examples=80, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@settings(max_examples=80, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.too_slow])
 @given(filters=st.lists(TOPIC, min_size=0, max_size=25), topics=st.lists(TOPIC, min_size=1, max_size=25),
        retained=st.lists(TOPIC, min_size=0, max_size=20, unique=True), slot_cap=st.sampled_from([0, 1, 2]))
 def test_hip_parity_property(filters, topics, retained, slot_cap):
