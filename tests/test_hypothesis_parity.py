@@ -134,3 +134,47 @@ def test_hip_parity_property(filters, topics, retained, slot_cap):
     for a, b_ in zip(eo[:-1], eo[1:]):
         assert sorted(got["topic_ids"][int(a):int(b_)].tolist()) == sorted(ev[int(a):int(b_)].tolist())
     r.close()
+
+
+_OP = st.tuples(st.booleans(), WILD, st.integers(0, 5))
+
+
+@settings(max_examples=400, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.too_slow])
+@given(ops=st.lists(_OP, min_size=1, max_size=60), topics=st.lists(WILD, min_size=1, max_size=20), slot_cap=st.sampled_from([0, 1, 2]))
+def test_router_churn_property(ops, topics, slot_cap):
+    _router_churn(ops, topics, slot_cap)
+
+
+def _router_churn(ops, topics, slot_cap):
+    """Arbitrary interleavings of subscribe / unsubscribe (trie insert, remove + prune, tombstones,
+    filter-id and node reuse) and then a match: trie.rs:113-149, router.rs:434-496."""
+    o = orc.DefaultRouter()
+    e = emu.EmuRouter(slot_cap=slot_cap, window_hits=3, tile=4)
+    subs, fids, refs = {}, {}, {}
+    nxt = 0
+    for add, f, ci in ops:
+        client = f"c{ci}"
+        if add:
+            if (f, client) in subs:
+                continue
+            ok = o.add(f, orc.mk_id(1, client), orc.mk_opts(qos=ci % 3), rel_id=nxt) == 0
+            if not ok:
+                with pytest.raises(ValueError):
+                    e.filter_add(f)
+                continue
+            fid = e.filter_add(f)
+            e.sub_add(fid, nxt, ci % 3)
+            subs[(f, client)] = nxt
+            fids[f] = fid
+            refs[f] = refs.get(f, 0) + 1
+            nxt += 1
+        elif (f, client) in subs:
+            assert o.remove(f, orc.mk_id(1, client)) == 0
+            assert e.sub_remove(fids[f], subs.pop((f, client))) == 0
+            refs[f] -= 1
+            if refs[f] == 0:
+                assert e.filter_remove(fids[f]) == 0
+                del fids[f], refs[f]
+    blob, offs = pack(topics)
+    compare_flat(e.match_batch(blob, offs), o.match_flat(blob, offs))
+    assert e.counters()["n_filters"] == len(fids) and e.counters()["n_subs"] == len(subs)

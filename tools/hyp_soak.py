@@ -36,6 +36,11 @@ def retain_wild(topics, filters, removes):
        removes=st.lists(st.integers(0, 24), max_size=6))
 def retain_plain(topics, filters, removes):
     H._retain_property(topics, filters, removes)
+@S
+@given(ops=st.lists(H._OP, min_size=1, max_size=80), topics=st.lists(H.WILD, min_size=1, max_size=20), slot_cap=st.sampled_from([0, 1, 2]))
+def router_churn(ops, topics, slot_cap):
+    H._router_churn(ops, topics, slot_cap)
+run('router_churn', router_churn)
 run('retain_wild', retain_wild)
 run('retain_plain', retain_plain)
 run('router_wild', router_wild)
