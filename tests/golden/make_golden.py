@@ -73,7 +73,18 @@ def seeded(cfg, n_sub, n_pub):
             "n_hits": int(exp["hit_offsets"][-1]), "stats": exp["stats"]}
 
 
+def delivery():
+    """Delivery stage: the oracle's forwards() dumps of a fixed world of 400 subscriptions
+    (3 nodes, v3/v5 mix, No Local, RAP, subscription identifiers, re-subscribes) x 120 publishes."""
+    from tests.test_deliver_parity import golden_dumps, golden_world
+    w, pubs = golden_world("emu")
+    dumps = golden_dumps(w, pubs, use_backend=False)
+    return {"seed": 77, "n_subs": 400, "n_pub": 120, "dumps_sha256": hashlib.sha256("\x00".join(dumps).encode()).hexdigest(),
+            "n_rows": sum(d.count("\n") for d in dumps), "first_nonempty": next(d for d in dumps if d)[:200]}
+
+
 def main():
+    json.dump(delivery(), open(os.path.join(HERE, "delivery_small.json"), "w"), indent=1)
     json.dump(reference_vectors(), open(os.path.join(HERE, "reference_vectors.json"), "w"), indent=1)
     out = [seeded(1, 2000, 3000), seeded(2, 20000, 5000), seeded(3, 20000, 3000), seeded(5, 20000, 1500)]
     json.dump(out, open(os.path.join(HERE, "seeded_small.json"), "w"), indent=1)

@@ -144,6 +144,38 @@ class World:
         return out
 
 
+def golden_world(kind, seed=77, n_subs=400, n_pub=120):
+    """A fixed world for tests/golden/delivery_small.json: (world, publishes) — the oracle's dumps of
+    these publishes are what the fixture hashes (tests/golden/make_golden.py)."""
+    w = World(kind, seed)
+    for _ in range(n_subs):
+        w.add(**w.random_sub())
+    r = random.Random(seed + 1)
+    known = sorted(w.owner_ids)
+    pubs = []
+    for _ in range(n_pub):
+        node, client, ct = r.choice(known) if r.random() < 0.7 else (r.choice(w.nodes), "stranger", 0)
+        pubs.append((r.choice(TOPICS), node, client, ct, r.randrange(3), r.random() < 0.5))
+    return w, pubs
+
+
+def golden_dumps(w, pubs, use_backend):
+    """Per publish the forwards dump ("" for an invalid topic): from the oracle, or folded from the backend's delivery words."""
+    if not use_backend:
+        return [w.oracle.forwards(orc.mk_id(n, c, ct), t, q, ret) or "" for t, n, c, ct, q, ret in pubs]
+    blob, offs = pack([p[0] for p in pubs])
+    attrs = np.zeros(len(pubs), dtype=capi.PUBLISH_ATTR_DTYPE)
+    for i, (_, n, c, ct, q, ret) in enumerate(pubs):
+        attrs[i] = (w.owner_ids.get((n, c, ct), capi.ID_NONE), q | (4 if ret else 0))
+    w.backend.commit()
+    got = w.backend.match_batch_deliver(blob, offs, attrs)
+    out = []
+    for i in range(len(pubs)):
+        lo, hi = int(got["hit_offsets"][i]), int(got["hit_offsets"][i + 1])
+        out.append("" if got["status"][i] < 0 else w.fold(got["tuples"][lo:hi], i))
+    return out
+
+
 @pytest.mark.parametrize("kind", BACKENDS)
 @pytest.mark.parametrize("seed,kw", [(1, {}), (2, dict(window_hits=64, chunk_topics=16)), (3, dict(slot_cap=2, window_hits=1))])
 def test_delivery_stage_matches_oracle_forwards(kind, seed, kw):
