@@ -122,6 +122,8 @@ struct rgr_handle {
     std::shared_mutex retain_mu;
     RetainTable retain_table;
     std::shared_ptr<RetainEpoch> retain_epoch;
+    std::mutex retain_commit_mu;       // serialises rgr_retain_commit (the compile scratch and image are reused)
+    RetainImage retain_img;
 };
 
 struct rgr_batch {

@@ -5,6 +5,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <thread>
 
 #include "rmqtt_gpu_router.h"
 #include "topic.hpp"
@@ -132,53 +133,70 @@ void RetainTable::compile(RetainImage& out) const {
     double t_prev = tnow();
     auto lap = [&](const char* what) { if (prof) { const double tn = tnow(); std::fprintf(stderr, "[retain.compile] %-12s %.3f s\n", what, tn - t_prev); t_prev = tn; } };
     const uint32_t total = uint32_t(nodes_.size());
-    // children lists of the mutable ids (counting sort by parent), ordered by token; the
-    // root's non-'$' children first (retain.rs:486-490, 505-509 skip '$' children at the root)
-    std::vector<uint32_t> cnt(size_t(total) + 1, 0), kids;
-    for (const REdge& e : edges_)
-        if (e.parent != kEdgeEmpty && e.parent != kEdgeTomb) cnt[e.parent + 1]++;
+    // ---- children lists of the mutable ids as packed (token << 32 | child), counting-sorted by
+    // parent and ordered by token; the root's non-'$' children first (retain.rs:486-490, 505-509
+    // skip '$' children at the root).  One pass over the edge table; everything after this works
+    // on sequential per-preorder arrays instead of chasing nodes_[].
+    RetainCompileScratch& sc = scratch_;
+    auto& cnt = sc.cnt;
+    cnt.assign(size_t(total) + 1, 0);
+    auto& hash_kid = sc.hash_kid;                         // node -> its literal "#" child (rare: filled on first use)
+    hash_kid.clear();
+    for (const REdge& e : edges_) {
+        if (e.parent == kEdgeEmpty || e.parent == kEdgeTomb) continue;
+        cnt[e.parent + 1]++;
+        if (e.token == kTokHash) {
+            if (hash_kid.empty()) hash_kid.assign(total, kNone);
+            hash_kid[e.parent] = e.child;
+        }
+    }
     for (uint32_t i = 0; i < total; ++i) cnt[i + 1] += cnt[i];
-    kids.resize(cnt[total]);
+    auto& kt = sc.kt;
+    kt.resize(cnt[total]);
     {
-        std::vector<uint32_t> pos(cnt.begin(), cnt.end() - 1);
+        auto& pos = sc.pos;
+        pos.assign(cnt.begin(), cnt.end() - 1);
         for (const REdge& e : edges_)
-            if (e.parent != kEdgeEmpty && e.parent != kEdgeTomb) kids[pos[e.parent]++] = e.child;
+            if (e.parent != kEdgeEmpty && e.parent != kEdgeTomb) kt[pos[e.parent]++] = (uint64_t(e.token) << 32) | e.child;
     }
-    for (uint32_t p = 0; p < total; ++p) {
-        auto b = kids.begin() + cnt[p], e = kids.begin() + cnt[p + 1];
-        if (e - b < 2) continue;
-        if (p == 0)
-            std::sort(b, e, [&](uint32_t x, uint32_t y) {
-                if (nodes_[x].meta != nodes_[y].meta) return !nodes_[x].meta;
-                return nodes_[x].token < nodes_[y].token;
-            });
-        else
-            std::sort(b, e, [&](uint32_t x, uint32_t y) { return nodes_[x].token < nodes_[y].token; });
-    }
+    auto kid = [&](uint32_t k) { return uint32_t(kt[k]); };
+    if (cnt[1] - cnt[0] >= 2)
+        std::sort(kt.begin() + cnt[0], kt.begin() + cnt[1], [&](uint64_t x, uint64_t y) {
+            const bool mx = nodes_[uint32_t(x)].meta, my = nodes_[uint32_t(y)].meta;
+            return mx != my ? !mx : x < y;
+        });
+    for (uint32_t p = 1; p < total; ++p)
+        if (cnt[p + 1] - cnt[p] >= 2) std::sort(kt.begin() + cnt[p], kt.begin() + cnt[p + 1]);   // token is the high half
+    out.root_nonmeta = 0;
+    for (uint32_t k = cnt[0]; k < cnt[1]; ++k) out.root_nonmeta += !nodes_[kid(k)].meta;
     lap("children");
-    // iterative DFS: preorder ids + subtree ends
+    // ---- iterative DFS: preorder ids; per preorder id its mutable id, parent (preorder), token, subtree end
     const uint32_t N = uint32_t(n_nodes_);
-    std::vector<uint32_t> pre(total, kNone), order;   // order[preorder id] = mutable id
-    order.reserve(N);
-    std::vector<uint32_t> sub_end(N, 0);
+    auto &order = sc.order, &ppre = sc.ppre, &ptok = sc.ptok, &sub_end = sc.sub_end;
+    order.assign(N, 0); ppre.assign(N, kNone); ptok.assign(N, 0); sub_end.assign(N, 0);
     {
-        std::vector<std::pair<uint32_t, uint32_t>> st;   // (node, next child index)
-        pre[0] = 0;
-        order.push_back(0);
-        st.emplace_back(0u, cnt[0]);
+        struct Frame { uint32_t m, p, k; };
+        std::vector<Frame> st;
+        uint32_t next = 1;
+        order[0] = 0;
+        st.push_back(Frame{0u, 0u, cnt[0]});
         while (!st.empty()) {
-            auto& top = st.back();
-            if (top.second < cnt[top.first + 1]) {
-                const uint32_t c = kids[top.second++];
-                pre[c] = uint32_t(order.size());
-                order.push_back(c);
-                st.emplace_back(c, cnt[c]);
+            Frame& top = st.back();
+            if (top.k < cnt[top.m + 1]) {
+                const uint64_t w = kt[top.k++];
+                const uint32_t c = uint32_t(w), p = next++;
+                order[p] = c; ppre[p] = top.p; ptok[p] = uint32_t(w >> 32);
+                st.push_back(Frame{c, p, cnt[c]});
             } else {
-                sub_end[pre[top.first]] = uint32_t(order.size());
+                sub_end[top.p] = next;
                 st.pop_back();
             }
         }
     }
+    // the root's first '$' child in preorder (N if none): children of p are p+1, sub_end[p+1], ...
+    uint32_t first_meta_pre = N > 1 ? 1 : N;
+    for (uint32_t i = 0; i < out.root_nonmeta; ++i) first_meta_pre = sub_end[first_meta_pre];
+    if (cnt[1] - cnt[0] == out.root_nonmeta) first_meta_pre = N;
     lap("preorder");
     out.n_nodes = N;
     out.child_off.assign(size_t(N) + 1, 0);
@@ -188,11 +206,10 @@ void RetainTable::compile(RetainImage& out) const {
     for (uint32_t p = 0; p < N; ++p) {
         const uint32_t m = order[p];
         out.child_off[p] = uint32_t(out.child_ids.size());
-        for (uint32_t k = cnt[m]; k < cnt[m + 1]; ++k) out.child_ids.push_back(pre[kids[k]]);
+        uint32_t c = p + 1;
+        for (uint32_t k = cnt[m]; k < cnt[m + 1]; ++k) { out.child_ids.push_back(c); c = sub_end[c]; }
     }
     out.child_off[N] = uint32_t(out.child_ids.size());
-    out.root_nonmeta = 0;
-    for (uint32_t k = cnt[0]; k < cnt[1]; ++k) out.root_nonmeta += !nodes_[kids[k]].meta;
     // ---- value layout.  desc[2p] = p's own value; desc[2p+1] = H(p) = what `p._matches(["#"])`
     // yields (retain.rs:502-524): every value below p — EXCEPT that a node y storing a literal "#"
     // level (child c) answers through the exact-first branch (retain.rs:472-483): below y only c's
@@ -200,88 +217,108 @@ void RetainTable::compile(RetainImage& out) const {
     // y after placing y's and c's values; the rest of subtree(y) goes to a deferred area of its
     // own (still contiguous for every start inside it).  With no literal "#" levels stored this is
     // plain preorder.
-    std::vector<uint32_t> own_pos(total, 0), hp_b(total, 0), hp_e(total, 0);
-    std::vector<uint32_t> hash_kid;                       // node -> its literal "#" child (rare: allocated on first use)
-    for (const REdge& e : edges_)
-        if (e.parent != kEdgeEmpty && e.parent != kEdgeTomb && e.token == kTokHash) {
-            if (hash_kid.empty()) hash_kid.assign(total, kNone);
-            hash_kid[e.parent] = e.child;
-        }
+    auto &own_pos = sc.own_pos, &hp_b = sc.hp_b, &hp_e = sc.hp_e;               // by mutable id, literal-"#" path only
     auto hash_child = [&](uint32_t m) -> uint32_t { return hash_kid.empty() ? kNone : hash_kid[m]; };
-    auto place_value = [&](uint32_t m) { own_pos[m] = uint32_t(out.vals.size()); if (nodes_[m].value != kNone) out.vals.push_back(SubEntry{nodes_[m].value, 0}); };
-    std::vector<uint32_t> deferred;                       // barrier nodes whose hidden part is still to be placed
-    uint32_t first_meta_pos = kNone;
-    // DFS below `m` (its own value is already placed): fills hp_b/hp_e of m and of everything visited
-    auto place_below = [&](uint32_t m0) {
-        std::vector<std::pair<uint32_t, uint32_t>> st;   // (node, next child index)
-        auto enter = [&](uint32_t m) {
-            hp_b[m] = uint32_t(out.vals.size());
-            const uint32_t c = hash_child(m);
-            if (c != kNone) {                             // barrier: only c's own value is visible below m
-                place_value(c);
-                hp_e[m] = uint32_t(out.vals.size());
-                deferred.push_back(m);
-                return;
+    FilterDesc root_desc{0, 0};
+    auto& has = sc.has;
+    has.assign(N, 0);
+    if (hash_kid.empty()) {
+        // no literal "#" level anywhere (the normal case): plain preorder, no traversal needed —
+        // H(p) is the value range of p's proper descendants
+        auto& val_rank = sc.val_rank;
+        val_rank.assign(size_t(N) + 1, 0);
+        for (uint32_t p = 0; p < N; ++p) {
+            const uint32_t v = nodes_[order[p]].value;
+            val_rank[p] = uint32_t(out.vals.size());
+            if (v != kNone) { out.vals.push_back(SubEntry{v, 0}); has[p] = 1; }
+        }
+        val_rank[N] = uint32_t(out.vals.size());
+        out.desc.assign(2 * size_t(N) + 1, FilterDesc{0, 0});
+        for (uint32_t p = 0; p < N; ++p) {
+            out.desc[2 * size_t(p)] = FilterDesc{val_rank[p], has[p]};
+            out.desc[2 * size_t(p) + 1] = FilterDesc{val_rank[p] + has[p], val_rank[sub_end[p]] - val_rank[p] - has[p]};
+        }
+        root_desc = FilterDesc{val_rank[0] + has[0], val_rank[first_meta_pre] - val_rank[0] - has[0]};
+    } else {
+        own_pos.assign(total, 0); hp_b.assign(total, 0); hp_e.assign(total, 0);
+        auto place_value = [&](uint32_t m) { own_pos[m] = uint32_t(out.vals.size()); if (nodes_[m].value != kNone) out.vals.push_back(SubEntry{nodes_[m].value, 0}); };
+        std::vector<uint32_t> deferred;                       // barrier nodes whose hidden part is still to be placed
+        uint32_t first_meta_pos = kNone;
+        // DFS below `m` (its own value is already placed): fills hp_b/hp_e of m and of everything visited
+        auto place_below = [&](uint32_t m0) {
+            std::vector<std::pair<uint32_t, uint32_t>> st;   // (node, next child index)
+            auto enter = [&](uint32_t m) {
+                hp_b[m] = uint32_t(out.vals.size());
+                const uint32_t c = hash_child(m);
+                if (c != kNone) {                             // barrier: only c's own value is visible below m
+                    place_value(c);
+                    hp_e[m] = uint32_t(out.vals.size());
+                    deferred.push_back(m);
+                    return;
+                }
+                st.emplace_back(m, cnt[m]);
+            };
+            enter(m0);
+            while (!st.empty()) {
+                auto& top = st.back();
+                if (top.second < cnt[top.first + 1]) {
+                    if (top.first == 0 && top.second == cnt[0] + out.root_nonmeta) first_meta_pos = uint32_t(out.vals.size());
+                    const uint32_t k = kid(top.second++);
+                    place_value(k);
+                    enter(k);
+                } else {
+                    hp_e[top.first] = uint32_t(out.vals.size());
+                    st.pop_back();
+                }
             }
-            st.emplace_back(m, cnt[m]);
         };
-        enter(m0);
-        while (!st.empty()) {
-            auto& top = st.back();
-            if (top.second < cnt[top.first + 1]) {
-                if (top.first == 0 && top.second == cnt[0] + out.root_nonmeta) first_meta_pos = uint32_t(out.vals.size());
-                const uint32_t k = kids[top.second++];
-                place_value(k);
-                enter(k);
-            } else {
-                hp_e[top.first] = uint32_t(out.vals.size());
-                st.pop_back();
+        place_value(0);
+        place_below(0);
+        const bool root_barrier = hash_child(0) != kNone;
+        if (first_meta_pos == kNone) first_meta_pos = hp_e[0];
+        root_desc = root_barrier ? FilterDesc{hp_b[0], hp_e[0] - hp_b[0]} : FilterDesc{hp_b[0], first_meta_pos - hp_b[0]};
+        for (size_t di = 0; di < deferred.size(); ++di) {     // (grows while we iterate)
+            const uint32_t y = deferred[di], c = hash_child(y);
+            for (uint32_t k = cnt[y]; k < cnt[y + 1]; ++k) {
+                const uint32_t ch = kid(k);
+                if (ch != c) place_value(ch);                 // c's own value sits next to y's
+                place_below(ch);
             }
         }
-    };
-    place_value(0);
-    place_below(0);
-    const bool root_barrier = hash_child(0) != kNone;
-    if (first_meta_pos == kNone) first_meta_pos = hp_e[0];
-    const FilterDesc root_desc = root_barrier ? FilterDesc{hp_b[0], hp_e[0] - hp_b[0]} : FilterDesc{hp_b[0], first_meta_pos - hp_b[0]};
-    for (size_t di = 0; di < deferred.size(); ++di) {     // (grows while we iterate)
-        const uint32_t y = deferred[di], c = hash_child(y);
-        for (uint32_t k = cnt[y]; k < cnt[y + 1]; ++k) {
-            const uint32_t ch = kids[k];
-            if (ch != c) place_value(ch);                 // c's own value sits next to y's
-            place_below(ch);
+        out.desc.assign(2 * size_t(N) + 1, FilterDesc{0, 0});
+        for (uint32_t p = 0; p < N; ++p) {
+            const uint32_t m = order[p];
+            out.desc[2 * size_t(p)] = FilterDesc{own_pos[m], nodes_[m].value != kNone ? 1u : 0u};
+            out.desc[2 * size_t(p) + 1] = FilterDesc{hp_b[m], hp_e[m] - hp_b[m]};
         }
-    }
-    out.desc.assign(2 * size_t(N) + 1, FilterDesc{0, 0});
-    for (uint32_t p = 0; p < N; ++p) {
-        const uint32_t m = order[p];
-        out.desc[2 * size_t(p)] = FilterDesc{own_pos[m], nodes_[m].value != kNone ? 1u : 0u};
-        out.desc[2 * size_t(p) + 1] = FilterDesc{hp_b[m], hp_e[m] - hp_b[m]};
     }
     // root '#': everything outside the root's '$' subtrees (the non-meta children come first), or the
     // literal "#" topic alone when one is stored
     out.desc[2 * size_t(N)] = root_desc;
     lap("values");
-    // grandchild index: (grandparent g, literal token t) -> run of nodes x (preorder ascending)
+    // ---- grandchild index: (grandparent g, literal token t) -> run of nodes x (preorder ascending)
     {
-        struct Tri { uint32_t g, tok, x; };
-        std::vector<Tri> tri;
+        using Tri = RetainCompileScratch::Tri;
+        auto& tri = sc.tri;
+        tri.clear();
         tri.reserve(N);
-        for (uint32_t m = 1; m < total; ++m) {
-            if (pre[m] == kNone) continue;                       // freed slot
-            const Node& nx = nodes_[m];
-            if (nx.token < kTokFirst || nx.parent == 0) continue;   // wildcard-token levels and depth-1 nodes are not indexed
-            const uint32_t p = nx.parent, g = nodes_[p].parent;
-            if (g == 0 && nodes_[p].meta) continue;              // a '+' at the root skips '$' children (retain.rs:486-490)
-            tri.push_back(Tri{pre[g], nx.token, pre[m]});
+        for (uint32_t x = 1; x < N; ++x) {
+            const uint32_t p = ppre[x];
+            if (ptok[x] < kTokFirst || p == 0) continue;             // wildcard-token levels and depth-1 nodes are not indexed
+            const uint32_t g = ppre[p];
+            if (g == 0 && p >= first_meta_pre) continue;             // a '+' at the root skips '$' children (retain.rs:486-490)
+            tri.push_back(Tri{g, ptok[x], x});
         }
         {   // order by (g, tok, x): counting sort on the grandparent, then each (small) group by (tok, x)
-            std::vector<uint32_t> goff(size_t(N) + 1, 0);
+            auto& goff = sc.goff;
+            goff.assign(size_t(N) + 1, 0);
             for (const Tri& t : tri) goff[t.g + 1]++;
             for (uint32_t i = 0; i < N; ++i) goff[i + 1] += goff[i];
-            std::vector<Tri> sorted(tri.size());
+            auto& sorted = sc.tri_sorted;
+            sorted.resize(tri.size());
             {
-                std::vector<uint32_t> pos(goff.begin(), goff.end() - 1);
+                auto& pos = sc.pos;
+                pos.assign(goff.begin(), goff.end() - 1);
                 for (const Tri& t : tri) sorted[pos[t.g]++] = t;
             }
             tri.swap(sorted);
@@ -306,17 +343,56 @@ void RetainTable::compile(RetainImage& out) const {
         }
     }
     lap("gc index");
-    // edge table over preorder ids
+    // ---- edge table over preorder ids.  Built in kParts fixed slot ranges (independent of the thread
+    // count, so the image is deterministic): entries — in preorder — are bucketed by the range of
+    // their home slot, every range is filled by one thread, and the few entries whose probe sequence
+    // leaves its range are inserted afterwards, sequentially.
     uint64_t cap = 1024;
     while (cap < uint64_t(N) * 2) cap <<= 1;
     out.edges.assign(cap, empty_redge());
+    lap("  edge.alloc");
     const uint32_t mask = uint32_t(cap - 1);
-    for (const REdge& e : edges_) {
-        if (e.parent == kEdgeEmpty || e.parent == kEdgeTomb) continue;
-        const uint32_t pp = pre[e.parent], pc = pre[e.child];
-        uint32_t i = edge_hash(pp, e.token) & mask;
-        while (out.edges[i].parent != kEdgeEmpty) i = (i + 1) & mask;
-        out.edges[i] = REdge{pp, e.token, pc, 0};
+    {
+        constexpr uint32_t kParts = 64;
+        const uint64_t psz = cap / kParts;
+        auto &home = sc.home, &pcount = sc.pcount;
+        home.assign(N, 0); pcount.assign(kParts + 1, 0);
+        for (uint32_t x = 1; x < N; ++x) { home[x] = edge_hash(ppre[x], ptok[x]) & mask; pcount[home[x] / psz + 1]++; }
+        for (uint32_t k = 0; k < kParts; ++k) pcount[k + 1] += pcount[k];
+        auto& sorted = sc.sorted;
+        sorted.resize(N > 1 ? N - 1 : 0);
+        {
+            auto& pos = sc.pos;
+            pos.assign(pcount.begin(), pcount.end() - 1);
+            for (uint32_t x = 1; x < N; ++x) sorted[pos[home[x] / psz]++] = x;      // stable: preorder inside a range
+        }
+        lap("  edge.bucket");
+        std::vector<std::vector<uint32_t>> spill(kParts);
+        auto fill = [&](uint32_t part) {
+            const uint64_t hi = uint64_t(part + 1) * psz;
+            for (uint32_t k = pcount[part]; k < pcount[part + 1]; ++k) {
+                const uint32_t x = sorted[k];
+                uint64_t i = home[x];
+                while (i < hi && out.edges[i].parent != kEdgeEmpty) ++i;
+                if (i == hi) spill[part].push_back(x);
+                else out.edges[i] = REdge{ppre[x], ptok[x], x, 0};
+            }
+        };
+        const unsigned nt = std::max(1u, std::min<unsigned>({std::thread::hardware_concurrency(), kParts, unsigned(N / 65536 + 1)}));
+        if (nt <= 1) { for (uint32_t part = 0; part < kParts; ++part) fill(part); }
+        else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; ++t)
+                th.emplace_back([&, t] { for (uint32_t part = t; part < kParts; part += nt) fill(part); });
+            for (auto& t : th) t.join();
+        }
+        lap("  edge.fill");
+        for (uint32_t part = 0; part < kParts; ++part)
+            for (const uint32_t x : spill[part]) {
+                uint32_t i = home[x];
+                while (out.edges[i].parent != kEdgeEmpty) i = (i + 1) & mask;
+                out.edges[i] = REdge{ppre[x], ptok[x], x, 0};
+            }
     }
     lap("edge table");
 }

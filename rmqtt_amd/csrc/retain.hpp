@@ -18,13 +18,23 @@
 namespace rgr {
 
 struct RetainImage {   // host copy of one snapshot, preorder-numbered
-    std::vector<REdge> edges;
+    FlatArray<REdge> edges;                // open-addressed, filled in parallel (retain.cpp)
     std::vector<GcEdge> gc_edges;          // grandchild index (kernels.hpp)
     std::vector<uint32_t> gc_ids;
     std::vector<uint32_t> child_off, child_ids;
     std::vector<FilterDesc> desc;
     std::vector<SubEntry> vals;
     uint32_t root_nonmeta = 0, n_nodes = 0;
+};
+
+// compile()'s temporaries, kept between calls: on this class of hosts first-touching a few hundred
+// MB of fresh pages costs more than the work done in them.
+struct RetainCompileScratch {
+    struct Tri { uint32_t g, tok, x; };
+    std::vector<uint32_t> cnt, hash_kid, order, ppre, ptok, sub_end, own_pos, hp_b, hp_e, val_rank, home, sorted, pcount, goff, pos;
+    std::vector<uint64_t> kt;
+    std::vector<uint8_t> has;
+    std::vector<Tri> tri, tri_sorted;
 };
 
 class RetainTable {
@@ -35,6 +45,7 @@ class RetainTable {
     int32_t topic_remove(std::string_view topic);     // RGR_OK / RGR_ENOENT / RGR_EINVAL_TOPIC
     // Tokenise a filter against the dictionary (read-only): flags as HostTable::tokenize_topic.
     uint8_t tokenize_filter(std::string_view f, std::vector<uint32_t>& toks) const;
+    // Not re-entrant (scratch buffers are reused): callers serialise compiles.
     void compile(RetainImage& out) const;
     const StringDict& dict() const { return dict_; }
     uint64_t n_topics() const { return n_values_; }
@@ -53,6 +64,7 @@ class RetainTable {
     uint32_t insert_edge(uint32_t parent, uint32_t token, uint32_t child);
     void rehash(uint64_t cap);
     bool tokenize(std::string_view s, std::vector<uint32_t>& toks, bool intern, bool* first_meta);
+    mutable RetainCompileScratch scratch_;
 };
 
 }  // namespace rgr

@@ -16,30 +16,18 @@
 
 namespace rgr {
 
-// ------------------------------------------------------------------ EdgeArray
-void EdgeArray::release() {
-    std::free(p_);
-    p_ = nullptr; n_ = 0;
-}
-
-void EdgeArray::assign(uint64_t n, const EdgeEntry& v) {
-    release();
-    if (!n) return;
+// ------------------------------------------------------------------ FlatArray helpers
+void* flat_alloc(size_t bytes) {
     void* mem = nullptr;
-    const size_t bytes = size_t(n) * sizeof(EdgeEntry);
     if (posix_memalign(&mem, bytes >= (2u << 20) ? (2u << 20) : 64, bytes) != 0) throw std::bad_alloc();
 #ifdef MADV_HUGEPAGE
     if (bytes >= (2u << 20)) (void)madvise(mem, bytes, MADV_HUGEPAGE);   // fewer first-touch faults
 #endif
-    p_ = static_cast<EdgeEntry*>(mem);
-    n_ = n;
-    unsigned nt = unsigned(std::min<uint64_t>(std::max(1u, std::thread::hardware_concurrency()), n / (1u << 20)));
-    if (nt <= 1) { std::fill(p_, p_ + n, v); return; }
-    nt = std::min(nt, 64u);
-    std::vector<std::thread> th;
-    for (unsigned k = 0; k < nt; ++k)
-        th.emplace_back([=] { std::fill(p_ + n * k / nt, p_ + n * (k + 1) / nt, v); });
-    for (auto& t : th) t.join();
+    return mem;
+}
+
+unsigned flat_fill_threads(uint64_t n) {
+    return unsigned(std::min<uint64_t>({uint64_t(std::max(1u, std::thread::hardware_concurrency())), n / (1u << 20), uint64_t(64)}));
 }
 
 // ------------------------------------------------------------------ StringDict

@@ -8,6 +8,9 @@
 // rgr_commit() snapshots this image into HBM as an immutable epoch.
 #pragma once
 #include <cstdint>
+#include <thread>
+#include <cstdlib>
+#include <algorithm>
 #include <string>
 #include <string_view>
 #include <utility>
@@ -51,34 +54,58 @@ class StringDict {
     void grow();
 };
 
-// The open-addressed edge table: a flat array that is (re)filled in parallel — at 10 M
-// subscriptions it is 8 GiB of mostly empty slots and a single-threaded first touch of those
-// pages dominated both the bulk build and the snapshot load.
-class EdgeArray {
+// A flat array that is (re)filled in parallel.  The open-addressed edge tables are mostly empty
+// slots (8 GiB at 10 M subscriptions) and a single-threaded first touch of those pages dominated
+// the bulk build, the snapshot load and the retained-topic compile.
+void* flat_alloc(size_t bytes);                       // 2 MiB-aligned + MADV_HUGEPAGE for big blocks; throws std::bad_alloc
+unsigned flat_fill_threads(uint64_t n);
+template <class T>
+class FlatArray {
    public:
-    EdgeArray() = default;
-    EdgeArray(const EdgeArray&) = delete;
-    EdgeArray& operator=(const EdgeArray&) = delete;
-    EdgeArray(EdgeArray&& o) noexcept : p_(o.p_), n_(o.n_) { o.p_ = nullptr; o.n_ = 0; }
-    EdgeArray& operator=(EdgeArray&& o) noexcept { if (this != &o) { release(); p_ = o.p_; n_ = o.n_; o.p_ = nullptr; o.n_ = 0; } return *this; }
-    ~EdgeArray() { release(); }
-    void assign(uint64_t n, const EdgeEntry& v);      // discard contents, n copies of v (parallel fill)
-    void swap(EdgeArray& o) noexcept { std::swap(p_, o.p_); std::swap(n_, o.n_); }
+    FlatArray() = default;
+    FlatArray(const FlatArray&) = delete;
+    FlatArray& operator=(const FlatArray&) = delete;
+    FlatArray(FlatArray&& o) noexcept : p_(o.p_), n_(o.n_), cap_(o.cap_) { o.p_ = nullptr; o.n_ = o.cap_ = 0; }
+    FlatArray& operator=(FlatArray&& o) noexcept {
+        if (this != &o) { release(); p_ = o.p_; n_ = o.n_; cap_ = o.cap_; o.p_ = nullptr; o.n_ = o.cap_ = 0; }
+        return *this;
+    }
+    ~FlatArray() { release(); }
+    // discard contents, n copies of v.  The allocation is kept when it is big enough (and not more
+    // than 4x too big): refilling mapped pages costs a fraction of first-touching fresh ones.
+    void assign(uint64_t n, const T& v) {
+        if (n > cap_ || n * 4 < cap_) {
+            release();
+            if (!n) return;
+            p_ = static_cast<T*>(flat_alloc(size_t(n) * sizeof(T)));
+            cap_ = n;
+        }
+        n_ = n;
+        if (!n) return;
+        const unsigned nt = flat_fill_threads(n);
+        if (nt <= 1) { std::fill(p_, p_ + n, v); return; }
+        std::vector<std::thread> th;
+        T* p = p_;
+        for (unsigned k = 0; k < nt; ++k) th.emplace_back([=] { std::fill(p + n * k / nt, p + n * (k + 1) / nt, v); });
+        for (auto& t : th) t.join();
+    }
+    void swap(FlatArray& o) noexcept { std::swap(p_, o.p_); std::swap(n_, o.n_); std::swap(cap_, o.cap_); }
     uint64_t size() const { return n_; }
-    const EdgeEntry* data() const { return p_; }
-    EdgeEntry* data() { return p_; }
-    const EdgeEntry& operator[](uint64_t i) const { return p_[i]; }
-    EdgeEntry& operator[](uint64_t i) { return p_[i]; }
-    const EdgeEntry* begin() const { return p_; }
-    const EdgeEntry* end() const { return p_ + n_; }
-    EdgeEntry* begin() { return p_; }
-    EdgeEntry* end() { return p_ + n_; }
+    const T* data() const { return p_; }
+    T* data() { return p_; }
+    const T& operator[](uint64_t i) const { return p_[i]; }
+    T& operator[](uint64_t i) { return p_[i]; }
+    const T* begin() const { return p_; }
+    const T* end() const { return p_ + n_; }
+    T* begin() { return p_; }
+    T* end() { return p_ + n_; }
 
    private:
-    EdgeEntry* p_ = nullptr;
-    uint64_t n_ = 0;
-    void release();
+    T* p_ = nullptr;
+    uint64_t n_ = 0, cap_ = 0;
+    void release() { std::free(p_); p_ = nullptr; n_ = cap_ = 0; }
 };
+using EdgeArray = FlatArray<EdgeEntry>;
 
 class HostTable {
    public:
