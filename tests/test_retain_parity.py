@@ -215,3 +215,37 @@ def test_commit_without_changes_keeps_the_epoch():
     r.retain_commit()
     assert r.stats()["retain_epoch"] != e1 and r.stats()["retain_topics"] == 3
     assert sorted(r.retain_match_batch(*pack(["s/+"]))["topic_ids"].tolist()) == [3, 4, 9]
+
+
+def test_repeated_commits_on_one_table(kind):
+    """One table compiled again and again while it grows, shrinks and gains / loses literal '#'
+    levels: the compile's scratch buffers and the retained image are reused between commits."""
+    import random
+    rng = random.Random(5)
+    b = make_backend(kind)
+    t = orc.RetainTree()
+    levels = ["a", "b", "c", "d", "", "$s", "+", "#"]
+    live = {}
+    filters = ["#", "+/#", "a/#", "a/+/#", "+/+", "a/b/#", "+/b/+", "$s/#", "a/+", "+", "a/b/c", "+/+/+/#"]
+    next_id = 0
+    for rnd in range(30):
+        grow = rnd % 7 != 6
+        for _ in range(rng.randint(5, 60) if grow else rng.randint(20, 120)):
+            if grow or not live:
+                n = rng.randint(1, 4)
+                name = "/".join(rng.choice(levels[:6] if rng.random() < 0.8 else levels) for _ in range(n))
+                if orc.parse_topic(name) is None:
+                    continue
+                rc = b.retain_add(name, next_id)
+                assert rc == 0, name
+                t.insert(name, next_id)
+                live[name] = next_id
+                next_id += 1
+            else:
+                name = rng.choice(sorted(live))
+                assert b.retain_remove(name) == 0
+                t.remove(name)
+                del live[name]
+        b.retain_commit()
+        check(b, t, filters)
+    assert len(live) > 20
