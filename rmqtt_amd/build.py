@@ -6,6 +6,8 @@
 
 The ``.so`` files are git-ignored but travel to the GPU box with the tree snapshot.
 """
+import contextlib
+import fcntl
 import os
 import shutil
 import subprocess
@@ -30,6 +32,26 @@ def _stale(target, deps):
     return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
 
 
+@contextlib.contextmanager
+def _build_lock():
+    """Several ranks of one job may import the package at once (torch.distributed.run): only one of
+    them compiles, the others wait and then find the library fresh."""
+    fd = os.open(os.path.join(HERE, ".build.lock"), os.O_CREAT | os.O_RDWR, 0o644)
+    try:
+        fcntl.flock(fd, fcntl.LOCK_EX)
+        yield
+    finally:
+        fcntl.flock(fd, fcntl.LOCK_UN)
+        os.close(fd)
+
+
+def _compile(cmd, target):
+    """Compile to a temporary name and rename: a reader never sees a half-written library."""
+    tmp = f"{target}.tmp{os.getpid()}"
+    subprocess.check_call([tmp if c == target else c for c in cmd])
+    os.replace(tmp, target)
+
+
 def hipcc():
     return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 
@@ -37,21 +59,27 @@ def hipcc():
 def build_workload(force=False):
     src = os.path.join(CSRC, "workload.cpp")
     if force or _stale(WL_LIB, [src]):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", WL_LIB, src])
+        with _build_lock():
+            if force or _stale(WL_LIB, [src]):
+                _compile(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", WL_LIB, src], WL_LIB)
     return WL_LIB
 
 
 def build_gpu(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in GPU_SRCS]
     deps = srcs + [os.path.join(CSRC, h) for h in GPU_HDRS] + [os.path.join(INCLUDE, "rmqtt_gpu_router.h")]
-    if force or _stale(GPU_LIB, deps):
+    if not (force or _stale(GPU_LIB, deps)):
+        return GPU_LIB
+    with _build_lock():
+        if not (force or _stale(GPU_LIB, deps)):
+            return GPU_LIB
         cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-pthread",
                "-Wall", "-Wno-unused-result", "-I", INCLUDE, "-I", CSRC, "-x", "hip"]
         cmd += os.environ.get("RGR_EXTRA_FLAGS", "").split()      # tuning sweeps: -DRGR_EXPAND_THREADS=... etc.
         cmd += srcs + ["-o", GPU_LIB]
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-        subprocess.check_call(cmd)
+        _compile(cmd, GPU_LIB)
     return GPU_LIB
 
 
@@ -61,9 +89,11 @@ def build_host_router(force=False):
     srcs = [os.path.join(hdir, "gpu_router.cpp"), os.path.join(hdir, "gpu_retain.cpp"), os.path.join(hdir, "router_capi.cpp")]
     deps = srcs + [os.path.join(hdir, "gpu_router.hpp"), os.path.join(hdir, "gpu_retain.hpp"), os.path.join(INCLUDE, "rmqtt_gpu_router.h"), GPU_LIB]
     if force or _stale(HOST_LIB, deps):
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I", INCLUDE, "-I", hdir] + srcs
-        cmd += ["-o", HOST_LIB, "-L", HERE, "-lrmqtt_gpu_router", "-Wl,-rpath,$ORIGIN"]
-        subprocess.check_call(cmd)
+        with _build_lock():
+            if force or _stale(HOST_LIB, deps):
+                cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I", INCLUDE, "-I", hdir] + srcs
+                cmd += ["-o", HOST_LIB, "-L", HERE, "-lrmqtt_gpu_router", "-Wl,-rpath,$ORIGIN"]
+                _compile(cmd, HOST_LIB)
     return HOST_LIB
 
 
