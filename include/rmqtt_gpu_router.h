@@ -80,6 +80,16 @@ enum {
     RGR_SUB_SHARED = 1u << 2,     /* member of a $share group (host post-filter)      */
     RGR_SUB_RAP = 1u << 3         /* v5 Retain As Published (shared.rs:889-897)       */
 };
+/* Flag bits 4-7 are a caller-defined TABLE id, opaque to the matcher: the
+ * reference keeps further `TopicTree`s that are matched against the same publish topic — the
+ * egress bridges (rmqtt-bridge-egress-mqtt/src/bridge.rs:103,202: `topics.read().matches(&topic)`
+ * per publish), ACL rule topics (rmqtt-acl/src/config.rs:170,330).  Their entries can live in
+ * the same handle as "subscriptions" of table 1, 2, ...: one device pass returns the hits of
+ * every table, still in TopicTree::matches filter order, and the consumer demultiplexes on
+ * RGR_SUB_TABLE(flags).  Table 0 = the router's relations. */
+#define RGR_SUB_TABLE_SHIFT 4
+#define RGR_SUB_TABLE_MASK 0xF0u
+#define RGR_SUB_TABLE(flags) (((flags) & RGR_SUB_TABLE_MASK) >> RGR_SUB_TABLE_SHIFT)
 
 /* Delivery word: what rgr_tuple.qos_flags holds for a batch that carries publish
  * attributes (rgr_batch_set_publish_attrs / rgr_match_batch_deliver) — the per-hit part of

@@ -17,6 +17,7 @@ RGR_TOPIC_OK, RGR_TOPIC_INVALID = 0, -2
 RGR_SUB_V5, RGR_SUB_NO_LOCAL, RGR_SUB_SHARED, RGR_SUB_RAP = 1, 2, 4, 8
 RGR_HIT_QOS_MASK, RGR_HIT_RETAIN, RGR_HIT_NO_LOCAL, RGR_HIT_V5_DUP = 3, 4, 8, 16
 ID_NONE = 0xFFFFFFFF
+RGR_SUB_TABLE_SHIFT, RGR_SUB_TABLE_MASK = 4, 0xF0     # flags bits 4-7: caller-defined table id
 
 TUPLE_DTYPE = np.dtype([("topic_idx", np.uint32), ("sub_id", np.uint32), ("qos_flags", np.uint32)])
 PUBLISH_ATTR_DTYPE = np.dtype([("from_id", np.uint32), ("qos_retain", np.uint32)])

@@ -229,3 +229,34 @@ def test_seeded_workloads_small(kind, cfg, n_sub, n_pub):
         assert exp["stats"]["invalid"] == 0
     else:
         assert exp["stats"]["hits"] > 0
+
+
+def test_several_tables_in_one_pass(kind):
+    """the reference matches every publish against more `TopicTree`s than the
+    router's — e.g. the egress bridges' `TopicTree<(BridgeName, EntryIndex)>`
+    (rmqtt-bridge-egress-mqtt/src/bridge.rs:103,202).  Tagged with a table id in the flag bits their
+    entries share the handle: one pass, results demultiplexed per table, each equal to that
+    table's own oracle TopicTree."""
+    from rmqtt_amd import capi
+    rng = random.Random(8)
+    b = parity.make_backend(kind)
+    trees = [orc.TopicTree(), orc.TopicTree(), orc.TopicTree()]
+    pool = ["a/b", "a/+", "a/#", "#", "+/b", "a/b/c", "+/+", "$SYS/#", "x/y", "a/b/#", "+/#", "x/+"]
+    next_id = 0
+    for table, tree in enumerate(trees):
+        for _ in range(40 if table == 0 else 12):
+            f = rng.choice(pool)
+            fid = b.filter_add(f)
+            b.sub_add(fid, next_id, rng.randrange(3), table << capi.RGR_SUB_TABLE_SHIFT)
+            tree.insert(f, next_id)
+            next_id += 1
+    b.commit()
+    topics = ["a/b", "a/b/c", "x/y", "a", "$SYS/q", "q", "a/+", "x/y/z"]
+    blob, offs = pack(topics)
+    got = b.match_batch(blob, offs)
+    for i, t in enumerate(topics):
+        tup = got["tuples"][int(got["hit_offsets"][i]):int(got["hit_offsets"][i + 1])]
+        tab = (tup["qos_flags"] >> 8 & capi.RGR_SUB_TABLE_MASK) >> capi.RGR_SUB_TABLE_SHIFT
+        for table, tree in enumerate(trees):
+            exp = [v for _, vals in tree.matches(t) for v in sorted(vals)]
+            assert tup["sub_id"][tab == table].tolist() == exp, (t, table)
