@@ -127,7 +127,26 @@ int32_t RetainTable::topic_remove(std::string_view topic) {
     return RGR_OK;
 }
 
-void RetainTable::compile(RetainImage& out) const {
+uint32_t RetainTable::find_node(std::string_view topic) const {
+    std::vector<uint32_t> toks;
+    if (for_each_level(topic, [](int64_t, std::string_view, LevelKind) {}) < 0) return kNone;
+    bool known = true;
+    for_each_level(topic, [&](int64_t, std::string_view seg, LevelKind k) {
+        const uint32_t t = k == LevelKind::Plus ? kTokPlus : k == LevelKind::Hash ? kTokHash : dict_.find(seg);
+        if (t == kTokUnknown) known = false;
+        toks.push_back(t);
+    });
+    if (!known) return kNone;
+    uint32_t cur = 0;
+    for (uint32_t t : toks) {
+        const uint32_t s = find(cur, t);
+        if (s == kNone) return kNone;
+        cur = edges_[s].child;
+    }
+    return cur;
+}
+
+void RetainTable::compile(RetainImage& out, std::vector<uint32_t>* val_of_node) const {
     const bool prof = std::getenv("RGR_BULK_PROFILE") != nullptr;
     auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_prev = tnow();
@@ -239,6 +258,10 @@ void RetainTable::compile(RetainImage& out) const {
             out.desc[2 * size_t(p) + 1] = FilterDesc{val_rank[p] + has[p], val_rank[sub_end[p]] - val_rank[p] - has[p]};
         }
         root_desc = FilterDesc{val_rank[0] + has[0], val_rank[first_meta_pre] - val_rank[0] - has[0]};
+        if (val_of_node) {
+            val_of_node->assign(total, kNone);
+            for (uint32_t p = 0; p < N; ++p) if (has[p]) (*val_of_node)[order[p]] = val_rank[p];
+        }
     } else {
         own_pos.assign(total, 0); hp_b.assign(total, 0); hp_e.assign(total, 0);
         auto place_value = [&](uint32_t m) { own_pos[m] = uint32_t(out.vals.size()); if (nodes_[m].value != kNone) out.vals.push_back(SubEntry{nodes_[m].value, 0}); };
@@ -290,6 +313,10 @@ void RetainTable::compile(RetainImage& out) const {
             const uint32_t m = order[p];
             out.desc[2 * size_t(p)] = FilterDesc{own_pos[m], nodes_[m].value != kNone ? 1u : 0u};
             out.desc[2 * size_t(p) + 1] = FilterDesc{hp_b[m], hp_e[m] - hp_b[m]};
+        }
+        if (val_of_node) {
+            val_of_node->assign(total, kNone);
+            for (uint32_t p = 0; p < N; ++p) { const uint32_t m = order[p]; if (nodes_[m].value != kNone) (*val_of_node)[m] = own_pos[m]; }
         }
     }
     // root '#': everything outside the root's '$' subtrees (the non-meta children come first), or the
@@ -395,6 +422,67 @@ void RetainTable::compile(RetainImage& out) const {
             }
     }
     lap("edge table");
+}
+
+// ------------------------------------------------------------------ TieredRetain
+namespace {
+bool has_wildcard_level(std::string_view topic) {
+    bool w = false;
+    for_each_level(topic, [&](int64_t, std::string_view, LevelKind k) { if (k == LevelKind::Plus || k == LevelKind::Hash) w = true; });
+    return w;
+}
+}  // namespace
+
+bool TieredRetain::in_delta(std::string_view topic) const {
+    const uint32_t n = delta_.find_node(topic);
+    return n != kNone && delta_.node_value(n) != kNone;
+}
+
+void TieredRetain::mark_dead(uint32_t node, uint32_t topic_id) {
+    const uint32_t idx = node < base_val_of_node_.size() ? base_val_of_node_[node] : kNone;
+    if (idx == kNone) return;                  // (cannot happen: a valued topic outside the delta is a live base value)
+    base_val_of_node_[node] = kNone;
+    pending_dead_.push_back(Dead{idx, topic_id});
+    n_dead_++;
+}
+
+int32_t TieredRetain::topic_add(std::string_view topic, uint32_t topic_id) {
+    const uint32_t node = all_.find_node(topic);
+    const uint32_t old = node != kNone ? all_.node_value(node) : kNone;
+    const bool was_delta = merged_once_ && old != kNone && in_delta(topic);
+    const int32_t rc = all_.topic_add(topic, topic_id);
+    if (rc == RGR_OK && old == kNone && has_wildcard_level(topic)) { n_wild_++; force_merge_ = true; }
+    if (rc != RGR_OK || !merged_once_ || old == topic_id) return rc;
+    if (old != kNone && !was_delta) mark_dead(node, old);     // value of a base topic replaced: the new one lives in the delta
+    return delta_.topic_add(topic, topic_id);
+}
+
+int32_t TieredRetain::topic_remove(std::string_view topic) {
+    const uint32_t node = all_.find_node(topic);
+    const uint32_t old = node != kNone ? all_.node_value(node) : kNone;
+    const bool was_delta = merged_once_ && old != kNone && in_delta(topic);
+    const int32_t rc = all_.topic_remove(topic);
+    if (rc == RGR_OK && has_wildcard_level(topic)) { n_wild_--; force_merge_ = true; }
+    if (rc != RGR_OK || !merged_once_) return rc;
+    if (was_delta) return delta_.topic_remove(topic);
+    mark_dead(node, old);
+    return RGR_OK;
+}
+
+void TieredRetain::compile_base(RetainImage& out) {
+    all_.compile(out, &base_val_of_node_);
+    delta_ = RetainTable();
+    delta_compiled_ = delta_.version();
+    pending_dead_.clear();
+    n_dead_ = 0;
+    base_topics_ = all_.n_topics();
+    merged_once_ = true;
+    force_merge_ = false;
+}
+
+void TieredRetain::compile_delta(RetainImage& out) {
+    delta_.compile(out);
+    delta_compiled_ = delta_.version();
 }
 
 }  // namespace rgr

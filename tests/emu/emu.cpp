@@ -24,6 +24,10 @@ namespace {
 struct Emu {
     HostTable table;
     RetainTable retain;
+    TieredRetain tiers;                     // two-tier retained set with its two "device" images
+    RetainImage tier_base, tier_delta;
+    bool tier_has_delta = false;
+    uint64_t tier_merges = 0, tier_delta_compiles = 0;
     uint32_t slot_cap = 32, chunk_topics = 1u << 21, lds_window = 2560, tile = 2048;
     uint64_t window_hits = 1ull << 28;
     uint64_t visited = 0, overflow_topics = 0, windows = 0, pairs = 0;
@@ -334,24 +338,28 @@ int32_t emu_retain_add_bulk(void* ev, const uint8_t* blob, const uint64_t* offs,
     return RGR_OK;
 }
 
-// Same outputs as rgr_retain_match_batch, as tuples (topic_idx = filter index, sub_id = topic id).
-int32_t emu_retain_match(void* ev, const uint8_t* blob, const uint64_t* offs, uint32_t n, int32_t* status, uint64_t** hit_offsets_out,
-                         rgr_tuple** tuples_out, uint64_t* n_hits_out) {
-    auto* e = static_cast<Emu*>(ev);
+}  // extern "C"
+
+namespace {
+// sentinels behind the arrays the per-lane code may read one element past
+void pad_image(RetainImage& img) {
+    img.vals.push_back(SubEntry{0, 0});
+    img.child_ids.push_back(0);
+    img.gc_ids.push_back(0);
+}
+
+// rgr_retain_match_batch against ONE compiled (and padded) image; `tk` tokenises the filters.
+int32_t retain_match_on(Emu* e, const RetainTable& tk, const RetainImage& img, const uint8_t* blob, const uint64_t* offs, uint32_t n, int32_t* status,
+                        uint64_t** hit_offsets_out, rgr_tuple** tuples_out, uint64_t* n_hits_out) {
     std::vector<uint32_t> tokens;
     std::vector<uint64_t> tok_off(size_t(n) + 1, 0);
     std::vector<uint8_t> tflags(n);
     for (uint32_t i = 0; i < n; ++i) {
-        tflags[i] = e->retain.tokenize_filter(std::string_view(reinterpret_cast<const char*>(blob) + offs[i], offs[i + 1] - offs[i]), tokens);
+        tflags[i] = tk.tokenize_filter(std::string_view(reinterpret_cast<const char*>(blob) + offs[i], offs[i + 1] - offs[i]), tokens);
         tok_off[i + 1] = tokens.size();
         status[i] = (tflags[i] & kTopicInvalid) ? RGR_TOPIC_INVALID : RGR_TOPIC_OK;
     }
     tokens.push_back(0);
-    RetainImage img;
-    e->retain.compile(img);
-    img.vals.push_back(SubEntry{0, 0});
-    img.child_ids.push_back(0);
-    img.gc_ids.push_back(0);
     RetainView rv{};
     rv.edges = img.edges.data(); rv.mask = uint32_t(img.edges.size() - 1);
     rv.gc_edges = img.gc_edges.data(); rv.gc_mask = uint32_t(img.gc_edges.size() - 1); rv.gc_ids = img.gc_ids.data();
@@ -414,6 +422,81 @@ int32_t emu_retain_match(void* ev, const uint8_t* blob, const uint64_t* offs, ui
     };
     auto no_walk = [](uint32_t, uint64_t, uint64_t, std::vector<uint32_t>&, auto&) { return 0u; };
     return run_pipeline(e, n, tok_off, tflags, tv, no_walk, prefill, true, hit_offsets_out, tuples_out, n_hits_out, nullptr, nullptr);
+}
+}  // namespace
+
+extern "C" {
+
+// Same outputs as rgr_retain_match_batch, as tuples (topic_idx = filter index, sub_id = topic id).
+int32_t emu_retain_match(void* ev, const uint8_t* blob, const uint64_t* offs, uint32_t n, int32_t* status, uint64_t** hit_offsets_out,
+                         rgr_tuple** tuples_out, uint64_t* n_hits_out) {
+    auto* e = static_cast<Emu*>(ev);
+    RetainImage img;
+    e->retain.compile(img);
+    pad_image(img);
+    return retain_match_on(e, e->retain, img, blob, offs, n, status, hit_offsets_out, tuples_out, n_hits_out);
+}
+
+// ---- two-tier retained set: the orchestration rgr_retain_commit / rgr_retain_match_batch run in
+// tiered mode (rgr_config.retain_delta_max > 0), over host images instead of device epochs.
+int32_t emu_tier_add(void* e, const char* t, uint32_t len, uint32_t id) { return static_cast<Emu*>(e)->tiers.topic_add(std::string_view(t, len), id); }
+int32_t emu_tier_remove(void* e, const char* t, uint32_t len) { return static_cast<Emu*>(e)->tiers.topic_remove(std::string_view(t, len)); }
+uint64_t emu_tier_counter(void* ev, int which) {
+    auto* e = static_cast<Emu*>(ev);
+    switch (which) {
+        case 0: return e->tiers.n_topics();
+        case 1: return e->tiers.n_delta();
+        case 2: return e->tiers.n_dead();
+        case 3: return e->tier_merges;
+        default: return e->tier_delta_compiles;
+    }
+}
+int32_t emu_tier_commit(void* ev, uint64_t delta_max) {
+    auto* e = static_cast<Emu*>(ev);
+    if (e->tiers.wants_merge(delta_max)) {
+        e->tiers.compile_base(e->tier_base);
+        pad_image(e->tier_base);
+        e->tier_has_delta = false;
+        e->tier_merges++;
+        return RGR_OK;
+    }
+    if (e->tiers.delta_dirty()) {
+        e->tiers.compile_delta(e->tier_delta);
+        pad_image(e->tier_delta);
+        e->tier_has_delta = true;
+        e->tier_delta_compiles++;
+    }
+    for (const auto& d : e->tiers.take_dead()) {          // the scatter of {topic_id, dead} into the base epoch's vals[]
+        if (d.val_index >= e->tier_base.vals.size() || e->tier_base.vals[d.val_index].sub_id != d.topic_id) return RGR_ESTATE;
+        e->tier_base.vals[d.val_index].qos_flags |= kRetainDead;
+    }
+    return RGR_OK;
+}
+// ids only (the merged answer); arrays malloc'ed
+int32_t emu_tier_match(void* ev, const uint8_t* blob, const uint64_t* offs, uint32_t n, int32_t* status, uint64_t** hit_offsets_out,
+                       uint32_t** ids_out, uint64_t* n_hits_out) {
+    auto* e = static_cast<Emu*>(ev);
+    uint64_t *bo = nullptr, *dof = nullptr, nb = 0, nd = 0;
+    rgr_tuple *bt = nullptr, *dt = nullptr;
+    int32_t rc = retain_match_on(e, e->tiers.base_table(), e->tier_base, blob, offs, n, status, &bo, &bt, &nb);
+    if (rc != RGR_OK) return rc;
+    std::vector<int32_t> st2(n);
+    if (e->tier_has_delta) {
+        rc = retain_match_on(e, e->tiers.delta_table(), e->tier_delta, blob, offs, n, st2.data(), &dof, &dt, &nd);
+        if (rc != RGR_OK) return rc;
+        for (uint32_t i = 0; i < n; ++i) if (st2[i] != status[i]) return RGR_ESTATE;
+    }
+    std::vector<uint32_t> bids(nb), bfl(nb), dids(nd);
+    for (uint64_t k = 0; k < nb; ++k) { bids[k] = bt[k].sub_id; bfl[k] = bt[k].qos_flags; }
+    for (uint64_t k = 0; k < nd; ++k) dids[k] = dt[k].sub_id;
+    std::vector<uint64_t> oo;
+    std::vector<uint32_t> oi;
+    merge_tier_hits(n, bo, bids.data(), bfl.data(), dof, dids.data(), oo, oi);
+    std::free(bo); std::free(bt); std::free(dof); std::free(dt);
+    *hit_offsets_out = dup(oo);
+    *ids_out = dup(oi);
+    *n_hits_out = oi.size();
+    return RGR_OK;
 }
 
 }  // extern "C"

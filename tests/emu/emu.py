@@ -48,6 +48,11 @@ def lib():
         L.emu_retain_remove.argtypes = [vp, C.c_char_p, u32]
         L.emu_retain_topics.argtypes = [vp]; L.emu_retain_topics.restype = u64
         L.emu_retain_version.argtypes = [vp]; L.emu_retain_version.restype = u64
+        L.emu_tier_add.argtypes = [vp, C.c_char_p, u32, u32]
+        L.emu_tier_remove.argtypes = [vp, C.c_char_p, u32]
+        L.emu_tier_counter.argtypes = [vp, C.c_int]; L.emu_tier_counter.restype = u64
+        L.emu_tier_commit.argtypes = [vp, u64]
+        L.emu_tier_match.argtypes = [vp, vp, vp, u32, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
         L.emu_retain_nodes.argtypes = [vp]; L.emu_retain_nodes.restype = u64
         L.emu_retain_add_bulk.argtypes = [vp, vp, vp, u64, vp, C.POINTER(u64)]
         L.emu_retain_match.argtypes = [vp, vp, vp, u32, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
@@ -161,6 +166,35 @@ class EmuRouter:
     # ---- retain twin (same surface as capi.Router)
     def retain_add(self, topic, topic_id):
         t = _b(topic); return lib().emu_retain_add(self._h, t, len(t), topic_id)
+
+    # ---- two-tier retained set (what rgr_config.retain_delta_max > 0 turns on in the product)
+    def tier_add(self, topic, topic_id):
+        t = _b(topic)
+        return lib().emu_tier_add(self._h, t, len(t), topic_id)
+
+    def tier_remove(self, topic):
+        t = _b(topic)
+        return lib().emu_tier_remove(self._h, t, len(t))
+
+    def tier_commit(self, delta_max):
+        rc = lib().emu_tier_commit(self._h, delta_max)
+        assert rc == 0, rc
+
+    def tier_counters(self):
+        names = ["n_topics", "n_delta", "n_dead", "merges", "delta_compiles"]
+        return {k: int(lib().emu_tier_counter(self._h, i)) for i, k in enumerate(names)}
+
+    def tier_match_batch(self, blob, offsets):
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        blob = np.ascontiguousarray(np.frombuffer(bytes(blob), dtype=np.uint8) if not isinstance(blob, np.ndarray) else blob)
+        n = len(offsets) - 1
+        status = np.zeros(n, dtype=np.int32)
+        ho, ids = C.c_void_p(), C.c_void_p()
+        nh = C.c_uint64(0)
+        rc = lib().emu_tier_match(self._h, blob.ctypes.data if len(blob) else None, offsets.ctypes.data, n, status.ctypes.data,
+                                  C.byref(ho), C.byref(ids), C.byref(nh))
+        assert rc == 0, rc
+        return dict(status=status, hit_offsets=_take(ho, n + 1, np.uint64), topic_ids=_take(ids, nh.value, np.uint32))
 
     def retain_version(self):
         return int(lib().emu_retain_version(self._h))
