@@ -122,6 +122,13 @@ typedef struct rgr_config {
     uint32_t collect_walk_stats;/* nonzero: count visited trie nodes in the walk kernel */
     uint32_t host_tokenize;     /* nonzero: tokenise topics on the host (threads above) instead
                                    of with the device tokeniser kernels                  */
+    uint32_t retain_delta_max;  /* retained-topic twin in two tiers: 0 = off —
+                                   one compiled table, every structural change recompiles it;
+                                   N > 0 = topics added since the last full compile live in a
+                                   small DELTA table (recompiled alone), removed ones get a dead
+                                   bit, and the tiers are merged when the delta exceeds N topics
+                                   or a quarter of the base is dead                          */
+    uint32_t _reserved0;
 } rgr_config;
 
 /* One emitted hit: exactly the (topic_idx, subscriber_id, qos) tuple of BASELINE.json. */
@@ -194,6 +201,8 @@ typedef struct rgr_stats {
     /* retained-topic twin: id of the current retain epoch (0 = none; unchanged by a
      * rgr_retain_commit that found nothing to do) and its topic count */
     uint64_t retain_epoch, retain_topics;
+    /* two-tier mode: topics in the delta tier, dead base entries, full compiles so far */
+    uint64_t retain_delta_topics, retain_dead, retain_merges;
 } rgr_stats;
 
 /* ---- lifecycle ----------------------------------------------------------------- */
@@ -280,10 +289,19 @@ typedef void (*rgr_window_consumer)(void* user, uint32_t topic_begin, uint32_t t
                                     uint64_t n_hits);
 int32_t rgr_batch_run_to_host(rgr_batch* b, rgr_window_consumer consume, void* user, uint64_t* n_hits, uint32_t* n_windows);
 
+/* rgr_tuple.qos_flags bit of a retained-path hit whose topic was removed after the base tier was
+ * compiled (two-tier mode, device-resident windows only; rgr_retain_match_batch drops such hits) */
+#define RGR_RETAIN_HIT_DEAD 1u
+
 /* ---- retained-message twin (RetainTree) ----------------------------------------------- */
 /* Insert / replace a retained topic carrying caller value `topic_id`. */
 int32_t rgr_retain_topic_add(rgr_handle* h, const char* topic, uint32_t len, uint32_t topic_id);
 int32_t rgr_retain_topic_remove(rgr_handle* h, const char* topic, uint32_t len);
+/* Device-resident batch against ONE tier (two-tier mode): 0 = base, 1 = delta (RGR_ENOENT when the
+ * delta tier is empty).  The complete answer of a filter is its base hits without RGR_RETAIN_HIT_DEAD
+ * ones plus its delta hits.  rgr_retain_batch_create is tier 0. */
+int32_t rgr_retain_batch_create_tier(rgr_handle* h, const uint8_t* filters_blob, const uint64_t* filter_offsets, uint32_t n,
+                                     uint32_t tier, rgr_batch** out);
 int32_t rgr_retain_add_bulk(rgr_handle* h, const uint8_t* blob, const uint64_t* offsets, uint64_t n,
                             const uint32_t* topic_ids, uint64_t* n_rejected);
 int32_t rgr_retain_commit(rgr_handle* h);

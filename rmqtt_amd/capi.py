@@ -32,7 +32,7 @@ SYMBOLS = [
     "rgr_batch_begin", "rgr_batch_next_window",
     "rgr_window_to_host", "rgr_batch_run", "rgr_batch_run_to_host",
     "rgr_retain_topic_add", "rgr_retain_topic_remove", "rgr_retain_add_bulk", "rgr_retain_commit",
-    "rgr_retain_match_batch", "rgr_retain_result_free", "rgr_retain_batch_create",
+    "rgr_retain_match_batch", "rgr_retain_result_free", "rgr_retain_batch_create", "rgr_retain_batch_create_tier",
     "rgr_shard_assign", "rgr_stats_get", "rgr_stats_reset",
 ]
 
@@ -40,7 +40,7 @@ SYMBOLS = [
 class Config(C.Structure):
     _fields_ = [("device", C.c_int32), ("slot_cap", C.c_uint32), ("window_hits", C.c_uint64),
                 ("chunk_topics", C.c_uint32), ("host_threads", C.c_uint32), ("collect_walk_stats", C.c_uint32),
-                ("host_tokenize", C.c_uint32)]
+                ("host_tokenize", C.c_uint32), ("retain_delta_max", C.c_uint32), ("_reserved0", C.c_uint32)]
 
 
 class Result(C.Structure):
@@ -71,7 +71,8 @@ class Stats(C.Structure):
                 [(n, C.c_double) for n in ("walk_ms", "scan_ms", "expand_ms", "tokenize_ms", "h2d_ms", "d2h_ms")] +
                 [(n, C.c_uint64) for n in ("alg_bytes_walk", "alg_bytes_expand", "commits_full", "commits_delta",
                                            "dedup_candidates", "dedup_launches")] +
-                [("dedup_ms", C.c_double), ("retain_epoch", C.c_uint64), ("retain_topics", C.c_uint64)])
+                [("dedup_ms", C.c_double)] +
+                [(n, C.c_uint64) for n in ("retain_epoch", "retain_topics", "retain_delta_topics", "retain_dead", "retain_merges")])
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}
@@ -131,6 +132,7 @@ def lib():
         L.rgr_retain_match_batch.argtypes = [vp, vp, vp, u32, C.POINTER(RetainResult)]
         L.rgr_retain_result_free.argtypes = [C.POINTER(RetainResult)]; L.rgr_retain_result_free.restype = None
         L.rgr_retain_batch_create.argtypes = [vp, vp, vp, u32, C.POINTER(vp)]
+        L.rgr_retain_batch_create_tier.argtypes = [vp, vp, vp, u32, u32, C.POINTER(vp)]
         L.rgr_shard_assign.argtypes = [vp, vp, u64, u32, i32, u32, vp]
         L.rgr_stats_get.argtypes = [vp, C.POINTER(Stats)]
         L.rgr_stats_reset.argtypes = [vp]
@@ -175,9 +177,10 @@ class Router:
     """One rgr_handle.  Thin: argument marshalling only."""
 
     def __init__(self, device=0, slot_cap=0, window_hits=0, chunk_topics=0, host_threads=0, collect_walk_stats=True,
-                 host_tokenize=False):
+                 host_tokenize=False, retain_delta_max=0):
         self._h = C.c_void_p()
-        cfg = Config(device, slot_cap, window_hits, chunk_topics, host_threads, int(collect_walk_stats), int(host_tokenize))
+        cfg = Config(device, slot_cap, window_hits, chunk_topics, host_threads, int(collect_walk_stats), int(host_tokenize),
+                     int(retain_delta_max), 0)
         _check(lib().rgr_create(C.byref(cfg), C.byref(self._h)))
 
     def close(self):
@@ -292,8 +295,8 @@ class Router:
     def batch(self, blob, offsets):
         return Batch(self, blob, offsets)
 
-    def retain_batch(self, blob, offsets):
-        return Batch(self, blob, offsets, retain=True)
+    def retain_batch(self, blob, offsets, tier=None):
+        return Batch(self, blob, offsets, retain=True, tier=tier)
 
     # ---- retain twin
     def retain_add(self, topic, topic_id):
@@ -342,12 +345,15 @@ class Router:
 class Batch:
     """Device-resident tokenised batch (rgr_batch_*)."""
 
-    def __init__(self, router, blob, offsets, retain=False):
+    def __init__(self, router, blob, offsets, retain=False, tier=None):
         self.router = router
         self.n = len(offsets) - 1
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         self._b = C.c_void_p()
         bp, bk = _blob_ptr(blob)
+        if retain and tier is not None:
+            _check(lib().rgr_retain_batch_create_tier(router._h, bp, offsets.ctypes.data, self.n, tier, C.byref(self._b)))
+            return
         create = lib().rgr_retain_batch_create if retain else lib().rgr_batch_create
         _check(create(router._h, bp, offsets.ctypes.data, self.n, C.byref(self._b)))
 

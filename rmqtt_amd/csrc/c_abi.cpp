@@ -124,6 +124,17 @@ struct rgr_handle {
     std::shared_ptr<RetainEpoch> retain_epoch;
     std::mutex retain_commit_mu;       // serialises rgr_retain_commit (the compile scratch and image are reused)
     RetainImage retain_img;
+    // two-tier mode (cfg.retain_delta_max > 0): `tiers` replaces retain_table, retain_epoch is the base tier
+    TieredRetain tiers;
+    std::shared_ptr<RetainEpoch> retain_delta_epoch;   // null while the delta tier is empty
+    std::shared_mutex retain_pair_mu;                  // shared: a query reads both tiers; exclusive: commit swaps the (base, delta) pair
+    RetainImage retain_delta_img;
+    uint64_t retain_merges = 0;
+    bool retain_tiered() const { return cfg.retain_delta_max > 0; }
+    // table that tokenises the filters of a retain batch of the given tier
+    const RetainTable& retain_tokenizer(uint32_t tier) const {
+        return !retain_tiered() ? retain_table : tier ? tiers.delta_table() : tiers.base_table();
+    }
 };
 
 struct rgr_batch {
@@ -152,6 +163,7 @@ struct rgr_batch {
     uint64_t arena_cap = 0;
     // pass state
     bool retain = false;             // batch of SUBSCRIBE filters against the retained-topic trie
+    uint32_t tier = 0;               // two-tier mode: 0 = base epoch, 1 = delta epoch
     std::shared_ptr<Epoch> epoch;
     std::shared_ptr<RetainEpoch> repoch;
     bool in_pass = false;
@@ -237,7 +249,7 @@ void tokenize_batch(rgr_handle* h, rgr_batch* b, const uint8_t* blob, const uint
             for (uint64_t i = lo; i < hi; ++i) {
                 const size_t mark = p.toks.size();
                 const std::string_view sv(reinterpret_cast<const char*>(blob) + offs[i], offs[i + 1] - offs[i]);
-                const uint8_t fl = b->retain ? h->retain_table.tokenize_filter(sv, p.toks) : h->table.tokenize_topic(sv, p.toks);
+                const uint8_t fl = b->retain ? h->retain_tokenizer(b->tier).tokenize_filter(sv, p.toks) : h->table.tokenize_topic(sv, p.toks);
                 p.flags.push_back(fl);
                 p.lens.push_back(uint32_t(p.toks.size() - mark));
             }
@@ -271,7 +283,7 @@ void tokenize_batch(rgr_handle* h, rgr_batch* b, const uint8_t* blob, const uint
     b->total_tokens = total;
     {
         std::shared_lock<std::shared_mutex> lk(b->retain ? h->retain_mu : h->table_mu);
-        b->dict_tokens = b->retain ? h->retain_table.dict().size() : h->table.dict_stamp();
+        b->dict_tokens = b->retain ? h->retain_tokenizer(b->tier).dict().size() : h->table.dict_stamp();
     }
     b->local.tokenize_ms += now_ms() - t0;
     const double t1 = now_ms();
@@ -811,7 +823,7 @@ int32_t rgr_commit(rgr_handle* h) {
 // `recycle`: take the workspace from the handle's pool (one-shot entry points); it goes back with
 // batch_release().  Public rgr_batch_create always builds a fresh one owned by the caller.
 static int32_t batch_create_impl(rgr_handle* h, const uint8_t* blob, const uint64_t* offs, uint32_t n, bool retain, rgr_batch** out,
-                                 bool recycle = false) {
+                                 bool recycle = false, uint32_t tier = 0) {
     return guarded([&]() -> int32_t {
         if (!h || !out || (n && (!blob || !offs))) return fail(RGR_EINVAL, "rgr_batch_create: bad argument");
         RGR_HIP(hipSetDevice(h->cfg.device));
@@ -827,6 +839,7 @@ static int32_t batch_create_impl(rgr_handle* h, const uint8_t* blob, const uint6
         b->h = h;
         b->n = n;
         b->retain = retain;
+        b->tier = retain ? tier : 0;
         b->deliver = false;
         b->in_pass = false; b->chunk_ready = false; b->cursor = 0; b->hits_before = 0;
         b->dict_tokens = ~0ull;
@@ -848,7 +861,8 @@ static int32_t batch_create_impl(rgr_handle* h, const uint8_t* blob, const uint6
             b->local.h2d_ms += now_ms() - t1;
             if (retain) {
                 std::shared_ptr<RetainEpoch> ep;
-                { std::lock_guard<std::mutex> g(h->epoch_mu); ep = h->retain_epoch; }
+                { std::lock_guard<std::mutex> g(h->epoch_mu); ep = tier ? h->retain_delta_epoch : h->retain_epoch; }
+                if (!ep && tier) return fail(RGR_ENOENT, "rgr_retain_batch_create_tier: the delta tier is empty");
                 if (!ep) return fail(RGR_ESTATE, "rgr_retain_batch_create: rgr_retain_commit has not been called");
                 tokenize_batch_device(b.get(), ep->dict);
             } else {
@@ -915,7 +929,8 @@ int32_t rgr_batch_begin(rgr_batch* b) {
         RGR_HIP(hipSetDevice(b->h->cfg.device));
         if (b->retain) {
             std::lock_guard<std::mutex> g(b->h->epoch_mu);
-            b->repoch = b->h->retain_epoch;
+            b->repoch = b->tier ? b->h->retain_delta_epoch : b->h->retain_epoch;
+            if (!b->repoch && b->tier) return fail(RGR_ENOENT, "rgr_batch_begin: the delta tier is empty");
             if (!b->repoch) return fail(RGR_ESTATE, "rgr_batch_begin: rgr_retain_commit has not been called");
         } else {
             b->epoch = current_epoch(b->h);
@@ -1316,6 +1331,13 @@ int32_t rgr_stats_get(rgr_handle* h, rgr_stats* out) {
             std::lock_guard<std::mutex> g(h->epoch_mu);
             out->retain_epoch = h->retain_epoch ? h->retain_epoch->id : 0;
             out->retain_topics = h->retain_epoch ? h->retain_epoch->n_topics : 0;
+            out->retain_merges = h->retain_merges;
+        }
+        if (h->retain_tiered()) {
+            std::shared_lock<std::shared_mutex> lk(h->retain_mu);
+            out->retain_topics = h->tiers.n_topics();
+            out->retain_delta_topics = h->tiers.n_delta();
+            out->retain_dead = h->tiers.n_dead();
         }
         {
             std::lock_guard<std::mutex> cg(h->commit_mu);

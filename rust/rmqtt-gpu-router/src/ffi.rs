@@ -29,6 +29,8 @@ pub struct rgr_config {
     pub host_threads: u32,
     pub collect_walk_stats: u32,
     pub host_tokenize: u32,
+    pub retain_delta_max: u32,
+    pub _reserved0: u32,
 }
 
 #[repr(C)]

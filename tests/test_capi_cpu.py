@@ -40,11 +40,20 @@ def test_library_contains_gfx950_code_object():
         assert kern in data
 
 
-def test_struct_layouts_match_header():
-    # sizes the Rust/ctypes side must agree with
-    assert C.sizeof(capi.Config) == 32
-    assert capi.TUPLE_DTYPE.itemsize == 12
-    assert C.sizeof(capi.Window) == 48
+def test_struct_layouts_match_header(tmp_path):
+    """sizeof of every struct of the header, from a C compiler, against the ctypes / numpy mirrors the
+    tests and bench use (the Rust side mirrors the same numbers)."""
+    import subprocess
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "rmqtt_gpu_router.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n",'
+                   "sizeof(rgr_config),sizeof(rgr_tuple),sizeof(rgr_window),sizeof(rgr_stats),sizeof(rgr_result),"
+                   "sizeof(rgr_filters_result),sizeof(rgr_retain_result),sizeof(rgr_publish_attr));return 0;}\n")
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert sizes == [C.sizeof(capi.Config), capi.TUPLE_DTYPE.itemsize, C.sizeof(capi.Window), C.sizeof(capi.Stats), C.sizeof(capi.Result),
+                     C.sizeof(capi.FiltersResult), C.sizeof(capi.RetainResult), capi.PUBLISH_ATTR_DTYPE.itemsize]
+    assert sizes[:3] == [40, 12, 48]
 
 
 @pytest.mark.skipif(has_gpu(), reason="a GPU is present")

@@ -4,6 +4,7 @@ The tier bookkeeping (`TieredRetain`, rmqtt_amd/csrc/retain.cpp) and the merge o
 answers (`merge_tier_hits`) are host code shared by the product and the emulator; these tests drive
 them through the emulator against the oracle's RetainTree under random add / replace / remove /
 commit sequences, with merges forced by a small delta limit."""
+import os
 import random
 
 import numpy as np
@@ -130,3 +131,47 @@ def tier_property(ops, delta_max, filters):
                 next_id += 1
     e.tier_commit(delta_max)
     check(e, t, filters)
+
+
+# ---- the same churn through the C ABI on the GPU (rgr_config.retain_delta_max > 0).  Written after
+# this round's GPU budget was spent: opt-in until it has been run once on a GPU (RGR_TEST_TIERED=1).
+@pytest.mark.gpu
+@pytest.mark.skipif(os.environ.get("RGR_TEST_TIERED") != "1", reason="two-tier mode not yet verified on a GPU; set RGR_TEST_TIERED=1")
+@pytest.mark.parametrize("delta_max", [1, 40, 10**6])
+def test_tiers_random_churn_hip(delta_max):
+    from rmqtt_amd import capi
+    rng = random.Random(delta_max + 7)
+    r = capi.Router(device=0, retain_delta_max=delta_max, window_hits=64)
+    t = orc.RetainTree()
+    levels = ["a", "b", "c", "", "$s", "+", "#"]
+    live = {}
+    next_id = 0
+    blob, offs = pack(FILTERS)
+    for rnd in range(40):
+        for _ in range(rng.randint(1, 25)):
+            x = rng.random()
+            if x < 0.6 or not live:
+                n = rng.randint(1, 4)
+                name = "/".join(rng.choice(levels[:5] if (rng.random() < 0.9 or delta_max == 10**6) else levels) for _ in range(n))
+                if orc.parse_topic(name) is None:
+                    continue
+                assert r.retain_add(name, next_id) == 0
+                t.insert(name, next_id)
+                live[name] = next_id
+                next_id += 1
+            else:
+                name = rng.choice(sorted(live))
+                assert r.retain_remove(name) == 0
+                t.remove(name)
+                del live[name]
+        r.retain_commit()
+        got = r.retain_match_batch(blob, offs)
+        st_, eo, ev, _ = t.match_batch(blob, offs)
+        assert np.array_equal(got["hit_offsets"], eo)
+        for a, b in zip(eo[:-1], eo[1:]):
+            assert sorted(got["topic_ids"][int(a):int(b)].tolist()) == sorted(ev[int(a):int(b)].tolist())
+        st = r.stats()
+        assert st["retain_topics"] == len(live)
+    st = r.stats()
+    if delta_max == 10**6:
+        assert st["retain_merges"] <= 3 and st["retain_delta_topics"] > 0
