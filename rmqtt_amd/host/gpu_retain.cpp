@@ -5,9 +5,10 @@
 
 namespace rmqtt {
 
-GpuRetainStorage::GpuRetainStorage(int device) {
+GpuRetainStorage::GpuRetainStorage(int device, uint32_t retain_delta_max) {
     rgr_config cfg{};
     cfg.device = device;
+    cfg.retain_delta_max = retain_delta_max;
     if (rgr_create(&cfg, &h_) != RGR_OK) h_ = nullptr;
 }
 GpuRetainStorage::~GpuRetainStorage() { if (h_) rgr_destroy(h_); }
@@ -89,9 +90,10 @@ size_t GpuRetainStorage::remove_expired_messages(int64_t now_ms) {
 }
 
 // ---- GpuMessageIndex (rmqtt-message-storage/src/ram.rs) ---------------------------------------
-GpuMessageIndex::GpuMessageIndex(int device) {
+GpuMessageIndex::GpuMessageIndex(int device, uint32_t retain_delta_max) {
     rgr_config cfg{};
     cfg.device = device;
+    cfg.retain_delta_max = retain_delta_max;
     if (rgr_create(&cfg, &h_) != RGR_OK) h_ = nullptr;
 }
 GpuMessageIndex::~GpuMessageIndex() { if (h_) rgr_destroy(h_); }

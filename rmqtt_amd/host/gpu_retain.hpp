@@ -26,7 +26,8 @@ struct Retain {                // types.rs `Retain`: the fields the index path c
 
 class GpuRetainStorage {
    public:
-    explicit GpuRetainStorage(int device = 0);
+    // retain_delta_max > 0: two-tier retained set (rgr_config.retain_delta_max)
+    explicit GpuRetainStorage(int device = 0, uint32_t retain_delta_max = 0);
     ~GpuRetainStorage();
     bool usable() const { return h_ != nullptr; }
     // `now_ms` / `expiry_ms` make TimedValue::is_expired (types.rs:2308-2338) testable: 0 = never expires.
@@ -62,7 +63,8 @@ using MsgID = uint64_t;
 
 class GpuMessageIndex {
    public:
-    explicit GpuMessageIndex(int device = 0);
+    // the index gains one leaf per stored message: this is the table the two-tier mode is for
+    explicit GpuMessageIndex(int device = 0, uint32_t retain_delta_max = 0);
     ~GpuMessageIndex();
     bool usable() const { return h_ != nullptr; }
     Result<bool> set(const TopicName& topic, MsgID msg_id);
