@@ -11,14 +11,29 @@ subscriptions with mixed '+'/'#' (seeded generator of SURVEY.md §8(d)), 10 M pu
 routed to their owner rank (strong scaling: total work fixed); ranks exchange per-rank
 hit counts (all-gather over RCCL), tuples stay on the owning GPU unless --gather tuples.
 
-One JSON line on rank 0: value = whole-job publish-topic matches/s; `roofline` for the
-dominant kernel (expand) from HIP events on the library's stream; `cpu_baseline` = the
-oracle (C++ restatement of DefaultRouter, "port") timed on this host on a bounded sample.
+One JSON line on rank 0:
+  value         whole-job publish-topic matches/s, tuples left in HBM
+  roofline      dominant kernel: `frac` = HBM bytes the PMC counters saw (FETCH_SIZE + WRITE_SIZE, two
+                separate rocprofv3 passes of this very script in --pmc-child mode) / HIP-event time /
+                8 TB/s; `alg_frac` = SURVEY §8(d)'s algorithmic bytes over the same time (its 8 B/hit
+                read term is served by L2/MALL for hot filters, so alg_frac can exceed frac — and 1)
+  parity_sample digests (count, sum, order-dependent sum, sum of squares of sub_id*4+qos per topic) of
+                the GPU's windows for a prefix of the batch against the oracle's for the same topics
+                on the FULL table; the line FAILS (exit 1) when they differ
+  cpu_baseline  the oracle's DefaultRouter::_matches-shaped pass ("port") on this host's cores over a
+                bounded prefix of the same batch
+  pcie_inclusive_matches_per_s   the same path with every window copied to pinned host memory
+  secondary     configs[1] and configs[4] (retained path) measured the same way in the same run
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -27,6 +42,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+T0 = time.time()
 
 
 def log(msg, rank=0):
@@ -34,7 +50,514 @@ def log(msg, rank=0):
         print(f"[bench +{time.time() - T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
-T0 = time.time()
+# ------------------------------------------------------------------------------------------- workload
+def gen_workload(cfg, scale, rank=0):
+    """Seeded inputs of BASELINE config `cfg`; cached under $TMPDIR so the --pmc-child
+    processes of the same run do not regenerate them."""
+    from rmqtt_amd import workload as wl
+    c = wl.CONFIGS[cfg]
+    n_sub = max(1, int(c["n_sub"] * scale))
+    n_pub = max(1, int(c["n_pub"] * scale))
+    cache = os.path.join(tempfile.gettempdir(), f"rgr_bench_wl_cfg{cfg}_{n_sub}_{n_pub}_u{os.getuid()}.npz")
+    if os.path.exists(cache):
+        try:
+            z = np.load(cache)
+            W = {k: z[k] for k in z.files}
+            W.update(cfg=cfg, n_sub=n_sub, n_pub=n_pub, retain=cfg == 5, c=c)
+            if "client" not in W:
+                W["client"] = W["qos"] = None
+            return W
+        except Exception:
+            pass
+    retain = cfg == 5
+    if retain:
+        # config 5: table = n_sub DISTINCT retained topics (publish generator), queries = n_pub wildcard SUBSCRIBE filters
+        log(f"config 5: generating {n_sub} retained topics / {n_pub} wildcard filters", rank)
+        blob, offs = wl.gen_topics(n_sub, wl.PUB_SEED + cfg, 0.01, c["p_blank"], c["fixed_depth"], distinct=True)
+        client = qos = None
+        tb, to, _, _ = wl.gen_subs(n_pub, wl.SUB_SEED + cfg, c["p_plus"], c["p_hash"], c["p_sys"], 0, c["fixed_depth"], force_wildcard=True)
+    else:
+        log(f"config {cfg}: generating {n_sub} subscriptions / {n_pub} publish topics", rank)
+        blob, offs, client, qos = wl.gen_subs(n_sub, wl.SUB_SEED + cfg, c["p_plus"], c["p_hash"], c["p_sys"], 0, c["fixed_depth"])
+        tb, to = wl.gen_topics(n_pub, wl.PUB_SEED + cfg, 0.01 if cfg != 1 else 0.0, c["p_blank"], c["fixed_depth"])
+    W = dict(blob=blob, offs=offs, tb=tb, to=to)
+    if not retain:
+        W.update(client=client, qos=qos)
+    if rank == 0 and n_sub >= 100_000:
+        try:
+            tmp = cache + f".{os.getpid()}.tmp.npz"
+            np.savez(tmp, **W)
+            os.replace(tmp, cache)
+        except OSError:
+            pass
+    W.update(cfg=cfg, n_sub=n_sub, n_pub=n_pub, retain=retain, c=c)
+    if retain:
+        W["client"] = W["qos"] = None
+    return W
+
+
+def prefix(W, n):
+    """First n query strings of the batch."""
+    from rmqtt_amd import shard
+    return shard.take(W["tb"], W["to"], np.arange(n))
+
+
+def build_table(r, W, blob, offs, sub_ids, qos, deliver_frac=-1.0):
+    from rmqtt_amd import capi
+    t = time.time()
+    if W["retain"]:
+        rej = r.retain_add_bulk(blob, offs)
+        r.retain_commit()
+    else:
+        flags = None
+        if deliver_frac >= 0:
+            drng = np.random.default_rng(11)
+            n = len(offs) - 1
+            is5 = drng.random(n) < deliver_frac
+            flags = (is5 * capi.RGR_SUB_V5 | (is5 & (drng.random(n) < 0.3)) * capi.RGR_SUB_NO_LOCAL |
+                     (is5 & (drng.random(n) < 0.5)) * capi.RGR_SUB_RAP).astype(np.uint8)
+        rej = r.subscribe_bulk(blob, offs, sub_ids, qos, flags)
+        if deliver_frac >= 0:
+            r.sub_attrs_bulk(W["client"].astype(np.uint32), W["client"].astype(np.uint32))     # one Id per client
+        r.commit()
+    return rej, time.time() - t
+
+
+# ------------------------------------------------------------------------------------------- GPU digests
+class _DevArr:      # zero-copy torch view of library-owned device memory
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def gpu_digests(batch, n_topics, retain):
+    """Per-topic digests of every window of one pass, reduced on the device (torch is plumbing here: the
+    tuples were produced by the library's kernels).  -> uint64 [n, 4] (router) / [n, 3] (retain), the same
+    definition as oracle.cpp's orc_router_match_digest / orc_retain_match_digest; plus structural checks of
+    the tuple stream (topic_idx column consistent with the CSR offsets)."""
+    import ctypes as C
+
+    import torch
+    from rmqtt_amd import capi
+    ncol = 3 if retain else 4
+    out = np.zeros((n_topics, ncol), dtype=np.uint64)
+    structure_ok = True
+    batch.begin()
+    while True:
+        w = batch.next_window()
+        if w is None:
+            break
+        nt = int(w.topic_end - w.topic_begin)
+        nh = int(w.n_hits)
+        offs = np.zeros(nt + 1, dtype=np.uint64)
+        capi._check(capi.lib().rgr_window_to_host(batch._b, C.byref(w), None, offs.ctypes.data))   # syncs the library's stream
+        if not nh:
+            continue
+        t = torch.as_tensor(_DevArr(w.d_tuples, (nh, 3), "<i4"), device="cuda")
+        d_off = torch.from_numpy(offs.astype(np.int64)).cuda()
+        local = t[:, 0].to(torch.int64) - int(w.topic_begin)
+        if int(local.min()) < 0 or int(local.max()) >= nt:
+            structure_ok = False
+            continue
+        start = d_off[local]
+        pos = torch.arange(nh, dtype=torch.int64, device="cuda")
+        structure_ok &= bool(((pos >= start) & (pos < d_off[local + 1])).all())      # tuple i belongs to the topic its column names
+        sid = t[:, 1].to(torch.int64) & 0xFFFFFFFF
+        acc = torch.zeros((ncol, nt), dtype=torch.int64, device="cuda")
+        acc[0].index_add_(0, local, torch.ones_like(sid))
+        if retain:
+            acc[1].index_add_(0, local, sid)
+            acc[2].index_add_(0, local, sid * sid)
+        else:
+            v = sid * 4 + (t[:, 2].to(torch.int64) & 0xFF)
+            acc[1].index_add_(0, local, v)
+            acc[2].index_add_(0, local, (pos - start + 1) * v)
+            acc[3].index_add_(0, local, v * v)
+        out[int(w.topic_begin):int(w.topic_end)] += acc.t().contiguous().cpu().numpy().view(np.uint64)
+        del t, local, start, pos, sid, acc
+    return out, structure_ok
+
+
+def parity_sample(r, o, W, n_p, threads):
+    """GPU digests vs oracle digests of the first n_p queries against the full table."""
+    sb, so = prefix(W, n_p)
+    t = time.time()
+    status, exp = o.match_digest(sb, so, threads)
+    cpu_s = time.time() - t
+    b = r.retain_batch(sb, so) if W["retain"] else r.batch(sb, so)
+    got, structure_ok = gpu_digests(b, n_p, W["retain"])
+    gst = b.status()
+    b.close()
+    same_status = bool(np.array_equal(gst < 0, status < 0))
+    bad = np.nonzero((got != exp).any(axis=1))[0]
+    ok = same_status and structure_ok and len(bad) == 0
+    rec = {"topics": int(n_p), "hits": int(exp[:, 0].sum()), "ok": bool(ok),
+           "digest": ("per filter: hits, sum(topic_id), sum(topic_id^2) mod 2^64 (set comparison: the reference's order is hash-map order)"
+                      if W["retain"] else
+                      "per topic: hits, sum(v), sum((k+1)*v) in canonical order, sum(v^2) mod 2^64, v = sub_id*4+qos"),
+           "table": "full", "oracle_s": round(cpu_s, 2)}
+    if not ok:
+        rec["first_bad_topic"] = int(bad[0]) if len(bad) else None
+        rec["status_equal"] = same_status
+        rec["tuple_structure_ok"] = bool(structure_ok)
+    return rec
+
+
+# ------------------------------------------------------------------------------------------- PMC traffic
+KCLASS = (("expand", "expand_kernel"), ("walk", "walk_kernel<false>"), ("retain", "retain_"))
+
+
+def run_pmc_children(args, phases):
+    """FETCH_SIZE and WRITE_SIZE of this run's kernels: two rocprofv3 passes (the TCC counters do not fit one)
+    over `bench.py --pmc-child`, which replays ONE pass of every phase.  Counters only + kernel trace — no
+    sys/hip/hsa trace domains.  -> {phase: {class: {"fetch_KiB", "write_KiB", "dispatches", "avg_us"}}} or None."""
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        log("pmc: rocprofv3 not found — roofline.traffic stays null")
+        return None
+    work = tempfile.mkdtemp(prefix="rgr_pmc_")
+    res = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            meta = os.path.join(work, f"{counter}.json")
+            cmd = [rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(work, counter), "-o", "pmc", "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", meta, "--pmc-phases", ",".join(phases),
+                   "--config", str(args.config), "--scale", str(args.scale), "--pmc-topics", str(args.pmc_topics)]
+            if args.window_hits:
+                cmd += ["--window-hits", str(args.window_hits)]
+            t = time.time()
+            env = dict(os.environ, TMPDIR=tempfile.gettempdir())
+            p = subprocess.run(cmd, cwd=tempfile.gettempdir(), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+            log(f"pmc: {counter} pass rc={p.returncode} in {time.time() - t:.0f}s")
+            if p.returncode != 0 or not os.path.exists(meta):
+                log("pmc: child failed: " + p.stderr.decode(errors="replace")[-600:])
+                return None
+            plan = json.load(open(meta))["phases"]
+            files = glob.glob(os.path.join(work, counter, "**", "*counter_collection.csv"), recursive=True)
+            rows = []
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") == counter:
+                        rows.append((int(row["Dispatch_Id"]), row["Kernel_Name"], float(row["Counter_Value"]),
+                                     int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
+            rows.sort()
+            for cls, needle in KCLASS:
+                seq = [x for x in rows if needle in x[1]]
+                at = 0
+                for ph in plan:
+                    # the retain_* kernels' dispatch count is only known from the trace: they all belong to the (one) retain phase
+                    k = (len(seq) if ph.get("retain") else 0) if cls == "retain" else int(ph["dispatches"].get(cls, 0))
+                    part = seq[at:at + k]
+                    at += k
+                    if len(part) != k:
+                        log(f"pmc: {counter}/{cls}: expected {k} dispatches in phase {ph['name']}, trace has {len(part)}")
+                        return None
+                    d = res.setdefault(ph["name"], {}).setdefault(cls, {"dispatches": k, "hits": ph["hits"], "topics": ph["topics"]})
+                    d[("fetch" if counter == "FETCH_SIZE" else "write") + "_KiB"] = sum(x[2] for x in part)
+                    d["avg_us_under_pmc"] = round(sum(x[3] for x in part) / max(1, k) / 1e3, 2)
+                if at != len(seq):
+                    log(f"pmc: {counter}/{cls}: {len(seq) - at} dispatches not attributed to a phase")
+                    return None
+        return res
+    except (subprocess.TimeoutExpired, OSError, KeyError, ValueError) as e:
+        log(f"pmc: failed ({e}) — roofline.traffic stays null")
+        return None
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
+def pmc_child(args):
+    """One pass per phase under rocprofv3's counters; writes how many dispatches of each kernel class every
+    phase issued so that the parent can split the counter rows."""
+    from rmqtt_amd import capi
+    phases = []
+    for name in args.pmc_phases.split(","):
+        cfg, scale = (args.config, args.scale) if name == "primary" else (int(name[6:]), 1.0)
+        W = gen_workload(cfg, scale)
+        r = capi.Router(device=0, window_hits=args.window_hits, collect_walk_stats=False)
+        build_table(r, W, W["blob"], W["offs"], np.arange(W["n_sub"], dtype=np.uint32), W["qos"])
+        n = min(W["n_pub"], args.pmc_topics)
+        sb, so = prefix(W, n) if n < W["n_pub"] else (W["tb"], W["to"])
+        b = r.retain_batch(sb, so) if W["retain"] else r.batch(sb, so)
+        r.stats_reset()
+        hits, _ = b.run()
+        st = r.stats()
+        # dispatches per class: one expand_kernel per window with hits; walk_kernel<false> once per chunk
+        # (router) — the retain path has no walk kernel, its retain_* kernels are counted as one class
+        disp = {"expand": int(st["expand_launches"]), "walk": 0 if W["retain"] else int(st["walk_launches"])}
+        phases.append({"name": name, "dispatches": disp, "hits": int(hits), "topics": int(n), "retain": bool(W["retain"])})
+        b.close(); r.close()
+    json.dump({"phases": phases}, open(args.pmc_child, "w"))
+
+
+def load_calibration():
+    """FETCH_SIZE scale factors per access pattern, measured with tools/membench.hip under rocprofv3
+    (profiles/pmc_calibration.json); 1.0 (raw) where no calibration exists."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_calibration.json")))
+    except (OSError, ValueError):
+        return {}
+
+
+# ------------------------------------------------------------------------------------------- one config
+def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_rank=0, dist=None, cdev="cuda"):
+    """Build the table of one BASELINE config, time `steps` passes, and (N=1) run the parity sample, the
+    PCIe-inclusive pass and the CPU baseline.  -> (record dict, phase info for the PMC children)."""
+    import torch
+    from rmqtt_amd import capi, shard
+    from rmqtt_amd import workload as wl
+
+    W = gen_workload(cfg, scale, rank)
+    c, n_sub, n_pub, retain = W["c"], W["n_sub"], W["n_pub"], W["retain"]
+    blob, offs, tb, to, client, qos = W["blob"], W["offs"], W["tb"], W["to"], W["client"], W["qos"]
+    sub_ids = np.arange(n_sub, dtype=np.uint32)
+    if world > 1 and retain:
+        raise SystemExit("config 5 (retained path) is a single-GPU config")
+    if world > 1:
+        f_owner = shard.assign(blob, offs, world, is_filter=True)
+        t_owner = shard.assign(tb, to, world, is_filter=False)
+        keep_f = np.nonzero((f_owner == rank) | (f_owner < 0))[0]
+        keep_t = np.nonzero(t_owner == rank)[0]
+        blob_r, offs_r = shard.take(blob, offs, keep_f)
+        tb_r, to_r = shard.take(tb, to, keep_t)
+        sub_ids_r, qos_r = sub_ids[keep_f], qos[keep_f]
+    else:
+        blob_r, offs_r, tb_r, to_r, sub_ids_r, qos_r = blob, offs, tb, to, sub_ids, qos
+    my_topics = len(to_r) - 1
+
+    # ---- table build + device-resident batch
+    deliver = args.deliver if (primary and world == 1 and not retain) else -1.0
+    r = capi.Router(device=local_rank, window_hits=args.window_hits, collect_walk_stats=True)
+    rej, build_s = build_table(r, W, blob_r, offs_r, sub_ids_r, qos_r, deliver)
+    st0 = r.stats()
+    if retain:
+        log(f"config {cfg}: retain table: {n_sub - rej} topics ({rej} names rejected by the parser), built in {build_s:.1f}s", rank)
+    else:
+        log(f"config {cfg}: table: {st0['n_filters']} filters, {st0['n_subs']} subs, {st0['n_nodes']} trie nodes, "
+            f"{st0['table_bytes_device'] / 2**30:.2f} GiB in HBM, built in {build_s:.1f}s (rejected {rej})", rank)
+    t = time.time()
+    batch = r.retain_batch(tb_r, to_r) if retain else r.batch(tb_r, to_r)
+    log(f"config {cfg}: batch: {my_topics} topics tokenised + uploaded in {time.time() - t:.1f}s", rank)
+    if deliver >= 0:
+        pa = np.zeros(my_topics, dtype=capi.PUBLISH_ATTR_DTYPE)
+        prng = np.random.default_rng(12)
+        pa["from_id"] = prng.choice(client.astype(np.uint32), size=my_topics)
+        pa["qos_retain"] = prng.integers(0, 3, size=my_topics) | (prng.integers(0, 2, size=my_topics) << 2)
+        batch.set_publish_attrs(pa)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step_gather_tuples():
+        """all-gatherv of every window's tuples (RCCL has no allgatherv: counts + padded all_gather)."""
+        hits = nwin = 0
+        batch.begin()
+        finished = False
+        while True:
+            w = None if finished else batch.next_window()
+            finished = w is None
+            done = torch.tensor([1 if w is None else 0], dtype=torch.int64, device=cdev)
+            dist.all_reduce(done, op=dist.ReduceOp.MIN)      # ranks own different window counts
+            if int(done.item()) == 1:
+                break
+            n = 0 if w is None else int(w.n_hits)
+            torch.cuda.synchronize()
+            local = torch.as_tensor(_DevArr(w.d_tuples, (n, 3), "<i4"), device="cuda") if n else torch.zeros((0, 3), dtype=torch.int32, device="cuda")
+            if cdev == "cpu":
+                local = local.cpu()
+            shard.allgatherv_tuples(local, world, rank, dist, cdev)
+            hits += n
+            nwin += 1
+        return hits, nwin
+
+    rank_hits = []          # per-rank hit counts of the last step (N>1, --gather counts): the shard imbalance
+
+    def step():
+        if world > 1 and args.gather == "tuples":
+            return step_gather_tuples()
+        hits, nwin = batch.run()      # synchronises the library's stream at the end of the pass
+        if world > 1 and args.gather != "none":
+            cnt = torch.tensor([hits], dtype=torch.int64, device=cdev)
+            allc = [torch.zeros_like(cnt) for _ in range(world)]
+            dist.all_gather(allc, cnt)
+            rank_hits[:] = [int(x.item()) for x in allc]
+        return hits, nwin
+
+    for _ in range(warmup):
+        step()
+    r.stats_reset()
+    barrier()
+    t_start = time.time()
+    hits = nwin = 0
+    for _ in range(steps):
+        hits, nwin = step()
+    barrier()
+    elapsed = time.time() - t_start
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        tot = torch.tensor([hits, my_topics], dtype=torch.int64, device=cdev)
+        dist.all_reduce(tot)
+        total_hits, total_topics = int(tot[0].item()), int(tot[1].item())
+    else:
+        total_hits, total_topics = hits, my_topics
+    st = r.stats()
+    if rank != 0:
+        batch.close(); r.close()
+        return None, None
+
+    K = steps
+    value = total_topics * K / elapsed
+    exp_s, walk_s = st["expand_ms"] / 1e3, st["walk_ms"] / 1e3
+    exp_gbs = st["alg_bytes_expand"] / exp_s / 1e9 if exp_s > 0 else 0.0
+    walk_gbs = st["alg_bytes_walk"] / walk_s / 1e9 if walk_s > 0 else 0.0
+    dominant = "expand_kernel" if exp_s >= walk_s else ("retain_rounds" if retain else "walk_kernel")
+    is_exp = dominant == "expand_kernel"
+    launches = st["expand_launches"] if is_exp else st["walk_launches"]
+    dom_s = exp_s if is_exp else walk_s
+    alg = exp_gbs if is_exp else walk_gbs
+    roofline = {"bound": "hbm", "kernel": dominant, "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                "alg_achieved": round(alg, 1), "alg_frac": round(alg / HBM_PEAK_GBS, 4),
+                "alg_note": "SURVEY 8(d) bytes (20 B/hit: 8 read + 12 written; 24 B/visited node + 8 B/matched filter + 4 B/level) over the same HIP-event "
+                            "time; the 8 B/hit read term is served by L2/MALL for hot filters, so alg_frac may exceed frac and 1.0",
+                "launches": int(launches), "avg_launch_ms": round(dom_s * 1e3 / max(1, launches), 4),
+                "alg_bytes_per_launch": int((st["alg_bytes_expand"] if is_exp else st["alg_bytes_walk"]) / max(1, launches)),
+                "hits_per_launch": int(st["hits"] / max(1, launches)) if is_exp else None,
+                "topics_per_launch": int(st["topics"] / max(1, launches)),
+                "walk_alg_GBps": round(walk_gbs, 1), "expand_alg_GBps": round(exp_gbs, 1)}
+
+    rec = {
+        "metric": f"publish-topic matches/sec with delivery stage (config {cfg}, scale {scale}, v5 fraction {deliver})" if deliver >= 0 else
+                  "publish-topic matches/sec @10M subs" if cfg in (3, 4) and scale == 1.0 else
+                  (f"retained-path SUBSCRIBE-filter matches/sec (config 5, scale {scale})" if retain else
+                   f"publish-topic matches/sec (config {cfg}, scale {scale})"),
+        "value": round(value, 1), "unit": "SUBSCRIBE-filter matches/s" if retain else "publish-topic matches/s",
+        "n_gpus": world, "steps": K, "warmup": warmup, "ms_per_step": round(elapsed * 1e3 / K, 3),
+        "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+        "dtype": "u32", "data": "synthetic",
+        "config": {"workload": (f"BASELINE.json configs[{cfg - 1}]: {n_sub} retained topics (publish generator, distinct), {n_pub} wildcard SUBSCRIBE filters "
+                                f"(config-3 filter generator, >=1 wildcard), seeds 0x{wl.PUB_SEED + cfg:X}/0x{wl.SUB_SEED + cfg:X}" if retain else
+                                f"BASELINE.json configs[{cfg - 1}]: {n_sub} subscriptions (p_plus/level {c['p_plus']}, p_hash {c['p_hash']}, "
+                                f"Zipf tokens s=1.1, Zipf clients s=1.0), {n_pub} publish topics, seeds 0x{wl.SUB_SEED + cfg:X}/0x{wl.PUB_SEED + cfg:X}"),
+                   "subscriptions": n_sub, "publishes": n_pub, "sharding": f"hash of the first {shard.KEY_LEVELS} levels x{world}" if world > 1 else "none",
+                   "gather": args.gather if world > 1 else "n/a", "windows_per_step": int(nwin)},
+        "hits_per_step": int(total_hits), "hits_per_s": round(total_hits * K / elapsed, 1),
+        "mean_hits_per_topic": round(total_hits / max(1, total_topics), 2),
+        "mean_visited_nodes_per_topic": round(st["visited_nodes"] / max(1, st["topics"]), 2),
+        "kernel_ms_per_step": {"walk": round(st["walk_ms"] / K, 3), "scan_compact_tiles": round(st["scan_ms"] / K, 3),
+                               "expand": round(st["expand_ms"] / K, 3)},
+        "alg_bytes_per_step": {"walk": int(st["alg_bytes_walk"] / K), "expand": int(st["alg_bytes_expand"] / K)},
+        "table": {"filters": int(st0["n_filters"]), "subs": int(st0["n_subs"]), "trie_nodes": int(st0["n_nodes"]),
+                  "hbm_bytes": int(st0["table_bytes_device"]), "host_build_s": round(build_s, 1)},
+        "roofline": roofline,
+    }
+    try:
+        if world > 1 and rank_hits and sum(rank_hits) > 0:
+            rec["shard_hits"] = rank_hits
+            rec["shard_imbalance_max_over_mean"] = round(max(rank_hits) * len(rank_hits) / sum(rank_hits), 3)
+    except Exception as e:      # reporting only: never fail the bench line over it
+        log(f"shard imbalance not reported: {e}", 0)
+    if deliver >= 0:
+        rec["delivery_stage"] = {"v5_fraction": deliver, "dedup_ms_per_step": round(st["dedup_ms"] / K, 3),
+                                 "dedup_candidates_per_step": int(st["dedup_candidates"] / K),
+                                 "dedup_launches_per_step": int(st["dedup_launches"] / K)}
+
+    hits_per_topic = max(1.0, total_hits / max(1, total_topics))
+    # ---- PCIe-inclusive rate: the same pass with every window copied into pinned host memory (bounded prefix:
+    # at config-3 fan-out a publish carries 178 KB of tuples, the full batch would be 1.8 TB over the link)
+    if world == 1 and not args.no_d2h and deliver < 0:
+        n_d = int(min(n_pub, max(1000, 6.0e9 / hits_per_topic)))        # ~72 GB of tuples at most
+        db, do = prefix(W, n_d) if n_d < n_pub else (tb, to)
+        b2 = r.retain_batch(db, do) if retain else r.batch(db, do)
+        b2.run_to_host()                           # warm the pinned staging ring
+        t = time.time()
+        h2, _ = b2.run_to_host()
+        dt = time.time() - t
+        b2.close()
+        rec["pcie_inclusive_matches_per_s"] = round(n_d / dt, 1)
+        rec["pcie_inclusive"] = {"sample": f"first {n_d} topics of the batch, every window streamed to pinned host memory (rgr_batch_run_to_host)",
+                                 "tuple_GBps": round(h2 * 12 / dt / 1e9, 2), "seconds": round(dt, 3)}
+
+    # ---- CPU baseline (reference-shaped port) + parity sample against the oracle on the full table (N=1 only)
+    if args.cpu_sample != 0 and world == 1 and deliver < 0:
+        from oracle import oracle as orc
+        cores = args.cpu_threads or os.cpu_count() or 1
+        t = time.time()
+        if retain:
+            o = orc.RetainTree()
+            o.insert_bulk(blob, offs)
+        else:
+            o = orc.DefaultRouter()
+            o.add_bulk(blob, offs, client, qos)
+        log(f"config {cfg}: oracle table built in {time.time() - t:.1f}s; cpu_baseline on {cores} threads", 0)
+        # bounded sample: ~15 s of CPU work at the oracle's measured rates (primary), ~5 s (secondary)
+        budget_hits = (3.5e7 if retain else 4.0e9) * cores / 256 * (1.0 if primary else 0.3)
+        n_s = args.cpu_sample if args.cpu_sample > 0 else int(min(n_pub, max(200 if retain else 2000, budget_hits / hits_per_topic)))
+        sb, so = prefix(W, n_s)
+        if retain:
+            sec, ost = o.match_timed(sb, so, cores, dynamic=True)
+            what = "RetainTree::matches (retain.rs:450-526), filters handed out one at a time"
+        else:
+            sec, ost = o.matches_timed(sb, so, cores)
+            what = ("DefaultRouter::_matches-shaped (router.rs:174-265: parse, trie walk, relations lookup, per-hit ref-counted clones into the "
+                    "collector; no canonicalising sort), chunks of 16 topics from an atomic cursor")
+        cpu = {"value": round(n_s / sec, 1), "unit": rec["unit"], "cores": cores, "kind": "port", "what": what,
+               "sample": f"first {n_s} queries of the same batch against the full {n_sub}-entry table, {ost['hits']} hits, {sec:.2f}s wall",
+               "hits_per_s": round(ost["hits"] / sec, 1)}
+        if cores > 1:      # SURVEY 8(d) also asks for the single-thread figure
+            n1 = max(20, min(n_s, int(n_s / cores * 0.15)))
+            s1b, s1o = prefix(W, n1)
+            sec1, ost1 = (o.match_timed(s1b, s1o, 1) if retain else o.matches_timed(s1b, s1o, 1))
+            cpu["single_thread"] = {"value": round(n1 / sec1, 1), "hits_per_s": round(ost1["hits"] / sec1, 1), "sample": f"first {n1} queries, {sec1:.2f}s wall"}
+        rec["cpu_baseline"] = cpu
+        if not args.no_parity:
+            n_p = int(min(n_s, max(256, (1.2e9 if primary else 4.0e8) / hits_per_topic)))
+            rec["parity_sample"] = parity_sample(r, o, W, n_p, cores)
+            log(f"config {cfg}: parity_sample {rec['parity_sample']}", 0)
+        del o
+    else:
+        rec["cpu_baseline"] = None
+
+    phase = {"st": st, "dominant": dominant, "retain": retain}
+    batch.close(); r.close()
+    return rec, phase
+
+
+def attach_traffic(rec, phase, pmc, cal):
+    """roofline.frac from the PMC children's counters of the dominant kernel, per launch like alg."""
+    rf = rec["roofline"]
+    if not pmc:
+        rf["traffic_note"] = "PMC passes unavailable in this run: frac not computed (alg_frac is the SURVEY 8(d) figure)"
+        return
+    cls = "expand" if rf["kernel"] == "expand_kernel" else ("retain" if phase["retain"] else "walk")
+    d = pmc.get(cls)
+    if not d or "fetch_KiB" not in d or "write_KiB" not in d or not d["dispatches"]:
+        rf["traffic_note"] = f"no PMC rows for {rf['kernel']}"
+        return
+    fs = float(cal.get(cls, {}).get("fetch_scale", 1.0))
+    ws = float(cal.get(cls, {}).get("write_scale", 1.0))
+    unit = d["hits"] if cls == "expand" else d["topics"]
+    f_b, w_b = d["fetch_KiB"] * 1024 * fs, d["write_KiB"] * 1024 * ws
+    per_unit = (f_b + w_b) / max(1, unit)
+    units_per_launch = rf["hits_per_launch"] if cls == "expand" else rf["topics_per_launch"]
+    traffic = per_unit * units_per_launch
+    ach = traffic / (rf["avg_launch_ms"] / 1e3) / 1e9 if rf["avg_launch_ms"] > 0 else 0.0
+    rf.update({"traffic": int(traffic), "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
+               "traffic_source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over {d['dispatches']} dispatches of this run's "
+                                 f"--pmc-child replay ({unit} {'hits' if cls == 'expand' else 'queries'})",
+               "traffic_per_unit_B": {"fetch_raw": round(d["fetch_KiB"] * 1024 / max(1, unit), 3), "fetch_scale": fs,
+                                      "write_raw": round(d["write_KiB"] * 1024 / max(1, unit), 3), "write_scale": ws,
+                                      "unit": "hit" if cls == "expand" else "query"},
+               "avg_launch_us_under_pmc": d.get("avg_us_under_pmc")})
+    other = "walk" if cls == "expand" else "expand"
+    o = pmc.get(other)
+    if o and "fetch_KiB" in o and "write_KiB" in o and o["dispatches"]:
+        ou = o["hits"] if other == "expand" else o["topics"]
+        rf[f"{other}_traffic_per_unit_B"] = {"fetch_raw": round(o["fetch_KiB"] * 1024 / max(1, ou), 3), "write_raw": round(o["write_KiB"] * 1024 / max(1, ou), 3),
+                                             "fetch_scale": float(cal.get(other, {}).get("fetch_scale", 1.0)),
+                                             "unit": "hit" if other == "expand" else "query"}
 
 
 def main():
@@ -45,15 +568,26 @@ def main():
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config number (1-based)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (non-headline runs only)")
     ap.add_argument("--gather", choices=["none", "counts", "tuples"], default="counts")
-    ap.add_argument("--cpu-sample", type=int, default=-1, help="topics in the CPU-baseline sample (0 = skip, -1 = auto)")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="queries in the CPU-baseline sample (0 = skip baseline and parity sample, -1 = auto)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--window-hits", type=int, default=0)
-    ap.add_argument("--d2h", action="store_true", help="also report the PCIe-inclusive rate (copies every window to host)")
+    ap.add_argument("--no-d2h", action="store_true", help="skip the PCIe-inclusive pass")
+    ap.add_argument("--d2h", action="store_true", help="(kept for compatibility: the PCIe-inclusive pass now runs by default)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity sample")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC passes (roofline.frac/traffic stay null)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] / configs[4] secondary records")
+    ap.add_argument("--secondary-steps", type=int, default=5)
+    ap.add_argument("--pmc-topics", type=int, default=2_000_000, help="queries per phase replayed under the counters")
+    ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-phases", default="primary", help=argparse.SUPPRESS)
     ap.add_argument("--deliver", type=float, default=-1.0, metavar="V5FRAC",
                     help="also run the delivery stage (SURVEY 8(f)-1): this fraction of the subscriptions is MQTT v5 "
                          "(No Local / RAP / per-client dedup); 0 = v3 only. Not the headline metric.")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo lets the N>1 logic be exercised on one GPU")
     args = ap.parse_args()
+
+    if args.pmc_child:
+        return pmc_child(args)
 
     import torch
     import torch.distributed as dist
@@ -77,256 +611,43 @@ def main():
         else:
             dist.init_process_group(args.dist_backend)
 
-    from rmqtt_amd import capi, shard
-    from rmqtt_amd import workload as wl
-
-    cfg = args.config
-    c = wl.CONFIGS[cfg]
-    n_sub = max(1, int(c["n_sub"] * args.scale))
-    n_pub = max(1, int(c["n_pub"] * args.scale))
-
-    retain = cfg == 5
-    # ---- synthetic inputs (identical on every rank: seeded)
-    if retain:
-        # config 5: table = n_sub DISTINCT retained topics (publish generator), queries = n_pub wildcard SUBSCRIBE filters
-        log(f"config 5: generating {n_sub} retained topics / {n_pub} wildcard filters", rank)
-        blob, offs = wl.gen_topics(n_sub, wl.PUB_SEED + cfg, 0.01, c["p_blank"], c["fixed_depth"], distinct=True)
-        client = qos = None
-        tb, to, _, _ = wl.gen_subs(n_pub, wl.SUB_SEED + cfg, c["p_plus"], c["p_hash"], c["p_sys"], 0, c["fixed_depth"], force_wildcard=True)
-    else:
-        log(f"config {cfg}: generating {n_sub} subscriptions / {n_pub} publish topics", rank)
-        blob, offs, client, qos = wl.gen_subs(n_sub, wl.SUB_SEED + cfg, c["p_plus"], c["p_hash"], c["p_sys"], 0, c["fixed_depth"])
-        tb, to = wl.gen_topics(n_pub, wl.PUB_SEED + cfg, 0.01 if cfg != 1 else 0.0, c["p_blank"], c["fixed_depth"])
-
-    sub_ids = np.arange(n_sub, dtype=np.uint32)
-    if world > 1 and retain:
-        raise SystemExit("config 5 (retained path) is a single-GPU config")
-    if world > 1:
-        f_owner = shard.assign(blob, offs, world, is_filter=True)
-        t_owner = shard.assign(tb, to, world, is_filter=False)
-        keep_f = np.nonzero((f_owner == rank) | (f_owner < 0))[0]
-        keep_t = np.nonzero(t_owner == rank)[0]
-        blob_r, offs_r = shard.take(blob, offs, keep_f)
-        tb_r, to_r = shard.take(tb, to, keep_t)
-        sub_ids_r, qos_r = sub_ids[keep_f], qos[keep_f]
-    else:
-        blob_r, offs_r, tb_r, to_r, sub_ids_r, qos_r = blob, offs, tb, to, sub_ids, qos
-    my_topics = len(to_r) - 1
-
-    # ---- table build + device-resident batch
-    r = capi.Router(device=local_rank, window_hits=args.window_hits, collect_walk_stats=True)
-    t = time.time()
-    if retain:
-        rej = r.retain_add_bulk(blob_r, offs_r)
-        r.retain_commit()
-    else:
-        deliver = args.deliver >= 0 and world == 1
-        flags_r = None
-        if deliver:
-            drng = np.random.default_rng(11)
-            is5 = drng.random(n_sub) < args.deliver
-            flags_r = (is5 * capi.RGR_SUB_V5 | (is5 & (drng.random(n_sub) < 0.3)) * capi.RGR_SUB_NO_LOCAL |
-                       (is5 & (drng.random(n_sub) < 0.5)) * capi.RGR_SUB_RAP).astype(np.uint8)
-        rej = r.subscribe_bulk(blob_r, offs_r, sub_ids_r, qos_r, flags_r)
-        if deliver:
-            r.sub_attrs_bulk(client.astype(np.uint32), client.astype(np.uint32))     # one Id per client
-        r.commit()
-    build_s = time.time() - t
-    st0 = r.stats()
-    if retain:
-        log(f"retain table: {n_sub - rej} topics ({rej} names rejected by the parser), built in {build_s:.1f}s", rank)
-    else:
-        log(f"table: {st0['n_filters']} filters, {st0['n_subs']} subs, {st0['n_nodes']} trie nodes, "
-            f"{st0['table_bytes_device'] / 2**30:.2f} GiB in HBM, built in {build_s:.1f}s (rejected {rej})", rank)
-    t = time.time()
-    batch = r.retain_batch(tb_r, to_r) if retain else r.batch(tb_r, to_r)
-    log(f"batch: {my_topics} topics tokenised + uploaded in {time.time() - t:.1f}s", rank)
-    if not retain and args.deliver >= 0 and world == 1:
-        pa = np.zeros(my_topics, dtype=capi.PUBLISH_ATTR_DTYPE)
-        prng = np.random.default_rng(12)
-        pa["from_id"] = prng.choice(client.astype(np.uint32), size=my_topics)
-        pa["qos_retain"] = prng.integers(0, 3, size=my_topics) | (prng.integers(0, 2, size=my_topics) << 2)
-        batch.set_publish_attrs(pa)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    class _DevTuples:   # zero-copy torch view of a window's device tuples
-        def __init__(self, ptr, n):
-            self.__cuda_array_interface__ = {"shape": (n, 3), "typestr": "<i4", "data": (ptr, False), "version": 2}
-
-    def step_gather_tuples():
-        """all-gatherv of every window's tuples (RCCL has no allgatherv: counts + padded all_gather)."""
-        hits = nwin = 0
-        batch.begin()
-        finished = False
-        while True:
-            w = None if finished else batch.next_window()
-            finished = w is None
-            done = torch.tensor([1 if w is None else 0], dtype=torch.int64, device=cdev)
-            dist.all_reduce(done, op=dist.ReduceOp.MIN)      # ranks own different window counts
-            if int(done.item()) == 1:
-                break
-            n = 0 if w is None else int(w.n_hits)
-            torch.cuda.synchronize()
-            local = torch.as_tensor(_DevTuples(w.d_tuples, n), device="cuda") if n else torch.zeros((0, 3), dtype=torch.int32, device="cuda")
-            if cdev == "cpu":
-                local = local.cpu()
-            shard.allgatherv_tuples(local, world, rank, dist, cdev)
-            hits += n
-            nwin += 1
-        return hits, nwin
-
-    rank_hits = []          # per-rank hit counts of the last step (N>1, --gather counts): the shard imbalance
-
-    def step():
-        if world > 1 and args.gather == "tuples":
-            return step_gather_tuples()
-        hits, nwin = batch.run()      # synchronises the library's stream at the end of the pass
-        if world > 1 and args.gather != "none":
-            cnt = torch.tensor([hits], dtype=torch.int64, device=cdev)
-            allc = [torch.zeros_like(cnt) for _ in range(world)]
-            dist.all_gather(allc, cnt)
-            rank_hits[:] = [int(x.item()) for x in allc]
-        return hits, nwin
-
-    for _ in range(args.warmup):
-        step()
-    r.stats_reset()
-    barrier()
-    t_start = time.time()
-    hits = nwin = 0
-    for _ in range(args.steps):
-        hits, nwin = step()
-    barrier()
-    elapsed = time.time() - t_start
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        tot = torch.tensor([hits, my_topics], dtype=torch.int64, device=cdev)
-        dist.all_reduce(tot)
-        total_hits, total_topics = int(tot[0].item()), int(tot[1].item())
-    else:
-        total_hits, total_topics = hits, my_topics
-    st = r.stats()
-
-    pcie = None
-    if args.d2h and rank == 0:
-        batch.run_to_host()                      # warm the pinned staging ring
-        t = time.time()
-        batch.run_to_host()
-        pcie = my_topics / (time.time() - t)
-
+    rec, phase = measure(args, args.config, args.scale, args.steps, args.warmup, True, rank, world, local_rank, dist, cdev)
     if rank != 0:
-        batch.close(); r.close()
         if world > 1:
             dist.destroy_process_group()
-        return
+        return 0
 
-    K = args.steps
-    value = total_topics * K / elapsed
-    # ---- roofline of the dominant kernel (expand): algorithmic bytes / HIP-event time
-    exp_s = st["expand_ms"] / 1e3
-    walk_s = st["walk_ms"] / 1e3
-    exp_gbs = st["alg_bytes_expand"] / exp_s / 1e9 if exp_s > 0 else 0.0
-    walk_gbs = st["alg_bytes_walk"] / walk_s / 1e9 if walk_s > 0 else 0.0
-    dominant = "expand_kernel" if exp_s >= walk_s else "walk_kernel"
-    ach = exp_gbs if dominant == "expand_kernel" else walk_gbs
-    launches = st["expand_launches"] if dominant == "expand_kernel" else st["walk_launches"]
-    dom_s = exp_s if dominant == "expand_kernel" else walk_s
-    # HBM traffic per launch from the PMC passes of profiles/collect_pmc.sh (FETCH_SIZE / WRITE_SIZE are
-    # collected in separate rocprofv3 runs, so they cannot be measured inside this process): measured
-    # bytes per hit x hits per launch.  null until a calibration file for this kernel exists.
-    traffic = None
-    try:
-        cal = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[dominant]
-        if dominant == "expand_kernel" and launches:
-            traffic = int((cal["write_bytes_per_hit"] + cal["fetch_bytes_per_hit"]) * st["hits"] / launches)
-        elif launches:
-            traffic = int(cal["bytes_per_topic"] * st["topics"] / launches)
-    except (OSError, KeyError, ValueError):
-        pass
-    roofline = {"bound": "hbm", "kernel": dominant, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "launches": int(launches), "avg_launch_ms": round(dom_s * 1e3 / max(1, launches), 4),
-                "alg_bytes_per_launch": int((st["alg_bytes_expand"] if dominant == "expand_kernel" else st["alg_bytes_walk"]) / max(1, launches)),
-                "walk_GBps": round(walk_gbs, 1), "expand_GBps": round(exp_gbs, 1)}
+    headline = world == 1 and args.deliver < 0
+    secondary = []
+    sec_phases = {}
+    if headline and not args.no_secondary and args.config == 3 and args.scale == 1.0:
+        for cfg in (2, 5):
+            try:
+                srec, sph = measure(args, cfg, 1.0, args.secondary_steps, 1, False)
+                secondary.append(srec)
+                sec_phases[f"config{cfg}"] = (srec, sph)
+            except Exception as e:        # a secondary record never takes the headline line down
+                log(f"secondary config {cfg} failed: {e!r}")
+                secondary.append({"config": {"workload": f"BASELINE.json configs[{cfg - 1}]"}, "error": repr(e)})
 
-    # ---- CPU baseline: the oracle ("port"), bounded sample of the same workload, this host's cores (N=1 only)
-    cpu = None
-    if args.cpu_sample != 0 and world == 1:
-        from oracle import oracle as orc
-        cores = args.cpu_threads or os.cpu_count() or 1
-        t = time.time()
-        if retain:
-            o = orc.RetainTree()
-            o.insert_bulk(blob, offs)
-        else:
-            o = orc.DefaultRouter()
-            o.add_bulk(blob, offs, client, qos)
-        log(f"cpu_baseline: oracle table built in {time.time() - t:.1f}s; timing on {cores} threads", 0)
-        hits_per_topic = max(1.0, total_hits / max(1, total_topics))
-        # bounded sample: about 20 s of CPU work at the oracle's measured rates
-        budget_hits = (3.5e7 if retain else 3.0e9) * cores / 256
-        n_s = args.cpu_sample if args.cpu_sample > 0 else int(min(n_pub, max(200 if retain else 2000, budget_hits / hits_per_topic)))
-        sb, so = shard.take(tb, to, np.arange(n_s))
-        sec, ost = o.match_timed(sb, so, cores)
-        cpu = {"value": round(n_s / sec, 1), "unit": "publish-topic matches/s", "cores": cores, "kind": "port",
-               "sample": f"first {n_s} publish topics of the same batch against the full {n_sub}-subscription table, "
-                         f"{ost['hits']} hits, {sec:.2f}s wall",
-               "hits_per_s": round(ost["hits"] / sec, 1)}
-        # SURVEY 8(d) also asks for the single-thread figure: a ~3 s prefix of the same sample on one core
-        if cores > 1:
-            n1 = max(20, min(n_s, int(n_s / cores * 0.15)))
-            s1b, s1o = shard.take(tb, to, np.arange(n1))
-            sec1, ost1 = o.match_timed(s1b, s1o, 1)
-            cpu["single_thread"] = {"value": round(n1 / sec1, 1), "hits_per_s": round(ost1["hits"] / sec1, 1),
-                                    "sample": f"first {n1} topics, {sec1:.2f}s wall"}
+    if headline and not args.no_pmc:
+        cal = load_calibration()
+        pmc = run_pmc_children(args, ["primary"] + list(sec_phases))
+        attach_traffic(rec, phase, pmc.get("primary") if pmc else None, cal)
+        for name, (srec, sph) in sec_phases.items():
+            attach_traffic(srec, sph, pmc.get(name) if pmc else None, cal)
+    if secondary:
+        rec["secondary"] = secondary
 
-    out = {
-        "metric": f"publish-topic matches/sec with delivery stage (config {cfg}, scale {args.scale}, v5 fraction {args.deliver})"
-                  if (args.deliver >= 0 and not retain and world == 1) else
-                  "publish-topic matches/sec @10M subs" if cfg in (3, 4) and args.scale == 1.0 else
-                  (f"retained-path SUBSCRIBE-filter matches/sec (config 5, scale {args.scale})" if retain else
-                   f"publish-topic matches/sec (config {cfg}, scale {args.scale})"),
-        "value": round(value, 1), "unit": "SUBSCRIBE-filter matches/s" if retain else "publish-topic matches/s",
-        "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(elapsed * 1e3 / K, 3),
-        "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
-        "dtype": "u32", "data": "synthetic",
-        "config": {"workload": f"BASELINE.json configs[{cfg - 1}]: {n_sub} subscriptions (p_plus/level {c['p_plus']}, p_hash {c['p_hash']}, "
-                               f"Zipf tokens s=1.1, Zipf clients s=1.0), {n_pub} publish topics, seeds 0x{wl.SUB_SEED + cfg:X}/0x{wl.PUB_SEED + cfg:X}",
-                   "subscriptions": n_sub, "publishes": n_pub, "sharding": f"hash of the first {shard.KEY_LEVELS} levels x{world}" if world > 1 else "none",
-                   "gather": args.gather if world > 1 else "n/a", "windows_per_step": int(nwin)},
-        "hits_per_step": int(total_hits), "hits_per_s": round(total_hits * K / elapsed, 1),
-        "mean_hits_per_topic": round(total_hits / max(1, total_topics), 2),
-        "mean_visited_nodes_per_topic": round(st["visited_nodes"] / max(1, st["topics"]), 2),
-        "kernel_ms_per_step": {"walk": round(st["walk_ms"] / K, 3), "scan_compact_tiles": round(st["scan_ms"] / K, 3),
-                               "expand": round(st["expand_ms"] / K, 3)},
-        "alg_bytes_per_step": {"walk": int(st["alg_bytes_walk"] / K), "expand": int(st["alg_bytes_expand"] / K)},
-        "table": {"filters": int(st0["n_filters"]), "subs": int(st0["n_subs"]), "trie_nodes": int(st0["n_nodes"]),
-                  "hbm_bytes": int(st0["table_bytes_device"]), "host_build_s": round(build_s, 1)},
-        "roofline": roofline, "cpu_baseline": cpu,
-    }
-    try:
-        if world > 1 and rank_hits and sum(rank_hits) > 0:
-            out["shard_hits"] = rank_hits
-            out["shard_imbalance_max_over_mean"] = round(max(rank_hits) * len(rank_hits) / sum(rank_hits), 3)
-    except Exception as e:      # reporting only: never fail the bench line over it
-        log(f"shard imbalance not reported: {e}", 0)
-    if args.deliver >= 0 and not retain and world == 1:
-        out["delivery_stage"] = {"v5_fraction": args.deliver, "dedup_ms_per_step": round(st["dedup_ms"] / K, 3),
-                                 "dedup_candidates_per_step": int(st["dedup_candidates"] / K),
-                                 "dedup_launches_per_step": int(st["dedup_launches"] / K)}
-    if pcie is not None:
-        out["pcie_inclusive_matches_per_s"] = round(pcie, 1)
-    print(json.dumps(out), flush=True)
-    batch.close(); r.close()
+    print(json.dumps(rec), flush=True)
     if world > 1:
         dist.destroy_process_group()
+    bad = [r_ for r_ in [rec] + secondary if isinstance(r_.get("parity_sample"), dict) and not r_["parity_sample"]["ok"]]
+    if bad:
+        log("PARITY SAMPLE FAILED: the GPU's tuples differ from the oracle's")
+        return 1
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -121,7 +121,8 @@ typedef struct rgr_config {
     uint32_t host_threads;      /* tokeniser threads (0 = hardware concurrency)         */
     uint32_t collect_walk_stats;/* nonzero: count visited trie nodes in the walk kernel */
     uint32_t host_tokenize;     /* nonzero: tokenise topics on the host (threads above) instead
-                                   of with the device tokeniser kernels                  */
+                                   of with the device tokeniser kernels (two-tier retain
+                                   batches are always tokenised on the device)           */
     uint32_t retain_delta_max;  /* retained-topic twin in two tiers: 0 = off —
                                    one compiled table, every structural change recompiles it;
                                    N > 0 = topics added since the last full compile live in a

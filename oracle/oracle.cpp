@@ -175,6 +175,44 @@ bool DefaultRouter::match_flat(uint32_t topic_idx, std::string_view topic_name, 
     return true;
 }
 
+// Reference-shaped publish match for the cpu_baseline leg (see orc_router_matches_timed): the work
+// of router.rs:174-265 per hit, results dropped at the end of the call like the caller's map.
+void DefaultRouter::prepare_shaped() {
+    if (shaped_ready_ == relations_count_ && !shaped_.empty()) return;
+    shaped_.clear();
+    for (auto& kv : relations_) {
+        auto& dst = shaped_[kv.first];
+        for (auto& r : kv.second.rels) dst.rels.push_back(ShapedEntry{std::make_shared<const std::string>(r.first), &r.second});
+    }
+    shaped_ready_ = relations_count_;
+}
+
+uint64_t DefaultRouter::matches_shaped(const Id& this_id, std::string_view topic_name, WalkStats* st) const {
+    struct Out { std::shared_ptr<const std::string> filter, client; SubscriptionOptions opts; };
+    Topic topic;
+    if (!parse_topic(topic_name, topic)) { if (st) st->invalid++; return 0; }            // router.rs:177
+    if (st) st->levels += topic.size();
+    std::unordered_map<NodeId, std::vector<Out>> collector_map;                          // router.rs:176
+    uint64_t hits = 0;
+    for (auto& item : topics_.matches(topic, st)) {                                      // router.rs:178
+        // router.rs:179: `to_topic_filter()` builds a FRESH ByteString per matched filter per publish, so the
+        // per-hit `topic_filter.clone()` (types.rs:520) bumps a refcount private to this call; only the ClientId
+        // clone (router.rs:224) touches a counter shared with other threads.
+        const auto filter = std::make_shared<const std::string>(join_levels(item.first));
+        auto rit = shaped_.find(*filter);                                                // router.rs:194
+        if (rit == shaped_.end()) continue;
+        for (auto& e : rit->second.rels) {                                               // container order
+            const Rel& rel = *e.rel;
+            auto nl = rel.opts.opt_no_local();
+            if (nl && *nl && this_id == rel.id) continue;                                // router.rs:196-201
+            collector_map[rel.id.node_id].push_back(Out{filter, e.client, rel.opts});    // router.rs:222-229
+            ++hits;
+        }
+    }
+    if (st) st->hits += hits;
+    return hits;                                                                         // map dropped here: the clones are released
+}
+
 bool DefaultRouter::has_matches(std::string_view t) const {
     Topic topic;
     if (!parse_topic(t, topic)) return false;
@@ -514,6 +552,136 @@ double orc_router_match_timed(void* r, const char* blob, const uint64_t* offs, u
     WalkStats tot;
     for (auto& s : sts) tot.add(s);
     if (stats) *stats = orc_stats{tot.levels, tot.visited, tot.matched, tot.hits, tot.invalid};
+    return sec;
+}
+
+
+// ---- per-topic digests (bench.py `parity_sample`, full-size GPU tests) ---------------------------
+// The flat result of 10^5 topics at config-3 fan-out is ~10^9 hits: too big to hand over, so the
+// checker compares digests instead.  Per topic four u64 (arithmetic mod 2^64):
+//   [0] hit count
+//   [1] sum of v          where v = sub_id * 4 + qos            (order-independent)
+//   [2] sum of (k+1) * v  with k = position of the hit inside the topic's list, in the canonical
+//                         order of SURVEY.md App. A.5 (filters in TopicTree::matches order, sub_id
+//                         ascending inside a filter)             (order-DEPENDENT)
+//   [3] sum of v * v                                             (order-independent)
+// Invalid topics give zeros and status -1.  Threads share the read-only table, dynamic chunks.
+void orc_router_match_digest(void* r, const char* blob, const uint64_t* offs, uint64_t n, int threads, int32_t* status, uint64_t* out) {
+    auto* rt = static_cast<DefaultRouter*>(r);
+    if (threads < 1) threads = 1;
+    std::atomic<uint64_t> next{0};
+    auto work = [&] {
+        std::vector<FlatHit> hits;
+        for (;;) {
+            const uint64_t lo = next.fetch_add(16), hi = std::min<uint64_t>(n, lo + 16);
+            if (lo >= n) break;
+            for (uint64_t i = lo; i < hi; ++i) {
+                hits.clear();
+                const bool ok = rt->match_flat(uint32_t(i), std::string_view(blob + offs[i], offs[i + 1] - offs[i]), hits, nullptr);
+                status[i] = ok ? 0 : -1;
+                uint64_t s1 = 0, s2 = 0, s3 = 0;
+                for (size_t k = 0; k < hits.size(); ++k) {
+                    const uint64_t v = uint64_t(hits[k].sub_id) * 4 + hits[k].qos;
+                    s1 += v; s2 += uint64_t(k + 1) * v; s3 += v * v;
+                }
+                out[4 * i] = hits.size(); out[4 * i + 1] = s1; out[4 * i + 2] = s2; out[4 * i + 3] = s3;
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int k = 0; k < threads; ++k) th.emplace_back(work);
+    for (auto& t : th) t.join();
+}
+
+// RetainTree::matches digests, per filter three u64: [0] hits, [1] sum of ids, [2] sum of id * id.
+// Order-independent only: the reference's own order is hash-map order (retain.rs:485, 504).
+void orc_retain_match_digest(void* t, const char* blob, const uint64_t* offs, uint64_t n, int threads, int32_t* status, uint64_t* out) {
+    auto* tree = static_cast<RetainTree<int64_t>*>(t);
+    if (threads < 1) threads = 1;
+    std::atomic<uint64_t> next{0};
+    auto work = [&] {
+        for (;;) {
+            const uint64_t lo = next.fetch_add(4), hi = std::min<uint64_t>(n, lo + 4);
+            if (lo >= n) break;
+            for (uint64_t i = lo; i < hi; ++i) {
+                Topic tp;
+                out[3 * i] = out[3 * i + 1] = out[3 * i + 2] = 0;
+                if (!parse_topic(std::string_view(blob + offs[i], offs[i + 1] - offs[i]), tp)) { status[i] = -1; continue; }
+                status[i] = 0;
+                uint64_t c = 0, s1 = 0, s2 = 0;
+                for (auto& kv : tree->matches(tp)) { const uint64_t v = uint64_t(kv.second); c++; s1 += v; s2 += v * v; }
+                out[3 * i] = c; out[3 * i + 1] = s1; out[3 * i + 2] = s2;
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int k = 0; k < threads; ++k) th.emplace_back(work);
+    for (auto& x : th) x.join();
+}
+
+// ---- cpu_baseline, reference-shaped -----------------------------------------------------------------
+// Times what DefaultRouter::_matches does per publish (router.rs:174-265) and nothing else: parse the
+// topic (:177), walk the trie (:178), re-join each matched filter (:179), look it up in `relations`
+// (:194), iterate its relation map in CONTAINER order (no canonicalising sort — that is test
+// infrastructure), No-Local check (:196-201), and per hit the collector's push of (filter, client,
+// opts) (:222-229, types.rs:510-521).  The reference's per-hit clones of TopicFilter / ClientId are
+// ByteString clones = atomic refcount bumps; the stand-in is a std::shared_ptr copy, which costs the
+// same atomic increment (and the matching decrement when the result map is dropped).  Threads model
+// tokio workers under the trie's RwLock read guard; topics are handed out in chunks of 16 from an
+// atomic cursor, so the Zipf hit distribution cannot strand a thread with the heavy topics.
+double orc_router_matches_timed(void* r, const char* blob, const uint64_t* offs, uint64_t n, int threads, orc_stats* stats) {
+    auto* rt = static_cast<DefaultRouter*>(r);
+    if (threads < 1) threads = 1;
+    rt->prepare_shaped();
+    std::vector<WalkStats> sts(threads);
+    std::atomic<uint64_t> next{0};
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    for (int k = 0; k < threads; ++k) {
+        th.emplace_back([&, k] {
+            Id nobody; nobody.node_id = 0;
+            for (;;) {
+                const uint64_t lo = next.fetch_add(16), hi = std::min<uint64_t>(n, lo + 16);
+                if (lo >= n) break;
+                for (uint64_t i = lo; i < hi; ++i)
+                    rt->matches_shaped(nobody, std::string_view(blob + offs[i], offs[i + 1] - offs[i]), &sts[k]);
+            }
+        });
+    }
+    for (auto& t : th) t.join();
+    double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    WalkStats tot;
+    for (auto& s : sts) tot.add(s);
+    if (stats) *stats = orc_stats{tot.levels, tot.visited, tot.matched, tot.hits, tot.invalid};
+    return sec;
+}
+
+// Dynamic-chunk variant of orc_retain_match_timed (same work per filter).
+double orc_retain_match_timed_dyn(void* t, const char* blob, const uint64_t* offs, uint64_t n, int threads, uint64_t* hits, uint64_t* visited) {
+    auto* tree = static_cast<RetainTree<int64_t>*>(t);
+    if (threads < 1) threads = 1;
+    std::vector<WalkStats> sts(threads);
+    std::atomic<uint64_t> next{0};
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    for (int k = 0; k < threads; ++k) {
+        th.emplace_back([&, k] {
+            for (;;) {
+                const uint64_t i = next.fetch_add(1);
+                if (i >= n) break;
+                Topic tp;
+                if (!parse_topic(std::string_view(blob + offs[i], offs[i + 1] - offs[i]), tp)) continue;
+                auto v = tree->matches(tp, &sts[k]);
+                (void)v;
+            }
+        });
+    }
+    for (auto& x : th) x.join();
+    double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    WalkStats tot;
+    for (auto& s : sts) tot.add(s);
+    if (hits) *hits = tot.hits;
+    if (visited) *visited = tot.visited;
     return sec;
 }
 

@@ -240,9 +240,18 @@ class DefaultRouter {   // router.rs:121-127
     int64_t relations_count() const { return relations_count_; }
     uint32_t filter_id_of(const std::string& f) const;
 
+    // cpu_baseline only (oracle.cpp: orc_router_matches_timed): the reference's per-publish work without the
+    // checker's canonicalisation; prepare_shaped() snapshots the relation maps with ref-counted strings.
+    void prepare_shaped();
+    uint64_t matches_shaped(const Id& this_id, std::string_view topic_name, WalkStats* st) const;
+
    private:
     struct Rel { Id id; SubscriptionOptions opts; uint32_t rel_id; };
     struct FilterEntry { uint32_t filter_id; std::unordered_map<std::string, Rel> rels; };
+    struct ShapedEntry { std::shared_ptr<const std::string> client; const Rel* rel; };
+    struct ShapedFilter { std::vector<ShapedEntry> rels; };
+    std::unordered_map<std::string, ShapedFilter> shaped_;
+    int64_t shaped_ready_ = -1;
     TopicTree<Unit> topics_;
     std::unordered_map<std::string, FilterEntry> relations_;   // AllRelationsMap, types.rs:476
     int64_t topics_count_ = 0, relations_count_ = 0;

@@ -81,6 +81,12 @@ def lib():
         L.orc_router_match_flat.restype = u64
         L.orc_router_match_timed.argtypes = [vp, vp, vp, u64, C.c_int, C.POINTER(OrcStats)]
         L.orc_router_match_timed.restype = C.c_double
+        L.orc_router_matches_timed.argtypes = [vp, vp, vp, u64, C.c_int, C.POINTER(OrcStats)]
+        L.orc_router_matches_timed.restype = C.c_double
+        L.orc_retain_match_timed_dyn.argtypes = [vp, vp, vp, u64, C.c_int, C.POINTER(u64), C.POINTER(u64)]
+        L.orc_retain_match_timed_dyn.restype = C.c_double
+        L.orc_router_match_digest.argtypes = [vp, vp, vp, u64, C.c_int, vp, vp]; L.orc_router_match_digest.restype = None
+        L.orc_retain_match_digest.argtypes = [vp, vp, vp, u64, C.c_int, vp, vp]; L.orc_retain_match_digest.restype = None
         _LIB = L
     return _LIB
 
@@ -202,11 +208,23 @@ class RetainTree:
         return int(lib().orc_retain_insert_bulk(self._h, _ptr(blob), offsets.ctypes.data, len(offsets) - 1,
                                                 None if ids is None else C.c_void_p(ids.ctypes.data)))
 
-    def match_timed(self, blob, offsets, threads=1):
+    def match_timed(self, blob, offsets, threads=1, dynamic=True):
+        """Timed RetainTree::matches over a batch on `threads` threads (cpu_baseline); `dynamic`: filters are
+        handed out one at a time from an atomic cursor instead of a static partition."""
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         h, v = C.c_uint64(0), C.c_uint64(0)
-        sec = lib().orc_retain_match_timed(self._h, _ptr(blob), offsets.ctypes.data, len(offsets) - 1, threads, C.byref(h), C.byref(v))
+        fn = lib().orc_retain_match_timed_dyn if dynamic else lib().orc_retain_match_timed
+        sec = fn(self._h, _ptr(blob), offsets.ctypes.data, len(offsets) - 1, threads, C.byref(h), C.byref(v))
         return float(sec), dict(hits=int(h.value), visited=int(v.value))
+
+    def match_digest(self, blob, offsets, threads=1):
+        """-> (status int32[n], digest uint64[n,3] = hits, sum of ids, sum of id^2 per filter)."""
+        n = len(offsets) - 1
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        status = np.zeros(n, dtype=np.int32)
+        out = np.zeros((n, 3), dtype=np.uint64)
+        lib().orc_retain_match_digest(self._h, _ptr(blob), offsets.ctypes.data, n, threads, status.ctypes.data, out.ctypes.data)
+        return status, out
 
     def match_batch(self, blob, offsets):
         n = len(offsets) - 1
@@ -288,10 +306,28 @@ class DefaultRouter:
                     qos=_take_arr(ps[3], tot, np.uint8), flags=_take_arr(ps[4], tot, np.uint8), stats=st.as_dict())
 
     def match_timed(self, blob, offsets, threads=1):
+        """Timed match_flat (the CHECKER's canonical form: sorts every relation list), static partition."""
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         st = OrcStats()
         sec = lib().orc_router_match_timed(self._h, _ptr(blob), offsets.ctypes.data, len(offsets) - 1, threads, C.byref(st))
         return float(sec), st.as_dict()
+
+    def matches_timed(self, blob, offsets, threads=1):
+        """Timed DefaultRouter::_matches-shaped pass (router.rs:174-265: no canonicalising sort, per-hit
+        ref-counted clones, dynamic chunks): the cpu_baseline figure."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        st = OrcStats()
+        sec = lib().orc_router_matches_timed(self._h, _ptr(blob), offsets.ctypes.data, len(offsets) - 1, threads, C.byref(st))
+        return float(sec), st.as_dict()
+
+    def match_digest(self, blob, offsets, threads=1):
+        """-> (status int32[n], digest uint64[n,4]) — see orc_router_match_digest (oracle.cpp)."""
+        n = len(offsets) - 1
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        status = np.zeros(n, dtype=np.int32)
+        out = np.zeros((n, 4), dtype=np.uint64)
+        lib().orc_router_match_digest(self._h, _ptr(blob), offsets.ctypes.data, n, threads, status.ctypes.data, out.ctypes.data)
+        return status, out
 
 
 def _ptr(buf):

@@ -6,6 +6,7 @@
 // Epochs are immutable device snapshots of the host table; a pass binds the epoch that
 // is current at rgr_batch_begin().
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
@@ -146,7 +147,8 @@ struct rgr_batch {
     DevBuf d_blob, d_offs, d_level_cnt;   // raw topics (device tokeniser)
     std::vector<uint8_t> h_blob;          // raw topics kept on the host (host tokeniser only)
     std::vector<uint64_t> h_offs;
-    uint64_t dict_tokens = ~0ull;         // dictionary size the batch was tokenised against
+    uint64_t dict_tokens = ~0ull;         // stamp of the dictionary the batch was tokenised against
+    bool host_tok = false;                // tokenised by the host threads (rgr_config.host_tokenize; never for two-tier retain batches)
     hipStream_t stream = nullptr;
     // chunk work buffers
     DevBuf slots, pair_cnt, hit_cnt, pair_live, hit_off, pair_base, ovf_list, ovf_base, scalars, arena;
@@ -681,6 +683,17 @@ int32_t rgr_commit(rgr_handle* h) {
         std::lock_guard<std::mutex> cg(h->commit_mu);
         auto prev = current_epoch(h);
         auto ep = std::make_shared<Epoch>();
+        // A commit that fails half way (device out of memory, HIP error) has already consumed the table's delta:
+        // every image is then marked for a full rebuild, so the NEXT commit publishes the complete table instead
+        // of silently missing the lost changes.
+        struct Recover {
+            rgr_handle* h; bool armed = true;
+            ~Recover() {
+                if (!armed) return;
+                for (int k = 0; k < 2; ++k) { if (h->edge_img[k]) h->edge_img[k]->need_full = true; if (h->filt_img[k]) h->filt_img[k]->need_full = true; }
+                h->sub_pool.reset(); h->host_desc.clear(); h->pool_garbage = 0;
+            }
+        } recover{h};
         {
             std::shared_lock<std::shared_mutex> lk(h->table_mu);
             HostTable::Delta delta;
@@ -812,6 +825,7 @@ int32_t rgr_commit(rgr_handle* h) {
             ep->edge_slots = edges.size();
             ep->bytes = ei.buf.bytes + fi.buf.bytes + h->sub_pool->buf.bytes + h->sub_pool->attr_buf.bytes;
         }
+        recover.armed = false;
         std::lock_guard<std::mutex> g(h->epoch_mu);
         ep->id = ++h->epoch_counter;
         h->epoch = ep;
@@ -844,7 +858,11 @@ static int32_t batch_create_impl(rgr_handle* h, const uint8_t* blob, const uint6
         b->in_pass = false; b->chunk_ready = false; b->cursor = 0; b->hits_before = 0;
         b->dict_tokens = ~0ull;
         b->epoch.reset(); b->repoch.reset();
-        if (h->cfg.host_tokenize) {
+        // two-tier retain batches are always tokenised on the device, against the dictionary image of the epoch
+        // they run on: no retain_mu on the query path (lock order, retain_abi.inc) and no host dictionary that a
+        // merge may replace under a reusable batch
+        b->host_tok = h->cfg.host_tokenize && !(retain && h->retain_tiered());
+        if (b->host_tok) {
             if (n) { b->h_blob.assign(blob + offs[0], blob + offs[n]); b->h_offs.assign(offs, offs + n + 1); for (auto& o : b->h_offs) o -= offs[0]; }
             else b->h_offs.assign(1, 0);
             tokenize_batch(h, b.get(), b->h_blob.data(), b->h_offs.data(), n);
@@ -937,7 +955,7 @@ int32_t rgr_batch_begin(rgr_batch* b) {
         }
         const uint64_t want = b->retain ? b->repoch->dict.n_tokens : b->epoch->dict->n_tokens;
         if (want != b->dict_tokens) {      // the dictionary grew since this batch was tokenised
-            if (b->h->cfg.host_tokenize) tokenize_batch(b->h, b, b->h_blob.data(), b->h_offs.data(), b->n);
+            if (b->host_tok) tokenize_batch(b->h, b, b->h_blob.data(), b->h_offs.data(), b->n);
             else tokenize_batch_device(b, b->retain ? b->repoch->dict : *b->epoch->dict);
         }
         b->in_pass = true;

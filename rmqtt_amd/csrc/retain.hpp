@@ -100,6 +100,9 @@ class TieredRetain {
     void compile_delta(RetainImage& out);      // topics added since the last merge
     struct Dead { uint32_t val_index, topic_id; };
     std::vector<Dead> take_dead() { std::vector<Dead> d; d.swap(pending_dead_); return d; }   // base entries to flag
+    // the same list left in place until the caller has applied it (a failed device patch must not lose it)
+    const std::vector<Dead>& pending_dead() const { return pending_dead_; }
+    void clear_pending_dead() { pending_dead_.clear(); }
     const RetainTable& base_table() const { return all_; }     // tokenises queries of the base tier
     const RetainTable& delta_table() const { return delta_; }
 

@@ -713,8 +713,21 @@ bool HostTable::load(const std::string& path, std::string* err) {
         t.filters_[i].node = fnode[i];
         t.filters_[i].subs.assign(subs.begin() + fdesc[i].begin, subs.begin() + fdesc[i].begin + fdesc[i].count);
     }
-    t.n_filters_ = h.n_filters; t.n_subs_ = h.n_subs; t.n_nodes_ = h.n_nodes; t.n_v5_ = h.n_v5;
-    t.edge_used_ = h.edge_used; t.edge_live_ = h.edge_live;
+    // the counters are recomputed from the arrays (the header's copies are only cross-checked): find_slot /
+    // insert_edge / the device probe loops terminate only while the table keeps empty slots, and the rehash
+    // thresholds read edge_used_ / edge_live_
+    uint64_t used = 0, live = 0, n_v5 = 0, live_filters = 0;
+    for (const EdgeEntry& e : t.edges_) { if (e.parent == kEdgeEmpty) continue; used++; if (e.parent != kEdgeTomb) live++; }
+    for (uint64_t i = 0; i < nf; ++i) if (fnode[i] != kNone) live_filters++;
+    for (const SubEntry& se : subs) if ((se.qos_flags >> 8) & kSubV5) n_v5++;
+    const uint64_t n_nodes = t.nodes_.size() - t.free_nodes_.size();
+    if (used * 2 > t.edges_.size()) return bad("edge table over its load limit");
+    if (t.free_nodes_.size() >= t.nodes_.size() || live + 1 != n_nodes) return bad("trie node count mismatch");
+    if (h.edge_used != used || h.edge_live != live || h.n_nodes != n_nodes || h.n_filters != live_filters || h.n_v5 != n_v5 ||
+        t.free_fids_.size() + live_filters != nf)
+        return bad("header counters do not match the arrays");
+    t.n_filters_ = live_filters; t.n_subs_ = total; t.n_nodes_ = n_nodes; t.n_v5_ = n_v5;
+    t.edge_used_ = used; t.edge_live_ = live;
     t.has_attrs_ = ha != 0;
     t.dict_gen_ = dict_gen_ + 1;
     t.delta_ = Delta{};

@@ -235,3 +235,60 @@ def test_delivery_stage_properties_at_scale():
     batch.begin()
     w = batch.next_window()
     assert np.array_equal(batch.window_to_host(w)[0]["qos_flags"], plain[0]["qos_flags"])
+
+
+def test_config5_full_size_sampled_oracle():
+    """BASELINE configs[4] at its FULL size (5 M retained topics x 1 M wildcard SUBSCRIBE filters, not
+    scaled by RMQTT_TEST_SCALE): every window of the full batch is checked structurally, and a random
+    sample of the filters is compared — as topic-id SETS, the reference's own order is hash-map order
+    (retain.rs:485,504) — with the oracle's RetainTree::matches (retain.rs:457-526) on the full table."""
+    import ctypes as C
+    cfg = 5
+    c = wl.CONFIGS[cfg]
+    n_top, n_f = c["n_sub"], c["n_pub"]
+    blob, offs = wl.gen_topics(n_top, wl.PUB_SEED + cfg, 0.01, c["p_blank"], c["fixed_depth"], distinct=True)
+    fb, fo, _, _ = wl.gen_subs(n_f, wl.SUB_SEED + cfg, c["p_plus"], c["p_hash"], c["p_sys"], 0, c["fixed_depth"], force_wildcard=True)
+    r = capi.Router(device=0)
+    rej = r.retain_add_bulk(blob, offs)
+    r.retain_commit()
+    assert r.stats()["retain_topics"] == n_top - rej
+    batch = r.retain_batch(fb, fo)
+    cnt = np.zeros(n_f, dtype=np.int64)
+    total, prev_end, nwin = 0, 0, 0
+    batch.begin()
+    while True:
+        w = batch.next_window()
+        if w is None:
+            break
+        assert w.topic_begin == prev_end and w.topic_end > w.topic_begin and w.hit_base == total
+        prev_end = w.topic_end
+        ho = np.zeros(w.topic_end - w.topic_begin + 1, dtype=np.uint64)
+        capi._check(capi.lib().rgr_window_to_host(batch._b, C.byref(w), None, ho.ctypes.data))
+        assert ho[0] == 0 and ho[-1] == w.n_hits
+        cnt[w.topic_begin:w.topic_end] = np.diff(ho.astype(np.int64))
+        total += int(w.n_hits)
+        nwin += 1
+    assert prev_end == n_f and nwin > 3 and total == cnt.sum()
+    # sampled filters vs the oracle on the FULL retained set: a uniform sample plus the heaviest filters
+    rng = np.random.default_rng(5)
+    heavy = np.argsort(cnt)[-8:]
+    sample = np.unique(np.concatenate([rng.choice(n_f, size=600, replace=False), heavy]))
+    sb, so = wl.take(fb, fo, sample)
+    o = orc.RetainTree()
+    assert o.insert_bulk(blob, offs) == rej
+    st_, exp = o.match_digest(sb, so, os.cpu_count() or 1)
+    got = r.retain_match_batch(sb, so)
+    go = got["hit_offsets"].astype(np.int64)
+    assert np.array_equal(got["status"] < 0, st_ < 0)
+    assert np.array_equal(np.diff(go), exp[:, 0].astype(np.int64)), "per-filter hit counts differ from RetainTree::matches"
+    assert np.array_equal(cnt[sample], exp[:, 0].astype(np.int64)), "device-resident windows disagree with the host-buffer entry point"
+    ids = got["topic_ids"].astype(np.uint64)
+    for k in range(len(sample)):
+        x = ids[go[k]:go[k + 1]]
+        assert len(np.unique(x)) == len(x), f"filter {sample[k]}: a retained topic reported twice"
+        assert int(x.sum()) == int(exp[k, 1]) and int((x * x).sum()) == int(exp[k, 2]), f"filter {sample[k]}: topic-id set differs"
+    # exact sets for a handful (digest collisions aside, this is the same statement; cheap insurance)
+    st2, eo, ev, _ = o.match_batch(*wl.take(fb, fo, sample[:40]))
+    for k in range(40):
+        assert sorted(ids[go[k]:go[k + 1]].tolist()) == ev[int(eo[k]):int(eo[k + 1])].tolist()
+    batch.close(); r.close()

@@ -4,8 +4,8 @@ The tier bookkeeping (`TieredRetain`, rmqtt_amd/csrc/retain.cpp) and the merge o
 answers (`merge_tier_hits`) are host code shared by the product and the emulator; these tests drive
 them through the emulator against the oracle's RetainTree under random add / replace / remove /
 commit sequences, with merges forced by a small delta limit."""
-import os
 import random
+import threading
 
 import numpy as np
 import pytest
@@ -133,10 +133,8 @@ def tier_property(ops, delta_max, filters):
     check(e, t, filters)
 
 
-# ---- the same churn through the C ABI on the GPU (rgr_config.retain_delta_max > 0).  Written after
-# this round's GPU budget was spent: opt-in until it has been run once on a GPU (RGR_TEST_TIERED=1).
+# ---- the same churn through the C ABI on the GPU (rgr_config.retain_delta_max > 0)
 @pytest.mark.gpu
-@pytest.mark.skipif(os.environ.get("RGR_TEST_TIERED") != "1", reason="two-tier mode not yet verified on a GPU; set RGR_TEST_TIERED=1")
 @pytest.mark.parametrize("delta_max", [1, 40, 10**6])
 def test_tiers_random_churn_hip(delta_max):
     from rmqtt_amd import capi
@@ -175,3 +173,60 @@ def test_tiers_random_churn_hip(delta_max):
     st = r.stats()
     if delta_max == 10**6:
         assert st["retain_merges"] <= 3 and st["retain_delta_topics"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("host_tokenize", [False, True])
+def test_tiers_concurrent_commit_and_match_hip(host_tokenize):
+    """Queries from several threads while another thread adds / replaces / removes topics and commits:
+    no deadlock (lock order retain_mu -> retain_pair_mu, queries never take retain_mu in two-tier mode) and a
+    replaced topic is always answered with exactly one of its values — never missing, as
+    RetainTree::insert replaces atomically (retain.rs:384)."""
+    from rmqtt_amd import capi
+    r = capi.Router(device=0, retain_delta_max=10**6, host_tokenize=host_tokenize)
+    stable = [f"s/{i}/v" for i in range(300)]
+    for i, s in enumerate(stable):
+        assert r.retain_add(s, i) == 0
+    assert r.retain_add("x/hot", 10_000) == 0
+    r.retain_commit()
+    blob, offs = pack(["s/#", "x/+", "s/+/v", "x/hot"])
+    stop = threading.Event()
+    errors = []
+
+    def writer():
+        try:
+            k = 0
+            while not stop.is_set() and k < 400:
+                k += 1
+                assert r.retain_add("x/hot", 10_000 + k) == 0          # replace: old value dies in the base, new one lives in the delta
+                if k % 3 == 0:
+                    assert r.retain_add(f"t/{k}", 20_000 + k) == 0
+                if k % 7 == 0:
+                    assert r.retain_remove(f"t/{k - 4}") in (0, capi.RGR_ENOENT)
+                r.retain_commit()
+        except Exception as e:      # pragma: no cover
+            errors.append(e)
+        finally:
+            stop.set()
+
+    def reader():
+        try:
+            while not stop.is_set():
+                got = r.retain_match_batch(blob, offs)
+                o = got["hit_offsets"]
+                assert o[1] - o[0] == len(stable) and o[3] - o[2] == len(stable)
+                for a, b in ((o[1], o[2]), (o[3], o[4])):
+                    ids = got["topic_ids"][int(a):int(b)].tolist()
+                    assert len(ids) == 1 and ids[0] >= 10_000, f"x/hot answered with {ids}"
+        except Exception as e:      # pragma: no cover
+            errors.append(e)
+            stop.set()
+
+    th = [threading.Thread(target=writer)] + [threading.Thread(target=reader) for _ in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in th), "deadlock between rgr_retain_commit and rgr_retain_match_batch"
+    assert not errors, errors[0]
+    r.close()
