@@ -465,6 +465,30 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
                                  "dedup_launches_per_step": int(st["dedup_launches"] / K)}
 
     hits_per_topic = max(1.0, total_hits / max(1, total_topics))
+    # ---- opt-in compact result formats (SURVEY 8(b)'s SoA result; rgr_batch_set_format), reported BESIDE the 12-byte
+    # tuple headline, never instead of it: same hits, same order, topic implied by the CSR offsets
+    if world == 1 and deliver < 0 and not args.no_formats:
+        rec["compact_formats"] = []
+        for name, fmt, bph in (("soa: sub_id u32[] + qos u8[]", capi.RGR_FORMAT_SOA, 5), ("packed: sub_id | qos << 30 u32[]", capi.RGR_FORMAT_PACKED, 4)):
+            try:
+                batch.set_format(fmt)
+                batch.run()
+                r.stats_reset()
+                torch.cuda.synchronize()
+                t = time.time()
+                for _ in range(steps):
+                    h2, _ = batch.run()
+                dt = time.time() - t
+                s2 = r.stats()
+                rec["compact_formats"].append({
+                    "format": name, "bytes_written_per_hit": bph, "value": round(my_topics * steps / dt, 1), "unit": rec["unit"],
+                    "ms_per_step": round(dt * 1e3 / steps, 3), "hits_per_s": round(h2 * steps / dt, 1),
+                    "expand_avg_launch_ms": round(s2["expand_ms"] / max(1, s2["expand_launches"]), 4),
+                    "expand_store_GBps": round(h2 * steps * bph / max(1e-9, s2["expand_ms"] / 1e3) / 1e9, 1),
+                    "speedup_vs_tuple": round((my_topics * steps / dt) / value, 3)})
+            except capi.RgrError as e:
+                rec["compact_formats"].append({"format": name, "error": str(e)})
+        batch.set_format(capi.RGR_FORMAT_TUPLE)
     # ---- PCIe-inclusive rate: the same pass with every window copied into pinned host memory (bounded prefix:
     # at config-3 fan-out a publish carries 178 KB of tuples, the full batch would be 1.8 TB over the link)
     if world == 1 and not args.no_d2h and deliver < 0:
@@ -574,6 +598,7 @@ def main():
     ap.add_argument("--no-d2h", action="store_true", help="skip the PCIe-inclusive pass")
     ap.add_argument("--d2h", action="store_true", help="(kept for compatibility: the PCIe-inclusive pass now runs by default)")
     ap.add_argument("--no-parity", action="store_true", help="skip the parity sample")
+    ap.add_argument("--no-formats", action="store_true", help="skip the compact-result-format passes")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC passes (roofline.frac/traffic stay null)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] / configs[4] secondary records")
     ap.add_argument("--secondary-steps", type=int, default=5)

@@ -179,10 +179,24 @@ typedef struct rgr_window {
     uint32_t topic_begin, topic_end;  /* topics [begin,end) of the batch                */
     uint64_t n_hits;
     uint64_t hit_base;                /* hits emitted by earlier windows of this pass   */
-    const rgr_tuple* d_tuples;        /* [n_hits]                                       */
+    const rgr_tuple* d_tuples;        /* [n_hits]; NULL in the compact formats          */
     const uint64_t* d_hit_offsets;    /* [topic_end-topic_begin+1]                      */
     uint64_t offsets_bias;
+    /* compact result formats (rgr_batch_set_format), NULL in RGR_FORMAT_TUPLE */
+    const uint32_t* d_sub_ids;        /* [n_hits] sub_id (RGR_FORMAT_SOA) or sub_id | qos << 30 (RGR_FORMAT_PACKED) */
+    const uint8_t* d_qos;             /* [n_hits] RGR_FORMAT_SOA only: bits 0-1 qos, bits 2-7 = RGR_SUB_* flag bits 0-5 */
 } rgr_window;
+
+/* Result format of a device-resident batch.  The 12-byte tuple is BASELINE.json's (topic_idx, subscriber_id,
+ * qos) as written; its topic_idx column is redundant with d_hit_offsets, and at config-3 fan-out (14.8 k hits
+ * per publish) the tuple bytes ARE the cost of a publish.  The compact formats (the SoA result of SURVEY.md
+ * §8(b)) keep the same hits in the same order and leave the topic to the CSR offsets. */
+enum {
+    RGR_FORMAT_TUPLE = 0,             /* rgr_tuple[n_hits], 12 B/hit (default)                                   */
+    RGR_FORMAT_SOA = 1,               /* d_sub_ids u32[n_hits] + d_qos u8[n_hits], 5 B/hit                        */
+    RGR_FORMAT_PACKED = 2             /* d_sub_ids u32[n_hits] = sub_id | qos << 30, 4 B/hit; needs sub ids < 2^30
+                                         (rgr_batch_begin fails with RGR_ECAPACITY otherwise)                  */
+};
 
 typedef struct rgr_stats {
     /* table */
@@ -272,6 +286,9 @@ const int32_t* rgr_batch_status(const rgr_batch* b);
  * runs the delivery stage and emits delivery words (RGR_HIT_*) in rgr_tuple.qos_flags.
  * NULL detaches them.  RGR_ESTATE inside a pass or on a retain batch. */
 int32_t rgr_batch_set_publish_attrs(rgr_batch* b, const rgr_publish_attr* attrs);
+/* Choose the result format of later passes (RGR_FORMAT_*).  RGR_ESTATE inside a pass or together with
+ * publish attributes (the delivery word needs the full tuple). */
+int32_t rgr_batch_set_format(rgr_batch* b, uint32_t format);
 /* Start a pass over the batch (binds the current epoch, rewinds the window cursor). */
 int32_t rgr_batch_begin(rgr_batch* b);
 /* Walk (as needed) and expand the next window of topics.  RGR_EOF after the last. */

@@ -18,6 +18,7 @@ RGR_SUB_V5, RGR_SUB_NO_LOCAL, RGR_SUB_SHARED, RGR_SUB_RAP = 1, 2, 4, 8
 RGR_HIT_QOS_MASK, RGR_HIT_RETAIN, RGR_HIT_NO_LOCAL, RGR_HIT_V5_DUP = 3, 4, 8, 16
 ID_NONE = 0xFFFFFFFF
 RGR_SUB_TABLE_SHIFT, RGR_SUB_TABLE_MASK = 4, 0xF0     # flags bits 4-7: caller-defined table id
+RGR_FORMAT_TUPLE, RGR_FORMAT_SOA, RGR_FORMAT_PACKED = 0, 1, 2
 
 TUPLE_DTYPE = np.dtype([("topic_idx", np.uint32), ("sub_id", np.uint32), ("qos_flags", np.uint32)])
 PUBLISH_ATTR_DTYPE = np.dtype([("from_id", np.uint32), ("qos_retain", np.uint32)])
@@ -29,7 +30,7 @@ SYMBOLS = [
     "rgr_sub_remove", "rgr_subscribe_bulk", "rgr_snapshot_save", "rgr_snapshot_load", "rgr_commit",
     "rgr_match_batch", "rgr_match_batch_deliver", "rgr_result_free", "rgr_match_filters", "rgr_filters_result_free",
     "rgr_batch_create", "rgr_batch_destroy", "rgr_batch_status", "rgr_batch_set_publish_attrs",
-    "rgr_batch_begin", "rgr_batch_next_window",
+    "rgr_batch_set_format", "rgr_batch_begin", "rgr_batch_next_window",
     "rgr_window_to_host", "rgr_batch_run", "rgr_batch_run_to_host",
     "rgr_retain_topic_add", "rgr_retain_topic_remove", "rgr_retain_add_bulk", "rgr_retain_commit",
     "rgr_retain_match_batch", "rgr_retain_result_free", "rgr_retain_batch_create", "rgr_retain_batch_create_tier",
@@ -61,7 +62,7 @@ class RetainResult(C.Structure):
 class Window(C.Structure):
     _fields_ = [("topic_begin", C.c_uint32), ("topic_end", C.c_uint32), ("n_hits", C.c_uint64),
                 ("hit_base", C.c_uint64), ("d_tuples", C.c_void_p), ("d_hit_offsets", C.c_void_p),
-                ("offsets_bias", C.c_uint64)]
+                ("offsets_bias", C.c_uint64), ("d_sub_ids", C.c_void_p), ("d_qos", C.c_void_p)]
 
 
 class Stats(C.Structure):
@@ -121,6 +122,7 @@ def lib():
         L.rgr_batch_destroy.argtypes = [vp]; L.rgr_batch_destroy.restype = None
         L.rgr_batch_status.argtypes = [vp]; L.rgr_batch_status.restype = vp
         L.rgr_batch_begin.argtypes = [vp]
+        L.rgr_batch_set_format.argtypes = [vp, u32]
         L.rgr_batch_next_window.argtypes = [vp, C.POINTER(Window)]
         L.rgr_window_to_host.argtypes = [vp, C.POINTER(Window), vp, vp]
         L.rgr_batch_run.argtypes = [vp, C.POINTER(u64), C.POINTER(u32)]
@@ -378,6 +380,10 @@ class Batch:
         pa = np.ascontiguousarray(publish_attrs, dtype=PUBLISH_ATTR_DTYPE)
         assert len(pa) == self.n
         _check(lib().rgr_batch_set_publish_attrs(self._b, pa.ctypes.data))
+
+    def set_format(self, fmt):
+        """RGR_FORMAT_TUPLE (12 B/hit) | RGR_FORMAT_SOA (sub ids + qos bytes, 5 B/hit) | RGR_FORMAT_PACKED (4 B/hit)."""
+        _check(lib().rgr_batch_set_format(self._b, fmt))
 
     def run(self):
         """One full pass; tuples stay on the device.  -> (n_hits, n_windows)"""

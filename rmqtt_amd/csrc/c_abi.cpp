@@ -84,6 +84,7 @@ struct Epoch {
     std::shared_ptr<SubsPool> subs;
     TrieView view{};
     uint64_t id = 0, n_filters = 0, n_subs = 0, n_nodes = 0, edge_slots = 0, bytes = 0, n_v5 = 0;
+    uint32_t max_sub_id = 0;          // upper bound of the sub ids ever added (RGR_FORMAT_PACKED needs < 2^30)
 };
 
 struct RetainEpoch {
@@ -92,6 +93,7 @@ struct RetainEpoch {
     RetainView view{};
     TrieView tv{};       // filt = run descriptors, subs = values: what count/compact/expand read
     uint64_t id = 0, n_topics = 0, n_nodes = 0, bytes = 0, table_version = 0;
+    uint32_t max_id = 0;              // upper bound of the topic ids ever added
 };
 
 enum SpanKind { kSpanWalk = 0, kSpanScan = 1, kSpanExpand = 2, kSpanDedup = 3 };
@@ -119,6 +121,7 @@ struct rgr_handle {
     // recycled batch workspaces (stream + grow-only device buffers) for the one-shot entry points
     std::mutex pool_mu;
     std::vector<rgr_batch*> pool;
+    std::shared_ptr<PinnedPool> pinned = std::make_shared<PinnedPool>();   // result blocks of the host-buffer entry points
     // RetainTree twin
     std::shared_mutex retain_mu;
     RetainTable retain_table;
@@ -156,8 +159,17 @@ struct rgr_batch {
     DevBuf out2;                         // second window buffer (rgr_batch_run_to_host double-buffers)
     PinnedBuf h_ring[2];                 // pinned staging for streamed windows
     bool alt_out = false;                // next_window expands into out2 instead of out
+    // streamed passes (rgr_batch_run_to_host, rgr_match_batch): copy stream + per-slot events, created once
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_expanded[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
+    void ensure_stream_state() {
+        if (copy_stream) return;
+        RGR_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) { RGR_HIP(hipEventCreateWithFlags(&ev_expanded[k], hipEventDisableTiming)); RGR_HIP(hipEventCreateWithFlags(&ev_copied[k], hipEventDisableTiming)); }
+    }
     // delivery stage (rgr_batch_set_publish_attrs)
     bool deliver = false;
+    int format = kFmtTuple;              // rgr_batch_set_format
     DevBuf d_pub, pair_qr, cand, cand_count, dedup_tab, topic_cand, cand_off, dedup_tmp;
     PinnedBuf h_cand_count;
     DevBuf rf_filter[2], rf_node[2], r_cnt, r_payload, r_ecnt, r_e0, r_e1, r_out_off, r_epos, r_big, r_end, r_depth;   // retain frontier rounds
@@ -207,6 +219,8 @@ struct rgr_batch {
     ~rgr_batch() {
         for (auto& s : spans) { (void)hipEventDestroy(s.a); (void)hipEventDestroy(s.b); }
         for (auto e : event_pool) (void)hipEventDestroy(e);
+        for (int k = 0; k < 2; ++k) { if (ev_expanded[k]) (void)hipEventDestroy(ev_expanded[k]); if (ev_copied[k]) (void)hipEventDestroy(ev_copied[k]); }
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -819,6 +833,7 @@ int32_t rgr_commit(rgr_handle* h) {
             ep->view.subs = h->sub_pool->buf.as<SubEntry>();
             ep->view.attrs = h->sub_pool->has_attrs ? h->sub_pool->attr_buf.as<SubAttr>() : nullptr;
             ep->n_v5 = h->table.n_v5_subs();
+            ep->max_sub_id = h->table.max_sub_id();
             ep->n_filters = h->table.n_filters();
             ep->n_subs = h->table.n_subs();
             ep->n_nodes = h->table.n_nodes();
@@ -855,6 +870,7 @@ static int32_t batch_create_impl(rgr_handle* h, const uint8_t* blob, const uint6
         b->retain = retain;
         b->tier = retain ? tier : 0;
         b->deliver = false;
+        b->format = kFmtTuple;
         b->in_pass = false; b->chunk_ready = false; b->cursor = 0; b->hits_before = 0;
         b->dict_tokens = ~0ull;
         b->epoch.reset(); b->repoch.reset();
@@ -931,6 +947,7 @@ int32_t rgr_batch_set_publish_attrs(rgr_batch* b, const rgr_publish_attr* attrs)
         if (b->in_pass) return fail(RGR_ESTATE, "rgr_batch_set_publish_attrs: inside a pass");
         if (b->retain) return fail(RGR_ESTATE, "rgr_batch_set_publish_attrs: not a publish batch");
         if (!attrs) { b->deliver = false; return RGR_OK; }
+        if (b->format != kFmtTuple) return fail(RGR_ESTATE, "rgr_batch_set_publish_attrs: the delivery stage needs RGR_FORMAT_TUPLE");
         RGR_HIP(hipSetDevice(b->h->cfg.device));
         static_assert(sizeof(rgr_publish_attr) == sizeof(PublishAttr), "rgr_publish_attr layout");
         b->d_pub.ensure(std::max<size_t>(1, b->n) * sizeof(PublishAttr));
@@ -939,6 +956,15 @@ int32_t rgr_batch_set_publish_attrs(rgr_batch* b, const rgr_publish_attr* attrs)
         b->deliver = true;
         return RGR_OK;
     });
+}
+
+int32_t rgr_batch_set_format(rgr_batch* b, uint32_t format) {
+    if (!b || format > RGR_FORMAT_PACKED) return fail(RGR_EINVAL, "rgr_batch_set_format: bad argument");
+    if (b->in_pass) return fail(RGR_ESTATE, "rgr_batch_set_format: inside a pass");
+    if (format != RGR_FORMAT_TUPLE && b->deliver) return fail(RGR_ESTATE, "rgr_batch_set_format: the delivery stage needs RGR_FORMAT_TUPLE");
+    static_assert(RGR_FORMAT_TUPLE == kFmtTuple && RGR_FORMAT_SOA == kFmtSoa && RGR_FORMAT_PACKED == kFmtPacked, "format constants");
+    b->format = int(format);
+    return RGR_OK;
 }
 
 int32_t rgr_batch_begin(rgr_batch* b) {
@@ -958,6 +984,8 @@ int32_t rgr_batch_begin(rgr_batch* b) {
             if (b->host_tok) tokenize_batch(b->h, b, b->h_blob.data(), b->h_offs.data(), b->n);
             else tokenize_batch_device(b, b->retain ? b->repoch->dict : *b->epoch->dict);
         }
+        if (b->format == kFmtPacked && (b->retain ? b->repoch->max_id : b->epoch->max_sub_id) >= (1u << 30))
+            return fail(RGR_ECAPACITY, "rgr_batch_begin: RGR_FORMAT_PACKED needs ids below 2^30");
         b->in_pass = true;
         b->cursor = 0;
         b->chunk_ready = false;
@@ -1004,7 +1032,8 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
         if (nh) {
             const uint32_t T = expand_tile_hits();
             DevBuf& outbuf = b->alt_out ? b->out2 : b->out;
-            outbuf.ensure(nh * sizeof(Tuple));
+            const uint64_t ids_bytes = (nh * 4 + 255) & ~uint64_t(255);           // compact formats: sub ids, then the qos bytes
+            outbuf.ensure(b->format == kFmtTuple ? nh * sizeof(Tuple) : ids_bytes + (b->format == kFmtSoa ? nh + 16 : 0));
             b->tile_first.ensure(((nh + T - 1) / T) * 4);
             ChunkArrays ca = make_chunk_arrays(b, n);
             size_t sp = b->span_begin(kSpanScan);
@@ -1036,9 +1065,15 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
                 }
             }
             sp = b->span_begin(kSpanExpand);
-            launch_expand(batch_view(b), ca, pair_lo, pair_hi, hit_lo, hit_hi, b->tile_first.as<uint32_t>(), outbuf.as<Tuple>(), b->stream,
-                          (b->deliver && !b->retain) ? &da : nullptr);
+            if (b->format == kFmtTuple)
+                launch_expand(batch_view(b), ca, pair_lo, pair_hi, hit_lo, hit_hi, b->tile_first.as<uint32_t>(), outbuf.as<Tuple>(), b->stream,
+                              (b->deliver && !b->retain) ? &da : nullptr);
+            else
+                launch_expand_compact(batch_view(b), ca, pair_lo, pair_hi, hit_lo, hit_hi, b->tile_first.as<uint32_t>(), b->format,
+                                      outbuf.as<uint32_t>(), outbuf.as<uint8_t>() + ids_bytes, b->stream);
             b->span_end(sp);
+            // the chunk's accounting charged 20 B per hit (8 read + 12 written); the compact formats write 5 / 4
+            if (b->format != kFmtTuple) b->local.alg_bytes_expand -= nh * (b->format == kFmtSoa ? 7 : 8);
             b->local.expand_launches++;
             if (dedup) {
                 // the table is partitioned by topic and sized by the candidate counts: one stream sync per
@@ -1066,7 +1101,13 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
         w->topic_end = b->chunk_begin + le;
         w->n_hits = nh;
         w->hit_base = b->hits_before;
-        w->d_tuples = reinterpret_cast<const rgr_tuple*>(b->alt_out ? b->out2.p : b->out.p);
+        {
+            void* op = b->alt_out ? b->out2.p : b->out.p;
+            const uint64_t ids_bytes = (nh * 4 + 255) & ~uint64_t(255);
+            w->d_tuples = b->format == kFmtTuple ? reinterpret_cast<const rgr_tuple*>(op) : nullptr;
+            w->d_sub_ids = b->format == kFmtTuple || !nh ? nullptr : static_cast<const uint32_t*>(op);
+            w->d_qos = b->format == kFmtSoa && nh ? static_cast<const uint8_t*>(op) + ids_bytes : nullptr;
+        }
         w->d_hit_offsets = b->hit_off.as<uint64_t>() + lc;
         w->offsets_bias = hit_lo;
         b->hits_before += nh;
@@ -1078,6 +1119,7 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
 int32_t rgr_window_to_host(rgr_batch* b, const rgr_window* w, rgr_tuple* host_tuples, uint64_t* host_hit_offsets) {
     return guarded([&]() -> int32_t {
         if (!b || !w) return fail(RGR_EINVAL, "rgr_window_to_host: bad argument");
+        if (host_tuples && b->format != kFmtTuple) return fail(RGR_ESTATE, "rgr_window_to_host: tuples exist only in RGR_FORMAT_TUPLE");
         RGR_HIP(hipSetDevice(b->h->cfg.device));
         const double t0 = now_ms();
         if (host_tuples && w->n_hits)
@@ -1111,78 +1153,84 @@ int32_t rgr_batch_run(rgr_batch* b, uint64_t* n_hits, uint32_t* n_windows) {
     return RGR_OK;
 }
 
+// One pass with every window copied to the host while the next one is being expanded: window i goes into
+// device buffer i & 1, its D2H copy runs on the copy stream behind an event, and the expansion into a
+// buffer waits for that buffer's previous copy.  dst(w) names the (pinned) destination of window w's tuples —
+// it is called after rgr_batch_next_window returned w, so the caller may size its storage from w — and
+// done(w, host_ptr) runs once the copy has landed.  The caller has called rgr_batch_begin.
+extern "C++" {
+template <class Dst, class Done>
+static int32_t stream_windows(rgr_batch* b, Dst dst, Done done, uint64_t* n_hits, uint32_t* n_windows) {
+    b->ensure_stream_state();
+    struct Pending { bool live = false; rgr_window w{}; rgr_tuple* host = nullptr; } pend[2];
+    uint64_t hits = 0;
+    uint32_t nw = 0;
+    int32_t r = RGR_OK;
+    const double t0 = now_ms();
+    auto drain = [&](int k) {
+        if (!pend[k].live) return;
+        RGR_HIP(hipEventSynchronize(b->ev_copied[k]));
+        pend[k].live = false;
+        done(pend[k].w, pend[k].host);
+    };
+    struct Restore { rgr_batch* b; ~Restore() { b->alt_out = false; } } restore{b};
+    for (int k = 0;; k ^= 1) {
+        drain(k);                                   // slot k's device buffer is free again
+        b->alt_out = k == 1;
+        rgr_window w;
+        r = rgr_batch_next_window(b, &w);
+        if (r != RGR_OK) break;
+        RGR_HIP(hipEventRecord(b->ev_expanded[k], b->stream));
+        rgr_tuple* host = dst(w, k);                 // (also for an empty window: the caller keeps its offsets there)
+        RGR_HIP(hipStreamWaitEvent(b->copy_stream, b->ev_expanded[k], 0));
+        if (w.n_hits) RGR_HIP(hipMemcpyAsync(host, w.d_tuples, w.n_hits * sizeof(rgr_tuple), hipMemcpyDeviceToHost, b->copy_stream));
+        RGR_HIP(hipEventRecord(b->ev_copied[k], b->copy_stream));
+        pend[k].live = true; pend[k].w = w; pend[k].host = host;
+        hits += w.n_hits;
+        nw++;
+    }
+    if (r != RGR_EOF) { (void)hipStreamSynchronize(b->copy_stream); return r; }
+    drain(0); drain(1);
+    b->local.d2h_ms += now_ms() - t0;
+    if (n_hits) *n_hits = hits;
+    if (n_windows) *n_windows = nw;
+    return RGR_OK;
+}
+}  // extern "C++"
+
 int32_t rgr_batch_run_to_host(rgr_batch* b, rgr_window_consumer consume, void* user, uint64_t* n_hits, uint32_t* n_windows) {
+    if (b && b->format != kFmtTuple) return fail(RGR_ESTATE, "rgr_batch_run_to_host: RGR_FORMAT_TUPLE only");
     int32_t rc = rgr_batch_begin(b);
     if (rc != RGR_OK) return rc;
     return guarded([&]() -> int32_t {
-        hipStream_t copy_stream;
-        RGR_HIP(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
-        hipEvent_t expanded[2], copied[2];
-        for (int k = 0; k < 2; ++k) { RGR_HIP(hipEventCreate(&expanded[k])); RGR_HIP(hipEventCreate(&copied[k])); }
-        struct Pending { bool live = false; uint32_t t0 = 0, t1 = 0; uint64_t n = 0; } pend[2];
-        uint64_t hits = 0;
-        uint32_t nw = 0;
-        int32_t r = RGR_OK;
-        const double t0 = now_ms();
-        auto drain = [&](int k) {
-            if (!pend[k].live) return;
-            RGR_HIP(hipEventSynchronize(copied[k]));
-            if (consume) consume(user, pend[k].t0, pend[k].t1, b->h_ring[k].as<rgr_tuple>(), pend[k].n);
-            pend[k].live = false;
-        };
-        for (int k = 0;; k ^= 1) {
-            drain(k);                                   // slot k (device buffer + staging) is free again
-            b->alt_out = k == 1;
-            // the expansion into buffer k must not start before its previous copy finished: drain() waited
-            rgr_window w;
-            r = rgr_batch_next_window(b, &w);
-            if (r != RGR_OK) break;
-            RGR_HIP(hipEventRecord(expanded[k], b->stream));
-            b->h_ring[k].ensure(std::max<uint64_t>(1, w.n_hits) * sizeof(rgr_tuple));
-            RGR_HIP(hipStreamWaitEvent(copy_stream, expanded[k], 0));
-            if (w.n_hits) RGR_HIP(hipMemcpyAsync(b->h_ring[k].p, w.d_tuples, w.n_hits * sizeof(rgr_tuple), hipMemcpyDeviceToHost, copy_stream));
-            RGR_HIP(hipEventRecord(copied[k], copy_stream));
-            pend[k] = Pending{true, w.topic_begin, w.topic_end, w.n_hits};
-            hits += w.n_hits;
-            nw++;
-        }
-        b->alt_out = false;
-        drain(0); drain(1);
-        for (int k = 0; k < 2; ++k) { (void)hipEventDestroy(expanded[k]); (void)hipEventDestroy(copied[k]); }
-        (void)hipStreamDestroy(copy_stream);
-        b->local.d2h_ms += now_ms() - t0;
-        if (r != RGR_EOF) return r;
-        if (n_hits) *n_hits = hits;
-        if (n_windows) *n_windows = nw;
-        return RGR_OK;
+        return stream_windows(
+            b,
+            [&](const rgr_window& w, int k) {
+                b->h_ring[k].ensure(std::max<uint64_t>(1, w.n_hits) * sizeof(rgr_tuple));
+                return b->h_ring[k].as<rgr_tuple>();
+            },
+            [&](const rgr_window& w, rgr_tuple* host) { if (consume) consume(user, w.topic_begin, w.topic_end, host, w.n_hits); },
+            n_hits, n_windows);
     });
 }
 
 // ------------------------------------------------------------------ host in / host out
 namespace {
-// Tuple storage of a host result: pinned (hipHostMalloc) once it is large, so that the D2H copies
-// run at PCIe speed instead of through the driver's pageable-memory staging.
+// Tuple storage of a host result: one pinned block from the handle's pool (the D2H copies run at PCIe speed
+// and hipHostMalloc is paid once per size class, not per call).
 struct TupleStore {
+    std::shared_ptr<PinnedPool> pool;
     rgr_tuple* p = nullptr;
-    size_t n = 0, cap = 0;
-    bool pinned = false;
-    ~TupleStore() { release(); }
-    void release() {
-        if (!p) return;
-        if (pinned) (void)hipHostFree(p); else std::free(p);
-        p = nullptr; n = cap = 0;
-    }
-    void grow(size_t want) {       // keeps contents
+    size_t n = 0, cap = 0, cap_bytes = 0;
+    ~TupleStore() { if (p && pool) pool->give(p, cap_bytes); }
+    void grow(size_t want) {       // keeps contents; no copy may be in flight into the old block
         if (want <= cap) return;
         const size_t ncap = std::max(want, cap * 2);
-        const bool pin = ncap * sizeof(rgr_tuple) >= (4u << 20);
-        rgr_tuple* np = nullptr;
-        if (pin) { RGR_HIP(hipHostMalloc(reinterpret_cast<void**>(&np), ncap * sizeof(rgr_tuple), hipHostMallocDefault)); }
-        else { np = static_cast<rgr_tuple*>(std::malloc(std::max<size_t>(1, ncap) * sizeof(rgr_tuple))); if (!np) throw std::bad_alloc(); }
+        size_t nbytes = 0;
+        rgr_tuple* np = static_cast<rgr_tuple*>(pool->take(std::max<size_t>(1, ncap) * sizeof(rgr_tuple), &nbytes));
         if (n) std::memcpy(np, p, n * sizeof(rgr_tuple));
-        const size_t keep = n;
-        release();
-        p = np; n = keep; cap = ncap; pinned = pin;
+        if (p) pool->give(p, cap_bytes);
+        p = np; cap = nbytes / sizeof(rgr_tuple); cap_bytes = nbytes;
     }
 };
 struct ResultOwner {
@@ -1202,27 +1250,40 @@ static int32_t match_batch_impl(rgr_handle* h, const uint8_t* blob, const uint64
     if (rc != RGR_OK) return rc;
     rc = guarded([&]() -> int32_t {
         auto own = std::make_unique<ResultOwner>();
+        own->tuples.pool = h->pinned;
         own->status.assign(b->status.begin(), b->status.end());
         own->offsets.assign(size_t(n) + 1, 0);
         int32_t r = attrs ? rgr_batch_set_publish_attrs(b, attrs) : RGR_OK;
         if (r != RGR_OK) return r;
         r = rgr_batch_begin(b);
         if (r != RGR_OK) return r;
-        std::vector<uint64_t> tmp;
-        for (;;) {
-            rgr_window w;
-            r = rgr_batch_next_window(b, &w);
-            if (r == RGR_EOF) break;
-            if (r != RGR_OK) return r;
-            const size_t base = own->tuples.n;
-            if (base == 0 && w.topic_end == n) own->tuples.grow(w.n_hits);            // single window: exact size
-            else own->tuples.grow(base + w.n_hits);
-            own->tuples.n = base + w.n_hits;
-            tmp.resize(size_t(w.topic_end - w.topic_begin) + 1);
-            r = rgr_window_to_host(b, &w, own->tuples.p + base, tmp.data());
-            if (r != RGR_OK) return r;
-            for (uint32_t i = 0; i <= w.topic_end - w.topic_begin; ++i) own->offsets[w.topic_begin + i] = base + tmp[i];
-        }
+        // Windows are expanded and copied in a two-deep pipeline straight into the result block.  The block is
+        // sized when a chunk's totals are known (one chunk = up to rgr_config.chunk_topics topics: the whole
+        // batch for any realistic call); only a batch of several chunks can make it grow, and it grows with no
+        // copy in flight (both slots drained first).
+        uint32_t sized_chunk = ~0u;
+        bool in_flight[2] = {false, false};
+        r = stream_windows(
+            b,
+            [&](const rgr_window& w, int k) {
+                if (b->chunk_begin != sized_chunk) {
+                    sized_chunk = b->chunk_begin;
+                    const uint64_t chunk_hits = b->h_hit_off.as<uint64_t>()[b->chunk_n];
+                    const size_t need = own->tuples.n + chunk_hits;
+                    if (need > own->tuples.cap) {
+                        for (int j = 0; j < 2; ++j) if (in_flight[j]) { RGR_HIP(hipEventSynchronize(b->ev_copied[j])); }
+                        own->tuples.grow(need);
+                    }
+                }
+                const size_t base = own->tuples.n;
+                own->tuples.n = base + w.n_hits;
+                const uint64_t* ho = b->h_hit_off.as<uint64_t>() + (w.topic_begin - b->chunk_begin);
+                for (uint32_t i = 0; i <= w.topic_end - w.topic_begin; ++i) own->offsets[w.topic_begin + i] = base + (ho[i] - w.offsets_bias);
+                in_flight[k] = true;
+                return own->tuples.p + base;
+            },
+            [&](const rgr_window&, rgr_tuple*) {}, nullptr, nullptr);
+        if (r != RGR_OK) return r;
         out->n_topics = n;
         out->n_hits = own->tuples.n;
         out->status = own->status.data();
@@ -1263,27 +1324,38 @@ int32_t rgr_match_filters(rgr_handle* h, const uint8_t* blob, const uint64_t* of
         own->offsets.assign(size_t(n) + 1, 0);
         int32_t r = rgr_batch_begin(b);
         if (r != RGR_OK) return r;
-        const uint32_t C = h->cfg.slot_cap;
-        std::vector<uint32_t> slots, cnt, arena;
-        std::vector<uint64_t> obase;
+        // Per chunk: walk, exclusive scan of the per-topic matched-filter counts, one kernel that writes the
+        // filter ids densely in iteration order, and two copies (offsets, ids) into pinned staging.  What
+        // crosses PCIe is 4 bytes per matched filter + 8 per topic — not the slot arrays.
         for (uint32_t begin = 0; begin < n; begin += b->chunk_n) {
             prepare_chunk(b, begin, true);
             const uint32_t cn = b->chunk_n;
-            slots.resize(size_t(C) * cn); cnt.resize(cn); obase.resize(cn);
             const Scalars* hs = b->h_scalars.as<Scalars>();
-            arena.resize(hs->ovf_cursor);
-            RGR_HIP(hipMemcpy(slots.data(), b->slots.p, slots.size() * 4, hipMemcpyDeviceToHost));
-            RGR_HIP(hipMemcpy(cnt.data(), b->pair_cnt.p, size_t(cn) * 4, hipMemcpyDeviceToHost));
-            if (hs->ovf_count) {
-                RGR_HIP(hipMemcpy(obase.data(), b->ovf_base.p, size_t(cn) * 8, hipMemcpyDeviceToHost));
-                RGR_HIP(hipMemcpy(arena.data(), b->arena.p, arena.size() * 4, hipMemcpyDeviceToHost));
+            b->pair_base.ensure((size_t(cn) + 1) * 8);
+            b->h_pair_base.ensure((size_t(cn) + 1) * 8);
+            b->scan_tmp.ensure((size_t(cn) / scan_block_topics() + 3) * 16);
+            uint64_t* d_off = b->pair_base.as<uint64_t>();
+            launch_scan_u32(b->pair_cnt.as<uint32_t>(), d_off, cn, b->scan_tmp.as<uint64_t>(), b->stream);
+            RGR_HIP(hipMemcpyAsync(b->h_pair_base.p, d_off, (size_t(cn) + 1) * 8, hipMemcpyDeviceToHost, b->stream));
+            RGR_HIP(hipStreamSynchronize(b->stream));
+            const uint64_t* ho = b->h_pair_base.as<uint64_t>();
+            const uint64_t P = ho[cn];
+            const size_t base = own->ids.size();
+            if (P) {
+                b->pair_src.ensure(P * 4);
+                b->h_ring[0].ensure(P * 4);
+                launch_pairs_dense(make_chunk_arrays(b, cn), d_off, b->pair_src.as<uint32_t>(), b->stream);
+                RGR_HIP(hipMemcpyAsync(b->h_ring[0].p, b->pair_src.p, P * 4, hipMemcpyDeviceToHost, b->stream));
+                RGR_HIP(hipStreamSynchronize(b->stream));
+                RGR_HIP(hipGetLastError());
+                own->ids.resize(base + P);
+                std::memcpy(own->ids.data() + base, b->h_ring[0].p, P * 4);
             }
-            for (uint32_t t = 0; t < cn; ++t) {
-                for (uint32_t j = 0; j < cnt[t]; ++j)
-                    own->ids.push_back(cnt[t] <= C ? slots[size_t(j) * cn + t] : arena[obase[t] + j]);
-                own->offsets[begin + t + 1] = own->ids.size();
-            }
+            for (uint32_t t = 0; t <= cn; ++t) own->offsets[begin + t] = base + ho[t];
+            b->local.pairs += P;
+            b->local.visited_nodes += hs->visited;
             b->local.overflow_topics += hs->ovf_count;
+            b->local.alg_bytes_walk += 24 * hs->visited + 8 * P;
         }
         RGR_HIP(hipStreamSynchronize(b->stream));
         b->resolve_spans();

@@ -4,6 +4,8 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
+#include <vector>
 #include <stdexcept>
 #include <string>
 
@@ -73,6 +75,54 @@ struct PinnedBuf {
         bytes = want;
     }
     template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+// Recycled pinned host blocks for the results of the host-buffer entry points: hipHostMalloc costs
+// milliseconds per call (it pins pages), so a result takes its tuple block from here and hands it back at
+// rgr_result_free.  Shared (shared_ptr) between the handle and every outstanding result, so a result may
+// outlive its handle.  Blocks are powers of two >= 64 KiB; at most `keep_bytes` stay cached.
+class PinnedPool {
+   public:
+    explicit PinnedPool(size_t keep_bytes = size_t(8) << 30) : keep_(keep_bytes) {}
+    PinnedPool(const PinnedPool&) = delete;
+    PinnedPool& operator=(const PinnedPool&) = delete;
+    ~PinnedPool() { for (auto& b : free_) (void)hipHostFree(b.p); }
+    void* take(size_t bytes, size_t* cap) {
+        size_t want = size_t(64) << 10;
+        if (bytes <= (size_t(1) << 30)) { while (want < bytes) want <<= 1; }
+        else want = (bytes + (size_t(256) << 20) - 1) & ~((size_t(256) << 20) - 1);      // big blocks: 256 MiB steps, not powers of two
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            size_t best = free_.size();
+            for (size_t i = 0; i < free_.size(); ++i)
+                if (free_[i].cap >= want && free_[i].cap <= want + want / 4 && (best == free_.size() || free_[i].cap < free_[best].cap)) best = i;
+            if (best != free_.size()) {
+                void* p = free_[best].p;
+                *cap = free_[best].cap;
+                held_ -= *cap;
+                free_[best] = free_.back(); free_.pop_back();
+                return p;
+            }
+        }
+        void* p = nullptr;
+        RGR_HIP(hipHostMalloc(&p, want, hipHostMallocDefault));
+        *cap = want;
+        return p;
+    }
+    void give(void* p, size_t cap) {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            if (held_ + cap <= keep_) { free_.push_back(Block{p, cap}); held_ += cap; return; }
+        }
+        (void)hipHostFree(p);
+    }
+
+   private:
+    struct Block { void* p; size_t cap; };
+    std::mutex mu_;
+    std::vector<Block> free_;
+    size_t held_ = 0, keep_;
 };
 
 }  // namespace rgr

@@ -339,6 +339,15 @@ __global__ __launch_bounds__(256) void retain_finish_kernel(uint32_t n, const ui
     if (f < n) pair_cnt[f] = uint32_t(ovf_end[f] - ovf_base[f]);
 }
 
+// --------------------------------------------------------------------------- dense matched-filter list
+__global__ __launch_bounds__(256) void pairs_dense_kernel(ChunkArrays c, const uint64_t* __restrict__ off, uint32_t* __restrict__ out) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= c.n) return;
+    const uint32_t cnt = c.pair_cnt[t];
+    const uint64_t o = off[t];
+    for (uint32_t j = 0; j < cnt; ++j) out[o + j] = pair_fid(c, t, cnt, j);
+}
+
 // --------------------------------------------------------------------------- count
 __global__ __launch_bounds__(256) void count_kernel(TrieView tv, ChunkArrays c) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
@@ -667,6 +676,72 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* 
     }
 }
 
+// --------------------------------------------------------------------------- expand, compact result formats
+// The 12-byte tuple repeats the topic index on every hit although d_hit_offsets already says which topic a
+// position belongs to.  The compact formats write only what is new per hit (SURVEY.md §8(b)'s SoA result):
+//   kFmtSoa     out_ids[pos] = sub_id (u32), out_qos[pos] = qos | flags << 2 (u8)        5 B/hit
+//   kFmtPacked  out_ids[pos] = sub_id | qos << 30 (u32; sub ids < 2^30)                   4 B/hit
+// Same tiles and staged pair view as expand_kernel, but a lane owns FOUR CONSECUTIVE positions, so a wave
+// stores 1 KiB of sub ids with one dwordx4 per lane (and 256 B of qos bytes with one dword per lane)
+// instead of 768 B of strided 12-byte tuples.
+template <int FMT>
+__global__ __launch_bounds__(kExpandThreads) void expand_compact_kernel(const SubEntry* __restrict__ subs, ChunkArrays c,
+                                                                        uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo,
+                                                                        uint64_t hit_hi, const uint32_t* __restrict__ tile_first,
+                                                                        uint32_t ntiles, uint32_t* __restrict__ out_ids,
+                                                                        uint8_t* __restrict__ out_qos) {
+    static_assert(kExpandPerThread == 4, "a lane packs four qos bytes into one word");
+    __shared__ int32_t s_off[kTile + 2];
+    __shared__ uint32_t s_src[kTile + 2];
+    const uint32_t tile = blockIdx.x;
+    const uint64_t base = hit_lo + uint64_t(tile) * kTile;
+    const uint32_t len = (hit_hi - base) < uint64_t(kTile) ? uint32_t(hit_hi - base) : uint32_t(kTile);
+    const uint64_t a = pair_lo + tile_first[tile];
+    const uint64_t b = (tile + 1 < ntiles) ? pair_lo + tile_first[tile + 1] + 1 : pair_hi;
+    const uint32_t np = uint32_t(b - a);
+    for (uint32_t i = threadIdx.x; i < np; i += kExpandThreads) {
+        uint32_t topic_unused;
+        tile_pair_view(c, a, i, base, s_off[i], s_src[i], topic_unused);
+    }
+    if (threadIdx.x == 0) s_off[np] = 0x7FFFFFFF;                       // sentinel: no pair starts after the last one
+    __syncthreads();
+    const uint32_t p0 = threadIdx.x * 4;
+    if (p0 >= len) return;
+    // owner of the lane's first position by binary search, of the next three by stepping (runs are long)
+    uint32_t i = np == 1 ? 0u : locate_pair([&](uint32_t m) { return s_off[m]; }, np, int32_t(p0));
+    const SubEntry* src[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t pos = p0 + j;
+        const bool live = pos < len;
+        while (live && s_off[i + 1] <= int32_t(pos)) ++i;
+        src[j] = subs + (uint64_t(s_src[i]) + (live ? uint32_t(int32_t(pos) - s_off[i]) : 0u));
+    }
+    SubEntry se[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) se[j] = *src[j];
+    uint32_t w[4];
+    uint32_t q = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const uint32_t qf = se[j].qos_flags;
+        if (FMT == kFmtPacked) w[j] = se[j].sub_id | (qf << 30);
+        else { w[j] = se[j].sub_id; q |= ((qf & 3u) | (((qf >> 8) & 0x3Fu) << 2)) << (8 * j); }
+    }
+    uint32_t* o = out_ids + (base - hit_lo) + p0;
+    if (p0 + 4 <= len) {
+        typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+        v4 v; v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+        __builtin_nontemporal_store(v, reinterpret_cast<v4*>(o));
+        if (FMT == kFmtSoa) __builtin_nontemporal_store(q, reinterpret_cast<uint32_t*>(out_qos + (base - hit_lo) + p0));
+    } else {
+        for (uint32_t j = 0; p0 + j < len; ++j) {
+            o[j] = w[j];
+            if (FMT == kFmtSoa) out_qos[(base - hit_lo) + p0 + j] = uint8_t(q >> (8 * j));
+        }
+    }
+}
+
 // --------------------------------------------------------------------------- v5 per-client dedup
 // types.rs:524-539: of a topic's v5 hits for one client the FIRST (in filter order = position
 // order) keeps filter + options, later ones only contribute their subscription identifier.
@@ -771,6 +846,10 @@ void launch_retain_finish(uint32_t n, const uint64_t* ovf_base, const uint64_t* 
     if (n) retain_finish_kernel<<<(n + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(n, ovf_base, ovf_end, pair_cnt);
 }
 
+void launch_pairs_dense(const ChunkArrays& c, const uint64_t* off, uint32_t* out, void* stream) {
+    if (c.n) pairs_dense_kernel<<<(c.n + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(c, off, out);
+}
+
 void launch_count(const TrieView& t, const ChunkArrays& c, void* stream) {
     if (c.n == 0) return;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -808,6 +887,15 @@ void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, ui
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (deliver) expand_kernel<true><<<ntiles, kExpandThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, *deliver);
     else expand_kernel<false><<<ntiles, kExpandThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, DeliverArgs{});
+}
+
+void launch_expand_compact(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint64_t hit_hi,
+                           const uint32_t* tile_first, int format, uint32_t* out_ids, uint8_t* out_qos, void* stream) {
+    if (hit_hi <= hit_lo) return;
+    const uint32_t ntiles = uint32_t((hit_hi - hit_lo + kTile - 1) / kTile);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (format == kFmtPacked) expand_compact_kernel<kFmtPacked><<<ntiles, kExpandThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out_ids, out_qos);
+    else expand_compact_kernel<kFmtSoa><<<ntiles, kExpandThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out_ids, out_qos);
 }
 
 void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, uint32_t ntiles, Tuple* tuples, const uint64_t* cand_off,

@@ -193,12 +193,19 @@ void launch_retain_emit(const RetainRound& r, const uint64_t* epos, uint64_t g_b
                         uint64_t* ovf_end, void* stream);
 void launch_retain_finish(uint32_t n, const uint64_t* ovf_base, const uint64_t* ovf_end, uint32_t* pair_cnt, void* stream);
 
+// matched filter ids of every topic of the chunk, densely, in iteration order: out[off[t] + j] = j-th matched
+// filter of topic t (off = exclusive scan of pair_cnt) — the result of rgr_match_filters
+void launch_pairs_dense(const ChunkArrays& c, const uint64_t* off, uint32_t* out, void* stream);
 void launch_count(const TrieView& t, const ChunkArrays& c, void* stream);
 void launch_scan(const ChunkArrays& c, uint64_t* block_tmp, void* stream);
 void launch_compact(const TrieView& t, const ChunkArrays& c, uint32_t topic_base, void* stream);
 void launch_tiles(const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint32_t* tile_first, void* stream);
 void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint64_t hit_hi,
                    const uint32_t* tile_first, Tuple* out, void* stream, const DeliverArgs* deliver = nullptr);
+// compact result formats (rgr_batch_set_format): sub ids (+ a qos byte array) without the topic column
+constexpr int kFmtTuple = 0, kFmtSoa = 1, kFmtPacked = 2;     // == RGR_FORMAT_*
+void launch_expand_compact(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint64_t hit_hi,
+                           const uint32_t* tile_first, int format, uint32_t* out_ids, uint8_t* out_qos, void* stream);
 // v5 per-client dedup over a window's candidates: first position per (topic, client) wins, every
 // other candidate gets kHitV5Dup.  `table` (pre-filled with 0xFF bytes) is partitioned by topic:
 // topic t of the window owns slots [2*cand_off[t], 2*cand_off[t+1]) — twice its candidate count

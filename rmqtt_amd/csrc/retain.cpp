@@ -98,6 +98,7 @@ int32_t RetainTable::topic_add(std::string_view topic, uint32_t topic_id) {
     if (nodes_[cur].value == kNone) n_values_++;
     if (nodes_[cur].value != topic_id) version_++;   // re-publishing a retained topic under the same id changes nothing on the device
     nodes_[cur].value = topic_id;                    // value.replace(), retain.rs:384
+    if (topic_id > max_id_) max_id_ = topic_id;
     return RGR_OK;
 }
 

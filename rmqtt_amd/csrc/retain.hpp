@@ -56,6 +56,7 @@ class RetainTable {
     uint64_t n_nodes() const { return n_nodes_; }
     // bumped by every mutation that changes what compile() would emit
     uint64_t version() const { return version_; }
+    uint32_t max_id() const { return max_id_; }        // upper bound of the topic ids ever stored
 
    private:
     struct Node { uint32_t parent, token, slot, nchild, value; bool meta; };
@@ -64,6 +65,7 @@ class RetainTable {
     std::vector<uint32_t> free_nodes_;
     std::vector<REdge> edges_;     // (parent,token)->child over the mutable node ids
     uint64_t edge_used_ = 0, edge_live_ = 0, n_values_ = 0, n_nodes_ = 1, version_ = 1;
+    uint32_t max_id_ = 0;
     uint32_t find(uint32_t parent, uint32_t token) const;
     uint32_t insert_edge(uint32_t parent, uint32_t token, uint32_t child);
     void rehash(uint64_t cap);

@@ -130,6 +130,7 @@ class HostTable {
     bool take_attrs_all_dirty() { const bool d = attrs_all_dirty_; attrs_all_dirty_ = false; return d; }
     void mark_attrs_all_dirty() { attrs_all_dirty_ = true; }
     uint64_t n_v5_subs() const { return n_v5_; }
+    uint32_t max_sub_id() const { return max_sub_id_; }   // upper bound of the sub ids ever added
     int32_t sub_remove(uint32_t fid, uint32_t sub_id);
     // Restore / bulk path (rmqtt-cluster-raft/src/router.rs:557-566 re-inserts every filter after a
     // snapshot): filter_add + sub_add for n subscriptions.  Tokenises on `threads` threads, sorts the
@@ -196,6 +197,7 @@ class HostTable {
     std::vector<Filter> filters_;
     std::vector<uint32_t> free_fids_;
     uint64_t n_filters_ = 0, n_subs_ = 0, n_nodes_ = 1, n_v5_ = 0;
+    uint32_t max_sub_id_ = 0;
     std::vector<SubAttr> attrs_;
     bool has_attrs_ = false, attrs_all_dirty_ = false;
     uint64_t dict_gen_ = 0;

@@ -1,0 +1,148 @@
+"""Compact result formats of a device-resident batch (rgr_batch_set_format, SURVEY.md §8(b)'s SoA result):
+the same hits in the same order as the 12-byte tuples, without the topic column — checked word for word
+against the tuple format of the same pass, which the parity suites pin against the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from rmqtt_amd import capi
+from rmqtt_amd import workload as wl
+
+pytestmark = pytest.mark.gpu
+
+_hip = None
+
+
+def d2h(ptr, nbytes):
+    global _hip
+    if _hip is None:
+        _hip = C.CDLL("libamdhip64.so")
+        _hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    out = np.empty(int(nbytes), dtype=np.uint8)
+    if nbytes:
+        assert _hip.hipMemcpy(out.ctypes.data, C.c_void_p(int(ptr)), int(nbytes), 2) == 0     # hipMemcpyDeviceToHost
+    return out
+
+
+def windows(batch, fmt):
+    """-> list of (topic_begin, topic_end, offsets, sub_ids | tuples, qos | None) of one pass in format fmt."""
+    batch.set_format(fmt)
+    out = []
+    batch.begin()
+    while True:
+        w = batch.next_window()
+        if w is None:
+            break
+        offs = np.zeros(w.topic_end - w.topic_begin + 1, dtype=np.uint64)
+        capi._check(capi.lib().rgr_window_to_host(batch._b, C.byref(w), None, offs.ctypes.data))      # syncs the stream
+        nh = int(w.n_hits)
+        if fmt == capi.RGR_FORMAT_TUPLE:
+            assert not w.d_sub_ids and not w.d_qos
+            a = d2h(w.d_tuples, nh * 12).view(capi.TUPLE_DTYPE) if nh else np.zeros(0, dtype=capi.TUPLE_DTYPE)
+            b = None
+        else:
+            assert not w.d_tuples
+            a = d2h(w.d_sub_ids, nh * 4).view(np.uint32) if nh else np.zeros(0, dtype=np.uint32)
+            b = (d2h(w.d_qos, nh) if nh else np.zeros(0, dtype=np.uint8)) if fmt == capi.RGR_FORMAT_SOA else None
+            assert (fmt == capi.RGR_FORMAT_SOA) == bool(w.d_qos) or nh == 0
+        out.append((int(w.topic_begin), int(w.topic_end), offs, a, b))
+    return out
+
+
+@pytest.mark.parametrize("window_hits", [1000, 4099, 1 << 20])
+def test_compact_formats_equal_tuples(window_hits):
+    cfg = 3
+    c = wl.CONFIGS[cfg]
+    n_sub = 60_000
+    blob, offs, client, qos = wl.gen_subs(n_sub, wl.SUB_SEED + cfg, c["p_plus"], c["p_hash"], c["p_sys"])
+    tb, to = wl.gen_topics(5_000, wl.PUB_SEED + cfg, 0.01, c["p_blank"])
+    rng = np.random.default_rng(3)
+    flags = rng.integers(0, 64, size=n_sub).astype(np.uint8)            # every RGR_SUB_* bit + 2 table bits
+    r = capi.Router(device=0, window_hits=window_hits)
+    assert r.subscribe_bulk(blob, offs, None, qos, flags) == 0
+    r.commit()
+    batch = r.batch(tb, to)
+    ref = windows(batch, capi.RGR_FORMAT_TUPLE)
+    soa = windows(batch, capi.RGR_FORMAT_SOA)
+    pk = windows(batch, capi.RGR_FORMAT_PACKED)
+    assert len(ref) == len(soa) == len(pk) and len(ref) > (3 if window_hits < (1 << 20) else 0)
+    total = 0
+    for (tb0, te0, o0, t, _), (tb1, te1, o1, ids, q), (tb2, te2, o2, pw, _) in zip(ref, soa, pk):
+        assert (tb0, te0) == (tb1, te1) == (tb2, te2) and np.array_equal(o0, o1) and np.array_equal(o0, o2)
+        assert np.array_equal(ids, t["sub_id"])
+        qf = t["qos_flags"]
+        assert np.array_equal(q, ((qf & 3) | (((qf >> 8) & 0x3F) << 2)).astype(np.uint8))
+        assert np.array_equal(pw, t["sub_id"] | ((qf & 3) << 30))
+        total += len(t)
+    assert total > 100_000
+    # back to tuples: the format is a per-pass choice
+    again = windows(batch, capi.RGR_FORMAT_TUPLE)
+    assert all(np.array_equal(a[3], b[3]) for a, b in zip(ref, again))
+    batch.close(); r.close()
+
+
+def test_compact_formats_retain_and_limits():
+    r = capi.Router(device=0, window_hits=512)
+    names = [f"k/{i}/v" for i in range(3000)] + ["k/7", "x"]
+    for i, s in enumerate(names):
+        assert r.retain_add(s, i) == 0
+    r.retain_commit()
+    fb, fo = capi.pack(["k/#", "k/+/v", "k/7/#", "#", "nope/+"])
+    b = r.retain_batch(fb, fo)
+    ref = windows(b, capi.RGR_FORMAT_TUPLE)
+    soa = windows(b, capi.RGR_FORMAT_SOA)
+    for (_, _, o0, t, _), (_, _, o1, ids, q) in zip(ref, soa):
+        assert np.array_equal(o0, o1) and np.array_equal(ids, t["sub_id"]) and not q.any()
+    assert sum(len(x[3]) for x in ref) == 3001 + 3000 + 2 + 3002
+    b.close()
+    # delivery stage and compact formats exclude each other; PACKED needs ids below 2^30
+    fid = r.filter_add("a/+")
+    r.sub_add(fid, (1 << 30) + 5, 1)
+    r.commit()
+    tb, to = capi.pack(["a/b"])
+    pb = r.batch(tb, to)
+    pb.set_format(capi.RGR_FORMAT_PACKED)
+    with pytest.raises(capi.RgrError) as e:
+        pb.begin()
+    assert e.value.code == capi.RGR_ECAPACITY
+    pb.set_format(capi.RGR_FORMAT_SOA)
+    assert windows(pb, capi.RGR_FORMAT_SOA)[0][3].tolist() == [(1 << 30) + 5]
+    with pytest.raises(capi.RgrError) as e:
+        pb.set_publish_attrs(np.zeros(1, dtype=capi.PUBLISH_ATTR_DTYPE))
+    assert e.value.code == capi.RGR_ESTATE
+    pb.set_format(capi.RGR_FORMAT_TUPLE)
+    pb.set_publish_attrs(np.zeros(1, dtype=capi.PUBLISH_ATTR_DTYPE))
+    with pytest.raises(capi.RgrError) as e:
+        pb.set_format(capi.RGR_FORMAT_SOA)
+    assert e.value.code == capi.RGR_ESTATE
+    pb.close(); r.close()
+
+
+def test_match_filters_dense_and_pinned_match_batch():
+    """rgr_match_filters (dense device-side list) against the per-topic filter sequence rgr_match_batch implies,
+    and rgr_match_batch's pooled pinned result across repeated calls of different sizes."""
+    cfg = 3
+    c = wl.CONFIGS[cfg]
+    blob, offs, client, qos = wl.gen_subs(40_000, wl.SUB_SEED + cfg, c["p_plus"], c["p_hash"], c["p_sys"])
+    tb, to = wl.gen_topics(9_000, wl.PUB_SEED + cfg, 0.01, c["p_blank"])
+    r = capi.Router(device=0, window_hits=50_000, chunk_topics=4096, slot_cap=4)     # several chunks, overflow arena, many windows
+    rej, fids = r.subscribe_bulk(blob, offs, None, qos, None, want_filter_ids=True)
+    r.commit()
+    sub_filter = fids                                             # sub_id i subscribes filter fids[i]
+    full = r.match_batch(tb, to)
+    mf = r.match_filters(tb, to)
+    po = mf["pair_offsets"].astype(np.int64)
+    ho = full["hit_offsets"].astype(np.int64)
+    assert np.array_equal(mf["status"], full["status"])
+    for t in range(len(to) - 1):
+        seq = sub_filter[full["tuples"]["sub_id"][ho[t]:ho[t + 1]]]
+        # the filters the hits came from, in order, runs collapsed == the matched filters that have subscribers
+        runs = seq[np.r_[True, seq[1:] != seq[:-1]]] if len(seq) else seq
+        assert np.array_equal(runs, mf["filter_ids"][po[t]:po[t + 1]]), t
+    assert np.array_equal(full["tuples"]["topic_idx"], np.repeat(np.arange(len(to) - 1, dtype=np.uint32), np.diff(ho)))
+    for n in (1, 17, 3000, 9000, 5):       # the pinned blocks are recycled across sizes
+        got = r.match_batch(*wl.take(tb, to, np.arange(n)))
+        assert np.array_equal(got["hit_offsets"], full["hit_offsets"][:n + 1])
+        assert np.array_equal(got["tuples"]["sub_id"], full["tuples"]["sub_id"][:ho[n]])
+    r.close()
