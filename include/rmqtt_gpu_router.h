@@ -286,6 +286,12 @@ const int32_t* rgr_batch_status(const rgr_batch* b);
  * runs the delivery stage and emits delivery words (RGR_HIT_*) in rgr_tuple.qos_flags.
  * NULL detaches them.  RGR_ESTATE inside a pass or on a retain batch. */
 int32_t rgr_batch_set_publish_attrs(rgr_batch* b, const rgr_publish_attr* attrs);
+/* Make later passes write ids[i] instead of i into rgr_tuple.topic_idx (ids: [n], host memory, copied; NULL
+ * restores the batch index).  This is how a shard of a multi-GPU router reports the caller's GLOBAL publish
+ * index (rgr_group_*), and how a broker's micro-batcher can tag hits with its own publish sequence numbers.
+ * Costs nothing per hit (the id is attached per (topic, filter) pair at compaction).  RGR_ESTATE inside a pass
+ * or together with publish attributes. */
+int32_t rgr_batch_set_topic_ids(rgr_batch* b, const uint32_t* ids);
 /* Choose the result format of later passes (RGR_FORMAT_*).  RGR_ESTATE inside a pass or together with
  * publish attributes (the delivery word needs the full tuple). */
 int32_t rgr_batch_set_format(rgr_batch* b, uint32_t format);
@@ -353,6 +359,63 @@ void rgr_retain_result_free(rgr_retain_result* r);
  * key_levels: 1..8 (0 = default 3). */
 int32_t rgr_shard_assign(const uint8_t* blob, const uint64_t* offsets, uint64_t n, uint32_t n_shards, int32_t is_filter,
                          uint32_t key_levels, int32_t* out);
+
+/* ---- multi-GPU: communicators and single-process shard groups ----------------
+ * With the rule above the DATA path needs no collective (a topic's whole hit list comes from its owner
+ * GPU); the exchange step is every rank learning every rank's hits, over RCCL / xGMI:
+ *   counts  one ncclAllGather per step                                       rgr_comm_allgather_u64
+ *   tuples  all-gatherv = counts + ncclGroupStart { ncclSend / ncclRecv per peer, exact sizes } ncclGroupEnd
+ *           (point-to-point on every xGMI link at once — a ring would be per-link bound), overlapped with
+ *           the next window's expansion                                      rgr_comm_gather_pass
+ * A communicator belongs to one handle (= one device).  One rank per process: rank 0 calls
+ * rgr_comm_unique_id, ships the 128 bytes to the other ranks by any means (the launcher's rendezvous,
+ * torch.distributed, a file) and every rank calls rgr_comm_create (ncclCommInitRank).  One process with
+ * several devices: rgr_group_create builds a handle + communicator per device (ncclCommInitAll) and
+ * shards tables and batches across them.  RCCL is dlopen'ed at first use. */
+#define RGR_COMM_ID_BYTES 128
+typedef struct rgr_comm rgr_comm;
+int32_t rgr_comm_unique_id(uint8_t* id /* [RGR_COMM_ID_BYTES] */);
+int32_t rgr_comm_create(rgr_handle* h, const uint8_t* id, uint32_t rank, uint32_t world, rgr_comm** out);
+void rgr_comm_destroy(rgr_comm* c);
+/* every rank's value on every rank: all[world] */
+int32_t rgr_comm_allgather_u64(rgr_comm* c, uint64_t mine, uint64_t* all);
+/* One pass of batch `b` (created on the communicator's handle) whose windows are all-gathered: in every round
+ * each rank contributes its next window (or nothing once it ran out) and receives all ranks' tuples in rank
+ * order.  consume (optional) sees each round's gathered DEVICE buffer — valid during the call only — with the
+ * per-rank tuple counts.  Collective: every rank must call it.  Tuples carry rgr_batch_set_topic_ids' ids. */
+typedef void (*rgr_gather_consumer)(void* user, const rgr_tuple* d_tuples, const uint64_t* counts, uint32_t world, uint64_t n_total);
+int32_t rgr_comm_gather_pass(rgr_comm* c, rgr_batch* b, rgr_gather_consumer consume, void* user, uint64_t* my_hits, uint64_t* all_hits);
+
+typedef struct rgr_group rgr_group;
+typedef struct rgr_group_batch rgr_group_batch;
+/* One handle per entry of devices[] (cfg->device is ignored).  Distinct ordinals: RCCL communicators over
+ * xGMI.  Repeated ordinals (several shards on one GPU — a test rig): the shards exchange through device copies
+ * with the same protocol; rgr_group_uses_rccl tells which. */
+int32_t rgr_group_create(const rgr_config* cfg, const int32_t* devices, uint32_t n_devices, rgr_group** out);
+void rgr_group_destroy(rgr_group* g);
+uint32_t rgr_group_size(const rgr_group* g);
+rgr_handle* rgr_group_handle(rgr_group* g, uint32_t shard);          /* per-shard stats, snapshots, retain twin ... */
+rgr_comm* rgr_group_comm(rgr_group* g, uint32_t shard);
+int32_t rgr_group_uses_rccl(const rgr_group* g);
+/* Router::add / remove / the restore loop, routed by rgr_shard_assign: a filter goes to its owner shard, or
+ * to every shard when a wildcard sits in its key levels.  sub ids stay the caller's. */
+int32_t rgr_group_subscribe_bulk(rgr_group* g, const uint8_t* blob, const uint64_t* offsets, uint64_t n, const uint32_t* sub_ids,
+                                 const uint8_t* qos, const uint8_t* flags, uint64_t* n_rejected);
+int32_t rgr_group_subscribe(rgr_group* g, const char* filter, uint32_t len, uint32_t sub_id, uint8_t qos, uint8_t flags);
+/* last_of_filter != 0: the caller's relations map for this filter became empty (router.rs:484-490): prune it */
+int32_t rgr_group_unsubscribe(rgr_group* g, const char* filter, uint32_t len, uint32_t sub_id, int32_t last_of_filter);
+int32_t rgr_group_commit(rgr_group* g);
+/* Router::matches over the group, host buffers in / out: identical to rgr_match_batch on one handle holding
+ * the whole table (same order, topic_idx = the caller's index). */
+int32_t rgr_group_match_batch(rgr_group* g, const uint8_t* topics_blob, const uint64_t* topic_offsets, uint32_t n, rgr_result* out);
+/* Device-resident form: the batch is split by owner shard; tuples carry the caller's topic index. */
+int32_t rgr_group_batch_create(rgr_group* g, const uint8_t* topics_blob, const uint64_t* topic_offsets, uint32_t n, rgr_group_batch** out);
+void rgr_group_batch_destroy(rgr_group_batch* gb);
+rgr_batch* rgr_group_batch_shard(rgr_group_batch* gb, uint32_t shard);
+/* one pass on all shards at once, tuples left on their GPUs; the per-shard hit counts are all-gathered */
+int32_t rgr_group_batch_run(rgr_group_batch* gb, uint64_t* shard_hits /* [size], optional */, uint64_t* total_hits);
+/* one pass with every window all-gathered to every shard; consume runs on shard `consumer_shard`'s thread */
+int32_t rgr_group_batch_gather(rgr_group_batch* gb, uint32_t consumer_shard, rgr_gather_consumer consume, void* user, uint64_t* total_hits);
 
 /* ---- observability ------------------------------------------------------------------------ */
 int32_t rgr_stats_get(rgr_handle* h, rgr_stats* out);

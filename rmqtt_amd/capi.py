@@ -30,12 +30,18 @@ SYMBOLS = [
     "rgr_sub_remove", "rgr_subscribe_bulk", "rgr_snapshot_save", "rgr_snapshot_load", "rgr_commit",
     "rgr_match_batch", "rgr_match_batch_deliver", "rgr_result_free", "rgr_match_filters", "rgr_filters_result_free",
     "rgr_batch_create", "rgr_batch_destroy", "rgr_batch_status", "rgr_batch_set_publish_attrs",
-    "rgr_batch_set_format", "rgr_batch_begin", "rgr_batch_next_window",
+    "rgr_batch_set_format", "rgr_batch_set_topic_ids", "rgr_batch_begin", "rgr_batch_next_window",
     "rgr_window_to_host", "rgr_batch_run", "rgr_batch_run_to_host",
     "rgr_retain_topic_add", "rgr_retain_topic_remove", "rgr_retain_add_bulk", "rgr_retain_commit",
     "rgr_retain_match_batch", "rgr_retain_result_free", "rgr_retain_batch_create", "rgr_retain_batch_create_tier",
     "rgr_shard_assign", "rgr_stats_get", "rgr_stats_reset",
+    "rgr_comm_unique_id", "rgr_comm_create", "rgr_comm_destroy", "rgr_comm_allgather_u64", "rgr_comm_gather_pass",
+    "rgr_group_create", "rgr_group_destroy", "rgr_group_size", "rgr_group_handle", "rgr_group_comm", "rgr_group_uses_rccl",
+    "rgr_group_subscribe_bulk", "rgr_group_subscribe", "rgr_group_unsubscribe", "rgr_group_commit", "rgr_group_match_batch",
+    "rgr_group_batch_create", "rgr_group_batch_destroy", "rgr_group_batch_shard", "rgr_group_batch_run", "rgr_group_batch_gather",
 ]
+GATHER_CONSUMER = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.c_uint64)
+RGR_COMM_ID_BYTES = 128
 
 
 class Config(C.Structure):
@@ -123,6 +129,7 @@ def lib():
         L.rgr_batch_status.argtypes = [vp]; L.rgr_batch_status.restype = vp
         L.rgr_batch_begin.argtypes = [vp]
         L.rgr_batch_set_format.argtypes = [vp, u32]
+        L.rgr_batch_set_topic_ids.argtypes = [vp, vp]
         L.rgr_batch_next_window.argtypes = [vp, C.POINTER(Window)]
         L.rgr_window_to_host.argtypes = [vp, C.POINTER(Window), vp, vp]
         L.rgr_batch_run.argtypes = [vp, C.POINTER(u64), C.POINTER(u32)]
@@ -138,6 +145,27 @@ def lib():
         L.rgr_shard_assign.argtypes = [vp, vp, u64, u32, i32, u32, vp]
         L.rgr_stats_get.argtypes = [vp, C.POINTER(Stats)]
         L.rgr_stats_reset.argtypes = [vp]
+        L.rgr_comm_unique_id.argtypes = [vp]
+        L.rgr_comm_create.argtypes = [vp, vp, u32, u32, C.POINTER(vp)]
+        L.rgr_comm_destroy.argtypes = [vp]; L.rgr_comm_destroy.restype = None
+        L.rgr_comm_allgather_u64.argtypes = [vp, u64, vp]
+        L.rgr_comm_gather_pass.argtypes = [vp, vp, GATHER_CONSUMER, vp, C.POINTER(u64), C.POINTER(u64)]
+        L.rgr_group_create.argtypes = [C.POINTER(Config), vp, u32, C.POINTER(vp)]
+        L.rgr_group_destroy.argtypes = [vp]; L.rgr_group_destroy.restype = None
+        L.rgr_group_size.argtypes = [vp]; L.rgr_group_size.restype = u32
+        L.rgr_group_handle.argtypes = [vp, u32]; L.rgr_group_handle.restype = vp
+        L.rgr_group_comm.argtypes = [vp, u32]; L.rgr_group_comm.restype = vp
+        L.rgr_group_uses_rccl.argtypes = [vp]
+        L.rgr_group_subscribe_bulk.argtypes = [vp, vp, vp, u64, vp, vp, vp, C.POINTER(u64)]
+        L.rgr_group_subscribe.argtypes = [vp, C.c_char_p, u32, u32, u8, u8]
+        L.rgr_group_unsubscribe.argtypes = [vp, C.c_char_p, u32, u32, i32]
+        L.rgr_group_commit.argtypes = [vp]
+        L.rgr_group_match_batch.argtypes = [vp, vp, vp, u32, C.POINTER(Result)]
+        L.rgr_group_batch_create.argtypes = [vp, vp, vp, u32, C.POINTER(vp)]
+        L.rgr_group_batch_destroy.argtypes = [vp]; L.rgr_group_batch_destroy.restype = None
+        L.rgr_group_batch_shard.argtypes = [vp, u32]; L.rgr_group_batch_shard.restype = vp
+        L.rgr_group_batch_run.argtypes = [vp, vp, C.POINTER(u64)]
+        L.rgr_group_batch_gather.argtypes = [vp, u32, GATHER_CONSUMER, vp, C.POINTER(u64)]
         _LIB = L
     return _LIB
 
@@ -381,6 +409,14 @@ class Batch:
         assert len(pa) == self.n
         _check(lib().rgr_batch_set_publish_attrs(self._b, pa.ctypes.data))
 
+    def set_topic_ids(self, ids):
+        """Tuples carry ids[i] instead of the batch index i (None restores it)."""
+        if ids is None:
+            _check(lib().rgr_batch_set_topic_ids(self._b, None)); return
+        a = np.ascontiguousarray(ids, dtype=np.uint32)
+        assert len(a) == self.n
+        _check(lib().rgr_batch_set_topic_ids(self._b, a.ctypes.data))
+
     def set_format(self, fmt):
         """RGR_FORMAT_TUPLE (12 B/hit) | RGR_FORMAT_SOA (sub ids + qos bytes, 5 B/hit) | RGR_FORMAT_PACKED (4 B/hit)."""
         _check(lib().rgr_batch_set_format(self._b, fmt))
@@ -410,3 +446,173 @@ class Batch:
         offs = np.zeros(w.topic_end - w.topic_begin + 1, dtype=np.uint64)
         _check(lib().rgr_window_to_host(self._b, C.byref(w), tuples.ctypes.data if w.n_hits else None, offs.ctypes.data))
         return tuples, offs
+
+
+_HIP = None
+
+
+def device_to_host(ptr, nbytes):
+    """Copy library-owned device memory to a numpy uint8 array (tests / bench checks only)."""
+    global _HIP
+    if _HIP is None:
+        _HIP = C.CDLL("libamdhip64.so")
+        _HIP.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    out = np.empty(int(nbytes), dtype=np.uint8)
+    if nbytes:
+        rc = _HIP.hipMemcpy(out.ctypes.data, C.c_void_p(int(ptr)), int(nbytes), 2)     # hipMemcpyDeviceToHost
+        if rc != 0:
+            raise RgrError(RGR_EDEVICE, f"hipMemcpy D2H failed ({rc})")
+    return out
+
+
+class Comm:
+    """One rank's RCCL communicator on a Router's device (rgr_comm_*): one rank per process."""
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * RGR_COMM_ID_BYTES)()
+        _check(lib().rgr_comm_unique_id(buf))
+        return bytes(buf)
+
+    def __init__(self, router, uid, rank, world):
+        self.router, self.rank, self.world = router, rank, world
+        self._c = C.c_void_p()
+        uid = bytes(uid)
+        assert len(uid) == RGR_COMM_ID_BYTES
+        _check(lib().rgr_comm_create(router._h, uid, rank, world, C.byref(self._c)))
+
+    def close(self):
+        if self._c:
+            lib().rgr_comm_destroy(self._c)
+            self._c = C.c_void_p()
+
+    def allgather_u64(self, mine):
+        out = np.zeros(self.world, dtype=np.uint64)
+        _check(lib().rgr_comm_allgather_u64(self._c, int(mine), out.ctypes.data))
+        return out
+
+    def gather_pass(self, batch, collect=False):
+        """All-gathered pass of `batch`.  -> (my_hits, all_hits, tuples | None): with collect, every round's
+        gathered device buffer is copied to the host and concatenated (tests)."""
+        parts = []
+
+        def cb(user, d_tuples, counts, world, n_total):
+            if collect and n_total:
+                parts.append(device_to_host(d_tuples, int(n_total) * 12).view(TUPLE_DTYPE))
+        fn = GATHER_CONSUMER(cb)
+        mine, allh = C.c_uint64(0), C.c_uint64(0)
+        _check(lib().rgr_comm_gather_pass(self._c, batch._b, fn, None, C.byref(mine), C.byref(allh)))
+        tup = (np.concatenate(parts) if parts else np.zeros(0, dtype=TUPLE_DTYPE)) if collect else None
+        return int(mine.value), int(allh.value), tup
+
+
+class Group:
+    """Single-process multi-device router (rgr_group_*): one shard per entry of `devices`."""
+
+    def __init__(self, devices, slot_cap=0, window_hits=0, chunk_topics=0, host_threads=0):
+        cfg = Config(0, slot_cap, window_hits, chunk_topics, host_threads, 1, 0, 0, 0)
+        devs = np.ascontiguousarray(devices, dtype=np.int32)
+        self._g = C.c_void_p()
+        _check(lib().rgr_group_create(C.byref(cfg), devs.ctypes.data, len(devs), C.byref(self._g)))
+        self.size = len(devs)
+
+    def close(self):
+        if self._g:
+            lib().rgr_group_destroy(self._g)
+            self._g = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def uses_rccl(self):
+        return bool(lib().rgr_group_uses_rccl(self._g))
+
+    def shard_stats(self, shard):
+        s = Stats()
+        _check(lib().rgr_stats_get(lib().rgr_group_handle(self._g, shard), C.byref(s)))
+        return s.as_dict()
+
+    def subscribe_bulk(self, blob, offsets, sub_ids=None, qos=None, flags=None):
+        n = len(offsets) - 1
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        keep = []
+
+        def p(a, dt):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dtype=dt); keep.append(a)
+            return C.c_void_p(a.ctypes.data)
+        rej = C.c_uint64(0)
+        bp, bk = _blob_ptr(blob)
+        _check(lib().rgr_group_subscribe_bulk(self._g, bp, offsets.ctypes.data, n, p(sub_ids, np.uint32), p(qos, np.uint8), p(flags, np.uint8), C.byref(rej)))
+        return int(rej.value)
+
+    def subscribe(self, f, sub_id, qos=0, flags=0):
+        f = _b(f)
+        _check(lib().rgr_group_subscribe(self._g, f, len(f), sub_id, qos, flags))
+
+    def unsubscribe(self, f, sub_id, last_of_filter=False):
+        f = _b(f)
+        _check(lib().rgr_group_unsubscribe(self._g, f, len(f), sub_id, int(last_of_filter)))
+
+    def commit(self):
+        _check(lib().rgr_group_commit(self._g))
+
+    def match_batch(self, blob, offsets):
+        n = len(offsets) - 1
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        r = Result()
+        bp, bk = _blob_ptr(blob)
+        _check(lib().rgr_group_match_batch(self._g, bp, offsets.ctypes.data, n, C.byref(r)))
+        try:
+            return dict(status=_copy(r.status, n, np.int32), hit_offsets=_copy(r.hit_offsets, n + 1, np.uint64),
+                        tuples=_copy(r.tuples, r.n_hits, TUPLE_DTYPE))
+        finally:
+            lib().rgr_result_free(C.byref(r))
+
+    def batch(self, blob, offsets):
+        return GroupBatch(self, blob, offsets)
+
+
+class GroupBatch:
+    def __init__(self, group, blob, offsets):
+        self.group = group
+        self.n = len(offsets) - 1
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self._b = C.c_void_p()
+        bp, bk = _blob_ptr(blob)
+        _check(lib().rgr_group_batch_create(group._g, bp, offsets.ctypes.data, self.n, C.byref(self._b)))
+
+    def close(self):
+        if self._b:
+            lib().rgr_group_batch_destroy(self._b)
+            self._b = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self):
+        """-> (per-shard hits uint64[size], total)"""
+        sh = np.zeros(self.group.size, dtype=np.uint64)
+        tot = C.c_uint64(0)
+        _check(lib().rgr_group_batch_run(self._b, sh.ctypes.data, C.byref(tot)))
+        return sh, int(tot.value)
+
+    def gather(self, consumer_shard=0, collect=False):
+        """All-gathered pass.  -> (total hits, tuples gathered on `consumer_shard` | None)"""
+        parts = []
+
+        def cb(user, d_tuples, counts, world, n_total):
+            if collect and n_total:
+                parts.append(device_to_host(d_tuples, int(n_total) * 12).view(TUPLE_DTYPE))
+        fn = GATHER_CONSUMER(cb)
+        tot = C.c_uint64(0)
+        _check(lib().rgr_group_batch_gather(self._b, consumer_shard, fn, None, C.byref(tot)))
+        tup = (np.concatenate(parts) if parts else np.zeros(0, dtype=TUPLE_DTYPE)) if collect else None
+        return int(tot.value), tup

@@ -170,6 +170,8 @@ struct rgr_batch {
     // delivery stage (rgr_batch_set_publish_attrs)
     bool deliver = false;
     int format = kFmtTuple;              // rgr_batch_set_format
+    bool has_topic_ids = false;          // rgr_batch_set_topic_ids
+    DevBuf d_topic_ids;
     DevBuf d_pub, pair_qr, cand, cand_count, dedup_tab, topic_cand, cand_off, dedup_tmp;
     PinnedBuf h_cand_count;
     DevBuf rf_filter[2], rf_node[2], r_cnt, r_payload, r_ecnt, r_e0, r_e1, r_out_off, r_epos, r_big, r_end, r_depth;   // retain frontier rounds
@@ -390,6 +392,7 @@ ChunkArrays make_chunk_arrays(rgr_batch* b, uint32_t n) {
     c.pair_topic = b->pair_topic.as<uint32_t>();
     c.pair_off = b->pair_off.as<uint64_t>();
     if (b->deliver && !b->retain) { c.pub = b->d_pub.as<PublishAttr>(); c.pair_qr = b->pair_qr.as<uint8_t>(); }
+    else if (b->has_topic_ids) c.topic_ids = b->d_topic_ids.as<uint32_t>();
     return c;
 }
 
@@ -871,6 +874,7 @@ static int32_t batch_create_impl(rgr_handle* h, const uint8_t* blob, const uint6
         b->tier = retain ? tier : 0;
         b->deliver = false;
         b->format = kFmtTuple;
+        b->has_topic_ids = false;
         b->in_pass = false; b->chunk_ready = false; b->cursor = 0; b->hits_before = 0;
         b->dict_tokens = ~0ull;
         b->epoch.reset(); b->repoch.reset();
@@ -948,12 +952,28 @@ int32_t rgr_batch_set_publish_attrs(rgr_batch* b, const rgr_publish_attr* attrs)
         if (b->retain) return fail(RGR_ESTATE, "rgr_batch_set_publish_attrs: not a publish batch");
         if (!attrs) { b->deliver = false; return RGR_OK; }
         if (b->format != kFmtTuple) return fail(RGR_ESTATE, "rgr_batch_set_publish_attrs: the delivery stage needs RGR_FORMAT_TUPLE");
+        if (b->has_topic_ids) return fail(RGR_ESTATE, "rgr_batch_set_publish_attrs: not together with rgr_batch_set_topic_ids");
         RGR_HIP(hipSetDevice(b->h->cfg.device));
         static_assert(sizeof(rgr_publish_attr) == sizeof(PublishAttr), "rgr_publish_attr layout");
         b->d_pub.ensure(std::max<size_t>(1, b->n) * sizeof(PublishAttr));
         if (b->n) RGR_HIP(hipMemcpyAsync(b->d_pub.p, attrs, size_t(b->n) * sizeof(PublishAttr), hipMemcpyHostToDevice, b->stream));
         RGR_HIP(hipStreamSynchronize(b->stream));
         b->deliver = true;
+        return RGR_OK;
+    });
+}
+
+int32_t rgr_batch_set_topic_ids(rgr_batch* b, const uint32_t* ids) {
+    return guarded([&]() -> int32_t {
+        if (!b) return fail(RGR_EINVAL, "rgr_batch_set_topic_ids: bad argument");
+        if (b->in_pass) return fail(RGR_ESTATE, "rgr_batch_set_topic_ids: inside a pass");
+        if (!ids) { b->has_topic_ids = false; return RGR_OK; }
+        if (b->deliver) return fail(RGR_ESTATE, "rgr_batch_set_topic_ids: not together with publish attributes");
+        RGR_HIP(hipSetDevice(b->h->cfg.device));
+        b->d_topic_ids.ensure(std::max<size_t>(1, b->n) * 4);
+        if (b->n) RGR_HIP(hipMemcpyAsync(b->d_topic_ids.p, ids, size_t(b->n) * 4, hipMemcpyHostToDevice, b->stream));
+        RGR_HIP(hipStreamSynchronize(b->stream));
+        b->has_topic_ids = true;
         return RGR_OK;
     });
 }
@@ -1242,7 +1262,7 @@ struct ResultOwner {
 }  // namespace
 
 static int32_t match_batch_impl(rgr_handle* h, const uint8_t* blob, const uint64_t* offs, uint32_t n, const rgr_publish_attr* attrs,
-                                rgr_result* out) {
+                                rgr_result* out, const uint32_t* topic_ids = nullptr) {
     if (!out) return fail(RGR_EINVAL, "rgr_match_batch: out is NULL");
     std::memset(out, 0, sizeof *out);
     rgr_batch* b = nullptr;
@@ -1255,6 +1275,7 @@ static int32_t match_batch_impl(rgr_handle* h, const uint8_t* blob, const uint64
         own->offsets.assign(size_t(n) + 1, 0);
         int32_t r = attrs ? rgr_batch_set_publish_attrs(b, attrs) : RGR_OK;
         if (r != RGR_OK) return r;
+        if (topic_ids) { r = rgr_batch_set_topic_ids(b, topic_ids); if (r != RGR_OK) return r; }
         r = rgr_batch_begin(b);
         if (r != RGR_OK) return r;
         // Windows are expanded and copied in a two-deep pipeline straight into the result block.  The block is
@@ -1449,3 +1470,4 @@ int32_t rgr_stats_reset(rgr_handle* h) {
 }  // extern "C"
 
 #include "retain_abi.inc"
+#include "group_abi.inc"

@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256) void compact_big_kernel(TrieView tv, ChunkArra
             if (ml) {
                 const uint64_t p = p0 + pl + (xl - ml);
                 c.pair_src[p] = fd.begin;
-                c.pair_topic[p] = topic_base + t;
+                c.pair_topic[p] = c.topic_ids ? c.topic_ids[topic_base + t] : topic_base + t;
                 if (c.pair_qr) c.pair_qr[p] = uint8_t(c.pub[topic_base + t].qos_retain);
                 c.pair_off[p] = o0 + pc + (xc - mc);
             }

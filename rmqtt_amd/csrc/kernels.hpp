@@ -162,6 +162,8 @@ struct ChunkArrays {
     // the pair at compaction so that the expansion's prologue has no dependent load for it
     const PublishAttr* pub;      // [n_batch]
     uint8_t* pair_qr;            // [P]
+    // rgr_batch_set_topic_ids: value written into rgr_tuple.topic_idx for batch topic i (null: i itself)
+    const uint32_t* topic_ids = nullptr;
 };
 
 // incremental epoch update: patch `n` edge records / filter descriptors of a device image

@@ -260,7 +260,7 @@ RGR_HD inline void compact_topic(const TrieView& tv, const ChunkArrays& c, uint3
             const FilterDesc fd = tv.filt[pair_fid(c, t, cnt, j)];
             if (fd.count) {
                 c.pair_src[p] = fd.begin;
-                c.pair_topic[p] = topic_base + t;
+                c.pair_topic[p] = c.topic_ids ? c.topic_ids[topic_base + t] : topic_base + t;
                 if (c.pair_qr) c.pair_qr[p] = uint8_t(c.pub[topic_base + t].qos_retain);
                 c.pair_off[p] = o;
                 ++p; o += fd.count;

@@ -1,0 +1,99 @@
+"""Multi-GPU layer of the C ABI (rgr_group_*, rgr_comm_*) on the HIP backend.
+
+A single-GPU box cannot host two RCCL ranks, so the group is built with a repeated device ordinal: several
+shards on one GPU, exchanging through device copies with the same protocol (counts round, then the
+all-gatherv payload).  Everything is checked against the oracle's DefaultRouter on the UNSHARDED table.  The
+RCCL transport itself is exercised with a world of one (ncclCommInitRank, ncclAllGather, the empty
+send/recv group); world > 1 over xGMI needs the multi-GPU node the driver runs bench.py on."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from rmqtt_amd import capi
+from rmqtt_amd import workload as wl
+
+pytestmark = pytest.mark.gpu
+
+
+def _world(n_sub=30_000, n_pub=6_000, cfg=3):
+    c = wl.CONFIGS[cfg]
+    blob, offs, client, qos = wl.gen_subs(n_sub, wl.SUB_SEED + cfg, c["p_plus"], c["p_hash"], c["p_sys"])
+    tb, to = wl.gen_topics(n_pub, wl.PUB_SEED + cfg, 0.01, c["p_blank"])
+    o = orc.DefaultRouter()
+    assert o.add_bulk(blob, offs, client, qos) == 0
+    return blob, offs, qos, tb, to, o.match_flat(tb, to)
+
+
+@pytest.mark.parametrize("shards", [1, 2, 3])
+def test_group_matches_the_unsharded_oracle(shards):
+    blob, offs, qos, tb, to, exp = _world()
+    g = capi.Group([0] * shards, window_hits=40_000, chunk_topics=2048)
+    assert g.uses_rccl() == (shards == 1)
+    assert g.subscribe_bulk(blob, offs, None, qos) == 0
+    g.commit()
+    # host in / host out: identical to one handle holding the whole table
+    got = g.match_batch(tb, to)
+    assert np.array_equal(got["status"] < 0, exp["status"] < 0)
+    assert np.array_equal(got["hit_offsets"], exp["hit_offsets"])
+    assert np.array_equal(got["tuples"]["sub_id"], exp["sub_ids"])
+    assert np.array_equal(got["tuples"]["qos_flags"] & 0xFF, exp["qos"])
+    ho = exp["hit_offsets"].astype(np.int64)
+    assert np.array_equal(got["tuples"]["topic_idx"], np.repeat(np.arange(len(to) - 1, dtype=np.uint32), np.diff(ho)))
+    # device-resident: per-shard counts are all-gathered and add up to the oracle's total
+    gb = g.batch(tb, to)
+    sh, tot = gb.run()
+    assert tot == len(exp["sub_ids"]) and int(sh.sum()) == tot and len(sh) == shards
+    if shards > 1:
+        assert (sh > 0).all()                                    # the hash really spreads the work
+    # all-gatherv of the tuples: every hit exactly once, tagged with the caller's topic index
+    for consumer in range(shards):
+        tot2, tup = gb.gather(consumer_shard=consumer, collect=True)
+        assert tot2 == tot and len(tup) == tot
+        order = np.lexsort((np.arange(len(tup)), tup["topic_idx"]))          # stable: keeps each topic's own order
+        tup = tup[order]
+        assert np.array_equal(tup["topic_idx"], got["tuples"]["topic_idx"])
+        assert np.array_equal(tup["sub_id"], exp["sub_ids"])
+    gb.close(); g.close()
+
+
+def test_group_single_subscribe_unsubscribe_routes_like_bulk():
+    g = capi.Group([0, 0], window_hits=64)
+    o = orc.DefaultRouter()
+    filters = ["a/b/c/d", "a/+/c/#", "+/b/#", "#", "x/y/z/w/#", "x/y/z/+", "a/b/c/+", "$SYS/a/#"]
+    for i, f in enumerate(filters):
+        g.subscribe(f, i, qos=i % 3)
+        assert o.add(f, orc.mk_id(1, f"c{i}"), orc.mk_opts(qos=i % 3), rel_id=i) == 0
+    g.commit()
+    tb, to = capi.pack(["a/b/c/d", "x/y/z/w", "x/y/z/w/v", "$SYS/a/b", "q", "a/b/c/e"])
+    exp = o.match_flat(tb, to)
+    got = g.match_batch(tb, to)
+    assert np.array_equal(got["hit_offsets"], exp["hit_offsets"]) and np.array_equal(got["tuples"]["sub_id"], exp["sub_ids"])
+    g.unsubscribe("a/+/c/#", 1, last_of_filter=True)          # replicated filter: removed from every shard
+    g.unsubscribe("a/b/c/d", 0, last_of_filter=True)          # owned filter
+    assert o.remove("a/+/c/#", orc.mk_id(1, "c1")) == 0 and o.remove("a/b/c/d", orc.mk_id(1, "c0")) == 0
+    g.commit()
+    exp = o.match_flat(tb, to)
+    got = g.match_batch(tb, to)
+    assert np.array_equal(got["hit_offsets"], exp["hit_offsets"]) and np.array_equal(got["tuples"]["sub_id"], exp["sub_ids"])
+    g.close()
+
+
+def test_rccl_communicator_world_of_one():
+    """ncclGetUniqueId / ncclCommInitRank / ncclAllGather / the send-recv group through the library, one rank."""
+    blob, offs, qos, tb, to, exp = _world(8_000, 2_000)
+    r = capi.Router(device=0, window_hits=30_000)
+    assert r.subscribe_bulk(blob, offs, None, qos) == 0
+    r.commit()
+    uid = capi.Comm.unique_id()
+    assert len(uid) == 128 and any(uid)
+    c = capi.Comm(r, uid, 0, 1)
+    assert c.allgather_u64(12345678901234).tolist() == [12345678901234]
+    b = r.batch(tb, to)
+    b.set_topic_ids(np.arange(len(to) - 1, dtype=np.uint32)[::-1].copy())       # caller-chosen ids ride along
+    mine, allh, tup = c.gather_pass(b, collect=True)
+    assert mine == allh == len(exp["sub_ids"]) == len(tup)
+    n = len(to) - 1
+    assert np.array_equal(tup["sub_id"], exp["sub_ids"])
+    ho = exp["hit_offsets"].astype(np.int64)
+    assert np.array_equal(tup["topic_idx"], np.repeat((n - 1 - np.arange(n)).astype(np.uint32), np.diff(ho)))
+    b.close(); c.close(); r.close()
