@@ -373,15 +373,47 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
 
     rank_hits = []          # per-rank hit counts of the last step (N>1, --gather counts): the shard imbalance
 
+    # N>1: the exchange step runs inside the library over RCCL (rgr_comm_*: ncclAllGather of the counts,
+    # all-gatherv of the tuples as a send/recv group) — torch.distributed only ships the 128-byte communicator
+    # id.  Under gloo (several ranks sharing one GPU: logic tests) RCCL cannot form a communicator and the
+    # torch collectives are used instead; `collective` in the output says which path ran.
+    comm = None
+    collective = "n/a"
+    if world > 1:
+        collective = "torch.distributed"
+        if args.dist_backend == "nccl" and not args.torch_collectives:
+            try:
+                uid = torch.zeros(capi.RGR_COMM_ID_BYTES, dtype=torch.uint8, device=cdev)
+                if rank == 0:
+                    uid = torch.frombuffer(bytearray(capi.Comm.unique_id()), dtype=torch.uint8).to(cdev)
+                dist.broadcast(uid, 0)
+                comm = capi.Comm(r, bytes(uid.cpu().numpy().tobytes()), rank, world)
+                collective = "rccl (rgr_comm_*, inside the library)"
+            except Exception as e:
+                log(f"library RCCL communicator unavailable ({e!r}): using torch.distributed collectives", rank)
+                comm = None
+            ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int64, device=cdev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0 and comm is not None:
+                comm.close(); comm = None; collective = "torch.distributed"
+        batch.set_topic_ids(keep_t.astype(np.uint32))          # tuples carry the GLOBAL publish index
+
     def step():
         if world > 1 and args.gather == "tuples":
+            if comm is not None:
+                mine, _, _ = comm.gather_pass(batch)
+                rank_hits[:] = []
+                return mine, 0
             return step_gather_tuples()
         hits, nwin = batch.run()      # synchronises the library's stream at the end of the pass
         if world > 1 and args.gather != "none":
-            cnt = torch.tensor([hits], dtype=torch.int64, device=cdev)
-            allc = [torch.zeros_like(cnt) for _ in range(world)]
-            dist.all_gather(allc, cnt)
-            rank_hits[:] = [int(x.item()) for x in allc]
+            if comm is not None:
+                rank_hits[:] = [int(x) for x in comm.allgather_u64(hits)]
+            else:
+                cnt = torch.tensor([hits], dtype=torch.int64, device=cdev)
+                allc = [torch.zeros_like(cnt) for _ in range(world)]
+                dist.all_gather(allc, cnt)
+                rank_hits[:] = [int(x.item()) for x in allc]
         return hits, nwin
 
     for _ in range(warmup):
@@ -404,6 +436,8 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
     else:
         total_hits, total_topics = hits, my_topics
     st = r.stats()
+    if comm is not None:
+        comm.close()
     if rank != 0:
         batch.close(); r.close()
         return None, None
@@ -442,7 +476,7 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
                                 f"BASELINE.json configs[{cfg - 1}]: {n_sub} subscriptions (p_plus/level {c['p_plus']}, p_hash {c['p_hash']}, "
                                 f"Zipf tokens s=1.1, Zipf clients s=1.0), {n_pub} publish topics, seeds 0x{wl.SUB_SEED + cfg:X}/0x{wl.PUB_SEED + cfg:X}"),
                    "subscriptions": n_sub, "publishes": n_pub, "sharding": f"hash of the first {shard.KEY_LEVELS} levels x{world}" if world > 1 else "none",
-                   "gather": args.gather if world > 1 else "n/a", "windows_per_step": int(nwin)},
+                   "gather": args.gather if world > 1 else "n/a", "collective": collective, "windows_per_step": int(nwin)},
         "hits_per_step": int(total_hits), "hits_per_s": round(total_hits * K / elapsed, 1),
         "mean_hits_per_topic": round(total_hits / max(1, total_topics), 2),
         "mean_visited_nodes_per_topic": round(st["visited_nodes"] / max(1, st["topics"]), 2),
@@ -517,7 +551,7 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
             o.add_bulk(blob, offs, client, qos)
         log(f"config {cfg}: oracle table built in {time.time() - t:.1f}s; cpu_baseline on {cores} threads", 0)
         # bounded sample: ~15 s of CPU work at the oracle's measured rates (primary), ~5 s (secondary)
-        budget_hits = (3.5e7 if retain else 4.0e9) * cores / 256 * (1.0 if primary else 0.3)
+        budget_hits = (3.5e7 if retain else 1.2e9) * cores / 256 * (1.0 if primary else 0.3)
         n_s = args.cpu_sample if args.cpu_sample > 0 else int(min(n_pub, max(200 if retain else 2000, budget_hits / hits_per_topic)))
         sb, so = prefix(W, n_s)
         if retain:
@@ -527,6 +561,11 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
             sec, ost = o.matches_timed(sb, so, cores)
             what = ("DefaultRouter::_matches-shaped (router.rs:174-265: parse, trie walk, relations lookup, per-hit ref-counted clones into the "
                     "collector; no canonicalising sort), chunks of 16 topics from an atomic cursor")
+        plain = None
+        if not retain:      # the same pass without the contended refcount bumps, for scale
+            sec_p, ost_p = o.matches_timed(sb, so, cores, refcounted=False)
+            plain = {"value": round(n_s / sec_p, 1), "hits_per_s": round(ost_p["hits"] / sec_p, 1),
+                     "what": "same pass with plain pointer copies instead of ref-counted clones (no atomic increments on hot ClientIds)"}
         cpu = {"value": round(n_s / sec, 1), "unit": rec["unit"], "cores": cores, "kind": "port", "what": what,
                "sample": f"first {n_s} queries of the same batch against the full {n_sub}-entry table, {ost['hits']} hits, {sec:.2f}s wall",
                "hits_per_s": round(ost["hits"] / sec, 1)}
@@ -535,6 +574,8 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
             s1b, s1o = prefix(W, n1)
             sec1, ost1 = (o.match_timed(s1b, s1o, 1) if retain else o.matches_timed(s1b, s1o, 1))
             cpu["single_thread"] = {"value": round(n1 / sec1, 1), "hits_per_s": round(ost1["hits"] / sec1, 1), "sample": f"first {n1} queries, {sec1:.2f}s wall"}
+        if plain:
+            cpu["without_refcounting"] = plain
         rec["cpu_baseline"] = cpu
         if not args.no_parity:
             n_p = int(min(n_s, max(256, (1.2e9 if primary else 4.0e8) / hits_per_topic)))
@@ -608,6 +649,7 @@ def main():
     ap.add_argument("--deliver", type=float, default=-1.0, metavar="V5FRAC",
                     help="also run the delivery stage (SURVEY 8(f)-1): this fraction of the subscriptions is MQTT v5 "
                          "(No Local / RAP / per-client dedup); 0 = v3 only. Not the headline metric.")
+    ap.add_argument("--torch-collectives", action="store_true", help="N>1: use torch.distributed collectives instead of the library's RCCL communicator")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo lets the N>1 logic be exercised on one GPU")
     args = ap.parse_args()
 

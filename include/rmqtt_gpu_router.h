@@ -402,12 +402,17 @@ int32_t rgr_group_uses_rccl(const rgr_group* g);
 int32_t rgr_group_subscribe_bulk(rgr_group* g, const uint8_t* blob, const uint64_t* offsets, uint64_t n, const uint32_t* sub_ids,
                                  const uint8_t* qos, const uint8_t* flags, uint64_t* n_rejected);
 int32_t rgr_group_subscribe(rgr_group* g, const char* filter, uint32_t len, uint32_t sub_id, uint8_t qos, uint8_t flags);
+/* with the delivery-stage attributes of rgr_sub_add_ex */
+int32_t rgr_group_subscribe_ex(rgr_group* g, const char* filter, uint32_t len, uint32_t sub_id, uint8_t qos, uint8_t flags,
+                               uint16_t node_idx, uint32_t owner_id, uint32_t client_idx);
 /* last_of_filter != 0: the caller's relations map for this filter became empty (router.rs:484-490): prune it */
 int32_t rgr_group_unsubscribe(rgr_group* g, const char* filter, uint32_t len, uint32_t sub_id, int32_t last_of_filter);
 int32_t rgr_group_commit(rgr_group* g);
 /* Router::matches over the group, host buffers in / out: identical to rgr_match_batch on one handle holding
  * the whole table (same order, topic_idx = the caller's index). */
 int32_t rgr_group_match_batch(rgr_group* g, const uint8_t* topics_blob, const uint64_t* topic_offsets, uint32_t n, rgr_result* out);
+int32_t rgr_group_match_batch_deliver(rgr_group* g, const uint8_t* topics_blob, const uint64_t* topic_offsets, uint32_t n,
+                                      const rgr_publish_attr* attrs, rgr_result* out);
 /* Device-resident form: the batch is split by owner shard; tuples carry the caller's topic index. */
 int32_t rgr_group_batch_create(rgr_group* g, const uint8_t* topics_blob, const uint64_t* topic_offsets, uint32_t n, rgr_group_batch** out);
 void rgr_group_batch_destroy(rgr_group_batch* gb);

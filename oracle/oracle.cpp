@@ -102,9 +102,10 @@ struct Collector {
     std::vector<SubRelation> v3_rels;
     std::vector<std::string> v5_order;                       // deterministic stand-in for HashMap order
     std::unordered_map<std::string, SubRelation> v5_rels;
-    void add(const std::string& filter, const std::string& client, const SubscriptionOptions& opts, uint32_t rel_id) {
+    void add(const std::string& filter, const std::string& client, const SubscriptionOptions& opts, uint32_t rel_id,
+             std::optional<SharedGroupInfo> group = std::nullopt) {
         if (opts.is_v3()) {
-            v3_rels.push_back(SubRelation{filter, client, opts, std::nullopt, rel_id});
+            v3_rels.push_back(SubRelation{filter, client, opts, std::nullopt, rel_id, std::move(group)});
             return;
         }
         auto it = v5_rels.find(client);
@@ -114,7 +115,7 @@ struct Collector {
                 else it->second.sub_ids = std::vector<uint32_t>{opts.sub_ident};
             }
         } else {                                              // types.rs:535-538
-            SubRelation r{filter, client, opts, std::nullopt, rel_id};
+            SubRelation r{filter, client, opts, std::nullopt, rel_id, std::move(group)};
             if (opts.sub_ident) r.sub_ids = std::vector<uint32_t>{opts.sub_ident};
             v5_rels.emplace(client, std::move(r));
             v5_order.push_back(client);
@@ -138,11 +139,26 @@ bool DefaultRouter::matches(const Id& this_id, std::string_view topic_name, SubR
         std::vector<const std::pair<const std::string, Rel>*> ordered;
         for (auto& kv : rit->second.rels) ordered.push_back(&kv);
         std::sort(ordered.begin(), ordered.end(), [](auto* a, auto* b) { return a->second.rel_id < b->second.rel_id; });
+        std::map<std::string, std::vector<SharedCandidate>> groups;                       // router.rs:183-192
         for (auto* kv : ordered) {
             const Rel& rel = kv->second;
             auto nl = rel.opts.opt_no_local();
             if (nl && *nl && this_id == rel.id) continue;      // router.rs:196-201
+            if (!rel.opts.shared_group.empty()) {              // router.rs:204-213: deferred to the group choice
+                groups[rel.opts.shared_group].push_back(SharedCandidate{rel.id.node_id, kv->first, rel.opts, true, rel.rel_id});
+                continue;
+            }
             collector_map[rel.id.node_id].add(filter, kv->first, rel.opts, rel.rel_id);   // router.rs:214-229
+            if (st) st->hits++;
+        }
+        for (auto& gk : groups) {                              // router.rs:236-255
+            auto& subs = gk.second;
+            std::vector<std::string> cids;
+            for (auto& c : subs) cids.push_back(c.client_id);
+            const auto idx = shared_choice_ ? shared_choice_(gk.first, this_id, topic_name, subs) : std::nullopt;
+            if (!idx) continue;
+            const SharedCandidate& c = subs[*idx];
+            collector_map[c.node_id].add(filter, c.client_id, c.opts, c.rel_id, SharedGroupInfo{gk.first, c.is_online, cids});
             if (st) st->hits++;
         }
     }
@@ -187,7 +203,8 @@ void DefaultRouter::prepare_shaped() {
     shaped_ready_ = relations_count_;
 }
 
-uint64_t DefaultRouter::matches_shaped(const Id& this_id, std::string_view topic_name, WalkStats* st) const {
+uint64_t DefaultRouter::matches_shaped(const Id& this_id, std::string_view topic_name, WalkStats* st, bool refcounted) const {
+    if (!refcounted) return matches_shaped_plain(this_id, topic_name, st);
     struct Out { std::shared_ptr<const std::string> filter, client; SubscriptionOptions opts; };
     Topic topic;
     if (!parse_topic(topic_name, topic)) { if (st) st->invalid++; return 0; }            // router.rs:177
@@ -211,6 +228,31 @@ uint64_t DefaultRouter::matches_shaped(const Id& this_id, std::string_view topic
     }
     if (st) st->hits += hits;
     return hits;                                                                         // map dropped here: the clones are released
+}
+
+// The same pass with plain pointers instead of ref-counted clones: what the work costs WITHOUT the contended
+// atomic increments on hot ClientIds (an upper bound on what a reference build with interned ids could do).
+uint64_t DefaultRouter::matches_shaped_plain(const Id& this_id, std::string_view topic_name, WalkStats* st) const {
+    struct Out { const std::string* filter; const std::string* client; SubscriptionOptions opts; };
+    Topic topic;
+    if (!parse_topic(topic_name, topic)) { if (st) st->invalid++; return 0; }
+    if (st) st->levels += topic.size();
+    std::unordered_map<NodeId, std::vector<Out>> collector_map;
+    uint64_t hits = 0;
+    for (auto& item : topics_.matches(topic, st)) {
+        const std::string filter = join_levels(item.first);
+        auto rit = shaped_.find(filter);
+        if (rit == shaped_.end()) continue;
+        for (auto& e : rit->second.rels) {
+            const Rel& rel = *e.rel;
+            auto nl = rel.opts.opt_no_local();
+            if (nl && *nl && this_id == rel.id) continue;
+            collector_map[rel.id.node_id].push_back(Out{&rit->first, e.client.get(), rel.opts});
+            ++hits;
+        }
+    }
+    if (st) st->hits += hits;
+    return hits;
 }
 
 bool DefaultRouter::has_matches(std::string_view t) const {
@@ -410,15 +452,39 @@ static Id mk_id(const orc_id* i) {
     id.client_id.assign(i->client_id, i->client_len);
     return id;
 }
-struct orc_opts { uint8_t v5, qos, no_local, retain_as_published, retain_handling; uint32_t sub_ident; };
+struct orc_opts { uint8_t v5, qos, no_local, retain_as_published, retain_handling; uint32_t sub_ident; const char* shared_group; uint32_t shared_group_len; };
 static SubscriptionOptions mk_opts(const orc_opts* o) {
     SubscriptionOptions s;
     s.v5 = o->v5; s.qos = o->qos; s.no_local = o->no_local; s.retain_as_published = o->retain_as_published;
     s.retain_handling = o->retain_handling; s.sub_ident = o->sub_ident;
+    if (o->shared_group && o->shared_group_len) s.shared_group.assign(o->shared_group, o->shared_group_len);
     return s;
 }
 
+// "\t$<group>:<online>:<sorted member client ids,>" for the member a shared group selected, "" otherwise
+static std::string group_text(const SubRelation& s) {
+    if (!s.group) return "";
+    auto c = s.group->group_cids;
+    std::sort(c.begin(), c.end());
+    std::string r = "\t$" + esc(s.group->group) + ":" + std::to_string(int(s.group->is_online)) + ":";
+    for (size_t i = 0; i < c.size(); ++i) { if (i) r.push_back(','); r += esc(c[i]); }
+    return r;
+}
+
 void* orc_router_new() { return new DefaultRouter(); }
+// Test policies for SharedSubscription::choice (order-independent): 0 = the reference's default (nobody),
+// 1 = the member with the smallest client id, 2 = the member with the largest rel_id.
+void orc_router_set_shared_policy(void* r, int policy) {
+    auto* rt = static_cast<DefaultRouter*>(r);
+    if (policy == 0) { rt->set_shared_choice(nullptr); return; }
+    rt->set_shared_choice([policy](const std::string&, const Id&, std::string_view, const std::vector<SharedCandidate>& c) -> std::optional<size_t> {
+        if (c.empty()) return std::nullopt;
+        size_t best = 0;
+        for (size_t i = 1; i < c.size(); ++i)
+            if (policy == 1 ? c[i].client_id < c[best].client_id : c[i].rel_id > c[best].rel_id) best = i;
+        return best;
+    });
+}
 void orc_router_free(void* r) { delete static_cast<DefaultRouter*>(r); }
 int orc_router_add(void* r, const char* f, uint64_t len, const orc_id* id, const orc_opts* o, uint32_t rel_id) {
     return static_cast<DefaultRouter*>(r)->add(std::string_view(f, len), mk_id(id), mk_opts(o), rel_id) ? 0 : -1;
@@ -459,14 +525,14 @@ char* orc_router_matches(void* r, const orc_id* this_id, const char* topic, uint
         std::vector<std::string> v3, v5;
         for (auto& s : kv.second) {
             if (s.opts.is_v3()) {
-                v3.push_back("3 " + esc(s.topic_filter) + "\t" + esc(s.client_id) + "\t" + std::to_string(s.opts.qos) + "\t" + std::to_string(s.rel_id) + "\n");
+                v3.push_back("3 " + esc(s.topic_filter) + "\t" + esc(s.client_id) + "\t" + std::to_string(s.opts.qos) + "\t" + std::to_string(s.rel_id) + group_text(s) + "\n");
             } else {
                 std::string ids;
                 if (s.sub_ids) {
                     auto v = *s.sub_ids; std::sort(v.begin(), v.end());
                     for (size_t i = 0; i < v.size(); ++i) { if (i) ids.push_back(','); ids += std::to_string(v[i]); }
                 } else ids = "-";
-                v5.push_back("5 " + esc(s.client_id) + "\t" + esc(s.topic_filter) + "\t" + std::to_string(s.opts.qos) + "\t" + std::to_string(int(s.opts.no_local)) + "\t" + ids + "\n");
+                v5.push_back("5 " + esc(s.client_id) + "\t" + esc(s.topic_filter) + "\t" + std::to_string(s.opts.qos) + "\t" + std::to_string(int(s.opts.no_local)) + "\t" + ids + group_text(s) + "\n");
             }
         }
         std::sort(v3.begin(), v3.end()); std::sort(v5.begin(), v5.end());
@@ -629,7 +695,7 @@ void orc_retain_match_digest(void* t, const char* blob, const uint64_t* offs, ui
 // same atomic increment (and the matching decrement when the result map is dropped).  Threads model
 // tokio workers under the trie's RwLock read guard; topics are handed out in chunks of 16 from an
 // atomic cursor, so the Zipf hit distribution cannot strand a thread with the heavy topics.
-double orc_router_matches_timed(void* r, const char* blob, const uint64_t* offs, uint64_t n, int threads, orc_stats* stats) {
+double orc_router_matches_timed(void* r, const char* blob, const uint64_t* offs, uint64_t n, int threads, int refcounted, orc_stats* stats) {
     auto* rt = static_cast<DefaultRouter*>(r);
     if (threads < 1) threads = 1;
     rt->prepare_shaped();
@@ -644,7 +710,7 @@ double orc_router_matches_timed(void* r, const char* blob, const uint64_t* offs,
                 const uint64_t lo = next.fetch_add(16), hi = std::min<uint64_t>(n, lo + 16);
                 if (lo >= n) break;
                 for (uint64_t i = lo; i < hi; ++i)
-                    rt->matches_shaped(nobody, std::string_view(blob + offs[i], offs[i + 1] - offs[i]), &sts[k]);
+                    rt->matches_shaped(nobody, std::string_view(blob + offs[i], offs[i + 1] - offs[i]), &sts[k], refcounted != 0);
             }
         });
     }

@@ -25,6 +25,7 @@
 // also an honest single-/multi-thread CPU baseline ("port" in bench.py).
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <map>
 #include <memory>
 #include <optional>
@@ -202,19 +203,28 @@ struct SubscriptionOptions {
     bool retain_as_published = false;      // v5 only (carried, not interpreted here)
     uint8_t retain_handling = 0;           // v5 only (carried)
     uint32_t sub_ident = 0;                // v5 subscription identifier, 0 = None
+    std::string shared_group;              // "" = None (types.rs:776, 815): the <group> of $share/<group>/<filter>
     std::optional<bool> opt_no_local() const { return v5 ? std::optional<bool>(no_local) : std::nullopt; }
     bool is_v3() const { return !v5; }
 };
 
-// SubRelation (types.rs:478-484) minus the shared-group member (host-side post
-// filter, out of scope — SURVEY.md App. A.3).
+// SharedGroupType (types.rs:474): (group, is_online of the chosen member, client ids of the whole group)
+struct SharedGroupInfo { std::string group; bool is_online = true; std::vector<std::string> group_cids; };
+// SubRelation (types.rs:478-484)
 struct SubRelation {
     std::string topic_filter;
     std::string client_id;
     SubscriptionOptions opts;
     std::optional<std::vector<uint32_t>> sub_ids;
     uint32_t rel_id = 0;    // test-only: dense relation id registered with add()
+    std::optional<SharedGroupInfo> group;   // Some for the member SharedSubscription::choice picked
 };
+// One candidate handed to SharedSubscription::choice (subscribe.rs:80-95): (node, client, opts, is_online)
+struct SharedCandidate { NodeId node_id; std::string client_id; SubscriptionOptions opts; bool is_online; uint32_t rel_id; };
+// choice(group, publisher, topic, candidates) -> index or nullopt.  The reference's default
+// (DefaultSharedSubscription, subscribe.rs:107) returns None: without the shared-subscription plugin no
+// member receives the publish.  Test policies must not depend on the candidates' order (it is hash-map order).
+using SharedChoice = std::function<std::optional<size_t>(const std::string&, const Id&, std::string_view, const std::vector<SharedCandidate>&)>;
 using SubRelationsMap = std::map<NodeId, std::vector<SubRelation>>;
 
 // ---------------------------------------------------------------- router.rs
@@ -229,6 +239,9 @@ class DefaultRouter {   // router.rs:121-127
     int remove(std::string_view topic_filter, const Id& id);
     // router.rs:174-265.  false => Err (invalid topic name).
     bool matches(const Id& this_id, std::string_view topic_name, SubRelationsMap& out, WalkStats* st = nullptr) const;
+    // SharedSubscription::choice used by matches() for $share members (router.rs:236-255); unset = the
+    // reference's default, which selects nobody.
+    void set_shared_choice(SharedChoice c) { shared_choice_ = std::move(c); }
     // Id-level view of the same walk for the C-ABI parity tests: per matched filter in
     // App. A.2 order, its relations sorted by rel_id (App. A.5 canonical form).
     // No-Local and the v5 collector are host glue and are not applied here.
@@ -243,13 +256,15 @@ class DefaultRouter {   // router.rs:121-127
     // cpu_baseline only (oracle.cpp: orc_router_matches_timed): the reference's per-publish work without the
     // checker's canonicalisation; prepare_shaped() snapshots the relation maps with ref-counted strings.
     void prepare_shaped();
-    uint64_t matches_shaped(const Id& this_id, std::string_view topic_name, WalkStats* st) const;
+    uint64_t matches_shaped(const Id& this_id, std::string_view topic_name, WalkStats* st, bool refcounted = true) const;
+    uint64_t matches_shaped_plain(const Id& this_id, std::string_view topic_name, WalkStats* st) const;
 
    private:
     struct Rel { Id id; SubscriptionOptions opts; uint32_t rel_id; };
     struct FilterEntry { uint32_t filter_id; std::unordered_map<std::string, Rel> rels; };
     struct ShapedEntry { std::shared_ptr<const std::string> client; const Rel* rel; };
     struct ShapedFilter { std::vector<ShapedEntry> rels; };
+    SharedChoice shared_choice_;
     std::unordered_map<std::string, ShapedFilter> shaped_;
     int64_t shaped_ready_ = -1;
     TopicTree<Unit> topics_;

@@ -28,7 +28,7 @@ class OrcId(C.Structure):
 
 class OrcOpts(C.Structure):
     _fields_ = [("v5", C.c_uint8), ("qos", C.c_uint8), ("no_local", C.c_uint8), ("retain_as_published", C.c_uint8),
-                ("retain_handling", C.c_uint8), ("sub_ident", C.c_uint32)]
+                ("retain_handling", C.c_uint8), ("sub_ident", C.c_uint32), ("shared_group", C.c_char_p), ("shared_group_len", C.c_uint32)]
 
 
 class OrcStats(C.Structure):
@@ -67,6 +67,7 @@ def lib():
         L.orc_retain_match_timed.argtypes = [vp, vp, vp, u64, C.c_int, C.POINTER(u64), C.POINTER(u64)]
         L.orc_retain_match_timed.restype = C.c_double
         L.orc_router_new.restype = vp
+        L.orc_router_set_shared_policy.argtypes = [vp, C.c_int]; L.orc_router_set_shared_policy.restype = None
         L.orc_router_free.argtypes = [vp]
         L.orc_router_add.argtypes = [vp, cp, u64, C.POINTER(OrcId), C.POINTER(OrcOpts), C.c_uint32]
         L.orc_router_remove.argtypes = [vp, cp, u64, C.POINTER(OrcId)]
@@ -81,7 +82,7 @@ def lib():
         L.orc_router_match_flat.restype = u64
         L.orc_router_match_timed.argtypes = [vp, vp, vp, u64, C.c_int, C.POINTER(OrcStats)]
         L.orc_router_match_timed.restype = C.c_double
-        L.orc_router_matches_timed.argtypes = [vp, vp, vp, u64, C.c_int, C.POINTER(OrcStats)]
+        L.orc_router_matches_timed.argtypes = [vp, vp, vp, u64, C.c_int, C.c_int, C.POINTER(OrcStats)]
         L.orc_router_matches_timed.restype = C.c_double
         L.orc_retain_match_timed_dyn.argtypes = [vp, vp, vp, u64, C.c_int, C.POINTER(u64), C.POINTER(u64)]
         L.orc_retain_match_timed_dyn.restype = C.c_double
@@ -244,8 +245,11 @@ def mk_id(node_id=1, client_id="c", create_time=0, lid=0):
     return i
 
 
-def mk_opts(qos=0, v5=False, no_local=False, sub_ident=0, rap=False, rh=0):
-    return OrcOpts(int(v5), qos, int(no_local), int(rap), rh, sub_ident)
+def mk_opts(qos=0, v5=False, no_local=False, sub_ident=0, rap=False, rh=0, shared_group=None):
+    g = _b(shared_group) if shared_group else None
+    o = OrcOpts(int(v5), qos, int(no_local), int(rap), rh, sub_ident, g, len(g) if g else 0)
+    o._keep = g
+    return o
 
 
 class DefaultRouter:
@@ -260,6 +264,11 @@ class DefaultRouter:
 
     def add(self, f, id_, opts, rel_id=0):
         f = _b(f); return lib().orc_router_add(self._h, f, len(f), C.byref(id_), C.byref(opts), rel_id)
+
+    def set_shared_policy(self, policy):
+        """SharedSubscription::choice stand-in: 0 = nobody (the reference's default), 1 = smallest client id,
+        2 = largest rel_id of the group."""
+        lib().orc_router_set_shared_policy(self._h, policy)
 
     def remove(self, f, id_):
         f = _b(f); return lib().orc_router_remove(self._h, f, len(f), C.byref(id_))
@@ -312,12 +321,13 @@ class DefaultRouter:
         sec = lib().orc_router_match_timed(self._h, _ptr(blob), offsets.ctypes.data, len(offsets) - 1, threads, C.byref(st))
         return float(sec), st.as_dict()
 
-    def matches_timed(self, blob, offsets, threads=1):
+    def matches_timed(self, blob, offsets, threads=1, refcounted=True):
         """Timed DefaultRouter::_matches-shaped pass (router.rs:174-265: no canonicalising sort, per-hit
-        ref-counted clones, dynamic chunks): the cpu_baseline figure."""
+        ref-counted clones, dynamic chunks): the cpu_baseline figure.  refcounted=False: plain pointer copies
+        instead of the ByteString-style atomic refcount bumps."""
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         st = OrcStats()
-        sec = lib().orc_router_matches_timed(self._h, _ptr(blob), offsets.ctypes.data, len(offsets) - 1, threads, C.byref(st))
+        sec = lib().orc_router_matches_timed(self._h, _ptr(blob), offsets.ctypes.data, len(offsets) - 1, threads, int(refcounted), C.byref(st))
         return float(sec), st.as_dict()
 
     def match_digest(self, blob, offsets, threads=1):

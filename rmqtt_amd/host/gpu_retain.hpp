@@ -61,10 +61,13 @@ class GpuRetainStorage {
 // the stored messages, expiries heap and forwardeds map stay host-side as in the reference.
 using MsgID = uint64_t;
 
+// One new leaf per stored message (ram.rs:333-394): the index runs in two-tier mode by default — additions recompile
+// a small delta table, removals set dead bits, the tiers merge when the delta passes this many topics.
+constexpr uint32_t kDefaultDeltaMax = 65536;
 class GpuMessageIndex {
    public:
     // the index gains one leaf per stored message: this is the table the two-tier mode is for
-    explicit GpuMessageIndex(int device = 0, uint32_t retain_delta_max = 0);
+    explicit GpuMessageIndex(int device = 0, uint32_t retain_delta_max = kDefaultDeltaMax);
     ~GpuMessageIndex();
     bool usable() const { return h_ != nullptr; }
     Result<bool> set(const TopicName& topic, MsgID msg_id);

@@ -2,12 +2,15 @@
 #include "gpu_router.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <string_view>
 
 namespace rmqtt {
 
 namespace {
 uint8_t flags_of(const SubscriptionOptions& o) {
-    return uint8_t((o.v5 ? RGR_SUB_V5 : 0) | (o.v5 && o.no_local ? RGR_SUB_NO_LOCAL : 0) | (o.v5 && o.retain_as_published ? RGR_SUB_RAP : 0));
+    return uint8_t((o.v5 ? RGR_SUB_V5 : 0) | (o.v5 && o.no_local ? RGR_SUB_NO_LOCAL : 0) | (o.v5 && o.retain_as_published ? RGR_SUB_RAP : 0) |
+                   (o.shared_group ? RGR_SUB_SHARED : 0));
 }
 // Every field Id equality looks at (types.rs:1841-1851), unambiguously joined.
 std::string id_key(const Id& id) {
@@ -36,33 +39,52 @@ uint32_t GpuRouter::Dense::find(const std::string& k) const {
     return it == ids.end() ? RGR_ID_NONE : it->second.first;
 }
 
-GpuRouter::GpuRouter(NodeId this_node, int device) : this_node_(this_node) {
+GpuRouter::GpuRouter(NodeId this_node, int device) : GpuRouter(this_node, std::vector<int>{device}) {}
+
+GpuRouter::GpuRouter(NodeId this_node, const std::vector<int>& devices) : this_node_(this_node) {
     rgr_config cfg{};
-    cfg.device = device;
-    if (rgr_create(&cfg, &h_) != RGR_OK) { h_ = nullptr; create_error_ = rgr_last_error(); }
+    std::vector<int32_t> devs(devices.begin(), devices.end());
+    if (rgr_group_create(&cfg, devs.data(), uint32_t(devs.size()), &g_) != RGR_OK) { g_ = nullptr; create_error_ = rgr_last_error(); }
 }
 
-GpuRouter::~GpuRouter() { if (h_) rgr_destroy(h_); }
+GpuRouter::~GpuRouter() { if (g_) rgr_group_destroy(g_); }
+
+uint32_t GpuRouter::shards() const { return g_ ? rgr_group_size(g_) : 0; }
 
 int32_t GpuRouter::commit_if_dirty() {
     if (!dirty_) return RGR_OK;
-    int32_t rc = rgr_commit(h_);
+    int32_t rc = rgr_group_commit(g_);
     if (rc == RGR_OK) dirty_ = false;
     return rc;
 }
 
+// Topic::from_str (topic.rs:357-394, 231-243): '+' / '#' only as whole levels, '#' only last, '$' only first.
+static bool valid_topic(const std::string& s) {
+    size_t start = 0, level = 0;
+    bool hash_seen = false;
+    for (;;) {
+        const size_t pos = s.find('/', start);
+        const std::string_view lv(s.data() + start, (pos == std::string::npos ? s.size() : pos) - start);
+        if (hash_seen) return false;
+        if (lv == "#") hash_seen = true;
+        else if (lv != "+") {
+            if (lv.find('+') != std::string_view::npos || lv.find('#') != std::string_view::npos) return false;
+            if (!lv.empty() && lv[0] == '$' && level != 0) return false;
+        }
+        if (pos == std::string::npos) return true;
+        start = pos + 1; ++level;
+    }
+}
+
 // router.rs:434-453
 Result<bool> GpuRouter::add(const std::string& topic_filter, const Id& id, const SubscriptionOptions& opts) {
-    if (!h_) return Result<bool>::Err(create_error_);
+    if (!g_) return Result<bool>::Err(create_error_);
+    if (!valid_topic(topic_filter)) return Result<bool>::Err("invalid topic filter `" + topic_filter + "`");   // router.rs:436 (`?`)
     std::lock_guard<std::mutex> g(mu_);
-    uint32_t fid = 0;
-    int32_t rc = rgr_filter_add(h_, topic_filter.data(), uint32_t(topic_filter.size()), &fid);   // Topic::from_str + trie insert
-    if (rc != RGR_OK) return Result<bool>::Err(std::string("invalid topic filter: ") + rgr_last_error());
     auto it = relations_.find(topic_filter);
     if (it == relations_.end()) {
         topics_count_.inc();
-        it = relations_.emplace(topic_filter, FilterEntry{fid, {}}).first;
-        filter_names_[fid] = &it->first;
+        it = relations_.emplace(topic_filter, FilterEntry{{}}).first;
     }
     auto& rels = it->second.rels;
     auto old = rels.find(id.client_id);
@@ -87,32 +109,33 @@ Result<bool> GpuRouter::add(const std::string& topic_filter, const Id& id, const
         nodes_.push_back(id.node_id);
     }
     slab_[sub_id] = Slot{&it->first, &old->second};
-    rc = rgr_sub_add_ex(h_, fid, sub_id, opts.qos, flags_of(opts), ni->second, owner_id, client_idx);
-    if (rc != RGR_OK) return Result<bool>::Err(rgr_last_error());
+    if (rgr_group_subscribe_ex(g_, topic_filter.data(), uint32_t(topic_filter.size()), sub_id, opts.qos, flags_of(opts), ni->second, owner_id,
+                               client_idx) != RGR_OK)
+        return Result<bool>::Err(rgr_last_error());
     dirty_ = true;
     return Result<bool>::Ok(true);
 }
 
 // router.rs:456-496
 Result<bool> GpuRouter::remove(const std::string& topic_filter, const Id& id) {
-    if (!h_) return Result<bool>::Err(create_error_);
+    if (!g_) return Result<bool>::Err(create_error_);
     std::lock_guard<std::mutex> g(mu_);
     auto it = relations_.find(topic_filter);
     if (it == relations_.end()) return Result<bool>::Ok(false);
     auto& rels = it->second.rels;
     auto r = rels.find(id.client_id);
     if (r == rels.end() || r->second.id != id) return Result<bool>::Ok(false);   // router.rs:460-467
-    const uint32_t sub_id = r->second.sub_id, fid = it->second.filter_id;
-    if (rgr_sub_remove(h_, fid, sub_id) != RGR_OK) return Result<bool>::Err(rgr_last_error());
+    const uint32_t sub_id = r->second.sub_id;
+    const bool last = rels.size() == 1;                              // router.rs:484-490: the filter leaves the trie with its last relation
+    if (rgr_group_unsubscribe(g_, topic_filter.data(), uint32_t(topic_filter.size()), sub_id, last ? 1 : 0) != RGR_OK)
+        return Result<bool>::Err(rgr_last_error());
     slab_[sub_id] = Slot{};
     free_sub_ids_.push_back(sub_id);
     owners_.release(id_key(r->second.id));
     clients_.release(client_key(r->second.id.node_id, r->second.id.client_id));
     rels.erase(r);
     relations_count_.dec();
-    if (rels.empty()) {                                              // router.rs:484-490
-        if (rgr_filter_remove(h_, fid) != RGR_OK) return Result<bool>::Err(rgr_last_error());
-        filter_names_.erase(fid);
+    if (last) {
         relations_.erase(it);
         topics_count_.dec();
     }
@@ -120,9 +143,35 @@ Result<bool> GpuRouter::remove(const std::string& topic_filter, const Id& id) {
     return Result<bool>::Ok(true);
 }
 
+namespace {
+// SubscriptioRelationsCollector (types.rs:503-541) of one node
+struct Collector {
+    SubRelations v3;
+    SubRelations v5;                                       // rows in first-hit order
+    std::unordered_map<ClientId, size_t> v5_index;         // the HashMap<ClientId, ...> of types.rs:506
+    // returns whether the hit created the client's v5 entry (true) or only contributed its identifier (false); v3: true
+    bool add(const TopicFilter& filter, const ClientId& client, const SubscriptionOptions& opts, std::optional<SharedGroupType> group) {
+        if (opts.is_v3()) { v3.push_back(SubRelation{filter, client, opts, std::nullopt, std::move(group)}); return true; }   // types.rs:519-521
+        auto it = v5_index.find(client);
+        if (it != v5_index.end()) {                                                                          // types.rs:526-534
+            if (opts.subscription_identifier) {
+                auto& ids = v5[it->second].sub_ids;
+                if (ids) ids->push_back(opts.subscription_identifier); else ids = std::vector<uint32_t>{opts.subscription_identifier};
+            }
+            return false;
+        }
+        SubRelation r{filter, client, opts, std::nullopt, std::move(group)};                                 // types.rs:535-538
+        if (opts.subscription_identifier) r.sub_ids = std::vector<uint32_t>{opts.subscription_identifier};
+        v5_index.emplace(client, v5.size());
+        v5.push_back(std::move(r));
+        return true;
+    }
+};
+}  // namespace
+
 Result<bool> GpuRouter::matches_batch(const std::vector<Id>& ids, const std::vector<TopicName>& topics,
                                       std::vector<std::optional<SubRelationsMap>>& out) {
-    if (!h_) return Result<bool>::Err(create_error_);
+    if (!g_) return Result<bool>::Err(create_error_);
     if (ids.size() != topics.size()) return Result<bool>::Err("matches_batch: ids/topics size mismatch");
     std::lock_guard<std::mutex> g(mu_);
     if (commit_if_dirty() != RGR_OK) return Result<bool>::Err(rgr_last_error());
@@ -133,37 +182,51 @@ Result<bool> GpuRouter::matches_batch(const std::vector<Id>& ids, const std::vec
     std::vector<rgr_publish_attr> attrs(topics.size());
     for (size_t i = 0; i < topics.size(); ++i) attrs[i] = rgr_publish_attr{owners_.find(id_key(ids[i])), 2u};
     rgr_result res{};
-    if (rgr_match_batch_deliver(h_, reinterpret_cast<const uint8_t*>(blob.data()), offs.data(), uint32_t(topics.size()), attrs.data(), &res) != RGR_OK)
+    if (rgr_group_match_batch_deliver(g_, reinterpret_cast<const uint8_t*>(blob.data()), offs.data(), uint32_t(topics.size()), attrs.data(), &res) != RGR_OK)
         return Result<bool>::Err(rgr_last_error());
     out.assign(topics.size(), std::nullopt);
     for (size_t t = 0; t < topics.size(); ++t) {
         if (res.status[t] != RGR_TOPIC_OK) continue;                 // Topic::from_str Err (router.rs:177)
-        SubRelationsMap m;                                           // collector_map (router.rs:176) + router.rs:258-261
-        std::map<NodeId, SubRelations> v5;                           // types.rs:488-497: v3 rows first, then the v5 map's rows
+        std::map<NodeId, Collector> collector_map;                   // router.rs:176
+        // members of $share groups of the filter whose hits are going by (router.rs:183-192), keyed by group
+        std::map<std::string, std::vector<std::pair<SharedCandidate, const Rel*>>> groups;
+        const std::string* cur_filter = nullptr;
+        bool shared_chosen = false;
+        auto flush_groups = [&]() {                                  // router.rs:236-255, once per matched filter
+            for (auto& gk : groups) {
+                std::vector<SharedCandidate> ncs;
+                std::vector<ClientId> cids;
+                for (auto& c : gk.second) { ncs.push_back(c.first); cids.push_back(c.first.client_id); }
+                const auto pick = shared_ ? shared_->choice(gk.first, ids[t], topics[t], ncs) : std::nullopt;
+                if (!pick || pick->first >= ncs.size()) continue;
+                const SharedCandidate& c = ncs[pick->first];
+                collector_map[c.node_id].add(*cur_filter, c.client_id, c.opts, SharedGroupType{gk.first, pick->second, cids});
+                shared_chosen = true;
+            }
+            groups.clear();
+        };
         for (uint64_t k = res.hit_offsets[t]; k < res.hit_offsets[t + 1]; ++k) {
             const uint32_t w = res.tuples[k].qos_flags;
-            if (w & RGR_HIT_NO_LOCAL) continue;                      // router.rs:196-201, decided on the device
             const Slot& s = slab_[res.tuples[k].sub_id];
+            if (s.filter != cur_filter) { flush_groups(); cur_filter = s.filter; }
+            if (w & RGR_HIT_NO_LOCAL) continue;                      // router.rs:196-201, decided on the device
             const Rel& rel = *s.rel;
             const NodeId node = nodes_[w >> 16];
-            if (rel.opts.is_v3()) { m[node].push_back(SubRelation{*s.filter, rel.id.client_id, rel.opts, std::nullopt}); continue; }
-            auto& rows = v5[node];
-            m[node];                                                  // the node has a collector even if only v5 rows follow
-            if (w & RGR_HIT_V5_DUP) {                                // types.rs:526-534: only the subscription identifier is kept
-                if (!rel.opts.subscription_identifier) continue;
-                for (auto& r : rows) {
-                    if (r.client_id != rel.id.client_id) continue;
-                    if (r.sub_ids) r.sub_ids->push_back(rel.opts.subscription_identifier);
-                    else r.sub_ids = std::vector<uint32_t>{rel.opts.subscription_identifier};
-                    break;
-                }
-            } else {                                                 // types.rs:535-538
-                SubRelation r{*s.filter, rel.id.client_id, rel.opts, std::nullopt};
-                if (rel.opts.subscription_identifier) r.sub_ids = std::vector<uint32_t>{rel.opts.subscription_identifier};
-                rows.push_back(std::move(r));
+            if (rel.opts.shared_group) {                              // router.rs:204-213
+                groups[*rel.opts.shared_group].push_back({SharedCandidate{node, rel.id.client_id, rel.opts, is_online(node, rel.id.client_id)}, &rel});
+                continue;
             }
+            const bool created = collector_map[node].add(*s.filter, rel.id.client_id, rel.opts, std::nullopt);   // router.rs:214-229
+            // the device's verdict on the same hit (types.rs:524-539 as a min-position-per-client problem)
+            if (!rel.opts.is_v3() && !shared_chosen && created == ((w & RGR_HIT_V5_DUP) != 0)) flag_mismatches_++;
         }
-        for (auto& kv : v5) { auto& dst = m[kv.first]; for (auto& r : kv.second) dst.push_back(std::move(r)); }
+        flush_groups();
+        SubRelationsMap m;                                           // router.rs:258-261 + types.rs:488-497: v3 rows, then the v5 map's
+        for (auto& kv : collector_map) {
+            auto& dst = m[kv.first];
+            dst = std::move(kv.second.v3);
+            for (auto& r : kv.second.v5) dst.push_back(std::move(r));
+        }
         out[t] = std::move(m);
     }
     rgr_result_free(&res);
@@ -179,23 +242,27 @@ Result<SubRelationsMap> GpuRouter::matches(const Id& id, const TopicName& topic)
     return Result<SubRelationsMap>::Ok(std::move(*out[0]));
 }
 
-// router.rs:157-170
+// router.rs:157-170: the matched filters, unique, in iteration order.  Every filter in the trie has at least one
+// relation (it leaves with its last one, router.rs:484-490), so the filters of the hits ARE the matched filters.
 Result<std::vector<Route>> GpuRouter::get(const std::string& topic) {
-    if (!h_) return Result<std::vector<Route>>::Err(create_error_);
+    if (!g_) return Result<std::vector<Route>>::Err(create_error_);
     std::lock_guard<std::mutex> g(mu_);
     if (commit_if_dirty() != RGR_OK) return Result<std::vector<Route>>::Err(rgr_last_error());
     const uint64_t offs[2] = {0, topic.size()};
-    rgr_filters_result res{};
-    if (rgr_match_filters(h_, reinterpret_cast<const uint8_t*>(topic.data()), offs, 1, &res) != RGR_OK)
+    rgr_result res{};
+    if (rgr_group_match_batch(g_, reinterpret_cast<const uint8_t*>(topic.data()), offs, 1, &res) != RGR_OK)
         return Result<std::vector<Route>>::Err(rgr_last_error());
     std::vector<Route> routes;
     const bool bad = res.status[0] != RGR_TOPIC_OK;
-    for (uint64_t k = 0; !bad && k < res.n_pairs; ++k) {
-        const std::string& f = *filter_names_.at(res.filter_ids[k]);
-        if (std::none_of(routes.begin(), routes.end(), [&](const Route& r) { return r.topic == f; }))   // .unique()
-            routes.push_back(Route{this_node_, f});
+    const std::string* last = nullptr;
+    for (uint64_t k = 0; !bad && k < res.n_hits; ++k) {
+        const std::string* f = slab_[res.tuples[k].sub_id].filter;
+        if (f == last) continue;
+        last = f;
+        if (std::none_of(routes.begin(), routes.end(), [&](const Route& r) { return r.topic == *f; }))   // .unique()
+            routes.push_back(Route{this_node_, *f});
     }
-    rgr_filters_result_free(&res);
+    rgr_result_free(&res);
     if (bad) return Result<std::vector<Route>>::Err("invalid topic `" + topic + "`");
     return Result<std::vector<Route>>::Ok(std::move(routes));
 }
@@ -231,6 +298,60 @@ std::vector<std::string> GpuRouter::list_topics(size_t top) {
     std::vector<std::string> v;
     for (auto& kv : relations_) { if (v.size() >= top) break; v.push_back(kv.first); }
     return v;
+}
+
+}  // namespace rmqtt
+
+namespace rmqtt {
+
+// ---------------------------------------------------------------------------------------------- Batcher
+Batcher::Batcher(GpuRouter& router, size_t max_batch, std::chrono::microseconds max_delay)
+    : router_(router), max_batch_(max_batch ? max_batch : 1), max_delay_(max_delay), driver_([this] { run(); }) {}
+
+Batcher::~Batcher() {
+    { std::lock_guard<std::mutex> g(mu_); stop_ = true; }
+    cv_req_.notify_all();
+    driver_.join();
+}
+
+Result<SubRelationsMap> Batcher::matches(const Id& id, const TopicName& topic) {
+    Req req{id, topic, std::nullopt, {}, false};
+    std::unique_lock<std::mutex> lk(mu_);
+    if (stop_) return Result<SubRelationsMap>::Err("batcher stopped");
+    queue_.push_back(&req);
+    requests_++;
+    cv_req_.notify_one();
+    cv_done_.wait(lk, [&] { return req.done; });
+    if (!req.err.empty()) return Result<SubRelationsMap>::Err(req.err);
+    if (!req.out) return Result<SubRelationsMap>::Err("invalid topic `" + topic + "`");
+    return Result<SubRelationsMap>::Ok(std::move(*req.out));
+}
+
+void Batcher::run() {
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+        cv_req_.wait(lk, [&] { return stop_ || !queue_.empty(); });
+        if (queue_.empty()) { if (stop_) return; continue; }
+        // deadline counted from the first request of the batch
+        const auto deadline = std::chrono::steady_clock::now() + max_delay_;
+        cv_req_.wait_until(lk, deadline, [&] { return stop_ || queue_.size() >= max_batch_; });
+        std::vector<Req*> reqs;
+        reqs.swap(queue_);
+        if (reqs.size() > max_batch_) { queue_.assign(reqs.begin() + max_batch_, reqs.end()); reqs.resize(max_batch_); }
+        lk.unlock();                                              // callers keep enqueueing during the device pass
+        std::vector<Id> ids;
+        std::vector<TopicName> topics;
+        for (Req* r : reqs) { ids.push_back(r->id); topics.push_back(r->topic); }
+        std::vector<std::optional<SubRelationsMap>> outs;
+        auto res = router_.matches_batch(ids, topics, outs);
+        lk.lock();
+        passes_++;
+        for (size_t i = 0; i < reqs.size(); ++i) {
+            if (!res.ok()) reqs[i]->err = res.error; else reqs[i]->out = std::move(outs[i]);
+            reqs[i]->done = true;
+        }
+        cv_done_.notify_all();
+    }
 }
 
 }  // namespace rmqtt

@@ -15,13 +15,23 @@
 // No Local (router.rs:196-201: whole-`Id` equality) and the v5 collector's first-hit-per-client
 // rule (types.rs:524-539) — are taken by the device's delivery stage (rgr_match_batch_deliver):
 // every relation is registered with a dense id of its `Id`, of its (node, ClientId) and of its
-// node (rgr_sub_add_ex), and `matches` only reads the RGR_HIT_* flags.  Shared-group choice
-// (router.rs:236-255) needs live session state and is not modelled (flagged RGR_SUB_SHARED for
-// the Rust glue).
+// node (rgr_sub_add_ex), and `matches` reads the RGR_HIT_* flags.  Shared-group members
+// (router.rs:202-213) are flagged RGR_SUB_SHARED, collected per (filter, group) while the hits of
+// one filter go by, and one of them is chosen through the `SharedSubscription` the broker installs
+// (router.rs:236-255) — the same place, order and arguments as the reference.
+//
+// The table lives in an rgr_group: one shard per device (`devices`), filters and publishes routed
+// by rgr_shard_assign — with one device this is exactly a single handle.  `Batcher` is the
+// deadline micro-batcher that sits between the per-publish trait call and the batched device
+// pass (the twin of rust/rmqtt-gpu-router/src/batcher.rs).
 #pragma once
+#include <condition_variable>
 #include <cstdint>
+#include <functional>
 #include <map>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <optional>
 #include <string>
 #include <unordered_map>
@@ -58,15 +68,27 @@ struct SubscriptionOptions {
     bool no_local = false, retain_as_published = false;
     uint8_t retain_handling = 0;
     uint32_t subscription_identifier = 0;   // 0 = None
+    std::optional<std::string> shared_group;     // types.rs:776,815: <group> of $share/<group>/<filter>
     bool is_v3() const { return !v5; }
     std::optional<bool> opt_no_local() const { return v5 ? std::optional<bool>(no_local) : std::nullopt; }
 };
 
-struct SubRelation {   // types.rs:478-484 (shared-group member omitted)
+struct SharedGroupType { std::string group; bool is_online = true; std::vector<ClientId> group_cids; };   // types.rs:474
+struct SubRelation {   // types.rs:478-484
     TopicFilter topic_filter;
     ClientId client_id;
     SubscriptionOptions opts;
     std::optional<std::vector<uint32_t>> sub_ids;
+    std::optional<SharedGroupType> group;        // Some for the member a shared group selected
+};
+// rmqtt/src/subscribe.rs:69-95.  The default selects nobody, like DefaultSharedSubscription
+// (subscribe.rs:107): without the shared-subscription plugin $share members receive nothing.
+struct SharedCandidate { NodeId node_id; ClientId client_id; SubscriptionOptions opts; bool is_online; };
+struct SharedSubscription {
+    virtual ~SharedSubscription() = default;
+    virtual bool is_supported() const { return false; }
+    virtual std::optional<std::pair<size_t, bool>> choice(const std::string& /*group*/, const struct Id& /*publisher*/, const TopicName& /*topic*/,
+                                                          const std::vector<SharedCandidate>& /*ncs*/) { return std::nullopt; }
 };
 using SubRelations = std::vector<SubRelation>;
 using SubRelationsMap = std::map<NodeId, SubRelations>;   // types.rs:486
@@ -106,10 +128,19 @@ class Router {   // rmqtt/src/router.rs:65-112
 class GpuRouter final : public Router {
    public:
     explicit GpuRouter(NodeId this_node, int device = 0);
+    // one shard per entry (ShardedGpuRouter of the Rust crate): rgr_group over these devices
+    GpuRouter(NodeId this_node, const std::vector<int>& devices);
     ~GpuRouter() override;
+    // extends.shared_subscription() and Router::is_online of the broker (router.rs:204-213, 236-245)
+    void set_shared_subscription(std::shared_ptr<SharedSubscription> s) { shared_ = std::move(s); }
+    void set_is_online(std::function<bool(NodeId, const ClientId&)> f) { is_online_ = std::move(f); }
+    // v5 hits whose RGR_HIT_V5_DUP flag disagreed with the host collector although no shared member had been
+    // chosen for that publish (must stay 0: the device's first-hit-per-client rule equals types.rs:524-539)
+    uint64_t flag_mismatches() const { return flag_mismatches_; }
+    uint32_t shards() const;
     GpuRouter(const GpuRouter&) = delete;
     GpuRouter& operator=(const GpuRouter&) = delete;
-    bool usable() const { return h_ != nullptr; }
+    bool usable() const { return g_ != nullptr; }
     const std::string& create_error() const { return create_error_; }
 
     Result<bool> add(const std::string& topic_filter, const Id& id, const SubscriptionOptions& opts) override;
@@ -119,7 +150,7 @@ class GpuRouter final : public Router {
     // out[i] is nullopt where the reference would return Err (invalid topic name).
     Result<bool> matches_batch(const std::vector<Id>& ids, const std::vector<TopicName>& topics,
                                std::vector<std::optional<SubRelationsMap>>& out);
-    bool is_online(NodeId, const std::string&) override { return true; }   // session state lives in the broker
+    bool is_online(NodeId node, const std::string& client) override { return is_online_ ? is_online_(node, client) : true; }   // session state lives in the broker
     std::vector<Route> gets(size_t limit) override;
     Result<std::vector<Route>> get(const std::string& topic) override;       // router.rs:157-170 (.unique())
     Result<bool> has_matches(const std::string& topic);                     // router.rs:151-154
@@ -138,17 +169,19 @@ class GpuRouter final : public Router {
         void release(const std::string& k);
         uint32_t find(const std::string& k) const;                             // RGR_ID_NONE if absent
     };
-    struct FilterEntry { uint32_t filter_id; std::unordered_map<ClientId, Rel> rels; };
+    struct FilterEntry { std::unordered_map<ClientId, Rel> rels; };
     struct Slot { const std::string* filter = nullptr; const Rel* rel = nullptr; };
 
-    rgr_handle* h_ = nullptr;
+    rgr_group* g_ = nullptr;
+    std::shared_ptr<SharedSubscription> shared_;
+    std::function<bool(NodeId, const ClientId&)> is_online_;
+    uint64_t flag_mismatches_ = 0;
     std::string create_error_;
     NodeId this_node_;
     std::mutex mu_;   // the reference uses DashMap + a trie RwLock; one mutex is enough for the mirror
     std::unordered_map<TopicFilter, FilterEntry> relations_;   // AllRelationsMap
     std::vector<Slot> slab_;           // sub_id -> relation
     std::vector<uint32_t> free_sub_ids_;
-    std::unordered_map<uint32_t, const std::string*> filter_names_;   // filter_id -> filter string
     Dense owners_, clients_;             // Id -> owner_id, (node, ClientId) -> client_idx
     std::vector<NodeId> nodes_;          // node_idx -> NodeId
     std::unordered_map<NodeId, uint16_t> node_idx_;
@@ -156,6 +189,33 @@ class GpuRouter final : public Router {
     bool dirty_ = false;
 
     int32_t commit_if_dirty();
+};
+
+// Deadline micro-batcher in front of GpuRouter::matches_batch: Router::matches is called once per PUBLISH
+// from many threads (rmqtt/src/shared.rs:772); callers enqueue (id, topic) and block on their own slot; one
+// driver thread drains the queue when it holds max_batch publishes or max_delay has passed since the first
+// one, runs ONE device pass and hands every caller its SubRelationsMap.  No lock of the router is held while
+// callers wait.
+class Batcher {
+   public:
+    Batcher(GpuRouter& router, size_t max_batch, std::chrono::microseconds max_delay);
+    ~Batcher();
+    Result<SubRelationsMap> matches(const Id& id, const TopicName& topic);
+    uint64_t passes() const { return passes_; }
+    uint64_t requests() const { return requests_; }
+
+   private:
+    struct Req { Id id; TopicName topic; std::optional<SubRelationsMap> out; std::string err; bool done = false; };
+    GpuRouter& router_;
+    size_t max_batch_;
+    std::chrono::microseconds max_delay_;
+    std::mutex mu_;
+    std::condition_variable cv_req_, cv_done_;
+    std::vector<Req*> queue_;
+    bool stop_ = false;
+    uint64_t passes_ = 0, requests_ = 0;
+    std::thread driver_;
+    void run();
 };
 
 }  // namespace rmqtt

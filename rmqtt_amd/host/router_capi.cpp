@@ -5,6 +5,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
+#include <memory>
 
 #include "gpu_retain.hpp"
 #include "gpu_router.hpp"
@@ -19,26 +21,47 @@ char* dup_str(const std::string& s) {
     return p;
 }
 struct hr_id { uint64_t node_id; const char* client_id; uint32_t client_len; int64_t create_time; uint16_t lid; };
-struct hr_opts { uint8_t v5, qos, no_local, retain_as_published, retain_handling; uint32_t sub_ident; };
+struct hr_opts { uint8_t v5, qos, no_local, retain_as_published, retain_handling; uint32_t sub_ident; const char* shared_group; uint32_t shared_group_len; };
 Id mk_id(const hr_id* i) { Id id; id.node_id = i->node_id; id.lid = i->lid; id.create_time = i->create_time; id.client_id.assign(i->client_id, i->client_len); return id; }
 SubscriptionOptions mk_opts(const hr_opts* o) {
     SubscriptionOptions s; s.v5 = o->v5; s.qos = o->qos; s.no_local = o->no_local; s.retain_as_published = o->retain_as_published;
-    s.retain_handling = o->retain_handling; s.subscription_identifier = o->sub_ident; return s;
+    s.retain_handling = o->retain_handling; s.subscription_identifier = o->sub_ident;
+    if (o->shared_group && o->shared_group_len) s.shared_group = std::string(o->shared_group, o->shared_group_len);
+    return s;
 }
+// "\t$<group>:<online>:<sorted member client ids,>" — same text as the oracle's dump (oracle.cpp group_text)
+std::string group_text(const SubRelation& s) {
+    if (!s.group) return "";
+    auto c = s.group->group_cids;
+    std::sort(c.begin(), c.end());
+    std::string r = "\t$" + s.group->group + ":" + std::to_string(int(s.group->is_online)) + ":";
+    for (size_t i = 0; i < c.size(); ++i) { if (i) r.push_back(','); r += c[i]; }
+    return r;
+}
+// order-independent test policy shared with the oracle (orc_router_set_shared_policy 1): smallest client id
+struct SmallestClient final : SharedSubscription {
+    bool is_supported() const override { return true; }
+    std::optional<std::pair<size_t, bool>> choice(const std::string&, const Id&, const TopicName&, const std::vector<SharedCandidate>& ncs) override {
+        if (ncs.empty()) return std::nullopt;
+        size_t best = 0;
+        for (size_t i = 1; i < ncs.size(); ++i) if (ncs[i].client_id < ncs[best].client_id) best = i;
+        return std::make_pair(best, ncs[best].is_online);
+    }
+};
 std::string dump(const SubRelationsMap& m) {
     std::string out;
     for (auto& kv : m) {
         out += "N " + std::to_string(kv.first) + "\n";
         std::vector<std::string> v3, v5;
         for (auto& s : kv.second) {
-            if (s.opts.is_v3()) v3.push_back("3 " + s.topic_filter + "\t" + s.client_id + "\t" + std::to_string(s.opts.qos) + "\n");
+            if (s.opts.is_v3()) v3.push_back("3 " + s.topic_filter + "\t" + s.client_id + "\t" + std::to_string(s.opts.qos) + group_text(s) + "\n");
             else {
                 std::string ids = "-";
                 if (s.sub_ids) {
                     auto v = *s.sub_ids; std::sort(v.begin(), v.end()); ids.clear();
                     for (size_t i = 0; i < v.size(); ++i) { if (i) ids.push_back(','); ids += std::to_string(v[i]); }
                 }
-                v5.push_back("5 " + s.client_id + "\t" + s.topic_filter + "\t" + std::to_string(s.opts.qos) + "\t" + std::to_string(int(s.opts.no_local)) + "\t" + ids + "\n");
+                v5.push_back("5 " + s.client_id + "\t" + s.topic_filter + "\t" + std::to_string(s.opts.qos) + "\t" + std::to_string(int(s.opts.no_local)) + "\t" + ids + group_text(s) + "\n");
             }
         }
         std::sort(v3.begin(), v3.end()); std::sort(v5.begin(), v5.end());
@@ -54,6 +77,41 @@ void* hr_new(uint64_t node_id, int device) {
     auto* r = new GpuRouter(node_id, device);
     if (!r->usable()) { delete r; return nullptr; }
     return r;
+}
+// one shard per entry of devs (repeated ordinals: several shards on one GPU)
+void* hr_new_sharded(uint64_t node_id, const int* devs, uint32_t n) {
+    auto* r = new GpuRouter(node_id, std::vector<int>(devs, devs + n));
+    if (!r->usable()) { delete r; return nullptr; }
+    return r;
+}
+uint32_t hr_shards(void* r) { return static_cast<GpuRouter*>(r)->shards(); }
+// 0 = the reference's default SharedSubscription (selects nobody), 1 = smallest client id of the group
+void hr_set_shared_policy(void* r, int policy) {
+    static_cast<GpuRouter*>(r)->set_shared_subscription(policy == 1 ? std::make_shared<SmallestClient>() : nullptr);
+}
+uint64_t hr_flag_mismatches(void* r) { return static_cast<GpuRouter*>(r)->flag_mismatches(); }
+// n publishes issued from n_threads threads through a Batcher (max_batch / max_delay_us): dumps joined by '\x1e'
+// ("!ERR" where matches returned Err); *passes = device passes the batcher needed.
+char* hr_batcher_run(void* r, const hr_id* ids, const char* const* topics, const uint32_t* lens, uint32_t n, uint32_t n_threads,
+                     uint32_t max_batch, uint32_t max_delay_us, uint64_t* passes) {
+    auto* router = static_cast<GpuRouter*>(r);
+    std::vector<std::string> outs(n);
+    {
+        Batcher b(*router, max_batch, std::chrono::microseconds(max_delay_us));
+        std::vector<std::thread> th;
+        for (uint32_t k = 0; k < n_threads; ++k)
+            th.emplace_back([&, k] {
+                for (uint32_t i = k; i < n; i += n_threads) {
+                    auto res = b.matches(mk_id(&ids[i]), std::string(topics[i], lens[i]));
+                    outs[i] = res.ok() ? dump(*res.value) : std::string("!ERR");
+                }
+            });
+        for (auto& t : th) t.join();
+        if (passes) *passes = b.passes();
+    }
+    std::string all;
+    for (uint32_t i = 0; i < n; ++i) { if (i) all.push_back('\x1e'); all += outs[i]; }
+    return dup_str(all);
 }
 void hr_free(void* r) { delete static_cast<GpuRouter*>(r); }
 void hr_free_str(char* p) { std::free(p); }

@@ -28,7 +28,7 @@ def _world(n_sub=30_000, n_pub=6_000, cfg=3):
 def test_group_matches_the_unsharded_oracle(shards):
     blob, offs, qos, tb, to, exp = _world()
     g = capi.Group([0] * shards, window_hits=40_000, chunk_topics=2048)
-    assert g.uses_rccl() == (shards == 1)
+    assert not g.uses_rccl()            # one GPU: the shards exchange through device copies (RCCL needs distinct devices)
     assert g.subscribe_bulk(blob, offs, None, qos) == 0
     g.commit()
     # host in / host out: identical to one handle holding the whole table

@@ -22,7 +22,7 @@ class HrId(C.Structure):
 
 class HrOpts(C.Structure):
     _fields_ = [("v5", C.c_uint8), ("qos", C.c_uint8), ("no_local", C.c_uint8), ("rap", C.c_uint8), ("rh", C.c_uint8),
-                ("sub_ident", C.c_uint32)]
+                ("sub_ident", C.c_uint32), ("shared_group", C.c_char_p), ("shared_group_len", C.c_uint32)]
 
 
 @pytest.fixture(scope="module")
@@ -32,6 +32,13 @@ def hr():
     vp = C.c_void_p
     L.hr_new.restype = vp; L.hr_new.argtypes = [C.c_uint64, C.c_int]
     L.hr_free.argtypes = [vp]; L.hr_free_str.argtypes = [vp]
+    L.hr_new_sharded.restype = vp; L.hr_new_sharded.argtypes = [C.c_uint64, C.POINTER(C.c_int), C.c_uint32]
+    L.hr_shards.argtypes = [vp]; L.hr_shards.restype = C.c_uint32
+    L.hr_set_shared_policy.argtypes = [vp, C.c_int]; L.hr_set_shared_policy.restype = None
+    L.hr_flag_mismatches.argtypes = [vp]; L.hr_flag_mismatches.restype = C.c_uint64
+    L.hr_batcher_run.argtypes = [vp, C.POINTER(HrId), C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                 C.POINTER(C.c_uint64)]
+    L.hr_batcher_run.restype = vp
     L.hr_add.argtypes = [vp, C.c_char_p, C.c_uint32, C.POINTER(HrId), C.POINTER(HrOpts)]
     L.hr_remove.argtypes = [vp, C.c_char_p, C.c_uint32, C.POINTER(HrId)]
     L.hr_matches.argtypes = [vp, C.POINTER(HrId), C.c_char_p, C.c_uint32]; L.hr_matches.restype = vp
@@ -229,3 +236,95 @@ def test_message_index_mirror(hr):
         assert [int(x) for x in got.split(",") if x] == exp, f
     assert hr.hm_get(m, b"a/#/b", 5) is None
     hr.hm_free(m)
+
+
+def _opts(qos=0, v5=False, no_local=False, sub_ident=0, group=None):
+    g = group.encode() if group else None
+    h = HrOpts(int(v5), qos, int(no_local), 0, 0, sub_ident, g, len(g) if g else 0)
+    h._keep = g
+    return h, orc.mk_opts(qos=qos, v5=v5, no_local=no_local, sub_ident=sub_ident, shared_group=group)
+
+
+def _random_world(hr, g, o, rng, n_ops=700, groups=("g1", "g2")):
+    """The same add / remove sequence on the mirror and on the oracle, with v3 / v5 / No Local / $share members."""
+    levels = ["a", "b", "c", "", "$SYS"]
+    live = []
+    for step in range(n_ops):
+        if rng.random() < 0.75 or not live:
+            f = "/".join(rng.choice(levels + ["+"]) for _ in range(rng.randint(1, 4)))
+            if rng.random() < 0.25:
+                f = f.rsplit("/", 1)[0] + "/#" if "/" in f else "#"
+            node, client = rng.choice([1, 1, 2, 3]), f"c{rng.randint(0, 25)}"
+            v5 = rng.random() < 0.5
+            grp = rng.choice(groups) if rng.random() < 0.3 else None
+            ho, oo = _opts(rng.randint(0, 2), v5, v5 and rng.random() < 0.4, rng.randint(0, 9) if v5 else 0, grp)
+            hi, oi = _id(node, client, rng.randint(0, 1))
+            ok_o = o.add(f, oi, oo, rel_id=step) == 0
+            ok_h = hr.hr_add(g, f.encode(), len(f.encode()), C.byref(hi), C.byref(ho)) == 0
+            assert ok_o == ok_h, f
+            if ok_o:
+                live.append((f, node, client))
+        else:
+            f, node, client = live.pop(rng.randrange(len(live)))
+            for ct in (0, 1):       # the Id must match in full (router.rs:460-467): at most one of the two create_times does
+                hi, oi = _id(node, client, ct)
+                assert (hr.hr_remove(g, f.encode(), len(f.encode()), C.byref(hi)) == 0) == (o.remove(f, oi) == 0)
+
+
+def _topics(rng, n):
+    levels = ["a", "b", "c", "", "$SYS", "zz"]
+    return ["/".join(rng.choice(levels) for _ in range(rng.randint(1, 4))) for _ in range(n)] + ["a/+", "b/#", "a/#/b"]
+
+
+@pytest.mark.parametrize("policy", [0, 1])
+@pytest.mark.parametrize("devices", [[0], [0, 0, 0]])
+def test_shared_groups_and_sharded_router_match_oracle(hr, policy, devices):
+    """$share members go through SharedSubscription::choice exactly where router.rs:202-255 does (policy 0 = the
+    reference's default: nobody is selected; policy 1 = an order-independent test policy installed on both sides),
+    on one handle and on a router sharded over three shards."""
+    devs = (C.c_int * len(devices))(*devices)
+    g = hr.hr_new_sharded(1, devs, len(devices))
+    assert g and hr.hr_shards(g) == len(devices)
+    o = orc.DefaultRouter()
+    hr.hr_set_shared_policy(g, policy)
+    o.set_shared_policy(policy)
+    rng = random.Random(policy * 10 + len(devices))
+    _random_world(hr, g, o, rng)
+    seen_group = False
+    for t in _topics(rng, 250):
+        for pub in (("c1", 1, 0), ("c7", 2, 1), ("nobody", 9, 0)):
+            hi, oi = _id(pub[1], pub[0], pub[2])
+            exp = _strip_rel(o.matches(oi, t))
+            got = _take(hr, hr.hr_matches(g, C.byref(hi), t.encode(), len(t.encode())))
+            assert got == exp, (t, pub)
+            seen_group |= bool(exp) and "\t$g" in exp
+    assert seen_group == (policy == 1)
+    assert hr.hr_flag_mismatches(g) == 0
+    hr.hr_free(g)
+
+
+def test_batcher_many_threads_one_pass_per_batch(hr):
+    """Publishes from 8 threads through the deadline micro-batcher: every caller gets exactly what the unbatched
+    trait call returns, and the batcher needed far fewer device passes than publishes."""
+    g = hr.hr_new(1, 0)
+    o = orc.DefaultRouter()
+    hr.hr_set_shared_policy(g, 1)
+    o.set_shared_policy(1)
+    rng = random.Random(99)
+    _random_world(hr, g, o, rng, n_ops=500)
+    topics = _topics(rng, 400)
+    n = len(topics)
+    ids_h, ids_o = zip(*[_id(rng.choice([1, 2]), f"c{rng.randint(0, 25)}", rng.randint(0, 1)) for _ in range(n)])
+    arr_ids = (HrId * n)(*ids_h)
+    enc = [t.encode() for t in topics]
+    arr_t = (C.c_char_p * n)(*enc)
+    arr_l = (C.c_uint32 * n)(*[len(e) for e in enc])
+    passes = C.c_uint64(0)
+    out = _take(hr, hr.hr_batcher_run(g, arr_ids, arr_t, arr_l, n, 8, 64, 2000, C.byref(passes)))
+    got = out.split("\x1e")
+    assert len(got) == n
+    for i, t in enumerate(topics):
+        exp = _strip_rel(o.matches(ids_o[i], t))
+        assert got[i] == ("!ERR" if exp is None else exp), (i, t)
+    assert 1 <= passes.value < n / 3
+    hr.hr_free(g)

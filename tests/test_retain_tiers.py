@@ -196,7 +196,7 @@ def test_tiers_concurrent_commit_and_match_hip(host_tokenize):
     def writer():
         try:
             k = 0
-            while not stop.is_set() and k < 400:
+            while not stop.is_set() and k < 60:
                 k += 1
                 assert r.retain_add("x/hot", 10_000 + k) == 0          # replace: old value dies in the base, new one lives in the delta
                 if k % 3 == 0:

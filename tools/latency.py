@@ -24,6 +24,17 @@ for bs in (1, 16, 256, 4096, 65536, 200_000):
     dt = (time.time() - t0) / reps
     print(f"config {cfg} x{scale}: batch {bs:7d}: {dt * 1e3:9.3f} ms/call  {bs / dt:14.0f} topics/s  {hits / reps / max(dt, 1e-9) / 1e6:10.1f} M tuples/s  (host blob in, host tuples out)")
 
+# ---- the filter-run result form (rgr_match_filters): matched filter ids only, the host expands from its own relations
+for bs in (1, 256, 4096, 65536, 200_000):
+    reps = max(3, min(200, 400_000 // bs))
+    batches = [wl.take(tb, to, np.arange(i * bs, (i + 1) * bs) % 200_000) for i in range(min(reps, 8))]
+    r.match_filters(*batches[0])
+    t0 = time.time(); pairs = 0
+    for i in range(reps):
+        res = r.match_filters(*batches[i % len(batches)]); pairs += len(res["filter_ids"])
+    dt = (time.time() - t0) / reps
+    print(f"config {cfg} x{scale}: batch {bs:7d}: {dt * 1e3:9.3f} ms/call  {bs / dt:14.0f} topics/s  {pairs / reps / max(dt, 1e-9) / 1e6:10.2f} M filter ids/s  (rgr_match_filters: host blob in, matched filter ids out)")
+
 # ---- commit latency: a burst of SUBSCRIBEs followed by rgr_commit (delta path)
 rng = np.random.default_rng(0)
 fb, fo, _, fq = wl.gen_subs(64 * 40, 777, c["p_plus"], c["p_hash"], c["p_sys"])
