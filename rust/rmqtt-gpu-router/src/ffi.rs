@@ -85,3 +85,23 @@ extern "C" {
     pub fn rgr_shard_assign(blob: *const u8, offsets: *const u64, n: u64, n_shards: u32, is_filter: i32, key_levels: u32,
                             out: *mut i32) -> i32;
 }
+
+// ---- multi-GPU group (one handle per device; include/rmqtt_gpu_router.h "multi-GPU") ----------------
+#[repr(C)]
+pub struct rgr_group { _p: [u8; 0] }
+
+extern "C" {
+    pub fn rgr_group_create(cfg: *const rgr_config, devices: *const i32, n_devices: u32, out: *mut *mut rgr_group) -> i32;
+    pub fn rgr_group_destroy(g: *mut rgr_group);
+    pub fn rgr_group_size(g: *const rgr_group) -> u32;
+    pub fn rgr_group_handle(g: *mut rgr_group, shard: u32) -> *mut rgr_handle;
+    pub fn rgr_group_subscribe_ex(g: *mut rgr_group, filter: *const c_char, len: u32, sub_id: u32, qos: u8, flags: u8, node_idx: u16,
+                                  owner_id: u32, client_idx: u32) -> i32;
+    pub fn rgr_group_unsubscribe(g: *mut rgr_group, filter: *const c_char, len: u32, sub_id: u32, last_of_filter: i32) -> i32;
+    pub fn rgr_group_subscribe_bulk(g: *mut rgr_group, blob: *const u8, offsets: *const u64, n: u64, sub_ids: *const u32, qos: *const u8,
+                                    flags: *const u8, n_rejected: *mut u64) -> i32;
+    pub fn rgr_group_commit(g: *mut rgr_group) -> i32;
+    pub fn rgr_group_match_batch(g: *mut rgr_group, blob: *const u8, offsets: *const u64, n: u32, out: *mut rgr_result) -> i32;
+    pub fn rgr_group_match_batch_deliver(g: *mut rgr_group, blob: *const u8, offsets: *const u64, n: u32, attrs: *const rgr_publish_attr,
+                                         out: *mut rgr_result) -> i32;
+}

@@ -1,146 +1,294 @@
 //! `GpuRouter`: wraps `DefaultRouter` exactly like `rmqtt-cluster-broadcast/src/router.rs:22-62`
 //! wraps it — every `Router` method is delegated to `inner`, except that `add`/`remove` are also
-//! mirrored into the device table and `matches` runs on the GPU.
+//! mirrored into the device table and `matches` runs on the GPU(s).
 //!
-//! Source only (no rustc in the build image); the C++ twin that IS compiled and tested against
-//! the oracle is rmqtt_amd/host/gpu_router.{hpp,cpp}.
+//! * one `rgr_group` = one handle per device; filters and publishes are routed by `rgr_shard_assign`
+//!   inside the library, so one device and eight devices are the same code here (`devices`);
+//! * `matches` never touches the device itself: it enqueues into the deadline micro-batcher
+//!   (`crate::batcher`) and awaits its slice of the batched pass — no lock is held across the wait
+//!   and the blocking FFI call runs under `spawn_blocking`;
+//! * pending `add`/`remove`s are committed (`rgr_group_commit`) by the batcher right before the next
+//!   pass, on its blocking thread, so SUBSCRIBE never waits for the device;
+//! * the per-hit decisions of `_matches` come back as delivery words (`RGR_HIT_*`): No Local
+//!   (router.rs:196-201) is decided on the device against the publisher's dense owner id; the v5
+//!   collector is `SubscriptioRelationsCollector` itself (types.rs:503-541), fed in the device's order,
+//!   which IS `TopicTree::matches`' filter order;
+//! * `$share` members (router.rs:202-213) are collected per (filter, group) while one filter's hits go by
+//!   and `SharedSubscription::choice` picks one (router.rs:236-255) — same place, same arguments.
+//!
+//! Source only (no rustc in the build image).  The C++ twin that IS compiled and tested against the
+//! oracle's `DefaultRouter` — same structure, same order of decisions, incl. the `$share` path, the
+//! sharded table and the batcher — is rmqtt_amd/host/gpu_router.{hpp,cpp} (tests/test_host_router.py).
 use std::ffi::CStr;
-use std::sync::Arc;
+use std::sync::atomic::{AtomicBool, Ordering};
+use std::sync::{Arc, RwLock};
+use std::time::Duration;
 
 use ahash::AHashMap as HashMap;
 use async_trait::async_trait;
+use rmqtt::context::ServerContext;
 use rmqtt::router::{DefaultRouter, Router};
 use rmqtt::types::*;
 use rmqtt::utils::Counter;
 use rmqtt::Result;
-use tokio::sync::Mutex;
 
+use crate::batcher::{Batcher, GroupPtr};
 use crate::ffi::*;
 
-struct Handle(*mut rgr_handle);
-unsafe impl Send for Handle {}
-unsafe impl Sync for Handle {} // the C ABI is thread-safe (include/rmqtt_gpu_router.h, "threading")
-impl Drop for Handle {
+struct Group(*mut rgr_group);
+unsafe impl Send for Group {}
+unsafe impl Sync for Group {} // the C ABI is thread-safe (include/rmqtt_gpu_router.h, "threading")
+impl Drop for Group {
     fn drop(&mut self) {
-        unsafe { rgr_destroy(self.0) }
+        unsafe { rgr_group_destroy(self.0) }
     }
 }
 
-/// sub_id slab: dense relation id -> (filter, client).  `relations` stays the source of truth.
+/// Dense u32 ids with reference counts (owner id per `Id`, client index per (node, ClientId)).
+#[derive(Default)]
+struct Dense<K: std::hash::Hash + Eq + Clone> {
+    ids: HashMap<K, (u32, u32)>, // key -> (id, refs)
+    free: Vec<u32>,
+    next: u32,
+}
+impl<K: std::hash::Hash + Eq + Clone> Dense<K> {
+    fn acquire(&mut self, k: &K) -> u32 {
+        if let Some(e) = self.ids.get_mut(k) {
+            e.1 += 1;
+            return e.0;
+        }
+        let id = self.free.pop().unwrap_or_else(|| { self.next += 1; self.next - 1 });
+        self.ids.insert(k.clone(), (id, 1));
+        id
+    }
+    fn release(&mut self, k: &K) {
+        if let Some(e) = self.ids.get_mut(k) {
+            e.1 -= 1;
+            if e.1 == 0 {
+                let id = e.0;
+                self.ids.remove(k);
+                self.free.push(id);
+            }
+        }
+    }
+    fn find(&self, k: &K) -> u32 {
+        self.ids.get(k).map(|e| e.0).unwrap_or(RGR_ID_NONE)
+    }
+}
+
+/// sub_id slab: dense relation id -> (filter, client).  `inner.relations` stays the source of truth
+/// for `Id` and options; the slab only says which relation a hit is.
 #[derive(Default)]
 struct Slab {
-    slots: Vec<Option<(TopicFilter, ClientId)>>,
+    slots: Vec<Option<(TopicFilter, ClientId, Id)>>,
     free: Vec<u32>,
-    ids: HashMap<(TopicFilter, ClientId), (u32 /*filter_id*/, u32 /*sub_id*/)>,
-    refs: HashMap<u32 /*filter_id*/, usize>,
-    dirty: bool,
+    ids: HashMap<(TopicFilter, ClientId), u32>,
+    per_filter: HashMap<TopicFilter, usize>,
+    owners: Dense<Id>,
+    clients: Dense<(NodeId, ClientId)>,
+    nodes: Vec<NodeId>,
+    node_idx: HashMap<NodeId, u16>,
 }
 
 #[derive(Clone)]
 pub struct GpuRouter {
+    scx: ServerContext,
     inner: DefaultRouter,
-    h: Arc<Handle>,
-    slab: Arc<Mutex<Slab>>,
+    g: Arc<Group>,
+    slab: Arc<RwLock<Slab>>,
+    dirty: Arc<AtomicBool>,
+    batcher: Arc<Batcher>,
 }
 
 fn last_error() -> String {
     unsafe { CStr::from_ptr(rgr_last_error()).to_string_lossy().into_owned() }
 }
 
+fn flags(opts: &SubscriptionOptions) -> u8 {
+    let mut f = 0;
+    if !opts.is_v3() { f |= RGR_SUB_V5; }
+    if opts.no_local() == Some(true) { f |= RGR_SUB_NO_LOCAL; }
+    if opts.retain_as_published() == Some(true) { f |= RGR_SUB_RAP; }
+    if opts.has_shared_group() { f |= RGR_SUB_SHARED; }
+    f
+}
+
 impl GpuRouter {
-    pub fn new(inner: DefaultRouter, device: i32) -> Result<Self> {
-        let cfg = rgr_config { device, ..Default::default() };
-        let mut h = std::ptr::null_mut();
-        if unsafe { rgr_create(&cfg, &mut h) } != RGR_OK {
-            return Err(anyhow::anyhow!("rgr_create: {}", last_error()));
+    /// `devices`: one shard per HIP device ordinal (a single entry = one GPU).  Must be called inside the
+    /// tokio runtime (the batcher's driver task is spawned here).
+    pub fn new(scx: ServerContext, devices: &[i32], max_batch: usize, max_delay: Duration) -> Result<Self> {
+        let cfg = rgr_config::default();
+        let mut g = std::ptr::null_mut();
+        if unsafe { rgr_group_create(&cfg, devices.as_ptr(), devices.len() as u32, &mut g) } != RGR_OK {
+            return Err(anyhow::anyhow!("rgr_group_create: {}", last_error()));
         }
-        Ok(Self { inner, h: Arc::new(Handle(h)), slab: Arc::new(Mutex::new(Slab::default())) })
+        let g = Arc::new(Group(g));
+        let dirty = Arc::new(AtomicBool::new(false));
+        let (gp, d2) = (GroupPtr(g.0), dirty.clone());
+        // pending subscription changes become visible right before the next pass, on the batcher's blocking thread
+        let batcher = Batcher::spawn(gp, max_batch, max_delay, move || {
+            if d2.swap(false, Ordering::AcqRel) && unsafe { rgr_group_commit(gp.0) } != RGR_OK {
+                d2.store(true, Ordering::Release);
+                return Err(format!("rgr_group_commit: {}", last_error()));
+            }
+            Ok(())
+        });
+        Ok(Self {
+            inner: DefaultRouter::new(Some(scx.clone())),
+            scx,
+            g,
+            slab: Arc::new(RwLock::new(Slab::default())),
+            dirty,
+            batcher: Arc::new(batcher),
+        })
     }
 
-    fn flags(opts: &SubscriptionOptions) -> u8 {
-        let mut f = 0;
-        if !opts.is_v3() { f |= RGR_SUB_V5; }
-        if opts.no_local() == Some(true) { f |= RGR_SUB_NO_LOCAL; }
-        if opts.has_shared_group() { f |= RGR_SUB_SHARED; }
-        f
+    pub fn _inner(&self) -> &DefaultRouter {
+        &self.inner
+    }
+
+    /// Mirror one relation into the device table (after `inner.add` accepted it).
+    fn mirror_add(&self, topic_filter: &str, id: &Id, opts: &SubscriptionOptions) -> Result<()> {
+        let mut s = self.slab.write().unwrap();
+        let key = (TopicFilter::from(topic_filter), id.client_id.clone());
+        let sub_id = match s.ids.get(&key) {
+            Some(sid) => {
+                // re-subscribe (HashMap::insert replaces, router.rs:447): same relation id, new Id / options
+                let sid = *sid;
+                if let Some((_, _, old_id)) = s.slots[sid as usize].take() {
+                    s.owners.release(&old_id);
+                    s.clients.release(&(old_id.node_id, old_id.client_id.clone()));
+                }
+                sid
+            }
+            None => {
+                let sid = s.free.pop().unwrap_or_else(|| { s.slots.push(None); (s.slots.len() - 1) as u32 });
+                s.ids.insert(key.clone(), sid);
+                *s.per_filter.entry(key.0.clone()).or_default() += 1;
+                sid
+            }
+        };
+        let owner_id = s.owners.acquire(id);
+        let client_idx = s.clients.acquire(&(id.node_id, id.client_id.clone()));
+        let node_idx = match s.node_idx.get(&id.node_id) {
+            Some(i) => *i,
+            None => {
+                if s.nodes.len() >= 0xFFFF { return Err(anyhow::anyhow!("more than 65535 distinct node ids")); }
+                let i = s.nodes.len() as u16;
+                s.nodes.push(id.node_id);
+                s.node_idx.insert(id.node_id, i);
+                i
+            }
+        };
+        s.slots[sub_id as usize] = Some((key.0, key.1, id.clone()));
+        let rc = unsafe {
+            rgr_group_subscribe_ex(self.g.0, topic_filter.as_ptr() as _, topic_filter.len() as u32, sub_id, opts.qos_value(), flags(opts),
+                                   node_idx, owner_id, client_idx)
+        };
+        if rc != RGR_OK { return Err(anyhow::anyhow!("rgr_group_subscribe_ex: {}", last_error())); }
+        self.dirty.store(true, Ordering::Release);
+        Ok(())
+    }
+
+    fn mirror_remove(&self, topic_filter: &str, id: &Id) -> Result<()> {
+        let mut s = self.slab.write().unwrap();
+        let key = (TopicFilter::from(topic_filter), id.client_id.clone());
+        let Some(sid) = s.ids.remove(&key) else { return Ok(()) };
+        if let Some((_, _, old_id)) = s.slots[sid as usize].take() {
+            s.owners.release(&old_id);
+            s.clients.release(&(old_id.node_id, old_id.client_id.clone()));
+        }
+        s.free.push(sid);
+        let last = {
+            let n = s.per_filter.get_mut(&key.0).map(|n| { *n -= 1; *n }).unwrap_or(0);
+            if n == 0 { s.per_filter.remove(&key.0); }
+            n == 0 // the filter leaves the trie with its last relation (router.rs:484-490)
+        };
+        let rc = unsafe { rgr_group_unsubscribe(self.g.0, topic_filter.as_ptr() as _, topic_filter.len() as u32, sid, last as i32) };
+        if rc != RGR_OK { return Err(anyhow::anyhow!("rgr_group_unsubscribe: {}", last_error())); }
+        self.dirty.store(true, Ordering::Release);
+        Ok(())
+    }
+
+    /// Rebuild the device table from `inner.relations` in one bulk call — for the restore path of the
+    /// cluster routers (rmqtt-cluster-raft/src/router.rs:557-566 re-inserts every relation after a snapshot).
+    pub fn resync(&self) -> Result<()> {
+        for e in self.inner.relations.iter() {
+            for (_client_id, (id, opts)) in e.value().iter() {
+                self.mirror_add(e.key(), id, opts)?;
+            }
+        }
+        Ok(())
     }
 }
 
 #[async_trait]
 impl Router for GpuRouter {
     async fn add(&self, topic_filter: &str, id: Id, opts: SubscriptionOptions) -> Result<()> {
-        self.inner.add(topic_filter, id.clone(), opts.clone()).await?; // rmqtt/src/router.rs:434-453
-        let mut s = self.slab.lock().await;
-        let key = (TopicFilter::from(topic_filter), id.client_id.clone());
-        let mut fid = 0u32;
-        if unsafe { rgr_filter_add(self.h.0, topic_filter.as_ptr() as _, topic_filter.len() as u32, &mut fid) } != RGR_OK {
-            return Err(anyhow::anyhow!("rgr_filter_add: {}", last_error()));
-        }
-        let sub_id = match s.ids.get(&key) {
-            Some((_, sid)) => *sid, // re-subscribe: options replaced in place
-            None => {
-                let sid = s.free.pop().unwrap_or_else(|| { s.slots.push(None); (s.slots.len() - 1) as u32 });
-                s.slots[sid as usize] = Some(key.clone());
-                s.ids.insert(key, (fid, sid));
-                *s.refs.entry(fid).or_default() += 1;
-                sid
-            }
-        };
-        unsafe { rgr_sub_add(self.h.0, fid, sub_id, opts.qos_value(), Self::flags(&opts)) };
-        s.dirty = true;
-        Ok(())
+        self.inner.add(topic_filter, id.clone(), opts.clone()).await?; // rmqtt/src/router.rs:434-453 (rejects invalid filters)
+        self.mirror_add(topic_filter, &id, &opts)
     }
 
     async fn remove(&self, topic_filter: &str, id: Id) -> Result<bool> {
         let removed = self.inner.remove(topic_filter, id.clone()).await?; // rmqtt/src/router.rs:456-496
         if removed {
-            let mut s = self.slab.lock().await;
-            if let Some((fid, sid)) = s.ids.remove(&(TopicFilter::from(topic_filter), id.client_id.clone())) {
-                unsafe { rgr_sub_remove(self.h.0, fid, sid) };
-                s.slots[sid as usize] = None;
-                s.free.push(sid);
-                let left = { let r = s.refs.get_mut(&fid).unwrap(); *r -= 1; *r };
-                if left == 0 {
-                    s.refs.remove(&fid);
-                    unsafe { rgr_filter_remove(self.h.0, fid) }; // prune, like trie.rs:134-149
-                }
-                s.dirty = true;
-            }
+            self.mirror_remove(topic_filter, &id)?;
         }
         Ok(removed)
     }
 
-    /// rmqtt/src/router.rs:499-501 / 174-265.  One publish per call here; `crate::batcher` puts a
-    /// deadline micro-batcher in front so that concurrent publishes share one device pass.
+    /// rmqtt/src/router.rs:499-501 / 174-265.
     async fn matches(&self, this_id: Id, topic: &TopicName) -> Result<SubRelationsMap> {
-        let mut s = self.slab.lock().await;
-        if s.dirty {
-            if unsafe { rgr_commit(self.h.0) } != RGR_OK { return Err(anyhow::anyhow!("rgr_commit: {}", last_error())); }
-            s.dirty = false;
-        }
-        let offsets = [0u64, topic.len() as u64];
-        let mut res: rgr_result = unsafe { std::mem::zeroed() };
-        if unsafe { rgr_match_batch(self.h.0, topic.as_ptr(), offsets.as_ptr(), 1, &mut res) } != RGR_OK {
-            return Err(anyhow::anyhow!("rgr_match_batch: {}", last_error()));
-        }
-        let status = unsafe { *res.status };
-        let tuples = unsafe { std::slice::from_raw_parts(res.tuples, res.n_hits as usize) }.to_vec();
-        unsafe { rgr_result_free(&mut res) };
-        if status != RGR_TOPIC_OK {
-            return Err(anyhow::anyhow!("invalid topic `{topic}`")); // Topic::from_str Err, router.rs:177
-        }
-        // Host post-processing identical to router.rs:194-261: No-Local, shared groups, collector.
+        let from_owner = self.slab.read().unwrap().owners.find(&this_id);
+        // the device pass (trie walk + relation expansion + No Local), shared with every concurrent publish
+        let hits = self.batcher.matches(topic, from_owner).await.map_err(|e| anyhow::anyhow!(e))?;
+
+        // which relation each hit is: resolved under the slab's read lock, which is NOT held across an await
+        let rels: Vec<(u32, TopicFilter, ClientId)> = {
+            let s = self.slab.read().unwrap();
+            hits.iter()
+                .filter_map(|t| s.slots.get(t.sub_id as usize).and_then(|x| x.as_ref()).map(|(f, c, _)| (t.qos_flags, f.clone(), c.clone())))
+                .collect()
+        };
+
         let mut collector_map: SubscriptioRelationsCollectorMap = Default::default();
-        for t in tuples {
-            let Some((filter, client_id)) = s.slots[t.sub_id as usize].as_ref() else { continue };
-            let Some(rels) = self.inner.relations.get(filter) else { continue };
-            let Some((id, opts)) = rels.get(client_id) else { continue };
-            if opts.no_local() == Some(true) && &this_id == id { continue; }
-            // shared-subscription members (RGR_SUB_SHARED) go through SharedSubscription::choice
-            // exactly as in router.rs:202-221 / 236-255 — omitted here for brevity.
-            collector_map.entry(id.node_id).or_default().add(filter, client_id.clone(), opts.clone(), None);
+        type Member = (NodeId, ClientId, SubscriptionOptions, Option<Vec<SubscriptionIdentifier>>, Option<IsOnline>);
+        let mut groups: HashMap<SharedGroup, Vec<Member>> = Default::default(); // router.rs:183-192, one filter at a time
+        let mut cur_filter: Option<TopicFilter> = None;
+        let mut i = 0;
+        while i <= rels.len() {
+            let boundary = i == rels.len() || cur_filter.as_ref() != Some(&rels[i].1);
+            if boundary {
+                // select a subscriber from every shared group of the filter that just ended (router.rs:236-255)
+                if let Some(filter) = cur_filter.as_ref() {
+                    for (group, mut s_subs) in groups.drain() {
+                        let group_cids = s_subs.iter().map(|(_, cid, _, _, _)| cid.clone()).collect();
+                        if let Some((idx, is_online)) =
+                            self.scx.extends.shared_subscription().await.choice(&self.scx, &group, &this_id, topic, &s_subs).await
+                        {
+                            let (node_id, client_id, opts, _, _) = s_subs.remove(idx);
+                            collector_map.entry(node_id).or_default().add(filter, client_id, opts, Some((group, is_online, group_cids)));
+                        }
+                    }
+                }
+                if i == rels.len() { break; }
+                cur_filter = Some(rels[i].1.clone());
+            }
+            let (word, filter, client_id) = &rels[i];
+            i += 1;
+            if word & RGR_HIT_NO_LOCAL != 0 { continue; } // router.rs:196-201, decided on the device (whole-`Id` equality via the owner id)
+            // Id and options come from the source of truth; a relation removed since the pass is skipped,
+            // as the reference would no longer see it either
+            let Some((id, opts)) = self.inner.relations.get(filter).and_then(|r| r.get(client_id).cloned()) else { continue };
+            if let Some(group) = opts.shared_group() {
+                // router.rs:204-213
+                let online = self.is_online(id.node_id, client_id).await;
+                groups.entry(group.clone()).or_default().push((id.node_id, client_id.clone(), opts.clone(), None, Some(online)));
+                continue;
+            }
+            collector_map.entry(id.node_id).or_default().add(filter, client_id.clone(), opts, None); // router.rs:214-229
         }
-        Ok(collector_map.into_iter().map(|(n, c)| (n, c.into())).collect())
+        Ok(collector_map.into_iter().map(|(n, c)| (n, c.into())).collect()) // router.rs:258-261
     }
 
     // ---- everything else: plain delegation (router.rs:65-112) -----------------------------
