@@ -69,8 +69,10 @@ enum {
 /* per-topic status values in result/status arrays */
 enum {
     RGR_TOPIC_OK = 0,
-    RGR_TOPIC_INVALID = -2    /* Topic::from_str would return Err => no subscribers
+    RGR_TOPIC_INVALID = -2,   /* Topic::from_str would return Err => no subscribers
                                  (rmqtt/src/shared.rs:774-777)                       */
+    RGR_PACKET_MALFORMED = -8 /* rgr_batch_create_from_publish: the codec would reject the packet
+                                 (DecodeError; rgr_publish_info.error says which)     */
 };
 
 /* subscription flag bits carried next to qos (opaque to the matcher) */
@@ -279,6 +281,28 @@ void rgr_filters_result_free(rgr_filters_result* r);
  * arrays resident in HBM. */
 int32_t rgr_batch_create(rgr_handle* h, const uint8_t* topics_blob, const uint64_t* topic_offsets, uint32_t n,
                          rgr_batch** out);
+/* PUBLISH-packet form of rgr_batch_create (the step right before the path): the batch is built
+ * from raw MQTT PUBLISH packets, each entry exactly one frame as the codec delimits it (first byte, remaining
+ * length, body: rmqtt-codec/src/v3/codec.rs:63-97).  The topic-name field, QoS, RETAIN, DUP and the packet id are
+ * extracted on the device exactly as v3/decode.rs:110-128 (version 3 / 4) and v5/packet/publish.rs:31-101 (version
+ * 5, including the property block's validation) do, and the topics go straight to the device tokeniser.
+ * Per-packet status: RGR_TOPIC_OK, RGR_TOPIC_INVALID (decoded fine, Topic::from_str fails) or
+ * RGR_PACKET_MALFORMED (the codec's DecodeError: such a publish never reaches the router).
+ * from_ids != NULL ([n] owner ids, RGR_ID_NONE allowed): the batch also carries publish attributes built from
+ * the packets' own QoS / RETAIN bits, i.e. every pass runs the delivery stage.  A v5 publish that uses a topic
+ * alias arrives with an empty topic name: resolve aliases before (session state, rmqtt/src/session.rs). */
+typedef struct rgr_publish_info {
+    uint64_t topic_off;         /* offset of the topic-name bytes inside the packets blob                 */
+    uint32_t topic_len;
+    uint32_t payload_off;       /* offset of the payload inside the packet                                */
+    uint16_t packet_id;         /* 0 = none (QoS 0)                                                       */
+    uint8_t qos, retain, dup;
+    uint8_t error;              /* 0 ok; 1 not a PUBLISH frame, 2 InvalidLength, 3 MalformedPacket, 4 Utf8Error */
+    uint8_t _pad[2];
+} rgr_publish_info;
+int32_t rgr_batch_create_from_publish(rgr_handle* h, const uint8_t* packets, const uint64_t* packet_offsets, uint32_t n, uint32_t version,
+                                      const uint32_t* from_ids, rgr_batch** out);
+const rgr_publish_info* rgr_batch_publish_info(const rgr_batch* b);      /* [n], host pointer, batch lifetime */
 void rgr_batch_destroy(rgr_batch* b);
 /* [n] statuses computed by the tokeniser (host pointer, valid for the batch lifetime) */
 const int32_t* rgr_batch_status(const rgr_batch* b);

@@ -13,7 +13,9 @@ from . import build as _build
 
 RGR_OK, RGR_EOF = 0, 1
 RGR_EINVAL, RGR_EINVAL_TOPIC, RGR_ENOMEM, RGR_EDEVICE, RGR_ECAPACITY, RGR_ENOENT, RGR_ESTATE = -1, -2, -3, -4, -5, -6, -7
-RGR_TOPIC_OK, RGR_TOPIC_INVALID = 0, -2
+RGR_TOPIC_OK, RGR_TOPIC_INVALID, RGR_PACKET_MALFORMED = 0, -2, -8
+PUBLISH_INFO_DTYPE = np.dtype([("topic_off", np.uint64), ("topic_len", np.uint32), ("payload_off", np.uint32), ("packet_id", np.uint16),
+                               ("qos", np.uint8), ("retain", np.uint8), ("dup", np.uint8), ("error", np.uint8), ("_pad", np.uint8, 2)])
 RGR_SUB_V5, RGR_SUB_NO_LOCAL, RGR_SUB_SHARED, RGR_SUB_RAP = 1, 2, 4, 8
 RGR_HIT_QOS_MASK, RGR_HIT_RETAIN, RGR_HIT_NO_LOCAL, RGR_HIT_V5_DUP = 3, 4, 8, 16
 ID_NONE = 0xFFFFFFFF
@@ -29,7 +31,7 @@ SYMBOLS = [
     "rgr_filter_add", "rgr_filter_find", "rgr_filter_remove", "rgr_sub_add", "rgr_sub_add_ex", "rgr_sub_attrs_bulk",
     "rgr_sub_remove", "rgr_subscribe_bulk", "rgr_snapshot_save", "rgr_snapshot_load", "rgr_commit",
     "rgr_match_batch", "rgr_match_batch_deliver", "rgr_result_free", "rgr_match_filters", "rgr_filters_result_free",
-    "rgr_batch_create", "rgr_batch_destroy", "rgr_batch_status", "rgr_batch_set_publish_attrs",
+    "rgr_batch_create", "rgr_batch_create_from_publish", "rgr_batch_publish_info", "rgr_batch_destroy", "rgr_batch_status", "rgr_batch_set_publish_attrs",
     "rgr_batch_set_format", "rgr_batch_set_topic_ids", "rgr_batch_begin", "rgr_batch_next_window",
     "rgr_window_to_host", "rgr_batch_run", "rgr_batch_run_to_host",
     "rgr_retain_topic_add", "rgr_retain_topic_remove", "rgr_retain_add_bulk", "rgr_retain_commit",
@@ -127,6 +129,8 @@ def lib():
         L.rgr_filters_result_free.argtypes = [C.POINTER(FiltersResult)]; L.rgr_filters_result_free.restype = None
         L.rgr_batch_create.argtypes = [vp, vp, vp, u32, C.POINTER(vp)]
         L.rgr_batch_destroy.argtypes = [vp]; L.rgr_batch_destroy.restype = None
+        L.rgr_batch_create_from_publish.argtypes = [vp, vp, vp, u32, u32, vp, C.POINTER(vp)]
+        L.rgr_batch_publish_info.argtypes = [vp]; L.rgr_batch_publish_info.restype = vp
         L.rgr_batch_status.argtypes = [vp]; L.rgr_batch_status.restype = vp
         L.rgr_batch_begin.argtypes = [vp]
         L.rgr_batch_set_format.argtypes = [vp, u32]
@@ -326,6 +330,10 @@ class Router:
     def batch(self, blob, offsets):
         return Batch(self, blob, offsets)
 
+    def publish_batch(self, packets, offsets, version=4, from_ids=None):
+        """Batch built from raw MQTT PUBLISH packets (one frame per entry)."""
+        return Batch(self, packets, offsets, publish_version=version, from_ids=from_ids)
+
     def retain_batch(self, blob, offsets, tier=None):
         return Batch(self, blob, offsets, retain=True, tier=tier)
 
@@ -376,12 +384,17 @@ class Router:
 class Batch:
     """Device-resident tokenised batch (rgr_batch_*)."""
 
-    def __init__(self, router, blob, offsets, retain=False, tier=None):
+    def __init__(self, router, blob, offsets, retain=False, tier=None, publish_version=None, from_ids=None):
         self.router = router
         self.n = len(offsets) - 1
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         self._b = C.c_void_p()
         bp, bk = _blob_ptr(blob)
+        if publish_version is not None:      # blob = raw MQTT PUBLISH packets (rgr_batch_create_from_publish)
+            f = None if from_ids is None else np.ascontiguousarray(from_ids, dtype=np.uint32)
+            _check(lib().rgr_batch_create_from_publish(router._h, bp, offsets.ctypes.data, self.n, publish_version,
+                                                       None if f is None else f.ctypes.data, C.byref(self._b)))
+            return
         if retain and tier is not None:
             _check(lib().rgr_retain_batch_create_tier(router._h, bp, offsets.ctypes.data, self.n, tier, C.byref(self._b)))
             return
@@ -401,6 +414,10 @@ class Batch:
 
     def status(self):
         return _copy(lib().rgr_batch_status(self._b), self.n, np.int32)
+
+    def publish_info(self):
+        p = lib().rgr_batch_publish_info(self._b)
+        return _copy(p, self.n, PUBLISH_INFO_DTYPE) if p else None
 
     def set_publish_attrs(self, publish_attrs):
         if publish_attrs is None:

@@ -148,6 +148,10 @@ struct rgr_batch {
     uint64_t total_tokens = 0, valid_levels = 0, valid_topics = 0;
     DevBuf d_tokens, d_tok_off, d_tflags, d_path;
     DevBuf d_blob, d_offs, d_level_cnt;   // raw topics (device tokeniser)
+    // rgr_batch_create_from_publish: raw PUBLISH packets, what the scan extracted, which packets the codec rejects
+    bool from_publish = false;
+    DevBuf d_pkts, d_pkt_offs, d_pubinfo, d_force;
+    std::vector<PubInfo> pub_info;
     std::vector<uint8_t> h_blob;          // raw topics kept on the host (host tokeniser only)
     std::vector<uint64_t> h_offs;
     uint64_t dict_tokens = ~0ull;         // stamp of the dictionary the batch was tokenised against
@@ -326,7 +330,8 @@ void tokenize_batch_device(rgr_batch* b, const DictImage& dict) {
     b->scan_tmp.ensure((size_t(n) / scan_block_topics() + 3) * 16);
     const uint8_t* blob = b->d_blob.as<uint8_t>();
     const uint64_t* offs = b->d_offs.as<uint64_t>();
-    launch_tok_count(blob, offs, n, b->d_level_cnt.as<uint32_t>(), b->d_tflags.as<uint8_t>(), b->stream);
+    launch_tok_count(blob, offs, n, b->d_level_cnt.as<uint32_t>(), b->d_tflags.as<uint8_t>(), b->stream,
+                     b->from_publish ? b->d_force.as<uint8_t>() : nullptr);
     launch_scan_u32(b->d_level_cnt.as<uint32_t>(), b->d_tok_off.as<uint64_t>(), n, b->scan_tmp.as<uint64_t>(), b->stream);
     uint64_t total = 0;
     std::vector<uint8_t> flags(n);
@@ -343,6 +348,8 @@ void tokenize_batch_device(rgr_batch* b, const DictImage& dict) {
     for (uint32_t i = 0; i < n; ++i) {
         if (flags[i] & kTopicInvalid) b->status[i] = RGR_TOPIC_INVALID; else b->valid_topics++;
     }
+    if (b->from_publish)
+        for (uint32_t i = 0; i < n; ++i) if (b->pub_info[i].error) b->status[i] = RGR_PACKET_MALFORMED;
     b->total_tokens = total;
     b->valid_levels = total;
     b->dict_tokens = dict.n_tokens;
@@ -875,6 +882,7 @@ static int32_t batch_create_impl(rgr_handle* h, const uint8_t* blob, const uint6
         b->deliver = false;
         b->format = kFmtTuple;
         b->has_topic_ids = false;
+        b->from_publish = false;
         b->in_pass = false; b->chunk_ready = false; b->cursor = 0; b->hits_before = 0;
         b->dict_tokens = ~0ull;
         b->epoch.reset(); b->repoch.reset();
@@ -914,6 +922,63 @@ static int32_t batch_create_impl(rgr_handle* h, const uint8_t* blob, const uint6
 
 int32_t rgr_batch_create(rgr_handle* h, const uint8_t* blob, const uint64_t* offs, uint32_t n, rgr_batch** out) {
     return batch_create_impl(h, blob, offs, n, false, out);
+}
+
+// PUBLISH-packet form: the codec's topic extraction and the tokeniser both run on the device.
+int32_t rgr_batch_create_from_publish(rgr_handle* h, const uint8_t* packets, const uint64_t* offs, uint32_t n, uint32_t version,
+                                      const uint32_t* from_ids, rgr_batch** out) {
+    return guarded([&]() -> int32_t {
+        if (!h || !out || (n && (!packets || !offs))) return fail(RGR_EINVAL, "rgr_batch_create_from_publish: bad argument");
+        if (version != 3 && version != 4 && version != 5) return fail(RGR_EINVAL, "rgr_batch_create_from_publish: version must be 3, 4 (MQTT 3.1 / 3.1.1) or 5");
+        RGR_HIP(hipSetDevice(h->cfg.device));
+        auto b = std::make_unique<rgr_batch>();
+        RGR_HIP(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+        b->h = h; b->n = n; b->from_publish = true;
+        const double t1 = now_ms();
+        const uint64_t nbytes = n ? offs[n] - offs[0] : 0;
+        std::vector<uint64_t> rel(size_t(n) + 1, 0);
+        for (uint32_t i = 0; i <= n && n; ++i) rel[i] = offs[i] - offs[0];
+        b->d_pkts.ensure(std::max<uint64_t>(16, nbytes + 16));
+        b->d_pkt_offs.ensure((size_t(n) + 1) * 8);
+        b->d_pubinfo.ensure(std::max<size_t>(1, n) * sizeof(PubInfo));
+        b->d_level_cnt.ensure(std::max<uint32_t>(1, n) * 4);
+        b->d_force.ensure(std::max<uint32_t>(1, n));
+        b->d_offs.ensure((size_t(n) + 1) * 8);
+        b->scan_tmp.ensure((size_t(n) / scan_block_topics() + 3) * 16);
+        DevBuf d_from;
+        if (nbytes) RGR_HIP(hipMemcpyAsync(b->d_pkts.p, packets + offs[0], nbytes, hipMemcpyHostToDevice, b->stream));
+        RGR_HIP(hipMemcpyAsync(b->d_pkt_offs.p, rel.data(), (size_t(n) + 1) * 8, hipMemcpyHostToDevice, b->stream));
+        if (from_ids) {
+            d_from.ensure(std::max<size_t>(1, n) * 4);
+            b->d_pub.ensure(std::max<size_t>(1, n) * sizeof(PublishAttr));
+            if (n) RGR_HIP(hipMemcpyAsync(d_from.p, from_ids, size_t(n) * 4, hipMemcpyHostToDevice, b->stream));
+        }
+        b->local.h2d_ms += now_ms() - t1;
+        const double t2 = now_ms();
+        // scan every packet; the topic lengths are exclusive-scanned into the offsets of a dense topic blob
+        launch_publish_scan(b->d_pkts.as<uint8_t>(), b->d_pkt_offs.as<uint64_t>(), n, int(version), b->d_pubinfo.as<PubInfo>(),
+                            b->d_level_cnt.as<uint32_t>(), b->d_force.as<uint8_t>(), from_ids ? d_from.as<uint32_t>() : nullptr,
+                            from_ids ? b->d_pub.as<PublishAttr>() : nullptr, b->stream);
+        launch_scan_u32(b->d_level_cnt.as<uint32_t>(), b->d_offs.as<uint64_t>(), n, b->scan_tmp.as<uint64_t>(), b->stream);
+        uint64_t topic_bytes = 0;
+        b->pub_info.resize(n);
+        RGR_HIP(hipMemcpyAsync(&topic_bytes, b->d_offs.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
+        if (n) RGR_HIP(hipMemcpyAsync(b->pub_info.data(), b->d_pubinfo.p, size_t(n) * sizeof(PubInfo), hipMemcpyDeviceToHost, b->stream));
+        RGR_HIP(hipStreamSynchronize(b->stream));
+        b->d_blob.ensure(std::max<uint64_t>(16, topic_bytes + 16));
+        launch_publish_topics(b->d_pkts.as<uint8_t>(), b->d_pubinfo.as<PubInfo>(), n, b->d_offs.as<uint64_t>(), b->d_blob.as<uint8_t>(), b->stream);
+        RGR_HIP(hipGetLastError());
+        b->local.tokenize_ms += now_ms() - t2;
+        tokenize_batch_device(b.get(), *current_epoch(h)->dict);
+        b->deliver = from_ids != nullptr;
+        *out = b.release();
+        return RGR_OK;
+    });
+}
+
+const rgr_publish_info* rgr_batch_publish_info(const rgr_batch* b) {
+    static_assert(sizeof(rgr_publish_info) == sizeof(PubInfo), "rgr_publish_info layout");
+    return b && b->from_publish ? reinterpret_cast<const rgr_publish_info*>(b->pub_info.data()) : nullptr;
 }
 
 // Return a recycled workspace to the pool (bounded; extras are destroyed).

@@ -81,9 +81,11 @@ __global__ __launch_bounds__(256) void scatter_desc_kernel(FilterDesc* __restric
 // Device-side Topic::from_str + dictionary lookup: one lane per topic, one pass over its bytes
 // per kernel (count, then fill after the exclusive scan of the level counts).
 __global__ __launch_bounds__(256) void tok_count_kernel(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offs, uint32_t n,
-                                                        uint32_t* __restrict__ level_cnt, uint8_t* __restrict__ tflags) {
+                                                        uint32_t* __restrict__ level_cnt, uint8_t* __restrict__ tflags,
+                                                        const uint8_t* __restrict__ force_invalid) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= n) return;
+    if (force_invalid && force_invalid[t]) { level_cnt[t] = 0; tflags[t] = kTopicInvalid; return; }
     uint8_t fl;
     level_cnt[t] = topic_level_count(blob + offs[t], offs[t + 1] - offs[t], &fl);
     tflags[t] = fl;
@@ -95,6 +97,30 @@ __global__ __launch_bounds__(256) void tok_fill_kernel(DictView d, const uint8_t
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= n || (tflags[t] & kTopicInvalid)) return;
     topic_tokens(d, blob + offs[t], offs[t + 1] - offs[t], tokens + tok_off[t]);
+}
+
+// PUBLISH packets: lane per packet (match_core.hpp publish_scan); then the topic-name fields are gathered into a
+// dense blob for the tokeniser.
+__global__ __launch_bounds__(256) void publish_scan_kernel(const uint8_t* __restrict__ pkts, const uint64_t* __restrict__ offs, uint32_t n, int version,
+                                                           PubInfo* __restrict__ info, uint32_t* __restrict__ topic_len, uint8_t* __restrict__ bad,
+                                                           const uint32_t* __restrict__ from_ids, PublishAttr* __restrict__ attrs) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    PubInfo pi;
+    publish_scan(pkts, offs[t], offs[t + 1] - offs[t], version, pi);
+    info[t] = pi;
+    topic_len[t] = pi.topic_len;
+    bad[t] = pi.error;
+    if (attrs) attrs[t] = PublishAttr{from_ids ? from_ids[t] : kNone, uint32_t(pi.qos) | (uint32_t(pi.retain) << 2)};
+}
+__global__ __launch_bounds__(256) void publish_topics_kernel(const uint8_t* __restrict__ pkts, const PubInfo* __restrict__ info, uint32_t n,
+                                                             const uint64_t* __restrict__ topic_offs, uint8_t* __restrict__ blob) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const PubInfo pi = info[t];
+    const uint8_t* s = pkts + pi.topic_off;
+    uint8_t* d = blob + topic_offs[t];
+    for (uint32_t i = 0; i < pi.topic_len; ++i) d[i] = s[i];
 }
 
 // exclusive scan u32 -> u64 (three phases, same block shape as the chunk scan)
@@ -794,8 +820,16 @@ void launch_scatter_desc(FilterDesc* dst, const uint32_t* fids, const FilterDesc
     if (n) scatter_desc_kernel<<<(n + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(dst, fids, recs, n);
 }
 
-void launch_tok_count(const uint8_t* blob, const uint64_t* offs, uint32_t n, uint32_t* level_cnt, uint8_t* tflags, void* stream) {
-    if (n) tok_count_kernel<<<(n + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(blob, offs, n, level_cnt, tflags);
+void launch_tok_count(const uint8_t* blob, const uint64_t* offs, uint32_t n, uint32_t* level_cnt, uint8_t* tflags, void* stream,
+                      const uint8_t* force_invalid) {
+    if (n) tok_count_kernel<<<(n + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(blob, offs, n, level_cnt, tflags, force_invalid);
+}
+void launch_publish_scan(const uint8_t* pkts, const uint64_t* pkt_offs, uint32_t n, int version, PubInfo* info, uint32_t* topic_len, uint8_t* bad,
+                         const uint32_t* from_ids, PublishAttr* attrs, void* stream) {
+    if (n) publish_scan_kernel<<<(n + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(pkts, pkt_offs, n, version, info, topic_len, bad, from_ids, attrs);
+}
+void launch_publish_topics(const uint8_t* pkts, const PubInfo* info, uint32_t n, const uint64_t* topic_offs, uint8_t* blob, void* stream) {
+    if (n) publish_topics_kernel<<<(n + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(pkts, info, n, topic_offs, blob);
 }
 
 void launch_scan_u32(const uint32_t* in, uint64_t* out, uint32_t n, uint64_t* block_tmp, void* stream) {

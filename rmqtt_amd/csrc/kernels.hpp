@@ -72,6 +72,20 @@ struct DictView {
     const char* arena;          // level strings, back to back
 };
 
+// PUBLISH-packet scan (the step right before Topic::from_str): what the codec extracts from one
+// framed PUBLISH packet (rmqtt-codec/src/v3/codec.rs:63-97, v3/decode.rs:110-128, v5/packet/publish.rs:31-52).
+struct PubInfo {                 // == rgr_publish_info
+    uint64_t topic_off;          // offset of the topic-name bytes inside the packets blob
+    uint32_t topic_len;
+    uint32_t payload_off;        // offset of the payload inside the packet
+    uint16_t packet_id;          // 0 = none (qos 0)
+    uint8_t qos, retain, dup;
+    uint8_t error;               // 0 ok, else kPubErr*
+    uint8_t pad[2];
+};
+static_assert(sizeof(PubInfo) == 24, "PubInfo layout");
+constexpr uint8_t kPubErrNotPublish = 1, kPubErrLength = 2, kPubErrMalformed = 3, kPubErrUtf8 = 4;
+
 // topic flag bits produced by the tokeniser
 constexpr uint8_t kTopicInvalid = 1;   // parser rejected it: zero matches
 constexpr uint8_t kTopicMeta = 2;      // first level starts with '$' (trie.rs:342-346)
@@ -170,7 +184,14 @@ struct ChunkArrays {
 void launch_scatter_edges(EdgeEntry* dst, const uint32_t* slots, const EdgeEntry* recs, uint32_t n, void* stream);
 void launch_scatter_desc(FilterDesc* dst, const uint32_t* fids, const FilterDesc* recs, uint32_t n, void* stream);
 // device tokeniser: blob/offsets -> per-topic level counts + flags, then token ids
-void launch_tok_count(const uint8_t* blob, const uint64_t* offs, uint32_t n, uint32_t* level_cnt, uint8_t* tflags, void* stream);
+// force_invalid (optional, [n]): nonzero entries are forced to kTopicInvalid (malformed PUBLISH packets)
+void launch_tok_count(const uint8_t* blob, const uint64_t* offs, uint32_t n, uint32_t* level_cnt, uint8_t* tflags, void* stream,
+                      const uint8_t* force_invalid = nullptr);
+// PUBLISH packets -> PubInfo per packet (+ topic_len[] for the scan, bad[] for the tokeniser, optional publish attrs)
+void launch_publish_scan(const uint8_t* pkts, const uint64_t* pkt_offs, uint32_t n, int version, PubInfo* info, uint32_t* topic_len, uint8_t* bad,
+                         const uint32_t* from_ids, PublishAttr* attrs, void* stream);
+// gather the topic-name fields into a dense blob (topic_offs = exclusive scan of topic_len)
+void launch_publish_topics(const uint8_t* pkts, const PubInfo* info, uint32_t n, const uint64_t* topic_offs, uint8_t* blob, void* stream);
 void launch_scan_u32(const uint32_t* in, uint64_t* out, uint32_t n, uint64_t* block_tmp, void* stream);   // out[n] = total
 void launch_tok_fill(const DictView& d, const uint8_t* blob, const uint64_t* offs, uint32_t n, const uint64_t* tok_off,
                      const uint8_t* tflags, uint32_t* tokens, void* stream);

@@ -74,6 +74,125 @@ RGR_HD inline void topic_tokens(const DictView& d, const uint8_t* s, uint64_t le
     });
 }
 
+// ---- PUBLISH packet scan, one framed packet per call -------------------------------------------------------
+// Restates what the reference's codec does to reach the topic of a PUBLISH:
+//   framing     first byte + variable-length "remaining length" (rmqtt-codec/src/v3/codec.rs:63-97,
+//               utils.rs:142-155: at most 4 bytes, a 5th continuation is InvalidLength); the packet handed in
+//               must be exactly one frame
+//   v3 body     topic = u16 length + UTF-8 bytes (utils.rs:102-114), qos = flags bits 1-2 (3 is an error),
+//               packet id (non-zero u16) when qos > 0, payload = the rest            (v3/decode.rs:110-128)
+//   v5 body     the same, then the property block: varint length + properties; PUBLISH allows
+//               0x01 bool, 0x02 u32 != 0, 0x03 / 0x08 utf8, 0x09 binary, 0x0B varint != 0 (repeatable),
+//               0x23 u16 != 0, 0x26 utf8 pair (repeatable); anything else, or a second occurrence of a
+//               single-valued one, is MalformedPacket                                 (v5/packet/publish.rs:31-101)
+// Strict UTF-8 as std::str::from_utf8 (ByteString::try_from): no overlongs, no surrogates, max U+10FFFF.
+RGR_HD inline bool utf8_valid(const uint8_t* s, uint32_t n) {
+    uint32_t i = 0;
+    while (i < n) {
+        const uint8_t c = s[i];
+        if (c < 0x80) { ++i; continue; }
+        uint32_t need; uint8_t lo = 0x80, hi = 0xBF;
+        if (c >= 0xC2 && c <= 0xDF) need = 1;
+        else if (c == 0xE0) { need = 2; lo = 0xA0; }
+        else if (c >= 0xE1 && c <= 0xEC) need = 2;
+        else if (c == 0xED) { need = 2; hi = 0x9F; }
+        else if (c == 0xEE || c == 0xEF) need = 2;
+        else if (c == 0xF0) { need = 3; lo = 0x90; }
+        else if (c >= 0xF1 && c <= 0xF3) need = 3;
+        else if (c == 0xF4) { need = 3; hi = 0x8F; }
+        else return false;
+        if (need > n - 1 - i) return false;                                 // truncated sequence
+        if (s[i + 1] < lo || s[i + 1] > hi) return false;
+        for (uint32_t k = 2; k <= need; ++k) if ((s[i + k] & 0xC0) != 0x80) return false;
+        i += need + 1;
+    }
+    return true;
+}
+
+// MQTT variable-length integer at p[pos..end): value and new position; 0 ok, kPubErrMalformed = ran out of bytes,
+// kPubErrLength = more than 4 bytes (utils.rs:142-155)
+RGR_HD inline uint8_t mqtt_varint(const uint8_t* p, uint64_t& pos, uint64_t end, uint32_t& val) {
+    uint32_t shift = 0;
+    val = 0;
+    for (;;) {
+        if (pos >= end) return kPubErrMalformed;
+        const uint8_t b = p[pos++];
+        val += uint32_t(b & 0x7F) << shift;
+        if (!(b & 0x80)) return 0;
+        if (shift >= 21) return kPubErrLength;
+        shift += 7;
+    }
+}
+
+RGR_HD inline void publish_scan(const uint8_t* blob, uint64_t off, uint64_t len, int version, PubInfo& out) {
+    out = PubInfo{};
+    const uint8_t* p = blob + off;
+    auto fail = [&](uint8_t e) { out.error = e; out.topic_len = 0; };
+    if (len < 2 || (p[0] >> 4) != 3) return fail(kPubErrNotPublish);
+    const uint8_t flags = p[0] & 0x0F;
+    uint64_t pos = 1;
+    uint32_t rem = 0;
+    if (uint8_t e = mqtt_varint(p, pos, len, rem)) return fail(e);
+    if (uint64_t(rem) != len - pos) return fail(kPubErrLength);            // the blob entry must be exactly one frame
+    const uint64_t end = len;
+    if (end - pos < 2) return fail(kPubErrLength);                          // u16::decode, utils.rs:76-81
+    const uint32_t tl = (uint32_t(p[pos]) << 8) | p[pos + 1];
+    pos += 2;
+    if (end - pos < tl) return fail(kPubErrLength);                         // Bytes::decode, utils.rs:102-108
+    if (!utf8_valid(p + pos, tl)) return fail(kPubErrUtf8);                 // ByteString::try_from, utils.rs:110-114
+    const uint64_t topic_pos = pos;
+    pos += tl;
+    const uint8_t qos = (flags >> 1) & 3;
+    if (qos == 3) return fail(kPubErrMalformed);                            // QoS::try_from
+    uint16_t pid = 0;
+    if (qos) {
+        if (end - pos < 2) return fail(kPubErrLength);
+        pid = uint16_t((uint32_t(p[pos]) << 8) | p[pos + 1]);
+        pos += 2;
+        if (!pid) return fail(kPubErrMalformed);                            // NonZeroU16::decode
+    }
+    if (version >= 5) {                                                     // parse_publish_properties, publish.rs:64-101
+        uint32_t plen = 0;
+        if (uint8_t e = mqtt_varint(p, pos, end, plen)) return fail(e);
+        if (end - pos < plen) return fail(kPubErrLength);
+        const uint64_t pend = pos + plen;
+        uint32_t seen = 0;                                                  // single-valued properties already read
+        auto once = [&](uint32_t bit) { if (seen & bit) return false; seen |= bit; return true; };
+        auto str = [&](bool utf8) -> uint8_t {                              // u16 length + bytes
+            if (pend - pos < 2) return kPubErrLength;
+            const uint32_t n = (uint32_t(p[pos]) << 8) | p[pos + 1];
+            pos += 2;
+            if (pend - pos < n) return kPubErrLength;
+            if (utf8 && !utf8_valid(p + pos, n)) return kPubErrUtf8;
+            pos += n;
+            return 0;
+        };
+        while (pos < pend) {
+            const uint8_t id = p[pos++];
+            uint8_t e = 0;
+            switch (id) {
+                case 0x01: if (!once(1)) e = kPubErrMalformed; else if (pend - pos < 1) e = kPubErrLength; else if (p[pos++] > 1) e = kPubErrMalformed; break;
+                case 0x02: if (!once(2)) e = kPubErrMalformed; else if (pend - pos < 4) e = kPubErrLength;
+                           else { const uint32_t v = (uint32_t(p[pos]) << 24) | (uint32_t(p[pos + 1]) << 16) | (uint32_t(p[pos + 2]) << 8) | p[pos + 3]; pos += 4; if (!v) e = kPubErrMalformed; } break;
+                case 0x03: if (!once(4)) e = kPubErrMalformed; else e = str(true); break;
+                case 0x08: if (!once(8)) e = kPubErrMalformed; else e = str(true); break;
+                case 0x09: if (!once(16)) e = kPubErrMalformed; else e = str(false); break;
+                case 0x0B: { uint32_t v = 0; e = mqtt_varint(p, pos, pend, v); if (!e && !v) e = kPubErrMalformed; } break;
+                case 0x23: if (!once(32)) e = kPubErrMalformed; else if (pend - pos < 2) e = kPubErrLength;
+                           else { const uint32_t v = (uint32_t(p[pos]) << 8) | p[pos + 1]; pos += 2; if (!v) e = kPubErrMalformed; } break;
+                case 0x26: e = str(true); if (!e) e = str(true); break;
+                default: e = kPubErrMalformed;
+            }
+            if (e) return fail(e);
+        }
+    }
+    out.topic_off = off + topic_pos;
+    out.topic_len = tl;
+    out.payload_off = uint32_t(pos);
+    out.packet_id = pid;
+    out.qos = qos; out.retain = flags & 1; out.dup = (flags >> 3) & 1;
+}
+
 // Depth-first walk of the subscription trie for ONE publish topic, emitting matched filter
 // ids in exactly TopicTree::matches' iteration order (rmqtt/src/trie.rs:327-375;
 // SURVEY.md App. A.2):

@@ -81,6 +81,10 @@ int32_t emu_subscribe_bulk(void* ev, const uint8_t* blob, const uint64_t* offs, 
     return RGR_OK;
 }
 
+// The per-packet PUBLISH scan the device runs (match_core.hpp publish_scan), on the host: PubInfo per packet.
+void emu_publish_scan(const uint8_t* blob, const uint64_t* offs, uint32_t n, int version, rgr::PubInfo* out) {
+    for (uint32_t i = 0; i < n; ++i) rgr::publish_scan(blob, offs[i], offs[i + 1] - offs[i], version, out[i]);
+}
 }  // extern "C" (helpers below are C++)
 
 namespace {

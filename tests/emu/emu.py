@@ -56,6 +56,7 @@ def lib():
         L.emu_retain_nodes.argtypes = [vp]; L.emu_retain_nodes.restype = u64
         L.emu_retain_add_bulk.argtypes = [vp, vp, vp, u64, vp, C.POINTER(u64)]
         L.emu_retain_match.argtypes = [vp, vp, vp, u32, vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(u64)]
+        L.emu_publish_scan.argtypes = [vp, vp, u32, C.c_int, vp]; L.emu_publish_scan.restype = None
         _LIB = L
     return _LIB
 
@@ -230,3 +231,17 @@ class EmuRouter:
 
     def counters(self):
         return {k: int(getattr(lib(), "emu_" + k)(self._h)) for k in ("n_nodes", "n_filters", "n_subs", "visited", "overflow_topics", "windows")}
+
+
+PUBLISH_INFO_DTYPE = np.dtype([("topic_off", np.uint64), ("topic_len", np.uint32), ("payload_off", np.uint32), ("packet_id", np.uint16),
+                               ("qos", np.uint8), ("retain", np.uint8), ("dup", np.uint8), ("error", np.uint8), ("_pad", np.uint8, 2)])
+
+
+def publish_scan(blob, offsets, version):
+    """The device's per-packet PUBLISH scan (match_core.hpp publish_scan) executed on the host."""
+    blob = np.ascontiguousarray(blob, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    n = len(offsets) - 1
+    out = np.zeros(n, dtype=PUBLISH_INFO_DTYPE)
+    lib().emu_publish_scan(blob.ctypes.data, offsets.ctypes.data, n, version, out.ctypes.data)
+    return out
