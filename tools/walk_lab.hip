@@ -1,0 +1,191 @@
+// Stand-alone A/B for the trie walk (DESIGN §4 / VERDICT r1 item 7) — NOT part of the product library.
+//
+//   A  lane per topic    the product's walk (match_core.hpp walk_topic): every lane runs its own explicit-stack
+//                        DFS, 64 independent dependent-gather chains per wave
+//   B  wave per topic    BASELINE.json's north-star shape: a wave owns ONE topic and walks the trie level by level;
+//                        the frontier of trie nodes lives in LDS, every lane takes one frontier node, reads its
+//                        '+' child (direct slot) and probes its literal child, and the next frontier is compacted
+//                        with wavefront ballot + prefix popcount
+// Both only COUNT matched filters per topic (B's level-synchronous order is not TopicTree::matches' order — the
+// product would have to sort it back) and the per-topic counts must agree.  The table is the product's own
+// (HostTable from table.cpp), the workload the seeded generator (workload.cpp).
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I rmqtt_amd/csrc -I include tools/walk_lab.hip rmqtt_amd/csrc/table.cpp \
+//         rmqtt_amd/csrc/workload.cpp -o tools/walk_lab -pthread
+//   tools/walk_lab [n_sub=1000000] [n_pub=1000000] [p_plus=0.028] [p_hash=0.0] [reps=5]
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string_view>
+#include <vector>
+
+#include "kernels.hpp"
+#include "match_core.hpp"
+#include "table.hpp"
+
+using namespace rgr;
+
+#define CHECK(x)                                                                                         \
+    do {                                                                                                 \
+        hipError_t e_ = (x);                                                                             \
+        if (e_ != hipSuccess) { std::fprintf(stderr, "%s: %s (line %d)\n", #x, hipGetErrorString(e_), __LINE__); std::exit(2); } \
+    } while (0)
+
+struct wl_params { uint64_t seed, n; double p_plus, p_hash, p_sys, p_blank; uint64_t n_clients; int32_t fixed_depth, force_wildcard, distinct, reserved; };
+extern "C" int wl_gen_subs(const wl_params* p, char** blob, uint64_t** offsets, uint32_t** client, uint8_t** qos);
+extern "C" int wl_gen_topics(const wl_params* p, char** blob, uint64_t** offsets);
+
+// ---- A: lane per topic (the product kernel's structure, counting only; the DFS stack is a private array)
+__global__ __launch_bounds__(256) void walk_lane(TrieView tv, const uint32_t* __restrict__ tokens, const uint64_t* __restrict__ tok_off,
+                                                 const uint8_t* __restrict__ tflags, uint32_t n, uint32_t* __restrict__ cnt_out) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const uint64_t off0 = tok_off[t];
+    const uint32_t L = uint32_t(tok_off[t + 1] - off0);
+    uint32_t path[24];
+    uint32_t cnt = 0;
+    if (!(tflags[t] & kTopicInvalid) && L <= 24) {
+        const EdgeEntry* edges = tv.edges;
+        walk_topic(
+            tv.root, tv.mask, L, (tflags[t] & kTopicMeta) != 0, [&](uint32_t d) { return tokens[off0 + d]; }, [&](uint32_t d) { return path[d]; },
+            [&](uint32_t d, uint32_t v) { path[d] = v; }, [&](uint32_t) { cnt++; },
+            [&](uint32_t slot, U4& e0, U4& e1) {
+                const uint4* ep = reinterpret_cast<const uint4*>(edges + slot);
+                const uint4 a0 = ep[0], a1 = ep[1];
+                e0 = U4{a0.x, a0.y, a0.z, a0.w};
+                e1 = U4{a1.x, a1.y, a1.z, a1.w};
+            });
+    }
+    cnt_out[t] = cnt;
+}
+
+// ---- B: wave per topic, level-synchronous frontier in LDS, ballot / prefix-popcount compaction
+constexpr int kWavesPerBlock = 4;
+constexpr int kFrontierCap = 256;     // nodes per level per topic (chunks of 64 lanes); beyond this the topic is flagged
+struct FNode { uint32_t node, plus_slot, hash_fid, term_fid, lit_cnt, lit_xor; };
+
+__global__ __launch_bounds__(64 * kWavesPerBlock) void walk_wave(TrieView tv, const uint32_t* __restrict__ tokens, const uint64_t* __restrict__ tok_off,
+                                                                const uint8_t* __restrict__ tflags, uint32_t n, uint32_t* __restrict__ cnt_out,
+                                                                uint32_t* __restrict__ overflow) {
+    __shared__ FNode s_f[kWavesPerBlock][2][kFrontierCap];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t t = blockIdx.x * kWavesPerBlock + w;
+    if (t >= n) return;
+    const uint64_t off0 = tok_off[t];
+    const uint32_t L = uint32_t(tok_off[t + 1] - off0);
+    uint32_t cnt = 0;
+    if (!(tflags[t] & kTopicInvalid)) {
+        const bool meta = (tflags[t] & kTopicMeta) != 0;
+        int cur = 0;
+        uint32_t width = 1;
+        if (lane == 0) s_f[w][0][0] = FNode{0, tv.root.plus_slot, tv.root.hash_fid, tv.root.term_fid, tv.root.lit_cnt, tv.root.lit_xor};
+        for (uint32_t d = 0; d <= L && width; ++d) {
+            uint32_t next_w = 0;
+            const uint32_t tk = d < L ? tokens[off0 + d] : 0u;
+            for (uint32_t base = 0; base < width; base += 64) {
+                const bool live = base + lane < width;
+                FNode f{};
+                if (live) f = s_f[w][cur][base + lane];
+                bool has_a = false, has_b = false;
+                FNode a{}, b{};
+                if (live) {
+                    if (d == L) { cnt += (f.term_fid != kNone) + (f.hash_fid != kNone); }
+                    else {
+                        const bool wild = !(d == 0 && meta);
+                        if (wild && f.hash_fid != kNone) cnt++;
+                        if (wild && f.plus_slot != kNone) {                                   // '+' child: direct slot
+                            const uint4* ep = reinterpret_cast<const uint4*>(tv.edges + f.plus_slot);
+                            const uint4 e0 = ep[0], e1 = ep[1];
+                            a = FNode{e0.z, e0.w, e1.x, e1.y, e1.z, e1.w}; has_a = true;
+                        }
+                        const bool ex = tk != kTokUnknown && (tk < kTokFirst || (f.lit_cnt != 0 && (f.lit_cnt != 1 || f.lit_xor == tk)));
+                        if (ex) {                                                             // literal child: hash probe
+                            for (uint32_t s = edge_hash(f.node, tk) & tv.mask;; s = (s + 1) & tv.mask) {
+                                const uint4* ep = reinterpret_cast<const uint4*>(tv.edges + s);
+                                const uint4 e0 = ep[0];
+                                if (e0.x == kEdgeEmpty) break;
+                                if (e0.x == f.node && e0.y == tk) { const uint4 e1 = ep[1]; b = FNode{e0.z, e0.w, e1.x, e1.y, e1.z, e1.w}; has_b = true; break; }
+                            }
+                        }
+                    }
+                }
+                // compaction: every lane contributes 0..2 nodes; wavefront ballot + prefix popcount place them
+                const unsigned long long ma = __ballot(has_a), mb = __ballot(has_b);
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const uint32_t pa = next_w + uint32_t(__popcll(ma & below));
+                const uint32_t pb = next_w + uint32_t(__popcll(ma)) + uint32_t(__popcll(mb & below));
+                if (has_a && pa < kFrontierCap) s_f[w][cur ^ 1][pa] = a;
+                if (has_b && pb < kFrontierCap) s_f[w][cur ^ 1][pb] = b;
+                next_w += uint32_t(__popcll(ma)) + uint32_t(__popcll(mb));
+            }
+            if (next_w > kFrontierCap) { if (lane == 0) atomicAdd(overflow, 1u); next_w = kFrontierCap; }
+            width = next_w;
+            cur ^= 1;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
+    if (lane == 0) cnt_out[t] = cnt;
+}
+
+int main(int argc, char** argv) {
+    const uint64_t n_sub = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : 1000000;
+    const uint64_t n_pub = argc > 2 ? std::strtoull(argv[2], nullptr, 10) : 1000000;
+    const double p_plus = argc > 3 ? std::atof(argv[3]) : 0.028;
+    const double p_hash = argc > 4 ? std::atof(argv[4]) : 0.0;
+    const int reps = argc > 5 ? std::atoi(argv[5]) : 5;
+    wl_params ps{0x5EED0002, n_sub, p_plus, p_hash, 0.005, 0.0, 0, 0, 0, 0, 0};
+    char* fb; uint64_t* fo; uint32_t* cl; uint8_t* q;
+    wl_gen_subs(&ps, &fb, &fo, &cl, &q);
+    wl_params pt{0x9B1C0002, n_pub, 0, 0, 0.01, 0.01, 0, 0, 0, 0, 0};
+    char* tb; uint64_t* to;
+    wl_gen_topics(&pt, &tb, &to);
+    HostTable table;
+    uint64_t rej = 0;
+    table.subscribe_bulk(reinterpret_cast<const uint8_t*>(fb), fo, n_sub, nullptr, q, nullptr, nullptr, &rej, 0);
+    std::vector<uint32_t> toks, lens(n_pub);
+    std::vector<uint8_t> flags(n_pub);
+    std::vector<uint64_t> toff(n_pub + 1, 0);
+    for (uint64_t i = 0; i < n_pub; ++i) {
+        const size_t mark = toks.size();
+        flags[i] = table.tokenize_topic(std::string_view(tb + to[i], to[i + 1] - to[i]), toks);
+        toff[i + 1] = toff[i] + (toks.size() - mark);
+    }
+    const auto& edges = table.edges();
+    EdgeEntry* d_edges; uint32_t *d_tok, *d_ca, *d_cb, *d_ovf; uint64_t* d_off; uint8_t* d_fl;
+    CHECK(hipMalloc(&d_edges, edges.size() * sizeof(EdgeEntry)));
+    CHECK(hipMemcpy(d_edges, edges.data(), edges.size() * sizeof(EdgeEntry), hipMemcpyHostToDevice));
+    CHECK(hipMalloc(&d_tok, (toks.size() + 1) * 4)); CHECK(hipMemcpy(d_tok, toks.data(), toks.size() * 4, hipMemcpyHostToDevice));
+    CHECK(hipMalloc(&d_off, (n_pub + 1) * 8)); CHECK(hipMemcpy(d_off, toff.data(), (n_pub + 1) * 8, hipMemcpyHostToDevice));
+    CHECK(hipMalloc(&d_fl, n_pub)); CHECK(hipMemcpy(d_fl, flags.data(), n_pub, hipMemcpyHostToDevice));
+    CHECK(hipMalloc(&d_ca, n_pub * 4)); CHECK(hipMalloc(&d_cb, n_pub * 4)); CHECK(hipMalloc(&d_ovf, 4)); CHECK(hipMemset(d_ovf, 0, 4));
+    TrieView tv{};
+    tv.edges = d_edges; tv.mask = uint32_t(edges.size() - 1); tv.root = table.root_header();
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    auto timeit = [&](auto launch) {
+        launch(); CHECK(hipDeviceSynchronize());
+        CHECK(hipEventRecord(e0));
+        for (int i = 0; i < reps; ++i) launch();
+        CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        return ms / reps;
+    };
+    const float ta = timeit([&] { walk_lane<<<uint32_t((n_pub + 255) / 256), 256>>>(tv, d_tok, d_off, d_fl, uint32_t(n_pub), d_ca); });
+    const float tw = timeit([&] { walk_wave<<<uint32_t((n_pub + kWavesPerBlock - 1) / kWavesPerBlock), 64 * kWavesPerBlock>>>(tv, d_tok, d_off, d_fl, uint32_t(n_pub), d_cb, d_ovf); });
+    std::vector<uint32_t> ca(n_pub), cb(n_pub);
+    uint32_t ovf = 0;
+    CHECK(hipMemcpy(ca.data(), d_ca, n_pub * 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(cb.data(), d_cb, n_pub * 4, hipMemcpyDeviceToHost));
+    CHECK(hipMemcpy(&ovf, d_ovf, 4, hipMemcpyDeviceToHost));
+    uint64_t sa = 0, sb = 0, diff = 0;
+    for (uint64_t i = 0; i < n_pub; ++i) { sa += ca[i]; sb += cb[i]; diff += ca[i] != cb[i]; }
+    std::printf("table: %llu subs (p_plus %.3f, p_hash %.2f), %llu trie nodes, %llu edge slots; %llu topics, %.2f matched filters/topic\n",
+                (unsigned long long)n_sub, p_plus, p_hash, (unsigned long long)table.n_nodes(), (unsigned long long)edges.size(), (unsigned long long)n_pub, double(sa) / n_pub);
+    std::printf("A lane per topic  (explicit-stack DFS per lane)            %9.3f ms  %8.1f M topics/s\n", ta, n_pub / ta / 1e3);
+    std::printf("B wave per topic  (LDS frontier, ballot + prefix popcount) %9.3f ms  %8.1f M topics/s   (%.1fx A)\n", tw, n_pub / tw / 1e3, tw / ta);
+    std::printf("matched-filter counts: A total %llu, B total %llu, topics that differ %llu, frontier overflows (>%d nodes/level, per launch x%d) %u\n",
+                (unsigned long long)sa, (unsigned long long)sb, (unsigned long long)diff, kFrontierCap, reps + 1, ovf);
+    return diff != 0 && ovf == 0;
+}
