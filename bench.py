@@ -570,7 +570,7 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
                "sample": f"first {n_s} queries of the same batch against the full {n_sub}-entry table, {ost['hits']} hits, {sec:.2f}s wall",
                "hits_per_s": round(ost["hits"] / sec, 1)}
         if cores > 1:      # SURVEY 8(d) also asks for the single-thread figure
-            n1 = max(20, min(n_s, int(n_s / cores * 0.15)))
+            n1 = max(20, min(n_s, int(n_s / cores * 2.0)))        # ~2 s of single-thread work
             s1b, s1o = prefix(W, n1)
             sec1, ost1 = (o.match_timed(s1b, s1o, 1) if retain else o.matches_timed(s1b, s1o, 1))
             cpu["single_thread"] = {"value": round(n1 / sec1, 1), "hits_per_s": round(ost1["hits"] / sec1, 1), "sample": f"first {n1} queries, {sec1:.2f}s wall"}
@@ -616,6 +616,15 @@ def attach_traffic(rec, phase, pmc, cal):
                                       "write_raw": round(d["write_KiB"] * 1024 / max(1, unit), 3), "write_scale": ws,
                                       "unit": "hit" if cls == "expand" else "query"},
                "avg_launch_us_under_pmc": d.get("avg_us_under_pmc")})
+    gc = cal.get("walk", {}).get("gather_ceiling_Ggathers_per_s")
+    if cls == "walk" and gc and rf["avg_launch_ms"] > 0:
+        # the walk's own yardstick: dependent random 32-byte gathers.  tools/membench.hip `calib` measures how many such
+        # gathers per second this chip sustains from a table far larger than its caches; upper trie levels are cache hits,
+        # so the walk can exceed it.
+        nodes_per_s = rec["mean_visited_nodes_per_topic"] * rf["topics_per_launch"] / (rf["avg_launch_ms"] / 1e3)
+        rf["random_gather"] = {"visited_nodes_per_s": round(nodes_per_s, 1), "ceiling_gathers_per_s": gc * 1e9,
+                               "frac_of_ceiling": round(nodes_per_s / (gc * 1e9), 3),
+                               "note": "ceiling = random 32-byte gathers/s from a 16 GiB table (tools/membench.hip calib, profiles/pmc_calibration.json)"}
     other = "walk" if cls == "expand" else "expand"
     o = pmc.get(other)
     if o and "fetch_KiB" in o and "write_KiB" in o and o["dispatches"]:

@@ -718,8 +718,12 @@ int32_t rgr_commit(rgr_handle* h) {
                 h->sub_pool.reset(); h->host_desc.clear(); h->pool_garbage = 0;
             }
         } recover{h};
+        const bool prof = std::getenv("RGR_COMMIT_PROFILE") != nullptr;
+        double t_prev = now_ms();
+        auto lap = [&](const char* what) { if (prof) { const double t = now_ms(); std::fprintf(stderr, "[commit] %-14s %.3f ms\n", what, t - t_prev); t_prev = t; } };
         {
             std::shared_lock<std::shared_mutex> lk(h->table_mu);
+            lap("lock");
             HostTable::Delta delta;
             h->table.take_delta(delta);              // (mutators hold table_mu exclusively; this is the only reader of the delta)
             const auto& edges = h->table.edges();
@@ -758,6 +762,7 @@ int32_t rgr_commit(rgr_handle* h) {
                 RGR_HIP(hipDeviceSynchronize());
             }
             ei.pending.clear(); ei.need_full = false;
+            lap("dict + edges");
             // ---- subscriber runs: dirty filters get a fresh run appended to the pool
             const uint64_t nf = h->table.filter_capacity();
             if (h->host_desc.size() < nf) h->host_desc.resize(nf, FilterDesc{0, 0});
@@ -812,6 +817,7 @@ int32_t rgr_commit(rgr_handle* h) {
                 }
                 h->sub_pool->used += stage.size();
             }
+            lap("subscriber runs");
             FiltImage& fi = *h->filt_img[tgt];
             if (fi.need_full || fi.cap < nf || fi.pending.size() > nf / 4) {
                 fi.cap = nf + nf / 4 + 1024;
@@ -831,6 +837,7 @@ int32_t rgr_commit(rgr_handle* h) {
                 RGR_HIP(hipDeviceSynchronize());
             }
             fi.pending.clear(); fi.need_full = false;
+            lap("filter descs");
             (full ? h->commits_full : h->commits_delta)++;
             h->cur_img = tgt;
             ep->edges = h->edge_img[tgt];

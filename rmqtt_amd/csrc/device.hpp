@@ -83,7 +83,7 @@ struct PinnedBuf {
 // outlive its handle.  Blocks are powers of two >= 64 KiB; at most `keep_bytes` stay cached.
 class PinnedPool {
    public:
-    explicit PinnedPool(size_t keep_bytes = size_t(8) << 30) : keep_(keep_bytes) {}
+    explicit PinnedPool(size_t keep_bytes = size_t(16) << 30) : keep_(keep_bytes) {}
     PinnedPool(const PinnedPool&) = delete;
     PinnedPool& operator=(const PinnedPool&) = delete;
     ~PinnedPool() { for (auto& b : free_) (void)hipHostFree(b.p); }

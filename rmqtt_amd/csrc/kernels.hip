@@ -707,16 +707,24 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* 
 // position belongs to.  The compact formats write only what is new per hit (SURVEY.md §8(b)'s SoA result):
 //   kFmtSoa     out_ids[pos] = sub_id (u32), out_qos[pos] = qos | flags << 2 (u8)        5 B/hit
 //   kFmtPacked  out_ids[pos] = sub_id | qos << 30 (u32; sub ids < 2^30)                   4 B/hit
-// Same tiles and staged pair view as expand_kernel, but a lane owns FOUR CONSECUTIVE positions, so a wave
-// stores 1 KiB of sub ids with one dwordx4 per lane (and 256 B of qos bytes with one dword per lane)
-// instead of 768 B of strided 12-byte tuples.
+// Same tiles and staged pair view as expand_kernel, but a lane owns groups of FOUR CONSECUTIVE positions, so a
+// wave stores 1 KiB of sub ids with one dwordx4 per lane (and 256 B of qos bytes with one dword per lane)
+// instead of 768 B of strided 12-byte tuples.  With a third of the store bytes the kernel is no longer bound by
+// the store stream but by the per-tile dependent chain (tile_first -> pair arrays -> LDS -> subscriber loads), so
+// it runs 256-thread blocks (8 per CU) rather than the tuple kernel's 512.
+#ifndef RGR_COMPACT_THREADS
+#define RGR_COMPACT_THREADS 256      // threads per 2048-hit tile: 256 x two groups of four consecutive positions (sweep: profiles/)
+#endif
+constexpr int kCompactThreads = RGR_COMPACT_THREADS;
+constexpr int kCompactGroups = kTile / (kCompactThreads * 4);
+static_assert(kCompactGroups >= 1 && kCompactGroups * kCompactThreads * 4 == kTile, "compact expansion geometry must cover the tile");
+
 template <int FMT>
-__global__ __launch_bounds__(kExpandThreads) void expand_compact_kernel(const SubEntry* __restrict__ subs, ChunkArrays c,
-                                                                        uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo,
-                                                                        uint64_t hit_hi, const uint32_t* __restrict__ tile_first,
-                                                                        uint32_t ntiles, uint32_t* __restrict__ out_ids,
-                                                                        uint8_t* __restrict__ out_qos) {
-    static_assert(kExpandPerThread == 4, "a lane packs four qos bytes into one word");
+__global__ __launch_bounds__(kCompactThreads) void expand_compact_kernel(const SubEntry* __restrict__ subs, ChunkArrays c,
+                                                                         uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo,
+                                                                         uint64_t hit_hi, const uint32_t* __restrict__ tile_first,
+                                                                         uint32_t ntiles, uint32_t* __restrict__ out_ids,
+                                                                         uint8_t* __restrict__ out_qos) {
     __shared__ int32_t s_off[kTile + 2];
     __shared__ uint32_t s_src[kTile + 2];
     const uint32_t tile = blockIdx.x;
@@ -725,45 +733,56 @@ __global__ __launch_bounds__(kExpandThreads) void expand_compact_kernel(const Su
     const uint64_t a = pair_lo + tile_first[tile];
     const uint64_t b = (tile + 1 < ntiles) ? pair_lo + tile_first[tile + 1] + 1 : pair_hi;
     const uint32_t np = uint32_t(b - a);
-    for (uint32_t i = threadIdx.x; i < np; i += kExpandThreads) {
+    for (uint32_t i = threadIdx.x; i < np; i += kCompactThreads) {
         uint32_t topic_unused;
         tile_pair_view(c, a, i, base, s_off[i], s_src[i], topic_unused);
     }
     if (threadIdx.x == 0) s_off[np] = 0x7FFFFFFF;                       // sentinel: no pair starts after the last one
     __syncthreads();
-    const uint32_t p0 = threadIdx.x * 4;
-    if (p0 >= len) return;
-    // owner of the lane's first position by binary search, of the next three by stepping (runs are long)
-    uint32_t i = np == 1 ? 0u : locate_pair([&](uint32_t m) { return s_off[m]; }, np, int32_t(p0));
-    const SubEntry* src[4];
+    // a lane owns kCompactGroups groups of four consecutive positions; all its subscriber loads are issued before
+    // its first store
+    const SubEntry* src[kCompactGroups][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t pos = p0 + j;
-        const bool live = pos < len;
-        while (live && s_off[i + 1] <= int32_t(pos)) ++i;
-        src[j] = subs + (uint64_t(s_src[i]) + (live ? uint32_t(int32_t(pos) - s_off[i]) : 0u));
+    for (int g = 0; g < kCompactGroups; ++g) {
+        const uint32_t p0 = (uint32_t(g) * kCompactThreads + threadIdx.x) * 4;
+        // owner of the group's first position by binary search, of the next three by stepping (runs are long)
+        uint32_t i = (np == 1 || p0 >= len) ? 0u : locate_pair([&](uint32_t m) { return s_off[m]; }, np, int32_t(p0));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t pos = p0 + j;
+            const bool live = pos < len;
+            while (live && s_off[i + 1] <= int32_t(pos)) ++i;
+            src[g][j] = subs + (uint64_t(s_src[i]) + (live ? uint32_t(int32_t(pos) - s_off[i]) : 0u));
+        }
     }
-    SubEntry se[4];
+    SubEntry se[kCompactGroups][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) se[j] = *src[j];
-    uint32_t w[4];
-    uint32_t q = 0;
+    for (int g = 0; g < kCompactGroups; ++g)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint32_t qf = se[j].qos_flags;
-        if (FMT == kFmtPacked) w[j] = se[j].sub_id | (qf << 30);
-        else { w[j] = se[j].sub_id; q |= ((qf & 3u) | (((qf >> 8) & 0x3Fu) << 2)) << (8 * j); }
-    }
-    uint32_t* o = out_ids + (base - hit_lo) + p0;
-    if (p0 + 4 <= len) {
-        typedef uint32_t v4 __attribute__((ext_vector_type(4)));
-        v4 v; v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
-        __builtin_nontemporal_store(v, reinterpret_cast<v4*>(o));
-        if (FMT == kFmtSoa) __builtin_nontemporal_store(q, reinterpret_cast<uint32_t*>(out_qos + (base - hit_lo) + p0));
-    } else {
-        for (uint32_t j = 0; p0 + j < len; ++j) {
-            o[j] = w[j];
-            if (FMT == kFmtSoa) out_qos[(base - hit_lo) + p0 + j] = uint8_t(q >> (8 * j));
+        for (int j = 0; j < 4; ++j) se[g][j] = *src[g][j];
+#pragma unroll
+    for (int g = 0; g < kCompactGroups; ++g) {
+        const uint32_t p0 = (uint32_t(g) * kCompactThreads + threadIdx.x) * 4;
+        if (p0 >= len) continue;
+        uint32_t w[4];
+        uint32_t q = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t qf = se[g][j].qos_flags;
+            if (FMT == kFmtPacked) w[j] = se[g][j].sub_id | (qf << 30);
+            else { w[j] = se[g][j].sub_id; q |= ((qf & 3u) | (((qf >> 8) & 0x3Fu) << 2)) << (8 * j); }
+        }
+        uint32_t* o = out_ids + (base - hit_lo) + p0;
+        if (p0 + 4 <= len) {
+            typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+            v4 v; v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
+            __builtin_nontemporal_store(v, reinterpret_cast<v4*>(o));
+            if (FMT == kFmtSoa) __builtin_nontemporal_store(q, reinterpret_cast<uint32_t*>(out_qos + (base - hit_lo) + p0));
+        } else {
+            for (uint32_t j = 0; p0 + j < len; ++j) {
+                o[j] = w[j];
+                if (FMT == kFmtSoa) out_qos[(base - hit_lo) + p0 + j] = uint8_t(q >> (8 * j));
+            }
         }
     }
 }
@@ -928,8 +947,8 @@ void launch_expand_compact(const TrieView& t, const ChunkArrays& c, uint64_t pai
     if (hit_hi <= hit_lo) return;
     const uint32_t ntiles = uint32_t((hit_hi - hit_lo + kTile - 1) / kTile);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (format == kFmtPacked) expand_compact_kernel<kFmtPacked><<<ntiles, kExpandThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out_ids, out_qos);
-    else expand_compact_kernel<kFmtSoa><<<ntiles, kExpandThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out_ids, out_qos);
+    if (format == kFmtPacked) expand_compact_kernel<kFmtPacked><<<ntiles, kCompactThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out_ids, out_qos);
+    else expand_compact_kernel<kFmtSoa><<<ntiles, kCompactThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out_ids, out_qos);
 }
 
 void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, uint32_t ntiles, Tuple* tuples, const uint64_t* cand_off,
