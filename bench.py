@@ -615,7 +615,10 @@ def attach_traffic(rec, phase, pmc, cal):
                "traffic_per_unit_B": {"fetch_raw": round(d["fetch_KiB"] * 1024 / max(1, unit), 3), "fetch_scale": fs,
                                       "write_raw": round(d["write_KiB"] * 1024 / max(1, unit), 3), "write_scale": ws,
                                       "unit": "hit" if cls == "expand" else "query"},
-               "avg_launch_us_under_pmc": d.get("avg_us_under_pmc")})
+               "avg_launch_us_under_pmc": d.get("avg_us_under_pmc"),
+               # the counters sit on the fabric side of L2: reads served by the 256 MiB Infinity Cache are counted too, so `frac`
+               # is an upper bound on HBM traffic when the read set fits it (config 5's 40 MB value array does); stores always reach HBM
+               "frac_stores_only": round(w_b / max(1, unit) * units_per_launch / (rf["avg_launch_ms"] / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if rf["avg_launch_ms"] > 0 else None})
     gc = cal.get("walk", {}).get("gather_ceiling_Ggathers_per_s")
     if cls == "walk" and gc and rf["avg_launch_ms"] > 0:
         # the walk's own yardstick: dependent random 32-byte gathers.  tools/membench.hip `calib` measures how many such

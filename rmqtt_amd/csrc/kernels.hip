@@ -740,26 +740,31 @@ __global__ __launch_bounds__(kCompactThreads) void expand_compact_kernel(const S
     if (threadIdx.x == 0) s_off[np] = 0x7FFFFFFF;                       // sentinel: no pair starts after the last one
     __syncthreads();
     // a lane owns kCompactGroups groups of four consecutive positions; all its subscriber loads are issued before
-    // its first store
-    const SubEntry* src[kCompactGroups][4];
+    // its first store.  Runs are long, so the four positions of a group almost always lie in ONE run: then the four
+    // 8-byte entries are 32 contiguous bytes and are fetched with two dwordx4 loads instead of four dwordx2.
+    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+    struct __attribute__((packed, aligned(8))) V4 { v4 v; };            // subs[] entries are 8-byte aligned, not 16
+    SubEntry se[kCompactGroups][4];
 #pragma unroll
     for (int g = 0; g < kCompactGroups; ++g) {
         const uint32_t p0 = (uint32_t(g) * kCompactThreads + threadIdx.x) * 4;
-        // owner of the group's first position by binary search, of the next three by stepping (runs are long)
+        // owner of the group's first position by binary search, of the next three by stepping
         uint32_t i = (np == 1 || p0 >= len) ? 0u : locate_pair([&](uint32_t m) { return s_off[m]; }, np, int32_t(p0));
+        if (p0 + 4 <= len && s_off[i + 1] > int32_t(p0 + 3)) {
+            const SubEntry* p = subs + (uint64_t(s_src[i]) + uint32_t(int32_t(p0) - s_off[i]));
+            const V4 x = *reinterpret_cast<const V4*>(p), y = *reinterpret_cast<const V4*>(p + 2);
+            se[g][0] = SubEntry{x.v.x, x.v.y}; se[g][1] = SubEntry{x.v.z, x.v.w};
+            se[g][2] = SubEntry{y.v.x, y.v.y}; se[g][3] = SubEntry{y.v.z, y.v.w};
+        } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t pos = p0 + j;
-            const bool live = pos < len;
-            while (live && s_off[i + 1] <= int32_t(pos)) ++i;
-            src[g][j] = subs + (uint64_t(s_src[i]) + (live ? uint32_t(int32_t(pos) - s_off[i]) : 0u));
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t pos = p0 + j;
+                const bool live = pos < len;
+                while (live && s_off[i + 1] <= int32_t(pos)) ++i;
+                se[g][j] = subs[uint64_t(s_src[i]) + (live ? uint32_t(int32_t(pos) - s_off[i]) : 0u)];
+            }
         }
     }
-    SubEntry se[kCompactGroups][4];
-#pragma unroll
-    for (int g = 0; g < kCompactGroups; ++g)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) se[g][j] = *src[g][j];
 #pragma unroll
     for (int g = 0; g < kCompactGroups; ++g) {
         const uint32_t p0 = (uint32_t(g) * kCompactThreads + threadIdx.x) * 4;
@@ -774,7 +779,6 @@ __global__ __launch_bounds__(kCompactThreads) void expand_compact_kernel(const S
         }
         uint32_t* o = out_ids + (base - hit_lo) + p0;
         if (p0 + 4 <= len) {
-            typedef uint32_t v4 __attribute__((ext_vector_type(4)));
             v4 v; v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
             __builtin_nontemporal_store(v, reinterpret_cast<v4*>(o));
             if (FMT == kFmtSoa) __builtin_nontemporal_store(q, reinterpret_cast<uint32_t*>(out_qos + (base - hit_lo) + p0));
