@@ -203,13 +203,19 @@ void DefaultRouter::prepare_shaped() {
     shaped_ready_ = relations_count_;
 }
 
-uint64_t DefaultRouter::matches_shaped(const Id& this_id, std::string_view topic_name, WalkStats* st, bool refcounted) const {
-    if (!refcounted) return matches_shaped_plain(this_id, topic_name, st);
-    struct Out { std::shared_ptr<const std::string> filter, client; SubscriptionOptions opts; };
+uint64_t DefaultRouter::matches_shaped(const Id& this_id, std::string_view topic_name, WalkStats* st, bool refcounted, ShapedScratch* scratch) const {
+    if (!refcounted) return matches_shaped_plain(this_id, topic_name, st, scratch);
+    using Out = ShapedScratch::OutRc;
     Topic topic;
     if (!parse_topic(topic_name, topic)) { if (st) st->invalid++; return 0; }            // router.rs:177
     if (st) st->levels += topic.size();
-    std::unordered_map<NodeId, std::vector<Out>> collector_map;                          // router.rs:176
+    // router.rs:176.  The reference builds a fresh map per call under jemalloc (rmqtt-bin/src/server.rs:27-28), whose
+    // thread caches hand the same blocks back without a syscall; under glibc a fresh 0.8 MB vector per publish means
+    // mmap/munmap per call and 256 threads queueing on the process's mmap lock.  The per-thread scratch keeps the
+    // vectors' capacity between calls (elements are still constructed and destroyed per call).
+    ShapedScratch local;
+    auto& collector_map = (scratch ? scratch : &local)->rc;
+    for (auto& kv : collector_map) kv.second.clear();
     uint64_t hits = 0;
     for (auto& item : topics_.matches(topic, st)) {                                      // router.rs:178
         // router.rs:179: `to_topic_filter()` builds a FRESH ByteString per matched filter per publish, so the
@@ -227,17 +233,20 @@ uint64_t DefaultRouter::matches_shaped(const Id& this_id, std::string_view topic
         }
     }
     if (st) st->hits += hits;
-    return hits;                                                                         // map dropped here: the clones are released
+    for (auto& kv : collector_map) kv.second.clear();                                    // the result is dropped here: the clones are released
+    return hits;
 }
 
 // The same pass with plain pointers instead of ref-counted clones: what the work costs WITHOUT the contended
 // atomic increments on hot ClientIds (an upper bound on what a reference build with interned ids could do).
-uint64_t DefaultRouter::matches_shaped_plain(const Id& this_id, std::string_view topic_name, WalkStats* st) const {
-    struct Out { const std::string* filter; const std::string* client; SubscriptionOptions opts; };
+uint64_t DefaultRouter::matches_shaped_plain(const Id& this_id, std::string_view topic_name, WalkStats* st, ShapedScratch* scratch) const {
+    using Out = ShapedScratch::OutPlain;
     Topic topic;
     if (!parse_topic(topic_name, topic)) { if (st) st->invalid++; return 0; }
     if (st) st->levels += topic.size();
-    std::unordered_map<NodeId, std::vector<Out>> collector_map;
+    ShapedScratch local;
+    auto& collector_map = (scratch ? scratch : &local)->plain;
+    for (auto& kv : collector_map) kv.second.clear();
     uint64_t hits = 0;
     for (auto& item : topics_.matches(topic, st)) {
         const std::string filter = join_levels(item.first);
@@ -706,11 +715,12 @@ double orc_router_matches_timed(void* r, const char* blob, const uint64_t* offs,
     for (int k = 0; k < threads; ++k) {
         th.emplace_back([&, k] {
             Id nobody; nobody.node_id = 0;
+            DefaultRouter::ShapedScratch scratch;
             for (;;) {
                 const uint64_t lo = next.fetch_add(16), hi = std::min<uint64_t>(n, lo + 16);
                 if (lo >= n) break;
                 for (uint64_t i = lo; i < hi; ++i)
-                    rt->matches_shaped(nobody, std::string_view(blob + offs[i], offs[i + 1] - offs[i]), &sts[k], refcounted != 0);
+                    rt->matches_shaped(nobody, std::string_view(blob + offs[i], offs[i + 1] - offs[i]), &sts[k], refcounted != 0, &scratch);
             }
         });
     }

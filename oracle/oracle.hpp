@@ -256,8 +256,14 @@ class DefaultRouter {   // router.rs:121-127
     // cpu_baseline only (oracle.cpp: orc_router_matches_timed): the reference's per-publish work without the
     // checker's canonicalisation; prepare_shaped() snapshots the relation maps with ref-counted strings.
     void prepare_shaped();
-    uint64_t matches_shaped(const Id& this_id, std::string_view topic_name, WalkStats* st, bool refcounted = true) const;
-    uint64_t matches_shaped_plain(const Id& this_id, std::string_view topic_name, WalkStats* st) const;
+    struct ShapedScratch {     // per-thread result storage of the timed pass (capacity kept between calls: see oracle.cpp)
+        struct OutRc { std::shared_ptr<const std::string> filter, client; SubscriptionOptions opts; };
+        struct OutPlain { const std::string* filter; const std::string* client; SubscriptionOptions opts; };
+        std::unordered_map<NodeId, std::vector<OutRc>> rc;
+        std::unordered_map<NodeId, std::vector<OutPlain>> plain;
+    };
+    uint64_t matches_shaped(const Id& this_id, std::string_view topic_name, WalkStats* st, bool refcounted = true, ShapedScratch* scratch = nullptr) const;
+    uint64_t matches_shaped_plain(const Id& this_id, std::string_view topic_name, WalkStats* st, ShapedScratch* scratch = nullptr) const;
 
    private:
     struct Rel { Id id; SubscriptionOptions opts; uint32_t rel_id; };
