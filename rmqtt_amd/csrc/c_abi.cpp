@@ -1126,10 +1126,10 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
             DevBuf& outbuf = b->alt_out ? b->out2 : b->out;
             const uint64_t ids_bytes = (nh * 4 + 255) & ~uint64_t(255);           // compact formats: sub ids, then the qos bytes
             outbuf.ensure(b->format == kFmtTuple ? nh * sizeof(Tuple) : ids_bytes + (b->format == kFmtSoa ? nh + 16 : 0));
-            b->tile_first.ensure(((nh + T - 1) / T) * 4);
+            b->tile_first.ensure(((nh + T - 1) / T) * sizeof(TileRec));
             ChunkArrays ca = make_chunk_arrays(b, n);
             size_t sp = b->span_begin(kSpanScan);
-            launch_tiles(ca, pair_lo, pair_hi, hit_lo, b->tile_first.as<uint32_t>(), b->stream);
+            launch_tiles(ca, pair_lo, pair_hi, hit_lo, b->tile_first.as<TileRec>(), b->stream);
             b->span_end(sp);
             // delivery stage: fused into the expansion; v5 hits additionally go through the per-client dedup
             DeliverArgs da{};
@@ -1158,10 +1158,10 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
             }
             sp = b->span_begin(kSpanExpand);
             if (b->format == kFmtTuple)
-                launch_expand(batch_view(b), ca, pair_lo, pair_hi, hit_lo, hit_hi, b->tile_first.as<uint32_t>(), outbuf.as<Tuple>(), b->stream,
+                launch_expand(batch_view(b), ca, pair_lo, pair_hi, hit_lo, hit_hi, b->tile_first.as<TileRec>(), outbuf.as<Tuple>(), b->stream,
                               (b->deliver && !b->retain) ? &da : nullptr);
             else
-                launch_expand_compact(batch_view(b), ca, pair_lo, pair_hi, hit_lo, hit_hi, b->tile_first.as<uint32_t>(), b->format,
+                launch_expand_compact(batch_view(b), ca, pair_lo, pair_hi, hit_lo, hit_hi, b->tile_first.as<TileRec>(), b->format,
                                       outbuf.as<uint32_t>(), outbuf.as<uint8_t>() + ids_bytes, b->stream);
             b->span_end(sp);
             // the chunk's accounting charged 20 B per hit (8 read + 12 written); the compact formats write 5 / 4

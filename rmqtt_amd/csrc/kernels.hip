@@ -564,10 +564,16 @@ __global__ __launch_bounds__(256) void compact_big_kernel(TrieView tv, ChunkArra
 }
 
 // --------------------------------------------------------------------------- tiles
-__global__ __launch_bounds__(256) void tiles_kernel(const uint64_t* pair_off, uint64_t pair_lo, uint64_t pair_hi,
-                                                    uint64_t hit_lo, uint32_t* tile_first) {
+__global__ __launch_bounds__(256) void tiles_kernel(ChunkArrays c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, TileRec* __restrict__ tile_first) {
     const uint64_t p = pair_lo + uint64_t(blockIdx.x) * 256 + threadIdx.x;
-    if (p < pair_hi) tiles_pair(pair_off, p, pair_lo, hit_lo, kTile, tile_first);
+    if (p >= pair_hi) return;
+    // pair p covers output positions [pair_off[p], pair_off[p+1]); it owns every tile whose first position falls inside
+    // (match_core.hpp tiles_pair), and leaves its own view at that position in the tile's record
+    const uint64_t s = c.pair_off[p] - hit_lo, e = c.pair_off[p + 1] - hit_lo;
+    const uint32_t src = c.pair_src[p], topic = c.pair_topic[p];
+    const uint32_t qr = c.pair_qr ? c.pair_qr[p] : 0u;
+    for (uint64_t k = (s + kTile - 1) / kTile; k * kTile < e; ++k)
+        tile_first[k] = TileRec{uint32_t(p - pair_lo), src + uint32_t(k * kTile - s), topic, qr};
 }
 
 // --------------------------------------------------------------------------- expand
@@ -577,7 +583,7 @@ __global__ __launch_bounds__(256) void tiles_kernel(const uint64_t* pair_off, ui
 template <bool kDeliver>
 __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* __restrict__ subs, ChunkArrays c,
                                                                 uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo,
-                                                                uint64_t hit_hi, const uint32_t* __restrict__ tile_first,
+                                                                uint64_t hit_hi, const TileRec* __restrict__ tile_first,
                                                                 uint32_t ntiles, Tuple* __restrict__ out, DeliverArgs da) {
     __shared__ int32_t s_off[kTile + 2];
     __shared__ uint32_t s_src[kTile + 2];
@@ -590,12 +596,17 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* 
     const uint32_t tile = blockIdx.x;
     const uint64_t base = hit_lo + uint64_t(tile) * kTile;
     const uint32_t len = (hit_hi - base) < uint64_t(kTile) ? uint32_t(hit_hi - base) : uint32_t(kTile);
-    const uint64_t a = pair_lo + tile_first[tile];
-    const uint64_t b = (tile + 1 < ntiles) ? pair_lo + tile_first[tile + 1] + 1 : pair_hi;
+    const TileRec rec = tile_first[tile];
+    const uint64_t a = pair_lo + rec.first;
+    const uint64_t b = (tile + 1 < ntiles) ? pair_lo + tile_first[tile + 1].first + 1 : pair_hi;
     const uint32_t np = uint32_t(b - a);
-    for (uint32_t i = threadIdx.x; i < np; i += kExpandThreads) {
-        tile_pair_view(c, a, i, base, s_off[i], s_src[i], s_topic[i]);
-        if (kDeliver) { s_qr[i] = c.pair_qr[a + i]; s_pc[i] = 0; }
+    if (np == 1) {                                   // the tile lies inside one run: its record is the whole pair view
+        if (threadIdx.x == 0) { s_off[0] = 0; s_src[0] = rec.src; s_topic[0] = rec.topic; if (kDeliver) { s_qr[0] = uint8_t(rec.qr); s_pc[0] = 0; } }
+    } else {
+        for (uint32_t i = threadIdx.x; i < np; i += kExpandThreads) {
+            tile_pair_view(c, a, i, base, s_off[i], s_src[i], s_topic[i]);
+            if (kDeliver) { s_qr[i] = c.pair_qr[a + i]; s_pc[i] = 0; }
+        }
     }
     __syncthreads();
     Tuple* o = out + (base - hit_lo);
@@ -722,7 +733,7 @@ static_assert(kCompactGroups >= 1 && kCompactGroups * kCompactThreads * 4 == kTi
 template <int FMT>
 __global__ __launch_bounds__(kCompactThreads) void expand_compact_kernel(const SubEntry* __restrict__ subs, ChunkArrays c,
                                                                          uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo,
-                                                                         uint64_t hit_hi, const uint32_t* __restrict__ tile_first,
+                                                                         uint64_t hit_hi, const TileRec* __restrict__ tile_first,
                                                                          uint32_t ntiles, uint32_t* __restrict__ out_ids,
                                                                          uint8_t* __restrict__ out_qos) {
     __shared__ int32_t s_off[kTile + 2];
@@ -730,9 +741,48 @@ __global__ __launch_bounds__(kCompactThreads) void expand_compact_kernel(const S
     const uint32_t tile = blockIdx.x;
     const uint64_t base = hit_lo + uint64_t(tile) * kTile;
     const uint32_t len = (hit_hi - base) < uint64_t(kTile) ? uint32_t(hit_hi - base) : uint32_t(kTile);
-    const uint64_t a = pair_lo + tile_first[tile];
-    const uint64_t b = (tile + 1 < ntiles) ? pair_lo + tile_first[tile + 1] + 1 : pair_hi;
+    const TileRec rec = tile_first[tile];
+    const uint64_t a = pair_lo + rec.first;
+    const uint64_t b = (tile + 1 < ntiles) ? pair_lo + tile_first[tile + 1].first + 1 : pair_hi;
     const uint32_t np = uint32_t(b - a);
+    if (np == 1) {
+        // the tile lies inside ONE run (the common case at high fan-out): no pair arrays, no LDS, no barrier — position pos
+        // of the tile is subs[rec.src + pos]
+        typedef uint32_t v4 __attribute__((ext_vector_type(4)));
+        struct __attribute__((packed, aligned(8))) V4 { v4 v; };
+        const SubEntry* run = subs + rec.src;
+        V4 x[kCompactGroups], y[kCompactGroups];
+#pragma unroll
+        for (int g = 0; g < kCompactGroups; ++g) {
+            const uint32_t p0 = (uint32_t(g) * kCompactThreads + threadIdx.x) * 4;
+            const uint32_t q0 = p0 + 4 <= len ? p0 : 0u;                  // (a partial last group re-reads the tile's head: discarded)
+            x[g] = *reinterpret_cast<const V4*>(run + q0); y[g] = *reinterpret_cast<const V4*>(run + q0 + 2);
+        }
+#pragma unroll
+        for (int g = 0; g < kCompactGroups; ++g) {
+            const uint32_t p0 = (uint32_t(g) * kCompactThreads + threadIdx.x) * 4;
+            if (p0 >= len) continue;
+            uint32_t* o = out_ids + (base - hit_lo) + p0;
+            if (p0 + 4 <= len) {
+                v4 v; uint32_t q;
+                if (FMT == kFmtPacked) { v.x = x[g].v.x | (x[g].v.y << 30); v.y = x[g].v.z | (x[g].v.w << 30); v.z = y[g].v.x | (y[g].v.y << 30); v.w = y[g].v.z | (y[g].v.w << 30); q = 0; }
+                else {
+                    v.x = x[g].v.x; v.y = x[g].v.z; v.z = y[g].v.x; v.w = y[g].v.z;
+                    auto qb = [](uint32_t qf) { return (qf & 3u) | (((qf >> 8) & 0x3Fu) << 2); };
+                    q = qb(x[g].v.y) | (qb(x[g].v.w) << 8) | (qb(y[g].v.y) << 16) | (qb(y[g].v.w) << 24);
+                }
+                __builtin_nontemporal_store(v, reinterpret_cast<v4*>(o));
+                if (FMT == kFmtSoa) __builtin_nontemporal_store(q, reinterpret_cast<uint32_t*>(out_qos + (base - hit_lo) + p0));
+            } else {
+                for (uint32_t j = 0; p0 + j < len; ++j) {
+                    const SubEntry se1 = run[p0 + j];
+                    o[j] = FMT == kFmtPacked ? (se1.sub_id | (se1.qos_flags << 30)) : se1.sub_id;
+                    if (FMT == kFmtSoa) out_qos[(base - hit_lo) + p0 + j] = uint8_t((se1.qos_flags & 3u) | (((se1.qos_flags >> 8) & 0x3Fu) << 2));
+                }
+            }
+        }
+        return;
+    }
     for (uint32_t i = threadIdx.x; i < np; i += kCompactThreads) {
         uint32_t topic_unused;
         tile_pair_view(c, a, i, base, s_off[i], s_src[i], topic_unused);
@@ -931,14 +981,14 @@ void launch_compact(const TrieView& t, const ChunkArrays& c, uint32_t topic_base
     compact_big_kernel<<<512, 256, 0, s>>>(t, c, topic_base);
 }
 
-void launch_tiles(const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint32_t* tile_first, void* stream) {
+void launch_tiles(const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, TileRec* tile_first, void* stream) {
     if (pair_hi <= pair_lo) return;
     const uint64_t np = pair_hi - pair_lo;
-    tiles_kernel<<<uint32_t((np + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(c.pair_off, pair_lo, pair_hi, hit_lo, tile_first);
+    tiles_kernel<<<uint32_t((np + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(c, pair_lo, pair_hi, hit_lo, tile_first);
 }
 
 void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint64_t hit_hi,
-                   const uint32_t* tile_first, Tuple* out, void* stream, const DeliverArgs* deliver) {
+                   const TileRec* tile_first, Tuple* out, void* stream, const DeliverArgs* deliver) {
     if (hit_hi <= hit_lo) return;
     const uint32_t ntiles = uint32_t((hit_hi - hit_lo + kTile - 1) / kTile);
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -947,7 +997,7 @@ void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, ui
 }
 
 void launch_expand_compact(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint64_t hit_hi,
-                           const uint32_t* tile_first, int format, uint32_t* out_ids, uint8_t* out_qos, void* stream) {
+                           const TileRec* tile_first, int format, uint32_t* out_ids, uint8_t* out_qos, void* stream) {
     if (hit_hi <= hit_lo) return;
     const uint32_t ntiles = uint32_t((hit_hi - hit_lo + kTile - 1) / kTile);
     hipStream_t s = static_cast<hipStream_t>(stream);

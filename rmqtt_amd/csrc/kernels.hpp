@@ -222,13 +222,17 @@ void launch_pairs_dense(const ChunkArrays& c, const uint64_t* off, uint32_t* out
 void launch_count(const TrieView& t, const ChunkArrays& c, void* stream);
 void launch_scan(const ChunkArrays& c, uint64_t* block_tmp, void* stream);
 void launch_compact(const TrieView& t, const ChunkArrays& c, uint32_t topic_base, void* stream);
-void launch_tiles(const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint32_t* tile_first, void* stream);
+// Per output tile: the first pair that intersects it, plus that pair's view at the tile's first position (where in
+// subs[] the tile starts reading, which topic it belongs to) — so a tile that lies inside ONE run, the common case at
+// high fan-out, starts its subscriber loads after a single 16-byte read instead of tile_first -> pair arrays -> LDS.
+struct alignas(16) TileRec { uint32_t first, src, topic, qr; };
+void launch_tiles(const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, TileRec* tile_first, void* stream);
 void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint64_t hit_hi,
-                   const uint32_t* tile_first, Tuple* out, void* stream, const DeliverArgs* deliver = nullptr);
+                   const TileRec* tile_first, Tuple* out, void* stream, const DeliverArgs* deliver = nullptr);
 // compact result formats (rgr_batch_set_format): sub ids (+ a qos byte array) without the topic column
 constexpr int kFmtTuple = 0, kFmtSoa = 1, kFmtPacked = 2;     // == RGR_FORMAT_*
 void launch_expand_compact(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint64_t hit_hi,
-                           const uint32_t* tile_first, int format, uint32_t* out_ids, uint8_t* out_qos, void* stream);
+                           const TileRec* tile_first, int format, uint32_t* out_ids, uint8_t* out_qos, void* stream);
 // v5 per-client dedup over a window's candidates: first position per (topic, client) wins, every
 // other candidate gets kHitV5Dup.  `table` (pre-filled with 0xFF bytes) is partitioned by topic:
 // topic t of the window owns slots [2*cand_off[t], 2*cand_off[t+1]) — twice its candidate count
