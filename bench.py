@@ -336,7 +336,8 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
             f"{st0['table_bytes_device'] / 2**30:.2f} GiB in HBM, built in {build_s:.1f}s (rejected {rej})", rank)
     t = time.time()
     batch = r.retain_batch(tb_r, to_r) if retain else r.batch(tb_r, to_r)
-    log(f"config {cfg}: batch: {my_topics} topics tokenised + uploaded in {time.time() - t:.1f}s", rank)
+    batch_create_s = time.time() - t
+    log(f"config {cfg}: batch: {my_topics} topics tokenised + uploaded in {batch_create_s:.1f}s", rank)
     if deliver >= 0:
         pa = np.zeros(my_topics, dtype=capi.PUBLISH_ATTR_DTYPE)
         prng = np.random.default_rng(12)
@@ -486,6 +487,11 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
         "table": {"filters": int(st0["n_filters"]), "subs": int(st0["n_subs"]), "trie_nodes": int(st0["n_nodes"]),
                   "hbm_bytes": int(st0["table_bytes_device"]), "host_build_s": round(build_s, 1)},
         "roofline": roofline,
+        # SURVEY 8(d) "end-to-end incl. H2D": the topics' host blob -> HBM + device tokeniser (rgr_batch_create, once per batch)
+        # and one pass; the D2H side is pcie_inclusive_matches_per_s below.  `value` itself starts with the tokens in HBM.
+        "h2d_inclusive": {"batch_create_ms": round(batch_create_s * 1e3, 2),
+                          "matches_per_s": round(my_topics / (batch_create_s + elapsed / K), 1),
+                          "what": "host topic strings -> rgr_batch_create (H2D + device tokeniser) -> one pass, tuples left in HBM"},
     }
     try:
         if world > 1 and rank_hits and sum(rank_hits) > 0:

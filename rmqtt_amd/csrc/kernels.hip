@@ -600,15 +600,21 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* 
     const uint64_t a = pair_lo + rec.first;
     const uint64_t b = (tile + 1 < ntiles) ? pair_lo + tile_first[tile + 1].first + 1 : pair_hi;
     const uint32_t np = uint32_t(b - a);
-    if (np == 1) {                                   // the tile lies inside one run: its record is the whole pair view
-        if (threadIdx.x == 0) { s_off[0] = 0; s_src[0] = rec.src; s_topic[0] = rec.topic; if (kDeliver) { s_qr[0] = uint8_t(rec.qr); s_pc[0] = 0; } }
+    // a tile that lies inside ONE run (the common case at high fan-out) needs nothing but its record: the plain kernel
+    // then skips the pair arrays, the LDS staging and the barrier; the delivery variant keeps its LDS bookkeeping
+    const bool one = np == 1;
+    if (one) {
+        if (kDeliver) {
+            if (threadIdx.x == 0) { s_off[0] = 0; s_src[0] = rec.src; s_topic[0] = rec.topic; s_qr[0] = uint8_t(rec.qr); s_pc[0] = 0; }
+            __syncthreads();
+        }
     } else {
         for (uint32_t i = threadIdx.x; i < np; i += kExpandThreads) {
             tile_pair_view(c, a, i, base, s_off[i], s_src[i], s_topic[i]);
             if (kDeliver) { s_qr[i] = c.pair_qr[a + i]; s_pc[i] = 0; }
         }
+        __syncthreads();
     }
-    __syncthreads();
     Tuple* o = out + (base - hit_lo);
     // three phases so that the 8 subscriber loads of a lane are all in flight before the first
     // store: (1) owner pair of each strided position (LDS binary search; free when one run
@@ -621,11 +627,11 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* 
     for (int j = 0; j < kExpandPerThread; ++j) {
         const uint32_t pos = uint32_t(j) * kExpandThreads + threadIdx.x;
         const bool live = pos < len;
-        const uint32_t i = (np == 1 || !live) ? 0u : locate_pair([&](uint32_t m) { return s_off[m]; }, np, int32_t(pos));
-        topic[j] = s_topic[i];
+        const uint32_t i = (one || !live) ? 0u : locate_pair([&](uint32_t m) { return s_off[m]; }, np, int32_t(pos));
+        topic[j] = one ? rec.topic : s_topic[i];
         pidx[j] = i;
         // dead tail positions read (and discard) the tile's first entry: keeps the loads branch-free
-        src[j] = subs + (uint64_t(s_src[i]) + (live ? uint32_t(int32_t(pos) - s_off[i]) : 0u));
+        src[j] = subs + (uint64_t(one ? rec.src : s_src[i]) + (live ? uint32_t(int32_t(pos) - (one ? 0 : s_off[i])) : 0u));
     }
     SubEntry se[kExpandPerThread];
 #pragma unroll
