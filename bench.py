@@ -509,7 +509,8 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
     # tuple headline, never instead of it: same hits, same order, topic implied by the CSR offsets
     if world == 1 and deliver < 0 and not args.no_formats:
         rec["compact_formats"] = []
-        for name, fmt, bph in (("soa: sub_id u32[] + qos u8[]", capi.RGR_FORMAT_SOA, 5), ("packed: sub_id | qos << 30 u32[]", capi.RGR_FORMAT_PACKED, 4)):
+        for name, fmt, bph in (("soa: sub_id u32[] + qos u8[]", capi.RGR_FORMAT_SOA, 5), ("packed: sub_id | qos << 30 u32[]", capi.RGR_FORMAT_PACKED, 4),
+                               ("runs: (topic, subscriber-run) descriptors, hits read in place from the epoch's subs[]", capi.RGR_FORMAT_RUNS, 0)):
             try:
                 batch.set_format(fmt)
                 batch.run()

@@ -187,6 +187,15 @@ typedef struct rgr_window {
     /* compact result formats (rgr_batch_set_format), NULL in RGR_FORMAT_TUPLE */
     const uint32_t* d_sub_ids;        /* [n_hits] sub_id (RGR_FORMAT_SOA) or sub_id | qos << 30 (RGR_FORMAT_PACKED) */
     const uint8_t* d_qos;             /* [n_hits] RGR_FORMAT_SOA only: bits 0-1 qos, bits 2-7 = RGR_SUB_* flag bits 0-5 */
+    /* RGR_FORMAT_RUNS: the window's hit list as runs, nothing materialised per hit.  Run r covers positions
+     * [d_run_off[r] - offsets_bias, d_run_off[r + 1] - offsets_bias) of the window; its k-th hit is the subscriber entry
+     * d_subs[d_run_src[r] + k] = { sub_id, qos | flags << 8 | node_idx << 16 } of topic d_run_topic[r].  Runs are in
+     * hit order (topic-major, TopicTree::matches filter order); d_subs stays valid for the pass (the epoch is pinned). */
+    uint64_t n_runs;
+    const uint32_t* d_run_src;        /* [n_runs]                                        */
+    const uint32_t* d_run_topic;      /* [n_runs] topic index (or rgr_batch_set_topic_ids' id) */
+    const uint64_t* d_run_off;        /* [n_runs + 1]                                    */
+    const uint64_t* d_subs;           /* the epoch's subscriber entries, 8 bytes each    */
 } rgr_window;
 
 /* Result format of a device-resident batch.  The 12-byte tuple is BASELINE.json's (topic_idx, subscriber_id,
@@ -196,8 +205,11 @@ typedef struct rgr_window {
 enum {
     RGR_FORMAT_TUPLE = 0,             /* rgr_tuple[n_hits], 12 B/hit (default)                                   */
     RGR_FORMAT_SOA = 1,               /* d_sub_ids u32[n_hits] + d_qos u8[n_hits], 5 B/hit                        */
-    RGR_FORMAT_PACKED = 2             /* d_sub_ids u32[n_hits] = sub_id | qos << 30, 4 B/hit; needs sub ids < 2^30
+    RGR_FORMAT_PACKED = 2,            /* d_sub_ids u32[n_hits] = sub_id | qos << 30, 4 B/hit; needs sub ids < 2^30
                                          (rgr_batch_begin fails with RGR_ECAPACITY otherwise)                  */
+    RGR_FORMAT_RUNS = 3               /* run descriptors only (d_run_*): a hit list is the concatenation of subscriber
+                                         runs that already sit in HBM, so a device-side consumer (a fan-out kernel) can
+                                         read them in place — 16 B per (topic, matched filter) instead of bytes per hit */
 };
 
 typedef struct rgr_stats {

@@ -1051,10 +1051,10 @@ int32_t rgr_batch_set_topic_ids(rgr_batch* b, const uint32_t* ids) {
 }
 
 int32_t rgr_batch_set_format(rgr_batch* b, uint32_t format) {
-    if (!b || format > RGR_FORMAT_PACKED) return fail(RGR_EINVAL, "rgr_batch_set_format: bad argument");
+    if (!b || format > RGR_FORMAT_RUNS) return fail(RGR_EINVAL, "rgr_batch_set_format: bad argument");
     if (b->in_pass) return fail(RGR_ESTATE, "rgr_batch_set_format: inside a pass");
     if (format != RGR_FORMAT_TUPLE && b->deliver) return fail(RGR_ESTATE, "rgr_batch_set_format: the delivery stage needs RGR_FORMAT_TUPLE");
-    static_assert(RGR_FORMAT_TUPLE == kFmtTuple && RGR_FORMAT_SOA == kFmtSoa && RGR_FORMAT_PACKED == kFmtPacked, "format constants");
+    static_assert(RGR_FORMAT_TUPLE == kFmtTuple && RGR_FORMAT_SOA == kFmtSoa && RGR_FORMAT_PACKED == kFmtPacked && RGR_FORMAT_RUNS == kFmtRuns, "format constants");
     b->format = int(format);
     return RGR_OK;
 }
@@ -1121,7 +1121,17 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
         }
         const uint64_t hit_lo = ho[lc], hit_hi = ho[le], pair_lo = pb[lc], pair_hi = pb[le];
         const uint64_t nh = hit_hi - hit_lo;
-        if (nh) {
+        w->n_runs = 0; w->d_run_src = nullptr; w->d_run_topic = nullptr; w->d_run_off = nullptr; w->d_subs = nullptr;
+        if (b->format == kFmtRuns) {
+            // nothing to expand: the dense pair arrays of the chunk ARE the run list (built by compact_kernel)
+            w->n_runs = pair_hi - pair_lo;
+            w->d_run_src = b->pair_src.as<uint32_t>() + pair_lo;
+            w->d_run_topic = b->pair_topic.as<uint32_t>() + pair_lo;
+            w->d_run_off = b->pair_off.as<uint64_t>() + pair_lo;
+            w->d_subs = reinterpret_cast<const uint64_t*>(batch_view(b).subs);
+            b->local.alg_bytes_expand -= nh * 20;            // (the chunk's accounting charged 20 B per hit)
+            b->local.alg_bytes_expand += (pair_hi - pair_lo) * 16;
+        } else if (nh) {
             const uint32_t T = expand_tile_hits();
             DevBuf& outbuf = b->alt_out ? b->out2 : b->out;
             const uint64_t ids_bytes = (nh * 4 + 255) & ~uint64_t(255);           // compact formats: sub ids, then the qos bytes
@@ -1197,7 +1207,7 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
             void* op = b->alt_out ? b->out2.p : b->out.p;
             const uint64_t ids_bytes = (nh * 4 + 255) & ~uint64_t(255);
             w->d_tuples = b->format == kFmtTuple ? reinterpret_cast<const rgr_tuple*>(op) : nullptr;
-            w->d_sub_ids = b->format == kFmtTuple || !nh ? nullptr : static_cast<const uint32_t*>(op);
+            w->d_sub_ids = (b->format == kFmtSoa || b->format == kFmtPacked) && nh ? static_cast<const uint32_t*>(op) : nullptr;
             w->d_qos = b->format == kFmtSoa && nh ? static_cast<const uint8_t*>(op) + ids_bytes : nullptr;
         }
         w->d_hit_offsets = b->hit_off.as<uint64_t>() + lc;

@@ -146,3 +146,46 @@ def test_match_filters_dense_and_pinned_match_batch():
         assert np.array_equal(got["hit_offsets"], full["hit_offsets"][:n + 1])
         assert np.array_equal(got["tuples"]["sub_id"], full["tuples"]["sub_id"][:ho[n]])
     r.close()
+
+
+def test_runs_format_is_the_hit_list_in_place():
+    """RGR_FORMAT_RUNS: concatenating subs[run.src .. run.src + len) over the window's runs reproduces the tuples."""
+    cfg = 3
+    c = wl.CONFIGS[cfg]
+    blob, offs, client, qos = wl.gen_subs(50_000, wl.SUB_SEED + cfg, c["p_plus"], c["p_hash"], c["p_sys"])
+    tb, to = wl.gen_topics(4_000, wl.PUB_SEED + cfg, 0.01, c["p_blank"])
+    r = capi.Router(device=0, window_hits=30_000, chunk_topics=1024)
+    assert r.subscribe_bulk(blob, offs, None, qos) == 0
+    r.commit()
+    batch = r.batch(tb, to)
+    batch.set_topic_ids(np.arange(len(to) - 1, dtype=np.uint32) + 1000)
+    ref = windows(batch, capi.RGR_FORMAT_TUPLE)
+    batch.set_format(capi.RGR_FORMAT_RUNS)
+    batch.begin()
+    k = 0
+    total = 0
+    while True:
+        w = batch.next_window()
+        if w is None:
+            break
+        offs_w = np.zeros(w.topic_end - w.topic_begin + 1, dtype=np.uint64)
+        capi._check(capi.lib().rgr_window_to_host(batch._b, C.byref(w), None, offs_w.ctypes.data))
+        assert not w.d_tuples and not w.d_sub_ids
+        t = ref[k][3]; k += 1
+        assert int(w.n_hits) == len(t)
+        nr = int(w.n_runs)
+        if not nr:
+            assert len(t) == 0
+            continue
+        src = d2h(w.d_run_src, nr * 4).view(np.uint32)
+        tpc = d2h(w.d_run_topic, nr * 4).view(np.uint32)
+        off = d2h(w.d_run_off, (nr + 1) * 8).view(np.uint64).astype(np.int64) - int(w.offsets_bias)
+        assert off[0] == 0 and off[-1] == len(t) and (np.diff(off) > 0).all()
+        lo, hi = int(src.min()), int((src + np.diff(off)).max())
+        subs = d2h(int(w.d_subs) + lo * 8, (hi - lo) * 8).view(np.dtype([("sub_id", np.uint32), ("qf", np.uint32)]))
+        idx = np.concatenate([np.arange(s - lo, s - lo + n) for s, n in zip(src.astype(np.int64), np.diff(off))])
+        assert np.array_equal(subs["sub_id"][idx], t["sub_id"]) and np.array_equal(subs["qf"][idx], t["qos_flags"])
+        assert np.array_equal(np.repeat(tpc, np.diff(off)), t["topic_idx"]) and tpc.min() >= 1000
+        total += len(t)
+    assert k == len(ref) and total > 50_000
+    batch.close(); r.close()
