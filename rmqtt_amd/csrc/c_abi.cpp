@@ -141,6 +141,19 @@ struct rgr_handle {
     }
 };
 
+// Everything one chunk of topics needs between its walk and the expansion of its last window.
+struct ChunkSlot {
+    DevBuf slots, pair_cnt, hit_cnt, pair_live, hit_off, pair_base, ovf_list, ovf_base, scalars, arena;
+    DevBuf pair_src, pair_topic, pair_off, pair_qr, r_big, scan_tmp;
+    PinnedBuf h_hit_off, h_pair_base, h_scalars;
+    uint64_t arena_cap = 0;
+    uint32_t begin = 0, n = 0;
+    bool ready = false;          // walked, counted, scanned, compacted; host arrays valid
+    bool inflight = false;       // prepared asynchronously on prep_stream: `done` tells when
+    hipEvent_t done = nullptr;
+    ~ChunkSlot() { if (done) (void)hipEventDestroy(done); }
+};
+
 struct rgr_batch {
     rgr_handle* h = nullptr;
     uint32_t n = 0;
@@ -157,9 +170,13 @@ struct rgr_batch {
     uint64_t dict_tokens = ~0ull;         // stamp of the dictionary the batch was tokenised against
     bool host_tok = false;                // tokenised by the host threads (rgr_config.host_tokenize; never for two-tier retain batches)
     hipStream_t stream = nullptr;
-    // chunk work buffers
-    DevBuf slots, pair_cnt, hit_cnt, pair_live, hit_off, pair_base, ovf_list, ovf_base, scalars, arena;
-    DevBuf pair_src, pair_topic, pair_off, tile_first, out, scan_tmp;
+    // chunk work buffers: two slots, so that the next chunk's walk / count / scan / compact can run on `prep_stream`
+    // while the current chunk's windows are being expanded
+    ChunkSlot cs[2];
+    ChunkSlot* c = &cs[0];
+    hipStream_t prep_stream = nullptr;
+    hipEvent_t ev_windows_done = nullptr;   // recorded on `stream` after the last window launch of a chunk
+    DevBuf tile_first, out, scan_tmp;
     DevBuf out2;                         // second window buffer (rgr_batch_run_to_host double-buffers)
     PinnedBuf h_ring[2];                 // pinned staging for streamed windows
     bool alt_out = false;                // next_window expands into out2 instead of out
@@ -176,19 +193,15 @@ struct rgr_batch {
     int format = kFmtTuple;              // rgr_batch_set_format
     bool has_topic_ids = false;          // rgr_batch_set_topic_ids
     DevBuf d_topic_ids;
-    DevBuf d_pub, pair_qr, cand, cand_count, dedup_tab, topic_cand, cand_off, dedup_tmp;
+    DevBuf d_pub, cand, cand_count, dedup_tab, topic_cand, cand_off, dedup_tmp;
     PinnedBuf h_cand_count;
-    DevBuf rf_filter[2], rf_node[2], r_cnt, r_payload, r_ecnt, r_e0, r_e1, r_out_off, r_epos, r_big, r_end, r_depth;   // retain frontier rounds
-    PinnedBuf h_hit_off, h_pair_base, h_scalars;
-    uint64_t arena_cap = 0;
+    DevBuf rf_filter[2], rf_node[2], r_cnt, r_payload, r_ecnt, r_e0, r_e1, r_out_off, r_epos, r_end, r_depth;   // retain frontier rounds
     // pass state
     bool retain = false;             // batch of SUBSCRIBE filters against the retained-topic trie
     uint32_t tier = 0;               // two-tier mode: 0 = base epoch, 1 = delta epoch
     std::shared_ptr<Epoch> epoch;
     std::shared_ptr<RetainEpoch> repoch;
     bool in_pass = false;
-    uint32_t chunk_begin = 0, chunk_n = 0;
-    bool chunk_ready = false;
     uint32_t cursor = 0;
     uint64_t hits_before = 0;        // hits emitted by earlier windows of this pass
     // timing
@@ -203,13 +216,14 @@ struct rgr_batch {
         RGR_HIP(hipEventCreate(&e));
         return e;
     }
-    size_t span_begin(int kind) {
+    size_t span_begin(int kind, hipStream_t on = nullptr) {
         Span s{get_event(), get_event(), kind};
-        RGR_HIP(hipEventRecord(s.a, stream));
+        RGR_HIP(hipEventRecord(s.a, on ? on : stream));
         spans.push_back(s);
         return spans.size() - 1;
     }
-    void span_end(size_t i) { RGR_HIP(hipEventRecord(spans[i].b, stream)); }
+    void span_end(size_t i, hipStream_t on = nullptr) { RGR_HIP(hipEventRecord(spans[i].b, on ? on : stream)); }
+    ChunkSlot* other_slot() { return c == &cs[0] ? &cs[1] : &cs[0]; }
     void resolve_spans() {   // stream must be synchronised
         for (auto& s : spans) {
             float ms = 0;
@@ -227,6 +241,8 @@ struct rgr_batch {
         for (auto e : event_pool) (void)hipEventDestroy(e);
         for (int k = 0; k < 2; ++k) { if (ev_expanded[k]) (void)hipEventDestroy(ev_expanded[k]); if (ev_copied[k]) (void)hipEventDestroy(ev_copied[k]); }
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
+        if (prep_stream) { (void)hipStreamSynchronize(prep_stream); (void)hipStreamDestroy(prep_stream); }
+        if (ev_windows_done) (void)hipEventDestroy(ev_windows_done);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -358,76 +374,81 @@ void tokenize_batch_device(rgr_batch* b, const DictImage& dict) {
 
 WalkArgs make_walk_args(rgr_batch* b, uint32_t n) {
     WalkArgs a{};
-    Scalars* sc = b->scalars.as<Scalars>();
+    Scalars* sc = b->c->scalars.as<Scalars>();
     a.tokens = b->d_tokens.as<uint32_t>();
     a.tok_off = b->d_tok_off.as<uint64_t>();
     a.tflags = b->d_tflags.as<uint8_t>();
-    a.topic_base = b->chunk_begin;
+    a.topic_base = b->c->begin;
     a.n = n;
     a.slot_cap = b->retain ? 0 : b->h->cfg.slot_cap;
-    a.slots = b->slots.as<uint32_t>();
-    a.pair_cnt = b->pair_cnt.as<uint32_t>();
+    a.slots = b->c->slots.as<uint32_t>();
+    a.pair_cnt = b->c->pair_cnt.as<uint32_t>();
     a.path_scratch = b->d_path.as<uint32_t>();
     a.visited = b->h->cfg.collect_walk_stats ? &sc->visited : nullptr;
-    a.ovf_list = b->ovf_list.as<uint32_t>();
+    a.ovf_list = b->c->ovf_list.as<uint32_t>();
     a.ovf_count = &sc->ovf_count;
-    a.ovf_base = b->ovf_base.as<uint64_t>();
+    a.ovf_base = b->c->ovf_base.as<uint64_t>();
     a.ovf_cursor = &sc->ovf_cursor;
-    a.ovf_arena = b->arena.as<uint32_t>();
-    a.ovf_arena_cap = b->arena_cap;
+    a.ovf_arena = b->c->arena.as<uint32_t>();
+    a.ovf_arena_cap = b->c->arena_cap;
     return a;
 }
 
 ChunkArrays make_chunk_arrays(rgr_batch* b, uint32_t n) {
     ChunkArrays c{};
-    Scalars* sc = b->scalars.as<Scalars>();
+    Scalars* sc = b->c->scalars.as<Scalars>();
     c.n = n;
     c.slot_cap = b->retain ? 0 : b->h->cfg.slot_cap;   // retain descriptor lists always live in the arena
-    c.slots = b->slots.as<uint32_t>();
-    c.pair_cnt = b->pair_cnt.as<uint32_t>();
-    c.hit_cnt = b->hit_cnt.as<uint32_t>();
-    c.pair_live = b->pair_live.as<uint32_t>();
-    c.hit_off = b->hit_off.as<uint64_t>();
-    c.pair_base = b->pair_base.as<uint64_t>();
-    c.ovf_base = b->ovf_base.as<uint64_t>();
-    c.ovf_arena = b->arena.as<uint32_t>();
-    c.ovf_arena_cap = b->arena_cap;
+    c.slots = b->c->slots.as<uint32_t>();
+    c.pair_cnt = b->c->pair_cnt.as<uint32_t>();
+    c.hit_cnt = b->c->hit_cnt.as<uint32_t>();
+    c.pair_live = b->c->pair_live.as<uint32_t>();
+    c.hit_off = b->c->hit_off.as<uint64_t>();
+    c.pair_base = b->c->pair_base.as<uint64_t>();
+    c.ovf_base = b->c->ovf_base.as<uint64_t>();
+    c.ovf_arena = b->c->arena.as<uint32_t>();
+    c.ovf_arena_cap = b->c->arena_cap;
     c.error_flag = &sc->error;
-    c.big_list = b->r_big.as<uint32_t>();
+    c.big_list = b->c->r_big.as<uint32_t>();
     c.big_count = &sc->big_count;
-    c.pair_src = b->pair_src.as<uint32_t>();
-    c.pair_topic = b->pair_topic.as<uint32_t>();
-    c.pair_off = b->pair_off.as<uint64_t>();
-    if (b->deliver && !b->retain) { c.pub = b->d_pub.as<PublishAttr>(); c.pair_qr = b->pair_qr.as<uint8_t>(); }
+    c.pair_src = b->c->pair_src.as<uint32_t>();
+    c.pair_topic = b->c->pair_topic.as<uint32_t>();
+    c.pair_off = b->c->pair_off.as<uint64_t>();
+    if (b->deliver && !b->retain) { c.pub = b->d_pub.as<PublishAttr>(); c.pair_qr = b->c->pair_qr.as<uint8_t>(); }
     else if (b->has_topic_ids) c.topic_ids = b->d_topic_ids.as<uint32_t>();
     return c;
 }
 
 void ensure_chunk_buffers(rgr_batch* b, uint32_t n) {
     const uint32_t C = b->retain ? 0 : b->h->cfg.slot_cap;
-    b->slots.ensure(std::max<size_t>(16, size_t(C) * n * 4));
-    b->pair_cnt.ensure(size_t(n) * 4);
-    b->hit_cnt.ensure(size_t(n) * 4);
-    b->pair_live.ensure(size_t(n) * 4);
-    b->hit_off.ensure((size_t(n) + 1) * 8);
-    b->pair_base.ensure((size_t(n) + 1) * 8);
-    b->ovf_list.ensure(size_t(n) * 4);
-    b->ovf_base.ensure(size_t(n) * 8);
-    b->scalars.ensure(sizeof(Scalars));
-    b->r_big.ensure(size_t(n) * 4);
-    if (b->arena_cap == 0) { b->arena_cap = 1u << 20; b->arena.ensure(b->arena_cap * 4); }
+    b->c->slots.ensure(std::max<size_t>(16, size_t(C) * n * 4));
+    b->c->pair_cnt.ensure(size_t(n) * 4);
+    b->c->hit_cnt.ensure(size_t(n) * 4);
+    b->c->pair_live.ensure(size_t(n) * 4);
+    b->c->hit_off.ensure((size_t(n) + 1) * 8);
+    b->c->pair_base.ensure((size_t(n) + 1) * 8);
+    b->c->ovf_list.ensure(size_t(n) * 4);
+    b->c->ovf_base.ensure(size_t(n) * 8);
+    b->c->scalars.ensure(sizeof(Scalars));
+    b->c->r_big.ensure(size_t(n) * 4);
+    if (b->c->arena_cap == 0) {
+        const char* e = std::getenv("RGR_ARENA_INIT");        // tests shrink it to exercise the grow-and-redo paths
+        b->c->arena_cap = e && std::atoll(e) > 0 ? uint64_t(std::atoll(e)) : (1u << 20);
+        b->c->arena.ensure(b->c->arena_cap * 4);
+    }
     const uint32_t nb = (n + scan_block_topics() - 1) / scan_block_topics();
     b->scan_tmp.ensure((size_t(nb) + 1) * 16);
-    b->h_hit_off.ensure((size_t(n) + 1) * 8);
-    b->h_pair_base.ensure((size_t(n) + 1) * 8);
-    b->h_scalars.ensure(sizeof(Scalars));
+    b->c->scan_tmp.ensure((size_t(nb) + 1) * 16);
+    b->c->h_hit_off.ensure((size_t(n) + 1) * 8);
+    b->c->h_pair_base.ensure((size_t(n) + 1) * 8);
+    b->c->h_scalars.ensure(sizeof(Scalars));
 }
 
 // RetainTree::matches for the chunk's filters: level-synchronous frontier rounds (kernels.hip).
 // Fills the arena with every filter's run descriptors (in trie preorder), ovf_base / pair_cnt.
 void retain_rounds(rgr_batch* b, uint32_t begin, uint32_t n) {
     const RetainView& rv = b->repoch->view;
-    Scalars* sc = b->scalars.as<Scalars>();
+    Scalars* sc = b->c->scalars.as<Scalars>();
     b->r_end.ensure(size_t(n) * 8);
     b->r_depth.ensure(std::max<size_t>(1, n) * 4);
     RGR_HIP(hipMemsetAsync(b->r_depth.p, 0, size_t(n) * 4, b->stream));
@@ -436,7 +457,7 @@ void retain_rounds(rgr_batch* b, uint32_t begin, uint32_t n) {
     for (uint32_t d = 0; m > 0; ++d) {
         if (m > (1ull << 31)) throw std::runtime_error("retain frontier exceeds 2^31 items");
         const uint32_t mm = uint32_t(m);
-        for (DevBuf* p : {&b->r_cnt, &b->r_payload, &b->r_ecnt, &b->r_e0, &b->r_e1, &b->r_big}) p->ensure(size_t(mm) * 4);
+        for (DevBuf* p : {&b->r_cnt, &b->r_payload, &b->r_ecnt, &b->r_e0, &b->r_e1, &b->c->r_big}) p->ensure(size_t(mm) * 4);
         b->r_out_off.ensure((size_t(mm) + 1) * 8);
         b->r_epos.ensure((size_t(mm) + 1) * 8);
         b->scan_tmp.ensure((size_t(mm) / scan_block_topics() + 3) * 16);
@@ -455,11 +476,11 @@ void retain_rounds(rgr_batch* b, uint32_t begin, uint32_t n) {
         RGR_HIP(hipMemcpyAsync(&tot[1], b->r_epos.as<uint64_t>() + mm, 8, hipMemcpyDeviceToHost, b->stream));
         RGR_HIP(hipStreamSynchronize(b->stream));
         const uint64_t m_next = tot[0], e_r = tot[1];
-        if (g_total + e_r > b->arena_cap) {
-            b->arena_cap = (g_total + e_r) * 2;
-            b->arena.ensure_preserve(b->arena_cap * 4, g_total * 4);
+        if (g_total + e_r > b->c->arena_cap) {
+            b->c->arena_cap = (g_total + e_r) * 2;
+            b->c->arena.ensure_preserve(b->c->arena_cap * 4, g_total * 4);
         }
-        launch_retain_emit(r, b->r_epos.as<uint64_t>(), g_total, b->arena.as<uint32_t>(), b->ovf_base.as<uint64_t>(),
+        launch_retain_emit(r, b->r_epos.as<uint64_t>(), g_total, b->c->arena.as<uint32_t>(), b->c->ovf_base.as<uint64_t>(),
                            b->r_end.as<uint64_t>(), b->stream);
         g_total += e_r;
         if (m_next) {
@@ -467,17 +488,31 @@ void retain_rounds(rgr_batch* b, uint32_t begin, uint32_t n) {
             b->rf_node[cur ^ 1].ensure(m_next * 4);
             RGR_HIP(hipMemsetAsync(&sc->big_count, 0, 4, b->stream));
             launch_retain_next(rv, r, b->r_out_off.as<uint64_t>(), b->rf_filter[cur ^ 1].as<uint32_t>(), b->rf_node[cur ^ 1].as<uint32_t>(),
-                               b->r_big.as<uint32_t>(), &sc->big_count, b->stream);
+                               b->c->r_big.as<uint32_t>(), &sc->big_count, b->stream);
         }
         launch_retain_advance(r, n, b->r_depth.as<uint32_t>(), b->stream);
         visited += m;
         cur ^= 1;
         m = m_next;
     }
-    launch_retain_finish(n, b->ovf_base.as<uint64_t>(), b->r_end.as<uint64_t>(), b->pair_cnt.as<uint32_t>(), b->stream);
+    launch_retain_finish(n, b->c->ovf_base.as<uint64_t>(), b->r_end.as<uint64_t>(), b->c->pair_cnt.as<uint32_t>(), b->stream);
     RGR_HIP(hipGetLastError());
     b->local.visited_nodes += visited;
     b->local.alg_bytes_walk += 24 * visited;
+}
+
+// accounting of a prepared chunk; its host arrays are valid
+void account_chunk(rgr_batch* b) {
+    const uint32_t n = b->c->n;
+    const Scalars* hs = b->c->h_scalars.as<Scalars>();
+    const uint64_t P = b->c->h_pair_base.as<uint64_t>()[n];
+    const uint64_t H = b->c->h_hit_off.as<uint64_t>()[n];
+    b->local.pairs += P;
+    b->local.hits += H;
+    b->local.visited_nodes += hs->visited;
+    b->local.overflow_topics += hs->ovf_count;
+    b->local.alg_bytes_walk += 24 * hs->visited + 8 * P;
+    b->local.alg_bytes_expand += 20 * H;
 }
 
 // Walk the chunk starting at `begin`; on return the host has hit_off / pair_base and the
@@ -485,12 +520,12 @@ void retain_rounds(rgr_batch* b, uint32_t begin, uint32_t n) {
 void prepare_chunk(rgr_batch* b, uint32_t begin, bool walk_only) {
     rgr_handle* h = b->h;
     const uint32_t n = std::min<uint32_t>(h->cfg.chunk_topics, b->n - begin);
-    b->chunk_begin = begin;
-    b->chunk_n = n;
+    b->c->begin = begin;
+    b->c->n = n;
     ensure_chunk_buffers(b, n);
     const TrieView& tv = batch_view(b);
     for (;;) {
-        RGR_HIP(hipMemsetAsync(b->scalars.p, 0, sizeof(Scalars), b->stream));
+        RGR_HIP(hipMemsetAsync(b->c->scalars.p, 0, sizeof(Scalars), b->stream));
         WalkArgs wa = make_walk_args(b, n);
         size_t sp = b->span_begin(kSpanWalk);
         if (b->retain) {
@@ -503,56 +538,126 @@ void prepare_chunk(rgr_batch* b, uint32_t begin, bool walk_only) {
         b->local.walk_launches++;
         RGR_HIP(hipGetLastError());
         if (walk_only) {
-            RGR_HIP(hipMemcpyAsync(b->h_scalars.p, b->scalars.p, sizeof(Scalars), hipMemcpyDeviceToHost, b->stream));
+            RGR_HIP(hipMemcpyAsync(b->c->h_scalars.p, b->c->scalars.p, sizeof(Scalars), hipMemcpyDeviceToHost, b->stream));
             RGR_HIP(hipStreamSynchronize(b->stream));
-            const Scalars* hs = b->h_scalars.as<Scalars>();
-            if (hs->ovf_cursor > b->arena_cap) {   // arena too small: grow and redo
-                b->arena_cap = hs->ovf_cursor * 2;
-                b->arena.ensure(b->arena_cap * 4);
+            const Scalars* hs = b->c->h_scalars.as<Scalars>();
+            if (hs->ovf_cursor > b->c->arena_cap) {   // arena too small: grow and redo
+                b->c->arena_cap = hs->ovf_cursor * 2;
+                b->c->arena.ensure(b->c->arena_cap * 4);
                 b->resolve_spans();
                 continue;
             }
             b->resolve_spans();
-            b->chunk_ready = true;
+            b->c->ready = true;
             return;
         }
         ChunkArrays ca = make_chunk_arrays(b, n);
         sp = b->span_begin(kSpanScan);
         launch_count(tv, ca, b->stream);
-        launch_scan(ca, b->scan_tmp.as<uint64_t>(), b->stream);
+        launch_scan(ca, b->c->scan_tmp.as<uint64_t>(), b->stream);
         b->span_end(sp);
-        RGR_HIP(hipMemcpyAsync(b->h_scalars.p, b->scalars.p, sizeof(Scalars), hipMemcpyDeviceToHost, b->stream));
-        RGR_HIP(hipMemcpyAsync(b->h_hit_off.p, b->hit_off.p, (size_t(n) + 1) * 8, hipMemcpyDeviceToHost, b->stream));
-        RGR_HIP(hipMemcpyAsync(b->h_pair_base.p, b->pair_base.p, (size_t(n) + 1) * 8, hipMemcpyDeviceToHost, b->stream));
+        RGR_HIP(hipMemcpyAsync(b->c->h_scalars.p, b->c->scalars.p, sizeof(Scalars), hipMemcpyDeviceToHost, b->stream));
+        RGR_HIP(hipMemcpyAsync(b->c->h_hit_off.p, b->c->hit_off.p, (size_t(n) + 1) * 8, hipMemcpyDeviceToHost, b->stream));
+        RGR_HIP(hipMemcpyAsync(b->c->h_pair_base.p, b->c->pair_base.p, (size_t(n) + 1) * 8, hipMemcpyDeviceToHost, b->stream));
         RGR_HIP(hipStreamSynchronize(b->stream));
         RGR_HIP(hipGetLastError());
         b->resolve_spans();
-        const Scalars* hs = b->h_scalars.as<Scalars>();
-        if (hs->error || hs->ovf_cursor > b->arena_cap) {
-            b->arena_cap = std::max<uint64_t>(b->arena_cap * 2, hs->ovf_cursor * 2);
-            b->arena.ensure(b->arena_cap * 4);
+        const Scalars* hs = b->c->h_scalars.as<Scalars>();
+        if (hs->error || hs->ovf_cursor > b->c->arena_cap) {
+            b->c->arena_cap = std::max<uint64_t>(b->c->arena_cap * 2, hs->ovf_cursor * 2);
+            b->c->arena.ensure(b->c->arena_cap * 4);
             continue;
         }
-        const uint64_t P = b->h_pair_base.as<uint64_t>()[n];
-        const uint64_t H = b->h_hit_off.as<uint64_t>()[n];
-        b->pair_src.ensure(std::max<uint64_t>(1, P) * 4);
-        b->pair_topic.ensure(std::max<uint64_t>(1, P) * 4);
-        b->pair_off.ensure((P + 1) * 8);
-        if (b->deliver && !b->retain) b->pair_qr.ensure(std::max<uint64_t>(1, P));
+        const uint64_t P = b->c->h_pair_base.as<uint64_t>()[n];
+        const uint64_t H = b->c->h_hit_off.as<uint64_t>()[n];
+        b->c->pair_src.ensure(std::max<uint64_t>(1, P) * 4);
+        b->c->pair_topic.ensure(std::max<uint64_t>(1, P) * 4);
+        b->c->pair_off.ensure((P + 1) * 8);
+        if (b->deliver && !b->retain) b->c->pair_qr.ensure(std::max<uint64_t>(1, P));
         ca = make_chunk_arrays(b, n);
         sp = b->span_begin(kSpanScan);
         launch_compact(tv, ca, begin, b->stream);
         b->span_end(sp);
-        // accounting
-        b->local.pairs += P;
-        b->local.hits += H;
-        b->local.visited_nodes += hs->visited;
-        b->local.overflow_topics += hs->ovf_count;
-        b->local.alg_bytes_walk += 24 * hs->visited + 8 * P;
-        b->local.alg_bytes_expand += 20 * H;
-        b->chunk_ready = true;
+        account_chunk(b);
+        b->c->ready = true;
         return;
     }
+}
+
+// The NEXT chunk, prepared while the current chunk's windows are being expanded: walk -> count -> scan -> compact are
+// enqueued on prep_stream into the idle slot with NO host synchronisation — the pair arrays are sized by their upper
+// bound (n * slot_cap + arena capacity) instead of the scanned total — and the host-side arrays (hit offsets, pair
+// bases, scalars) follow by asynchronous copies; `done` fires when all of it has landed.  rgr_batch_next_window
+// adopts the slot when the cursor reaches it (an arena overflow, detected then, redoes the chunk synchronously).
+// Walk (random gathers) and expansion (streaming stores) overlap well: at config 3 the per-chunk preparation was
+// ~10 % of a 12-byte pass and ~28 % of a 4-byte one.
+void prefetch_chunk(rgr_batch* b, uint32_t begin) {
+    rgr_handle* h = b->h;
+    if (b->retain || begin >= b->n || std::getenv("RGR_NO_PREFETCH")) return;
+    ChunkSlot* cur = b->c;
+    struct Back { rgr_batch* b; ChunkSlot* c; ~Back() { b->c = c; } } back{b, cur};
+    b->c = b->other_slot();
+    ChunkSlot& nx = *b->c;
+    const uint32_t n = std::min<uint32_t>(h->cfg.chunk_topics, b->n - begin);
+    nx.begin = begin; nx.n = n; nx.ready = false; nx.inflight = false;
+    if (!b->prep_stream) RGR_HIP(hipStreamCreateWithFlags(&b->prep_stream, hipStreamNonBlocking));
+    if (!b->ev_windows_done) RGR_HIP(hipEventCreateWithFlags(&b->ev_windows_done, hipEventDisableTiming));
+    if (!nx.done) RGR_HIP(hipEventCreateWithFlags(&nx.done, hipEventDisableTiming));
+    ensure_chunk_buffers(b, n);
+    const uint64_t pmax = uint64_t(n) * h->cfg.slot_cap + nx.arena_cap;
+    nx.pair_src.ensure(std::max<uint64_t>(1, pmax) * 4);
+    nx.pair_topic.ensure(std::max<uint64_t>(1, pmax) * 4);
+    nx.pair_off.ensure((pmax + 1) * 8);
+    if (b->deliver) nx.pair_qr.ensure(std::max<uint64_t>(1, pmax));
+    hipStream_t ps = b->prep_stream;
+    // expansions of the chunk this slot held before may still be in flight on the main stream
+    RGR_HIP(hipEventRecord(b->ev_windows_done, b->stream));
+    RGR_HIP(hipStreamWaitEvent(ps, b->ev_windows_done, 0));
+    const TrieView& tv = batch_view(b);
+    RGR_HIP(hipMemsetAsync(nx.scalars.p, 0, sizeof(Scalars), ps));
+    WalkArgs wa = make_walk_args(b, n);
+    size_t sp = b->span_begin(kSpanWalk, ps);
+    launch_walk(tv, wa, false, ps);
+    launch_walk(tv, wa, true, ps);
+    b->span_end(sp, ps);
+    b->local.walk_launches++;
+    ChunkArrays ca = make_chunk_arrays(b, n);
+    sp = b->span_begin(kSpanScan, ps);
+    launch_count(tv, ca, ps);
+    launch_scan(ca, nx.scan_tmp.as<uint64_t>(), ps);
+    launch_compact(tv, ca, begin, ps);
+    b->span_end(sp, ps);
+    RGR_HIP(hipMemcpyAsync(nx.h_scalars.p, nx.scalars.p, sizeof(Scalars), hipMemcpyDeviceToHost, ps));
+    RGR_HIP(hipMemcpyAsync(nx.h_hit_off.p, nx.hit_off.p, (size_t(n) + 1) * 8, hipMemcpyDeviceToHost, ps));
+    RGR_HIP(hipMemcpyAsync(nx.h_pair_base.p, nx.pair_base.p, (size_t(n) + 1) * 8, hipMemcpyDeviceToHost, ps));
+    RGR_HIP(hipEventRecord(nx.done, ps));
+    RGR_HIP(hipGetLastError());
+    nx.inflight = true;
+}
+
+// Make the chunk starting at `begin` the current one: adopt the prefetched slot when there is one, else prepare it now.
+void enter_chunk(rgr_batch* b, uint32_t begin) {
+    ChunkSlot* o = b->other_slot();
+    if (o->inflight && o->begin == begin) {
+        RGR_HIP(hipEventSynchronize(o->done));
+        o->inflight = false;
+        b->c = o;
+        const Scalars* hs = o->h_scalars.as<Scalars>();
+        if (hs->error || hs->ovf_cursor > o->arena_cap) {      // overflow arena too small: grow it and redo the chunk on the main stream
+            o->arena_cap = std::max<uint64_t>(o->arena_cap * 2, hs->ovf_cursor * 2);
+            o->arena.ensure(o->arena_cap * 4);
+            b->resolve_spans();
+            prepare_chunk(b, begin, false);
+        } else {
+            account_chunk(b);
+            o->ready = true;
+        }
+    } else {
+        if (o->inflight) { RGR_HIP(hipEventSynchronize(o->done)); o->inflight = false; }   // (a prefetch nobody came for)
+        b->c->ready = false;
+        prepare_chunk(b, begin, false);
+    }
+    prefetch_chunk(b, b->c->begin + b->c->n);
 }
 
 }  // namespace
@@ -890,7 +995,9 @@ static int32_t batch_create_impl(rgr_handle* h, const uint8_t* blob, const uint6
         b->format = kFmtTuple;
         b->has_topic_ids = false;
         b->from_publish = false;
-        b->in_pass = false; b->chunk_ready = false; b->cursor = 0; b->hits_before = 0;
+        for (ChunkSlot& cs : b->cs) { if (cs.inflight) { RGR_HIP(hipEventSynchronize(cs.done)); cs.inflight = false; } cs.ready = false; }
+        b->c = &b->cs[0];
+        b->in_pass = false; b->cursor = 0; b->hits_before = 0;
         b->dict_tokens = ~0ull;
         b->epoch.reset(); b->repoch.reset();
         // two-tier retain batches are always tokenised on the device, against the dictionary image of the epoch
@@ -994,6 +1101,8 @@ static void batch_release(rgr_batch* b) {
     rgr_handle* h = b->h;
     (void)hipSetDevice(h->cfg.device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
+    if (b->prep_stream) (void)hipStreamSynchronize(b->prep_stream);
+    for (ChunkSlot& cs : b->cs) cs.inflight = false;
     try { b->resolve_spans(); } catch (...) {
         for (auto& sp : b->spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
         b->spans.clear();
@@ -1011,6 +1120,7 @@ void rgr_batch_destroy(rgr_batch* b) {
     if (!b) return;
     (void)hipSetDevice(b->h->cfg.device);
     if (b->stream) (void)hipStreamSynchronize(b->stream);
+    if (b->prep_stream) (void)hipStreamSynchronize(b->prep_stream);
     merge_stats(b->h, b->local);
     delete b;
 }
@@ -1078,9 +1188,13 @@ int32_t rgr_batch_begin(rgr_batch* b) {
         }
         if (b->format == kFmtPacked && (b->retain ? b->repoch->max_id : b->epoch->max_sub_id) >= (1u << 30))
             return fail(RGR_ECAPACITY, "rgr_batch_begin: RGR_FORMAT_PACKED needs ids below 2^30");
+        for (ChunkSlot& cs : b->cs) {          // a pass abandoned midway may have left a prefetch behind
+            if (cs.inflight) { RGR_HIP(hipEventSynchronize(cs.done)); cs.inflight = false; }
+            cs.ready = false;
+        }
+        b->c = &b->cs[0];
         b->in_pass = true;
         b->cursor = 0;
-        b->chunk_ready = false;
         b->hits_before = 0;
         b->local.topics += b->n;
         b->local.invalid_topics += b->n - b->valid_topics;
@@ -1104,14 +1218,11 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
             merge_stats(h, b->local);
             return RGR_EOF;
         }
-        if (!b->chunk_ready || b->cursor >= b->chunk_begin + b->chunk_n) {
-            b->chunk_ready = false;
-            prepare_chunk(b, b->cursor, false);
-        }
-        const uint32_t n = b->chunk_n;
-        const uint32_t lc = b->cursor - b->chunk_begin;
-        const uint64_t* ho = b->h_hit_off.as<uint64_t>();
-        const uint64_t* pb = b->h_pair_base.as<uint64_t>();
+        if (!b->c->ready || b->cursor >= b->c->begin + b->c->n) enter_chunk(b, b->cursor);
+        const uint32_t n = b->c->n;
+        const uint32_t lc = b->cursor - b->c->begin;
+        const uint64_t* ho = b->c->h_hit_off.as<uint64_t>();
+        const uint64_t* pb = b->c->h_pair_base.as<uint64_t>();
         const uint64_t cap = h->cfg.window_hits;
         uint32_t le;
         if (ho[n] - ho[lc] <= cap) le = n;
@@ -1125,9 +1236,9 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
         if (b->format == kFmtRuns) {
             // nothing to expand: the dense pair arrays of the chunk ARE the run list (built by compact_kernel)
             w->n_runs = pair_hi - pair_lo;
-            w->d_run_src = b->pair_src.as<uint32_t>() + pair_lo;
-            w->d_run_topic = b->pair_topic.as<uint32_t>() + pair_lo;
-            w->d_run_off = b->pair_off.as<uint64_t>() + pair_lo;
+            w->d_run_src = b->c->pair_src.as<uint32_t>() + pair_lo;
+            w->d_run_topic = b->c->pair_topic.as<uint32_t>() + pair_lo;
+            w->d_run_off = b->c->pair_off.as<uint64_t>() + pair_lo;
             w->d_subs = reinterpret_cast<const uint64_t*>(batch_view(b).subs);
             b->local.alg_bytes_expand -= nh * 20;            // (the chunk's accounting charged 20 B per hit)
             b->local.alg_bytes_expand += (pair_hi - pair_lo) * 16;
@@ -1163,7 +1274,7 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
                     da.cand = b->cand.as<Cand>();
                     da.tile_ncand = b->cand_count.as<uint32_t>();
                     da.topic_cand = b->topic_cand.as<uint32_t>();
-                    da.topic_lo = b->chunk_begin + lc;
+                    da.topic_lo = b->c->begin + lc;
                 }
             }
             sp = b->span_begin(kSpanExpand);
@@ -1200,7 +1311,7 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
             }
         }
         w->topic_begin = b->cursor;
-        w->topic_end = b->chunk_begin + le;
+        w->topic_end = b->c->begin + le;
         w->n_hits = nh;
         w->hit_base = b->hits_before;
         {
@@ -1210,10 +1321,10 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
             w->d_sub_ids = (b->format == kFmtSoa || b->format == kFmtPacked) && nh ? static_cast<const uint32_t*>(op) : nullptr;
             w->d_qos = b->format == kFmtSoa && nh ? static_cast<const uint8_t*>(op) + ids_bytes : nullptr;
         }
-        w->d_hit_offsets = b->hit_off.as<uint64_t>() + lc;
+        w->d_hit_offsets = b->c->hit_off.as<uint64_t>() + lc;
         w->offsets_bias = hit_lo;
         b->hits_before += nh;
-        b->cursor = b->chunk_begin + le;
+        b->cursor = b->c->begin + le;
         return RGR_OK;
     });
 }
@@ -1228,7 +1339,7 @@ int32_t rgr_window_to_host(rgr_batch* b, const rgr_window* w, rgr_tuple* host_tu
             RGR_HIP(hipMemcpyAsync(host_tuples, w->d_tuples, w->n_hits * sizeof(rgr_tuple), hipMemcpyDeviceToHost, b->stream));
         RGR_HIP(hipStreamSynchronize(b->stream));
         if (host_hit_offsets) {
-            const uint64_t* ho = b->h_hit_off.as<uint64_t>() + (w->topic_begin - b->chunk_begin);
+            const uint64_t* ho = b->c->h_hit_off.as<uint64_t>() + (w->topic_begin - b->c->begin);
             const uint32_t m = w->topic_end - w->topic_begin;
             for (uint32_t i = 0; i <= m; ++i) host_hit_offsets[i] = ho[i] - w->offsets_bias;
         }
@@ -1369,9 +1480,9 @@ static int32_t match_batch_impl(rgr_handle* h, const uint8_t* blob, const uint64
         r = stream_windows(
             b,
             [&](const rgr_window& w, int k) {
-                if (b->chunk_begin != sized_chunk) {
-                    sized_chunk = b->chunk_begin;
-                    const uint64_t chunk_hits = b->h_hit_off.as<uint64_t>()[b->chunk_n];
+                if (b->c->begin != sized_chunk) {
+                    sized_chunk = b->c->begin;
+                    const uint64_t chunk_hits = b->c->h_hit_off.as<uint64_t>()[b->c->n];
                     const size_t need = own->tuples.n + chunk_hits;
                     if (need > own->tuples.cap) {
                         for (int j = 0; j < 2; ++j) if (in_flight[j]) { RGR_HIP(hipEventSynchronize(b->ev_copied[j])); }
@@ -1380,7 +1491,7 @@ static int32_t match_batch_impl(rgr_handle* h, const uint8_t* blob, const uint64
                 }
                 const size_t base = own->tuples.n;
                 own->tuples.n = base + w.n_hits;
-                const uint64_t* ho = b->h_hit_off.as<uint64_t>() + (w.topic_begin - b->chunk_begin);
+                const uint64_t* ho = b->c->h_hit_off.as<uint64_t>() + (w.topic_begin - b->c->begin);
                 for (uint32_t i = 0; i <= w.topic_end - w.topic_begin; ++i) own->offsets[w.topic_begin + i] = base + (ho[i] - w.offsets_bias);
                 in_flight[k] = true;
                 return own->tuples.p + base;
@@ -1430,25 +1541,25 @@ int32_t rgr_match_filters(rgr_handle* h, const uint8_t* blob, const uint64_t* of
         // Per chunk: walk, exclusive scan of the per-topic matched-filter counts, one kernel that writes the
         // filter ids densely in iteration order, and two copies (offsets, ids) into pinned staging.  What
         // crosses PCIe is 4 bytes per matched filter + 8 per topic — not the slot arrays.
-        for (uint32_t begin = 0; begin < n; begin += b->chunk_n) {
+        for (uint32_t begin = 0; begin < n; begin += b->c->n) {
             prepare_chunk(b, begin, true);
-            const uint32_t cn = b->chunk_n;
-            const Scalars* hs = b->h_scalars.as<Scalars>();
-            b->pair_base.ensure((size_t(cn) + 1) * 8);
-            b->h_pair_base.ensure((size_t(cn) + 1) * 8);
+            const uint32_t cn = b->c->n;
+            const Scalars* hs = b->c->h_scalars.as<Scalars>();
+            b->c->pair_base.ensure((size_t(cn) + 1) * 8);
+            b->c->h_pair_base.ensure((size_t(cn) + 1) * 8);
             b->scan_tmp.ensure((size_t(cn) / scan_block_topics() + 3) * 16);
-            uint64_t* d_off = b->pair_base.as<uint64_t>();
-            launch_scan_u32(b->pair_cnt.as<uint32_t>(), d_off, cn, b->scan_tmp.as<uint64_t>(), b->stream);
-            RGR_HIP(hipMemcpyAsync(b->h_pair_base.p, d_off, (size_t(cn) + 1) * 8, hipMemcpyDeviceToHost, b->stream));
+            uint64_t* d_off = b->c->pair_base.as<uint64_t>();
+            launch_scan_u32(b->c->pair_cnt.as<uint32_t>(), d_off, cn, b->scan_tmp.as<uint64_t>(), b->stream);
+            RGR_HIP(hipMemcpyAsync(b->c->h_pair_base.p, d_off, (size_t(cn) + 1) * 8, hipMemcpyDeviceToHost, b->stream));
             RGR_HIP(hipStreamSynchronize(b->stream));
-            const uint64_t* ho = b->h_pair_base.as<uint64_t>();
+            const uint64_t* ho = b->c->h_pair_base.as<uint64_t>();
             const uint64_t P = ho[cn];
             const size_t base = own->ids.size();
             if (P) {
-                b->pair_src.ensure(P * 4);
+                b->c->pair_src.ensure(P * 4);
                 b->h_ring[0].ensure(P * 4);
-                launch_pairs_dense(make_chunk_arrays(b, cn), d_off, b->pair_src.as<uint32_t>(), b->stream);
-                RGR_HIP(hipMemcpyAsync(b->h_ring[0].p, b->pair_src.p, P * 4, hipMemcpyDeviceToHost, b->stream));
+                launch_pairs_dense(make_chunk_arrays(b, cn), d_off, b->c->pair_src.as<uint32_t>(), b->stream);
+                RGR_HIP(hipMemcpyAsync(b->h_ring[0].p, b->c->pair_src.p, P * 4, hipMemcpyDeviceToHost, b->stream));
                 RGR_HIP(hipStreamSynchronize(b->stream));
                 RGR_HIP(hipGetLastError());
                 own->ids.resize(base + P);

@@ -534,6 +534,7 @@ __global__ __launch_bounds__(256) void compact_big_kernel(TrieView tv, ChunkArra
     for (uint32_t b = blockIdx.x; b < nb; b += gridDim.x) {
         const uint32_t t = c.big_list[b];
         const uint32_t cnt = c.pair_cnt[t];
+        if (c.pair_live[t] == 0) continue;      // nothing to emit — also every topic count_big_kernel refused (list beyond the arena)
         uint64_t p0 = c.pair_base[t], o0 = c.hit_off[t];
         for (uint32_t j0 = 0; j0 < cnt; j0 += 256) {
             const uint32_t j = j0 + threadIdx.x;

@@ -189,3 +189,35 @@ def test_runs_format_is_the_hit_list_in_place():
         total += len(t)
     assert k == len(ref) and total > 50_000
     batch.close(); r.close()
+
+
+@pytest.mark.parametrize("prefetch", [True, False])
+def test_chunk_prefetch_and_arena_regrow(prefetch, monkeypatch):
+    """Many small chunks (the next one is prepared on a second stream while the current one expands) with a tiny
+    overflow arena that has to grow and redo — in the prefetched and in the synchronous path — against one big
+    chunk of the same batch."""
+    cfg = 3
+    c = wl.CONFIGS[cfg]
+    blob, offs, client, qos = wl.gen_subs(40_000, wl.SUB_SEED + cfg, 0.2, c["p_hash"], c["p_sys"])     # wildcard-heavy: long matched-filter lists
+    tb, to = wl.gen_topics(6_000, wl.PUB_SEED + cfg, 0.01, c["p_blank"])
+    ref_r = capi.Router(device=0)
+    assert ref_r.subscribe_bulk(blob, offs, None, qos) == 0
+    ref_r.commit()
+    ref = ref_r.match_batch(tb, to)
+    ref_r.close()
+    monkeypatch.setenv("RGR_ARENA_INIT", "8")
+    if not prefetch:
+        monkeypatch.setenv("RGR_NO_PREFETCH", "1")
+    r = capi.Router(device=0, window_hits=20_000, chunk_topics=256, slot_cap=2)
+    assert r.subscribe_bulk(blob, offs, None, qos) == 0
+    r.commit()
+    for _ in range(2):                     # second call: recycled workspace, arenas already grown
+        got = r.match_batch(tb, to)
+        assert np.array_equal(got["hit_offsets"], ref["hit_offsets"])
+        assert np.array_equal(got["tuples"]["sub_id"], ref["tuples"]["sub_id"]) and np.array_equal(got["tuples"]["topic_idx"], ref["tuples"]["topic_idx"])
+    b = r.batch(tb, to)
+    h1, w1 = b.run()
+    b.begin(); b.next_window(); b.next_window()      # abandon a pass midway (a prefetch may be in flight) ...
+    h2, w2 = b.run()                                  # ... and start over
+    assert h1 == h2 == len(ref["tuples"]) and w1 == w2 and r.stats()["overflow_topics"] > 0
+    b.close(); r.close()
