@@ -148,7 +148,9 @@ struct ChunkSlot {
     PinnedBuf h_hit_off, h_pair_base, h_scalars;
     uint64_t arena_cap = 0;
     uint32_t begin = 0, n = 0;
-    bool ready = false;          // walked, counted, scanned, compacted; host arrays valid
+    uint64_t total_hits = 0, total_pairs = 0;
+    bool host_arrays = false;    // h_hit_off / h_pair_base hold the chunk's per-topic offsets (skipped for a one-window chunk until someone asks)
+    bool ready = false;          // walked, counted, scanned, compacted
     bool inflight = false;       // prepared asynchronously on prep_stream: `done` tells when
     hipEvent_t done = nullptr;
     ~ChunkSlot() { if (done) (void)hipEventDestroy(done); }
@@ -180,6 +182,7 @@ struct rgr_batch {
     DevBuf out2;                         // second window buffer (rgr_batch_run_to_host double-buffers)
     PinnedBuf h_ring[2];                 // pinned staging for streamed windows
     bool alt_out = false;                // next_window expands into out2 instead of out
+    bool want_host_offsets = false;      // host-out entry points: fetch the per-topic offsets with the chunk's totals
     // streamed passes (rgr_batch_run_to_host, rgr_match_batch): copy stream + per-slot events, created once
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_expanded[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
@@ -441,7 +444,7 @@ void ensure_chunk_buffers(rgr_batch* b, uint32_t n) {
     b->c->scan_tmp.ensure((size_t(nb) + 1) * 16);
     b->c->h_hit_off.ensure((size_t(n) + 1) * 8);
     b->c->h_pair_base.ensure((size_t(n) + 1) * 8);
-    b->c->h_scalars.ensure(sizeof(Scalars));
+    b->c->h_scalars.ensure(sizeof(Scalars) + 16);      // + chunk totals (hits, pairs)
 }
 
 // RetainTree::matches for the chunk's filters: level-synchronous frontier rounds (kernels.hip).
@@ -501,12 +504,22 @@ void retain_rounds(rgr_batch* b, uint32_t begin, uint32_t n) {
     b->local.alg_bytes_walk += 24 * visited;
 }
 
-// accounting of a prepared chunk; its host arrays are valid
+// per-topic hit offsets / pair bases of the current chunk on the host (window planning, host-side offsets)
+void fetch_host_arrays(rgr_batch* b) {
+    if (b->c->host_arrays) return;
+    const uint32_t n = b->c->n;
+    RGR_HIP(hipMemcpyAsync(b->c->h_hit_off.p, b->c->hit_off.p, (size_t(n) + 1) * 8, hipMemcpyDeviceToHost, b->stream));
+    RGR_HIP(hipMemcpyAsync(b->c->h_pair_base.p, b->c->pair_base.p, (size_t(n) + 1) * 8, hipMemcpyDeviceToHost, b->stream));
+    RGR_HIP(hipStreamSynchronize(b->stream));
+    b->c->host_arrays = true;
+}
+
+// accounting of a prepared chunk
 void account_chunk(rgr_batch* b) {
     const uint32_t n = b->c->n;
     const Scalars* hs = b->c->h_scalars.as<Scalars>();
-    const uint64_t P = b->c->h_pair_base.as<uint64_t>()[n];
-    const uint64_t H = b->c->h_hit_off.as<uint64_t>()[n];
+    const uint64_t P = b->c->total_pairs, H = b->c->total_hits;
+    (void)n;
     b->local.pairs += P;
     b->local.hits += H;
     b->local.visited_nodes += hs->visited;
@@ -556,9 +569,12 @@ void prepare_chunk(rgr_batch* b, uint32_t begin, bool walk_only) {
         launch_count(tv, ca, b->stream);
         launch_scan(ca, b->c->scan_tmp.as<uint64_t>(), b->stream);
         b->span_end(sp);
+        // the totals first (24 bytes); the per-topic offset arrays (16 B per topic) cross PCIe only if the chunk needs
+        // more than one window — at low fan-out (config 2: 0.46 hits per topic) they were a third of the pass
+        uint64_t* tot = b->c->h_scalars.as<uint64_t>() + sizeof(Scalars) / 8;
         RGR_HIP(hipMemcpyAsync(b->c->h_scalars.p, b->c->scalars.p, sizeof(Scalars), hipMemcpyDeviceToHost, b->stream));
-        RGR_HIP(hipMemcpyAsync(b->c->h_hit_off.p, b->c->hit_off.p, (size_t(n) + 1) * 8, hipMemcpyDeviceToHost, b->stream));
-        RGR_HIP(hipMemcpyAsync(b->c->h_pair_base.p, b->c->pair_base.p, (size_t(n) + 1) * 8, hipMemcpyDeviceToHost, b->stream));
+        RGR_HIP(hipMemcpyAsync(&tot[0], b->c->hit_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
+        RGR_HIP(hipMemcpyAsync(&tot[1], b->c->pair_base.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
         RGR_HIP(hipStreamSynchronize(b->stream));
         RGR_HIP(hipGetLastError());
         b->resolve_spans();
@@ -568,8 +584,10 @@ void prepare_chunk(rgr_batch* b, uint32_t begin, bool walk_only) {
             b->c->arena.ensure(b->c->arena_cap * 4);
             continue;
         }
-        const uint64_t P = b->c->h_pair_base.as<uint64_t>()[n];
-        const uint64_t H = b->c->h_hit_off.as<uint64_t>()[n];
+        const uint64_t H = tot[0], P = tot[1];
+        b->c->total_hits = H; b->c->total_pairs = P;
+        b->c->host_arrays = false;
+        if (H > h->cfg.window_hits || b->want_host_offsets) fetch_host_arrays(b);
         b->c->pair_src.ensure(std::max<uint64_t>(1, P) * 4);
         b->c->pair_topic.ensure(std::max<uint64_t>(1, P) * 4);
         b->c->pair_off.ensure((P + 1) * 8);
@@ -649,6 +667,9 @@ void enter_chunk(rgr_batch* b, uint32_t begin) {
             b->resolve_spans();
             prepare_chunk(b, begin, false);
         } else {
+            o->total_hits = o->h_hit_off.as<uint64_t>()[o->n];
+            o->total_pairs = o->h_pair_base.as<uint64_t>()[o->n];
+            o->host_arrays = true;
             account_chunk(b);
             o->ready = true;
         }
@@ -995,6 +1016,7 @@ static int32_t batch_create_impl(rgr_handle* h, const uint8_t* blob, const uint6
         b->format = kFmtTuple;
         b->has_topic_ids = false;
         b->from_publish = false;
+        b->want_host_offsets = false;
         for (ChunkSlot& cs : b->cs) { if (cs.inflight) { RGR_HIP(hipEventSynchronize(cs.done)); cs.inflight = false; } cs.ready = false; }
         b->c = &b->cs[0];
         b->in_pass = false; b->cursor = 0; b->hits_before = 0;
@@ -1221,16 +1243,21 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
         if (!b->c->ready || b->cursor >= b->c->begin + b->c->n) enter_chunk(b, b->cursor);
         const uint32_t n = b->c->n;
         const uint32_t lc = b->cursor - b->c->begin;
-        const uint64_t* ho = b->c->h_hit_off.as<uint64_t>();
-        const uint64_t* pb = b->c->h_pair_base.as<uint64_t>();
         const uint64_t cap = h->cfg.window_hits;
         uint32_t le;
-        if (ho[n] - ho[lc] <= cap) le = n;
-        else {
-            le = uint32_t(std::upper_bound(ho + lc, ho + n + 1, ho[lc] + cap) - ho) - 1;
-            if (le <= lc) le = lc + 1;       // a single topic larger than the window: give it its own window
+        uint64_t hit_lo, hit_hi, pair_lo, pair_hi;
+        if (!b->c->host_arrays) {            // the whole chunk is one window (its totals fit): no per-topic arrays needed
+            le = n; hit_lo = 0; hit_hi = b->c->total_hits; pair_lo = 0; pair_hi = b->c->total_pairs;
+        } else {
+            const uint64_t* ho = b->c->h_hit_off.as<uint64_t>();
+            const uint64_t* pb = b->c->h_pair_base.as<uint64_t>();
+            if (ho[n] - ho[lc] <= cap) le = n;
+            else {
+                le = uint32_t(std::upper_bound(ho + lc, ho + n + 1, ho[lc] + cap) - ho) - 1;
+                if (le <= lc) le = lc + 1;       // a single topic larger than the window: give it its own window
+            }
+            hit_lo = ho[lc]; hit_hi = ho[le]; pair_lo = pb[lc]; pair_hi = pb[le];
         }
-        const uint64_t hit_lo = ho[lc], hit_hi = ho[le], pair_lo = pb[lc], pair_hi = pb[le];
         const uint64_t nh = hit_hi - hit_lo;
         w->n_runs = 0; w->d_run_src = nullptr; w->d_run_topic = nullptr; w->d_run_off = nullptr; w->d_subs = nullptr;
         if (b->format == kFmtRuns) {
@@ -1339,6 +1366,7 @@ int32_t rgr_window_to_host(rgr_batch* b, const rgr_window* w, rgr_tuple* host_tu
             RGR_HIP(hipMemcpyAsync(host_tuples, w->d_tuples, w->n_hits * sizeof(rgr_tuple), hipMemcpyDeviceToHost, b->stream));
         RGR_HIP(hipStreamSynchronize(b->stream));
         if (host_hit_offsets) {
+            fetch_host_arrays(b);
             const uint64_t* ho = b->c->h_hit_off.as<uint64_t>() + (w->topic_begin - b->c->begin);
             const uint32_t m = w->topic_end - w->topic_begin;
             for (uint32_t i = 0; i <= m; ++i) host_hit_offsets[i] = ho[i] - w->offsets_bias;
@@ -1469,6 +1497,7 @@ static int32_t match_batch_impl(rgr_handle* h, const uint8_t* blob, const uint64
         int32_t r = attrs ? rgr_batch_set_publish_attrs(b, attrs) : RGR_OK;
         if (r != RGR_OK) return r;
         if (topic_ids) { r = rgr_batch_set_topic_ids(b, topic_ids); if (r != RGR_OK) return r; }
+        b->want_host_offsets = true;
         r = rgr_batch_begin(b);
         if (r != RGR_OK) return r;
         // Windows are expanded and copied in a two-deep pipeline straight into the result block.  The block is
@@ -1482,7 +1511,7 @@ static int32_t match_batch_impl(rgr_handle* h, const uint8_t* blob, const uint64
             [&](const rgr_window& w, int k) {
                 if (b->c->begin != sized_chunk) {
                     sized_chunk = b->c->begin;
-                    const uint64_t chunk_hits = b->c->h_hit_off.as<uint64_t>()[b->c->n];
+                    const uint64_t chunk_hits = b->c->total_hits;
                     const size_t need = own->tuples.n + chunk_hits;
                     if (need > own->tuples.cap) {
                         for (int j = 0; j < 2; ++j) if (in_flight[j]) { RGR_HIP(hipEventSynchronize(b->ev_copied[j])); }
@@ -1491,6 +1520,7 @@ static int32_t match_batch_impl(rgr_handle* h, const uint8_t* blob, const uint64
                 }
                 const size_t base = own->tuples.n;
                 own->tuples.n = base + w.n_hits;
+                fetch_host_arrays(b);
                 const uint64_t* ho = b->c->h_hit_off.as<uint64_t>() + (w.topic_begin - b->c->begin);
                 for (uint32_t i = 0; i <= w.topic_end - w.topic_begin; ++i) own->offsets[w.topic_begin + i] = base + (ho[i] - w.offsets_bias);
                 in_flight[k] = true;
