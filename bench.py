@@ -644,6 +644,50 @@ def attach_traffic(rec, phase, pmc, cal):
                                              "unit": "hit" if other == "expand" else "query"}
 
 
+def measure_group(args):
+    """BASELINE configs[3] on the hardware at hand: the 10 M-subscription table hash-sharded over --group shards inside ONE
+    process (rgr_group_*), all shards on GPU 0 when the box has a single device.  Not a scaling measurement — every shard
+    shares one GPU — but the sharded product path at full size: placement, per-shard hit counts all-gathered through the
+    group's communicators, the total checked against the unsharded table, and (--gather tuples) the all-gatherv pass."""
+    import torch
+    from rmqtt_amd import capi
+    W = gen_workload(args.config, args.scale)
+    ndev = torch.cuda.device_count()
+    devices = [i % ndev for i in range(args.group)]
+    g = capi.Group(devices, window_hits=args.window_hits)
+    t = time.time()
+    rej = g.subscribe_bulk(W["blob"], W["offs"], None, W["qos"])
+    g.commit()
+    build_s = time.time() - t
+    per = [g.shard_stats(s) for s in range(args.group)]
+    log(f"group: {args.group} shards on devices {devices} (rccl: {g.uses_rccl()}), built in {build_s:.1f}s; subs per shard {[p['n_subs'] for p in per]}")
+    gb = g.batch(W["tb"], W["to"])
+    for _ in range(args.warmup):
+        gb.run()
+    torch.cuda.synchronize()
+    t = time.time()
+    for _ in range(args.steps):
+        sh, tot = gb.run()
+    dt = time.time() - t
+    rec = {"metric": f"publish-topic matches/sec @10M subs, table hash-sharded x{args.group} in one process (rgr_group) on {len(set(devices))} GPU(s)",
+           "value": round(W["n_pub"] * args.steps / dt, 1), "unit": "publish-topic matches/s", "n_gpus": len(set(devices)), "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "n/a (shards share the device)",
+           "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+           "config": {"workload": f"BASELINE.json configs[3] layout: {W['n_sub']} subscriptions sharded by the first 3 topic levels over {args.group} shards, {W['n_pub']} publishes",
+                      "shards": args.group, "devices": devices, "transport": "rccl" if g.uses_rccl() else "device copies (shards share a GPU)"},
+           "hits_per_step": int(tot), "shard_hits": [int(x) for x in sh], "shard_imbalance_max_over_mean": round(float(sh.max()) * args.group / max(1, int(sh.sum())), 3),
+           "shard_subs": [int(p["n_subs"]) for p in per], "replicated_subs": int(sum(p["n_subs"] for p in per) - (W["n_sub"] - rej)),
+           "table_hbm_bytes_per_shard": [int(p["table_bytes_device"]) for p in per]}
+    if args.gather == "tuples":
+        t = time.time()
+        tot2, _ = gb.gather(0)
+        rec["allgatherv_pass_s"] = round(time.time() - t, 3)
+        rec["allgatherv_total_hits"] = int(tot2)
+    print(json.dumps(rec), flush=True)
+    gb.close(); g.close()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -668,12 +712,16 @@ def main():
     ap.add_argument("--deliver", type=float, default=-1.0, metavar="V5FRAC",
                     help="also run the delivery stage (SURVEY 8(f)-1): this fraction of the subscriptions is MQTT v5 "
                          "(No Local / RAP / per-client dedup); 0 = v3 only. Not the headline metric.")
+    ap.add_argument("--group", type=int, default=0, metavar="SHARDS",
+                    help="run the single-process sharded router (rgr_group_*) with this many shards on the visible GPUs instead of the N=1 bench")
     ap.add_argument("--torch-collectives", action="store_true", help="N>1: use torch.distributed collectives instead of the library's RCCL communicator")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL) for real runs; gloo lets the N>1 logic be exercised on one GPU")
     args = ap.parse_args()
 
     if args.pmc_child:
         return pmc_child(args)
+    if args.group > 0:
+        return measure_group(args)
 
     import torch
     import torch.distributed as dist

@@ -41,10 +41,10 @@ namespace {
 constexpr int kWalkThreads = RGR_WALK_THREADS;
 constexpr int kWalkWindow = RGR_WALK_WINDOW;
 #ifndef RGR_EXPAND_THREADS
-#define RGR_EXPAND_THREADS 512
+#define RGR_EXPAND_THREADS 1024
 #endif
 #ifndef RGR_EXPAND_PER_THREAD
-#define RGR_EXPAND_PER_THREAD 4
+#define RGR_EXPAND_PER_THREAD 2
 #endif
 #ifndef RGR_EXPAND_NT
 #define RGR_EXPAND_NT 1          // nontemporal tuple stores: the output is write-once, keep L2 for the subscriber runs
