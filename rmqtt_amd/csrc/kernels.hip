@@ -581,11 +581,12 @@ __global__ __launch_bounds__(256) void tiles_kernel(ChunkArrays c, uint64_t pair
 // kDeliver: the delivery stage fused into the expansion — the tuple's third word becomes the
 // delivery word (deliver_word, match_core.hpp) and v5 hits that may be per-client duplicates are
 // appended to the window's candidate list (one global atomic per block that has any).
-template <bool kDeliver>
-__global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* __restrict__ subs, ChunkArrays c,
+template <bool kDeliver, int kThreads, int kPer>
+__global__ __launch_bounds__(kThreads) void expand_kernel(const SubEntry* __restrict__ subs, ChunkArrays c,
                                                                 uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo,
                                                                 uint64_t hit_hi, const TileRec* __restrict__ tile_first,
                                                                 uint32_t ntiles, Tuple* __restrict__ out, DeliverArgs da) {
+    static_assert(kThreads * kPer == kTile, "expand geometry must cover the tile");
     __shared__ int32_t s_off[kTile + 2];
     __shared__ uint32_t s_src[kTile + 2];
     __shared__ uint32_t s_topic[kTile + 2];
@@ -610,7 +611,7 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* 
             __syncthreads();
         }
     } else {
-        for (uint32_t i = threadIdx.x; i < np; i += kExpandThreads) {
+        for (uint32_t i = threadIdx.x; i < np; i += kThreads) {
             tile_pair_view(c, a, i, base, s_off[i], s_src[i], s_topic[i]);
             if (kDeliver) { s_qr[i] = c.pair_qr[a + i]; s_pc[i] = 0; }
         }
@@ -621,12 +622,12 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* 
     // store: (1) owner pair of each strided position (LDS binary search; free when one run
     // covers the whole tile), (2) 8-byte subscriber loads, (3) 12-byte tuple stores — a wave
     // stores 768 contiguous bytes per instruction.
-    uint32_t topic[kExpandPerThread];
-    uint32_t pidx[kExpandPerThread];
-    const SubEntry* src[kExpandPerThread];
+    uint32_t topic[kPer];
+    uint32_t pidx[kPer];
+    const SubEntry* src[kPer];
 #pragma unroll
-    for (int j = 0; j < kExpandPerThread; ++j) {
-        const uint32_t pos = uint32_t(j) * kExpandThreads + threadIdx.x;
+    for (int j = 0; j < kPer; ++j) {
+        const uint32_t pos = uint32_t(j) * kThreads + threadIdx.x;
         const bool live = pos < len;
         const uint32_t i = (one || !live) ? 0u : locate_pair([&](uint32_t m) { return s_off[m]; }, np, int32_t(pos));
         topic[j] = one ? rec.topic : s_topic[i];
@@ -634,16 +635,16 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* 
         // dead tail positions read (and discard) the tile's first entry: keeps the loads branch-free
         src[j] = subs + (uint64_t(one ? rec.src : s_src[i]) + (live ? uint32_t(int32_t(pos) - (one ? 0 : s_off[i])) : 0u));
     }
-    SubEntry se[kExpandPerThread];
+    SubEntry se[kPer];
 #pragma unroll
-    for (int j = 0; j < kExpandPerThread; ++j) {
+    for (int j = 0; j < kPer; ++j) {
         se[j] = *src[j];
     }
-    uint32_t cslot[kDeliver ? kExpandPerThread : 1], cclient[kDeliver ? kExpandPerThread : 1];
+    uint32_t cslot[kDeliver ? kPer : 1], cclient[kDeliver ? kPer : 1];
     if (kDeliver) {
 #pragma unroll
-        for (int j = 0; j < kExpandPerThread; ++j) {
-            const uint32_t pos = uint32_t(j) * kExpandThreads + threadIdx.x;
+        for (int j = 0; j < kPer; ++j) {
+            const uint32_t pos = uint32_t(j) * kThreads + threadIdx.x;
             cslot[j] = kNone; cclient[j] = kNone;
             if (pos < len) {
                 const uint32_t fl = se[j].qos_flags >> 8;
@@ -663,7 +664,7 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* 
             // per pair present in the wave instead of one per lane
             const int lane = threadIdx.x & 63;
 #pragma unroll
-            for (int j = 0; j < kExpandPerThread; ++j) {
+            for (int j = 0; j < kPer; ++j) {
                 const bool is = cclient[j] != kNone;
                 const unsigned long long m = __ballot(is);
                 if (!m) continue;
@@ -684,8 +685,8 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* 
         }
     }
 #pragma unroll
-    for (int j = 0; j < kExpandPerThread; ++j) {
-        const uint32_t pos = uint32_t(j) * kExpandThreads + threadIdx.x;
+    for (int j = 0; j < kPer; ++j) {
+        const uint32_t pos = uint32_t(j) * kThreads + threadIdx.x;
         if (pos < len) {
 #if RGR_EXPAND_NT
             __builtin_nontemporal_store(topic[j], &o[pos].topic_idx);
@@ -704,7 +705,7 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* 
         __syncthreads();
         if (threadIdx.x == 0) da.tile_ncand[tile] = s_ncand;
         if (s_ncand)   // per-topic candidate counts: the tile's pairs of one topic are adjacent, their first pair's lane sums them
-            for (uint32_t i = threadIdx.x; i < np; i += kExpandThreads) {
+            for (uint32_t i = threadIdx.x; i < np; i += kThreads) {
                 const uint32_t tp = s_topic[i];
                 if (i != 0 && s_topic[i - 1] == tp) continue;
                 uint32_t sum = 0;
@@ -714,9 +715,9 @@ __global__ __launch_bounds__(kExpandThreads) void expand_kernel(const SubEntry* 
         // the tile's candidates go to the tile's own slice of the list: no global cursor
         Cand* mine = da.cand + uint64_t(tile) * kTile;
 #pragma unroll
-        for (int j = 0; j < kExpandPerThread; ++j)
+        for (int j = 0; j < kPer; ++j)
             if (cslot[j] != kNone)
-                mine[cslot[j]] = Cand{uint32_t(base - hit_lo) + uint32_t(j) * kExpandThreads + threadIdx.x, cclient[j], topic[j] - da.topic_lo};
+                mine[cslot[j]] = Cand{uint32_t(base - hit_lo) + uint32_t(j) * kThreads + threadIdx.x, cclient[j], topic[j] - da.topic_lo};
     }
 }
 
@@ -999,8 +1000,10 @@ void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, ui
     if (hit_hi <= hit_lo) return;
     const uint32_t ntiles = uint32_t((hit_hi - hit_lo + kTile - 1) / kTile);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (deliver) expand_kernel<true><<<ntiles, kExpandThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, *deliver);
-    else expand_kernel<false><<<ntiles, kExpandThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, DeliverArgs{});
+    // the plain kernel runs 1024 x 2 (with the single-run fast path: +3 % over 512 x 4, profiles/r02f_sweep_*); the delivery
+    // variant keeps 512 x 4 — its per-wave candidate bookkeeping was 19 % slower at 1024 x 2 (profiles/r02g_bench_config3_deliver_*)
+    if (deliver) expand_kernel<true, kTile / 4, 4><<<ntiles, kTile / 4, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, *deliver);
+    else expand_kernel<false, kExpandThreads, kExpandPerThread><<<ntiles, kExpandThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, DeliverArgs{});
 }
 
 void launch_expand_compact(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint64_t hit_hi,
