@@ -568,13 +568,7 @@ __global__ __launch_bounds__(256) void compact_big_kernel(TrieView tv, ChunkArra
 __global__ __launch_bounds__(256) void tiles_kernel(ChunkArrays c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, TileRec* __restrict__ tile_first) {
     const uint64_t p = pair_lo + uint64_t(blockIdx.x) * 256 + threadIdx.x;
     if (p >= pair_hi) return;
-    // pair p covers output positions [pair_off[p], pair_off[p+1]); it owns every tile whose first position falls inside
-    // (match_core.hpp tiles_pair), and leaves its own view at that position in the tile's record
-    const uint64_t s = c.pair_off[p] - hit_lo, e = c.pair_off[p + 1] - hit_lo;
-    const uint32_t src = c.pair_src[p], topic = c.pair_topic[p];
-    const uint32_t qr = c.pair_qr ? c.pair_qr[p] : 0u;
-    for (uint64_t k = (s + kTile - 1) / kTile; k * kTile < e; ++k)
-        tile_first[k] = TileRec{uint32_t(p - pair_lo), src + uint32_t(k * kTile - s), topic, qr};
+    tiles_pair_rec(c, p, pair_lo, hit_lo, kTile, tile_first);
 }
 
 // --------------------------------------------------------------------------- expand

@@ -397,6 +397,16 @@ RGR_HD inline void tiles_pair(const uint64_t* pair_off, uint64_t p, uint64_t pai
     for (uint64_t k = (s + tile - 1) / tile; k * tile < e; ++k) tile_first[k] = uint32_t(p - pair_lo);
 }
 
+// The same with the tile's record: besides the first pair, that pair's own view at the tile's first position (where in
+// subs[] the tile starts reading, its topic, its publish qos|retain) — a tile that lies inside one run needs nothing else.
+RGR_HD inline void tiles_pair_rec(const ChunkArrays& c, uint64_t p, uint64_t pair_lo, uint64_t hit_lo, uint32_t tile, TileRec* tile_rec) {
+    const uint64_t s = c.pair_off[p] - hit_lo, e = c.pair_off[p + 1] - hit_lo;
+    const uint32_t src = c.pair_src[p], topic = c.pair_topic[p];
+    const uint32_t qr = c.pair_qr ? c.pair_qr[p] : 0u;
+    for (uint64_t k = (s + tile - 1) / tile; k * tile < e; ++k)
+        tile_rec[k] = TileRec{uint32_t(p - pair_lo), src + uint32_t(k * tile - s), topic, qr};
+}
+
 // Largest i in [0,np) with off[i] <= pos (off[0] <= pos is guaranteed by the caller).
 template <class OffAt> RGR_HD inline uint32_t locate_pair(OffAt off_at, uint32_t np, int32_t pos) {
     uint32_t lo = 0, hi = np;

@@ -175,7 +175,11 @@ int32_t run_pipeline(Emu* e, uint32_t n, const std::vector<uint64_t>& tok_off, c
                 const uint32_t T = e->tile;
                 const uint32_t ntiles = uint32_t((nh + T - 1) / T);
                 std::vector<uint32_t> tile_first(ntiles, 0xDEADBEEF);
-                for (uint64_t p = pair_lo; p < pair_hi; ++p) tiles_pair(pair_off.data(), p, pair_lo, hit_lo, T, tile_first.data());
+                std::vector<TileRec> tile_rec(ntiles, TileRec{0xDEADBEEF, 0, 0, 0});
+                for (uint64_t p = pair_lo; p < pair_hi; ++p) {
+                    tiles_pair(pair_off.data(), p, pair_lo, hit_lo, T, tile_first.data());
+                    tiles_pair_rec(ca, p, pair_lo, hit_lo, T, tile_rec.data());          // what tiles_kernel writes on the device
+                }
                 std::vector<int32_t> s_off(T + 2);
                 std::vector<uint32_t> s_src(T + 2), s_topic(T + 2);
                 rgr_tuple* out = tuples.data() + out_base + hit_lo;
@@ -188,7 +192,13 @@ int32_t run_pipeline(Emu* e, uint32_t n, const std::vector<uint64_t>& tok_off, c
                     const uint64_t b = (tile + 1 < ntiles) ? pair_lo + tile_first[tile + 1] + 1 : pair_hi;
                     const uint32_t np = uint32_t(b - a);
                     if (np > T + 1) return RGR_EINVAL;
+                    if (tile_rec[tile].first != tile_first[tile]) return RGR_EINVAL;
                     for (uint32_t i = 0; i < np; ++i) tile_pair_view(ca, a, i, base, s_off[i], s_src[i], s_topic[i]);
+                    if (np == 1) {      // the kernels' single-run fast path reads the record instead of the pair arrays: must be the same view
+                        const TileRec& rc = tile_rec[tile];
+                        if (s_off[0] != 0 || rc.src != s_src[0] || rc.topic != s_topic[0] || (pub && uint8_t(rc.qr) != ca.pair_qr[a])) return RGR_ESTATE;
+                        s_src[0] = rc.src; s_topic[0] = rc.topic;
+                    }
                     for (uint32_t pos = 0; pos < len; ++pos) {
                         const uint32_t i = locate_pair([&](uint32_t m) { return s_off[m]; }, np, int32_t(pos));
                         const uint64_t src = uint64_t(s_src[i]) + uint32_t(int32_t(pos) - s_off[i]);
