@@ -388,7 +388,25 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
                 if rank == 0:
                     uid = torch.frombuffer(bytearray(capi.Comm.unique_id()), dtype=torch.uint8).to(cdev)
                 dist.broadcast(uid, 0)
-                comm = capi.Comm(r, bytes(uid.cpu().numpy().tobytes()), rank, world)
+                # ncclCommInitRank is collective and blocks: run it on a helper thread so that a rendezvous that never
+                # completes turns into the torch.distributed path instead of a hung bench (RCCL's first initialisation takes
+                # about a minute on this image)
+                import threading
+                box = {}
+
+                def _init():
+                    try:
+                        box["comm"] = capi.Comm(r, bytes(uid.cpu().numpy().tobytes()), rank, world)
+                    except Exception as e:      # noqa: BLE001
+                        box["err"] = e
+                th = threading.Thread(target=_init, daemon=True)
+                th.start()
+                th.join(timeout=float(os.environ.get("RGR_COMM_INIT_TIMEOUT_S", "300")))
+                if th.is_alive():
+                    raise TimeoutError("rgr_comm_create did not return")
+                if "err" in box:
+                    raise box["err"]
+                comm = box["comm"]
                 collective = "rccl (rgr_comm_*, inside the library)"
             except Exception as e:
                 log(f"library RCCL communicator unavailable ({e!r}): using torch.distributed collectives", rank)
