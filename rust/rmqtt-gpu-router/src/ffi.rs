@@ -105,3 +105,81 @@ extern "C" {
     pub fn rgr_group_match_batch_deliver(g: *mut rgr_group, blob: *const u8, offsets: *const u64, n: u32, attrs: *const rgr_publish_attr,
                                          out: *mut rgr_result) -> i32;
 }
+
+// ---- device-resident batches, result formats, PUBLISH-packet batches, communicators (not used by the plugin itself;
+// declared for consumers that keep the hits on the device) -----------------------------------------------------------
+#[repr(C)]
+pub struct rgr_batch { _p: [u8; 0] }
+#[repr(C)]
+pub struct rgr_comm { _p: [u8; 0] }
+
+pub const RGR_FORMAT_TUPLE: u32 = 0;
+pub const RGR_FORMAT_SOA: u32 = 1;
+pub const RGR_FORMAT_PACKED: u32 = 2;
+pub const RGR_FORMAT_RUNS: u32 = 3;
+pub const RGR_TOPIC_INVALID: i32 = -2;
+pub const RGR_PACKET_MALFORMED: i32 = -8;
+pub const RGR_COMM_ID_BYTES: usize = 128;
+
+#[repr(C)]
+pub struct rgr_window {
+    pub topic_begin: u32,
+    pub topic_end: u32,
+    pub n_hits: u64,
+    pub hit_base: u64,
+    pub d_tuples: *const rgr_tuple,
+    pub d_hit_offsets: *const u64,
+    pub offsets_bias: u64,
+    pub d_sub_ids: *const u32,
+    pub d_qos: *const u8,
+    pub n_runs: u64,
+    pub d_run_src: *const u32,
+    pub d_run_topic: *const u32,
+    pub d_run_off: *const u64,
+    pub d_subs: *const u64,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct rgr_publish_info {
+    pub topic_off: u64,
+    pub topic_len: u32,
+    pub payload_off: u32,
+    pub packet_id: u16,
+    pub qos: u8,
+    pub retain: u8,
+    pub dup: u8,
+    pub error: u8,
+    pub _pad: [u8; 2],
+}
+
+extern "C" {
+    pub fn rgr_batch_create(h: *mut rgr_handle, blob: *const u8, offsets: *const u64, n: u32, out: *mut *mut rgr_batch) -> i32;
+    pub fn rgr_batch_create_from_publish(h: *mut rgr_handle, packets: *const u8, packet_offsets: *const u64, n: u32, version: u32,
+                                         from_ids: *const u32, out: *mut *mut rgr_batch) -> i32;
+    pub fn rgr_batch_publish_info(b: *const rgr_batch) -> *const rgr_publish_info;
+    pub fn rgr_batch_status(b: *const rgr_batch) -> *const i32;
+    pub fn rgr_batch_destroy(b: *mut rgr_batch);
+    pub fn rgr_batch_set_publish_attrs(b: *mut rgr_batch, attrs: *const rgr_publish_attr) -> i32;
+    pub fn rgr_batch_set_topic_ids(b: *mut rgr_batch, ids: *const u32) -> i32;
+    pub fn rgr_batch_set_format(b: *mut rgr_batch, format: u32) -> i32;
+    pub fn rgr_batch_begin(b: *mut rgr_batch) -> i32;
+    pub fn rgr_batch_next_window(b: *mut rgr_batch, w: *mut rgr_window) -> i32;
+    pub fn rgr_batch_run(b: *mut rgr_batch, n_hits: *mut u64, n_windows: *mut u32) -> i32;
+    pub fn rgr_match_filters(h: *mut rgr_handle, blob: *const u8, offsets: *const u64, n: u32, out: *mut rgr_filters_result) -> i32;
+    pub fn rgr_filters_result_free(r: *mut rgr_filters_result);
+    pub fn rgr_comm_unique_id(id: *mut u8) -> i32;
+    pub fn rgr_comm_create(h: *mut rgr_handle, id: *const u8, rank: u32, world: u32, out: *mut *mut rgr_comm) -> i32;
+    pub fn rgr_comm_destroy(c: *mut rgr_comm);
+    pub fn rgr_comm_allgather_u64(c: *mut rgr_comm, mine: u64, all: *mut u64) -> i32;
+}
+
+#[repr(C)]
+pub struct rgr_filters_result {
+    pub n_topics: u32,
+    pub n_pairs: u64,
+    pub status: *mut i32,
+    pub pair_offsets: *mut u64,
+    pub filter_ids: *mut u32,
+    pub _owner: *mut c_void,
+}
