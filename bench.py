@@ -499,6 +499,7 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
         "hits_per_step": int(total_hits), "hits_per_s": round(total_hits * K / elapsed, 1),
         "mean_hits_per_topic": round(total_hits / max(1, total_topics), 2),
         "mean_visited_nodes_per_topic": round(st["visited_nodes"] / max(1, st["topics"]), 2),
+        "overflow_topics_per_step": int(st["overflow_topics"] / K),      # topics with more than slot_cap matched filters (re-walked into the arena)
         "kernel_ms_per_step": {"walk": round(st["walk_ms"] / K, 3), "scan_compact_tiles": round(st["scan_ms"] / K, 3),
                                "expand": round(st["expand_ms"] / K, 3)},
         "alg_bytes_per_step": {"walk": int(st["alg_bytes_walk"] / K), "expand": int(st["alg_bytes_expand"] / K)},

@@ -39,6 +39,9 @@ namespace {
 #define RGR_WALK_WINDOW 2560             // LDS words per array (tokens, stack): 2 x 10 KiB per 256 topics
 #endif
 constexpr int kWalkThreads = RGR_WALK_THREADS;
+// the overflow re-walk handles the few topics with more than slot_cap matched filters — the heaviest walks of the chunk.
+// One wave per block spreads them over the CUs instead of packing 256 of them into each of a handful of blocks.
+constexpr int kOvfThreads = 64;
 constexpr int kWalkWindow = RGR_WALK_WINDOW;
 #ifndef RGR_EXPAND_THREADS
 #define RGR_EXPAND_THREADS 1024
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(kWalkThreads) void walk_kernel(TrieView tv, WalkArg
     uint32_t staged = 0;    // tokens held in LDS
 
     if (OVF) {
-        const uint32_t i = blockIdx.x * kWalkThreads + tid;
+        const uint32_t i = blockIdx.x * kOvfThreads + tid;
         active = i < min(*a.ovf_count, a.n);
         tl = active ? a.ovf_list[i] : 0;
     } else {
@@ -927,7 +930,7 @@ void launch_walk(const TrieView& t, const WalkArgs& a, bool overflow_pass, void*
     // The overflow pass does not know the overflow count on the host: it is launched over the
     // whole chunk and every block beyond *ovf_count exits at once.
     if (!overflow_pass) walk_kernel<false><<<(a.n + kWalkThreads - 1) / kWalkThreads, kWalkThreads, 0, s>>>(t, a);
-    else walk_kernel<true><<<(a.n + kWalkThreads - 1) / kWalkThreads, kWalkThreads, 0, s>>>(t, a);
+    else walk_kernel<true><<<(a.n + kOvfThreads - 1) / kOvfThreads, kOvfThreads, 0, s>>>(t, a);
 }
 
 void launch_retain_step(const RetainView& t, const RetainRound& r, void* stream) {
