@@ -403,7 +403,7 @@ ChunkArrays make_chunk_arrays(rgr_batch* b, uint32_t n) {
     c.n = n;
     c.slot_cap = b->retain ? 0 : b->h->cfg.slot_cap;   // retain descriptor lists always live in the arena
     c.slots = b->c->slots.as<uint32_t>();
-    c.slot_desc = b->retain ? nullptr : b->c->slot_desc.as<FilterDesc>();
+    c.slot_desc = (b->retain || std::getenv("RGR_NO_SLOT_DESC")) ? nullptr : b->c->slot_desc.as<FilterDesc>();    // (env: A/B switch)
     c.pair_cnt = b->c->pair_cnt.as<uint32_t>();
     c.hit_cnt = b->c->hit_cnt.as<uint32_t>();
     c.pair_live = b->c->pair_live.as<uint32_t>();
