@@ -13,6 +13,7 @@
 //! Source only (no rustc in the build image); C++ twin, compiled and tested against the oracle's RetainTree:
 //! rmqtt_amd/host/gpu_retain.{hpp,cpp} (tests/test_host_router.py::test_retain_storage_mirror).
 use std::ffi::CStr;
+use std::str::FromStr;
 use std::sync::atomic::{AtomicBool, Ordering};
 use std::sync::Mutex;
 use std::time::Duration;
@@ -20,6 +21,7 @@ use std::time::Duration;
 use ahash::AHashMap as HashMap;
 use async_trait::async_trait;
 use rmqtt::retain::RetainStorage;
+use rmqtt::topic::Topic;
 use rmqtt::types::*;
 use rmqtt::utils::Counter;
 use rmqtt::Result;
