@@ -437,6 +437,8 @@ int32_t rgr_group_uses_rccl(const rgr_group* g);
  * to every shard when a wildcard sits in its key levels.  sub ids stay the caller's. */
 int32_t rgr_group_subscribe_bulk(rgr_group* g, const uint8_t* blob, const uint64_t* offsets, uint64_t n, const uint32_t* sub_ids,
                                  const uint8_t* qos, const uint8_t* flags, uint64_t* n_rejected);
+/* delivery-stage attributes of bulk-loaded subscriptions (rgr_sub_attrs_bulk), per sub id */
+int32_t rgr_group_sub_attrs_bulk(rgr_group* g, const uint32_t* sub_ids, const uint32_t* owner_ids, const uint32_t* client_idx, uint64_t n);
 int32_t rgr_group_subscribe(rgr_group* g, const char* filter, uint32_t len, uint32_t sub_id, uint8_t qos, uint8_t flags);
 /* with the delivery-stage attributes of rgr_sub_add_ex */
 int32_t rgr_group_subscribe_ex(rgr_group* g, const char* filter, uint32_t len, uint32_t sub_id, uint8_t qos, uint8_t flags,

@@ -39,7 +39,7 @@ SYMBOLS = [
     "rgr_shard_assign", "rgr_stats_get", "rgr_stats_reset",
     "rgr_comm_unique_id", "rgr_comm_create", "rgr_comm_destroy", "rgr_comm_allgather_u64", "rgr_comm_gather_pass",
     "rgr_group_create", "rgr_group_destroy", "rgr_group_size", "rgr_group_handle", "rgr_group_comm", "rgr_group_uses_rccl",
-    "rgr_group_subscribe_bulk", "rgr_group_subscribe", "rgr_group_subscribe_ex", "rgr_group_unsubscribe", "rgr_group_commit",
+    "rgr_group_subscribe_bulk", "rgr_group_sub_attrs_bulk", "rgr_group_subscribe", "rgr_group_subscribe_ex", "rgr_group_unsubscribe", "rgr_group_commit",
     "rgr_group_match_batch", "rgr_group_match_batch_deliver",
     "rgr_group_batch_create", "rgr_group_batch_destroy", "rgr_group_batch_shard", "rgr_group_batch_run", "rgr_group_batch_gather",
 ]

@@ -100,6 +100,7 @@ extern "C" {
     pub fn rgr_group_unsubscribe(g: *mut rgr_group, filter: *const c_char, len: u32, sub_id: u32, last_of_filter: i32) -> i32;
     pub fn rgr_group_subscribe_bulk(g: *mut rgr_group, blob: *const u8, offsets: *const u64, n: u64, sub_ids: *const u32, qos: *const u8,
                                     flags: *const u8, n_rejected: *mut u64) -> i32;
+    pub fn rgr_group_sub_attrs_bulk(g: *mut rgr_group, sub_ids: *const u32, owner_ids: *const u32, client_idx: *const u32, n: u64) -> i32;
     pub fn rgr_group_commit(g: *mut rgr_group) -> i32;
     pub fn rgr_group_match_batch(g: *mut rgr_group, blob: *const u8, offsets: *const u64, n: u32, out: *mut rgr_result) -> i32;
     pub fn rgr_group_match_batch_deliver(g: *mut rgr_group, blob: *const u8, offsets: *const u64, n: u32, attrs: *const rgr_publish_attr,
