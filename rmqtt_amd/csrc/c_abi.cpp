@@ -143,7 +143,7 @@ struct rgr_handle {
 
 // Everything one chunk of topics needs between its walk and the expansion of its last window.
 struct ChunkSlot {
-    DevBuf slots, slot_desc, pair_cnt, hit_cnt, pair_live, hit_off, pair_base, ovf_list, ovf_base, scalars, arena;
+    DevBuf slots, pair_cnt, hit_cnt, pair_live, hit_off, pair_base, ovf_list, ovf_base, scalars, arena;
     DevBuf pair_src, pair_topic, pair_off, pair_qr, r_big, scan_tmp;
     PinnedBuf h_hit_off, h_pair_base, h_scalars;
     uint64_t arena_cap = 0;
@@ -403,7 +403,6 @@ ChunkArrays make_chunk_arrays(rgr_batch* b, uint32_t n) {
     c.n = n;
     c.slot_cap = b->retain ? 0 : b->h->cfg.slot_cap;   // retain descriptor lists always live in the arena
     c.slots = b->c->slots.as<uint32_t>();
-    c.slot_desc = (b->retain || std::getenv("RGR_NO_SLOT_DESC")) ? nullptr : b->c->slot_desc.as<FilterDesc>();    // (env: A/B switch)
     c.pair_cnt = b->c->pair_cnt.as<uint32_t>();
     c.hit_cnt = b->c->hit_cnt.as<uint32_t>();
     c.pair_live = b->c->pair_live.as<uint32_t>();
@@ -426,7 +425,6 @@ ChunkArrays make_chunk_arrays(rgr_batch* b, uint32_t n) {
 void ensure_chunk_buffers(rgr_batch* b, uint32_t n) {
     const uint32_t C = b->retain ? 0 : b->h->cfg.slot_cap;
     b->c->slots.ensure(std::max<size_t>(16, size_t(C) * n * 4));
-    if (!b->retain) b->c->slot_desc.ensure(std::max<size_t>(16, size_t(C) * n * sizeof(FilterDesc)));
     b->c->pair_cnt.ensure(size_t(n) * 4);
     b->c->hit_cnt.ensure(size_t(n) * 4);
     b->c->pair_live.ensure(size_t(n) * 4);

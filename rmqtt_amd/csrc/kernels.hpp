@@ -178,9 +178,6 @@ struct ChunkArrays {
     uint8_t* pair_qr;            // [P]
     // rgr_batch_set_topic_ids: value written into rgr_tuple.topic_idx for batch topic i (null: i itself)
     const uint32_t* topic_ids = nullptr;
-    // [C][n] run descriptor of every slot, written by the count step (which gathers filt[fid] anyway) so that the
-    // compaction reads it back coalesced instead of gathering filt[fid] a second time; null = gather again
-    FilterDesc* slot_desc = nullptr;
 };
 
 // incremental epoch update: patch `n` edge records / filter descriptors of a device image

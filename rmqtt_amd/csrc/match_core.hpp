@@ -361,11 +361,9 @@ RGR_HD inline void count_topic(const TrieView& tv, const ChunkArrays& c, uint32_
         *c.error_flag = 1; c.hit_cnt[t] = 0; c.pair_live[t] = 0;
         return;
     }
-    const bool keep = c.slot_desc && cnt <= c.slot_cap;
     for (uint32_t j = 0; j < cnt; ++j) {
-        const FilterDesc fd = tv.filt[pair_fid(c, t, cnt, j)];
-        if (keep) c.slot_desc[uint64_t(j) * c.n + t] = fd;
-        hits += fd.count; live += fd.count != 0;
+        const uint32_t n = tv.filt[pair_fid(c, t, cnt, j)].count;
+        hits += n; live += n != 0;
     }
     c.hit_cnt[t] = hits;
     c.pair_live[t] = live;
@@ -377,9 +375,8 @@ RGR_HD inline void compact_topic(const TrieView& tv, const ChunkArrays& c, uint3
     uint64_t o = c.hit_off[t];
     uint64_t p = c.pair_base[t];
     if (c.pair_live[t]) {
-        const bool kept = c.slot_desc && cnt <= c.slot_cap;
         for (uint32_t j = 0; j < cnt; ++j) {
-            const FilterDesc fd = kept ? c.slot_desc[uint64_t(j) * c.n + t] : tv.filt[pair_fid(c, t, cnt, j)];
+            const FilterDesc fd = tv.filt[pair_fid(c, t, cnt, j)];
             if (fd.count) {
                 c.pair_src[p] = fd.begin;
                 c.pair_topic[p] = c.topic_ids ? c.topic_ids[topic_base + t] : topic_base + t;

@@ -139,8 +139,6 @@ int32_t run_pipeline(Emu* e, uint32_t n, const std::vector<uint64_t>& tok_off, c
         }
         uint32_t err = 0;
         ChunkArrays ca{};
-        std::vector<FilterDesc> slot_desc(size_t(C) * cn + 1, FilterDesc{0xDEADBEEF, 0xDEADBEEF});
-        ca.slot_desc = slot_desc.data();
         ca.n = cn; ca.slot_cap = C; ca.slots = slots.data(); ca.pair_cnt = pair_cnt.data(); ca.hit_cnt = hit_cnt.data();
         ca.pair_live = pair_live.data(); ca.hit_off = hit_off.data(); ca.pair_base = pair_base.data();
         ca.ovf_base = ovf_base.data(); ca.ovf_arena = arena.data(); ca.ovf_arena_cap = arena.size(); ca.error_flag = &err;
