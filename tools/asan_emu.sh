@@ -13,4 +13,4 @@ trap '[ -f /tmp/libemu_plain.so ] && cp /tmp/libemu_plain.so "$SO" && touch "$SO
 LD_PRELOAD="$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so)" \
 ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
 python -m pytest tests/test_parity.py tests/test_retain_parity.py tests/test_deliver_parity.py tests/test_snapshot.py \
-    tests/test_golden_fixtures.py tests/test_hypothesis_parity.py tests/test_retain_tiers.py -x -q -m "not gpu" -p no:cacheprovider
+    tests/test_golden_fixtures.py tests/test_hypothesis_parity.py tests/test_retain_tiers.py tests/test_publish_packets.py -x -q -m "not gpu" -p no:cacheprovider
