@@ -203,7 +203,7 @@ def parity_sample(r, o, W, n_p, threads):
 
 
 # ------------------------------------------------------------------------------------------- PMC traffic
-KCLASS = (("expand", "expand_kernel"), ("walk", "walk_kernel<false>"), ("retain", "retain_"))
+KCLASS = (("expand", ("expand_kernel", "expand_tuple4_kernel")), ("walk", ("walk_kernel<false>",)), ("retain", ("retain_",)))
 
 
 def run_pmc_children(args, phases):
@@ -240,8 +240,8 @@ def run_pmc_children(args, phases):
                         rows.append((int(row["Dispatch_Id"]), row["Kernel_Name"], float(row["Counter_Value"]),
                                      int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
             rows.sort()
-            for cls, needle in KCLASS:
-                seq = [x for x in rows if needle in x[1]]
+            for cls, needles in KCLASS:
+                seq = [x for x in rows if any(nd in x[1] for nd in needles)]
                 at = 0
                 for ph in plan:
                     # the retain_* kernels' dispatch count is only known from the trace: they all belong to the (one) retain phase
@@ -466,8 +466,12 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
     exp_s, walk_s = st["expand_ms"] / 1e3, st["walk_ms"] / 1e3
     exp_gbs = st["alg_bytes_expand"] / exp_s / 1e9 if exp_s > 0 else 0.0
     walk_gbs = st["alg_bytes_walk"] / walk_s / 1e9 if walk_s > 0 else 0.0
-    dominant = "expand_kernel" if exp_s >= walk_s else ("retain_rounds" if retain else "walk_kernel")
-    is_exp = dominant == "expand_kernel"
+    is_exp = exp_s >= walk_s
+    # the plain tuple expansion is one of two kernels (rgr_version() says which one this build / environment runs)
+    exp_name = "expand_tuple4_kernel" if b"expand_tuple4_kernel" in capi.lib().rgr_version() else "expand_kernel"
+    if deliver >= 0:
+        exp_name = "expand_kernel<true>"
+    dominant = exp_name if is_exp else ("retain_rounds" if retain else "walk_kernel")
     launches = st["expand_launches"] if is_exp else st["walk_launches"]
     dom_s = exp_s if is_exp else walk_s
     alg = exp_gbs if is_exp else walk_gbs
@@ -622,7 +626,7 @@ def attach_traffic(rec, phase, pmc, cal):
     if not pmc:
         rf["traffic_note"] = "PMC passes unavailable in this run: frac not computed (alg_frac is the SURVEY 8(d) figure)"
         return
-    cls = "expand" if rf["kernel"] == "expand_kernel" else ("retain" if phase["retain"] else "walk")
+    cls = "expand" if rf["kernel"].startswith("expand_") else ("retain" if phase["retain"] else "walk")
     d = pmc.get(cls)
     if not d or "fetch_KiB" not in d or "write_KiB" not in d or not d["dispatches"]:
         rf["traffic_note"] = f"no PMC rows for {rf['kernel']}"

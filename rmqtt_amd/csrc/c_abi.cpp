@@ -687,7 +687,10 @@ void enter_chunk(rgr_batch* b, uint32_t begin) {
 extern "C" {
 
 const char* rgr_last_error(void) { return g_last_error.c_str(); }
-const char* rgr_version(void) { return "rmqtt_gpu_router 0.1 (gfx950)"; }
+const char* rgr_version(void) {
+    static const std::string v = std::string("rmqtt_gpu_router 0.2 (gfx950; tuple expansion: ") + expand_tuple_kernel_name() + ")";
+    return v.c_str();
+}
 
 int32_t rgr_create(const rgr_config* cfg, rgr_handle** out) {
     return guarded([&]() -> int32_t {

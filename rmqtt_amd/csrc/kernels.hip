@@ -968,6 +968,11 @@ __global__ __launch_bounds__(256) void dedup_flag_kernel(const Cand* __restrict_
 
 // ------------------------------------------------------------------------------ launchers
 uint32_t expand_tile_hits() { return kTile; }
+static bool tuple4_enabled() {
+    static const bool v = [] { const char* e = std::getenv("RGR_TUPLE4"); return e ? std::atoi(e) != 0 : kTuple4Default; }();
+    return v;
+}
+const char* expand_tuple_kernel_name() { return tuple4_enabled() ? "expand_tuple4_kernel" : "expand_kernel"; }
 uint32_t scan_block_topics() { return kScanBlock; }
 
 void launch_scatter_edges(EdgeEntry* dst, const uint32_t* slots, const EdgeEntry* recs, uint32_t n, void* stream) {
@@ -1078,8 +1083,7 @@ void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, ui
     hipStream_t s = static_cast<hipStream_t>(stream);
     // the plain kernel runs 1024 x 2 (with the single-run fast path: +3 % over 512 x 4, profiles/r02f_sweep_*); the delivery
     // variant keeps 512 x 4 — its per-wave candidate bookkeeping was 19 % slower at 1024 x 2 (profiles/r02g_bench_config3_deliver_*)
-    static const bool tuple4 = [] { const char* e = std::getenv("RGR_TUPLE4"); return e ? std::atoi(e) != 0 : kTuple4Default; }();
-    if (!deliver && tuple4) { expand_tuple4_kernel<<<ntiles, kCompactThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out); return; }
+    if (!deliver && tuple4_enabled()) { expand_tuple4_kernel<<<ntiles, kCompactThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out); return; }
     if (deliver) expand_kernel<true, kTile / 4, 4><<<ntiles, kTile / 4, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, *deliver);
     else expand_kernel<false, kExpandThreads, kExpandPerThread><<<ntiles, kExpandThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, DeliverArgs{});
 }

@@ -240,6 +240,7 @@ void launch_expand_compact(const TrieView& t, const ChunkArrays& c, uint64_t pai
 void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, uint32_t ntiles, Tuple* tuples, const uint64_t* cand_off,
                   unsigned long long* table, void* stream);
 uint32_t expand_tile_hits();
+const char* expand_tuple_kernel_name();      // which kernel expands plain 12-byte tuple windows (profilers see this name)
 uint32_t scan_block_topics();
 
 }  // namespace rgr
