@@ -203,7 +203,7 @@ def parity_sample(r, o, W, n_p, threads):
 
 
 # ------------------------------------------------------------------------------------------- PMC traffic
-KCLASS = (("expand", ("expand_kernel", "expand_tuple4_kernel")), ("walk", ("walk_kernel<false>",)), ("retain", ("retain_",)))
+KCLASS = (("expand", ("expand_kernel",)), ("walk", ("walk_kernel<false>",)), ("retain", ("retain_",)))
 
 
 def run_pmc_children(args, phases):
@@ -467,8 +467,7 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
     exp_gbs = st["alg_bytes_expand"] / exp_s / 1e9 if exp_s > 0 else 0.0
     walk_gbs = st["alg_bytes_walk"] / walk_s / 1e9 if walk_s > 0 else 0.0
     is_exp = exp_s >= walk_s
-    # the plain tuple expansion is one of two kernels (rgr_version() says which one this build / environment runs)
-    exp_name = "expand_tuple4_kernel" if b"expand_tuple4_kernel" in capi.lib().rgr_version() else "expand_kernel"
+    exp_name = "expand_kernel"
     if deliver >= 0:
         exp_name = "expand_kernel<true>"
     dominant = exp_name if is_exp else ("retain_rounds" if retain else "walk_kernel")

@@ -734,7 +734,6 @@ __global__ __launch_bounds__(kThreads) void expand_kernel(const SubEntry* __rest
 #define RGR_COMPACT_THREADS 256      // threads per 2048-hit tile: 256 x two groups of four consecutive positions (sweep: profiles/)
 #endif
 constexpr int kCompactThreads = RGR_COMPACT_THREADS;
-constexpr bool kTuple4Default = false;    // expand_tuple4_kernel instead of expand_kernel<false> for plain tuple windows (RGR_TUPLE4 overrides)
 constexpr int kCompactGroups = kTile / (kCompactThreads * 4);
 static_assert(kCompactGroups >= 1 && kCompactGroups * kCompactThreads * 4 == kTile, "compact expansion geometry must cover the tile");
 
@@ -849,82 +848,6 @@ __global__ __launch_bounds__(kCompactThreads) void expand_compact_kernel(const S
     }
 }
 
-// --------------------------------------------------------------------------- expand, 12-byte tuples, four positions per lane
-// The tuple format written the way the compact kernel writes: a lane owns groups of FOUR CONSECUTIVE positions, reads their
-// 32 contiguous bytes of subscriber entries with two dwordx4 loads and writes their 48 contiguous bytes of tuples with three
-// dwordx4 stores (a wave: 3 KiB contiguous), instead of one 8-byte load and one 12-byte store per position.  Same tiles, same
-// TileRec fast path, no delivery stage (that variant stays in expand_kernel<true>).
-__global__ __launch_bounds__(kCompactThreads) void expand_tuple4_kernel(const SubEntry* __restrict__ subs, ChunkArrays c, uint64_t pair_lo,
-                                                                        uint64_t pair_hi, uint64_t hit_lo, uint64_t hit_hi,
-                                                                        const TileRec* __restrict__ tile_first, uint32_t ntiles,
-                                                                        Tuple* __restrict__ out) {
-    __shared__ int32_t s_off[kTile + 2];
-    __shared__ uint32_t s_src[kTile + 2];
-    __shared__ uint32_t s_topic[kTile + 2];
-    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
-    struct __attribute__((packed, aligned(8))) V4 { v4 v; };
-    const uint32_t tile = blockIdx.x;
-    const uint64_t base = hit_lo + uint64_t(tile) * kTile;
-    const uint32_t len = (hit_hi - base) < uint64_t(kTile) ? uint32_t(hit_hi - base) : uint32_t(kTile);
-    const TileRec rec = tile_first[tile];
-    const uint64_t a = pair_lo + rec.first;
-    const uint64_t b = (tile + 1 < ntiles) ? pair_lo + tile_first[tile + 1].first + 1 : pair_hi;
-    const uint32_t np = uint32_t(b - a);
-    const bool one = np == 1;
-    if (!one) {
-        for (uint32_t i = threadIdx.x; i < np; i += kCompactThreads) tile_pair_view(c, a, i, base, s_off[i], s_src[i], s_topic[i]);
-        if (threadIdx.x == 0) s_off[np] = 0x7FFFFFFF;
-        __syncthreads();
-    }
-    SubEntry se[kCompactGroups][4];
-    uint32_t tp[kCompactGroups][4];
-#pragma unroll
-    for (int g = 0; g < kCompactGroups; ++g) {
-        const uint32_t p0 = (uint32_t(g) * kCompactThreads + threadIdx.x) * 4;
-        uint32_t i = (one || p0 >= len) ? 0u : locate_pair([&](uint32_t m) { return s_off[m]; }, np, int32_t(p0));
-        const bool same = one || (p0 + 4 <= len && s_off[i + 1] > int32_t(p0 + 3));
-        if (same) {
-            const uint32_t q0 = p0 + 4 <= len ? p0 : 0u;                   // (a partial last group re-reads the run's head: discarded)
-            const SubEntry* p = one ? subs + (uint64_t(rec.src) + q0) : subs + (uint64_t(s_src[i]) + uint32_t(int32_t(p0) - s_off[i]));
-            const V4 x = *reinterpret_cast<const V4*>(p), y = *reinterpret_cast<const V4*>(p + 2);
-            se[g][0] = SubEntry{x.v.x, x.v.y}; se[g][1] = SubEntry{x.v.z, x.v.w};
-            se[g][2] = SubEntry{y.v.x, y.v.y}; se[g][3] = SubEntry{y.v.z, y.v.w};
-            const uint32_t t = one ? rec.topic : s_topic[i];
-            tp[g][0] = t; tp[g][1] = t; tp[g][2] = t; tp[g][3] = t;
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t pos = p0 + j;
-                const bool live = pos < len;
-                while (live && s_off[i + 1] <= int32_t(pos)) ++i;
-                se[g][j] = subs[uint64_t(s_src[i]) + (live ? uint32_t(int32_t(pos) - s_off[i]) : 0u)];
-                tp[g][j] = s_topic[i];
-            }
-        }
-    }
-#pragma unroll
-    for (int g = 0; g < kCompactGroups; ++g) {
-        const uint32_t p0 = (uint32_t(g) * kCompactThreads + threadIdx.x) * 4;
-        if (p0 >= len) continue;
-        Tuple* o = out + (base - hit_lo) + p0;
-        if (p0 + 4 <= len) {
-            // 4 tuples = 12 words = three 16-byte stores; (base - hit_lo + p0) is a multiple of 4, so o is 48-byte aligned
-            v4 s0, s1, s2;
-            s0.x = tp[g][0]; s0.y = se[g][0].sub_id; s0.z = se[g][0].qos_flags; s0.w = tp[g][1];
-            s1.x = se[g][1].sub_id; s1.y = se[g][1].qos_flags; s1.z = tp[g][2]; s1.w = se[g][2].sub_id;
-            s2.x = se[g][2].qos_flags; s2.y = tp[g][3]; s2.z = se[g][3].sub_id; s2.w = se[g][3].qos_flags;
-            v4* ov = reinterpret_cast<v4*>(o);
-            __builtin_nontemporal_store(s0, ov); __builtin_nontemporal_store(s1, ov + 1); __builtin_nontemporal_store(s2, ov + 2);
-        } else {
-            for (uint32_t j = 0; p0 + j < len; ++j) {
-                // (a partial group of a single-run tile was loaded from the run's head: fetch its real entries)
-                const SubEntry e1 = one ? subs[uint64_t(rec.src) + p0 + j] : se[g][j];
-                o[j] = Tuple{one ? rec.topic : tp[g][j], e1.sub_id, e1.qos_flags};
-            }
-        }
-    }
-}
-
 // --------------------------------------------------------------------------- v5 per-client dedup
 // types.rs:524-539: of a topic's v5 hits for one client the FIRST (in filter order = position
 // order) keeps filter + options, later ones only contribute their subscription identifier.
@@ -968,11 +891,7 @@ __global__ __launch_bounds__(256) void dedup_flag_kernel(const Cand* __restrict_
 
 // ------------------------------------------------------------------------------ launchers
 uint32_t expand_tile_hits() { return kTile; }
-static bool tuple4_enabled() {
-    static const bool v = [] { const char* e = std::getenv("RGR_TUPLE4"); return e ? std::atoi(e) != 0 : kTuple4Default; }();
-    return v;
-}
-const char* expand_tuple_kernel_name() { return tuple4_enabled() ? "expand_tuple4_kernel" : "expand_kernel"; }
+const char* expand_tuple_kernel_name() { return "expand_kernel"; }
 uint32_t scan_block_topics() { return kScanBlock; }
 
 void launch_scatter_edges(EdgeEntry* dst, const uint32_t* slots, const EdgeEntry* recs, uint32_t n, void* stream) {
@@ -1083,7 +1002,6 @@ void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, ui
     hipStream_t s = static_cast<hipStream_t>(stream);
     // the plain kernel runs 1024 x 2 (with the single-run fast path: +3 % over 512 x 4, profiles/r02f_sweep_*); the delivery
     // variant keeps 512 x 4 — its per-wave candidate bookkeeping was 19 % slower at 1024 x 2 (profiles/r02g_bench_config3_deliver_*)
-    if (!deliver && tuple4_enabled()) { expand_tuple4_kernel<<<ntiles, kCompactThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out); return; }
     if (deliver) expand_kernel<true, kTile / 4, 4><<<ntiles, kTile / 4, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, *deliver);
     else expand_kernel<false, kExpandThreads, kExpandPerThread><<<ntiles, kExpandThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, DeliverArgs{});
 }
