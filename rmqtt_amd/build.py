@@ -86,13 +86,13 @@ def build_gpu(force=False, verbose=False):
 def build_host_router(force=False):
     """C++ mirror of the reference's Router trait over the C ABI + its test shim."""
     hdir = os.path.join(HERE, "host")
-    srcs = [os.path.join(hdir, "gpu_router.cpp"), os.path.join(hdir, "gpu_retain.cpp"), os.path.join(hdir, "router_capi.cpp")]
-    deps = srcs + [os.path.join(hdir, "gpu_router.hpp"), os.path.join(hdir, "gpu_retain.hpp"), os.path.join(INCLUDE, "rmqtt_gpu_router.h"), GPU_LIB]
+    srcs = [os.path.join(hdir, f) for f in ("gpu_router.cpp", "gpu_retain.cpp", "raft_snapshot.cpp", "router_capi.cpp")]
+    deps = srcs + [os.path.join(hdir, f) for f in ("gpu_router.hpp", "gpu_retain.hpp", "raft_snapshot.hpp")] + [os.path.join(INCLUDE, "rmqtt_gpu_router.h"), GPU_LIB]
     if force or _stale(HOST_LIB, deps):
         with _build_lock():
             if force or _stale(HOST_LIB, deps):
                 cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I", INCLUDE, "-I", hdir] + srcs
-                cmd += ["-o", HOST_LIB, "-L", HERE, "-lrmqtt_gpu_router", "-Wl,-rpath,$ORIGIN"]
+                cmd += ["-o", HOST_LIB, "-L", HERE, "-lrmqtt_gpu_router", "-lz", "-ldl", "-Wl,-rpath,$ORIGIN"]
                 _compile(cmd, HOST_LIB)
     return HOST_LIB
 

@@ -1,5 +1,6 @@
 // GpuRouter — see gpu_router.hpp.  Uses nothing but the C ABI of rmqtt_gpu_router.h.
 #include "gpu_router.hpp"
+#include "raft_snapshot.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -43,8 +44,8 @@ GpuRouter::GpuRouter(NodeId this_node, int device) : GpuRouter(this_node, std::v
 
 GpuRouter::GpuRouter(NodeId this_node, const std::vector<int>& devices) : this_node_(this_node) {
     rgr_config cfg{};
-    std::vector<int32_t> devs(devices.begin(), devices.end());
-    if (rgr_group_create(&cfg, devs.data(), uint32_t(devs.size()), &g_) != RGR_OK) { g_ = nullptr; create_error_ = rgr_last_error(); }
+    devices_.assign(devices.begin(), devices.end());
+    if (rgr_group_create(&cfg, devices_.data(), uint32_t(devices_.size()), &g_) != RGR_OK) { g_ = nullptr; create_error_ = rgr_last_error(); }
 }
 
 GpuRouter::~GpuRouter() { if (g_) rgr_group_destroy(g_); }
@@ -112,6 +113,60 @@ Result<bool> GpuRouter::add(const std::string& topic_filter, const Id& id, const
     if (rgr_group_subscribe_ex(g_, topic_filter.data(), uint32_t(topic_filter.size()), sub_id, opts.qos, flags_of(opts), ni->second, owner_id,
                                client_idx) != RGR_OK)
         return Result<bool>::Err(rgr_last_error());
+    dirty_ = true;
+    return Result<bool>::Ok(true);
+}
+
+// rmqtt-cluster-raft/src/router.rs:549-566
+Result<bool> GpuRouter::restore(const raft::Snapshot& snap) {
+    if (!g_) return Result<bool>::Err(create_error_);
+    for (auto& r : snap.relations)
+        if (!valid_topic(r.topic_filter)) return Result<bool>::Err("invalid topic filter `" + r.topic_filter + "`");   // router.rs:559
+    if (snap.relations.size() >= RGR_ID_NONE) return Result<bool>::Err("snapshot holds more relations than sub ids");
+    std::lock_guard<std::mutex> g(mu_);
+    // relations.clear() (router.rs:557): a fresh device table takes the place of the old one
+    rgr_group* fresh = nullptr;
+    rgr_config cfg{};
+    if (rgr_group_create(&cfg, devices_.data(), uint32_t(devices_.size()), &fresh) != RGR_OK) return Result<bool>::Err(rgr_last_error());
+    std::unordered_map<TopicFilter, FilterEntry> relations;
+    for (auto& r : snap.relations) relations[r.topic_filter].rels[r.client_id] = Rel{r.id, r.opts, 0, 0};   // HashMap::insert: the later entry wins
+    std::vector<Slot> slab;
+    Dense owners, clients;
+    std::string blob;
+    std::vector<uint64_t> offs{0};
+    std::vector<uint32_t> sub_ids, owner_ids, client_idx;
+    std::vector<uint8_t> qos, flags;
+    for (auto& kv : relations)
+        for (auto& rel : kv.second.rels) {
+            Rel& x = rel.second;
+            x.sub_id = uint32_t(slab.size());
+            x.owner_id = owners.acquire(id_key(x.id));
+            slab.push_back(Slot{&kv.first, &x});
+            blob += kv.first;
+            offs.push_back(blob.size());
+            sub_ids.push_back(x.sub_id);
+            owner_ids.push_back(x.owner_id);
+            client_idx.push_back(clients.acquire(client_key(x.id.node_id, x.id.client_id)));
+            qos.push_back(x.opts.qos);
+            flags.push_back(flags_of(x.opts));
+        }
+    uint64_t rejected = 0;
+    const uint64_t n = sub_ids.size();
+    int32_t rc = rgr_group_subscribe_bulk(fresh, reinterpret_cast<const uint8_t*>(blob.data()), offs.data(), n, sub_ids.data(), qos.data(), flags.data(),
+                                          &rejected);
+    if (rc == RGR_OK && rejected != 0) { rgr_group_destroy(fresh); return Result<bool>::Err(std::to_string(rejected) + " filters of the snapshot were rejected"); }
+    if (rc == RGR_OK) rc = rgr_group_sub_attrs_bulk(fresh, sub_ids.data(), owner_ids.data(), client_idx.data(), n);
+    if (rc != RGR_OK) { std::string e = rgr_last_error(); rgr_group_destroy(fresh); return Result<bool>::Err(e); }
+    rgr_group_destroy(g_);
+    g_ = fresh;
+    relations_ = std::move(relations);      // node-based map: the slab's pointers into it stay valid
+    slab_ = std::move(slab);
+    free_sub_ids_.clear();
+    owners_ = std::move(owners);
+    clients_ = std::move(clients);
+    bulk_loaded_ = true;
+    topics_count_ = Counter{snap.topics_count.count, snap.topics_count.max};             // router.rs:555
+    relations_count_ = Counter{snap.relations_count.count, snap.relations_count.max};   // router.rs:568
     dirty_ = true;
     return Result<bool>::Ok(true);
 }
@@ -211,7 +266,7 @@ Result<bool> GpuRouter::matches_batch(const std::vector<Id>& ids, const std::vec
             if (s.filter != cur_filter) { flush_groups(); cur_filter = s.filter; }
             if (w & RGR_HIT_NO_LOCAL) continue;                      // router.rs:196-201, decided on the device
             const Rel& rel = *s.rel;
-            const NodeId node = nodes_[w >> 16];
+            const NodeId node = bulk_loaded_ ? rel.id.node_id : nodes_[w >> 16];
             if (rel.opts.shared_group) {                              // router.rs:204-213
                 groups[*rel.opts.shared_group].push_back({SharedCandidate{node, rel.id.client_id, rel.opts, is_online(node, rel.id.client_id)}, &rel});
                 continue;

@@ -104,6 +104,8 @@ template <class T> struct Result {
     static Result Err(std::string e) { Result r; r.error = std::move(e); return r; }
 };
 
+namespace raft { struct Snapshot; }   // raft_snapshot.hpp
+
 struct Counter {   // rmqtt-utils/src/counter.rs:39 (count, max)
     int64_t count = 0, max = 0;
     void inc() { if (++count > max) max = count; }
@@ -158,6 +160,12 @@ class GpuRouter final : public Router {
     Counter topics() override { return topics_count_; }
     Counter routes() override { return relations_count_; }
     std::vector<std::string> list_topics(size_t top) override;
+    // ClusterRouter::restore (rmqtt-cluster-raft/src/router.rs:466-580) from a decoded Raft snapshot
+    // (raft::decode_snapshot): the relations map is replaced and the device table is rebuilt through the bulk
+    // path (rgr_group_subscribe_bulk: one sort + compile instead of one trie insert per relation).
+    // Unlike the reference, which stops half-way at the first invalid filter (router.rs:559 `?` after
+    // relations.clear()), every filter is validated first and an Err leaves the router as it was.
+    Result<bool> restore(const raft::Snapshot& snap);
 
    private:
     struct Rel { Id id; SubscriptionOptions opts; uint32_t sub_id; uint32_t owner_id; };
@@ -178,6 +186,8 @@ class GpuRouter final : public Router {
     uint64_t flag_mismatches_ = 0;
     std::string create_error_;
     NodeId this_node_;
+    std::vector<int32_t> devices_;
+    bool bulk_loaded_ = false;           // relations loaded by restore(): the tuples' node bits are not populated
     std::mutex mu_;   // the reference uses DashMap + a trie RwLock; one mutex is enough for the mirror
     std::unordered_map<TopicFilter, FilterEntry> relations_;   // AllRelationsMap
     std::vector<Slot> slab_;           // sub_id -> relation

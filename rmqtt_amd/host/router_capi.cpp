@@ -10,6 +10,7 @@
 
 #include "gpu_retain.hpp"
 #include "gpu_router.hpp"
+#include "raft_snapshot.hpp"
 
 using namespace rmqtt;
 
@@ -184,6 +185,63 @@ char* hm_get(void* s, const char* f, uint32_t fl) {
     return dup_str(out);
 }
 uint64_t hm_values_size(void* s) { return static_cast<GpuMessageIndex*>(s)->values_size(); }
+
+// ---- Raft snapshot reader shim (raft_snapshot.hpp) --------------------------------------------
+// features: bit 0 = shared-subscription, bit 1 = limit-subscription.  The error of the last failed call of
+// this thread is kept for rs_last_error.
+static thread_local std::string g_rs_error;
+static raft::Features rs_features(uint32_t bits) { raft::Features f; f.shared_subscription = bits & 1; f.limit_subscription = bits & 2; return f; }
+static std::string hex(const std::string& s) {
+    static const char* d = "0123456789abcdef";
+    std::string o;
+    for (unsigned char c : s) { o.push_back(d[c >> 4]); o.push_back(d[c & 15]); }
+    return o.empty() ? "-" : o;
+}
+static std::string id_text(const Id& id) {
+    return std::to_string(id.node_id) + "\t" + std::to_string(id.lid) + "\t" + (id.local_addr.empty() ? "-" : id.local_addr) + "\t" +
+           (id.remote_addr.empty() ? "-" : id.remote_addr) + "\t" + hex(id.client_id) + "\t" + hex(id.username) + "\t" + std::to_string(id.create_time);
+}
+const char* rs_last_error() { return g_rs_error.c_str(); }
+// plain bytes of one compressed section (malloc'ed, *out_len bytes); NULL on error
+uint8_t* rs_uncompress(const uint8_t* p, uint64_t n, int compression, uint64_t* out_len) {
+    auto r = raft::uncompress(raft::Compression(compression), p, size_t(n));
+    if (!r.ok()) { g_rs_error = r.error; return nullptr; }
+    *out_len = r.value->size();
+    auto* o = static_cast<uint8_t*>(std::malloc(r.value->size() + 1));
+    if (!r.value->empty()) std::memcpy(o, r.value->data(), r.value->size());
+    return o;
+}
+// canonical text of a decoded snapshot, rows in wire order (strings as hex, "-" = empty / None):
+//   F <n_filters>
+//   R <filter> <key> <id...> <3|5> <qos> <group> <limit_subs> <no_local> <rap> <rh> <sub_ident>
+//   C <key> <id...> <online> <handshaking> <handshak_duration>
+//   T <count> <max> <merge_mode>            (topics_count)      N ... (relations_count)
+char* rs_decode_dump(const uint8_t* p, uint64_t n, int compression, uint32_t features) {
+    auto r = raft::decode_snapshot(p, size_t(n), raft::Compression(compression), rs_features(features));
+    if (!r.ok()) { g_rs_error = r.error; return nullptr; }
+    const raft::Snapshot& s = *r.value;
+    std::string o = "F\t" + std::to_string(s.n_filters) + "\n";
+    for (auto& x : s.relations) {
+        o += "R\t" + hex(x.topic_filter) + "\t" + hex(x.client_id) + "\t" + id_text(x.id) + "\t" + (x.opts.v5 ? "5" : "3") + "\t" + std::to_string(x.opts.qos) +
+             "\t" + (x.opts.shared_group ? hex(*x.opts.shared_group) + "." : std::string("-")) + "\t" + (x.limit_subs ? std::to_string(*x.limit_subs) : std::string("-")) +
+             "\t" + std::to_string(int(x.opts.no_local)) + "\t" + std::to_string(int(x.opts.retain_as_published)) + "\t" + std::to_string(x.opts.retain_handling) +
+             "\t" + (x.opts.subscription_identifier ? std::to_string(x.opts.subscription_identifier) : std::string("-")) + "\n";
+    }
+    for (auto& c : s.client_states)
+        o += "C\t" + hex(c.client_id) + "\t" + id_text(c.id) + "\t" + std::to_string(int(c.online)) + "\t" + std::to_string(int(c.handshaking)) + "\t" +
+             std::to_string(c.handshak_duration) + "\n";
+    o += "T\t" + std::to_string(s.topics_count.count) + "\t" + std::to_string(s.topics_count.max) + "\t" + std::to_string(s.topics_count.merge_mode) + "\n";
+    o += "N\t" + std::to_string(s.relations_count.count) + "\t" + std::to_string(s.relations_count.max) + "\t" + std::to_string(s.relations_count.merge_mode) + "\n";
+    return dup_str(o);
+}
+// ClusterRouter::restore on the mirror: 0 ok, -1 error (rs_last_error)
+int hr_restore_raft(void* r, const uint8_t* p, uint64_t n, int compression, uint32_t features) {
+    auto s = raft::decode_snapshot(p, size_t(n), raft::Compression(compression), rs_features(features));
+    if (!s.ok()) { g_rs_error = s.error; return -1; }
+    auto res = static_cast<GpuRouter*>(r)->restore(*s.value);
+    if (!res.ok()) { g_rs_error = res.error; return -1; }
+    return 0;
+}
 
 int64_t hr_topics(void* r) { return static_cast<GpuRouter*>(r)->topics().count; }
 int64_t hr_routes(void* r) { return static_cast<GpuRouter*>(r)->routes().count; }
