@@ -495,8 +495,12 @@ void HostTable::subscribe_bulk(const uint8_t* blob, const uint64_t* offs, uint64
 
 // Build the whole edge table from the node array (bulk restore into an empty table).
 void HostTable::materialize_edges(const std::vector<uint32_t>& lit_cnt, const std::vector<uint32_t>& lit_xor) {
+    // load <= 0.25 by default: short probe sequences for the walk kernel.  RGR_EDGE_SLOTS_PER_NODE (2..16) trades probe
+    // length against footprint — a denser table may stay resident in the 256 MiB Infinity Cache (tools/walk_lab)
+    uint64_t per_node = 4;
+    if (const char* e = std::getenv("RGR_EDGE_SLOTS_PER_NODE")) per_node = std::min<uint64_t>(16, std::max<uint64_t>(2, std::strtoull(e, nullptr, 10)));
     uint64_t cap = 1024;
-    while (cap < n_nodes_ * 4) cap <<= 1;            // load <= 0.25: short probe sequences for the walk kernel
+    while (cap < n_nodes_ * per_node) cap <<= 1;
     const bool prof = std::getenv("RGR_BULK_PROFILE") != nullptr;
     auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_prev = tnow();

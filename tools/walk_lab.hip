@@ -6,15 +6,22 @@
 //                        the frontier of trie nodes lives in LDS, every lane takes one frontier node, reads its
 //                        '+' child (direct slot) and probes its literal child, and the next frontier is compacted
 //                        with wavefront ballot + prefix popcount
-// Both only COUNT matched filters per topic (B's level-synchronous order is not TopicTree::matches' order — the
+//   C  lane per topic    same DFS over BASELINE.json's "CSR level array" instead of the hash edge table: one 32-byte
+//      over CSR          record per trie node, the children of a node contiguous and sorted by level token, the exact
+//                        child found by binary search over the children's records (the record that matches IS the
+//                        child's header); '+' child by direct index.  Same miss filter as A.
+// All only COUNT matched filters per topic (B's level-synchronous order is not TopicTree::matches' order — the
 // product would have to sort it back) and the per-topic counts must agree.  The table is the product's own
 // (HostTable from table.cpp), the workload the seeded generator (workload.cpp).
 //
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I rmqtt_amd/csrc -I include tools/walk_lab.hip rmqtt_amd/csrc/table.cpp \
 //         rmqtt_amd/csrc/workload.cpp -o tools/walk_lab -pthread
 //   tools/walk_lab [n_sub=1000000] [n_pub=1000000] [p_plus=0.028] [p_hash=0.0] [reps=5]
+//   tools/walk_lab host [n_sub] [n_pub] [p_plus] [p_hash]      CPU only: A's and C's per-lane functions run on the host
+//                                                              and their per-topic counts are compared (no GPU needed)
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -60,6 +67,126 @@ __global__ __launch_bounds__(256) void walk_lane(TrieView tv, const uint32_t* __
             });
     }
     cnt_out[t] = cnt;
+}
+
+// ---- C: the same DFS over CSR children lists
+struct CsrRec { uint32_t token, child_begin, child_cnt, plus_idx, hash_fid, term_fid, lit_cnt, lit_xor; };   // 32 B
+static_assert(sizeof(CsrRec) == 32, "one record per trie node, the size of an edge record");
+struct CsrRoot { uint32_t child_begin, child_cnt, plus_idx, hash_fid, term_fid, lit_cnt, lit_xor; };
+
+// walk_topic's control flow (match_core.hpp) with the edge-table probe replaced by a binary search over the
+// node's children; `load(i)` reads record i.  Returns the number of matched filters; *visited counts records read.
+template <class TokAt, class PathGet, class PathSet, class Load>
+RGR_HD inline uint32_t walk_csr_topic(const CsrRoot& root, uint32_t L, bool meta, TokAt tok_at, PathGet path_get, PathSet path_set, Load load,
+                                      uint32_t* reads) {
+    uint32_t cnt = 0, d = 0, nreads = 0;
+    // current node: its children range and header fields
+    uint32_t cb = root.child_begin, cc = root.child_cnt, plus = root.plus_idx, hash_fid = root.hash_fid, term_fid = root.term_fid,
+             lit_cnt = root.lit_cnt, lit_xor = root.lit_xor;
+    bool arrive = true;
+    for (;;) {
+        uint32_t want_tok = 0, lo = 0, hi = 0;
+        bool direct = false, search = false;
+        uint32_t direct_idx = 0;
+        if (arrive) {
+            if (d == L) {
+                cnt += (term_fid != kNone) + (hash_fid != kNone);
+            } else {
+                const bool wild = !(d == 0 && meta);
+                if (wild && hash_fid != kNone) cnt++;
+                const uint32_t tk = tok_at(d);
+                const bool ex = tk != kTokUnknown && (tk < kTokFirst || (lit_cnt != 0 && (lit_cnt != 1 || lit_xor == tk)));
+                const bool pl = wild && plus != kNone;
+                if (pl) {
+                    // the exact lookup is deferred: remember the children range of this node (begin, count packed in two words)
+                    path_set(2 * d, ex ? cb : kNone); path_set(2 * d + 1, cc);
+                    direct = true; direct_idx = plus;
+                } else {
+                    path_set(2 * d, kNone);
+                    if (ex) { search = true; want_tok = tk; lo = cb; hi = cb + cc; }
+                }
+            }
+        }
+        if (!direct && !search) {                                        // pop: the deepest pending exact lookup
+            int64_t s = int64_t(d) - 1;
+            uint32_t pb = kNone;
+            for (; s >= 0; --s) { pb = path_get(2 * uint32_t(s)); if (pb != kNone) break; }
+            if (s < 0) break;
+            path_set(2 * uint32_t(s), kNone);
+            d = uint32_t(s);
+            want_tok = tok_at(d); lo = pb; hi = pb + path_get(2 * d + 1); search = true;
+        }
+        CsrRec r{};
+        bool found = false;
+        if (direct) { r = load(direct_idx); nreads++; found = true; }
+        else {
+            while (lo < hi) {                                             // children sorted by token
+                const uint32_t mid = lo + ((hi - lo) >> 1);
+                const CsrRec m = load(mid); nreads++;
+                if (m.token == want_tok) { r = m; found = true; break; }
+                if (m.token < want_tok) lo = mid + 1; else hi = mid;
+            }
+        }
+        if (!found) { arrive = false; continue; }                        // dead end: pop again (d stays where the probe was)
+        cb = r.child_begin; cc = r.child_cnt; plus = r.plus_idx; hash_fid = r.hash_fid; term_fid = r.term_fid; lit_cnt = r.lit_cnt; lit_xor = r.lit_xor;
+        d += 1;
+        arrive = true;
+    }
+    if (reads) *reads = nreads;
+    return cnt;
+}
+
+__global__ __launch_bounds__(256) void walk_csr(const CsrRec* __restrict__ recs, CsrRoot root, const uint32_t* __restrict__ tokens,
+                                                const uint64_t* __restrict__ tok_off, const uint8_t* __restrict__ tflags, uint32_t n,
+                                                uint32_t* __restrict__ cnt_out) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n) return;
+    const uint64_t off0 = tok_off[t];
+    const uint32_t L = uint32_t(tok_off[t + 1] - off0);
+    uint32_t path[48];
+    uint32_t cnt = 0;
+    if (!(tflags[t] & kTopicInvalid) && L <= 24) {
+        cnt = walk_csr_topic(
+            root, L, (tflags[t] & kTopicMeta) != 0, [&](uint32_t d) { return tokens[off0 + d]; }, [&](uint32_t i) { return path[i]; },
+            [&](uint32_t i, uint32_t v) { path[i] = v; },
+            [&](uint32_t i) {
+                const uint4* rp = reinterpret_cast<const uint4*>(recs + i);
+                const uint4 a = rp[0], b = rp[1];
+                return CsrRec{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            },
+            nullptr);
+    }
+    cnt_out[t] = cnt;
+}
+
+// CSR image of the product's table: every live edge record (parent, token) -> child becomes the child's CsrRec;
+// records sorted by (parent, token), so a node's children are contiguous and ordered.
+struct CsrImage { std::vector<CsrRec> recs; CsrRoot root; };
+static CsrImage build_csr(const HostTable& table) {
+    const auto& edges = table.edges();
+    struct E { uint32_t parent, token, slot; };
+    std::vector<E> es;
+    uint32_t max_node = 0;
+    for (size_t s = 0; s < edges.size(); ++s) {
+        const U4* h = reinterpret_cast<const U4*>(&edges[s]);
+        if (h[0].x == kEdgeEmpty || h[0].x == kEdgeTomb) continue;
+        es.push_back(E{h[0].x, h[0].y, uint32_t(s)});
+        max_node = std::max(max_node, std::max(h[0].x, h[0].z));
+    }
+    std::sort(es.begin(), es.end(), [](const E& a, const E& b) { return a.parent != b.parent ? a.parent < b.parent : a.token < b.token; });
+    std::vector<uint32_t> first(size_t(max_node) + 2, 0), cnt(size_t(max_node) + 2, 0);
+    for (size_t i = es.size(); i-- > 0;) { first[es[i].parent] = uint32_t(i); cnt[es[i].parent]++; }
+    CsrImage img;
+    img.recs.resize(es.size());
+    auto plus_of = [&](uint32_t node) { return cnt[node] && es[first[node]].token == kTokPlus ? first[node] : kNone; };
+    for (size_t i = 0; i < es.size(); ++i) {
+        const U4* h = reinterpret_cast<const U4*>(&edges[es[i].slot]);
+        const uint32_t child = h[0].z;
+        img.recs[i] = CsrRec{es[i].token, first[child], cnt[child], plus_of(child), h[1].x, h[1].y, h[1].z, h[1].w};
+    }
+    const NodeHeader r = table.root_header();
+    img.root = CsrRoot{first[0], cnt[0], plus_of(0), r.hash_fid, r.term_fid, r.lit_cnt, r.lit_xor};
+    return img;
 }
 
 // ---- B: wave per topic, level-synchronous frontier in LDS, ballot / prefix-popcount compaction
@@ -132,6 +259,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void walk_wave(TrieView tv, co
 }
 
 int main(int argc, char** argv) {
+    const bool host_only = argc > 1 && std::strcmp(argv[1], "host") == 0;
+    if (host_only) { --argc; ++argv; }
     const uint64_t n_sub = argc > 1 ? std::strtoull(argv[1], nullptr, 10) : 1000000;
     const uint64_t n_pub = argc > 2 ? std::strtoull(argv[2], nullptr, 10) : 1000000;
     const double p_plus = argc > 3 ? std::atof(argv[3]) : 0.028;
@@ -155,6 +284,34 @@ int main(int argc, char** argv) {
         toff[i + 1] = toff[i] + (toks.size() - mark);
     }
     const auto& edges = table.edges();
+    const CsrImage csr = build_csr(table);
+    if (host_only) {
+        // the per-lane functions of A and C on the host: identical counts, and how many dependent 32-byte reads each needs
+        const uint32_t mask = uint32_t(edges.size() - 1);
+        uint64_t sa = 0, sc = 0, diff = 0, reads_a = 0, reads_c = 0, walked = 0;
+        for (uint64_t t = 0; t < n_pub; ++t) {
+            const uint32_t L = uint32_t(toff[t + 1] - toff[t]);
+            if ((flags[t] & kTopicInvalid) || L > 24) continue;
+            const uint32_t* tk = toks.data() + toff[t];
+            uint32_t path[48], ca = 0, ra = 0, rc = 0;
+            walk_topic(
+                table.root_header(), mask, L, (flags[t] & kTopicMeta) != 0, [&](uint32_t d) { return tk[d]; }, [&](uint32_t d) { return path[d]; },
+                [&](uint32_t d, uint32_t v) { path[d] = v; }, [&](uint32_t) { ca++; },
+                [&](uint32_t slot, U4& e0, U4& e1) { const U4* h = reinterpret_cast<const U4*>(&edges[slot]); e0 = h[0]; e1 = h[1]; ra++; });
+            const uint32_t cc = walk_csr_topic(
+                csr.root, L, (flags[t] & kTopicMeta) != 0, [&](uint32_t d) { return tk[d]; }, [&](uint32_t i) { return path[i]; },
+                [&](uint32_t i, uint32_t v) { path[i] = v; }, [&](uint32_t i) { return csr.recs[i]; }, &rc);
+            sa += ca; sc += cc; diff += ca != cc; reads_a += ra; reads_c += rc; walked++;
+        }
+        std::printf("table: %llu subs (p_plus %.3f, p_hash %.2f), %llu trie nodes, %llu edge slots (%.1f MiB), CSR %llu records (%.1f MiB); %llu topics\n",
+                    (unsigned long long)n_sub, p_plus, p_hash, (unsigned long long)table.n_nodes(), (unsigned long long)edges.size(), edges.size() * 32.0 / 1048576,
+                    (unsigned long long)csr.recs.size(), csr.recs.size() * 32.0 / 1048576, (unsigned long long)n_pub);
+        std::printf("host check: matched filters A (hash edge table) %llu, C (CSR children lists) %llu, topics that differ %llu\n", (unsigned long long)sa,
+                    (unsigned long long)sc, (unsigned long long)diff);
+        std::printf("dependent 32-byte record reads per topic: A %.2f, C %.2f (C / A = %.2f)\n", double(reads_a) / walked, double(reads_c) / walked,
+                    double(reads_c) / double(reads_a));
+        return diff != 0;
+    }
     EdgeEntry* d_edges; uint32_t *d_tok, *d_ca, *d_cb, *d_ovf; uint64_t* d_off; uint8_t* d_fl;
     CHECK(hipMalloc(&d_edges, edges.size() * sizeof(EdgeEntry)));
     CHECK(hipMemcpy(d_edges, edges.data(), edges.size() * sizeof(EdgeEntry), hipMemcpyHostToDevice));
@@ -174,18 +331,27 @@ int main(int argc, char** argv) {
         return ms / reps;
     };
     const float ta = timeit([&] { walk_lane<<<uint32_t((n_pub + 255) / 256), 256>>>(tv, d_tok, d_off, d_fl, uint32_t(n_pub), d_ca); });
+    CsrRec* d_csr; uint32_t* d_cc;
+    CHECK(hipMalloc(&d_csr, std::max<size_t>(1, csr.recs.size()) * sizeof(CsrRec)));
+    CHECK(hipMemcpy(d_csr, csr.recs.data(), csr.recs.size() * sizeof(CsrRec), hipMemcpyHostToDevice));
+    CHECK(hipMalloc(&d_cc, n_pub * 4));
+    const float tc = timeit([&] { walk_csr<<<uint32_t((n_pub + 255) / 256), 256>>>(d_csr, csr.root, d_tok, d_off, d_fl, uint32_t(n_pub), d_cc); });
     const float tw = timeit([&] { walk_wave<<<uint32_t((n_pub + kWavesPerBlock - 1) / kWavesPerBlock), 64 * kWavesPerBlock>>>(tv, d_tok, d_off, d_fl, uint32_t(n_pub), d_cb, d_ovf); });
-    std::vector<uint32_t> ca(n_pub), cb(n_pub);
+    std::vector<uint32_t> ca(n_pub), cb(n_pub), ccv(n_pub);
+    CHECK(hipMemcpy(ccv.data(), d_cc, n_pub * 4, hipMemcpyDeviceToHost));
     uint32_t ovf = 0;
     CHECK(hipMemcpy(ca.data(), d_ca, n_pub * 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(cb.data(), d_cb, n_pub * 4, hipMemcpyDeviceToHost));
     CHECK(hipMemcpy(&ovf, d_ovf, 4, hipMemcpyDeviceToHost));
-    uint64_t sa = 0, sb = 0, diff = 0;
-    for (uint64_t i = 0; i < n_pub; ++i) { sa += ca[i]; sb += cb[i]; diff += ca[i] != cb[i]; }
+    uint64_t sa = 0, sb = 0, diff = 0, sc = 0, diff_c = 0;
+    for (uint64_t i = 0; i < n_pub; ++i) { sa += ca[i]; sb += cb[i]; diff += ca[i] != cb[i]; sc += ccv[i]; diff_c += ca[i] != ccv[i]; }
     std::printf("table: %llu subs (p_plus %.3f, p_hash %.2f), %llu trie nodes, %llu edge slots; %llu topics, %.2f matched filters/topic\n",
                 (unsigned long long)n_sub, p_plus, p_hash, (unsigned long long)table.n_nodes(), (unsigned long long)edges.size(), (unsigned long long)n_pub, double(sa) / n_pub);
     std::printf("A lane per topic  (explicit-stack DFS per lane)            %9.3f ms  %8.1f M topics/s\n", ta, n_pub / ta / 1e3);
     std::printf("B wave per topic  (LDS frontier, ballot + prefix popcount) %9.3f ms  %8.1f M topics/s   (%.1fx A)\n", tw, n_pub / tw / 1e3, tw / ta);
+    std::printf("C lane per topic  (CSR children lists, binary search)       %9.3f ms  %8.1f M topics/s   (%.1fx A; %.1f MiB of records vs %.1f MiB)\n", tc,
+                n_pub / tc / 1e3, tc / ta, csr.recs.size() * 32.0 / 1048576, edges.size() * 32.0 / 1048576);
+    std::printf("matched-filter counts: C total %llu, topics that differ from A %llu\n", (unsigned long long)sc, (unsigned long long)diff_c);
     std::printf("matched-filter counts: A total %llu, B total %llu, topics that differ %llu, frontier overflows (>%d nodes/level, per launch x%d) %u\n",
                 (unsigned long long)sa, (unsigned long long)sb, (unsigned long long)diff, kFrontierCap, reps + 1, ovf);
-    return diff != 0 && ovf == 0;
+    return (diff != 0 && ovf == 0) || diff_c != 0;
 }
