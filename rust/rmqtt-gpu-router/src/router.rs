@@ -213,9 +213,19 @@ impl GpuRouter {
     /// Rebuild the device table from `inner.relations` with ONE bulk call — the restore path of the cluster routers
     /// (rmqtt-cluster-raft/src/router.rs:557-566 re-inserts every relation after a snapshot; the snapshot itself —
     /// postcard + zstd/lz4 of `relations`, :387-463 — is decoded by the broker as today, `rgr_group_subscribe_bulk`
-    /// then builds the trie in sorted order instead of 10 M single inserts).  Call it on an empty GpuRouter.
+    /// then builds the trie in sorted order instead of 10 M single inserts).  `restore` writes `inner.relations`
+    /// directly, without `add` calls, so this is the one call a maintainer adds at its end; whatever was mirrored
+    /// before leaves the device table first (the C++ mirror's `GpuRouter::restore` swaps in a fresh group instead).
     pub fn resync(&self) -> Result<()> {
         let mut s = self.slab.write().unwrap();
+        let old: Vec<(u32, TopicFilter)> =
+            s.slots.iter().enumerate().filter_map(|(i, x)| x.as_ref().map(|(f, _, _)| (i as u32, f.clone()))).collect();
+        for (sid, f) in old {
+            let left = s.per_filter.get_mut(&f).map(|n| { *n -= 1; *n }).unwrap_or(0);
+            let rc = unsafe { rgr_group_unsubscribe(self.g.0, f.as_ptr() as _, f.len() as u32, sid, (left == 0) as i32) };
+            if rc != RGR_OK { return Err(anyhow::anyhow!("rgr_group_unsubscribe: {}", last_error())); }
+        }
+        *s = Slab::default();
         let (mut blob, mut offs) = (Vec::<u8>::new(), vec![0u64]);
         let (mut sub_ids, mut qos, mut fl) = (Vec::<u32>::new(), Vec::<u8>::new(), Vec::<u8>::new());
         let (mut owners, mut clients) = (Vec::<u32>::new(), Vec::<u32>::new());
