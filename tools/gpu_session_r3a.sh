@@ -12,6 +12,9 @@ mkdir -p $O
 [ -x tools/walk_lab ] || hipcc --offload-arch=gfx950 -O3 -std=c++17 -I rmqtt_amd/csrc -I include tools/walk_lab.hip rmqtt_amd/csrc/table.cpp \
     rmqtt_amd/csrc/workload.cpp -o tools/walk_lab -pthread
 ( timeout 300 tools/walk_lab 10000000 2000000 0.028 0.1 5 ) > $O/walk_lab_config3_size.txt 2>&1; cat $O/walk_lab_config3_size.txt
+#   4. v5 dedup: global table vs LDS tables (tools/dedup_lab.hip), config-3 shape and a low-fan-out shape
+[ -x tools/dedup_lab ] || hipcc --offload-arch=gfx950 -O3 -std=c++17 -I rmqtt_amd/csrc -I include tools/dedup_lab.hip -o tools/dedup_lab
+( timeout 120 tools/dedup_lab 26; timeout 120 tools/dedup_lab 26 50 0.1 2500000 5 1.0; timeout 120 tools/dedup_lab 26 14800 0.5 ) > $O/dedup_lab.txt 2>&1; cat $O/dedup_lab.txt
 for x in 4 8; do
   for cfg in 2 3; do
     ( RGR_EDGE_SLOTS_PER_NODE=$x timeout 600 python bench.py --config $cfg --steps 10 --warmup 3 --no-pmc --no-secondary --no-formats --no-d2h --cpu-sample 0 \
