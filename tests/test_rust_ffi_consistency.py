@@ -169,3 +169,53 @@ def test_constants_match_the_header():
     for name, v in rc.items():
         assert name in hc, f"{name} of ffi.rs is not in the header"
         assert (hc[name] & 0xFFFFFFFF) == (v & 0xFFFFFFFF), (name, hc[name], v)
+
+
+def _call_args(src, start):
+    """Arguments of the call whose '(' is at src[start]: top-level comma split with (), [], {} and <> balanced."""
+    depth, cur, args, i = 0, "", [], start
+    while True:
+        ch = src[i]
+        if ch in "([{":
+            depth += 1
+            if depth > 1:
+                cur += ch
+        elif ch in ")]}":
+            depth -= 1
+            if depth == 0:
+                break
+            cur += ch
+        elif ch == "," and depth == 1:
+            args.append(cur)
+            cur = ""
+        else:
+            cur += ch
+        i += 1
+    if cur.strip():
+        args.append(cur)
+    return args
+
+
+def test_every_ffi_call_site_passes_the_declared_number_of_arguments():
+    """rustc would refuse a call with the wrong arity; here the call sites of the crate are counted against ffi.rs."""
+    rf, _, _ = parse_rust()
+    src_dir = os.path.dirname(FFI)
+    calls = 0
+    problems = []
+    for fn in sorted(os.listdir(src_dir)):
+        if not fn.endswith(".rs") or fn == "ffi.rs":
+            continue
+        src = strip_comments(open(os.path.join(src_dir, fn)).read())
+        for m in re.finditer(r"\b(rgr_\w+)\s*\(", src):
+            name = m.group(1)
+            if name not in rf:
+                if re.search(r"\b(struct|type)\s+" + name + r"\b", src) or name in ("rgr_config", "rgr_result", "rgr_retain_result", "rgr_publish_attr", "rgr_tuple"):
+                    continue
+                problems.append(f"{fn}: calls {name}, which ffi.rs does not declare")
+                continue
+            args = _call_args(src, m.end() - 1)
+            calls += 1
+            if len(args) != len(rf[name][1]):
+                problems.append(f"{fn}: {name} called with {len(args)} arguments, declared with {len(rf[name][1])}")
+    assert calls >= 20
+    assert not problems, "\n".join(problems)
