@@ -219,3 +219,26 @@ def test_every_ffi_call_site_passes_the_declared_number_of_arguments():
                 problems.append(f"{fn}: {name} called with {len(args)} arguments, declared with {len(rf[name][1])}")
     assert calls >= 20
     assert not problems, "\n".join(problems)
+
+
+def test_rust_sources_are_bracket_balanced():
+    """The cheapest syntax check available without rustc: (), [] and {} balance in every source file of the crate
+    (comments, string and char literals removed)."""
+    src_dir = os.path.dirname(FFI)
+    pairs = {")": "(", "]": "[", "}": "{"}
+    for fn in sorted(os.listdir(src_dir)):
+        if not fn.endswith(".rs"):
+            continue
+        src = strip_comments(open(os.path.join(src_dir, fn)).read())
+        src = re.sub(r'r#"(?:.|\n)*?"#', '""', src)                      # raw strings
+        src = re.sub(r'"(?:\\.|[^"\\])*"', '""', src)                    # string literals
+        src = re.sub(r"'(?:\\.|[^'\\])'", "' '", src)                    # char literals (lifetimes have no closing quote)
+        stack = []
+        for ln, line in enumerate(src.split("\n"), 1):
+            for ch in line:
+                if ch in "([{":
+                    stack.append((ch, ln))
+                elif ch in ")]}":
+                    assert stack and stack[-1][0] == pairs[ch], f"{fn}:{ln}: unmatched {ch!r}"
+                    stack.pop()
+        assert not stack, f"{fn}: {stack[-1][0]!r} opened at line {stack[-1][1]} is never closed"
