@@ -9,6 +9,8 @@ O=gpurun_out/r3a
 mkdir -p $O
 ( timeout 900 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log ); tail -3 $O/pytest_gpu.log
 ( timeout 200 python __graft_entry__.py smoke > $O/smoke.log 2>&1 ); tail -1 $O/smoke.log
+# maximum MQTT sizes (65 535-byte levels, 32 768-level topics, 2^14-way forks) through the HIP path: so far emulator only
+( RMQTT_MAX_SIZES_BACKEND=hip timeout 300 python -m pytest tests/test_max_sizes_cpu.py -q -m gpu > $O/pytest_max_sizes_hip.log 2>&1 ); tail -2 $O/pytest_max_sizes_hip.log
 [ -x tools/walk_lab ] || hipcc --offload-arch=gfx950 -O3 -std=c++17 -I rmqtt_amd/csrc -I include tools/walk_lab.hip rmqtt_amd/csrc/table.cpp \
     rmqtt_amd/csrc/workload.cpp -o tools/walk_lab -pthread
 ( timeout 300 tools/walk_lab 10000000 2000000 0.028 0.1 5 ) > $O/walk_lab_config3_size.txt 2>&1; cat $O/walk_lab_config3_size.txt
