@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <mutex>
 
 namespace rmqtt {
@@ -238,6 +239,7 @@ Result<Bytes> lz4_block(const uint8_t* p, size_t n) {
     using R = Result<Bytes>;
     if (n < 4) return R::Err("lz4: no size prefix");
     const size_t want = size_t(p[0]) | size_t(p[1]) << 8 | size_t(p[2]) << 16 | size_t(p[3]) << 24;
+    if (want > (n - 4) * 255 + 64) return R::Err("lz4: size prefix larger than this block can expand to");   // a match extends by at most 255 per byte
     Bytes out;
     out.reserve(want);
     size_t i = 4;
@@ -480,7 +482,7 @@ uint64_t le64(const uint8_t* p) {
 
 }  // namespace
 
-Result<std::vector<uint8_t>> uncompress(Compression c, const uint8_t* p, size_t n) {
+static Result<std::vector<uint8_t>> uncompress_impl(Compression c, const uint8_t* p, size_t n) {
     switch (c) {
         case Compression::None: return Result<Bytes>::Ok(Bytes(p, p + n));
         case Compression::Zstd: return zstd_stream(p, n);
@@ -491,7 +493,13 @@ Result<std::vector<uint8_t>> uncompress(Compression c, const uint8_t* p, size_t 
     return Result<Bytes>::Err("unknown compression " + std::to_string(int(c)));
 }
 
-Result<Snapshot> decode_snapshot(const uint8_t* p, size_t n, Compression comp, Features f) {
+// allocation failures (a crafted length can ask for gigabytes) come back as Err like everything else
+Result<std::vector<uint8_t>> uncompress(Compression c, const uint8_t* p, size_t n) {
+    try { return uncompress_impl(c, p, n); }
+    catch (const std::exception& e) { return Result<Bytes>::Err(std::string("uncompress: ") + e.what()); }
+}
+
+static Result<Snapshot> decode_snapshot_impl(const uint8_t* p, size_t n, Compression comp, Features f) {
     using R = Result<Snapshot>;
     // router.rs:512-531: [len][relations][len][client_states][len][topics_count][len][relations_count]
     const uint8_t* sec[4];
@@ -550,6 +558,11 @@ Result<Snapshot> decode_snapshot(const uint8_t* p, size_t n, Compression comp, F
         if (!read_counter(r, s == 2 ? snap.topics_count : snap.relations_count)) return R::Err(r.err);
     }
     return R::Ok(std::move(snap));
+}
+
+Result<Snapshot> decode_snapshot(const uint8_t* p, size_t n, Compression comp, Features f) {
+    try { return decode_snapshot_impl(p, n, comp, f); }
+    catch (const std::exception& e) { return Result<Snapshot>::Err(std::string("decode_snapshot: ") + e.what()); }
 }
 
 }  // namespace raft

@@ -324,6 +324,8 @@ def test_lz4_details(L):
     assert cpp_uncompress(L, struct.pack("<I", 10) + bytes([0x14, ord("a"), 5, 0]), rs.LZ4) is None   # offset before the start
     assert cpp_uncompress(L, struct.pack("<I", 10) + bytes([0xF0, 255]), rs.LZ4) is None        # literal length runs off the end
     assert cpp_uncompress(L, b"\x01\x00", rs.LZ4) is None                                        # no size prefix
+    assert cpp_uncompress(L, struct.pack("<I", 0xFFFFFFFF) + b"\x10a", rs.LZ4) is None             # a prefix no 2-byte block can expand to
+    assert b"size prefix" in L.rs_last_error()
 
 
 def test_snappy_details(L):
