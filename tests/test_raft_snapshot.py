@@ -525,3 +525,33 @@ def test_restore_on_the_router_mirror_matches_oracle(L, devices):
         t = "/".join(rng.choice(levels if i == 0 else levels[:4]) for i in range(rng.randint(1, 5)))
         matches(o, 1, "cl1", 0, t)
     L.hr_free(g)
+
+
+# ---------------------------------------------------------------------------------------------
+# property-based: arbitrary strings / integers at the edges of every field
+# ---------------------------------------------------------------------------------------------
+from hypothesis import HealthCheck, given, settings, strategies as st   # noqa: E402
+
+_text = st.text(max_size=12)
+_addr = st.one_of(st.none(),
+                  st.tuples(st.just("v4"), st.tuples(*[st.integers(0, 255)] * 4), st.integers(0, 65535)),
+                  st.tuples(st.just("v6"), st.tuples(*[st.integers(0, 255)] * 16), st.integers(0, 65535)))
+_id = st.fixed_dictionaries(dict(node_id=st.integers(0, 2**64 - 1), lid=st.integers(0, 65535), local_addr=_addr, remote_addr=_addr, client_id=_text,
+                                 username=st.one_of(st.none(), _text), create_time=st.integers(-2**63, 2**63 - 1)))
+_opts = st.one_of(
+    st.fixed_dictionaries(dict(v5=st.just(False), qos=st.integers(0, 2), shared_group=st.one_of(st.none(), _text), limit_subs=st.one_of(st.none(), st.integers(0, 2**64 - 1)),
+                               no_local=st.just(False), rap=st.just(False), rh=st.just(0), sub_ident=st.none())),
+    st.fixed_dictionaries(dict(v5=st.just(True), qos=st.integers(0, 2), shared_group=st.one_of(st.none(), _text), limit_subs=st.one_of(st.none(), st.integers(0, 2**64 - 1)),
+                               no_local=st.booleans(), rap=st.booleans(), rh=st.integers(0, 2), sub_ident=st.one_of(st.none(), st.integers(1, 2**32 - 1)))))
+_relations = st.lists(st.tuples(_text, st.lists(st.tuples(_text, _id, _opts), max_size=3)), max_size=5)
+_states = st.lists(st.tuples(_text, _id, st.booleans(), st.booleans(), st.integers(-2**63, 2**63 - 1)), max_size=3)
+_counter = st.tuples(st.integers(-2**63, 2**63 - 1), st.integers(-2**63, 2**63 - 1), st.integers(0, 4))
+
+
+@settings(max_examples=400, deadline=None, derandomize=True, suppress_health_check=list(HealthCheck))
+@given(relations=_relations, states=_states, tc=_counter, rc=_counter, features=st.sampled_from([0, 1, 2, 3]), compression=st.sampled_from([rs.NONE, rs.ZLIB, rs.LZ4, rs.SNAPPY]))
+def test_reader_property(L, relations, states, tc, rc, features, compression):
+    snap = rs.encode_snapshot(relations, states, tc, rc, compression=compression, features=features)
+    want = rs.dump(relations, states, tc, rc, features=features)
+    assert cpp_dump(L, snap, compression, features) == want
+    assert rs.dump(*rs.decode_snapshot(snap, compression, features), features=features) == want
