@@ -189,6 +189,63 @@ static CsrImage build_csr(const HostTable& table) {
     return img;
 }
 
+// ---- A': the product's walk with a 64-bit child-token bitmap in the header instead of (lit_cnt, lit_xor): bit (mix(token) & 63)
+// is set for every literal child, so a probe is skipped whenever the topic's token maps to a clear bit — exact (a set bit only
+// means "maybe").  Host-side counting only for now: how many of A's dead-end probes would it remove?
+RGR_HD inline uint32_t bits_slot(uint32_t tok) { uint32_t x = tok * 0x9E3779B1u; return (x >> 26) & 63u; }
+template <class TokAt, class PathGet, class PathSet, class Emit, class Load>
+RGR_HD inline uint32_t walk_topic_bits(const NodeHeader& root, uint64_t root_bits, uint32_t mask, uint32_t L, bool meta, TokAt tok_at, PathGet path_get,
+                                       PathSet path_set, Emit emit, Load load) {
+    enum : int { kArrive = 0, kPop = 1, kProbe = 2, kDirect = 3 };
+    uint32_t visited = 0, node = 0, d = 0;
+    NodeHeader h = root;
+    uint64_t bits = root_bits;
+    int mode = kArrive;
+    int64_t scan = -1;
+    uint32_t slot = 0, want_parent = 0, want_tok = 0;
+    for (;;) {
+        if (mode == kArrive) {
+            visited++;
+            if (d == L) {
+                if (h.term_fid != kNone) emit(h.term_fid);
+                if (h.hash_fid != kNone) emit(h.hash_fid);
+                mode = kPop; scan = int64_t(d) - 1;
+            } else {
+                const bool wild = !(d == 0 && meta);
+                if (wild && h.hash_fid != kNone) emit(h.hash_fid);
+                const uint32_t tk = tok_at(d);
+                const bool ex = tk != kTokUnknown && (tk < kTokFirst || ((bits >> bits_slot(tk)) & 1ull));
+                const bool pl = wild && h.plus_slot != kNone;
+                if (pl) { path_set(d, ex ? node : kNone); slot = h.plus_slot; mode = kDirect; }
+                else if (ex) { path_set(d, kNone); want_parent = node; want_tok = tk; slot = edge_hash(node, tk) & mask; mode = kProbe; }
+                else { path_set(d, kNone); mode = kPop; scan = int64_t(d) - 1; }
+            }
+        }
+        if (mode == kPop) {
+            uint32_t pn = kNone;
+            int64_t s = scan;
+            for (; s >= 0; --s) { pn = path_get(uint32_t(s)); if (pn != kNone) break; }
+            if (s < 0) break;
+            path_set(uint32_t(s), kNone);
+            d = uint32_t(s);
+            want_parent = pn; want_tok = tok_at(d);
+            slot = edge_hash(pn, want_tok) & mask; mode = kProbe;
+        }
+        U4 e0, e1;
+        load(slot, e0, e1);
+        if (mode == kProbe) {
+            if (e0.x == kEdgeEmpty) { mode = kPop; scan = int64_t(d) - 1; continue; }
+            if (e0.x != want_parent || e0.y != want_tok) { slot = (slot + 1) & mask; continue; }
+        }
+        node = e0.z;
+        h.plus_slot = e0.w; h.hash_fid = e1.x; h.term_fid = e1.y;
+        bits = uint64_t(e1.z) | uint64_t(e1.w) << 32;
+        d += 1;
+        mode = kArrive;
+    }
+    return visited;
+}
+
 // ---- B: wave per topic, level-synchronous frontier in LDS, ballot / prefix-popcount compaction
 constexpr int kWavesPerBlock = 4;
 constexpr int kFrontierCap = 256;     // nodes per level per topic (chunks of 64 lanes); beyond this the topic is flagged
@@ -288,19 +345,41 @@ int main(int argc, char** argv) {
     if (host_only) {
         // the per-lane functions of A and C on the host: identical counts, and how many dependent 32-byte reads each needs
         const uint32_t mask = uint32_t(edges.size() - 1);
-        uint64_t sa = 0, sc = 0, diff = 0, reads_a = 0, reads_c = 0, walked = 0;
+        uint64_t sa = 0, sc = 0, diff = 0, reads_a = 0, reads_c = 0, walked = 0, visited_a = 0, reads_b = 0, diff_bits = 0;
+        // child-token bitmaps per node (A'): from the edge records
+        std::vector<uint64_t> bits(size_t(table.n_nodes()) + 1 + 64, 0);
+        {
+            uint32_t max_node = 0;
+            for (size_t sl = 0; sl < edges.size(); ++sl) { const U4* h = reinterpret_cast<const U4*>(&edges[sl]); if (h[0].x != kEdgeEmpty && h[0].x != kEdgeTomb) max_node = std::max(max_node, std::max(h[0].x, h[0].z)); }
+            bits.assign(size_t(max_node) + 1, 0);
+            for (size_t sl = 0; sl < edges.size(); ++sl) {
+                const U4* h = reinterpret_cast<const U4*>(&edges[sl]);
+                if (h[0].x == kEdgeEmpty || h[0].x == kEdgeTomb || h[0].y < kTokFirst) continue;
+                bits[h[0].x] |= 1ull << bits_slot(h[0].y);
+            }
+        }
         for (uint64_t t = 0; t < n_pub; ++t) {
             const uint32_t L = uint32_t(toff[t + 1] - toff[t]);
             if ((flags[t] & kTopicInvalid) || L > 24) continue;
             const uint32_t* tk = toks.data() + toff[t];
             uint32_t path[48], ca = 0, ra = 0, rc = 0;
-            walk_topic(
+            visited_a += walk_topic(
                 table.root_header(), mask, L, (flags[t] & kTopicMeta) != 0, [&](uint32_t d) { return tk[d]; }, [&](uint32_t d) { return path[d]; },
                 [&](uint32_t d, uint32_t v) { path[d] = v; }, [&](uint32_t) { ca++; },
                 [&](uint32_t slot, U4& e0, U4& e1) { const U4* h = reinterpret_cast<const U4*>(&edges[slot]); e0 = h[0]; e1 = h[1]; ra++; });
             const uint32_t cc = walk_csr_topic(
                 csr.root, L, (flags[t] & kTopicMeta) != 0, [&](uint32_t d) { return tk[d]; }, [&](uint32_t i) { return path[i]; },
                 [&](uint32_t i, uint32_t v) { path[i] = v; }, [&](uint32_t i) { return csr.recs[i]; }, &rc);
+            uint32_t cb2 = 0, rb = 0;
+            walk_topic_bits(
+                table.root_header(), bits[0], mask, L, (flags[t] & kTopicMeta) != 0, [&](uint32_t d) { return tk[d]; }, [&](uint32_t d) { return path[d]; },
+                [&](uint32_t d, uint32_t v) { path[d] = v; }, [&](uint32_t) { cb2++; },
+                [&](uint32_t slot, U4& e0, U4& e1) {
+                    const U4* h = reinterpret_cast<const U4*>(&edges[slot]);
+                    e0 = h[0]; e1 = h[1]; rb++;
+                    if (e0.x != kEdgeEmpty && e0.x != kEdgeTomb) { e1.z = uint32_t(bits[e0.z]); e1.w = uint32_t(bits[e0.z] >> 32); }
+                });
+            diff_bits += cb2 != ca; reads_b += rb;
             sa += ca; sc += cc; diff += ca != cc; reads_a += ra; reads_c += rc; walked++;
         }
         std::printf("table: %llu subs (p_plus %.3f, p_hash %.2f), %llu trie nodes, %llu edge slots (%.1f MiB), CSR %llu records (%.1f MiB); %llu topics\n",
@@ -310,7 +389,13 @@ int main(int argc, char** argv) {
                     (unsigned long long)sc, (unsigned long long)diff);
         std::printf("dependent 32-byte record reads per topic: A %.2f, C %.2f (C / A = %.2f)\n", double(reads_a) / walked, double(reads_c) / walked,
                     double(reads_c) / double(reads_a));
-        return diff != 0;
+        // A: every visited node except the root costs one successful read; the rest are probes that ended on an empty slot
+        // (the child does not exist and the header's miss filter could not tell) or stepped over a colliding record
+        std::printf("A: %.2f visited nodes per topic, %.2f reads that found their record, %.2f that did not (%.0f %% of the reads)\n", double(visited_a) / walked,
+                    double(visited_a - walked) / walked, double(reads_a - (visited_a - walked)) / walked, 100.0 * double(reads_a - (visited_a - walked)) / double(reads_a));
+        std::printf("A' (64-bit child-token bitmap as the miss filter): %.2f reads per topic (%.2f x A), topics that differ %llu\n", double(reads_b) / walked,
+                    double(reads_b) / double(reads_a), (unsigned long long)diff_bits);
+        return diff != 0 || diff_bits != 0;
     }
     EdgeEntry* d_edges; uint32_t *d_tok, *d_ca, *d_cb, *d_ovf; uint64_t* d_off; uint8_t* d_fl;
     CHECK(hipMalloc(&d_edges, edges.size() * sizeof(EdgeEntry)));
