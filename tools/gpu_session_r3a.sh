@@ -4,6 +4,8 @@
 #      through the PRODUCT (RGR_EDGE_SLOTS_PER_NODE is read by HostTable::materialize_edges) at config 2 and config 3
 #   3. gather rate vs table size (is the walk's 38.9 G gathers/s ceiling a property of HBM or of the 16 GiB table the
 #      calibration used?)
+#   0. (before this session) `git merge next/bitmap-miss-filter`: the 64-bit child-token bitmap miss filter, CPU-verified only;
+#      step 1 is then its GPU validation and step 2's config-2 line its measurement (walk 0.585 ms per 1 M topics before)
 set -u
 O=gpurun_out/r3a
 mkdir -p $O
