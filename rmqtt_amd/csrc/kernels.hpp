@@ -37,12 +37,15 @@ struct alignas(16) EdgeEntry {
     uint32_t plus_slot;   // slot of the child's '+' edge record, kNone if none
     uint32_t hash_fid;    // filter id of "<child>/#", kNone if none
     uint32_t term_fid;    // filter id ending at <child>, kNone if none
-    uint32_t lit_cnt;     // number of literal (non-wildcard) edges leaving <child>
-    uint32_t lit_xor;     // XOR of their tokens: the sole literal edge's token when lit_cnt == 1
+    uint32_t lit_lo;      // 64-bit bitmap over the literal (non-wildcard) edges leaving <child>: bit lit_bit(token) is set for
+    uint32_t lit_hi;      // every such edge.  A clear bit proves the edge absent (no probe); a set bit means "maybe"
 };
+// Which bit of the child-token bitmap a level token maps to.  (r3: replaces {lit_cnt, lit_xor}, which was exact only for nodes
+// with at most one literal child: 32 % of the walk's record reads were probes for children that do not exist.)
+RGR_HD inline uint32_t lit_bit(uint32_t token) { return (token * 0x9E3779B1u) >> 26; }
 static_assert(sizeof(EdgeEntry) == 32, "edge record is one 32-byte sector");
 
-struct NodeHeader { uint32_t plus_slot, hash_fid, term_fid, lit_cnt, lit_xor; };
+struct NodeHeader { uint32_t plus_slot, hash_fid, term_fid, lit_lo, lit_hi; };
 
 struct FilterDesc { uint32_t begin, count; };
 struct SubEntry { uint32_t sub_id, qos_flags; };

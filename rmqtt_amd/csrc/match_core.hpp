@@ -232,11 +232,11 @@ RGR_HD inline uint32_t walk_topic(const NodeHeader& root, uint32_t mask, uint32_
                 const bool wild = !(d == 0 && meta);
                 if (wild && h.hash_fid != kNone) emit(h.hash_fid);      // trie.rs:349-355
                 const uint32_t tk = tok_at(d);
-                // miss filter: the header knows how many literal edges leave this node and, when
-                // there is exactly one, its token — most dead-end probes are skipped.  Wildcard
-                // tokens in a publish topic (tk < kTokFirst) always probe (App. A.4 quirk).
-                const bool ex = tk != kTokUnknown &&
-                                (tk < kTokFirst || (h.lit_cnt != 0 && (h.lit_cnt != 1 || h.lit_xor == tk)));
+                // miss filter: the header carries a 64-bit bitmap of the literal edges that leave this node; a clear bit
+                // proves there is no such child, so dead-end probes are (almost all) skipped.  Wildcard tokens in a
+                // publish topic (tk < kTokFirst) always probe (App. A.4 quirk).
+                const uint32_t lb = lit_bit(tk);
+                const bool ex = tk != kTokUnknown && (tk < kTokFirst || (((lb & 32u) ? h.lit_hi : h.lit_lo) >> (lb & 31u)) & 1u);
                 const bool pl = wild && h.plus_slot != kNone;
                 if (pl) {                                                // trie.rs:358-362
                     path_set(d, ex ? node : kNone);                      // exact lookup deferred
@@ -268,7 +268,7 @@ RGR_HD inline uint32_t walk_topic(const NodeHeader& root, uint32_t mask, uint32_
             if (e0.x != want_parent || e0.y != want_tok) { slot = (slot + 1) & mask; continue; }
         }
         node = e0.z;
-        h.plus_slot = e0.w; h.hash_fid = e1.x; h.term_fid = e1.y; h.lit_cnt = e1.z; h.lit_xor = e1.w;
+        h.plus_slot = e0.w; h.hash_fid = e1.x; h.term_fid = e1.y; h.lit_lo = e1.z; h.lit_hi = e1.w;
         d += 1;
         mode = kArrive;
     }

@@ -150,14 +150,22 @@ void HostTable::rehash(uint64_t new_cap) {
     }
     edge_used_ = edge_live_;
     delta_.relocated = true;
-    // slots moved: re-point every header's plus_slot
+    // slots moved: re-point every header's plus_slot; the child-token bitmaps are rebuilt from the live edges (drops stale bits)
     for (EdgeEntry& e : edges_) {
         if (e.parent == kEdgeEmpty) continue;
         const uint32_t pc = nodes_[e.child].plus_child;
         e.plus_slot = pc == kNone ? kNone : nodes_[pc].slot;
+        e.lit_lo = e.lit_hi = 0;
     }
     const uint32_t rp = nodes_[0].plus_child;
     root_hdr_.plus_slot = rp == kNone ? kNone : nodes_[rp].slot;
+    root_hdr_.lit_lo = root_hdr_.lit_hi = 0;
+    for (const EdgeEntry& e : edges_) {
+        if (e.parent == kEdgeEmpty || e.token < kTokFirst) continue;
+        const uint32_t b = lit_bit(e.token), m = 1u << (b & 31u);
+        if (e.parent == 0) ((b & 32u) ? root_hdr_.lit_hi : root_hdr_.lit_lo) |= m;
+        else { EdgeEntry& p = edges_[nodes_[e.parent].slot]; ((b & 32u) ? p.lit_hi : p.lit_lo) |= m; }
+    }
 }
 
 uint32_t HostTable::insert_edge(uint32_t parent, uint32_t token, uint32_t child) {
@@ -194,11 +202,16 @@ void HostTable::set_plus_slot(uint32_t node, uint32_t slot) {
 void HostTable::set_hash_fid(uint32_t node, uint32_t fid) {
     if (node == 0) root_hdr_.hash_fid = fid; else { edges_[nodes_[node].slot].hash_fid = fid; touch(nodes_[node].slot); }
 }
+// Child-token bitmap of `node`'s header.  A new literal edge sets its bit; a removed one leaves it (another child may share
+// the bit, and a stale bit only costs the walk one probe) — rehash() and the bulk build recompute the bitmaps exactly.
 void HostTable::literal_edge(uint32_t node, uint32_t token, int delta) {
-    uint32_t& cnt = node == 0 ? root_hdr_.lit_cnt : edges_[nodes_[node].slot].lit_cnt;
-    uint32_t& x = node == 0 ? root_hdr_.lit_xor : edges_[nodes_[node].slot].lit_xor;
-    cnt += uint32_t(delta);
-    x ^= token;
+    if (delta <= 0) return;
+    const uint32_t b = lit_bit(token);
+    uint32_t& w = node == 0 ? ((b & 32u) ? root_hdr_.lit_hi : root_hdr_.lit_lo)
+                            : ((b & 32u) ? edges_[nodes_[node].slot].lit_hi : edges_[nodes_[node].slot].lit_lo);
+    const uint32_t m = 1u << (b & 31u);
+    if (w & m) return;
+    w |= m;
     if (node != 0) touch(nodes_[node].slot);
 }
 void HostTable::set_term_fid(uint32_t node, uint32_t fid) {
@@ -431,11 +444,11 @@ void HostTable::subscribe_bulk(const uint8_t* blob, const uint64_t* offs, uint64
     // materialised once at the end (sequential pass with software prefetch) instead of 2 random
     // DRAM accesses per created node.
     const bool deferred = n_nodes_ == 1 && edge_live_ == 0;
-    std::vector<uint32_t> lit_cnt, lit_xor;
+    std::vector<uint64_t> lit_bits;       // per node: child-token bitmap (kernels.hpp lit_bit)
     if (deferred) {
-        lit_cnt.assign(nodes_.size(), 0); lit_xor.assign(nodes_.size(), 0);
+        lit_bits.assign(nodes_.size(), 0);
         nodes_.reserve(nodes_.size() + new_nodes_total);
-        lit_cnt.reserve(nodes_.size() + new_nodes_total); lit_xor.reserve(nodes_.size() + new_nodes_total);
+        lit_bits.reserve(nodes_.size() + new_nodes_total);
         filters_.reserve(n_filters_ + idx.size());
     } else {
         reserve(n_filters_ + idx.size(), n_nodes_ + 2 * new_nodes_total);
@@ -447,12 +460,12 @@ void HostTable::subscribe_bulk(const uint8_t* blob, const uint64_t* offs, uint64
         }
         const uint32_t id = uint32_t(nodes_.size());
         nodes_.push_back(Node{parent, tok, kNone, 0, kNone, kNone, kNone});
-        lit_cnt.push_back(0); lit_xor.push_back(0);
+        lit_bits.push_back(0);
         nodes_[parent].nchild++;
         n_nodes_++;
         if (tok == kTokPlus) nodes_[parent].plus_child = id;
         else if (tok == kTokHash) nodes_[parent].hash_child = id;
-        else { lit_cnt[parent]++; lit_xor[parent] ^= tok; }
+        else lit_bits[parent] |= 1ull << lit_bit(tok);
         return id;
     };
     std::vector<uint32_t> path{0};                   // path[l] = node reached after l levels of the previous filter
@@ -487,14 +500,14 @@ void HostTable::subscribe_bulk(const uint8_t* blob, const uint64_t* offs, uint64
         if (fids_out) fids_out[i] = fid;
     }
     lap("insert");
-    if (deferred) materialize_edges(lit_cnt, lit_xor);
+    if (deferred) materialize_edges(lit_bits);
     lap("materialise");
     if (fids_out) for (uint64_t i = 0; i < n; ++i) if (!valid[i]) fids_out[i] = kNone;
     if (n_rejected) *n_rejected = rejected;
 }
 
 // Build the whole edge table from the node array (bulk restore into an empty table).
-void HostTable::materialize_edges(const std::vector<uint32_t>& lit_cnt, const std::vector<uint32_t>& lit_xor) {
+void HostTable::materialize_edges(const std::vector<uint64_t>& lit_bits) {
     // load <= 0.25 by default: short probe sequences for the walk kernel.  RGR_EDGE_SLOTS_PER_NODE (2..16) trades probe
     // length against footprint — a denser table may stay resident in the 256 MiB Infinity Cache (tools/walk_lab)
     uint64_t per_node = 4;
@@ -531,7 +544,7 @@ void HostTable::materialize_edges(const std::vector<uint32_t>& lit_cnt, const st
         Node& nd = nodes_[id];
         uint32_t i = edge_hash(nd.parent, nd.token) & mask;
         while (edges_[i].parent != kEdgeEmpty) i = (i + 1) & mask;
-        edges_[i] = EdgeEntry{nd.parent, nd.token, id, kNone, hdr_hash_fid(id), nd.term_fid, lit_cnt[id], lit_xor[id]};
+        edges_[i] = EdgeEntry{nd.parent, nd.token, id, kNone, hdr_hash_fid(id), nd.term_fid, uint32_t(lit_bits[id]), uint32_t(lit_bits[id] >> 32)};
         nd.slot = i;
     }
     lap("fill");
@@ -540,7 +553,7 @@ void HostTable::materialize_edges(const std::vector<uint32_t>& lit_cnt, const st
         edges_[nodes_[id].slot].plus_slot = nodes_[nodes_[id].plus_child].slot;
     }
     root_hdr_ = NodeHeader{nodes_[0].plus_child == kNone ? kNone : nodes_[nodes_[0].plus_child].slot, hdr_hash_fid(0), nodes_[0].term_fid,
-                           lit_cnt[0], lit_xor[0]};
+                           uint32_t(lit_bits[0]), uint32_t(lit_bits[0] >> 32)};
     edge_live_ = edge_used_ = n_nodes_ - 1;
     delta_.relocated = true;
 }
@@ -564,6 +577,7 @@ uint64_t HostTable::max_filter_subs() const {
 // ------------------------------------------------------------------------------ snapshot file
 namespace {
 constexpr char kSnapMagic[8] = {'R', 'G', 'R', 'S', 'N', 'A', 'P', '1'};
+constexpr uint32_t kSnapVersion = 2;      // 2: the last 8 bytes of an edge record are the child-token bitmap (1: lit_cnt, lit_xor)
 struct SnapWriter {
     std::FILE* f;
     uint64_t sum = 0xcbf29ce484222325ull;
@@ -614,7 +628,7 @@ bool HostTable::save(const std::string& path, std::string* err) const {
     SnapWriter w{f};
     SnapHeader h{};
     std::memcpy(h.magic, kSnapMagic, 8);
-    h.version = 1; h.edge_bytes = sizeof(EdgeEntry); h.node_bytes = sizeof(Node); h.sub_bytes = sizeof(SubEntry);
+    h.version = kSnapVersion; h.edge_bytes = sizeof(EdgeEntry); h.node_bytes = sizeof(Node); h.sub_bytes = sizeof(SubEntry);
     h.n_filters = n_filters_; h.n_subs = n_subs_; h.n_nodes = n_nodes_; h.n_v5 = n_v5_; h.edge_used = edge_used_; h.edge_live = edge_live_;
     w.pod(h);
     dict_.save(w);
@@ -658,7 +672,7 @@ bool HostTable::load(const std::string& path, std::string* err) {
     r.left = uint64_t(size) - 8;
     SnapHeader h{};
     if (!r.pod(h) || std::memcmp(h.magic, kSnapMagic, 8) != 0) return bad("not a snapshot (bad magic)");
-    if (h.version != 1 || h.edge_bytes != sizeof(EdgeEntry) || h.node_bytes != sizeof(Node) || h.sub_bytes != sizeof(SubEntry))
+    if (h.version != kSnapVersion || h.edge_bytes != sizeof(EdgeEntry) || h.node_bytes != sizeof(Node) || h.sub_bytes != sizeof(SubEntry))
         return bad("snapshot of an incompatible build");
     const bool prof = std::getenv("RGR_BULK_PROFILE") != nullptr;
     auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };

@@ -212,7 +212,7 @@ class HostTable {
     void set_hash_fid(uint32_t node, uint32_t fid);
     void set_term_fid(uint32_t node, uint32_t fid);
     void literal_edge(uint32_t node, uint32_t token, int delta);
-    void materialize_edges(const std::vector<uint32_t>& lit_cnt, const std::vector<uint32_t>& lit_xor);
+    void materialize_edges(const std::vector<uint64_t>& lit_bits);
     uint32_t walk_existing(const std::vector<uint32_t>& toks) const;
 };
 

@@ -329,7 +329,7 @@ int32_t emu_match_deliver(void* ev, const uint8_t* blob, const uint64_t* offs, u
             [&](uint32_t slot, U4& e0, U4& e1) {
                 const EdgeEntry& en = tv.edges[slot];
                 e0 = U4{en.parent, en.token, en.child, en.plus_slot};
-                e1 = U4{en.hash_fid, en.term_fid, en.lit_cnt, en.lit_xor};
+                e1 = U4{en.hash_fid, en.term_fid, en.lit_lo, en.lit_hi};
             });
     };
     auto no_prefill = [](uint32_t, uint32_t, std::vector<uint32_t>&, std::vector<uint64_t>&, std::vector<uint32_t>&) {};

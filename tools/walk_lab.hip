@@ -69,6 +69,9 @@ __global__ __launch_bounds__(256) void walk_lane(TrieView tv, const uint32_t* __
     cnt_out[t] = cnt;
 }
 
+// the record's last two words (called lit_cnt / lit_xor in this file's structs) are the child-token bitmap halves of the product
+RGR_HD inline bool lit_has(uint32_t lo, uint32_t hi, uint32_t tk) { const uint32_t b = lit_bit(tk); return (((b & 32u) ? hi : lo) >> (b & 31u)) & 1u; }
+
 // ---- C: the same DFS over CSR children lists
 struct CsrRec { uint32_t token, child_begin, child_cnt, plus_idx, hash_fid, term_fid, lit_cnt, lit_xor; };   // 32 B
 static_assert(sizeof(CsrRec) == 32, "one record per trie node, the size of an edge record");
@@ -95,7 +98,7 @@ RGR_HD inline uint32_t walk_csr_topic(const CsrRoot& root, uint32_t L, bool meta
                 const bool wild = !(d == 0 && meta);
                 if (wild && hash_fid != kNone) cnt++;
                 const uint32_t tk = tok_at(d);
-                const bool ex = tk != kTokUnknown && (tk < kTokFirst || (lit_cnt != 0 && (lit_cnt != 1 || lit_xor == tk)));
+                const bool ex = tk != kTokUnknown && (tk < kTokFirst || lit_has(lit_cnt, lit_xor, tk));
                 const bool pl = wild && plus != kNone;
                 if (pl) {
                     // the exact lookup is deferred: remember the children range of this node (begin, count packed in two words)
@@ -185,14 +188,14 @@ static CsrImage build_csr(const HostTable& table) {
         img.recs[i] = CsrRec{es[i].token, first[child], cnt[child], plus_of(child), h[1].x, h[1].y, h[1].z, h[1].w};
     }
     const NodeHeader r = table.root_header();
-    img.root = CsrRoot{first[0], cnt[0], plus_of(0), r.hash_fid, r.term_fid, r.lit_cnt, r.lit_xor};
+    img.root = CsrRoot{first[0], cnt[0], plus_of(0), r.hash_fid, r.term_fid, r.lit_lo, r.lit_hi};
     return img;
 }
 
 // ---- A': the product's walk with a 64-bit child-token bitmap in the header instead of (lit_cnt, lit_xor): bit (mix(token) & 63)
 // is set for every literal child, so a probe is skipped whenever the topic's token maps to a clear bit — exact (a set bit only
 // means "maybe").  Host-side counting only for now: how many of A's dead-end probes would it remove?
-RGR_HD inline uint32_t bits_slot(uint32_t tok) { uint32_t x = tok * 0x9E3779B1u; return (x >> 26) & 63u; }
+RGR_HD inline uint32_t bits_slot(uint32_t tok) { return lit_bit(tok); }      // (the product adopted this filter: A' now only cross-checks A)
 template <class TokAt, class PathGet, class PathSet, class Emit, class Load>
 RGR_HD inline uint32_t walk_topic_bits(const NodeHeader& root, uint64_t root_bits, uint32_t mask, uint32_t L, bool meta, TokAt tok_at, PathGet path_get,
                                        PathSet path_set, Emit emit, Load load) {
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void walk_wave(TrieView tv, co
         const bool meta = (tflags[t] & kTopicMeta) != 0;
         int cur = 0;
         uint32_t width = 1;
-        if (lane == 0) s_f[w][0][0] = FNode{0, tv.root.plus_slot, tv.root.hash_fid, tv.root.term_fid, tv.root.lit_cnt, tv.root.lit_xor};
+        if (lane == 0) s_f[w][0][0] = FNode{0, tv.root.plus_slot, tv.root.hash_fid, tv.root.term_fid, tv.root.lit_lo, tv.root.lit_hi};
         for (uint32_t d = 0; d <= L && width; ++d) {
             uint32_t next_w = 0;
             const uint32_t tk = d < L ? tokens[off0 + d] : 0u;
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void walk_wave(TrieView tv, co
                             const uint4 e0 = ep[0], e1 = ep[1];
                             a = FNode{e0.z, e0.w, e1.x, e1.y, e1.z, e1.w}; has_a = true;
                         }
-                        const bool ex = tk != kTokUnknown && (tk < kTokFirst || (f.lit_cnt != 0 && (f.lit_cnt != 1 || f.lit_xor == tk)));
+                        const bool ex = tk != kTokUnknown && (tk < kTokFirst || lit_has(f.lit_cnt, f.lit_xor, tk));
                         if (ex) {                                                             // literal child: hash probe
                             for (uint32_t s = edge_hash(f.node, tk) & tv.mask;; s = (s + 1) & tv.mask) {
                                 const uint4* ep = reinterpret_cast<const uint4*>(tv.edges + s);
