@@ -1,10 +1,8 @@
 """Maximum sizes the wire format allows (an MQTT UTF-8 string is at most 65 535 bytes), through the product's host
 code and the kernels' per-lane functions on the CPU emulator, against the oracle: one 65 535-byte level, 32 768
 levels in one topic, blank levels only, 16-level-deep '+' chains that fork at every level (the 2^L case of
-trie.rs:301-409), and the same shapes on the retained path.  The hip twins of the ordinary edge cases live in
-test_parity.py / test_retain_parity.py; these sizes first run on hardware in the next GPU session
-(tools/gpu_session_r3a.sh runs this file with RMQTT_MAX_SIZES_BACKEND=hip)."""
-import os
+trie.rs:301-409), and the same shapes on the retained path.  Every case runs on both backends: `emu` in the CPU
+suite, `hip` (through the C ABI) under `-m gpu`."""
 import threading
 
 import numpy as np
@@ -13,8 +11,7 @@ import pytest
 from oracle import oracle as orc
 from tests.parity import Pair, make_backend, pack
 
-KIND = os.environ.get("RMQTT_MAX_SIZES_BACKEND", "emu")
-pytestmark = [pytest.mark.gpu] if KIND == "hip" else []
+BACKENDS = ["emu", pytest.param("hip", marks=pytest.mark.gpu)]
 
 MAXLEN = 65535
 
@@ -23,12 +20,12 @@ def on_big_stack(fn):
     """The ORACLE recurses once per topic level (the reference does too: Node::_insert / _remove, trie.rs:113-149, would
     need more than a tokio worker's 2 MiB stack for such a filter), so its calls run on a thread with a 1 GiB stack.
     The product's walk is iterative and does not care."""
-    def deco():
+    def deco(kind):
         box = {}
 
         def run():
             try:
-                fn()
+                fn(kind)
             except BaseException as e:      # noqa: BLE001 - re-raised on the test's thread
                 box["e"] = e
         old = threading.stack_size(1 << 30)
@@ -42,12 +39,12 @@ def on_big_stack(fn):
             raise box["e"]
     deco.__name__ = fn.__name__
     deco.__doc__ = fn.__doc__
-    return deco
+    return pytest.mark.parametrize("kind", BACKENDS)(deco)
 
 
 @on_big_stack
-def test_router_maximum_topic_and_filter_sizes():
-    p = Pair(KIND)
+def test_router_maximum_topic_and_filter_sizes(kind):
+    p = Pair(kind)
     one_level = "x" * MAXLEN                                      # a single level of the maximum length
     many_levels = "/".join(["a"] * 32768)                         # 32 768 levels, 65 535 bytes
     blanks = "/" * (MAXLEN)                                       # 65 536 blank levels
@@ -72,9 +69,10 @@ def test_router_maximum_topic_and_filter_sizes():
     assert np.diff(got["hit_offsets"]).tolist()[1] == 2           # '#' and 'a/#' are what is left for the deep topic
 
 
-def test_router_every_level_forks():
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_router_every_level_forks(kind):
     """'+' and the literal at every level: the walk visits 2^L nodes (L = 14: 16 384 matched filters for one topic)."""
-    p = Pair(KIND)
+    p = Pair(kind)
     L = 14
     n = 0
     for mask in range(1 << L):
@@ -89,8 +87,8 @@ def test_router_every_level_forks():
 
 
 @on_big_stack
-def test_retain_maximum_sizes():
-    b = make_backend(KIND)
+def test_retain_maximum_sizes(kind):
+    b = make_backend(kind)
     t = orc.RetainTree()
     topics = ["x" * MAXLEN, "/".join(["a"] * 32768), "/" * MAXLEN, "a", "/".join(["a"] * 32767), "$SYS/" + "y" * (MAXLEN - 5)]
     for i, tp in enumerate(topics):
@@ -111,13 +109,14 @@ def test_retain_maximum_sizes():
         t.remove(tp)
 
 
-def test_product_host_code_does_not_recurse_per_level():
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_product_host_code_does_not_recurse_per_level(kind):
     """The same deep filters through the product's table compiler and walk on a 256 KiB stack (a tokio worker has 2 MiB):
     insert, commit, match, remove + prune, retained add / match / remove — no per-level recursion anywhere."""
     out = {}
 
     def body():
-        b = make_backend(KIND)
+        b = make_backend(kind)
         deep, blanks = "/".join(["a"] * 32768), "/" * MAXLEN
         fids = []
         for i, f in enumerate([deep, blanks, "/".join(["+"] * 32768), "/".join(["a"] * 32767) + "/#"]):
