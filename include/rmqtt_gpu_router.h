@@ -116,7 +116,7 @@ typedef struct rgr_batch rgr_batch;
 typedef struct rgr_config {
     int32_t device;             /* HIP device ordinal                                   */
     uint32_t slot_cap;          /* matched-filter slots per topic before the overflow
-                                   arena is used (0 = default 32)                       */
+                                   arena is used (0 = default 64)                       */
     uint64_t window_hits;       /* capacity of one expansion window in hits
                                    (0 = default 2^28 => 3 GiB of tuples)                */
     uint32_t chunk_topics;      /* topics walked per pass (0 = default 2^21)            */

@@ -701,7 +701,7 @@ int32_t rgr_create(const rgr_config* cfg, rgr_handle** out) {
         auto h = std::make_unique<rgr_handle>();
         if (cfg) h->cfg = *cfg;
         if (h->cfg.device < 0 || h->cfg.device >= ndev) return fail(RGR_EDEVICE, "rgr_create: bad device ordinal");
-        if (!h->cfg.slot_cap) h->cfg.slot_cap = 32;
+        if (!h->cfg.slot_cap) h->cfg.slot_cap = 64;
         if (!h->cfg.window_hits) h->cfg.window_hits = 1ull << 28;
         if (!h->cfg.chunk_topics) h->cfg.chunk_topics = 1u << 21;
         RGR_HIP(hipSetDevice(h->cfg.device));

@@ -200,39 +200,35 @@ __global__ __launch_bounds__(kWalkThreads) void walk_kernel(TrieView tv, WalkArg
         const uint64_t rel = off0 - win_base;          // position of level 0 inside the window
         const uint64_t arena_base = OVF ? a.ovf_base[tl] : 0;
 
-        // LDS window first, HBM only beyond it.  Written as an unconditional ds_read (clamped index)
-        // plus a branch-guarded global load: a ?: over the two pointers makes hipcc emit flat_load,
-        // which sends LDS-resident reads through the vector-memory path.
-        // (hipcc lowers the LDS-or-HBM select below to flat_load; an explicit ds_read + guarded
-        // global_load variant miscompared on small batches and was dropped — see DESIGN.md §10.)
-        auto tok_at = [&](uint32_t d) -> uint32_t {
-            const uint64_t i = rel + d;
-            return (!OVF && i < staged) ? s_tok[i] : a.tokens[off0 + d];
-        };
-        auto path_get = [&](uint32_t d) -> uint32_t {
-            const uint64_t i = rel + d;
-            return (!OVF && i < staged) ? s_path[i] : a.path_scratch[off0 + d];
-        };
-        auto path_set = [&](uint32_t d, uint32_t v) {
-            const uint64_t i = rel + d;
-            if (!OVF && i < staged) s_path[i] = v; else a.path_scratch[off0 + d] = v;
-        };
         auto emit = [&](uint32_t fid) {
             if (OVF) { if (arena_base + cnt < a.ovf_arena_cap) a.ovf_arena[arena_base + cnt] = fid; }
             else if (cnt < a.slot_cap) a.slots[uint64_t(cnt) * a.n + tl] = fid;
             cnt++;
         };
-
+        const EdgeEntry* edges = tv.edges;
+        auto load = [&](uint32_t slot, U4& e0, U4& e1) {
+            const uint4* ep = reinterpret_cast<const uint4*>(edges + slot);
+            const uint4 a0 = ep[0], a1 = ep[1];
+            e0 = U4{a0.x, a0.y, a0.z, a0.w};
+            e1 = U4{a1.x, a1.y, a1.z, a1.w};
+        };
         if (!(fl & kTopicInvalid)) {
-            const EdgeEntry* edges = tv.edges;
-            visited = walk_topic(
-                tv.root, tv.mask, L, (fl & kTopicMeta) != 0, tok_at, path_get, path_set, emit,
-                [&](uint32_t slot, U4& e0, U4& e1) {
-                    const uint4* ep = reinterpret_cast<const uint4*>(edges + slot);
-                    const uint4 a0 = ep[0], a1 = ep[1];
-                    e0 = U4{a0.x, a0.y, a0.z, a0.w};
-                    e1 = U4{a1.x, a1.y, a1.z, a1.w};
-                });
+            // Tokens and DFS stack: the LDS window when the WHOLE topic lies inside it (the common case: 10 words per topic
+            // are staged), HBM otherwise.  The choice is made once per topic and the walk is instantiated twice, so the LDS
+            // instance reads with ds_read: a per-access `i < staged ? s_tok[i] : a.tokens[..]` is lowered to flat_load, which
+            // sends LDS-resident reads through the vector-memory path (r2: DESIGN.md §10).
+            const uint32_t rel32 = uint32_t(rel);
+            if (!OVF && rel + L <= uint64_t(staged)) {
+                visited = walk_topic(
+                    tv.root, tv.mask, L, (fl & kTopicMeta) != 0, [&](uint32_t d) { return s_tok[rel32 + d]; },
+                    [&](uint32_t d) { return s_path[rel32 + d]; }, [&](uint32_t d, uint32_t v) { s_path[rel32 + d] = v; }, emit, load);
+            } else {
+                const uint32_t* gtok = a.tokens + off0;
+                uint32_t* gpath = a.path_scratch + off0;
+                visited = walk_topic(
+                    tv.root, tv.mask, L, (fl & kTopicMeta) != 0, [&](uint32_t d) { return gtok[d]; }, [&](uint32_t d) { return gpath[d]; },
+                    [&](uint32_t d, uint32_t v) { gpath[d] = v; }, emit, load);
+            }
         }
         if (!OVF) {
             a.pair_cnt[tl] = cnt;
@@ -520,14 +516,61 @@ __global__ __launch_bounds__(kScanThreads) void scan_down_kernel(ChunkArrays c, 
 }
 
 // --------------------------------------------------------------------------- compact
-__global__ __launch_bounds__(256) void compact_kernel(TrieView tv, ChunkArrays c, uint32_t topic_base) {
-    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= c.n) return;
-    if (c.pair_cnt[t] > kBigPairs) {                       // -> compact_big_kernel (list built by count_kernel)
-        if (t == c.n - 1) c.pair_off[c.pair_base[c.n]] = c.hit_off[c.n];
-        return;
+// Dense (topic, subscriber-run) pairs of the chunk, in topic order.  One WAVE per 64 consecutive topics: their pairs
+// occupy ONE contiguous range [pair_base[t0], pair_base[t0+64]) of the pair arrays, so the wave stages them in LDS
+// (kCompactStage pairs per round; a lane deposits its topic's pairs at their final index relative to the round) and
+// writes every round out with fully coalesced stores.  (r3: the lane-per-topic version wrote 3 x 4-8 bytes per pair at
+// addresses ~16 pairs apart between neighbouring lanes — 1.84 ms per 2 M-topic chunk at config 3, bound by those
+// scattered stores, profiles/r02g_bench_config3_kernel_stats_rocprofv3.txt.)
+// Topics with more than kBigPairs matched filters are left to compact_big_kernel, which runs AFTER this kernel on the
+// same stream: whatever this kernel's write-out leaves in their ranges is overwritten there.
+#ifndef RGR_COMPACT_STAGE
+#define RGR_COMPACT_STAGE 512
+#endif
+constexpr int kCompactStage = RGR_COMPACT_STAGE;
+constexpr int kCompactWave = 64;
+__global__ __launch_bounds__(kCompactWave) void compact_kernel(TrieView tv, ChunkArrays c, uint32_t topic_base) {
+    __shared__ uint64_t s_off[kCompactStage];
+    __shared__ uint32_t s_src[kCompactStage];
+    __shared__ uint32_t s_topic[kCompactStage];
+    __shared__ uint8_t s_qr[kCompactStage];
+    const uint32_t t0 = blockIdx.x * kCompactWave;
+    const uint32_t t = t0 + threadIdx.x;
+    const uint32_t t1 = min(t0 + uint32_t(kCompactWave), c.n);
+    const uint64_t P0 = c.pair_base[t0], P1 = c.pair_base[t1];
+    const bool in = t < c.n;
+    const uint32_t cnt = in ? c.pair_cnt[t] : 0u;
+    const bool mine = in && cnt <= kBigPairs && c.pair_live[t] != 0;
+    uint64_t p = in ? c.pair_base[t] : P1;
+    uint64_t o = in ? c.hit_off[t] : 0;
+    uint32_t j = 0;
+    const uint32_t topic_val = !in ? 0u : c.topic_ids ? c.topic_ids[topic_base + t] : topic_base + t;
+    const uint8_t qr = (in && c.pair_qr) ? uint8_t(c.pub[topic_base + t].qos_retain) : uint8_t(0);
+    if (in && t == c.n - 1) c.pair_off[c.pair_base[c.n]] = c.hit_off[c.n];   // sentinel: total hits of the chunk
+    for (uint64_t w0 = P0; w0 < P1; w0 += kCompactStage) {
+        const uint64_t w1 = (P1 - w0) < uint64_t(kCompactStage) ? P1 : w0 + kCompactStage;
+        if (mine) {
+            while (j < cnt && p < w1) {                      // p >= w0: earlier rounds consumed everything below
+                const FilterDesc fd = tv.filt[pair_fid(c, t, cnt, j)];
+                ++j;
+                if (fd.count) {
+                    const uint32_t i = uint32_t(p - w0);
+                    s_src[i] = fd.begin; s_topic[i] = topic_val; s_off[i] = o;
+                    if (c.pair_qr) s_qr[i] = qr;
+                    ++p; o += fd.count;
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t m = uint32_t(w1 - w0);
+        for (uint32_t i = threadIdx.x; i < m; i += kCompactWave) {
+            c.pair_src[w0 + i] = s_src[i];
+            c.pair_topic[w0 + i] = s_topic[i];
+            c.pair_off[w0 + i] = s_off[i];
+            if (c.pair_qr) c.pair_qr[w0 + i] = s_qr[i];
+        }
+        __syncthreads();
     }
-    compact_topic(tv, c, topic_base, t);
 }
 
 // Order-preserving compaction of one long pair list by a whole block: 256 pairs per step, block
@@ -985,7 +1028,7 @@ void launch_scan(const ChunkArrays& c, uint64_t* block_tmp, void* stream) {
 void launch_compact(const TrieView& t, const ChunkArrays& c, uint32_t topic_base, void* stream) {
     if (c.n == 0) return;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    compact_kernel<<<(c.n + 255) / 256, 256, 0, s>>>(t, c, topic_base);
+    compact_kernel<<<(c.n + kCompactWave - 1) / kCompactWave, kCompactWave, 0, s>>>(t, c, topic_base);
     compact_big_kernel<<<512, 256, 0, s>>>(t, c, topic_base);
 }
 

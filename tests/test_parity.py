@@ -195,6 +195,33 @@ def test_long_pair_lists(kind):
     assert exp["hit_offsets"][1] > 600          # the first topic really has a long list
 
 
+def test_lds_window_boundary_small_batches(kind):
+    """The walk keeps a block's tokens and DFS stacks in an LDS window (10 words per topic) and takes them from HBM
+    for a topic that does not lie wholly inside it; the choice is per topic, so one wave runs both instances
+    (kernels.hip walk_kernel).  Small batches of every size around the block / wave sizes, with long topics mixed in
+    at varying positions so that the window ends inside, before and after them (r2: an explicit ds_read variant
+    miscompared on small batches — this is its regression test)."""
+    import random
+    rng = random.Random(77)
+    kw = dict(lds_window=24) if kind == "emu" else {}
+    p = Pair(kind, **kw)
+    fl = ["a/#", "a/+/c", "a/b/c", "+/b/#", "#", "a/b/c/d/e/f/g/h/i/j/k/l/m/n/o/p", "a/+/+/+/+/+/+/+/+/+/+/+/+/+/#", "+", "a", "a/b/+/d/+/f/#",
+          "/".join(["+"] * 30), "/".join(["a"] * 30), "/".join(["a"] * 29) + "/#", "b/+", "b/c/#"]
+    for i, f in enumerate(fl):
+        assert p.add(f, f"c{i}", i, qos=i % 3)
+    p.commit()
+    short = ["a/b/c", "a/x/c", "b/c", "b/c/d", "a", "x", "a/b", "a/b/c/d", "$SYS/x", ""]
+    long_ = ["/".join(["a"] * 30), "/".join(["a"] * 31), "a/b/c/d/e/f/g/h/i/j/k/l/m/n/o/p", "/".join(["a"] * 200), "a/" + "/".join(["q"] * 400),
+             "/".join(["a", "b"] * 15), "/".join(["a"] * 3000)]
+    for n in [1, 2, 3, 7, 31, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300, 511, 513]:
+        for frac in (0.0, 0.02, 0.3):
+            topics = [rng.choice(long_) if rng.random() < frac else rng.choice(short) for _ in range(n)]
+            if frac and n > 2:
+                topics[rng.randrange(n)] = long_[3]
+                topics[-1] = long_[1]
+            p.check(*pack(topics), what=f"n={n} long fraction {frac}")
+
+
 def test_matched_filter_order(kind):   # TopicTree::matches order incl. duplicates (App. A.2 / A.4)
     p = Pair(kind)
     fl = ["a/b", "a/#", "a/+", "+/b", "#", "+/#", "a/b/#", "+/+", "a/+/#", "test/+", "test/#"]
