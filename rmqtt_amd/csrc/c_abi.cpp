@@ -196,8 +196,7 @@ struct rgr_batch {
     int format = kFmtTuple;              // rgr_batch_set_format
     bool has_topic_ids = false;          // rgr_batch_set_topic_ids
     DevBuf d_topic_ids;
-    DevBuf d_pub, cand, cand_count, dedup_tab, topic_cand, cand_off, dedup_tmp;
-    PinnedBuf h_cand_count;
+    DevBuf d_pub, cand, cand_count, topic_cand, dedup_items, dedup_scalars;   // dedup_scalars: u64 candidates of the pass, u32 work-item count
     DevBuf rf_filter[2], rf_node[2], r_cnt, r_payload, r_ecnt, r_e0, r_e1, r_out_off, r_epos, r_end, r_depth;   // retain frontier rounds
     // pass state
     bool retain = false;             // batch of SUBSCRIBE filters against the retained-topic trie
@@ -1218,6 +1217,7 @@ int32_t rgr_batch_begin(rgr_batch* b) {
             cs.ready = false;
         }
         b->c = &b->cs[0];
+        if (b->dedup_scalars.p) RGR_HIP(hipMemsetAsync(b->dedup_scalars.p, 0, 16, b->stream));     // (a pass abandoned midway leaves its count behind)
         b->in_pass = true;
         b->cursor = 0;
         b->hits_before = 0;
@@ -1236,7 +1236,13 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
         rgr_handle* h = b->h;
         RGR_HIP(hipSetDevice(h->cfg.device));
         if (b->cursor >= b->n) {
+            unsigned long long n_cand = 0;
+            if (b->dedup_scalars.p) {                 // candidates the pass's dedup kernels saw (accumulated on the device)
+                RGR_HIP(hipMemcpyAsync(&n_cand, b->dedup_scalars.p, 8, hipMemcpyDeviceToHost, b->stream));
+                RGR_HIP(hipMemsetAsync(b->dedup_scalars.p, 0, 8, b->stream));
+            }
             RGR_HIP(hipStreamSynchronize(b->stream));
+            b->local.dedup_candidates += n_cand;
             RGR_HIP(hipGetLastError());
             b->resolve_spans();
             b->in_pass = false;
@@ -1296,10 +1302,9 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
                     const uint64_t ntl = (nh + T - 1) / T;
                     b->cand.ensure(ntl * T * sizeof(Cand));
                     b->cand_count.ensure(ntl * 4);                       // per-tile counts (every tile writes its own)
-                    b->h_cand_count.ensure(8);
                     b->topic_cand.ensure((size_t(nt) + 1) * 4);
-                    b->cand_off.ensure((size_t(nt) + 2) * 8);
-                    b->dedup_tmp.ensure((size_t(nt) / scan_block_topics() + 3) * 16);
+                    b->dedup_items.ensure((size_t(nt) + nh / dedup_topic_cap() + 2) * sizeof(DedupItem));
+                    if (!b->dedup_scalars.p) { b->dedup_scalars.ensure(16); RGR_HIP(hipMemsetAsync(b->dedup_scalars.p, 0, 16, b->stream)); }
                     RGR_HIP(hipMemsetAsync(b->topic_cand.p, 0, (size_t(nt) + 1) * 4, b->stream));
                     da.cand = b->cand.as<Cand>();
                     da.tile_ncand = b->cand_count.as<uint32_t>();
@@ -1319,25 +1324,13 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
             if (b->format != kFmtTuple) b->local.alg_bytes_expand -= nh * (b->format == kFmtSoa ? 7 : 8);
             b->local.expand_launches++;
             if (dedup) {
-                // the table is partitioned by topic and sized by the candidate counts: one stream sync per
-                // window, only in this mode
-                const uint32_t nt = le - lc;
+                // LDS tables (tile-local, then one block per spanning topic); stream-ordered, no host synchronisation
                 sp = b->span_begin(kSpanDedup);
-                launch_scan_u32(b->topic_cand.as<uint32_t>(), b->cand_off.as<uint64_t>(), nt, b->dedup_tmp.as<uint64_t>(), b->stream);
+                launch_dedup(b->cand.as<Cand>(), b->cand_count.as<uint32_t>(), uint32_t((nh + T - 1) / T), outbuf.as<Tuple>(), b->topic_cand.as<uint32_t>(),
+                             le - lc, b->c->hit_off.as<uint64_t>() + lc, hit_lo, b->dedup_items.as<DedupItem>(),
+                             reinterpret_cast<uint32_t*>(b->dedup_scalars.as<unsigned long long>() + 1), b->dedup_scalars.as<unsigned long long>(), b->stream);
                 b->span_end(sp);
-                RGR_HIP(hipMemcpyAsync(b->h_cand_count.p, b->cand_off.as<uint64_t>() + nt, 8, hipMemcpyDeviceToHost, b->stream));
-                RGR_HIP(hipStreamSynchronize(b->stream));
-                const uint64_t nc = *b->h_cand_count.as<uint64_t>();
-                if (nc) {
-                    b->dedup_tab.ensure(2 * nc * 8);
-                    sp = b->span_begin(kSpanDedup);
-                    RGR_HIP(hipMemsetAsync(b->dedup_tab.p, 0xFF, 2 * nc * 8, b->stream));
-                    launch_dedup(b->cand.as<Cand>(), b->cand_count.as<uint32_t>(), uint32_t((nh + T - 1) / T), outbuf.as<Tuple>(),
-                                 b->cand_off.as<uint64_t>(), b->dedup_tab.as<unsigned long long>(), b->stream);
-                    b->span_end(sp);
-                    b->local.dedup_candidates += nc;
-                    b->local.dedup_launches++;
-                }
+                b->local.dedup_launches++;
             }
         }
         w->topic_begin = b->cursor;

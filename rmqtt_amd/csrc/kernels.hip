@@ -892,40 +892,120 @@ __global__ __launch_bounds__(kCompactThreads) void expand_compact_kernel(const S
 }
 
 // --------------------------------------------------------------------------- v5 per-client dedup
-// types.rs:524-539: of a topic's v5 hits for one client the FIRST (in filter order = position
-// order) keeps filter + options, later ones only contribute their subscription identifier.
-// Pass 1 records the minimum position per (topic, client) in an open-addressed table, pass 2
-// flags every candidate that is not that minimum.
-constexpr unsigned long long kDedupEmpty = ~0ull;
-__global__ __launch_bounds__(256) void dedup_insert_kernel(const Cand* __restrict__ cand, const uint32_t* __restrict__ tile_ncand,
-                                                           const uint64_t* __restrict__ cand_off, unsigned long long* table) {
-    const uint32_t n = tile_ncand[blockIdx.x];
-    const Cand* mine_list = cand + uint64_t(blockIdx.x) * kTile;
+// types.rs:524-539: of a topic's v5 hits for one client the FIRST (in filter order = position order) keeps filter +
+// options, later ones only contribute their subscription identifier.  Min-position-per-(topic, client), resolved in LDS
+// (match_core.hpp): dedup_tile_kernel for topics inside one tile, dedup_classify_kernel + dedup_topic_kernel for topics
+// that span tiles.  No global table, no device-scope atomics per candidate, no host synchronisation per window (r2: one
+// atomicCAS + atomicMin through the fabric per candidate and a stream sync for the table size — 2.14 ms per 2^28-hit
+// window at config 3 with 10 % v5, profiles/r02h_bench_config3_deliver_v5frac0.1_512x4.json).
+static_assert(kTile <= (1 << kDedupIdxBits), "tile table packs position-in-tile and candidate index into 11 bits each");
+constexpr int kDedupTileSlots = 2 * kTile;            // u32 slots: 16 KiB
+constexpr int kDedupTopicSlots = 4096;                // u64 slots: 32 KiB -> 4 blocks of 512 threads per CU
+constexpr int kDedupTopicCap = kDedupTopicSlots / 2;  // candidates per part
+constexpr int kDedupTopicThreads = 512;
+
+__global__ __launch_bounds__(256) void dedup_tile_kernel(const Cand* __restrict__ cand, const uint32_t* __restrict__ tile_ncand,
+                                                         const uint64_t* __restrict__ hit_off, uint64_t hit_lo, Tuple* __restrict__ tuples,
+                                                         unsigned long long* __restrict__ stat) {
+    __shared__ uint32_t s_topic[kTile], s_client[kTile], s_pos[kTile];
+    __shared__ uint32_t s_tab[kDedupTileSlots];
+    __shared__ uint32_t s_inside;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t n = tile_ncand[tile];
+    if (threadIdx.x == 0 && n) atomicAdd(stat, static_cast<unsigned long long>(n));      // candidates of the pass (rgr_stats)
+    if (n < 2) return;                                                                    // nothing can be a duplicate
+    const Cand* list = cand + uint64_t(tile) * kTile;
+    const uint64_t lo = uint64_t(tile) * kTile, hi = lo + kTile;
+    if (threadIdx.x == 0) s_inside = 0;
+    for (uint32_t i = threadIdx.x; i < uint32_t(kDedupTileSlots); i += 256) s_tab[i] = kNone;
+    __syncthreads();
+    uint32_t inside = 0;
     for (uint32_t i = threadIdx.x; i < n; i += 256) {
-        const Cand c = mine_list[i];
-        const uint32_t t = c.topic;
-        const uint64_t b = 2 * cand_off[t], len = 2 * (cand_off[t + 1] - cand_off[t]);
-        const unsigned long long mine = (static_cast<unsigned long long>(c.client_idx) << 32) | c.pos;
-        for (uint64_t s = dedup_slot(c.client_idx, len);; s = (s + 1 == len) ? 0 : s + 1) {
-            const unsigned long long prev = atomicCAS(&table[b + s], kDedupEmpty, mine);
-            if (prev == kDedupEmpty) break;
-            if (uint32_t(prev >> 32) == c.client_idx) { atomicMin(&table[b + s], mine); break; }   // same client: smaller position wins
-        }
+        const Cand c = list[i];
+        const uint64_t h0 = hit_off[c.topic] - hit_lo, h1 = hit_off[c.topic + 1] - hit_lo;
+        const bool in = h0 >= lo && h1 <= hi;                  // the topic lies entirely inside this tile
+        s_topic[i] = in ? c.topic : kNone; s_client[i] = c.client_idx; s_pos[i] = c.pos;
+        inside += in;
     }
+    if (inside) atomicAdd(&s_inside, inside);
+    __syncthreads();
+    if (s_inside < 2) return;
+    auto key_topic = [&](uint32_t k) { return s_topic[k]; };
+    auto key_client = [&](uint32_t k) { return s_client[k]; };
+    auto tab_load = [&](uint32_t sl) { return s_tab[sl]; };
+    for (uint32_t i = threadIdx.x; i < n; i += 256)
+        if (s_topic[i] != kNone)
+            dedup_tile_insert(i, s_pos[i] - uint32_t(lo), uint32_t(kDedupTileSlots - 1), key_topic, key_client, tab_load,
+                              [&](uint32_t sl, uint32_t v) { return atomicCAS(&s_tab[sl], kNone, v); }, [&](uint32_t sl, uint32_t v) { atomicMin(&s_tab[sl], v); });
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n; i += 256)
+        if (s_topic[i] != kNone && dedup_tile_is_dup(i, uint32_t(kDedupTileSlots - 1), key_topic, key_client, tab_load)) tuples[s_pos[i]].qos_flags |= kHitV5Dup;
 }
-__global__ __launch_bounds__(256) void dedup_flag_kernel(const Cand* __restrict__ cand, const uint32_t* __restrict__ tile_ncand,
-                                                         Tuple* __restrict__ tuples, const uint64_t* __restrict__ cand_off,
-                                                         const unsigned long long* __restrict__ table) {
-    const uint32_t n = tile_ncand[blockIdx.x];
-    const Cand* mine_list = cand + uint64_t(blockIdx.x) * kTile;
-    for (uint32_t i = threadIdx.x; i < n; i += 256) {
-        const Cand c = mine_list[i];
-        const uint32_t t = c.topic;
-        const uint64_t b = 2 * cand_off[t], len = 2 * (cand_off[t + 1] - cand_off[t]);
-        for (uint64_t s = dedup_slot(c.client_idx, len);; s = (s + 1 == len) ? 0 : s + 1) {
-            const unsigned long long e = table[b + s];
-            if (uint32_t(e >> 32) == c.client_idx && e != kDedupEmpty) { if (uint32_t(e) != c.pos) tuples[c.pos].qos_flags |= kHitV5Dup; break; }
-            if (e == kDedupEmpty) break;   // unreachable: every candidate was inserted
+
+// One work item per part of every topic that spans tiles and has at least two candidates.
+__global__ __launch_bounds__(256) void dedup_classify_kernel(const uint32_t* __restrict__ topic_cand, uint32_t nt, const uint64_t* __restrict__ hit_off,
+                                                             uint64_t hit_lo, DedupItem* __restrict__ items, uint32_t* __restrict__ item_count) {
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= nt) return;
+    const uint32_t nc = topic_cand[t];
+    if (nc < 2) return;
+    const uint64_t h0 = hit_off[t] - hit_lo, h1 = hit_off[t + 1] - hit_lo;
+    if (h0 / kTile == (h1 - 1) / kTile) return;                 // inside one tile: dedup_tile_kernel
+    const uint32_t parts = (nc + kDedupTopicCap - 1) / kDedupTopicCap;
+    const uint32_t at = atomicAdd(item_count, parts);
+    for (uint32_t p = 0; p < parts; ++p) items[at + p] = DedupItem{t, p, parts, nc};
+}
+
+__global__ __launch_bounds__(kDedupTopicThreads) void dedup_topic_kernel(const Cand* __restrict__ cand, const uint32_t* __restrict__ tile_ncand,
+                                                                         const uint64_t* __restrict__ hit_off, uint64_t hit_lo,
+                                                                         const DedupItem* __restrict__ items, const uint32_t* __restrict__ item_count,
+                                                                         Tuple* __restrict__ tuples, uint32_t max_slots) {
+    __shared__ unsigned long long s_tab[kDedupTopicSlots];
+    __shared__ uint32_t s_over;
+    const uint32_t ni = *item_count;
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    constexpr uint32_t kWaves = kDedupTopicThreads / 64;
+    for (uint32_t it = blockIdx.x; it < ni; it += gridDim.x) {
+        const DedupItem item = items[it];
+        const uint64_t h0 = hit_off[item.topic] - hit_lo, h1 = hit_off[item.topic + 1] - hit_lo;
+        const uint32_t tile0 = uint32_t(h0 / kTile), tile1 = uint32_t((h1 - 1) / kTile);
+        const uint32_t mask = dedup_topic_slots(item.nc, item.parts, max_slots) - 1;
+        // sub-parts: 1 unless the part's distinct clients overflow the table (then doubled and redone: the flags are idempotent)
+        for (uint32_t S = 1;; S <<= 1) {
+            bool over = false;
+            for (uint32_t sub = 0; sub < S && !over; ++sub) {
+                const uint64_t nparts = uint64_t(item.parts) * S;
+                const uint32_t mine = item.part * S + sub;
+                __syncthreads();
+                for (uint32_t i = threadIdx.x; i <= mask; i += kDedupTopicThreads) s_tab[i] = kDedupEmpty;
+                if (threadIdx.x == 0) s_over = 0;
+                __syncthreads();
+                // every wave takes whole tiles: a tile's list is read by 64 lanes with a stride of 64
+                for (uint32_t tile = tile0 + wave; tile <= tile1; tile += kWaves) {
+                    const uint32_t n = tile_ncand[tile];
+                    const Cand* list = cand + uint64_t(tile) * kTile;
+                    for (uint32_t i = lane; i < n; i += 64) {
+                        const Cand c = list[i];
+                        if (c.topic != item.topic || (nparts > 1 && dedup_part(c.client_idx, nparts) != mine)) continue;
+                        if (!dedup_topic_insert(c.client_idx, c.pos, mask, [&](uint32_t sl, unsigned long long v) { return atomicCAS(&s_tab[sl], kDedupEmpty, v); },
+                                                [&](uint32_t sl, unsigned long long v) { atomicMin(&s_tab[sl], v); }))
+                            s_over = 1;
+                    }
+                }
+                __syncthreads();
+                over = s_over != 0;
+                if (over) break;
+                for (uint32_t tile = tile0 + wave; tile <= tile1; tile += kWaves) {
+                    const uint32_t n = tile_ncand[tile];
+                    const Cand* list = cand + uint64_t(tile) * kTile;
+                    for (uint32_t i = lane; i < n; i += 64) {
+                        const Cand c = list[i];
+                        if (c.topic != item.topic || (nparts > 1 && dedup_part(c.client_idx, nparts) != mine)) continue;
+                        if (dedup_topic_is_dup(c.client_idx, c.pos, mask, [&](uint32_t sl) { return s_tab[sl]; })) tuples[c.pos].qos_flags |= kHitV5Dup;
+                    }
+                }
+            }
+            if (!over) break;
         }
     }
 }
@@ -1058,12 +1138,24 @@ void launch_expand_compact(const TrieView& t, const ChunkArrays& c, uint64_t pai
     else expand_compact_kernel<kFmtSoa><<<ntiles, kCompactThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out_ids, out_qos);
 }
 
-void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, uint32_t ntiles, Tuple* tuples, const uint64_t* cand_off,
-                  unsigned long long* table, void* stream) {
+uint32_t dedup_topic_cap() { return kDedupTopicCap; }
+
+void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, uint32_t ntiles, Tuple* tuples, const uint32_t* topic_cand, uint32_t nt,
+                  const uint64_t* hit_off, uint64_t hit_lo, DedupItem* items, uint32_t* item_count, unsigned long long* stat, void* stream) {
     if (!ntiles) return;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    dedup_insert_kernel<<<ntiles, 256, 0, s>>>(cand, tile_ncand, cand_off, table);
-    dedup_flag_kernel<<<ntiles, 256, 0, s>>>(cand, tile_ncand, tuples, cand_off, table);
+    (void)hipMemsetAsync(item_count, 0, 4, s);
+    dedup_tile_kernel<<<ntiles, 256, 0, s>>>(cand, tile_ncand, hit_off, hit_lo, tuples, stat);
+    dedup_classify_kernel<<<(nt + 255) / 256, 256, 0, s>>>(topic_cand, nt, hit_off, hit_lo, items, item_count);
+    // the item count stays on the device: a fixed grid of persistent blocks (4 per CU fit) strides over the items
+    // RGR_DEDUP_TEST_SLOTS (tests only): a smaller table, so that parts overflow and the re-split path runs on ordinary inputs
+    static const uint32_t max_slots = [] {
+        const char* e = std::getenv("RGR_DEDUP_TEST_SLOTS");
+        uint32_t v = e ? uint32_t(std::atoi(e)) : 0u, p2 = 64;
+        while (p2 < v && p2 < uint32_t(kDedupTopicSlots)) p2 <<= 1;
+        return v ? p2 : uint32_t(kDedupTopicSlots);
+    }();
+    dedup_topic_kernel<<<1024, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, hit_off, hit_lo, items, item_count, tuples, max_slots);
 }
 
 }  // namespace rgr

@@ -236,12 +236,15 @@ void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, ui
 constexpr int kFmtTuple = 0, kFmtSoa = 1, kFmtPacked = 2, kFmtRuns = 3;     // == RGR_FORMAT_*
 void launch_expand_compact(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint64_t hit_hi,
                            const TileRec* tile_first, int format, uint32_t* out_ids, uint8_t* out_qos, void* stream);
-// v5 per-client dedup over a window's candidates: first position per (topic, client) wins, every
-// other candidate gets kHitV5Dup.  `table` (pre-filled with 0xFF bytes) is partitioned by topic:
-// topic t of the window owns slots [2*cand_off[t], 2*cand_off[t+1]) — twice its candidate count
-// (cand_off = exclusive scan of DeliverArgs::topic_cand) — and a slot holds (client_idx << 32 | pos).
-void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, uint32_t ntiles, Tuple* tuples, const uint64_t* cand_off,
-                  unsigned long long* table, void* stream);
+// v5 per-client dedup over a window's candidates (match_core.hpp: LDS tile tables + LDS topic tables): first position per
+// (topic, client) wins, every other candidate gets kHitV5Dup.  hit_off points at the window's first topic (chunk-local
+// offsets, hit_lo = the window's first position); topic_cand[nt] = candidates per window topic (DeliverArgs); items must hold
+// nt + n_hits / dedup_topic_cap() + 1 entries; *stat accumulates the candidate count.  Everything is stream-ordered: no host sync.
+// work item of the topic pass: part `part` of `parts` of window topic `topic` (nc candidates in total)
+struct DedupItem { uint32_t topic, part, parts, nc; };
+void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, uint32_t ntiles, Tuple* tuples, const uint32_t* topic_cand, uint32_t nt,
+                  const uint64_t* hit_off, uint64_t hit_lo, DedupItem* items, uint32_t* item_count, unsigned long long* stat, void* stream);
+uint32_t dedup_topic_cap();
 uint32_t expand_tile_hits();
 const char* expand_tuple_kernel_name();      // which kernel expands plain 12-byte tuple windows (profilers see this name)
 uint32_t scan_block_topics();

@@ -444,13 +444,77 @@ RGR_HD inline uint32_t deliver_word(uint32_t qos_flags, PublishAttr pa, SubAttr 
     return w;
 }
 
-// Slot of `client` inside a topic's region of `len` (>= 2) dedup-table slots.
-RGR_HD inline uint64_t dedup_slot(uint32_t client, uint64_t len) {
-    uint64_t x = client;
-    x ^= x >> 16; x *= 0x7feb352dull; x &= 0xFFFFFFFFull;
-    x ^= x >> 15; x *= 0x846ca68bull; x &= 0xFFFFFFFFull;
+// ---- v5 per-client dedup (types.rs:524-539) in LDS tables (r3) --------------------------------------------------
+// Among the v5 hits ("candidates") of ONE publish topic the first hit of every client — lowest position — keeps filter and
+// options; every later one is flagged kHitV5Dup.  Duplicates only exist among the hits of one topic and a topic's hits are
+// consecutive positions, so the (topic, client) -> first-position table never has to be global:
+//   tile table   every topic that lies entirely inside one expansion tile is resolved by that tile's block: u32 slots,
+//                value = position-in-tile << 11 | index in the tile's candidate list (min = first position; the index leads
+//                to the key), key = (topic, client) of the candidate the value names
+//   topic table  a topic that spans tiles is resolved by a block of its own walking the candidate lists of its tiles: u64
+//                slots, client << 32 | position.  A topic with more candidates than a table holds is split into PARTS by
+//                client (dedup_part: a range partition of a bijective mix of the client index, so no client is in two
+//                parts); a part that still overflows (distinct clients > slots) is re-split on the fly.
+// The same functions run in kernels.hip (LDS, ds atomics) and in tests/emu (plain memory).
+RGR_HD inline uint32_t mix32(uint32_t x) {           // bijective
+    x ^= x >> 16; x *= 0x7feb352du;
+    x ^= x >> 15; x *= 0x846ca68bu;
     x ^= x >> 16;
-    return len <= 0xFFFFFFFFull ? (x * len) >> 32 : x % len;
+    return x;
+}
+RGR_HD inline uint32_t dedup_part(uint32_t client, uint64_t nparts) { return uint32_t((uint64_t(mix32(client)) * nparts) >> 32); }
+
+constexpr uint32_t kDedupIdxBits = 11;               // candidates per tile (and positions per tile) <= 2048
+template <class KeyTopic, class KeyClient, class Load, class Cas, class Min>
+RGR_HD inline void dedup_tile_insert(uint32_t i, uint32_t pos_in_tile, uint32_t mask, KeyTopic key_topic, KeyClient key_client, Load tab_load, Cas tab_cas,
+                                     Min tab_min) {
+    const uint32_t topic = key_topic(i), client = key_client(i);
+    const uint32_t v = (pos_in_tile << kDedupIdxBits) | i;
+    for (uint32_t s = edge_hash(topic, client) & mask;; s = (s + 1) & mask) {      // the table has more slots than a tile has candidates
+        uint32_t cur = tab_load(s);
+        if (cur == kNone) { cur = tab_cas(s, v); if (cur == kNone) return; }
+        const uint32_t k = cur & ((1u << kDedupIdxBits) - 1u);
+        if (key_topic(k) == topic && key_client(k) == client) { tab_min(s, v); return; }
+    }
+}
+template <class KeyTopic, class KeyClient, class Load>
+RGR_HD inline bool dedup_tile_is_dup(uint32_t i, uint32_t mask, KeyTopic key_topic, KeyClient key_client, Load tab_load) {
+    const uint32_t topic = key_topic(i), client = key_client(i);
+    for (uint32_t s = edge_hash(topic, client) & mask;; s = (s + 1) & mask) {
+        const uint32_t cur = tab_load(s);
+        if (cur == kNone) return false;                                              // unreachable: every candidate was inserted
+        const uint32_t k = cur & ((1u << kDedupIdxBits) - 1u);
+        if (key_topic(k) == topic && key_client(k) == client) return k != i;
+    }
+}
+
+constexpr unsigned long long kDedupEmpty = ~0ull;
+// false = the table is full (the caller re-splits the part)
+template <class Cas, class Min>
+RGR_HD inline bool dedup_topic_insert(uint32_t client, uint32_t pos, uint32_t mask, Cas tab_cas, Min tab_min) {
+    const unsigned long long mine = (static_cast<unsigned long long>(client) << 32) | pos;
+    uint32_t steps = 0;
+    for (uint32_t s = mix32(client) & mask;; s = (s + 1) & mask) {
+        const unsigned long long prev = tab_cas(s, mine);
+        if (prev == kDedupEmpty) return true;
+        if (uint32_t(prev >> 32) == client) { tab_min(s, mine); return true; }        // same client: the smaller position wins
+        if (++steps > mask) return false;
+    }
+}
+template <class Load>
+RGR_HD inline bool dedup_topic_is_dup(uint32_t client, uint32_t pos, uint32_t mask, Load tab_load) {
+    for (uint32_t s = mix32(client) & mask;; s = (s + 1) & mask) {
+        const unsigned long long e = tab_load(s);
+        if (e == kDedupEmpty) return false;                                          // unreachable
+        if (uint32_t(e >> 32) == client) return uint32_t(e) != pos;
+    }
+}
+// Slots a part's table uses: a power of two >= 2 x its expected candidates (+ slack), within [64, max_slots].
+RGR_HD inline uint32_t dedup_topic_slots(uint32_t nc, uint32_t parts, uint32_t max_slots) {
+    const uint32_t want = 2u * ((nc + parts - 1) / parts) + 16u;
+    uint32_t len = 64;
+    while (len < want && len < max_slots) len <<= 1;
+    return len;
 }
 
 }  // namespace rgr

@@ -218,43 +218,89 @@ int32_t run_pipeline(Emu* e, uint32_t n, const std::vector<uint64_t>& tok_off, c
                         out[(base - hit_lo) + pos] = rgr_tuple{s_topic[i], se.sub_id, se.qos_flags};
                     }
                 }
-                if (!cand.empty()) {   // launch_dedup: the same topic-partitioned table, sequentially; candidates reversed
-                    std::reverse(cand.begin(), cand.end());          // (their order on the device is arbitrary)
+                if (!cand.empty()) {   // launch_dedup: tile tables, classification, topic tables (match_core.hpp), sequentially
                     const uint32_t topic_lo = begin + lc, nt = le - lc;
-                    std::vector<uint64_t> cand_off(size_t(nt) + 1, 0);
+                    std::vector<std::vector<Cand>> lists(ntiles);     // DeliverArgs::cand: every tile's own list, in arbitrary order
+                    std::vector<uint32_t> topic_cand(nt, 0);          // DeliverArgs::topic_cand
                     for (const Cand& c : cand) {
                         if (c.topic != out[c.pos].topic_idx - topic_lo) return RGR_ESTATE;
-                        cand_off[c.topic + 1]++;                      // DeliverArgs::topic_cand + scan
+                        lists[c.pos / T].push_back(c);
+                        topic_cand[c.topic]++;
                     }
-                    for (uint32_t t = 0; t < nt; ++t) cand_off[t + 1] += cand_off[t];
-                    std::vector<uint64_t> table(2 * cand.size(), ~0ull);
-                    auto region = [&](const Cand& c, uint64_t& b, uint64_t& len) {
-                        const uint32_t t = c.topic;
-                        b = 2 * cand_off[t]; len = 2 * (cand_off[t + 1] - cand_off[t]);
-                    };
-                    for (const Cand& c : cand) {                      // dedup_insert_kernel
-                        uint64_t b, len; region(c, b, len);
-                        const uint64_t mine = (uint64_t(c.client_idx) << 32) | c.pos;
-                        for (uint64_t sl = dedup_slot(c.client_idx, len);; sl = (sl + 1 == len) ? 0 : sl + 1) {
-                            uint64_t& e = table[b + sl];
-                            if (e == ~0ull) { e = mine; break; }
-                            if (uint32_t(e >> 32) == c.client_idx) { e = std::min(e, mine); break; }
-                        }
-                    }
+                    for (auto& l : lists) std::reverse(l.begin(), l.end());
+                    auto h_off = [&](uint32_t t) { return hit_off[lc + t] - hit_lo; };       // window-relative first position of window topic t
                     std::map<uint64_t, uint32_t> first;                // independent statement of types.rs:524-539
                     auto key_of = [&](const Cand& c) { return (uint64_t(out[c.pos].topic_idx) << 32) | c.client_idx; };
                     for (const Cand& c : cand) { auto it = first.find(key_of(c)); if (it == first.end() || c.pos < it->second) first[key_of(c)] = c.pos; }
-                    for (const Cand& c : cand) {                      // dedup_flag_kernel
-                        uint64_t b, len; region(c, b, len);
-                        for (uint64_t sl = dedup_slot(c.client_idx, len);; sl = (sl + 1 == len) ? 0 : sl + 1) {
-                            const uint64_t e = table[b + sl];
-                            if (e == ~0ull) return RGR_ESTATE;
-                            if (uint32_t(e >> 32) != c.client_idx) continue;
-                            if ((uint32_t(e) != c.pos) != (first[key_of(c)] != c.pos)) return RGR_ESTATE;
-                            if (uint32_t(e) != c.pos) out[c.pos].qos_flags |= kHitV5Dup;
-                            break;
+                    std::vector<uint8_t> decided(nh, 0);
+                    auto flag = [&](const Cand& c, bool dup) {
+                        if (dup != (first[key_of(c)] != c.pos)) return false;
+                        if (dup) out[c.pos].qos_flags |= kHitV5Dup;
+                        decided[c.pos] = 1;
+                        return true;
+                    };
+                    // dedup_tile_kernel
+                    uint32_t tslots = 2; while (tslots < 2 * T) tslots <<= 1;
+                    for (uint32_t tile = 0; tile < ntiles; ++tile) {
+                        const auto& l = lists[tile];
+                        if (l.size() < 2) continue;
+                        if (l.size() > T || T > (1u << kDedupIdxBits)) return RGR_EINVAL;
+                        const uint64_t lo = uint64_t(tile) * T, hi = lo + T;
+                        std::vector<uint32_t> k_topic(l.size()), tab(tslots, kNone);
+                        uint32_t inside = 0;
+                        for (size_t i = 0; i < l.size(); ++i) {
+                            const bool in = h_off(l[i].topic) >= lo && h_off(l[i].topic + 1) <= hi;
+                            k_topic[i] = in ? l[i].topic : kNone; inside += in;
+                        }
+                        if (inside < 2) continue;
+                        auto kt = [&](uint32_t k) { return k_topic[k]; };
+                        auto kc = [&](uint32_t k) { return l[k].client_idx; };
+                        auto ld = [&](uint32_t sl) { return tab[sl]; };
+                        for (uint32_t i = 0; i < l.size(); ++i)
+                            if (k_topic[i] != kNone)
+                                dedup_tile_insert(i, l[i].pos - uint32_t(lo), tslots - 1, kt, kc, ld,
+                                                  [&](uint32_t sl, uint32_t v) { const uint32_t o = tab[sl]; if (o == kNone) tab[sl] = v; return o; },
+                                                  [&](uint32_t sl, uint32_t v) { tab[sl] = std::min(tab[sl], v); });
+                        for (uint32_t i = 0; i < l.size(); ++i)
+                            if (k_topic[i] != kNone && !flag(l[i], dedup_tile_is_dup(i, tslots - 1, kt, kc, ld))) return RGR_ESTATE;
+                    }
+                    // dedup_classify_kernel + dedup_topic_kernel; a deliberately tiny table (8 slots, 4 candidates per part) so that
+                    // small tests already exercise several parts and the overflow re-split
+                    const uint32_t max_slots = 8, cap = 4;
+                    for (uint32_t t = 0; t < nt; ++t) {
+                        const uint32_t nc = topic_cand[t];
+                        if (nc < 2) continue;
+                        const uint64_t h0 = h_off(t), h1 = h_off(t + 1);
+                        if (h0 / T == (h1 - 1) / T) continue;
+                        const uint32_t parts = (nc + cap - 1) / cap;
+                        for (uint32_t part = 0; part < parts; ++part) {
+                            const uint32_t tile0 = uint32_t(h0 / T), tile1 = uint32_t((h1 - 1) / T);
+                            const uint32_t mask = dedup_topic_slots(nc, parts, max_slots) - 1;
+                            for (uint32_t S = 1;; S <<= 1) {
+                                bool over = false;
+                                for (uint32_t sub = 0; sub < S && !over; ++sub) {
+                                    const uint64_t nparts = uint64_t(parts) * S;
+                                    const uint32_t mine = part * S + sub;
+                                    std::vector<unsigned long long> tab(size_t(mask) + 1, kDedupEmpty);
+                                    auto sel = [&](const Cand& c) { return c.topic == t && (nparts == 1 || dedup_part(c.client_idx, nparts) == mine); };
+                                    for (uint32_t tile = tile0; tile <= tile1 && !over; ++tile)
+                                        for (const Cand& c : lists[tile])
+                                            if (sel(c) && !dedup_topic_insert(c.client_idx, c.pos, mask,
+                                                                              [&](uint32_t sl, unsigned long long v) { const unsigned long long o = tab[sl]; if (o == kDedupEmpty) tab[sl] = v; return o; },
+                                                                              [&](uint32_t sl, unsigned long long v) { tab[sl] = std::min(tab[sl], v); })) { over = true; break; }
+                                    if (over) break;
+                                    for (uint32_t tile = tile0; tile <= tile1; ++tile)
+                                        for (const Cand& c : lists[tile])
+                                            if (sel(c) && !flag(c, dedup_topic_is_dup(c.client_idx, c.pos, mask, [&](uint32_t sl) { return tab[sl]; }))) return RGR_ESTATE;
+                                }
+                                if (!over) break;
+                                if (S > (1u << 20)) return RGR_ESTATE;
+                            }
                         }
                     }
+                    // every candidate of a topic with at least two candidates was decided by exactly one of the two passes' rules
+                    for (const Cand& c : cand)
+                        if (!decided[c.pos] && topic_cand[c.topic] >= 2 && first[key_of(c)] != c.pos) return RGR_ESTATE;
                 }
             }
             lc = le;

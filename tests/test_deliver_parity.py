@@ -210,6 +210,29 @@ def test_v5_dedup_many_candidates(kind):
     w.check(8)
 
 
+@pytest.mark.parametrize("test_slots", [0, 64])
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_v5_dedup_topics_spanning_tiles_in_parts(kind, test_slots, monkeypatch):
+    """Topics with ~10 k v5 candidates each: they span several expansion tiles (block-per-topic LDS tables) and exceed one
+    table, so they are split into parts by client; with RGR_DEDUP_TEST_SLOTS=64 every part overflows its (shrunken) table
+    and the on-the-fly re-split runs.  Small topics in the same window go through the tile tables."""
+    if test_slots:
+        monkeypatch.setenv("RGR_DEDUP_TEST_SLOTS", str(test_slots))
+    w = World(kind, 21)
+    w.clients = [f"k{i}" for i in range(1500)]
+    w.client_node = {c: w.nodes[i % 3] for i, c in enumerate(w.clients)}
+    filters = ["a/b/c", "a/b/+", "a/+/c", "+/b/c", "a/b/#", "a/#", "#", "+/+/+", "+/#"]
+    for i, c in enumerate(w.clients):
+        for j, f in enumerate(filters):
+            if (i + 2 * j) % 5 != 3:
+                w.add(f, c, 0, (i + j) % 3, (i + j) % 7 != 0, (i % 5) == 0, (j % 2) == 0, (i * 9 + j) % 200)
+    for i, c in enumerate(w.clients[:40]):          # low-fan-out topics: two overlapping filters, a handful of clients
+        w.add("q/r/s", c, 0, 1, True, False, False, 0)
+        if i % 2:
+            w.add("q/r/+", c, 0, 2, True, False, True, 7)
+    w.check(14)
+
+
 @pytest.mark.parametrize("kind", BACKENDS)
 def test_delivery_without_registered_ids(kind):
     """Plain rgr_sub_add (no owner / client ids): qos downgrade and RAP still apply, No Local
