@@ -228,6 +228,7 @@ def gpu_digests(batch, n_topics, retain, fmt=0, subs_len=0):
             acc[:, 3] = seg(v * v)
             del v, s1
         del sid, q, d_off, start, end, cnt
+        torch.cuda.synchronize()                    # torch's reads of the window must finish before the library expands the next one into the same buffer
     structure_ok &= expect_begin == n_topics
     batch.set_format(capi.RGR_FORMAT_TUPLE)
     info["runs_per_topic"] = runs_per_topic

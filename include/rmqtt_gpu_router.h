@@ -286,6 +286,13 @@ int32_t rgr_match_batch_deliver(rgr_handle* h, const uint8_t* topics_blob, const
 void rgr_result_free(rgr_result* r);
 int32_t rgr_match_filters(rgr_handle* h, const uint8_t* topics_blob, const uint64_t* topic_offsets, uint32_t n,
                           rgr_filters_result* out);
+/* The same walk, but filter_ids[k] holds the SUB ID of the k-th matched filter's first subscriber (RGR_ID_NONE when the filter
+ * has no subscriber) instead of the library's filter id.  This is the entry point for Router::matches (router.rs:174-265) on a
+ * host that keeps the reference's relations map (AllRelationsMap, types.rs:476): sub id -> its relation -> the filter string ->
+ * `relations.get(filter)`, then the per-client loop of router.rs:194-231 runs on the host's own map.  4 bytes per matched
+ * FILTER cross PCIe instead of 12 per HIT, and no filter-id bookkeeping is needed (ids are per handle; sub ids are the caller's). */
+int32_t rgr_match_filter_subs(rgr_handle* h, const uint8_t* topics_blob, const uint64_t* topic_offsets, uint32_t n,
+                              rgr_filters_result* out);
 void rgr_filters_result_free(rgr_filters_result* r);
 
 /* ---- matching, device-resident batches (bench / multi-GPU / streaming consumers) ------ */
@@ -451,6 +458,8 @@ int32_t rgr_group_commit(rgr_group* g);
 int32_t rgr_group_match_batch(rgr_group* g, const uint8_t* topics_blob, const uint64_t* topic_offsets, uint32_t n, rgr_result* out);
 int32_t rgr_group_match_batch_deliver(rgr_group* g, const uint8_t* topics_blob, const uint64_t* topic_offsets, uint32_t n,
                                       const rgr_publish_attr* attrs, rgr_result* out);
+/* rgr_match_filter_subs over the group (topics routed to their owner shard, lists stitched back into the caller's order). */
+int32_t rgr_group_match_filter_subs(rgr_group* g, const uint8_t* topics_blob, const uint64_t* topic_offsets, uint32_t n, rgr_filters_result* out);
 /* Device-resident form: the batch is split by owner shard; tuples carry the caller's topic index. */
 int32_t rgr_group_batch_create(rgr_group* g, const uint8_t* topics_blob, const uint64_t* topic_offsets, uint32_t n, rgr_group_batch** out);
 void rgr_group_batch_destroy(rgr_group_batch* gb);

@@ -30,7 +30,7 @@ SYMBOLS = [
     "rgr_create", "rgr_destroy", "rgr_last_error", "rgr_version",
     "rgr_filter_add", "rgr_filter_find", "rgr_filter_remove", "rgr_sub_add", "rgr_sub_add_ex", "rgr_sub_attrs_bulk",
     "rgr_sub_remove", "rgr_subscribe_bulk", "rgr_snapshot_save", "rgr_snapshot_load", "rgr_commit",
-    "rgr_match_batch", "rgr_match_batch_deliver", "rgr_result_free", "rgr_match_filters", "rgr_filters_result_free",
+    "rgr_match_batch", "rgr_match_batch_deliver", "rgr_result_free", "rgr_match_filters", "rgr_match_filter_subs", "rgr_filters_result_free",
     "rgr_batch_create", "rgr_batch_create_from_publish", "rgr_batch_publish_info", "rgr_batch_destroy", "rgr_batch_status", "rgr_batch_set_publish_attrs",
     "rgr_batch_set_format", "rgr_batch_set_topic_ids", "rgr_batch_begin", "rgr_batch_next_window",
     "rgr_window_to_host", "rgr_batch_run", "rgr_batch_run_to_host",
@@ -40,7 +40,7 @@ SYMBOLS = [
     "rgr_comm_unique_id", "rgr_comm_create", "rgr_comm_destroy", "rgr_comm_allgather_u64", "rgr_comm_gather_pass",
     "rgr_group_create", "rgr_group_destroy", "rgr_group_size", "rgr_group_handle", "rgr_group_comm", "rgr_group_uses_rccl",
     "rgr_group_subscribe_bulk", "rgr_group_sub_attrs_bulk", "rgr_group_subscribe", "rgr_group_subscribe_ex", "rgr_group_unsubscribe", "rgr_group_commit",
-    "rgr_group_match_batch", "rgr_group_match_batch_deliver",
+    "rgr_group_match_batch", "rgr_group_match_batch_deliver", "rgr_group_match_filter_subs",
     "rgr_group_batch_create", "rgr_group_batch_destroy", "rgr_group_batch_shard", "rgr_group_batch_run", "rgr_group_batch_gather",
 ]
 GATHER_CONSUMER = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.c_uint64)
@@ -316,12 +316,14 @@ class Router:
         finally:
             lib().rgr_result_free(C.byref(r))
 
-    def match_filters(self, blob, offsets):
+    def match_filters(self, blob, offsets, first_subs=False):
+        """Matched filters per topic, in TopicTree::matches order: the library's filter ids, or (first_subs) the sub id of
+        each filter's first subscriber (ID_NONE when it has none) — rgr_match_filter_subs."""
         n = len(offsets) - 1
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         r = FiltersResult()
         bp, bk = _blob_ptr(blob)
-        _check(lib().rgr_match_filters(self._h, bp, offsets.ctypes.data, n, C.byref(r)))
+        _check((lib().rgr_match_filter_subs if first_subs else lib().rgr_match_filters)(self._h, bp, offsets.ctypes.data, n, C.byref(r)))
         try:
             return dict(status=_copy(r.status, n, np.int32), pair_offsets=_copy(r.pair_offsets, n + 1, np.uint64),
                         filter_ids=_copy(r.filter_ids, r.n_pairs, np.uint32))
@@ -591,6 +593,19 @@ class Group:
                         tuples=_copy(r.tuples, r.n_hits, TUPLE_DTYPE))
         finally:
             lib().rgr_result_free(C.byref(r))
+
+    def match_filter_subs(self, blob, offsets):
+        """rgr_group_match_filter_subs: per topic, the sub id of each matched filter's first subscriber, in the caller's topic order."""
+        n = len(offsets) - 1
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        r = FiltersResult()
+        bp, bk = _blob_ptr(blob)
+        _check(lib().rgr_group_match_filter_subs(self._g, bp, offsets.ctypes.data, n, C.byref(r)))
+        try:
+            return dict(status=_copy(r.status, n, np.int32), pair_offsets=_copy(r.pair_offsets, n + 1, np.uint64),
+                        filter_ids=_copy(r.filter_ids, r.n_pairs, np.uint32))
+        finally:
+            lib().rgr_filters_result_free(C.byref(r))
 
     def batch(self, blob, offsets):
         return GroupBatch(self, blob, offsets)

@@ -1552,7 +1552,7 @@ void rgr_result_free(rgr_result* r) {
     std::memset(r, 0, sizeof *r);
 }
 
-int32_t rgr_match_filters(rgr_handle* h, const uint8_t* blob, const uint64_t* offs, uint32_t n, rgr_filters_result* out) {
+static int32_t match_filters_impl(rgr_handle* h, const uint8_t* blob, const uint64_t* offs, uint32_t n, rgr_filters_result* out, bool reps) {
     if (!out) return fail(RGR_EINVAL, "rgr_match_filters: out is NULL");
     std::memset(out, 0, sizeof *out);
     rgr_batch* b = nullptr;
@@ -1584,7 +1584,7 @@ int32_t rgr_match_filters(rgr_handle* h, const uint8_t* blob, const uint64_t* of
             if (P) {
                 b->c->pair_src.ensure(P * 4);
                 b->h_ring[0].ensure(P * 4);
-                launch_pairs_dense(make_chunk_arrays(b, cn), d_off, b->c->pair_src.as<uint32_t>(), b->stream);
+                launch_pairs_dense(batch_view(b), make_chunk_arrays(b, cn), d_off, b->c->pair_src.as<uint32_t>(), reps, b->stream);
                 RGR_HIP(hipMemcpyAsync(b->h_ring[0].p, b->c->pair_src.p, P * 4, hipMemcpyDeviceToHost, b->stream));
                 RGR_HIP(hipStreamSynchronize(b->stream));
                 RGR_HIP(hipGetLastError());
@@ -1610,6 +1610,13 @@ int32_t rgr_match_filters(rgr_handle* h, const uint8_t* blob, const uint64_t* of
     });
     batch_release(b);
     return rc;
+}
+
+int32_t rgr_match_filters(rgr_handle* h, const uint8_t* blob, const uint64_t* offs, uint32_t n, rgr_filters_result* out) {
+    return match_filters_impl(h, blob, offs, n, out, false);
+}
+int32_t rgr_match_filter_subs(rgr_handle* h, const uint8_t* blob, const uint64_t* offs, uint32_t n, rgr_filters_result* out) {
+    return match_filters_impl(h, blob, offs, n, out, true);
 }
 
 void rgr_filters_result_free(rgr_filters_result* r) {

@@ -367,12 +367,20 @@ __global__ __launch_bounds__(256) void retain_finish_kernel(uint32_t n, const ui
 }
 
 // --------------------------------------------------------------------------- dense matched-filter list
-__global__ __launch_bounds__(256) void pairs_dense_kernel(ChunkArrays c, const uint64_t* __restrict__ off, uint32_t* __restrict__ out) {
+// REPS: instead of the filter id, the sub id of the filter's FIRST subscriber (kNone when it has none): a host that keeps
+// its own relations map keyed by filter string (the reference's AllRelationsMap) finds the filter through that relation
+// and expands from its own map, as router.rs:194-231 does — no filter-id bookkeeping on the host, shard-independent.
+template <bool REPS>
+__global__ __launch_bounds__(256) void pairs_dense_kernel(TrieView tv, ChunkArrays c, const uint64_t* __restrict__ off, uint32_t* __restrict__ out) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= c.n) return;
     const uint32_t cnt = c.pair_cnt[t];
     const uint64_t o = off[t];
-    for (uint32_t j = 0; j < cnt; ++j) out[o + j] = pair_fid(c, t, cnt, j);
+    for (uint32_t j = 0; j < cnt; ++j) {
+        const uint32_t fid = pair_fid(c, t, cnt, j);
+        if (REPS) { const FilterDesc fd = tv.filt[fid]; out[o + j] = fd.count ? tv.subs[fd.begin].sub_id : kNone; }
+        else out[o + j] = fid;
+    }
 }
 
 // --------------------------------------------------------------------------- count
@@ -1084,8 +1092,11 @@ void launch_retain_finish(uint32_t n, const uint64_t* ovf_base, const uint64_t* 
     if (n) retain_finish_kernel<<<(n + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(n, ovf_base, ovf_end, pair_cnt);
 }
 
-void launch_pairs_dense(const ChunkArrays& c, const uint64_t* off, uint32_t* out, void* stream) {
-    if (c.n) pairs_dense_kernel<<<(c.n + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(c, off, out);
+void launch_pairs_dense(const TrieView& t, const ChunkArrays& c, const uint64_t* off, uint32_t* out, bool reps, void* stream) {
+    if (!c.n) return;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (reps) pairs_dense_kernel<true><<<(c.n + 255) / 256, 256, 0, s>>>(t, c, off, out);
+    else pairs_dense_kernel<false><<<(c.n + 255) / 256, 256, 0, s>>>(t, c, off, out);
 }
 
 void launch_count(const TrieView& t, const ChunkArrays& c, void* stream) {

@@ -221,7 +221,8 @@ void launch_retain_finish(uint32_t n, const uint64_t* ovf_base, const uint64_t* 
 
 // matched filter ids of every topic of the chunk, densely, in iteration order: out[off[t] + j] = j-th matched
 // filter of topic t (off = exclusive scan of pair_cnt) — the result of rgr_match_filters
-void launch_pairs_dense(const ChunkArrays& c, const uint64_t* off, uint32_t* out, void* stream);
+// reps: the first subscriber's sub id of each matched filter instead of its filter id (kNone: no subscriber)
+void launch_pairs_dense(const TrieView& t, const ChunkArrays& c, const uint64_t* off, uint32_t* out, bool reps, void* stream);
 void launch_count(const TrieView& t, const ChunkArrays& c, void* stream);
 void launch_scan(const ChunkArrays& c, uint64_t* block_tmp, void* stream);
 void launch_compact(const TrieView& t, const ChunkArrays& c, uint32_t topic_base, void* stream);

@@ -55,7 +55,12 @@ uint32_t GpuRouter::shards() const { return g_ ? rgr_group_size(g_) : 0; }
 int32_t GpuRouter::commit_if_dirty() {
     if (!dirty_) return RGR_OK;
     int32_t rc = rgr_group_commit(g_);
-    if (rc == RGR_OK) dirty_ = false;
+    if (rc == RGR_OK) {
+        dirty_ = false;
+        // the device table no longer holds the ids removed before this commit: they may be handed out again
+        free_sub_ids_.insert(free_sub_ids_.end(), quarantined_sub_ids_.begin(), quarantined_sub_ids_.end());
+        quarantined_sub_ids_.clear();
+    }
     return rc;
 }
 
@@ -81,7 +86,8 @@ static bool valid_topic(const std::string& s) {
 Result<bool> GpuRouter::add(const std::string& topic_filter, const Id& id, const SubscriptionOptions& opts) {
     if (!g_) return Result<bool>::Err(create_error_);
     if (!valid_topic(topic_filter)) return Result<bool>::Err("invalid topic filter `" + topic_filter + "`");   // router.rs:436 (`?`)
-    std::lock_guard<std::mutex> g(mu_);
+    std::unique_lock<std::shared_mutex> g(mu_);
+    mutation_epoch_++;
     auto it = relations_.find(topic_filter);
     if (it == relations_.end()) {
         topics_count_.inc();
@@ -109,7 +115,7 @@ Result<bool> GpuRouter::add(const std::string& topic_filter, const Id& id, const
         ni = node_idx_.emplace(id.node_id, uint16_t(nodes_.size())).first;
         nodes_.push_back(id.node_id);
     }
-    slab_[sub_id] = Slot{&it->first, &old->second};
+    slab_[sub_id] = Slot{&it->first, &old->second, &it->second};
     if (rgr_group_subscribe_ex(g_, topic_filter.data(), uint32_t(topic_filter.size()), sub_id, opts.qos, flags_of(opts), ni->second, owner_id,
                                client_idx) != RGR_OK)
         return Result<bool>::Err(rgr_last_error());
@@ -123,7 +129,8 @@ Result<bool> GpuRouter::restore(const raft::Snapshot& snap) {
     for (auto& r : snap.relations)
         if (!valid_topic(r.topic_filter)) return Result<bool>::Err("invalid topic filter `" + r.topic_filter + "`");   // router.rs:559
     if (snap.relations.size() >= RGR_ID_NONE) return Result<bool>::Err("snapshot holds more relations than sub ids");
-    std::lock_guard<std::mutex> g(mu_);
+    std::unique_lock<std::shared_mutex> g(mu_);
+    mutation_epoch_++;
     // relations.clear() (router.rs:557): a fresh device table takes the place of the old one
     rgr_group* fresh = nullptr;
     rgr_config cfg{};
@@ -141,7 +148,7 @@ Result<bool> GpuRouter::restore(const raft::Snapshot& snap) {
             Rel& x = rel.second;
             x.sub_id = uint32_t(slab.size());
             x.owner_id = owners.acquire(id_key(x.id));
-            slab.push_back(Slot{&kv.first, &x});
+            slab.push_back(Slot{&kv.first, &x, &kv.second});
             blob += kv.first;
             offs.push_back(blob.size());
             sub_ids.push_back(x.sub_id);
@@ -162,6 +169,7 @@ Result<bool> GpuRouter::restore(const raft::Snapshot& snap) {
     relations_ = std::move(relations);      // node-based map: the slab's pointers into it stay valid
     slab_ = std::move(slab);
     free_sub_ids_.clear();
+    quarantined_sub_ids_.clear();
     owners_ = std::move(owners);
     clients_ = std::move(clients);
     bulk_loaded_ = true;
@@ -174,7 +182,7 @@ Result<bool> GpuRouter::restore(const raft::Snapshot& snap) {
 // router.rs:456-496
 Result<bool> GpuRouter::remove(const std::string& topic_filter, const Id& id) {
     if (!g_) return Result<bool>::Err(create_error_);
-    std::lock_guard<std::mutex> g(mu_);
+    std::unique_lock<std::shared_mutex> g(mu_);
     auto it = relations_.find(topic_filter);
     if (it == relations_.end()) return Result<bool>::Ok(false);
     auto& rels = it->second.rels;
@@ -184,8 +192,9 @@ Result<bool> GpuRouter::remove(const std::string& topic_filter, const Id& id) {
     const bool last = rels.size() == 1;                              // router.rs:484-490: the filter leaves the trie with its last relation
     if (rgr_group_unsubscribe(g_, topic_filter.data(), uint32_t(topic_filter.size()), sub_id, last ? 1 : 0) != RGR_OK)
         return Result<bool>::Err(rgr_last_error());
+    mutation_epoch_++;
     slab_[sub_id] = Slot{};
-    free_sub_ids_.push_back(sub_id);
+    quarantined_sub_ids_.push_back(sub_id);          // reusable after the next commit (see mu_)
     owners_.release(id_key(r->second.id));
     clients_.release(client_key(r->second.id.node_id, r->second.id.client_id));
     rels.erase(r);
@@ -224,11 +233,104 @@ struct Collector {
 };
 }  // namespace
 
+// ---- Filters path: device walk -> one sub id per matched filter -> host expansion from relations_ (router.rs:194-231)
+Result<bool> GpuRouter::filters_pass(const std::vector<TopicName>& topics, FilterPass& pass) {
+    if (!g_) return Result<bool>::Err(create_error_);
+    std::string blob;
+    std::vector<uint64_t> offs(topics.size() + 1, 0);
+    for (size_t i = 0; i < topics.size(); ++i) { blob += topics[i]; offs[i + 1] = blob.size(); }
+    for (;;) {
+        if (dirty_) {                                             // publish pending mutations first: exclusive
+            std::unique_lock<std::shared_mutex> x(mu_);
+            if (commit_if_dirty() != RGR_OK) return Result<bool>::Err(rgr_last_error());
+        }
+        std::shared_lock<std::shared_mutex> g(mu_);
+        if (dirty_) continue;                                     // a mutation slipped in between the two locks
+        pass.epoch = mutation_epoch_;
+        rgr_filters_result_free(&pass.res);
+        if (rgr_group_match_filter_subs(g_, reinterpret_cast<const uint8_t*>(blob.data()), offs.data(), uint32_t(topics.size()), &pass.res) != RGR_OK)
+            return Result<bool>::Err(rgr_last_error());
+        return Result<bool>::Ok(true);
+    }
+}
+
+// caller holds mu_ (shared) and the pass is current
+std::optional<SubRelationsMap> GpuRouter::expand_locked(const rgr_filters_result& res, size_t t, const Id& id, const TopicName& topic, uint64_t* hits) {
+    if (res.status[t] != RGR_TOPIC_OK) return std::nullopt;                  // Topic::from_str Err (router.rs:177)
+    std::map<NodeId, Collector> collector_map;                                 // router.rs:176
+    uint64_t n_hits = 0;
+    for (uint64_t k = res.pair_offsets[t]; k < res.pair_offsets[t + 1]; ++k) {  // matched filters in TopicTree::matches order (router.rs:181)
+        const uint32_t rep = res.filter_ids[k];
+        if (rep == RGR_ID_NONE || rep >= slab_.size() || !slab_[rep].entry) continue;     // (a filter without relations: router.rs:184 `None`)
+        const Slot& s = slab_[rep];
+        std::map<std::string, std::vector<SharedCandidate>> groups;           // router.rs:183-192
+        for (const auto& kv : s.entry->rels) {                                  // router.rs:194: iteration order unspecified there too
+            const Rel& rel = kv.second;
+            ++n_hits;
+            if (rel.opts.v5 && rel.opts.no_local && rel.id == id) continue;     // router.rs:196-201
+            const NodeId node = rel.id.node_id;
+            if (rel.opts.shared_group) {                                        // router.rs:204-213
+                groups[*rel.opts.shared_group].push_back(SharedCandidate{node, rel.id.client_id, rel.opts, is_online(node, rel.id.client_id)});
+                continue;
+            }
+            collector_map[node].add(*s.filter, rel.id.client_id, rel.opts, std::nullopt);       // router.rs:214-229
+        }
+        for (auto& gk : groups) {                                               // router.rs:236-255, once per matched filter
+            std::vector<ClientId> cids;
+            for (auto& c : gk.second) cids.push_back(c.client_id);
+            const auto pick = shared_ ? shared_->choice(gk.first, id, topic, gk.second) : std::nullopt;
+            if (!pick || pick->first >= gk.second.size()) continue;
+            const SharedCandidate& c = gk.second[pick->first];
+            collector_map[c.node_id].add(*s.filter, c.client_id, c.opts, SharedGroupType{gk.first, pick->second, cids});
+        }
+    }
+    if (hits) *hits = n_hits;
+    SubRelationsMap m;                                                          // router.rs:258-261 + types.rs:488-497
+    for (auto& kv : collector_map) {
+        auto& dst = m[kv.first];
+        dst = std::move(kv.second.v3);
+        for (auto& r : kv.second.v5) dst.push_back(std::move(r));
+    }
+    return m;
+}
+
+std::optional<SubRelationsMap> GpuRouter::expand(const FilterPass& pass, size_t t, const Id& id, const TopicName& topic) {
+    {
+        std::shared_lock<std::shared_mutex> g(mu_);
+        if (pass.epoch == mutation_epoch_) {
+            uint64_t hits = 0;
+            auto m = expand_locked(pass.res, t, id, topic, &hits);
+            mean_hits_ = 0.9 * std::min(mean_hits_.load(), 1e8) + 0.1 * double(hits);
+            return m;
+        }
+    }
+    // the table changed since the pass ran (its sub ids may have been freed): match this publish again on the current table
+    stale_expansions_++;
+    FilterPass fresh;
+    for (;;) {
+        if (!filters_pass({topic}, fresh).ok()) return std::nullopt;
+        std::shared_lock<std::shared_mutex> g(mu_);
+        if (fresh.epoch == mutation_epoch_) return expand_locked(fresh.res, 0, id, topic, nullptr);
+    }
+}
+
 Result<bool> GpuRouter::matches_batch(const std::vector<Id>& ids, const std::vector<TopicName>& topics,
                                       std::vector<std::optional<SubRelationsMap>>& out) {
     if (!g_) return Result<bool>::Err(create_error_);
     if (ids.size() != topics.size()) return Result<bool>::Err("matches_batch: ids/topics size mismatch");
-    std::lock_guard<std::mutex> g(mu_);
+    if (mode_ == MatchMode::Deliver || (mode_ == MatchMode::Auto && mean_hits_ < kAutoDeliverBelow)) return matches_batch_deliver(ids, topics, out);
+    FilterPass pass;
+    auto r = filters_pass(topics, pass);
+    if (!r.ok()) return r;
+    out.assign(topics.size(), std::nullopt);
+    for (size_t t = 0; t < topics.size(); ++t) out[t] = expand(pass, t, ids[t], topics[t]);
+    return Result<bool>::Ok(true);
+}
+
+// ---- Deliver path: 12-byte tuples with the device's delivery words
+Result<bool> GpuRouter::matches_batch_deliver(const std::vector<Id>& ids, const std::vector<TopicName>& topics,
+                                              std::vector<std::optional<SubRelationsMap>>& out) {
+    std::unique_lock<std::shared_mutex> g(mu_);
     if (commit_if_dirty() != RGR_OK) return Result<bool>::Err(rgr_last_error());
     std::string blob;
     std::vector<uint64_t> offs(topics.size() + 1, 0);
@@ -284,6 +386,7 @@ Result<bool> GpuRouter::matches_batch(const std::vector<Id>& ids, const std::vec
         }
         out[t] = std::move(m);
     }
+    if (!topics.empty()) mean_hits_ = 0.9 * std::min(mean_hits_.load(), 1e8) + 0.1 * double(res.n_hits) / double(topics.size());
     rgr_result_free(&res);
     return Result<bool>::Ok(true);
 }
@@ -301,7 +404,7 @@ Result<SubRelationsMap> GpuRouter::matches(const Id& id, const TopicName& topic)
 // relation (it leaves with its last one, router.rs:484-490), so the filters of the hits ARE the matched filters.
 Result<std::vector<Route>> GpuRouter::get(const std::string& topic) {
     if (!g_) return Result<std::vector<Route>>::Err(create_error_);
-    std::lock_guard<std::mutex> g(mu_);
+    std::unique_lock<std::shared_mutex> g(mu_);
     if (commit_if_dirty() != RGR_OK) return Result<std::vector<Route>>::Err(rgr_last_error());
     const uint64_t offs[2] = {0, topic.size()};
     rgr_result res{};
@@ -329,7 +432,7 @@ Result<bool> GpuRouter::has_matches(const std::string& topic) {
 }
 
 std::vector<Route> GpuRouter::gets(size_t limit) {   // router.rs:514-541: unique (node, filter) pairs
-    std::lock_guard<std::mutex> g(mu_);
+    std::shared_lock<std::shared_mutex> g(mu_);
     std::vector<Route> out;
     for (auto& kv : relations_) {
         std::vector<NodeId> seen;
@@ -344,12 +447,12 @@ std::vector<Route> GpuRouter::gets(size_t limit) {   // router.rs:514-541: uniqu
 }
 
 size_t GpuRouter::topics_tree() {
-    std::lock_guard<std::mutex> g(mu_);
+    std::shared_lock<std::shared_mutex> g(mu_);
     return relations_.size();      // one trie value per distinct filter (router.rs:571-574)
 }
 
 std::vector<std::string> GpuRouter::list_topics(size_t top) {
-    std::lock_guard<std::mutex> g(mu_);
+    std::shared_lock<std::shared_mutex> g(mu_);
     std::vector<std::string> v;
     for (auto& kv : relations_) { if (v.size() >= top) break; v.push_back(kv.first); }
     return v;
@@ -370,16 +473,20 @@ Batcher::~Batcher() {
 }
 
 Result<SubRelationsMap> Batcher::matches(const Id& id, const TopicName& topic) {
-    Req req{id, topic, std::nullopt, {}, false};
-    std::unique_lock<std::mutex> lk(mu_);
-    if (stop_) return Result<SubRelationsMap>::Err("batcher stopped");
-    queue_.push_back(&req);
-    requests_++;
-    cv_req_.notify_one();
-    cv_done_.wait(lk, [&] { return req.done; });
+    Req req{id, topic, nullptr, 0, {}, false};
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        if (stop_) return Result<SubRelationsMap>::Err("batcher stopped");
+        queue_.push_back(&req);
+        requests_++;
+        cv_req_.notify_one();
+        cv_done_.wait(lk, [&] { return req.done; });
+    }
     if (!req.err.empty()) return Result<SubRelationsMap>::Err(req.err);
-    if (!req.out) return Result<SubRelationsMap>::Err("invalid topic `" + topic + "`");
-    return Result<SubRelationsMap>::Ok(std::move(*req.out));
+    // the expansion (router.rs:194-261) runs HERE, on the caller's thread: N callers expand in parallel, like N tokio workers
+    auto m = router_.expand(*req.pass, req.index, id, topic);
+    if (!m) return Result<SubRelationsMap>::Err("invalid topic `" + topic + "`");
+    return Result<SubRelationsMap>::Ok(std::move(*m));
 }
 
 void Batcher::run() {
@@ -394,15 +501,14 @@ void Batcher::run() {
         reqs.swap(queue_);
         if (reqs.size() > max_batch_) { queue_.assign(reqs.begin() + max_batch_, reqs.end()); reqs.resize(max_batch_); }
         lk.unlock();                                              // callers keep enqueueing during the device pass
-        std::vector<Id> ids;
         std::vector<TopicName> topics;
-        for (Req* r : reqs) { ids.push_back(r->id); topics.push_back(r->topic); }
-        std::vector<std::optional<SubRelationsMap>> outs;
-        auto res = router_.matches_batch(ids, topics, outs);
+        for (Req* r : reqs) topics.push_back(r->topic);
+        auto pass = std::make_shared<GpuRouter::FilterPass>();
+        auto res = router_.filters_pass(topics, *pass);
         lk.lock();
         passes_++;
         for (size_t i = 0; i < reqs.size(); ++i) {
-            if (!res.ok()) reqs[i]->err = res.error; else reqs[i]->out = std::move(outs[i]);
+            if (!res.ok()) reqs[i]->err = res.error; else { reqs[i]->pass = pass; reqs[i]->index = i; }
             reqs[i]->done = true;
         }
         cv_done_.notify_all();

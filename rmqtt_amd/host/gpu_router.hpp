@@ -25,6 +25,7 @@
 // deadline micro-batcher that sits between the per-publish trait call and the batched device
 // pass (the twin of rust/rmqtt-gpu-router/src/batcher.rs).
 #pragma once
+#include <atomic>
 #include <condition_variable>
 #include <cstdint>
 #include <functional>
@@ -33,6 +34,7 @@
 #include <mutex>
 #include <thread>
 #include <optional>
+#include <shared_mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -152,6 +154,32 @@ class GpuRouter final : public Router {
     // out[i] is nullopt where the reference would return Err (invalid topic name).
     Result<bool> matches_batch(const std::vector<Id>& ids, const std::vector<TopicName>& topics,
                                std::vector<std::optional<SubRelationsMap>>& out);
+    // How `matches` asks the device (r3):
+    //   Filters  rgr_group_match_filter_subs: the device walks the trie and returns, per publish, one sub id per matched filter
+    //            (4 B per FILTER over PCIe); the per-client loop of router.rs:194-231 — No Local, $share, the v3/v5 collector —
+    //            runs on the host over this router's own relations map, exactly where the reference runs it.  This is the
+    //            default: at config-3 fan-out the 12-byte tuples of the Deliver path are 178 KB per publish over PCIe.
+    //   Deliver  rgr_group_match_batch_deliver: 12-byte tuples carrying the device's delivery words (No Local, v5 first-hit
+    //            flags, node index); the host only folds them into the map.  Kept for low fan-out and as the cross-check of the
+    //            device's delivery stage (flag_mismatches()).
+    //   Auto     Filters, unless the running mean of hits per publish is below kAutoDeliverBelow.
+    enum class MatchMode { Auto, Filters, Deliver };
+    void set_match_mode(MatchMode m) { mode_ = m; }
+    static constexpr double kAutoDeliverBelow = 8.0;
+    // The two halves of the Filters path, for a batcher that lets every CALLER expand its own publish in parallel (as every
+    // tokio worker does in the reference): one device pass for the whole batch, then expand() per publish on any thread.
+    struct FilterPass {
+        rgr_filters_result res{};
+        uint64_t epoch = 0;                 // mutation epoch the pass saw
+        FilterPass() = default;
+        FilterPass(const FilterPass&) = delete;
+        FilterPass& operator=(const FilterPass&) = delete;
+        ~FilterPass() { rgr_filters_result_free(&res); }
+    };
+    Result<bool> filters_pass(const std::vector<TopicName>& topics, FilterPass& pass);
+    // nullopt: the reference would return Err (invalid topic name)
+    std::optional<SubRelationsMap> expand(const FilterPass& pass, size_t t, const Id& id, const TopicName& topic);
+    uint64_t stale_expansions() const { return stale_expansions_; }
     bool is_online(NodeId node, const std::string& client) override { return is_online_ ? is_online_(node, client) : true; }   // session state lives in the broker
     std::vector<Route> gets(size_t limit) override;
     Result<std::vector<Route>> get(const std::string& topic) override;       // router.rs:157-170 (.unique())
@@ -178,7 +206,7 @@ class GpuRouter final : public Router {
         uint32_t find(const std::string& k) const;                             // RGR_ID_NONE if absent
     };
     struct FilterEntry { std::unordered_map<ClientId, Rel> rels; };
-    struct Slot { const std::string* filter = nullptr; const Rel* rel = nullptr; };
+    struct Slot { const std::string* filter = nullptr; const Rel* rel = nullptr; const FilterEntry* entry = nullptr; };
 
     rgr_group* g_ = nullptr;
     std::shared_ptr<SharedSubscription> shared_;
@@ -188,7 +216,17 @@ class GpuRouter final : public Router {
     NodeId this_node_;
     std::vector<int32_t> devices_;
     bool bulk_loaded_ = false;           // relations loaded by restore(): the tuples' node bits are not populated
-    std::mutex mu_;   // the reference uses DashMap + a trie RwLock; one mutex is enough for the mirror
+    // add / remove / restore / commit: exclusive; a device pass and the host expansion of its result: shared (the reference:
+    // DashMap + a trie RwLock).  A sub id freed by remove() is quarantined until the next commit has dropped it from the device
+    // table, and a pass remembers the mutation epoch it ran at: expand() re-runs a publish whose pass is older than the last
+    // mutation, so a recycled id can never resolve to a relation the device did not match.
+    std::shared_mutex mu_;
+    std::mutex commit_mu_;
+    std::atomic<uint64_t> mutation_epoch_{0};
+    std::atomic<uint64_t> stale_expansions_{0};
+    std::vector<uint32_t> quarantined_sub_ids_;
+    MatchMode mode_ = MatchMode::Auto;
+    std::atomic<double> mean_hits_{1e9};         // running mean of hits per publish (Auto)
     std::unordered_map<TopicFilter, FilterEntry> relations_;   // AllRelationsMap
     std::vector<Slot> slab_;           // sub_id -> relation
     std::vector<uint32_t> free_sub_ids_;
@@ -196,9 +234,11 @@ class GpuRouter final : public Router {
     std::vector<NodeId> nodes_;          // node_idx -> NodeId
     std::unordered_map<NodeId, uint16_t> node_idx_;
     Counter topics_count_, relations_count_;
-    bool dirty_ = false;
+    std::atomic<bool> dirty_{false};
 
-    int32_t commit_if_dirty();
+    int32_t commit_if_dirty();           // caller holds mu_ exclusively
+    Result<bool> matches_batch_deliver(const std::vector<Id>& ids, const std::vector<TopicName>& topics, std::vector<std::optional<SubRelationsMap>>& out);
+    std::optional<SubRelationsMap> expand_locked(const rgr_filters_result& res, size_t t, const Id& id, const TopicName& topic, uint64_t* hits);
 };
 
 // Deadline micro-batcher in front of GpuRouter::matches_batch: Router::matches is called once per PUBLISH
@@ -215,7 +255,8 @@ class Batcher {
     uint64_t requests() const { return requests_; }
 
    private:
-    struct Req { Id id; TopicName topic; std::optional<SubRelationsMap> out; std::string err; bool done = false; };
+    // the driver thread runs ONE device pass per batch; every caller then expands its own publish from the shared pass
+    struct Req { Id id; TopicName topic; std::shared_ptr<GpuRouter::FilterPass> pass; size_t index = 0; std::string err; bool done = false; };
     GpuRouter& router_;
     size_t max_batch_;
     std::chrono::microseconds max_delay_;

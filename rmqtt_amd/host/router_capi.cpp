@@ -2,6 +2,8 @@
 // Router mirror and compare its SubRelationsMap with the oracle's DefaultRouter, in the
 // canonical text form of SURVEY.md App. A.5 (see oracle.cpp: orc_router_matches).
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -91,6 +93,65 @@ void hr_set_shared_policy(void* r, int policy) {
     static_cast<GpuRouter*>(r)->set_shared_subscription(policy == 1 ? std::make_shared<SmallestClient>() : nullptr);
 }
 uint64_t hr_flag_mismatches(void* r) { return static_cast<GpuRouter*>(r)->flag_mismatches(); }
+// 0 auto, 1 filters (rgr_group_match_filter_subs + host expansion), 2 deliver (tuples with delivery words)
+void hr_set_match_mode(void* r, int mode) {
+    static_cast<GpuRouter*>(r)->set_match_mode(mode == 1 ? GpuRouter::MatchMode::Filters : mode == 2 ? GpuRouter::MatchMode::Deliver : GpuRouter::MatchMode::Auto);
+}
+uint64_t hr_stale_expansions(void* r) { return static_cast<GpuRouter*>(r)->stale_expansions(); }
+// Bulk restore straight from (filter, client) arrays — the bench's way to load 10 M relations without 10 M trait calls
+// (same path as ClusterRouter::restore: GpuRouter::restore over a decoded snapshot).
+int hr_restore_bulk(void* r, const uint8_t* blob, const uint64_t* offs, const uint32_t* client, const uint8_t* qos, uint64_t n) {
+    raft::Snapshot snap;
+    snap.relations.reserve(n);
+    for (uint64_t i = 0; i < n; ++i) {
+        raft::Relation rel;
+        rel.topic_filter.assign(reinterpret_cast<const char*>(blob) + offs[i], offs[i + 1] - offs[i]);
+        rel.client_id = "c" + std::to_string(client[i]);
+        rel.id.node_id = 1; rel.id.client_id = rel.client_id;
+        rel.opts.qos = qos ? qos[i] : 0;
+        snap.relations.push_back(std::move(rel));
+    }
+    auto res = static_cast<GpuRouter*>(r)->restore(snap);
+    return res.ok() ? 0 : -1;
+}
+// What a broker sees: n_threads host threads call Router::matches through the Batcher, one publish per call, for
+// `seconds` (or until every topic was published `rounds` times).  out[0] = publishes, out[1] = hits (rows of the returned
+// maps), out[2] = device passes; lat_us (optional, [n_lat]) receives per-call latencies of thread 0 in microseconds.
+int hr_e2e_run(void* r, const uint8_t* blob, const uint64_t* offs, uint32_t n, uint32_t n_threads, uint32_t max_batch, uint32_t max_delay_us,
+               double seconds, uint64_t* out, double* wall_s, float* lat_us, uint32_t n_lat, uint32_t* n_lat_out) {
+    auto* router = static_cast<GpuRouter*>(r);
+    std::atomic<uint64_t> pubs{0}, hits{0};
+    std::atomic<bool> stop{false};
+    uint32_t lat_n = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    uint64_t passes = 0;
+    {
+        Batcher b(*router, max_batch, std::chrono::microseconds(max_delay_us));
+        std::vector<std::thread> th;
+        for (uint32_t k = 0; k < n_threads; ++k)
+            th.emplace_back([&, k] {
+                Id id; id.node_id = 1; id.client_id = "publisher" + std::to_string(k);
+                uint64_t my_p = 0, my_h = 0;
+                for (uint64_t i = k; !stop.load(std::memory_order_relaxed); i += n_threads) {
+                    const uint32_t t = uint32_t(i % n);
+                    const auto a = std::chrono::steady_clock::now();
+                    auto res = b.matches(id, std::string(reinterpret_cast<const char*>(blob) + offs[t], offs[t + 1] - offs[t]));
+                    if (k == 0 && lat_us && lat_n < n_lat) lat_us[lat_n++] = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - a).count();
+                    ++my_p;
+                    if (res.ok()) for (auto& kv : *res.value) my_h += kv.second.size();
+                }
+                pubs += my_p; hits += my_h;
+            });
+        std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
+        stop = true;
+        for (auto& t : th) t.join();
+        passes = b.passes();
+    }
+    if (wall_s) *wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    out[0] = pubs; out[1] = hits; out[2] = passes;
+    if (n_lat_out) *n_lat_out = lat_n;
+    return 0;
+}
 // n publishes issued from n_threads threads through a Batcher (max_batch / max_delay_us): dumps joined by '\x1e'
 // ("!ERR" where matches returned Err); *passes = device passes the batcher needed.
 char* hr_batcher_run(void* r, const hr_id* ids, const char* const* topics, const uint32_t* lens, uint32_t n, uint32_t n_threads,

@@ -9,6 +9,7 @@ import re
 
 import pytest
 
+from oracle import brute
 from oracle import oracle as orc
 from rmqtt_amd import build
 
@@ -36,6 +37,8 @@ def hr():
     L.hr_shards.argtypes = [vp]; L.hr_shards.restype = C.c_uint32
     L.hr_set_shared_policy.argtypes = [vp, C.c_int]; L.hr_set_shared_policy.restype = None
     L.hr_flag_mismatches.argtypes = [vp]; L.hr_flag_mismatches.restype = C.c_uint64
+    L.hr_set_match_mode.argtypes = [vp, C.c_int]; L.hr_set_match_mode.restype = None
+    L.hr_stale_expansions.argtypes = [vp]; L.hr_stale_expansions.restype = C.c_uint64
     L.hr_batcher_run.argtypes = [vp, C.POINTER(HrId), C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                  C.POINTER(C.c_uint64)]
     L.hr_batcher_run.restype = vp
@@ -79,9 +82,14 @@ def _strip_rel(s):   # oracle v3 rows carry a test-only rel_id column
     return None if s is None else re.sub(r"^(3 [^\t\n]*\t[^\t\n]*\t\d+)\t\d+", r"\1", s, flags=re.M)
 
 
-def test_router_mirror_matches_oracle(hr):
+MODES = [pytest.param(1, id="filters"), pytest.param(2, id="deliver")]     # GpuRouter::MatchMode: how `matches` asks the device
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_router_mirror_matches_oracle(hr, mode):
     g = hr.hr_new(1, 0)
     assert g
+    hr.hr_set_match_mode(g, mode)
     o = orc.DefaultRouter()
     rng = random.Random(7)
     levels = ["a", "b", "c", "", "$SYS"]
@@ -276,15 +284,17 @@ def _topics(rng, n):
     return ["/".join(rng.choice(levels) for _ in range(rng.randint(1, 4))) for _ in range(n)] + ["a/+", "b/#", "a/#/b"]
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("policy", [0, 1])
 @pytest.mark.parametrize("devices", [[0], [0, 0, 0]])
-def test_shared_groups_and_sharded_router_match_oracle(hr, policy, devices):
+def test_shared_groups_and_sharded_router_match_oracle(hr, policy, devices, mode):
     """$share members go through SharedSubscription::choice exactly where router.rs:202-255 does (policy 0 = the
     reference's default: nobody is selected; policy 1 = an order-independent test policy installed on both sides),
     on one handle and on a router sharded over three shards."""
     devs = (C.c_int * len(devices))(*devices)
     g = hr.hr_new_sharded(1, devs, len(devices))
     assert g and hr.hr_shards(g) == len(devices)
+    hr.hr_set_match_mode(g, mode)
     o = orc.DefaultRouter()
     hr.hr_set_shared_policy(g, policy)
     o.set_shared_policy(policy)
@@ -327,4 +337,54 @@ def test_batcher_many_threads_one_pass_per_batch(hr):
         exp = _strip_rel(o.matches(ids_o[i], t))
         assert got[i] == ("!ERR" if exp is None else exp), (i, t)
     assert 1 <= passes.value < n / 3
+    hr.hr_free(g)
+
+
+def test_matches_while_the_table_changes(hr):
+    """Publishes from 6 threads through the batcher while another thread subscribes and unsubscribes: a sub id freed by
+    `remove` is quarantined until the next commit and every pass carries the mutation epoch it ran at, so an expansion never
+    resolves a recycled id to a relation the device did not match.  Every returned row must be a relation whose filter
+    matches the published topic (checked with the oracle's pairwise matcher), and relations that are never touched must
+    always be delivered."""
+    import threading
+    g = hr.hr_new(1, 0)
+    hr.hr_set_match_mode(g, 1)
+    stable = [("s/+/x", "keep1"), ("s/#", "keep2"), ("s/a/x", "keep3")]
+    for f, c in stable:
+        hid, _ = _id(1, c)
+        assert hr.hr_add(g, f.encode(), len(f), C.byref(hid), C.byref(HrOpts())) == 0
+    stop = threading.Event()
+
+    def churn():
+        k = 0
+        while not stop.is_set():
+            f = ["t/+/y", "t/#", "u/+", "t/a/y", "+/a/#"][k % 5]
+            hid, _ = _id(1, f"churn{k % 7}")
+            hr.hr_add(g, f.encode(), len(f), C.byref(hid), C.byref(HrOpts()))
+            if k % 3:
+                hr.hr_remove(g, f.encode(), len(f), C.byref(hid))
+            k += 1
+    th = threading.Thread(target=churn)
+    th.start()
+    try:
+        topics = ["s/a/x", "t/a/y", "u/q", "s/b/x", "t/b/y"] * 60
+        n = len(topics)
+        ids_h = [_id(1, f"pub{i % 5}")[0] for i in range(n)]
+        arr_ids = (HrId * n)(*ids_h)
+        enc = [t.encode() for t in topics]
+        arr_t = (C.c_char_p * n)(*enc)
+        arr_l = (C.c_uint32 * n)(*[len(e) for e in enc])
+        passes = C.c_uint64(0)
+        for _ in range(4):
+            out = _take(hr, hr.hr_batcher_run(g, arr_ids, arr_t, arr_l, n, 6, 32, 300, C.byref(passes))).split("\x1e")
+            for t, dump in zip(topics, out):
+                rows = [ln.split("\t") for ln in dump.split("\n") if ln.startswith("3 ")]
+                got = {(r[0][2:], r[1]) for r in rows}
+                for f, c in got:
+                    assert brute.filter_matches(f, t), (f, t)
+                for f, c in stable:
+                    assert ((f, c) in got) == brute.filter_matches(f, t), (f, c, t)
+    finally:
+        stop.set()
+        th.join()
     hr.hr_free(g)
