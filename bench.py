@@ -797,6 +797,8 @@ def measure_group(args):
     ndev = torch.cuda.device_count()
     devices = [i % ndev for i in range(args.group)]
     g = capi.Group(devices, window_hits=args.window_hits)
+    if args.key_levels:
+        g.set_key_levels(args.key_levels)
     t = time.time()
     rej = g.subscribe_bulk(W["blob"], W["offs"], None, W["qos"])
     g.commit()
@@ -815,7 +817,8 @@ def measure_group(args):
            "value": round(W["n_pub"] * args.steps / dt, 1), "unit": "publish-topic matches/s", "n_gpus": len(set(devices)), "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": round(dt * 1e3 / args.steps, 3), "higher_is_better": True, "scaling": "n/a (shards share the device)",
            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-           "config": {"workload": f"BASELINE.json configs[3] layout: {W['n_sub']} subscriptions sharded by the first 3 topic levels over {args.group} shards, {W['n_pub']} publishes",
+           "config": {"workload": f"BASELINE.json configs[3] layout: {W['n_sub']} subscriptions sharded by the first {args.key_levels or 3} topic level(s) over {args.group} shards, {W['n_pub']} publishes",
+                      "key_levels": args.key_levels or 3,
                       "shards": args.group, "devices": devices, "transport": "rccl" if g.uses_rccl() else "device copies (shards share a GPU)"},
            "hits_per_step": int(tot), "shard_hits": [int(x) for x in sh], "shard_imbalance_max_over_mean": round(float(sh.max()) * args.group / max(1, int(sh.sum())), 3),
            "shard_subs": [int(p["n_subs"]) for p in per], "replicated_subs": int(sum(p["n_subs"] for p in per) - (W["n_sub"] - rej)),
@@ -825,6 +828,16 @@ def measure_group(args):
         tot2, _ = gb.gather(0)
         rec["allgatherv_pass_s"] = round(time.time() - t, 3)
         rec["allgatherv_total_hits"] = int(tot2)
+    if args.gather == "runs":
+        # the exchange step that can run at full fan-out: 16-byte run descriptors, subs[] replicated on every shard
+        gb.gather_runs(0)                           # (first call replicates the subscriber entries)
+        t = time.time()
+        n_runs, n_hits, _ = gb.gather_runs(0)
+        dt2 = time.time() - t
+        rec["run_gather"] = {"pass_s": round(dt2, 3), "matches_per_s": round(W["n_pub"] / dt2, 1), "runs": int(n_runs), "hits_described": int(n_hits),
+                             "bytes_gathered_per_shard": int(n_runs) * 16, "vs_tuples_bytes": int(n_hits) * 12,
+                             "what": "rgr_group_batch_gather_runs: every shard receives every shard's run descriptors (16 B per (topic, filter) run); "
+                                     "hits are read in place from the replicated subs[]"}
     print(json.dumps(rec), flush=True)
     gb.close(); g.close()
     return 0
@@ -837,7 +850,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=3, help="BASELINE.json config number (1-based)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (non-headline runs only)")
-    ap.add_argument("--gather", choices=["none", "counts", "tuples"], default="counts")
+    ap.add_argument("--gather", choices=["none", "counts", "tuples", "runs"], default="counts")
+    ap.add_argument("--key-levels", type=int, default=0, help="--group: leading topic levels hashed into the shard key (default 3; 1 = SURVEY 8(e))")
     ap.add_argument("--cpu-sample", type=int, default=-1, help="queries in the CPU-baseline sample (0 = skip baseline and parity sample, -1 = auto)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--window-hits", type=int, default=0)

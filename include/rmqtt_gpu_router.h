@@ -162,6 +162,18 @@ typedef struct rgr_result {
     void* _owner;
 } rgr_result;
 
+/* Node directory of a delivery result whose tuples were partitioned by node on the device (rgr_match_batch_deliver_grouped):
+ * SubRelationsMap is keyed by node (types.rs:486-497; router.rs:258-261), so per publish the host wants one contiguous slice of
+ * delivery tuples per node.  Inside every topic the tuples are ordered by node index (ascending; stable: TopicTree::matches filter
+ * order and sub-id order are kept inside a node).  Topic t owns groups [group_offsets[t], group_offsets[t+1]); group g holds the
+ * tuples [group_begin[g], group_begin[g+1]) of rgr_result.tuples, all of node index group_node[g] (= delivery word >> 16). */
+typedef struct rgr_node_groups {
+    uint64_t n_groups;
+    uint64_t* group_offsets;    /* [n_topics+1]                                         */
+    uint32_t* group_node;       /* [n_groups]                                           */
+    uint64_t* group_begin;      /* [n_groups+1]                                         */
+} rgr_node_groups;
+
 /* Matched-filter view (TopicTree::matches items without the relation expansion). */
 typedef struct rgr_filters_result {
     uint32_t n_topics;
@@ -283,6 +295,11 @@ int32_t rgr_match_batch(rgr_handle* h, const uint8_t* topics_blob, const uint64_
 /* Same, with the delivery stage: tuples carry delivery words (RGR_HIT_*). attrs: [n]. */
 int32_t rgr_match_batch_deliver(rgr_handle* h, const uint8_t* topics_blob, const uint64_t* topic_offsets, uint32_t n,
                                 const rgr_publish_attr* attrs, rgr_result* out);
+/* rgr_match_batch_deliver with the per-publish grouping by node done on the device ("grouping by NodeId ... as a
+ * second kernel"): a stable radix partition of every topic's tuples by the node index of the delivery word, plus the directory.
+ * `groups` points into memory owned by `out` (released by rgr_result_free(out)). */
+int32_t rgr_match_batch_deliver_grouped(rgr_handle* h, const uint8_t* topics_blob, const uint64_t* topic_offsets, uint32_t n,
+                                        const rgr_publish_attr* attrs, rgr_result* out, rgr_node_groups* groups);
 void rgr_result_free(rgr_result* r);
 int32_t rgr_match_filters(rgr_handle* h, const uint8_t* topics_blob, const uint64_t* topic_offsets, uint32_t n,
                           rgr_filters_result* out);
@@ -429,6 +446,24 @@ int32_t rgr_comm_allgather_u64(rgr_comm* c, uint64_t mine, uint64_t* all);
 typedef void (*rgr_gather_consumer)(void* user, const rgr_tuple* d_tuples, const uint64_t* counts, uint32_t world, uint64_t n_total);
 int32_t rgr_comm_gather_pass(rgr_comm* c, rgr_batch* b, rgr_gather_consumer consume, void* user, uint64_t* my_hits, uint64_t* all_hits);
 
+/* ---- the exchange step with RUN DESCRIPTORS instead of tuples (BASELINE configs[3] at full fan-out) -------------------------
+ * All-gathering every 12-byte tuple to every rank moves 8 x 1.78 TB per pass at config-3 fan-out.  What a rank needs in order to
+ * KNOW every rank's hits is much smaller: the subscriber entries are table data (8 bytes per subscription: 80 MB at 10 M), so
+ * every rank keeps a replica of every rank's subs[] (rgr_comm_replicate_subs: one all-gatherv after a commit), and a pass then
+ * all-gathers only the RUN descriptors — 16 bytes per (topic, matched filter with subscribers) pair.  The hits of descriptor d
+ * are peer_subs(d.shard)[d.src .. d.src + d.len), in order, for topic d.topic (the caller's id when rgr_batch_set_topic_ids was
+ * used), exactly the tuples rgr_comm_gather_pass would have delivered for that run. */
+typedef struct rgr_run { uint32_t shard, src, len, topic; } rgr_run;
+/* Replicate the current epoch's subscriber entries of every rank on every rank.  Collective: every rank calls it, after its
+ * rgr_commit and before rgr_comm_gather_runs_pass (which refuses a batch whose epoch differs from the replicated one). */
+int32_t rgr_comm_replicate_subs(rgr_comm* c);
+/* Device pointer to this rank's replica of rank `rank`'s subs[] ({ sub_id, qos | flags << 8 | node_idx << 16 }, 8 bytes each). */
+int32_t rgr_comm_peer_subs(rgr_comm* c, uint32_t rank, const uint64_t** d_subs, uint64_t* n_entries);
+/* Called once per round with the descriptors of every rank (rank p's counts[p] descriptors start at sum(counts[0..p))). */
+typedef void (*rgr_runs_consumer)(void* user, const rgr_run* d_runs, const uint64_t* counts, uint32_t world, uint64_t n_total);
+int32_t rgr_comm_gather_runs_pass(rgr_comm* c, rgr_batch* b, rgr_runs_consumer consume, void* user, uint64_t* my_runs, uint64_t* all_runs,
+                                  uint64_t* all_hits);
+
 typedef struct rgr_group rgr_group;
 typedef struct rgr_group_batch rgr_group_batch;
 /* One handle per entry of devices[] (cfg->device is ignored).  Distinct ordinals: RCCL communicators over
@@ -437,6 +472,8 @@ typedef struct rgr_group_batch rgr_group_batch;
 int32_t rgr_group_create(const rgr_config* cfg, const int32_t* devices, uint32_t n_devices, rgr_group** out);
 void rgr_group_destroy(rgr_group* g);
 uint32_t rgr_group_size(const rgr_group* g);
+/* Leading topic levels hashed into the shard key (default 3; 1 = SURVEY 8(e)'s first-level rule).  Only while the group is empty. */
+int32_t rgr_group_set_key_levels(rgr_group* g, uint32_t key_levels);
 rgr_handle* rgr_group_handle(rgr_group* g, uint32_t shard);          /* per-shard stats, snapshots, retain twin ... */
 rgr_comm* rgr_group_comm(rgr_group* g, uint32_t shard);
 int32_t rgr_group_uses_rccl(const rgr_group* g);
@@ -458,6 +495,8 @@ int32_t rgr_group_commit(rgr_group* g);
 int32_t rgr_group_match_batch(rgr_group* g, const uint8_t* topics_blob, const uint64_t* topic_offsets, uint32_t n, rgr_result* out);
 int32_t rgr_group_match_batch_deliver(rgr_group* g, const uint8_t* topics_blob, const uint64_t* topic_offsets, uint32_t n,
                                       const rgr_publish_attr* attrs, rgr_result* out);
+int32_t rgr_group_match_batch_deliver_grouped(rgr_group* g, const uint8_t* topics_blob, const uint64_t* topic_offsets, uint32_t n,
+                                              const rgr_publish_attr* attrs, rgr_result* out, rgr_node_groups* groups);
 /* rgr_match_filter_subs over the group (topics routed to their owner shard, lists stitched back into the caller's order). */
 int32_t rgr_group_match_filter_subs(rgr_group* g, const uint8_t* topics_blob, const uint64_t* topic_offsets, uint32_t n, rgr_filters_result* out);
 /* Device-resident form: the batch is split by owner shard; tuples carry the caller's topic index. */
@@ -468,6 +507,11 @@ rgr_batch* rgr_group_batch_shard(rgr_group_batch* gb, uint32_t shard);
 int32_t rgr_group_batch_run(rgr_group_batch* gb, uint64_t* shard_hits /* [size], optional */, uint64_t* total_hits);
 /* one pass with every window all-gathered to every shard; consume runs on shard `consumer_shard`'s thread */
 int32_t rgr_group_batch_gather(rgr_group_batch* gb, uint32_t consumer_shard, rgr_gather_consumer consume, void* user, uint64_t* total_hits);
+/* The run-descriptor form of rgr_group_batch_gather (rgr_comm_replicate_subs on every shard first when its table changed). */
+int32_t rgr_group_batch_gather_runs(rgr_group_batch* gb, uint32_t consumer_shard, rgr_runs_consumer consume, void* user, uint64_t* total_runs,
+                                    uint64_t* total_hits);
+/* Device pointer to shard `holder`'s replica of shard `of`'s subs[] (valid until the next rgr_group_batch_gather_runs after a commit). */
+int32_t rgr_group_peer_subs(rgr_group* g, uint32_t holder, uint32_t of, const uint64_t** d_subs, uint64_t* n_entries);
 
 /* ---- observability ------------------------------------------------------------------------ */
 int32_t rgr_stats_get(rgr_handle* h, rgr_stats* out);

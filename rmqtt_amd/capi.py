@@ -30,7 +30,7 @@ SYMBOLS = [
     "rgr_create", "rgr_destroy", "rgr_last_error", "rgr_version",
     "rgr_filter_add", "rgr_filter_find", "rgr_filter_remove", "rgr_sub_add", "rgr_sub_add_ex", "rgr_sub_attrs_bulk",
     "rgr_sub_remove", "rgr_subscribe_bulk", "rgr_snapshot_save", "rgr_snapshot_load", "rgr_commit",
-    "rgr_match_batch", "rgr_match_batch_deliver", "rgr_result_free", "rgr_match_filters", "rgr_match_filter_subs", "rgr_filters_result_free",
+    "rgr_match_batch", "rgr_match_batch_deliver", "rgr_match_batch_deliver_grouped", "rgr_group_match_batch_deliver_grouped", "rgr_result_free", "rgr_match_filters", "rgr_match_filter_subs", "rgr_filters_result_free",
     "rgr_batch_create", "rgr_batch_create_from_publish", "rgr_batch_publish_info", "rgr_batch_destroy", "rgr_batch_status", "rgr_batch_set_publish_attrs",
     "rgr_batch_set_format", "rgr_batch_set_topic_ids", "rgr_batch_begin", "rgr_batch_next_window",
     "rgr_window_to_host", "rgr_batch_run", "rgr_batch_run_to_host",
@@ -38,12 +38,15 @@ SYMBOLS = [
     "rgr_retain_match_batch", "rgr_retain_result_free", "rgr_retain_batch_create", "rgr_retain_batch_create_tier",
     "rgr_shard_assign", "rgr_stats_get", "rgr_stats_reset",
     "rgr_comm_unique_id", "rgr_comm_create", "rgr_comm_destroy", "rgr_comm_allgather_u64", "rgr_comm_gather_pass",
-    "rgr_group_create", "rgr_group_destroy", "rgr_group_size", "rgr_group_handle", "rgr_group_comm", "rgr_group_uses_rccl",
+    "rgr_comm_replicate_subs", "rgr_comm_peer_subs", "rgr_comm_gather_runs_pass", "rgr_group_batch_gather_runs", "rgr_group_peer_subs",
+    "rgr_group_create", "rgr_group_destroy", "rgr_group_size", "rgr_group_set_key_levels", "rgr_group_handle", "rgr_group_comm", "rgr_group_uses_rccl",
     "rgr_group_subscribe_bulk", "rgr_group_sub_attrs_bulk", "rgr_group_subscribe", "rgr_group_subscribe_ex", "rgr_group_unsubscribe", "rgr_group_commit",
     "rgr_group_match_batch", "rgr_group_match_batch_deliver", "rgr_group_match_filter_subs",
     "rgr_group_batch_create", "rgr_group_batch_destroy", "rgr_group_batch_shard", "rgr_group_batch_run", "rgr_group_batch_gather",
 ]
 GATHER_CONSUMER = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.c_uint64)
+RUN_DTYPE = np.dtype([("shard", np.uint32), ("src", np.uint32), ("len", np.uint32), ("topic", np.uint32)])      # == rgr_run
+SUB_ENTRY_DTYPE = np.dtype([("sub_id", np.uint32), ("qos_flags", np.uint32)])                                      # one subs[] entry
 RGR_COMM_ID_BYTES = 128
 
 
@@ -56,6 +59,10 @@ class Config(C.Structure):
 class Result(C.Structure):
     _fields_ = [("n_topics", C.c_uint32), ("n_hits", C.c_uint64), ("status", C.c_void_p),
                 ("hit_offsets", C.c_void_p), ("tuples", C.c_void_p), ("_owner", C.c_void_p)]
+
+
+class NodeGroups(C.Structure):
+    _fields_ = [("n_groups", C.c_uint64), ("group_offsets", C.c_void_p), ("group_node", C.c_void_p), ("group_begin", C.c_void_p)]
 
 
 class FiltersResult(C.Structure):
@@ -300,19 +307,28 @@ class Router:
         finally:
             lib().rgr_result_free(C.byref(r))
 
-    def match_batch_deliver(self, blob, offsets, publish_attrs):
+    def match_batch_deliver(self, blob, offsets, publish_attrs, grouped=False):
         """match_batch with the delivery stage: tuples carry delivery words (RGR_HIT_*).
-        publish_attrs: PUBLISH_ATTR_DTYPE[n] (from_id, qos_retain)."""
+        publish_attrs: PUBLISH_ATTR_DTYPE[n] (from_id, qos_retain).  grouped: every topic's tuples partitioned by node on the
+        device (rgr_match_batch_deliver_grouped) + the node directory (group_offsets / group_node / group_begin)."""
         n = len(offsets) - 1
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         pa = np.ascontiguousarray(publish_attrs, dtype=PUBLISH_ATTR_DTYPE)
         assert len(pa) == n
         r = Result()
+        g = NodeGroups()
         bp, bk = _blob_ptr(blob)
-        _check(lib().rgr_match_batch_deliver(self._h, bp, offsets.ctypes.data, n, pa.ctypes.data, C.byref(r)))
+        if grouped:
+            _check(lib().rgr_match_batch_deliver_grouped(self._h, bp, offsets.ctypes.data, n, pa.ctypes.data, C.byref(r), C.byref(g)))
+        else:
+            _check(lib().rgr_match_batch_deliver(self._h, bp, offsets.ctypes.data, n, pa.ctypes.data, C.byref(r)))
         try:
-            return dict(status=_copy(r.status, n, np.int32), hit_offsets=_copy(r.hit_offsets, n + 1, np.uint64),
-                        tuples=_copy(r.tuples, r.n_hits, TUPLE_DTYPE))
+            out = dict(status=_copy(r.status, n, np.int32), hit_offsets=_copy(r.hit_offsets, n + 1, np.uint64),
+                       tuples=_copy(r.tuples, r.n_hits, TUPLE_DTYPE))
+            if grouped:
+                out.update(group_offsets=_copy(g.group_offsets, n + 1, np.uint64), group_node=_copy(g.group_node, g.n_groups, np.uint32),
+                           group_begin=_copy(g.group_begin, g.n_groups + 1, np.uint64))
+            return out
         finally:
             lib().rgr_result_free(C.byref(r))
 
@@ -551,6 +567,10 @@ class Group:
     def uses_rccl(self):
         return bool(lib().rgr_group_uses_rccl(self._g))
 
+    def set_key_levels(self, k):
+        """Leading topic levels hashed into the shard key (default 3); only while the group is empty."""
+        _check(lib().rgr_group_set_key_levels(self._g, k))
+
     def shard_stats(self, shard):
         s = Stats()
         _check(lib().rgr_stats_get(lib().rgr_group_handle(self._g, shard), C.byref(s)))
@@ -593,6 +613,12 @@ class Group:
                         tuples=_copy(r.tuples, r.n_hits, TUPLE_DTYPE))
         finally:
             lib().rgr_result_free(C.byref(r))
+
+    def peer_subs(self, holder, of):
+        """Shard `holder`'s replica of shard `of`'s subscriber entries (after a gather_runs pass), copied to the host."""
+        p, n = C.c_void_p(), C.c_uint64(0)
+        _check(lib().rgr_group_peer_subs(self._g, holder, of, C.byref(p), C.byref(n)))
+        return device_to_host(p, int(n.value) * 8).view(SUB_ENTRY_DTYPE) if n.value else np.zeros(0, dtype=SUB_ENTRY_DTYPE)
 
     def match_filter_subs(self, blob, offsets):
         """rgr_group_match_filter_subs: per topic, the sub id of each matched filter's first subscriber, in the caller's topic order."""
@@ -650,3 +676,17 @@ class GroupBatch:
         _check(lib().rgr_group_batch_gather(self._b, consumer_shard, fn, None, C.byref(tot)))
         tup = (np.concatenate(parts) if parts else np.zeros(0, dtype=TUPLE_DTYPE)) if collect else None
         return int(tot.value), tup
+
+    def gather_runs(self, consumer_shard=0, collect=False):
+        """All-gathered pass with RUN DESCRIPTORS as the payload (rgr_group_batch_gather_runs).
+        -> (total runs, total hits, descriptors gathered on `consumer_shard` (RUN_DTYPE) | None)"""
+        parts = []
+
+        def cb(user, d_runs, counts, world, n_total):
+            if collect and n_total:
+                parts.append(device_to_host(d_runs, int(n_total) * 16).view(RUN_DTYPE))
+        fn = GATHER_CONSUMER(cb)
+        runs, hits = C.c_uint64(0), C.c_uint64(0)
+        _check(lib().rgr_group_batch_gather_runs(self._b, consumer_shard, fn, None, C.byref(runs), C.byref(hits)))
+        got = (np.concatenate(parts) if parts else np.zeros(0, dtype=RUN_DTYPE)) if collect else None
+        return int(runs.value), int(hits.value), got

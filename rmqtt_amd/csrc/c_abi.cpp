@@ -85,6 +85,7 @@ struct Epoch {
     TrieView view{};
     uint64_t id = 0, n_filters = 0, n_subs = 0, n_nodes = 0, edge_slots = 0, bytes = 0, n_v5 = 0;
     uint32_t max_sub_id = 0;          // upper bound of the sub ids ever added (RGR_FORMAT_PACKED needs < 2^30)
+    uint32_t max_node_idx = 0;        // upper bound of the node indices in the delivery words (node partition: how many radix passes)
 };
 
 struct RetainEpoch {
@@ -193,6 +194,10 @@ struct rgr_batch {
     }
     // delivery stage (rgr_batch_set_publish_attrs)
     bool deliver = false;
+    bool group_by_node = false;          // host-out deliver calls: partition every topic's tuples by node + directory (rgr_node_groups)
+    DevBuf node_tmp[2], grp_cnt, grp_off, grp_node, grp_begin;      // node_tmp: one per window slot (the D2H copy of window k overlaps window k+1)
+    std::vector<uint64_t> h_grp_off, h_grp_begin;     // directory of the window rgr_batch_next_window returned last
+    std::vector<uint32_t> h_grp_node;
     int format = kFmtTuple;              // rgr_batch_set_format
     bool has_topic_ids = false;          // rgr_batch_set_topic_ids
     DevBuf d_topic_ids;
@@ -979,6 +984,7 @@ int32_t rgr_commit(rgr_handle* h) {
             ep->view.attrs = h->sub_pool->has_attrs ? h->sub_pool->attr_buf.as<SubAttr>() : nullptr;
             ep->n_v5 = h->table.n_v5_subs();
             ep->max_sub_id = h->table.max_sub_id();
+            ep->max_node_idx = h->table.max_node_idx();
             ep->n_filters = h->table.n_filters();
             ep->n_subs = h->table.n_subs();
             ep->n_nodes = h->table.n_nodes();
@@ -1036,7 +1042,11 @@ static int32_t batch_create_impl(rgr_handle* h, const uint8_t* blob, const uint6
             const double t1 = now_ms();
             const uint64_t nbytes = n ? offs[n] - offs[0] : 0;
             std::vector<uint64_t> rel(size_t(n) + 1, 0);
-            for (uint32_t i = 0; i <= n && n; ++i) rel[i] = offs[i] - offs[0];
+            // the framing comes from the network side: offsets must not go backwards (publish_scan computes offs[i+1] - offs[i] and reads
+        // that many bytes of the uploaded blob)
+        for (uint32_t i = 0; i < n; ++i)
+            if (offs[i] > offs[i + 1]) return fail(RGR_EINVAL, "rgr_batch_create_from_publish: packet_offsets are not monotonic");
+        for (uint32_t i = 0; i <= n && n; ++i) rel[i] = offs[i] - offs[0];
             b->d_blob.ensure(std::max<uint64_t>(16, nbytes + 16));
             b->d_offs.ensure((size_t(n) + 1) * 8);
             if (nbytes) RGR_HIP(hipMemcpyAsync(b->d_blob.p, blob + offs[0], nbytes, hipMemcpyHostToDevice, b->stream));
@@ -1075,6 +1085,10 @@ int32_t rgr_batch_create_from_publish(rgr_handle* h, const uint8_t* packets, con
         const double t1 = now_ms();
         const uint64_t nbytes = n ? offs[n] - offs[0] : 0;
         std::vector<uint64_t> rel(size_t(n) + 1, 0);
+        // the framing comes from the network side: offsets must not go backwards (publish_scan computes offs[i+1] - offs[i] and reads
+        // that many bytes of the uploaded blob)
+        for (uint32_t i = 0; i < n; ++i)
+            if (offs[i] > offs[i + 1]) return fail(RGR_EINVAL, "rgr_batch_create_from_publish: packet_offsets are not monotonic");
         for (uint32_t i = 0; i <= n && n; ++i) rel[i] = offs[i] - offs[0];
         b->d_pkts.ensure(std::max<uint64_t>(16, nbytes + 16));
         b->d_pkt_offs.ensure((size_t(n) + 1) * 8);
@@ -1333,12 +1347,50 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
                 b->local.dedup_launches++;
             }
         }
+        void* grouped_out = nullptr;
+        if (b->group_by_node && b->deliver && !b->retain && b->format == kFmtTuple) {
+            const uint32_t nt = le - lc;
+            const uint64_t* d_ho = b->c->hit_off.as<uint64_t>() + lc;
+            Tuple* cur = (b->alt_out ? b->out2 : b->out).as<Tuple>();
+            if (nh && b->epoch->max_node_idx > 0) {          // one radix-256 pass per byte of the largest node index
+                DevBuf& tmp = b->node_tmp[b->alt_out ? 1 : 0];
+                tmp.ensure(nh * sizeof(Tuple));
+                Tuple* other = tmp.as<Tuple>();
+                size_t sp = b->span_begin(kSpanExpand);
+                for (uint32_t shift = 16; shift < 32 && (b->epoch->max_node_idx >> (shift - 16)) != 0; shift += 8) {
+                    launch_node_partition(cur, other, d_ho, hit_lo, nt, shift, b->stream);
+                    std::swap(cur, other);
+                }
+                b->span_end(sp);
+            }
+            grouped_out = cur;
+            // directory: groups per topic -> scan -> (node, first position) per group
+            b->grp_cnt.ensure(std::max<size_t>(1, nt) * 4);
+            b->grp_off.ensure((size_t(nt) + 1) * 8);
+            b->scan_tmp.ensure((size_t(nt) / scan_block_topics() + 3) * 16);
+            launch_node_groups(cur, d_ho, hit_lo, nt, b->grp_cnt.as<uint32_t>(), nullptr, nullptr, nullptr, 0, b->stream);
+            launch_scan_u32(b->grp_cnt.as<uint32_t>(), b->grp_off.as<uint64_t>(), nt, b->scan_tmp.as<uint64_t>(), b->stream);
+            b->h_grp_off.assign(size_t(nt) + 1, 0);
+            RGR_HIP(hipMemcpyAsync(b->h_grp_off.data(), b->grp_off.p, (size_t(nt) + 1) * 8, hipMemcpyDeviceToHost, b->stream));
+            RGR_HIP(hipStreamSynchronize(b->stream));
+            const uint64_t ng = b->h_grp_off[nt];
+            b->h_grp_node.assign(ng, 0);
+            b->h_grp_begin.assign(ng, 0);
+            if (ng) {
+                b->grp_node.ensure(ng * 4);
+                b->grp_begin.ensure(ng * 8);
+                launch_node_groups(cur, d_ho, hit_lo, nt, nullptr, b->grp_off.as<uint64_t>(), b->grp_node.as<uint32_t>(), b->grp_begin.as<uint64_t>(), 0, b->stream);
+                RGR_HIP(hipMemcpyAsync(b->h_grp_node.data(), b->grp_node.p, ng * 4, hipMemcpyDeviceToHost, b->stream));
+                RGR_HIP(hipMemcpyAsync(b->h_grp_begin.data(), b->grp_begin.p, ng * 8, hipMemcpyDeviceToHost, b->stream));
+                RGR_HIP(hipStreamSynchronize(b->stream));
+            }
+        }
         w->topic_begin = b->cursor;
         w->topic_end = b->c->begin + le;
         w->n_hits = nh;
         w->hit_base = b->hits_before;
         {
-            void* op = b->alt_out ? b->out2.p : b->out.p;
+            void* op = grouped_out ? grouped_out : (b->alt_out ? b->out2.p : b->out.p);
             const uint64_t ids_bytes = (nh * 4 + 255) & ~uint64_t(255);
             w->d_tuples = b->format == kFmtTuple ? reinterpret_cast<const rgr_tuple*>(op) : nullptr;
             w->d_sub_ids = (b->format == kFmtSoa || b->format == kFmtPacked) && nh ? static_cast<const uint32_t*>(op) : nullptr;
@@ -1475,13 +1527,16 @@ struct ResultOwner {
     std::vector<uint64_t> offsets;
     TupleStore tuples;
     std::vector<uint32_t> ids;
+    std::vector<uint64_t> grp_off, grp_begin;     // rgr_node_groups
+    std::vector<uint32_t> grp_node;
 };
 }  // namespace
 
 static int32_t match_batch_impl(rgr_handle* h, const uint8_t* blob, const uint64_t* offs, uint32_t n, const rgr_publish_attr* attrs,
-                                rgr_result* out, const uint32_t* topic_ids = nullptr) {
+                                rgr_result* out, const uint32_t* topic_ids = nullptr, rgr_node_groups* groups = nullptr) {
     if (!out) return fail(RGR_EINVAL, "rgr_match_batch: out is NULL");
     std::memset(out, 0, sizeof *out);
+    if (groups) std::memset(groups, 0, sizeof *groups);
     rgr_batch* b = nullptr;
     int32_t rc = batch_create_impl(h, blob, offs, n, false, &b, true);
     if (rc != RGR_OK) return rc;
@@ -1494,6 +1549,9 @@ static int32_t match_batch_impl(rgr_handle* h, const uint8_t* blob, const uint64
         if (r != RGR_OK) return r;
         if (topic_ids) { r = rgr_batch_set_topic_ids(b, topic_ids); if (r != RGR_OK) return r; }
         b->want_host_offsets = true;
+        b->group_by_node = groups != nullptr && attrs != nullptr;
+        struct ClearGrouping { rgr_batch* b; ~ClearGrouping() { b->group_by_node = false; } } clear_grouping{b};
+        if (b->group_by_node) own->grp_off.assign(size_t(n) + 1, 0);
         r = rgr_batch_begin(b);
         if (r != RGR_OK) return r;
         // Windows are expanded and copied in a two-deep pipeline straight into the result block.  The block is
@@ -1519,6 +1577,12 @@ static int32_t match_batch_impl(rgr_handle* h, const uint8_t* blob, const uint64
                 fetch_host_arrays(b);
                 const uint64_t* ho = b->c->h_hit_off.as<uint64_t>() + (w.topic_begin - b->c->begin);
                 for (uint32_t i = 0; i <= w.topic_end - w.topic_begin; ++i) own->offsets[w.topic_begin + i] = base + (ho[i] - w.offsets_bias);
+                if (b->group_by_node) {                        // the window's node directory, rebased to the result block
+                    const uint64_t g0 = own->grp_node.size();
+                    for (uint32_t i = 0; i <= w.topic_end - w.topic_begin; ++i) own->grp_off[w.topic_begin + i] = g0 + b->h_grp_off[i];
+                    own->grp_node.insert(own->grp_node.end(), b->h_grp_node.begin(), b->h_grp_node.end());
+                    for (uint64_t gb : b->h_grp_begin) own->grp_begin.push_back(base + gb);
+                }
                 in_flight[k] = true;
                 return own->tuples.p + base;
             },
@@ -1529,6 +1593,14 @@ static int32_t match_batch_impl(rgr_handle* h, const uint8_t* blob, const uint64
         out->status = own->status.data();
         out->hit_offsets = own->offsets.data();
         out->tuples = own->tuples.p;
+        if (groups && attrs) {
+            for (uint32_t i = 1; i <= n; ++i) if (own->grp_off[i] < own->grp_off[i - 1]) own->grp_off[i] = own->grp_off[i - 1];   // (topics after the last window)
+            own->grp_begin.push_back(own->tuples.n);
+            groups->n_groups = own->grp_node.size();
+            groups->group_offsets = own->grp_off.data();
+            groups->group_node = own->grp_node.data();
+            groups->group_begin = own->grp_begin.data();
+        }
         out->_owner = own.release();
         return RGR_OK;
     });
@@ -1544,6 +1616,12 @@ int32_t rgr_match_batch_deliver(rgr_handle* h, const uint8_t* blob, const uint64
                                 rgr_result* out) {
     if (n && !attrs) return fail(RGR_EINVAL, "rgr_match_batch_deliver: attrs is NULL");
     return match_batch_impl(h, blob, offs, n, attrs, out);
+}
+
+int32_t rgr_match_batch_deliver_grouped(rgr_handle* h, const uint8_t* blob, const uint64_t* offs, uint32_t n, const rgr_publish_attr* attrs,
+                                        rgr_result* out, rgr_node_groups* groups) {
+    if ((n && !attrs) || !groups) return fail(RGR_EINVAL, "rgr_match_batch_deliver_grouped: bad argument");
+    return match_batch_impl(h, blob, offs, n, attrs, out, nullptr, groups);
 }
 
 void rgr_result_free(rgr_result* r) {

@@ -25,6 +25,7 @@
 //   scatter_*       incremental epoch update: patch dirty edge records / filter descriptors.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 
 #include "kernels.hpp"
@@ -627,6 +628,15 @@ __global__ __launch_bounds__(256) void tiles_kernel(ChunkArrays c, uint64_t pair
     tiles_pair_rec(c, p, pair_lo, hit_lo, kTile, tile_first);
 }
 
+// --------------------------------------------------------------------------- run descriptors for the exchange step
+// One 16-byte descriptor per (topic, subscriber-run) pair of a window: what crosses xGMI in the run gather instead of the
+// 12-byte tuples themselves (at config-3 fan-out ~20 runs = 320 B per publish instead of 178 KB of tuples).
+__global__ __launch_bounds__(256) void pack_runs_kernel(const uint32_t* __restrict__ src, const uint32_t* __restrict__ topic,
+                                                        const uint64_t* __restrict__ off, uint64_t n, uint32_t shard, RunDesc* __restrict__ out) {
+    const uint64_t r = uint64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (r < n) out[r] = RunDesc{shard, src[r], uint32_t(off[r + 1] - off[r]), topic[r]};
+}
+
 // --------------------------------------------------------------------------- expand
 // kDeliver: the delivery stage fused into the expansion — the tuple's third word becomes the
 // delivery word (deliver_word, match_core.hpp) and v5 hits that may be per-client duplicates are
@@ -640,10 +650,10 @@ __global__ __launch_bounds__(kThreads) void expand_kernel(const SubEntry* __rest
     __shared__ int32_t s_off[kTile + 2];
     __shared__ uint32_t s_src[kTile + 2];
     __shared__ uint32_t s_topic[kTile + 2];
-    __shared__ uint32_t s_ncand;
+    __shared__ uint32_t s_ncand, s_inside;
     __shared__ uint32_t s_pc[kDeliver ? kTile + 2 : 1];   // dedup candidates per staged pair
     __shared__ uint8_t s_qr[kDeliver ? kTile + 2 : 1];    // publish qos | retain<<2 of the pair's topic
-    if (kDeliver && threadIdx.x == 0) s_ncand = 0;
+    if (kDeliver && threadIdx.x == 0) { s_ncand = 0; s_inside = 0; }
 
     const uint32_t tile = blockIdx.x;
     const uint64_t base = hit_lo + uint64_t(tile) * kTile;
@@ -753,15 +763,25 @@ __global__ __launch_bounds__(kThreads) void expand_kernel(const SubEntry* __rest
     // uniformly) when the epoch holds no v5 subscription
     if (kDeliver && da.cand) {
         __syncthreads();
-        if (threadIdx.x == 0) da.tile_ncand[tile] = s_ncand;
-        if (s_ncand)   // per-topic candidate counts: the tile's pairs of one topic are adjacent, their first pair's lane sums them
+        if (s_ncand) {   // per-topic candidate counts: the tile's pairs of one topic are adjacent, their first pair's lane sums them
             for (uint32_t i = threadIdx.x; i < np; i += kThreads) {
                 const uint32_t tp = s_topic[i];
                 if (i != 0 && s_topic[i - 1] == tp) continue;
-                uint32_t sum = 0;
-                for (uint32_t k = i; k < np && s_topic[k] == tp; ++k) sum += s_pc[k];
+                uint32_t sum = 0, k = i;
+                for (; k < np && s_topic[k] == tp; ++k) sum += s_pc[k];
                 if (sum) atomicAdd(&da.topic_cand[tp - da.topic_lo], sum);
+                // Does this topic lie ENTIRELY inside the tile with at least two candidates?  Only then can the tile-local dedup
+                // find a duplicate here (topics that span tiles are the topic pass's): the tile pass skips every other tile.
+                if (sum >= 2) {
+                    bool inside = true;
+                    if (i == 0) inside = c.pair_off[a] == base && (a == pair_lo || c.pair_topic[a - 1] != tp);
+                    if (inside && k == np) inside = c.pair_off[b] <= base + kTile && (b == pair_hi || c.pair_topic[b] != tp);
+                    if (inside) s_inside = 1;
+                }
             }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) da.tile_ncand[tile] = s_ncand | (s_inside << 31);
         // the tile's candidates go to the tile's own slice of the list: no global cursor
         Cand* mine = da.cand + uint64_t(tile) * kTile;
 #pragma unroll
@@ -912,42 +932,42 @@ constexpr int kDedupTopicSlots = 4096;                // u64 slots: 32 KiB -> 4 
 constexpr int kDedupTopicCap = kDedupTopicSlots / 2;  // candidates per part
 constexpr int kDedupTopicThreads = 512;
 
-__global__ __launch_bounds__(256) void dedup_tile_kernel(const Cand* __restrict__ cand, const uint32_t* __restrict__ tile_ncand,
+__global__ __launch_bounds__(256) void dedup_tile_kernel(const Cand* __restrict__ cand, const uint32_t* __restrict__ tile_ncand, uint32_t ntiles,
                                                          const uint64_t* __restrict__ hit_off, uint64_t hit_lo, Tuple* __restrict__ tuples,
                                                          unsigned long long* __restrict__ stat) {
     __shared__ uint32_t s_topic[kTile], s_client[kTile], s_pos[kTile];
     __shared__ uint32_t s_tab[kDedupTileSlots];
-    __shared__ uint32_t s_inside;
-    const uint32_t tile = blockIdx.x;
-    const uint32_t n = tile_ncand[tile];
-    if (threadIdx.x == 0 && n) atomicAdd(stat, static_cast<unsigned long long>(n));      // candidates of the pass (rgr_stats)
-    if (n < 2) return;                                                                    // nothing can be a duplicate
-    const Cand* list = cand + uint64_t(tile) * kTile;
-    const uint64_t lo = uint64_t(tile) * kTile, hi = lo + kTile;
-    if (threadIdx.x == 0) s_inside = 0;
-    for (uint32_t i = threadIdx.x; i < uint32_t(kDedupTileSlots); i += 256) s_tab[i] = kNone;
-    __syncthreads();
-    uint32_t inside = 0;
-    for (uint32_t i = threadIdx.x; i < n; i += 256) {
-        const Cand c = list[i];
-        const uint64_t h0 = hit_off[c.topic] - hit_lo, h1 = hit_off[c.topic + 1] - hit_lo;
-        const bool in = h0 >= lo && h1 <= hi;                  // the topic lies entirely inside this tile
-        s_topic[i] = in ? c.topic : kNone; s_client[i] = c.client_idx; s_pos[i] = c.pos;
-        inside += in;
+    unsigned long long seen = 0;                                  // candidates of the tiles this block visited (rgr_stats)
+    // a fixed grid strides over the tiles: all but a few are skipped after one 4-byte read (bit 31 of tile_ncand, set by the
+    // expansion, says whether a whole topic with two or more candidates lies inside the tile)
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const uint32_t raw = tile_ncand[tile];
+        const uint32_t n = raw & 0x7FFFFFFFu;
+        seen += n;
+        if (!(raw >> 31)) continue;
+        const Cand* list = cand + uint64_t(tile) * kTile;
+        const uint64_t lo = uint64_t(tile) * kTile, hi = lo + kTile;
+        __syncthreads();                                          // the previous tile's lookups are done
+        for (uint32_t i = threadIdx.x; i < uint32_t(kDedupTileSlots); i += 256) s_tab[i] = kNone;
+        for (uint32_t i = threadIdx.x; i < n; i += 256) {
+            const Cand c = list[i];
+            const uint64_t h0 = hit_off[c.topic] - hit_lo, h1 = hit_off[c.topic + 1] - hit_lo;
+            const bool in = h0 >= lo && h1 <= hi;                  // the topic lies entirely inside this tile
+            s_topic[i] = in ? c.topic : kNone; s_client[i] = c.client_idx; s_pos[i] = c.pos;
+        }
+        __syncthreads();
+        auto key_topic = [&](uint32_t k) { return s_topic[k]; };
+        auto key_client = [&](uint32_t k) { return s_client[k]; };
+        auto tab_load = [&](uint32_t sl) { return s_tab[sl]; };
+        for (uint32_t i = threadIdx.x; i < n; i += 256)
+            if (s_topic[i] != kNone)
+                dedup_tile_insert(i, s_pos[i] - uint32_t(lo), uint32_t(kDedupTileSlots - 1), key_topic, key_client, tab_load,
+                                  [&](uint32_t sl, uint32_t v) { return atomicCAS(&s_tab[sl], kNone, v); }, [&](uint32_t sl, uint32_t v) { atomicMin(&s_tab[sl], v); });
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < n; i += 256)
+            if (s_topic[i] != kNone && dedup_tile_is_dup(i, uint32_t(kDedupTileSlots - 1), key_topic, key_client, tab_load)) tuples[s_pos[i]].qos_flags |= kHitV5Dup;
     }
-    if (inside) atomicAdd(&s_inside, inside);
-    __syncthreads();
-    if (s_inside < 2) return;
-    auto key_topic = [&](uint32_t k) { return s_topic[k]; };
-    auto key_client = [&](uint32_t k) { return s_client[k]; };
-    auto tab_load = [&](uint32_t sl) { return s_tab[sl]; };
-    for (uint32_t i = threadIdx.x; i < n; i += 256)
-        if (s_topic[i] != kNone)
-            dedup_tile_insert(i, s_pos[i] - uint32_t(lo), uint32_t(kDedupTileSlots - 1), key_topic, key_client, tab_load,
-                              [&](uint32_t sl, uint32_t v) { return atomicCAS(&s_tab[sl], kNone, v); }, [&](uint32_t sl, uint32_t v) { atomicMin(&s_tab[sl], v); });
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n; i += 256)
-        if (s_topic[i] != kNone && dedup_tile_is_dup(i, uint32_t(kDedupTileSlots - 1), key_topic, key_client, tab_load)) tuples[s_pos[i]].qos_flags |= kHitV5Dup;
+    if (threadIdx.x == 0 && seen) atomicAdd(stat, seen);
 }
 
 // One work item per part of every topic that spans tiles and has at least two candidates.
@@ -990,7 +1010,7 @@ __global__ __launch_bounds__(kDedupTopicThreads) void dedup_topic_kernel(const C
                 __syncthreads();
                 // every wave takes whole tiles: a tile's list is read by 64 lanes with a stride of 64
                 for (uint32_t tile = tile0 + wave; tile <= tile1; tile += kWaves) {
-                    const uint32_t n = tile_ncand[tile];
+                    const uint32_t n = tile_ncand[tile] & 0x7FFFFFFFu;
                     const Cand* list = cand + uint64_t(tile) * kTile;
                     for (uint32_t i = lane; i < n; i += 64) {
                         const Cand c = list[i];
@@ -1004,7 +1024,7 @@ __global__ __launch_bounds__(kDedupTopicThreads) void dedup_topic_kernel(const C
                 over = s_over != 0;
                 if (over) break;
                 for (uint32_t tile = tile0 + wave; tile <= tile1; tile += kWaves) {
-                    const uint32_t n = tile_ncand[tile];
+                    const uint32_t n = tile_ncand[tile] & 0x7FFFFFFFu;
                     const Cand* list = cand + uint64_t(tile) * kTile;
                     for (uint32_t i = lane; i < n; i += 64) {
                         const Cand c = list[i];
@@ -1015,6 +1035,101 @@ __global__ __launch_bounds__(kDedupTopicThreads) void dedup_topic_kernel(const C
             }
             if (!over) break;
         }
+    }
+}
+
+// --------------------------------------------------------------------------- delivery results grouped by node
+// SubRelationsMap is keyed by node (types.rs:486-497; router.rs:258-261 builds it from one collector per node): the host glue
+// wants, per publish, one contiguous slice of delivery tuples per node.  The node index rides in bits 16-31 of the delivery
+// word; this is a stable partition of every topic's tuples by that index (filter order, and sub-id order inside a filter, are
+// preserved inside a node) — one radix-256 pass per byte of the largest node index in the table, i.e. one pass for up to 256
+// nodes, none at all for a single-node broker.  One WAVE per topic: histogram of the digit in LDS, exclusive scan of the 256
+// buckets across the lanes, then the scatter with ballot ranks (stable).
+constexpr int kNodeWaves = 4;
+// LDS traffic of ONE wave is issued in order, but the compiler must not move it across the phases of the wave-level
+// algorithm below (the waves of a block work on different topics with different trip counts: no __syncthreads here)
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__global__ __launch_bounds__(64 * kNodeWaves) void node_partition_kernel(const Tuple* __restrict__ in, Tuple* __restrict__ out,
+                                                                         const uint64_t* __restrict__ hit_off, uint64_t hit_lo, uint32_t nt, uint32_t shift) {
+    __shared__ uint32_t s_cnt[kNodeWaves][256];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t* cnt = s_cnt[wave];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (uint32_t t = blockIdx.x * kNodeWaves + wave; t < nt; t += gridDim.x * kNodeWaves) {
+        const uint64_t h0 = hit_off[t] - hit_lo, h1 = hit_off[t + 1] - hit_lo;
+        if (h1 == h0) continue;
+        if (h1 - h0 == 1) { if (lane == 0) out[h0] = in[h0]; continue; }
+        wave_lds_sync();
+        for (uint32_t i = lane; i < 256; i += 64) cnt[i] = 0;
+        wave_lds_sync();
+        for (uint64_t p0 = h0; p0 < h1; p0 += 64) {                       // histogram
+            const uint64_t p = p0 + lane;
+            if (p < h1) atomicAdd(&cnt[(in[p].qos_flags >> shift) & 0xFFu], 1u);
+        }
+        wave_lds_sync();
+        // exclusive scan of the 256 bucket counts: a lane owns 4 consecutive buckets
+        const uint32_t c0 = cnt[lane * 4], c1 = cnt[lane * 4 + 1], c2 = cnt[lane * 4 + 2], c3 = cnt[lane * 4 + 3];
+        uint32_t x = c0 + c1 + c2 + c3;
+        const uint32_t own = x;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o, 64); if (int(lane) >= o) x += y; }
+        const uint32_t base = x - own;
+        cnt[lane * 4] = base; cnt[lane * 4 + 1] = base + c0; cnt[lane * 4 + 2] = base + c0 + c1; cnt[lane * 4 + 3] = base + c0 + c1 + c2;
+        wave_lds_sync();
+        for (uint64_t p0 = h0; p0 < h1; p0 += 64) {                       // stable scatter
+            const uint64_t p = p0 + lane;
+            const bool live = p < h1;
+            Tuple tp{};
+            if (live) tp = in[p];
+            const uint32_t d = (tp.qos_flags >> shift) & 0xFFu;
+            uint32_t dst = 0;
+            unsigned long long rest = __ballot(live);
+            while (rest) {                                                // one round per distinct digit present in the chunk
+                const int leader = __ffsll(static_cast<long long>(rest)) - 1;
+                const uint32_t dl = __shfl(d, leader, 64);
+                const unsigned long long m = __ballot(live && d == dl);
+                const uint32_t b = cnt[dl];                               // (read by every lane before the leader moves the bucket on)
+                wave_lds_sync();
+                if (live && d == dl) dst = b + uint32_t(__popcll(m & below));
+                if (int(lane) == leader) cnt[dl] = b + uint32_t(__popcll(m));
+                wave_lds_sync();
+                rest &= ~m;
+            }
+            if (live) out[h0 + dst] = tp;
+        }
+    }
+}
+
+// Directory of the partitioned window: per topic the number of node groups, then (after the scan) one entry per group.
+// is_start(p): first hit of its topic, or another node than its predecessor.
+__global__ __launch_bounds__(64 * kNodeWaves) void node_groups_kernel(const Tuple* __restrict__ tuples, const uint64_t* __restrict__ hit_off, uint64_t hit_lo,
+                                                                      uint32_t nt, uint32_t* __restrict__ group_cnt, const uint64_t* __restrict__ group_off,
+                                                                      uint32_t* __restrict__ group_node, uint64_t* __restrict__ group_begin, uint64_t begin_bias) {
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (uint32_t t = blockIdx.x * kNodeWaves + wave; t < nt; t += gridDim.x * kNodeWaves) {
+        const uint64_t h0 = hit_off[t] - hit_lo, h1 = hit_off[t + 1] - hit_lo;
+        uint32_t groups = 0;
+        uint32_t prev = kNone;                                            // node of the position before the chunk
+        for (uint64_t p0 = h0; p0 < h1; p0 += 64) {
+            const uint64_t p = p0 + lane;
+            const bool live = p < h1;
+            const uint32_t node = live ? tuples[p].qos_flags >> 16 : 0u;
+            uint32_t left = __shfl_up(node, 1, 64);
+            if (lane == 0) left = prev;
+            const bool start = live && (p == h0 || node != left);
+            const unsigned long long m = __ballot(start);
+            if (group_node && start) {
+                const uint64_t g = group_off[t] + groups + uint32_t(__popcll(m & below));
+                group_node[g] = node; group_begin[g] = begin_bias + p;
+            }
+            groups += uint32_t(__popcll(m));
+            prev = __shfl(node, 63, 64);
+        }
+        if (!group_node && lane == 0) group_cnt[t] = groups;
     }
 }
 
@@ -1149,6 +1264,23 @@ void launch_expand_compact(const TrieView& t, const ChunkArrays& c, uint64_t pai
     else expand_compact_kernel<kFmtSoa><<<ntiles, kCompactThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out_ids, out_qos);
 }
 
+void launch_pack_runs(const uint32_t* src, const uint32_t* topic, const uint64_t* off, uint64_t n, uint32_t shard, RunDesc* out, void* stream) {
+    if (n) pack_runs_kernel<<<uint32_t((n + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(src, topic, off, n, shard, out);
+}
+
+void launch_node_partition(const Tuple* in, Tuple* out, const uint64_t* hit_off, uint64_t hit_lo, uint32_t nt, uint32_t shift, void* stream) {
+    if (!nt) return;
+    const uint32_t blocks = std::min<uint32_t>((nt + kNodeWaves - 1) / kNodeWaves, 8192);
+    node_partition_kernel<<<blocks, 64 * kNodeWaves, 0, static_cast<hipStream_t>(stream)>>>(in, out, hit_off, hit_lo, nt, shift);
+}
+void launch_node_groups(const Tuple* tuples, const uint64_t* hit_off, uint64_t hit_lo, uint32_t nt, uint32_t* group_cnt, const uint64_t* group_off,
+                        uint32_t* group_node, uint64_t* group_begin, uint64_t begin_bias, void* stream) {
+    if (!nt) return;
+    const uint32_t blocks = std::min<uint32_t>((nt + kNodeWaves - 1) / kNodeWaves, 8192);
+    node_groups_kernel<<<blocks, 64 * kNodeWaves, 0, static_cast<hipStream_t>(stream)>>>(tuples, hit_off, hit_lo, nt, group_cnt, group_off, group_node, group_begin,
+                                                                                        begin_bias);
+}
+
 uint32_t dedup_topic_cap() { return kDedupTopicCap; }
 
 void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, uint32_t ntiles, Tuple* tuples, const uint32_t* topic_cand, uint32_t nt,
@@ -1156,7 +1288,7 @@ void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, uint32_t ntiles,
     if (!ntiles) return;
     hipStream_t s = static_cast<hipStream_t>(stream);
     (void)hipMemsetAsync(item_count, 0, 4, s);
-    dedup_tile_kernel<<<ntiles, 256, 0, s>>>(cand, tile_ncand, hit_off, hit_lo, tuples, stat);
+    dedup_tile_kernel<<<std::min<uint32_t>(ntiles, 2048u), 256, 0, s>>>(cand, tile_ncand, ntiles, hit_off, hit_lo, tuples, stat);
     dedup_classify_kernel<<<(nt + 255) / 256, 256, 0, s>>>(topic_cand, nt, hit_off, hit_lo, items, item_count);
     // the item count stays on the device: a fixed grid of persistent blocks (4 per CU fit) strides over the items
     // RGR_DEDUP_TEST_SLOTS (tests only): a smaller table, so that parts overflow and the re-split path runs on ordinary inputs

@@ -246,6 +246,15 @@ struct DedupItem { uint32_t topic, part, parts, nc; };
 void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, uint32_t ntiles, Tuple* tuples, const uint32_t* topic_cand, uint32_t nt,
                   const uint64_t* hit_off, uint64_t hit_lo, DedupItem* items, uint32_t* item_count, unsigned long long* stat, void* stream);
 uint32_t dedup_topic_cap();
+// Delivery results grouped by node (SubRelationsMap's shape, types.rs:486-497): stable partition of every topic's tuples by
+// one byte (`shift` = 16 or 24) of the delivery word's node index; then the directory of the node groups — called twice: with
+// group_node == null it writes group_cnt[t], with the scanned offsets it writes (node, first position + begin_bias) per group.
+void launch_node_partition(const Tuple* in, Tuple* out, const uint64_t* hit_off, uint64_t hit_lo, uint32_t nt, uint32_t shift, void* stream);
+void launch_node_groups(const Tuple* tuples, const uint64_t* hit_off, uint64_t hit_lo, uint32_t nt, uint32_t* group_cnt, const uint64_t* group_off,
+                        uint32_t* group_node, uint64_t* group_begin, uint64_t begin_bias, void* stream);
+// run descriptors of a window packed for the exchange step (== rgr_run)
+struct RunDesc { uint32_t shard, src, len, topic; };
+void launch_pack_runs(const uint32_t* src, const uint32_t* topic, const uint64_t* off, uint64_t n, uint32_t shard, RunDesc* out, void* stream);
 uint32_t expand_tile_hits();
 const char* expand_tuple_kernel_name();      // which kernel expands plain 12-byte tuple windows (profilers see this name)
 uint32_t scan_block_topics();

@@ -97,6 +97,8 @@ Result<bool> GpuRouter::add(const std::string& topic_filter, const Id& id, const
     auto old = rels.find(id.client_id);
     uint32_t sub_id;
     const uint32_t owner_id = owners_.acquire(id_key(id));
+    if (opts.shared_group) shared_rels_++;
+    if (old != rels.end() && old->second.opts.shared_group) shared_rels_--;
     if (old == rels.end()) {
         relations_count_.inc();
         if (!free_sub_ids_.empty()) { sub_id = free_sub_ids_.back(); free_sub_ids_.pop_back(); }
@@ -173,6 +175,8 @@ Result<bool> GpuRouter::restore(const raft::Snapshot& snap) {
     owners_ = std::move(owners);
     clients_ = std::move(clients);
     bulk_loaded_ = true;
+    shared_rels_ = 0;
+    for (auto& kv : relations_) for (auto& rel : kv.second.rels) shared_rels_ += rel.second.opts.shared_group ? 1 : 0;
     topics_count_ = Counter{snap.topics_count.count, snap.topics_count.max};             // router.rs:555
     relations_count_ = Counter{snap.relations_count.count, snap.relations_count.max};   // router.rs:568
     dirty_ = true;
@@ -193,6 +197,7 @@ Result<bool> GpuRouter::remove(const std::string& topic_filter, const Id& id) {
     if (rgr_group_unsubscribe(g_, topic_filter.data(), uint32_t(topic_filter.size()), sub_id, last ? 1 : 0) != RGR_OK)
         return Result<bool>::Err(rgr_last_error());
     mutation_epoch_++;
+    if (r->second.opts.shared_group) shared_rels_--;
     slab_[sub_id] = Slot{};
     quarantined_sub_ids_.push_back(sub_id);          // reusable after the next commit (see mu_)
     owners_.release(id_key(r->second.id));
@@ -239,19 +244,20 @@ Result<bool> GpuRouter::filters_pass(const std::vector<TopicName>& topics, Filte
     std::string blob;
     std::vector<uint64_t> offs(topics.size() + 1, 0);
     for (size_t i = 0; i < topics.size(); ++i) { blob += topics[i]; offs[i + 1] = blob.size(); }
-    for (;;) {
-        if (dirty_) {                                             // publish pending mutations first: exclusive
-            std::unique_lock<std::shared_mutex> x(mu_);
-            if (commit_if_dirty() != RGR_OK) return Result<bool>::Err(rgr_last_error());
-        }
-        std::shared_lock<std::shared_mutex> g(mu_);
-        if (dirty_) continue;                                     // a mutation slipped in between the two locks
-        pass.epoch = mutation_epoch_;
-        rgr_filters_result_free(&pass.res);
-        if (rgr_group_match_filter_subs(g_, reinterpret_cast<const uint8_t*>(blob.data()), offs.data(), uint32_t(topics.size()), &pass.res) != RGR_OK)
-            return Result<bool>::Err(rgr_last_error());
-        return Result<bool>::Ok(true);
-    }
+    // commit + device pass under the exclusive lock: the pass sees exactly the table of mutation epoch `pass.epoch` (add / remove
+    // wait for the pass — a fraction of a millisecond — as they wait for the trie's write lock in the reference, router.rs:438)
+    std::unique_lock<std::shared_mutex> x(mu_);
+    return filters_pass_locked(blob, offs, pass);
+}
+
+// caller holds mu_ exclusively
+Result<bool> GpuRouter::filters_pass_locked(const std::string& blob, const std::vector<uint64_t>& offs, FilterPass& pass) {
+    if (commit_if_dirty() != RGR_OK) return Result<bool>::Err(rgr_last_error());
+    pass.epoch = mutation_epoch_;
+    rgr_filters_result_free(&pass.res);
+    if (rgr_group_match_filter_subs(g_, reinterpret_cast<const uint8_t*>(blob.data()), offs.data(), uint32_t(offs.size() - 1), &pass.res) != RGR_OK)
+        return Result<bool>::Err(rgr_last_error());
+    return Result<bool>::Ok(true);
 }
 
 // caller holds mu_ (shared) and the pass is current
@@ -304,14 +310,14 @@ std::optional<SubRelationsMap> GpuRouter::expand(const FilterPass& pass, size_t 
             return m;
         }
     }
-    // the table changed since the pass ran (its sub ids may have been freed): match this publish again on the current table
+    // the table changed since the pass ran (its sub ids may have been freed): match this publish again, alone, with the table held
+    // still from the commit to the end of the expansion — always current, no retry loop
     stale_expansions_++;
     FilterPass fresh;
-    for (;;) {
-        if (!filters_pass({topic}, fresh).ok()) return std::nullopt;
-        std::shared_lock<std::shared_mutex> g(mu_);
-        if (fresh.epoch == mutation_epoch_) return expand_locked(fresh.res, 0, id, topic, nullptr);
-    }
+    const std::vector<uint64_t> offs{0, topic.size()};
+    std::unique_lock<std::shared_mutex> x(mu_);
+    if (!filters_pass_locked(topic, offs, fresh).ok()) return std::nullopt;
+    return expand_locked(fresh.res, 0, id, topic, nullptr);
 }
 
 Result<bool> GpuRouter::matches_batch(const std::vector<Id>& ids, const std::vector<TopicName>& topics,
@@ -339,6 +345,39 @@ Result<bool> GpuRouter::matches_batch_deliver(const std::vector<Id>& ids, const 
     std::vector<rgr_publish_attr> attrs(topics.size());
     for (size_t i = 0; i < topics.size(); ++i) attrs[i] = rgr_publish_attr{owners_.find(id_key(ids[i])), 2u};
     rgr_result res{};
+    // Without $share members the grouping by node (router.rs:258-261: one collector per node) is done on the device: every
+    // topic's tuples arrive partitioned by node index, one slice per collector.  ($share picks are added where their filter's
+    // hits end, across nodes — router.rs:236-255 — so tables that hold shared members keep the ungrouped order.)
+    if (shared_rels_ == 0 && !bulk_loaded_) {
+        rgr_node_groups ng{};
+        if (rgr_group_match_batch_deliver_grouped(g_, reinterpret_cast<const uint8_t*>(blob.data()), offs.data(), uint32_t(topics.size()), attrs.data(), &res, &ng) != RGR_OK)
+            return Result<bool>::Err(rgr_last_error());
+        out.assign(topics.size(), std::nullopt);
+        for (size_t t = 0; t < topics.size(); ++t) {
+            if (res.status[t] != RGR_TOPIC_OK) continue;
+            SubRelationsMap m;
+            for (uint64_t gi = ng.group_offsets[t]; gi < ng.group_offsets[t + 1]; ++gi) {
+                Collector col;                                           // the node's SubscriptioRelationsCollector
+                const uint64_t e = gi + 1 < ng.group_offsets[t + 1] ? ng.group_begin[gi + 1] : res.hit_offsets[t + 1];
+                for (uint64_t k = ng.group_begin[gi]; k < e; ++k) {
+                    const uint32_t w = res.tuples[k].qos_flags;
+                    if (w & RGR_HIT_NO_LOCAL) continue;                  // router.rs:196-201, decided on the device
+                    const Slot& sl = slab_[res.tuples[k].sub_id];
+                    const Rel& rel = *sl.rel;
+                    const bool created = col.add(*sl.filter, rel.id.client_id, rel.opts, std::nullopt);
+                    if (!rel.opts.is_v3() && created == ((w & RGR_HIT_V5_DUP) != 0)) flag_mismatches_++;
+                }
+                if (col.v3.empty() && col.v5.empty()) continue;          // (every hit of the node was the publisher's own No Local subscription)
+                auto& dst = m[nodes_[ng.group_node[gi]]];
+                dst = std::move(col.v3);
+                for (auto& r : col.v5) dst.push_back(std::move(r));
+            }
+            out[t] = std::move(m);
+        }
+        if (!topics.empty()) mean_hits_ = 0.9 * std::min(mean_hits_.load(), 1e8) + 0.1 * double(res.n_hits) / double(topics.size());
+        rgr_result_free(&res);
+        return Result<bool>::Ok(true);
+    }
     if (rgr_group_match_batch_deliver(g_, reinterpret_cast<const uint8_t*>(blob.data()), offs.data(), uint32_t(topics.size()), attrs.data(), &res) != RGR_OK)
         return Result<bool>::Err(rgr_last_error());
     out.assign(topics.size(), std::nullopt);

@@ -215,6 +215,7 @@ class GpuRouter final : public Router {
     std::string create_error_;
     NodeId this_node_;
     std::vector<int32_t> devices_;
+    uint64_t shared_rels_ = 0;           // relations that are $share members (their picks need the ungrouped hit order)
     bool bulk_loaded_ = false;           // relations loaded by restore(): the tuples' node bits are not populated
     // add / remove / restore / commit: exclusive; a device pass and the host expansion of its result: shared (the reference:
     // DashMap + a trie RwLock).  A sub id freed by remove() is quarantined until the next commit has dropped it from the device
@@ -237,6 +238,7 @@ class GpuRouter final : public Router {
     std::atomic<bool> dirty_{false};
 
     int32_t commit_if_dirty();           // caller holds mu_ exclusively
+    Result<bool> filters_pass_locked(const std::string& blob, const std::vector<uint64_t>& offs, FilterPass& pass);   // mu_ held exclusively
     Result<bool> matches_batch_deliver(const std::vector<Id>& ids, const std::vector<TopicName>& topics, std::vector<std::optional<SubRelationsMap>>& out);
     std::optional<SubRelationsMap> expand_locked(const rgr_filters_result& res, size_t t, const Id& id, const TopicName& topic, uint64_t* hits);
 };

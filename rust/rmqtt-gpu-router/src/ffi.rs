@@ -105,6 +105,7 @@ extern "C" {
     pub fn rgr_group_match_batch(g: *mut rgr_group, blob: *const u8, offsets: *const u64, n: u32, out: *mut rgr_result) -> i32;
     pub fn rgr_group_match_batch_deliver(g: *mut rgr_group, blob: *const u8, offsets: *const u64, n: u32, attrs: *const rgr_publish_attr,
                                          out: *mut rgr_result) -> i32;
+    pub fn rgr_group_match_filter_subs(g: *mut rgr_group, blob: *const u8, offsets: *const u64, n: u32, out: *mut rgr_filters_result) -> i32;
 }
 
 // ---- device-resident batches, result formats, PUBLISH-packet batches, communicators (not used by the plugin itself;
@@ -168,6 +169,7 @@ extern "C" {
     pub fn rgr_batch_next_window(b: *mut rgr_batch, w: *mut rgr_window) -> i32;
     pub fn rgr_batch_run(b: *mut rgr_batch, n_hits: *mut u64, n_windows: *mut u32) -> i32;
     pub fn rgr_match_filters(h: *mut rgr_handle, blob: *const u8, offsets: *const u64, n: u32, out: *mut rgr_filters_result) -> i32;
+    pub fn rgr_match_filter_subs(h: *mut rgr_handle, blob: *const u8, offsets: *const u64, n: u32, out: *mut rgr_filters_result) -> i32;
     pub fn rgr_filters_result_free(r: *mut rgr_filters_result);
     pub fn rgr_comm_unique_id(id: *mut u8) -> i32;
     pub fn rgr_comm_create(h: *mut rgr_handle, id: *const u8, rank: u32, world: u32, out: *mut *mut rgr_comm) -> i32;

@@ -106,6 +106,9 @@ impl GpuRetainIndex {
 #[derive(Default)]
 struct Messages {
     slab: Vec<Option<(TopicName, TimedValue<Retain>)>>,
+    /// `clock` value at which the slot was last given to a topic (parallel to `slab`); `clock` counts assignments
+    stamp: Vec<u64>,
+    clock: u64,
     free: Vec<u32>,
     ids: HashMap<TopicName, u32>,
 }
@@ -161,13 +164,16 @@ impl RetainStorage for GpuRetainStorage {
             }
             return Ok(());
         }
-        let id = had.unwrap_or_else(|| m.free.pop().unwrap_or_else(|| { m.slab.push(None); (m.slab.len() - 1) as u32 }));
+        let id = had.unwrap_or_else(|| m.free.pop().unwrap_or_else(|| { m.slab.push(None); m.stamp.push(0); (m.slab.len() - 1) as u32 }));
         if let Err(e) = self.index.insert(topic, id) {
             if had.is_none() { m.free.push(id); }
             return Err(e);
         }
         m.slab[id as usize] = Some((topic.clone(), TimedValue::new(retain, expiry_interval)));
         if had.is_none() {
+            m.clock += 1;
+            let now = m.clock;
+            m.stamp[id as usize] = now;
             m.ids.insert(topic.clone(), id);
             self.retaineds.inc();
         }
@@ -177,11 +183,15 @@ impl RetainStorage for GpuRetainStorage {
     /// retain.rs:250-267 (`get_message`): match on the device, drop expired entries, clone the messages.
     async fn get(&self, topic_filter: &TopicFilter) -> Result<Vec<(TopicName, Retain)>> {
         let (index, filter) = (self.index.clone(), topic_filter.to_string());
+        let asked_at = self.messages.lock().unwrap().clock;
         let ids = tokio::task::spawn_blocking(move || index.query(&[filter.as_str()])).await??;
         let ids = ids.into_iter().next().unwrap().map_err(|e| anyhow::anyhow!(e))?;
         let m = self.messages.lock().unwrap();
+        // a topic id freed and re-issued between the device query and this lookup would name ANOTHER topic: every slot
+        // carries the stamp of its last assignment, and a slot assigned after the query started is not part of its answer
         Ok(ids
             .into_iter()
+            .filter(|id| m.stamp.get(*id as usize).map(|s| *s <= asked_at).unwrap_or(false))
             .filter_map(|id| m.slab.get(id as usize).and_then(|e| e.as_ref()))
             .filter(|(_, tv)| !tv.is_expired())
             .map(|(t, tv)| (t.clone(), tv.value().clone()))

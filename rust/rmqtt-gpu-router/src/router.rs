@@ -9,11 +9,15 @@
 //!   and the blocking FFI call runs under `spawn_blocking`;
 //! * pending `add`/`remove`s are committed (`rgr_group_commit`) by the batcher right before the next
 //!   pass, on its blocking thread, so SUBSCRIBE never waits for the device;
-//! * the per-hit decisions of `_matches` come back as delivery words (`RGR_HIT_*`): No Local
-//!   (router.rs:196-201) is decided on the device against the publisher's dense owner id; the v5
-//!   collector is `SubscriptioRelationsCollector` itself (types.rs:503-541), fed in the device's order,
-//!   which IS `TopicTree::matches`' filter order;
-//! * `$share` members (router.rs:202-213) are collected per (filter, group) while one filter's hits go by
+//! * the device does the trie walk (`TopicTree::matches`, trie.rs:301-409) and answers, per matched filter in
+//!   iteration order, with the sub id of that filter's first subscriber (`rgr_group_match_filter_subs`); the sub id
+//!   leads to the filter string, and the per-client loop of `_matches` (router.rs:194-231: No Local by whole-`Id`
+//!   equality, `$share` members, the v3/v5 collector) runs in the caller's task over `inner.relations`, the source
+//!   of truth — N tokio workers expand N publishes in parallel, as in the reference;
+//! * a sub id freed by `remove` is QUARANTINED until the next commit has dropped it from the device table, and every
+//!   pass carries the mutation epoch it ran at: a publish whose pass is older than the last mutation is matched again
+//!   on its own, so a recycled id can never resolve to a relation the device did not match (round-2 advisor finding);
+//! * `$share` members (router.rs:202-213) are collected per (filter, group) while one filter's relations go by
 //!   and `SharedSubscription::choice` picks one (router.rs:236-255) — same place, same arguments.
 //!
 //! Source only (no rustc in the build image).  The C++ twin that IS compiled and tested against the
@@ -32,7 +36,7 @@ use rmqtt::types::*;
 use rmqtt::utils::Counter;
 use rmqtt::Result;
 
-use crate::batcher::{Batcher, GroupPtr};
+use crate::batcher::{match_many, Batcher, GroupPtr, MutationEpoch};
 use crate::ffi::*;
 
 struct Group(*mut rgr_group);
@@ -82,6 +86,9 @@ impl<K: std::hash::Hash + Eq + Clone> Dense<K> {
 struct Slab {
     slots: Vec<Option<(TopicFilter, ClientId, Id)>>,
     free: Vec<u32>,
+    /// sub ids freed since the last commit: the device table may still hold them, so they are not handed out again
+    /// before a commit has gone by (then they move to `free`)
+    quarantine: Vec<u32>,
     ids: HashMap<(TopicFilter, ClientId), u32>,
     per_filter: HashMap<TopicFilter, usize>,
     owners: Dense<Id>,
@@ -97,6 +104,7 @@ pub struct GpuRouter {
     g: Arc<Group>,
     slab: Arc<RwLock<Slab>>,
     dirty: Arc<AtomicBool>,
+    epoch: Arc<MutationEpoch>,
     batcher: Arc<Batcher>,
 }
 
@@ -124,23 +132,52 @@ impl GpuRouter {
         }
         let g = Arc::new(Group(g));
         let dirty = Arc::new(AtomicBool::new(false));
-        let (gp, d2) = (GroupPtr(g.0), dirty.clone());
+        let epoch = Arc::new(MutationEpoch::default());
+        let slab = Arc::new(RwLock::new(Slab::default()));
+        let commit = Self::committer(GroupPtr(g.0), dirty.clone(), epoch.clone(), slab.clone());
         // pending subscription changes become visible right before the next pass, on the batcher's blocking thread
-        let batcher = Batcher::spawn(gp, max_batch, max_delay, move || {
-            if d2.swap(false, Ordering::AcqRel) && unsafe { rgr_group_commit(gp.0) } != RGR_OK {
-                d2.store(true, Ordering::Release);
+        let batcher = Batcher::spawn(GroupPtr(g.0), max_batch, max_delay, commit);
+        Ok(Self { inner: DefaultRouter::new(Some(scx.clone())), scx, g, slab, dirty, epoch, batcher: Arc::new(batcher) })
+    }
+
+    /// What runs right before a device pass: the mutation epoch the pass may claim (read BEFORE the commit, so a
+    /// mutation racing with the commit makes the pass look older than it is, never newer), then `rgr_group_commit`;
+    /// the sub ids freed before this commit leave quarantine once it succeeded.
+    fn committer(gp: GroupPtr, dirty: Arc<AtomicBool>, epoch: Arc<MutationEpoch>, slab: Arc<RwLock<Slab>>)
+                 -> impl Fn() -> std::result::Result<u64, String> + Send + Sync + Clone + 'static {
+        move || {
+            let e = epoch.get();
+            if dirty.swap(false, Ordering::AcqRel) {
+                let released = std::mem::take(&mut slab.write().unwrap().quarantine);
+                if unsafe { rgr_group_commit(gp.0) } != RGR_OK {
+                    dirty.store(true, Ordering::Release);
+                    slab.write().unwrap().quarantine.extend(released);
+                    return Err(format!("rgr_group_commit: {}", last_error()));
+                }
+                slab.write().unwrap().free.extend(released);
+            }
+            Ok(e)
+        }
+    }
+
+    /// sub id of each matched filter's first subscriber -> the filter strings, in `TopicTree::matches` order
+    fn filters_of(s: &Slab, first_subs: &[u32]) -> Vec<TopicFilter> {
+        first_subs.iter().filter_map(|sid| s.slots.get(*sid as usize).and_then(|x| x.as_ref()).map(|(f, _, _)| f.clone())).collect()
+    }
+
+    /// Commit, match ONE topic and resolve its filters while holding the slab exclusively (blocking: call under `spawn_blocking`).
+    fn match_one_exclusive(&self, topic: &str) -> std::result::Result<Vec<TopicFilter>, String> {
+        let mut s = self.slab.write().unwrap();
+        if self.dirty.swap(false, Ordering::AcqRel) {
+            if unsafe { rgr_group_commit(self.g.0) } != RGR_OK {
+                self.dirty.store(true, Ordering::Release);
                 return Err(format!("rgr_group_commit: {}", last_error()));
             }
-            Ok(())
-        });
-        Ok(Self {
-            inner: DefaultRouter::new(Some(scx.clone())),
-            scx,
-            g,
-            slab: Arc::new(RwLock::new(Slab::default())),
-            dirty,
-            batcher: Arc::new(batcher),
-        })
+            let released = std::mem::take(&mut s.quarantine);
+            s.free.extend(released);
+        }
+        let hits = unsafe { match_many(GroupPtr(self.g.0), &[topic.to_string()], self.epoch.get()) }?.remove(0)?;
+        Ok(Self::filters_of(&s, &hits.first_subs))
     }
 
     pub fn _inner(&self) -> &DefaultRouter {
@@ -186,6 +223,7 @@ impl GpuRouter {
                                    node_idx, owner_id, client_idx)
         };
         if rc != RGR_OK { return Err(anyhow::anyhow!("rgr_group_subscribe_ex: {}", last_error())); }
+        self.epoch.bump();
         self.dirty.store(true, Ordering::Release);
         Ok(())
     }
@@ -198,7 +236,7 @@ impl GpuRouter {
             s.owners.release(&old_id);
             s.clients.release(&(old_id.node_id, old_id.client_id.clone()));
         }
-        s.free.push(sid);
+        s.quarantine.push(sid); // not `free`: the device keeps the id until the next commit
         let last = {
             let n = s.per_filter.get_mut(&key.0).map(|n| { *n -= 1; *n }).unwrap_or(0);
             if n == 0 { s.per_filter.remove(&key.0); }
@@ -206,6 +244,7 @@ impl GpuRouter {
         };
         let rc = unsafe { rgr_group_unsubscribe(self.g.0, topic_filter.as_ptr() as _, topic_filter.len() as u32, sid, last as i32) };
         if rc != RGR_OK { return Err(anyhow::anyhow!("rgr_group_unsubscribe: {}", last_error())); }
+        self.epoch.bump();
         self.dirty.store(true, Ordering::Release);
         Ok(())
     }
@@ -252,6 +291,7 @@ impl GpuRouter {
         if unsafe { rgr_group_sub_attrs_bulk(self.g.0, sub_ids.as_ptr(), owners.as_ptr(), clients.as_ptr(), n) } != RGR_OK {
             return Err(anyhow::anyhow!("rgr_group_sub_attrs_bulk: {}", last_error()));
         }
+        self.epoch.bump();
         self.dirty.store(true, Ordering::Release);
         Ok(())
     }
@@ -274,54 +314,55 @@ impl Router for GpuRouter {
 
     /// rmqtt/src/router.rs:499-501 / 174-265.
     async fn matches(&self, this_id: Id, topic: &TopicName) -> Result<SubRelationsMap> {
-        let from_owner = self.slab.read().unwrap().owners.find(&this_id);
-        // the device pass (trie walk + relation expansion + No Local), shared with every concurrent publish
-        let hits = self.batcher.matches(topic, from_owner).await.map_err(|e| anyhow::anyhow!(e))?;
-
-        // which relation each hit is: resolved under the slab's read lock, which is NOT held across an await
-        let rels: Vec<(u32, TopicFilter, ClientId)> = {
+        // the device pass (trie walk), shared with every concurrent publish: one sub id per matched filter
+        let hits = self.batcher.matches(topic).await.map_err(|e| anyhow::anyhow!(e))?;
+        // sub id -> filter string, under the slab's read lock (never held across an await).  The answer is only used when no
+        // add / remove has happened since the pass: otherwise this publish is matched again on its own (rare).
+        let resolved: Option<Vec<TopicFilter>> = {
             let s = self.slab.read().unwrap();
-            hits.iter()
-                .filter_map(|t| s.slots.get(t.sub_id as usize).and_then(|x| x.as_ref()).map(|(f, c, _)| (t.qos_flags, f.clone(), c.clone())))
-                .collect()
+            (self.epoch.get() == hits.epoch).then(|| Self::filters_of(&s, &hits.first_subs))
+        };
+        let filters = match resolved {
+            Some(f) => f,
+            None => {
+                // the table changed since the batched pass: this publish is matched again on its own with the slab held exclusively
+                // from the commit to the resolution (mirror_add / mirror_remove wait for it) — always current, no retry loop
+                let (this, t) = (self.clone(), topic.to_string());
+                tokio::task::spawn_blocking(move || this.match_one_exclusive(&t))
+                    .await
+                    .map_err(|e| anyhow::anyhow!(e.to_string()))?
+                    .map_err(|e| anyhow::anyhow!(e))?
+            }
         };
 
         let mut collector_map: SubscriptioRelationsCollectorMap = Default::default();
         type Member = (NodeId, ClientId, SubscriptionOptions, Option<Vec<SubscriptionIdentifier>>, Option<IsOnline>);
-        let mut groups: HashMap<SharedGroup, Vec<Member>> = Default::default(); // router.rs:183-192, one filter at a time
-        let mut cur_filter: Option<TopicFilter> = None;
-        let mut i = 0;
-        while i <= rels.len() {
-            let boundary = i == rels.len() || cur_filter.as_ref() != Some(&rels[i].1);
-            if boundary {
-                // select a subscriber from every shared group of the filter that just ended (router.rs:236-255)
-                if let Some(filter) = cur_filter.as_ref() {
-                    for (group, mut s_subs) in groups.drain() {
-                        let group_cids = s_subs.iter().map(|(_, cid, _, _, _)| cid.clone()).collect();
-                        if let Some((idx, is_online)) =
-                            self.scx.extends.shared_subscription().await.choice(&self.scx, &group, &this_id, topic, &s_subs).await
-                        {
-                            let (node_id, client_id, opts, _, _) = s_subs.remove(idx);
-                            collector_map.entry(node_id).or_default().add(filter, client_id, opts, Some((group, is_online, group_cids)));
-                        }
-                    }
+        for filter in filters.iter() {
+            // Id and options come from the source of truth; a filter whose relations are gone since the pass is skipped,
+            // as the reference would no longer see them either (router.rs:184)
+            let members: Vec<(ClientId, Id, SubscriptionOptions)> = match self.inner.relations.get(filter) {
+                Some(rels) => rels.iter().map(|(c, (id, o))| (c.clone(), id.clone(), o.clone())).collect(),
+                None => continue,
+            };
+            let mut groups: HashMap<SharedGroup, Vec<Member>> = Default::default(); // router.rs:183-192, one filter at a time
+            for (client_id, id, opts) in members {
+                if opts.no_local() == Some(true) && id == this_id { continue; } // router.rs:196-201: whole-`Id` equality
+                if let Some(group) = opts.shared_group() {
+                    // router.rs:204-213
+                    let online = self.is_online(id.node_id, &client_id).await;
+                    groups.entry(group.clone()).or_default().push((id.node_id, client_id, opts.clone(), None, Some(online)));
+                    continue;
                 }
-                if i == rels.len() { break; }
-                cur_filter = Some(rels[i].1.clone());
+                collector_map.entry(id.node_id).or_default().add(filter, client_id, opts, None); // router.rs:214-229
             }
-            let (word, filter, client_id) = &rels[i];
-            i += 1;
-            if word & RGR_HIT_NO_LOCAL != 0 { continue; } // router.rs:196-201, decided on the device (whole-`Id` equality via the owner id)
-            // Id and options come from the source of truth; a relation removed since the pass is skipped,
-            // as the reference would no longer see it either
-            let Some((id, opts)) = self.inner.relations.get(filter).and_then(|r| r.get(client_id).cloned()) else { continue };
-            if let Some(group) = opts.shared_group() {
-                // router.rs:204-213
-                let online = self.is_online(id.node_id, client_id).await;
-                groups.entry(group.clone()).or_default().push((id.node_id, client_id.clone(), opts.clone(), None, Some(online)));
-                continue;
+            // select a subscriber from every shared group of this filter (router.rs:236-255)
+            for (group, mut s_subs) in groups.drain() {
+                let group_cids = s_subs.iter().map(|(_, cid, _, _, _)| cid.clone()).collect();
+                if let Some((idx, is_online)) = self.scx.extends.shared_subscription().await.choice(&self.scx, &group, &this_id, topic, &s_subs).await {
+                    let (node_id, client_id, opts, _, _) = s_subs.remove(idx);
+                    collector_map.entry(node_id).or_default().add(filter, client_id, opts, Some((group, is_online, group_cids)));
+                }
             }
-            collector_map.entry(id.node_id).or_default().add(filter, client_id.clone(), opts, None); // router.rs:214-229
         }
         Ok(collector_map.into_iter().map(|(n, c)| (n, c.into())).collect()) // router.rs:258-261
     }

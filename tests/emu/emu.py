@@ -156,9 +156,27 @@ class EmuRouter:
         s, ho, tp, _, _ = self._match(blob, offsets)
         return dict(status=s, hit_offsets=ho, tuples=tp)
 
-    def match_batch_deliver(self, blob, offsets, publish_attrs):
+    def match_batch_deliver(self, blob, offsets, publish_attrs, grouped=False):
         s, ho, tp, _, _ = self._match(blob, offsets, publish_attrs)
-        return dict(status=s, hit_offsets=ho, tuples=tp)
+        if not grouped:
+            return dict(status=s, hit_offsets=ho, tuples=tp)
+        # rgr_match_batch_deliver_grouped, stated independently of the device's radix passes: per topic a stable sort by node index
+        tp = tp.copy()
+        go, gn, gb = [0], [], []
+        for t in range(len(ho) - 1):
+            a, e = int(ho[t]), int(ho[t + 1])
+            seg = tp[a:e]
+            node = seg["qos_flags"] >> 16
+            seg = seg[np.argsort(node, kind="stable")]
+            tp[a:e] = seg
+            node = seg["qos_flags"] >> 16
+            starts = np.nonzero(np.r_[True, node[1:] != node[:-1]])[0] if e > a else np.zeros(0, dtype=np.int64)
+            gn.extend(int(x) for x in node[starts])
+            gb.extend(a + int(x) for x in starts)
+            go.append(len(gn))
+        gb.append(len(tp))
+        return dict(status=s, hit_offsets=ho, tuples=tp, group_offsets=np.array(go, dtype=np.uint64), group_node=np.array(gn, dtype=np.uint32),
+                    group_begin=np.array(gb, dtype=np.uint64))
 
     def match_filters(self, blob, offsets):
         s, _, _, po, pf = self._match(blob, offsets)

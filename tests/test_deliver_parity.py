@@ -233,6 +233,50 @@ def test_v5_dedup_topics_spanning_tiles_in_parts(kind, test_slots, monkeypatch):
     w.check(14)
 
 
+@pytest.mark.parametrize("n_nodes", [1, 3, 300])
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_delivery_grouped_by_node(kind, n_nodes):
+    """rgr_match_batch_deliver_grouped: every topic's delivery tuples partitioned by node on the device (SubRelationsMap is keyed
+    by node, types.rs:486-497) — the same tuples as the ungrouped call, stably reordered by node index, plus the directory.
+    300 nodes need two radix-256 passes; one node needs none."""
+    import random
+    rng = random.Random(n_nodes)
+    b = make_backend(kind, window_hits=900) if kind == "hip" else make_backend(kind, window_hits=900)
+    filters = ["a/b/c", "a/+/c", "a/#", "#", "+/b/#", "a/b/+", "x/y", "x/+", "+/+"]
+    sid = 0
+    for f in filters:
+        fid = b.filter_add(f)
+        for _ in range(rng.randint(40, 160)):
+            node = rng.randrange(n_nodes)
+            b.sub_add_ex(fid, sid, rng.randrange(3), capi.RGR_SUB_V5 if rng.random() < 0.4 else 0, node, sid % 97, sid % 53)
+            sid += 1
+    b.commit()
+    topics = ["a/b/c", "x/y", "a/q/c", "nothing/here/at/all/x", "q", "a/b/c/d", "a/b/c"] * 5
+    blob, offs = pack(topics)
+    attrs = np.zeros(len(topics), dtype=capi.PUBLISH_ATTR_DTYPE)
+    attrs["from_id"] = capi.ID_NONE
+    attrs["qos_retain"] = 2
+    plain = b.match_batch_deliver(blob, offs, attrs)
+    got = b.match_batch_deliver(blob, offs, attrs, grouped=True)
+    assert np.array_equal(plain["hit_offsets"], got["hit_offsets"]) and np.array_equal(plain["status"], got["status"])
+    ho = got["hit_offsets"].astype(np.int64)
+    go, gn, gb = got["group_offsets"].astype(np.int64), got["group_node"], got["group_begin"].astype(np.int64)
+    assert len(go) == len(topics) + 1 and go[0] == 0 and go[-1] == len(gn) and len(gb) == len(gn) + 1 and gb[-1] == len(got["tuples"])
+    for t in range(len(topics)):
+        a, e = ho[t], ho[t + 1]
+        ref = plain["tuples"][a:e]
+        exp = ref[np.argsort(ref["qos_flags"] >> 16, kind="stable")]
+        assert np.array_equal(got["tuples"][a:e], exp), t
+        nodes = got["tuples"]["qos_flags"][a:e] >> 16
+        groups = list(range(go[t], go[t + 1]))
+        assert (len(groups) == 0) == (e == a)
+        assert list(gn[groups]) == sorted(set(nodes.tolist()))
+        for g in groups:
+            lo, hi = gb[g], gb[g + 1] if g + 1 < go[t + 1] else e
+            assert a <= lo < hi <= e and (nodes[lo - a:hi - a] == gn[g]).all()
+    assert len(set(gn.tolist())) == min(n_nodes, len(set(gn.tolist()))) and (n_nodes == 1) == (set(gn.tolist()) <= {0})
+
+
 @pytest.mark.parametrize("kind", BACKENDS)
 def test_delivery_without_registered_ids(kind):
     """Plain rgr_sub_add (no owner / client ids): qos downgrade and RAP still apply, No Local

@@ -53,6 +53,24 @@ def test_group_matches_the_unsharded_oracle(shards):
         tup = tup[order]
         assert np.array_equal(tup["topic_idx"], got["tuples"]["topic_idx"])
         assert np.array_equal(tup["sub_id"], exp["sub_ids"])
+    # the same exchange with RUN DESCRIPTORS as the payload (16 B per (topic, filter) run instead of 12 B per hit): every shard
+    # holds a replica of every shard's subs[]; descriptor d names peer_subs(d.shard)[d.src .. d.src + d.len) for topic d.topic
+    for consumer in range(shards):
+        n_runs, n_hits, runs = gb.gather_runs(consumer_shard=consumer, collect=True)
+        assert n_hits == tot and n_runs == len(runs) and int(runs["len"].sum()) == tot and (runs["len"] > 0).all()
+        subs = [g.peer_subs(consumer, p) for p in range(shards)]
+        order = np.lexsort((np.arange(len(runs)), runs["topic"]))                # stable: keeps each topic's own run order
+        rs = runs[order]
+        sid = np.concatenate([subs[int(r["shard"])]["sub_id"][int(r["src"]):int(r["src"]) + int(r["len"])] for r in rs]) if len(rs) else np.zeros(0, np.uint32)
+        qf = np.concatenate([subs[int(r["shard"])]["qos_flags"][int(r["src"]):int(r["src"]) + int(r["len"])] for r in rs]) if len(rs) else np.zeros(0, np.uint32)
+        assert np.array_equal(sid, exp["sub_ids"]) and np.array_equal(qf & 0xFF, exp["qos"])
+        assert np.array_equal(np.repeat(rs["topic"], rs["len"]), got["tuples"]["topic_idx"])
+    # after a table change the replicas are refreshed by the next run gather
+    g.subscribe("#", 4_000_000, qos=1)
+    g.commit()
+    n_runs2, n_hits2, runs2 = gb.gather_runs(consumer_shard=0, collect=True)
+    n_valid = int((exp["status"] >= 0).sum()) - sum(1 for t, st in zip(wl.strings(tb, to), exp["status"]) if st >= 0 and t.startswith("$"))
+    assert n_hits2 == tot + n_valid                                             # '#' matches every valid non-$ topic once more
     gb.close(); g.close()
 
 

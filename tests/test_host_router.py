@@ -347,6 +347,7 @@ def test_matches_while_the_table_changes(hr):
     matches the published topic (checked with the oracle's pairwise matcher), and relations that are never touched must
     always be delivered."""
     import threading
+    import time
     g = hr.hr_new(1, 0)
     hr.hr_set_match_mode(g, 1)
     stable = [("s/+/x", "keep1"), ("s/#", "keep2"), ("s/a/x", "keep3")]
@@ -364,6 +365,8 @@ def test_matches_while_the_table_changes(hr):
             if k % 3:
                 hr.hr_remove(g, f.encode(), len(f), C.byref(hid))
             k += 1
+            if k % 8 == 0:
+                time.sleep(0.001)           # (leave some passes current: both the shared and the exclusive expansion run)
     th = threading.Thread(target=churn)
     th.start()
     try:

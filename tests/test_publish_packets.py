@@ -180,4 +180,11 @@ def test_publish_packet_batch_on_the_gpu_equals_topic_batch(version):
     pq = info["qos"][t["topic_idx"]]
     sq = qos[t["sub_id"]]
     assert np.array_equal(t["qos_flags"] & 3, np.minimum(pq, sq))
-    b2.close(); r.close()
+    b2.close()
+    # framing that goes backwards is refused on the host (the device would compute a negative packet length from it)
+    bad_offs = poffs.copy()
+    bad_offs[7], bad_offs[8] = bad_offs[8], bad_offs[7] - 1
+    with pytest.raises(capi.RgrError) as e:
+        r.publish_batch(pblob, bad_offs, version=version)
+    assert e.value.code == capi.RGR_EINVAL
+    r.close()
