@@ -843,6 +843,73 @@ def measure_group(args):
     return 0
 
 
+def measure_router_e2e(args):
+    """What a broker sees through the drop-in boundary: N host threads call Router::matches (one publish per call, as
+    DefaultShared::forwards does, shared.rs:772) on the C++ twin of the GpuRouter through its deadline micro-batcher; beside it
+    the oracle's DefaultRouter::_matches-shaped pass on the same number of threads of the same host.  Both build the full
+    SubRelationsMap per publish.  One JSON line per config (2 and 3) with publishes/s and per-call latency."""
+    import ctypes as C
+
+    from oracle import oracle as orc
+    from rmqtt_amd import build
+    build.build_gpu()
+    L = C.CDLL(build.build_host_router())
+    vp = C.c_void_p
+    L.hr_new.restype = vp; L.hr_new.argtypes = [C.c_uint64, C.c_int]
+    L.hr_free.argtypes = [vp]
+    L.hr_set_match_mode.argtypes = [vp, C.c_int]; L.hr_set_match_mode.restype = None
+    L.hr_stale_expansions.argtypes = [vp]; L.hr_stale_expansions.restype = C.c_uint64
+    L.hr_restore_bulk.argtypes = [vp, vp, vp, vp, vp, C.c_uint64]
+    L.hr_e2e_run.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, vp, vp, vp, C.c_uint32, vp]
+    cores = args.cpu_threads or os.cpu_count() or 1
+    out = []
+    for cfg in (2, 3):
+        W = gen_workload(cfg, args.scale)
+        n_t = int(min(W["n_pub"], 200_000))
+        tb, to = prefix(W, n_t)
+        tb = np.ascontiguousarray(tb, dtype=np.uint8); to = np.ascontiguousarray(to, dtype=np.uint64)
+        blob = np.ascontiguousarray(W["blob"], dtype=np.uint8); offs = np.ascontiguousarray(W["offs"], dtype=np.uint64)
+        client = np.ascontiguousarray(W["client"], dtype=np.uint32); qos = np.ascontiguousarray(W["qos"], dtype=np.uint8)
+        g = L.hr_new(1, 0)
+        t = time.time()
+        assert L.hr_restore_bulk(g, blob.ctypes.data, offs.ctypes.data, client.ctypes.data, qos.ctypes.data, W["n_sub"]) == 0
+        log(f"router e2e config {cfg}: GpuRouter::restore of {W['n_sub']} relations in {time.time() - t:.1f}s")
+        rec = {"metric": f"Router::matches publishes/sec through the drop-in boundary (config {cfg})", "unit": "publishes/s", "threads": cores,
+               "config": {"workload": f"BASELINE.json configs[{cfg - 1}]: {W['n_sub']} subscriptions; {n_t} publish topics cycled, one publish per trait call",
+                          "batcher": {"max_batch": 4096, "max_delay_us": 200}}, "gpu": []}
+        for mode, name in ((1, "filters: rgr_group_match_filter_subs + host expansion in the callers"), (2, "deliver: 12-byte tuples with delivery words, grouped by node on the device")):
+            L.hr_set_match_mode(g, mode)
+            res = (C.c_uint64 * 3)()
+            wall = C.c_double(0)
+            lat = np.zeros(200_000, dtype=np.float32)
+            nl = C.c_uint32(0)
+            secs = 6.0 if mode == 1 else 4.0
+            L.hr_e2e_run(g, tb.ctypes.data, to.ctypes.data, n_t, cores, 4096, 200, 1.0, res, C.byref(wall), None, 0, None)      # warm
+            L.hr_e2e_run(g, tb.ctypes.data, to.ctypes.data, n_t, cores, 4096, 200, secs, res, C.byref(wall), lat.ctypes.data, len(lat), C.byref(nl))
+            l = np.sort(lat[:nl.value])
+            rec["gpu"].append({"mode": name, "value": round(res[0] / wall.value, 1), "rows_per_s": round(res[1] / wall.value, 1), "device_passes": int(res[2]),
+                               "publishes": int(res[0]), "wall_s": round(wall.value, 2),
+                               "latency_us": {"p50": round(float(l[len(l) // 2]), 1), "p99": round(float(l[int(len(l) * 0.99)]), 1)} if len(l) else None})
+            log(f"router e2e config {cfg}: {rec['gpu'][-1]}")
+        L.hr_free(g)
+        o = orc.DefaultRouter()
+        o.add_bulk(W["blob"], W["offs"], W["client"], W["qos"])
+        n_c = n_t if cfg == 2 else int(min(n_t, 80_000 * cores / 256 + 2000))
+        cb, co = prefix(W, n_c)
+        sec, ost = o.matches_timed(cb, co, cores)
+        sec1, ost1 = o.matches_timed(*prefix(W, max(50, n_c // cores * 2)), 1)
+        rec["cpu_reference_port"] = {"value": round(n_c / sec, 1), "rows_per_s": round(ost["hits"] / sec, 1), "threads": cores, "kind": "port",
+                                     "what": "oracle DefaultRouter::_matches-shaped pass (router.rs:174-265), per-hit ref-counted clones", "sample": n_c,
+                                     "single_thread": round(max(50, n_c // cores * 2) / sec1, 1)}
+        best = max(x["value"] for x in rec["gpu"])
+        rec["value"] = best
+        rec["vs_cpu_port"] = round(best / rec["cpu_reference_port"]["value"], 2)
+        del o
+        out.append(rec)
+        print(json.dumps(rec), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -868,6 +935,7 @@ def main():
     ap.add_argument("--deliver", type=float, default=-1.0, metavar="V5FRAC",
                     help="also run the delivery stage (SURVEY 8(f)-1): this fraction of the subscriptions is MQTT v5 "
                          "(No Local / RAP / per-client dedup); 0 = v3 only. Not the headline metric.")
+    ap.add_argument("--router-e2e", action="store_true", help="time Router::matches through the host Router mirror + batcher beside the CPU port (configs 2 and 3)")
     ap.add_argument("--group", type=int, default=0, metavar="SHARDS",
                     help="run the single-process sharded router (rgr_group_*) with this many shards on the visible GPUs instead of the N=1 bench")
     ap.add_argument("--torch-collectives", action="store_true", help="N>1: use torch.distributed collectives instead of the library's RCCL communicator")
@@ -878,6 +946,8 @@ def main():
         return pmc_child(args)
     if args.group > 0:
         return measure_group(args)
+    if args.router_e2e:
+        return measure_router_e2e(args)
 
     import torch
     import torch.distributed as dist

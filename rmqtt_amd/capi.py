@@ -179,6 +179,24 @@ def lib():
         L.rgr_group_batch_shard.argtypes = [vp, u32]; L.rgr_group_batch_shard.restype = vp
         L.rgr_group_batch_run.argtypes = [vp, vp, C.POINTER(u64)]
         L.rgr_group_batch_gather.argtypes = [vp, u32, GATHER_CONSUMER, vp, C.POINTER(u64)]
+        # round 3
+        L.rgr_match_filter_subs.argtypes = [vp, vp, vp, u32, C.POINTER(FiltersResult)]
+        L.rgr_group_match_filter_subs.argtypes = [vp, vp, vp, u32, C.POINTER(FiltersResult)]
+        L.rgr_match_batch_deliver_grouped.argtypes = [vp, vp, vp, u32, vp, C.POINTER(Result), C.POINTER(NodeGroups)]
+        L.rgr_group_match_batch_deliver.argtypes = [vp, vp, vp, u32, vp, C.POINTER(Result)]
+        L.rgr_group_match_batch_deliver_grouped.argtypes = [vp, vp, vp, u32, vp, C.POINTER(Result), C.POINTER(NodeGroups)]
+        L.rgr_group_set_key_levels.argtypes = [vp, u32]
+        L.rgr_comm_replicate_subs.argtypes = [vp]
+        L.rgr_comm_peer_subs.argtypes = [vp, u32, C.POINTER(vp), C.POINTER(u64)]
+        L.rgr_comm_gather_runs_pass.argtypes = [vp, vp, GATHER_CONSUMER, vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
+        L.rgr_group_batch_gather_runs.argtypes = [vp, u32, GATHER_CONSUMER, vp, C.POINTER(u64), C.POINTER(u64)]
+        L.rgr_group_peer_subs.argtypes = [vp, u32, u32, C.POINTER(vp), C.POINTER(u64)]
+        L.rgr_group_subscribe_ex.argtypes = [vp, C.c_char_p, u32, u32, u8, u8, C.c_uint16, u32, u32]
+        L.rgr_group_sub_attrs_bulk.argtypes = [vp, vp, vp, vp, u64]
+        for name in SYMBOLS:            # a symbol without argtypes would take 64-bit pointers as C ints (r3d: a truncated pointer, SIGSEGV)
+            fn = getattr(L, name)
+            if fn.argtypes is None and name not in ("rgr_last_error", "rgr_version"):
+                raise RuntimeError(f"capi: {name} has no argtypes")
         _LIB = L
     return _LIB
 

@@ -719,30 +719,6 @@ __global__ __launch_bounds__(kThreads) void expand_kernel(const SubEntry* __rest
                 if (cand && da.cand && at.client_idx != kNone) cclient[j] = at.client_idx;
             }
         }
-        if (da.cand) {
-            // slots in the block's candidate list and per-pair counts, one LDS atomic per wave and
-            // per pair present in the wave instead of one per lane
-            const int lane = threadIdx.x & 63;
-#pragma unroll
-            for (int j = 0; j < kPer; ++j) {
-                const bool is = cclient[j] != kNone;
-                const unsigned long long m = __ballot(is);
-                if (!m) continue;
-                const int leader = __ffsll(static_cast<long long>(m)) - 1;
-                uint32_t wbase = 0;
-                if (lane == leader) wbase = atomicAdd(&s_ncand, uint32_t(__popcll(m)));
-                wbase = __shfl(wbase, leader, 64);
-                if (is) cslot[j] = wbase + uint32_t(__popcll(m & ((1ull << lane) - 1ull)));
-                unsigned long long rest = m;
-                while (rest) {                                           // usually one or two pairs per wave
-                    const int l0 = __ffsll(static_cast<long long>(rest)) - 1;
-                    const uint32_t p0 = __shfl(pidx[j], l0, 64);
-                    const unsigned long long same = __ballot(is && pidx[j] == p0);
-                    if (lane == l0) atomicAdd(&s_pc[p0], uint32_t(__popcll(same)));
-                    rest &= ~same;
-                }
-            }
-        }
     }
 #pragma unroll
     for (int j = 0; j < kPer; ++j) {
@@ -759,9 +735,32 @@ __global__ __launch_bounds__(kThreads) void expand_kernel(const SubEntry* __rest
 #endif
         }
     }
-    // candidate bookkeeping after the tuple stores are in flight; the whole part is skipped (block-
-    // uniformly) when the epoch holds no v5 subscription
+    // candidate bookkeeping AFTER the tuple stores were issued (r3: it used to sit between the loads and the stores and held the
+    // store stream back — the kernel is bound by those stores); the whole part is skipped (block-uniformly) when the epoch holds
+    // no v5 subscription
     if (kDeliver && da.cand) {
+        // slots in the block's candidate list and per-pair counts, one LDS atomic per wave and
+        // per pair present in the wave instead of one per lane
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const bool is = cclient[j] != kNone;
+            const unsigned long long m = __ballot(is);
+            if (!m) continue;
+            const int leader = __ffsll(static_cast<long long>(m)) - 1;
+            uint32_t wbase = 0;
+            if (lane == leader) wbase = atomicAdd(&s_ncand, uint32_t(__popcll(m)));
+            wbase = __shfl(wbase, leader, 64);
+            if (is) cslot[j] = wbase + uint32_t(__popcll(m & ((1ull << lane) - 1ull)));
+            unsigned long long rest = m;
+            while (rest) {                                           // usually one or two pairs per wave
+                const int l0 = __ffsll(static_cast<long long>(rest)) - 1;
+                const uint32_t p0 = __shfl(pidx[j], l0, 64);
+                const unsigned long long same = __ballot(is && pidx[j] == p0);
+                if (lane == l0) atomicAdd(&s_pc[p0], uint32_t(__popcll(same)));
+                rest &= ~same;
+            }
+        }
         __syncthreads();
         if (s_ncand) {   // per-topic candidate counts: the tile's pairs of one topic are adjacent, their first pair's lane sums them
             for (uint32_t i = threadIdx.x; i < np; i += kThreads) {
@@ -787,7 +786,7 @@ __global__ __launch_bounds__(kThreads) void expand_kernel(const SubEntry* __rest
 #pragma unroll
         for (int j = 0; j < kPer; ++j)
             if (cslot[j] != kNone)
-                mine[cslot[j]] = Cand{uint32_t(base - hit_lo) + uint32_t(j) * kThreads + threadIdx.x, cclient[j], topic[j] - da.topic_lo};
+                mine[cslot[j]] = Cand{uint32_t(base - hit_lo) + uint32_t(j) * kThreads + threadIdx.x, cclient[j], topic[j] - da.topic_lo, se[j].qos_flags};
     }
 }
 
@@ -965,7 +964,8 @@ __global__ __launch_bounds__(256) void dedup_tile_kernel(const Cand* __restrict_
                                   [&](uint32_t sl, uint32_t v) { return atomicCAS(&s_tab[sl], kNone, v); }, [&](uint32_t sl, uint32_t v) { atomicMin(&s_tab[sl], v); });
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < n; i += 256)
-            if (s_topic[i] != kNone && dedup_tile_is_dup(i, uint32_t(kDedupTileSlots - 1), key_topic, key_client, tab_load)) tuples[s_pos[i]].qos_flags |= kHitV5Dup;
+            if (s_topic[i] != kNone && dedup_tile_is_dup(i, uint32_t(kDedupTileSlots - 1), key_topic, key_client, tab_load))
+                tuples[s_pos[i]].qos_flags = list[i].word | kHitV5Dup;          // the candidate carries its delivery word: a store, not a read-modify-write
     }
     if (threadIdx.x == 0 && seen) atomicAdd(stat, seen);
 }
@@ -1029,7 +1029,7 @@ __global__ __launch_bounds__(kDedupTopicThreads) void dedup_topic_kernel(const C
                     for (uint32_t i = lane; i < n; i += 64) {
                         const Cand c = list[i];
                         if (c.topic != item.topic || (nparts > 1 && dedup_part(c.client_idx, nparts) != mine)) continue;
-                        if (dedup_topic_is_dup(c.client_idx, c.pos, mask, [&](uint32_t sl) { return s_tab[sl]; })) tuples[c.pos].qos_flags |= kHitV5Dup;
+                        if (dedup_topic_is_dup(c.client_idx, c.pos, mask, [&](uint32_t sl) { return s_tab[sl]; })) tuples[c.pos].qos_flags = c.word | kHitV5Dup;
                     }
                 }
             }

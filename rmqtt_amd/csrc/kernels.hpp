@@ -54,7 +54,8 @@ struct Tuple { uint32_t topic_idx, sub_id, qos_flags; };   // == rgr_tuple
 // per-publish attributes parallel to the batch's topics.
 struct SubAttr { uint32_t owner_id, client_idx; };
 struct PublishAttr { uint32_t from_id, qos_retain; };       // == rgr_publish_attr
-struct Cand { uint32_t pos, client_idx, topic; };           // v5 hit that may be a per-client duplicate: window-relative position and topic
+struct alignas(16) Cand { uint32_t pos, client_idx, topic, word; };   // v5 hit that may be a per-client duplicate: window-relative position, topic,
+                                                                      // and its delivery word (the dedup flags it with a plain store)
 constexpr uint32_t kSubV5 = 1u << 0, kSubNoLocal = 1u << 1, kSubShared = 1u << 2, kSubRap = 1u << 3;   // RGR_SUB_*
 constexpr uint32_t kHitRetain = 1u << 2, kHitNoLocal = 1u << 3, kHitV5Dup = 1u << 4;                    // RGR_HIT_*
 struct DeliverArgs {

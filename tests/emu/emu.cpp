@@ -213,7 +213,7 @@ int32_t run_pipeline(Emu* e, uint32_t n, const std::vector<uint64_t>& tok_off, c
                             }
                             bool is_cand;
                             se.qos_flags = deliver_word(se.qos_flags, pa, at, is_cand);
-                            if (is_cand && at.client_idx != kNone) cand.push_back(Cand{uint32_t(base - hit_lo) + pos, at.client_idx, s_topic[i] - (begin + lc)});
+                            if (is_cand && at.client_idx != kNone) cand.push_back(Cand{uint32_t(base - hit_lo) + pos, at.client_idx, s_topic[i] - (begin + lc), se.qos_flags});
                         }
                         out[(base - hit_lo) + pos] = rgr_tuple{s_topic[i], se.sub_id, se.qos_flags};
                     }
@@ -235,7 +235,7 @@ int32_t run_pipeline(Emu* e, uint32_t n, const std::vector<uint64_t>& tok_off, c
                     std::vector<uint8_t> decided(nh, 0);
                     auto flag = [&](const Cand& c, bool dup) {
                         if (dup != (first[key_of(c)] != c.pos)) return false;
-                        if (dup) out[c.pos].qos_flags |= kHitV5Dup;
+                        if (dup) out[c.pos].qos_flags = c.word | kHitV5Dup;
                         decided[c.pos] = 1;
                         return true;
                     };

@@ -218,7 +218,7 @@ static Window make_window(uint64_t n_pos, double mean_hits, double v5, uint64_t 
             if (urand() >= v5) continue;
             const uint32_t client = uint32_t(std::min<double>(double(n_clients - 1), std::exp(urand() * lnN) - 1.0));
             const uint32_t tile = uint32_t(p / kT);
-            w.cand[uint64_t(tile) * kT + w.tile_ncand[tile]++] = Cand{uint32_t(p), client, t};
+            w.cand[uint64_t(tile) * kT + w.tile_ncand[tile]++] = Cand{uint32_t(p), client, t, 0u};
             w.cand_off[t + 1]++;
             w.n_cand++;
             if (!first.emplace(client, uint32_t(p)).second) { w.ref[p] = 1; w.n_dup++; }
