@@ -636,7 +636,7 @@ class Group:
         """Shard `holder`'s replica of shard `of`'s subscriber entries (after a gather_runs pass), copied to the host."""
         p, n = C.c_void_p(), C.c_uint64(0)
         _check(lib().rgr_group_peer_subs(self._g, holder, of, C.byref(p), C.byref(n)))
-        return device_to_host(p, int(n.value) * 8).view(SUB_ENTRY_DTYPE) if n.value else np.zeros(0, dtype=SUB_ENTRY_DTYPE)
+        return device_to_host(p.value, int(n.value) * 8).view(SUB_ENTRY_DTYPE) if n.value else np.zeros(0, dtype=SUB_ENTRY_DTYPE)
 
     def match_filter_subs(self, blob, offsets):
         """rgr_group_match_filter_subs: per topic, the sub id of each matched filter's first subscriber, in the caller's topic order."""

@@ -3,7 +3,14 @@
 Each rank keeps the subscriptions it owns under the first-two-level hash (plus the replicated
 wildcard-rooted ones), matches only the publish topics it owns (host emulator backend — the
 sharding logic is backend-independent), then all ranks all-gatherv their tuples; rank 0 checks
-the union bit-exactly against the oracle over the UNSHARDED table."""
+the union bit-exactly against the oracle over the UNSHARDED table.
+
+RMQTT_DIST_BACKEND=hip (the `-m gpu` variant): every rank is a process of its own that drives the PRODUCT library
+(capi.Router, all ranks on GPU 0 of a one-GPU box) and the exchange goes through torch.distributed (gloo).  The library's
+own exchange (rgr_comm_*: ncclCommInitRank + ncclAllGather + the send/recv group) cannot form a communicator with two
+ranks on ONE device — RCCL refuses duplicate devices — so across processes it runs only on the multi-GPU node the driver
+uses (bench.py --gpus N); its protocol (counts round, then exact-size payloads, failure flag) is exercised in-process by
+tests/test_group_gpu.py over the same-device transport and with a world of one over RCCL."""
 import os
 import sys
 
@@ -34,8 +41,14 @@ def main():
     keep_t = np.nonzero(t_owner == rank)[0]
     fb, fo = shard.take(blob, offs, keep_f)
     pb, po = shard.take(tb, to, keep_t)
-    r = emu.EmuRouter()
-    assert r.subscribe_bulk(fb, fo, keep_f.astype(np.uint32), qos[keep_f]) == 0
+    if os.environ.get("RMQTT_DIST_BACKEND") == "hip":
+        from rmqtt_amd import capi
+        r = capi.Router(device=0, window_hits=50_000)
+        assert r.subscribe_bulk(fb, fo, keep_f.astype(np.uint32), qos[keep_f]) == 0
+        r.commit()
+    else:
+        r = emu.EmuRouter()
+        assert r.subscribe_bulk(fb, fo, keep_f.astype(np.uint32), qos[keep_f]) == 0
     got = r.match_batch(pb, po)
     t = got["tuples"]
     local = torch.from_numpy(np.stack([keep_t[t["topic_idx"]].astype(np.int64), t["sub_id"].astype(np.int64),

@@ -4,6 +4,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 from rmqtt_amd import shard
 from tests.conftest import ROOT
 from tests.parity import pack
@@ -30,6 +32,18 @@ def test_two_rank_gloo_sharded_match():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29517", os.path.join(ROOT, "tests", "dist_worker.py")]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert "rank0:" in p.stdout
+
+
+@pytest.mark.gpu
+def test_two_rank_gloo_sharded_match_product_library():
+    """The same two-rank run with every rank driving the product library on the GPU (two processes, one device; the exchange
+    through gloo — see tests/dist_worker.py for why rgr_comm_* itself cannot span two processes on one device)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", RMQTT_DIST_BACKEND="hip")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29519", os.path.join(ROOT, "tests", "dist_worker.py")]
     p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert "rank0:" in p.stdout
