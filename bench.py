@@ -767,7 +767,11 @@ def attach_traffic(rec, phase, pmc, cal):
                "avg_launch_us_under_pmc": d.get("avg_us_under_pmc"),
                # the counters sit on the fabric side of L2: reads served by the 256 MiB Infinity Cache are counted too, so `frac`
                # is an upper bound on HBM traffic when the read set fits it (config 5's 40 MB value array does); stores always reach HBM
-               "frac_stores_only": round(w_b / max(1, unit) * units_per_launch / (rf["avg_launch_ms"] / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if rf["avg_launch_ms"] > 0 else None})
+               "frac_stores_only": round(w_b / max(1, unit) * units_per_launch / (rf["avg_launch_ms"] / 1e3) / 1e9 / HBM_PEAK_GBS, 4) if rf["avg_launch_ms"] > 0 else None,
+               "frac_note": "frac = HBM bytes the PMC counters saw (traffic) / HIP-event time / 8 TB/s — the physical figure.  alg_frac = SURVEY 8(d)'s "
+                            "algorithmic bytes (20 B/hit) over the same time; it exceeds frac, and 1, on the expansion because its 8 B/hit READ term never "
+                            "reaches HBM: 64 filters produce 98 % of config 3's hits, their subscriber runs stay in L2 / Infinity Cache (the counters see "
+                            "0.25 B fetched per hit).  frac_stores_only = the 12 B/hit of tuple stores alone, the floor no cache can remove."})
     gc = cal.get("walk", {}).get("gather_ceiling_Ggathers_per_s")
     if cls == "walk" and gc and rf["avg_launch_ms"] > 0:
         # the walk's own yardstick: dependent random 32-byte gathers.  tools/membench.hip `calib` measures how many such

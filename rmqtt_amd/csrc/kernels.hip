@@ -696,9 +696,24 @@ __global__ __launch_bounds__(kThreads) void expand_kernel(const SubEntry* __rest
         src[j] = subs + (uint64_t(one ? rec.src : s_src[i]) + (live ? uint32_t(int32_t(pos) - (one ? 0 : s_off[i])) : 0u));
     }
     SubEntry se[kPer];
+    // The delivery variant needs the subscription's attributes (owner id: No Local; client index: v5 dedup) for its v5 hits.  Whether
+    // a hit is v5 is only known once its subscriber entry has arrived, so loading the attributes afterwards puts a second memory
+    // latency in front of the tuple stores of every tile — the kernel is bound by those stores.  When the epoch holds v5 subscriptions
+    // the attributes (same index as the entry: L2-resident for the hot runs) and the publisher id are therefore loaded WITH the entries.
+    const bool spec = kDeliver && da.cand != nullptr && da.attrs != nullptr;
+    uint32_t sown[kDeliver ? kPer : 1], scli[kDeliver ? kPer : 1], sfrom[kDeliver ? kPer : 1];
 #pragma unroll
-    for (int j = 0; j < kPer; ++j) {
-        se[j] = *src[j];
+    for (int j = 0; j < kPer; ++j) se[j] = *src[j];
+    if (kDeliver) {
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            sown[j] = kNone; scli[j] = kNone; sfrom[j] = kNone;
+            if (spec) {
+                const uint2 a2 = *reinterpret_cast<const uint2*>(da.attrs + (src[j] - subs));
+                sown[j] = a2.x; scli[j] = a2.y;
+                sfrom[j] = da.pub[topic[j]].from_id;
+            }
+        }
     }
     uint32_t cslot[kDeliver ? kPer : 1], cclient[kDeliver ? kPer : 1];
     if (kDeliver) {
@@ -711,8 +726,8 @@ __global__ __launch_bounds__(kThreads) void expand_kernel(const SubEntry* __rest
                 PublishAttr pa{kNone, s_qr[pidx[j]]};
                 SubAttr at{kNone, kNone};
                 if ((fl & kSubV5) && da.attrs) {                         // v3 hits need neither
-                    at = da.attrs[src[j] - subs];
-                    if (fl & kSubNoLocal) pa.from_id = da.pub[topic[j]].from_id;
+                    at = spec ? SubAttr{sown[j], scli[j]} : da.attrs[src[j] - subs];
+                    if (fl & kSubNoLocal) pa.from_id = spec ? sfrom[j] : da.pub[topic[j]].from_id;
                 }
                 bool cand;
                 se[j].qos_flags = deliver_word(se[j].qos_flags, pa, at, cand);
@@ -998,55 +1013,40 @@ __global__ __launch_bounds__(kDedupTopicThreads) void dedup_topic_kernel(const C
         const uint64_t h0 = hit_off[item.topic] - hit_lo, h1 = hit_off[item.topic + 1] - hit_lo;
         const uint32_t tile0 = uint32_t(h0 / kTile), tile1 = uint32_t((h1 - 1) / kTile);
         const uint32_t mask = dedup_topic_slots(item.nc, item.parts, max_slots) - 1;
-        // The wave's FIRST tile (a topic of up to kWaves tiles gives every wave exactly one) is read once and kept in registers for
-        // both passes: the flag pass then has no global load in front of its LDS lookups (r3c: 0.44 ms per 2^28-hit window, bound by
-        // the chain item -> offsets -> tile count -> list, walked twice).
-        constexpr int kKeep = 4;
-        const uint32_t tfirst = tile0 + wave;
-        const uint32_t n_first = tfirst <= tile1 ? tile_ncand[tfirst] & 0x7FFFFFFFu : 0u;
-        const bool kept_ok = n_first <= 64u * kKeep;
-        Cand kept[kKeep];
-#pragma unroll
-        for (int q = 0; q < kKeep; ++q) {
-            const uint32_t i = lane + 64u * uint32_t(q);
-            kept[q] = (kept_ok && i < n_first) ? cand[uint64_t(tfirst) * kTile + i] : Cand{0u, 0u, kNone, 0u};
-        }
         // sub-parts: 1 unless the part's distinct clients overflow the table (then doubled and redone: the flags are idempotent)
         for (uint32_t S = 1;; S <<= 1) {
             bool over = false;
             for (uint32_t sub = 0; sub < S && !over; ++sub) {
                 const uint64_t nparts = uint64_t(item.parts) * S;
                 const uint32_t mine = item.part * S + sub;
-                auto selected = [&](const Cand& c) { return c.topic == item.topic && (nparts == 1 || dedup_part(c.client_idx, nparts) == mine); };
-                auto insert = [&](const Cand& c) {
-                    if (!dedup_topic_insert(c.client_idx, c.pos, mask, [&](uint32_t sl, unsigned long long v) { return atomicCAS(&s_tab[sl], kDedupEmpty, v); },
-                                            [&](uint32_t sl, unsigned long long v) { atomicMin(&s_tab[sl], v); }))
-                        s_over = 1;
-                };
-                auto flag = [&](const Cand& c) {
-                    if (dedup_topic_is_dup(c.client_idx, c.pos, mask, [&](uint32_t sl) { return s_tab[sl]; })) tuples[c.pos].qos_flags = c.word | kHitV5Dup;
-                };
-                // every wave takes whole tiles: a tile's list is read by 64 lanes with a stride of 64
-                auto for_other_tiles = [&](auto&& fn) {
-                    for (uint32_t tile = kept_ok ? tfirst + kWaves : tfirst; tile <= tile1; tile += kWaves) {
-                        const uint32_t n = tile_ncand[tile] & 0x7FFFFFFFu;
-                        const Cand* list = cand + uint64_t(tile) * kTile;
-                        for (uint32_t i = lane; i < n; i += 64) { const Cand c = list[i]; if (selected(c)) fn(c); }
-                    }
-                };
                 __syncthreads();
                 for (uint32_t i = threadIdx.x; i <= mask; i += kDedupTopicThreads) s_tab[i] = kDedupEmpty;
                 if (threadIdx.x == 0) s_over = 0;
                 __syncthreads();
-#pragma unroll
-                for (int q = 0; q < kKeep; ++q) if (selected(kept[q])) insert(kept[q]);
-                for_other_tiles(insert);
+                // every wave takes whole tiles: a tile's list is read by 64 lanes with a stride of 64
+                for (uint32_t tile = tile0 + wave; tile <= tile1; tile += kWaves) {
+                    const uint32_t n = tile_ncand[tile] & 0x7FFFFFFFu;
+                    const Cand* list = cand + uint64_t(tile) * kTile;
+                    for (uint32_t i = lane; i < n; i += 64) {
+                        const Cand c = list[i];
+                        if (c.topic != item.topic || (nparts > 1 && dedup_part(c.client_idx, nparts) != mine)) continue;
+                        if (!dedup_topic_insert(c.client_idx, c.pos, mask, [&](uint32_t sl, unsigned long long v) { return atomicCAS(&s_tab[sl], kDedupEmpty, v); },
+                                                [&](uint32_t sl, unsigned long long v) { atomicMin(&s_tab[sl], v); }))
+                            s_over = 1;
+                    }
+                }
                 __syncthreads();
                 over = s_over != 0;
                 if (over) break;
-#pragma unroll
-                for (int q = 0; q < kKeep; ++q) if (selected(kept[q])) flag(kept[q]);
-                for_other_tiles(flag);
+                for (uint32_t tile = tile0 + wave; tile <= tile1; tile += kWaves) {
+                    const uint32_t n = tile_ncand[tile] & 0x7FFFFFFFu;
+                    const Cand* list = cand + uint64_t(tile) * kTile;
+                    for (uint32_t i = lane; i < n; i += 64) {
+                        const Cand c = list[i];
+                        if (c.topic != item.topic || (nparts > 1 && dedup_part(c.client_idx, nparts) != mine)) continue;
+                        if (dedup_topic_is_dup(c.client_idx, c.pos, mask, [&](uint32_t sl) { return s_tab[sl]; })) tuples[c.pos].qos_flags = c.word | kHitV5Dup;
+                    }
+                }
             }
             if (!over) break;
         }

@@ -91,7 +91,7 @@ Result<bool> GpuRouter::add(const std::string& topic_filter, const Id& id, const
     auto it = relations_.find(topic_filter);
     if (it == relations_.end()) {
         topics_count_.inc();
-        it = relations_.emplace(topic_filter, FilterEntry{{}, ByteStr(topic_filter)}).first;
+        it = relations_.emplace(topic_filter, FilterEntry{{}}).first;
     }
     auto& rels = it->second.rels;
     auto old = rels.find(id.client_id);
@@ -103,12 +103,12 @@ Result<bool> GpuRouter::add(const std::string& topic_filter, const Id& id, const
         relations_count_.inc();
         if (!free_sub_ids_.empty()) { sub_id = free_sub_ids_.back(); free_sub_ids_.pop_back(); }
         else { sub_id = uint32_t(slab_.size()); slab_.emplace_back(); }
-        old = rels.emplace(id.client_id, Rel{id, opts, sub_id, owner_id, ByteStr(id.client_id)}).first;
+        old = rels.emplace(id.client_id, Rel{id, opts, sub_id, owner_id}).first;
     } else {
         sub_id = old->second.sub_id;
         owners_.release(id_key(old->second.id));
         clients_.release(client_key(old->second.id.node_id, old->second.id.client_id));
-        old->second = Rel{id, opts, sub_id, owner_id, ByteStr(id.client_id)};              // HashMap::insert replaces (router.rs:447)
+        old->second = Rel{id, opts, sub_id, owner_id};              // HashMap::insert replaces (router.rs:447)
     }
     const uint32_t client_idx = clients_.acquire(client_key(id.node_id, id.client_id));
     auto ni = node_idx_.find(id.node_id);
@@ -138,8 +138,7 @@ Result<bool> GpuRouter::restore(const raft::Snapshot& snap) {
     rgr_config cfg{};
     if (rgr_group_create(&cfg, devices_.data(), uint32_t(devices_.size()), &fresh) != RGR_OK) return Result<bool>::Err(rgr_last_error());
     std::unordered_map<TopicFilter, FilterEntry> relations;
-    for (auto& r : snap.relations) relations[r.topic_filter].rels[r.client_id] = Rel{r.id, r.opts, 0, 0, ByteStr(r.client_id)};   // HashMap::insert: the later entry wins
-    for (auto& kv : relations) kv.second.name = ByteStr(kv.first);
+    for (auto& r : snap.relations) relations[r.topic_filter].rels[r.client_id] = Rel{r.id, r.opts, 0, 0};   // HashMap::insert: the later entry wins
     std::vector<Slot> slab;
     Dense owners, clients;
     std::string blob;
@@ -220,9 +219,9 @@ struct Collector {
     SubRelations v5;                                       // rows in first-hit order
     std::unordered_map<ClientId, size_t> v5_index;         // the HashMap<ClientId, ...> of types.rs:506
     // returns whether the hit created the client's v5 entry (true) or only contributed its identifier (false); v3: true
-    bool add(const ByteStr& filter, const ByteStr& client, const SubscriptionOptions& opts, std::optional<SharedGroupType> group) {
+    bool add(const TopicFilter& filter, const ClientId& client, const SubscriptionOptions& opts, std::optional<SharedGroupType> group) {
         if (opts.is_v3()) { v3.push_back(SubRelation{filter, client, opts, std::nullopt, std::move(group)}); return true; }   // types.rs:519-521
-        auto it = v5_index.find(client.str());
+        auto it = v5_index.find(client);
         if (it != v5_index.end()) {                                                                          // types.rs:526-534
             if (opts.subscription_identifier) {
                 auto& ids = v5[it->second].sub_ids;
@@ -232,7 +231,7 @@ struct Collector {
         }
         SubRelation r{filter, client, opts, std::nullopt, std::move(group)};                                 // types.rs:535-538
         if (opts.subscription_identifier) r.sub_ids = std::vector<uint32_t>{opts.subscription_identifier};
-        v5_index.emplace(client.str(), v5.size());
+        v5_index.emplace(client, v5.size());
         v5.push_back(std::move(r));
         return true;
     }
@@ -280,7 +279,7 @@ std::optional<SubRelationsMap> GpuRouter::expand_locked(const rgr_filters_result
                 groups[*rel.opts.shared_group].push_back(SharedCandidate{node, rel.id.client_id, rel.opts, is_online(node, rel.id.client_id)});
                 continue;
             }
-            collector_map[node].add(s.entry->name, rel.client, rel.opts, std::nullopt);         // router.rs:214-229 (two ref-counted clones per row)
+            collector_map[node].add(*s.filter, rel.id.client_id, rel.opts, std::nullopt);       // router.rs:214-229
         }
         for (auto& gk : groups) {                                               // router.rs:236-255, once per matched filter
             std::vector<ClientId> cids;
@@ -288,7 +287,7 @@ std::optional<SubRelationsMap> GpuRouter::expand_locked(const rgr_filters_result
             const auto pick = shared_ ? shared_->choice(gk.first, id, topic, gk.second) : std::nullopt;
             if (!pick || pick->first >= gk.second.size()) continue;
             const SharedCandidate& c = gk.second[pick->first];
-            collector_map[c.node_id].add(s.entry->name, ByteStr(c.client_id), c.opts, SharedGroupType{gk.first, pick->second, cids});
+            collector_map[c.node_id].add(*s.filter, c.client_id, c.opts, SharedGroupType{gk.first, pick->second, cids});
         }
     }
     if (hits) *hits = n_hits;
@@ -365,7 +364,7 @@ Result<bool> GpuRouter::matches_batch_deliver(const std::vector<Id>& ids, const 
                     if (w & RGR_HIT_NO_LOCAL) continue;                  // router.rs:196-201, decided on the device
                     const Slot& sl = slab_[res.tuples[k].sub_id];
                     const Rel& rel = *sl.rel;
-                    const bool created = col.add(sl.entry->name, rel.client, rel.opts, std::nullopt);
+                    const bool created = col.add(*sl.filter, rel.id.client_id, rel.opts, std::nullopt);
                     if (!rel.opts.is_v3() && created == ((w & RGR_HIT_V5_DUP) != 0)) flag_mismatches_++;
                 }
                 if (col.v3.empty() && col.v5.empty()) continue;          // (every hit of the node was the publisher's own No Local subscription)
@@ -397,7 +396,7 @@ Result<bool> GpuRouter::matches_batch_deliver(const std::vector<Id>& ids, const 
                 const auto pick = shared_ ? shared_->choice(gk.first, ids[t], topics[t], ncs) : std::nullopt;
                 if (!pick || pick->first >= ncs.size()) continue;
                 const SharedCandidate& c = ncs[pick->first];
-                collector_map[c.node_id].add(ByteStr(*cur_filter), ByteStr(c.client_id), c.opts, SharedGroupType{gk.first, pick->second, cids});
+                collector_map[c.node_id].add(*cur_filter, c.client_id, c.opts, SharedGroupType{gk.first, pick->second, cids});
                 shared_chosen = true;
             }
             groups.clear();
@@ -413,7 +412,7 @@ Result<bool> GpuRouter::matches_batch_deliver(const std::vector<Id>& ids, const 
                 groups[*rel.opts.shared_group].push_back({SharedCandidate{node, rel.id.client_id, rel.opts, is_online(node, rel.id.client_id)}, &rel});
                 continue;
             }
-            const bool created = collector_map[node].add(s.entry->name, rel.client, rel.opts, std::nullopt);   // router.rs:214-229
+            const bool created = collector_map[node].add(*s.filter, rel.id.client_id, rel.opts, std::nullopt);   // router.rs:214-229
             // the device's verdict on the same hit (types.rs:524-539 as a min-position-per-client problem)
             if (!rel.opts.is_v3() && !shared_chosen && created == ((w & RGR_HIT_V5_DUP) != 0)) flag_mismatches_++;
         }

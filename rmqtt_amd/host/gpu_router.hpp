@@ -47,28 +47,6 @@ using NodeId = uint64_t;
 using ClientId = std::string;
 using TopicFilter = std::string;
 using TopicName = std::string;
-// Stand-in for bytestring::ByteString (what TopicFilter / ClientId are in the reference): an immutable string whose clones only
-// bump a reference count.  The rows of a SubRelationsMap are clones (types.rs:478-484, router.rs:214-229) — with 14.8 k rows per
-// publish at config-3 fan-out a deep copy per row (a malloc for every filter longer than 15 bytes) is what the host would be doing.
-class ByteStr {
-   public:
-    ByteStr() : p_(empty_()) {}
-    ByteStr(const std::string& s) : p_(std::make_shared<const std::string>(s)) {}
-    ByteStr(std::string&& s) : p_(std::make_shared<const std::string>(std::move(s))) {}
-    ByteStr(const char* s) : p_(std::make_shared<const std::string>(s)) {}
-    const std::string& str() const { return *p_; }
-    operator const std::string&() const { return *p_; }
-    bool operator==(const ByteStr& o) const { return p_ == o.p_ || *p_ == *o.p_; }
-    bool operator<(const ByteStr& o) const { return *p_ < *o.p_; }
-
-   private:
-    static const std::shared_ptr<const std::string>& empty_() { static const auto e = std::make_shared<const std::string>(); return e; }
-    std::shared_ptr<const std::string> p_;
-};
-inline std::string operator+(const std::string& a, const ByteStr& b) { return a + b.str(); }
-inline std::string operator+(const ByteStr& a, const std::string& b) { return a.str() + b; }
-inline std::string operator+(const ByteStr& a, const char* b) { return a.str() + b; }
-
 // types.rs:1899-1911; equality over every field (types.rs:1841-1851).
 struct Id {
     NodeId node_id = 0;
@@ -97,9 +75,12 @@ struct SubscriptionOptions {
 };
 
 struct SharedGroupType { std::string group; bool is_online = true; std::vector<ClientId> group_cids; };   // types.rs:474
+// Rows hold their own copies of the filter and the client id.  (r3 measured the alternative — ref-counted strings like the reference's
+// ByteString clones — on 256 threads at config-3 fan-out: 8.8 M rows/s against 38 M rows/s for plain copies; every thread bumps the reference
+// counts of the same few hot filters and clients, and those cache lines ping-pong.  profiles/r03f_router_e2e_refcounted_rows_slower.jsonl)
 struct SubRelation {   // types.rs:478-484
-    ByteStr topic_filter;
-    ByteStr client_id;
+    TopicFilter topic_filter;
+    ClientId client_id;
     SubscriptionOptions opts;
     std::optional<std::vector<uint32_t>> sub_ids;
     std::optional<SharedGroupType> group;        // Some for the member a shared group selected
@@ -217,7 +198,7 @@ class GpuRouter final : public Router {
     Result<bool> restore(const raft::Snapshot& snap);
 
    private:
-    struct Rel { Id id; SubscriptionOptions opts; uint32_t sub_id; uint32_t owner_id; ByteStr client; };   // client: the row's ClientId clone source
+    struct Rel { Id id; SubscriptionOptions opts; uint32_t sub_id; uint32_t owner_id; };
     struct Dense {                       // string key -> dense u32 id with reference counts
         std::unordered_map<std::string, std::pair<uint32_t, uint32_t>> ids;   // key -> (id, refs)
         std::vector<uint32_t> free;
@@ -226,7 +207,7 @@ class GpuRouter final : public Router {
         void release(const std::string& k);
         uint32_t find(const std::string& k) const;                             // RGR_ID_NONE if absent
     };
-    struct FilterEntry { std::unordered_map<ClientId, Rel> rels; ByteStr name; };                          // name: the row's TopicFilter clone source
+    struct FilterEntry { std::unordered_map<ClientId, Rel> rels; };
     struct Slot { const std::string* filter = nullptr; const Rel* rel = nullptr; const FilterEntry* entry = nullptr; };
 
     rgr_group* g_ = nullptr;

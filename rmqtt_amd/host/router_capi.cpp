@@ -57,14 +57,14 @@ std::string dump(const SubRelationsMap& m) {
         out += "N " + std::to_string(kv.first) + "\n";
         std::vector<std::string> v3, v5;
         for (auto& s : kv.second) {
-            if (s.opts.is_v3()) v3.push_back("3 " + s.topic_filter.str() + "\t" + s.client_id.str() + "\t" + std::to_string(s.opts.qos) + group_text(s) + "\n");
+            if (s.opts.is_v3()) v3.push_back("3 " + s.topic_filter + "\t" + s.client_id + "\t" + std::to_string(s.opts.qos) + group_text(s) + "\n");
             else {
                 std::string ids = "-";
                 if (s.sub_ids) {
                     auto v = *s.sub_ids; std::sort(v.begin(), v.end()); ids.clear();
                     for (size_t i = 0; i < v.size(); ++i) { if (i) ids.push_back(','); ids += std::to_string(v[i]); }
                 }
-                v5.push_back("5 " + s.client_id.str() + "\t" + s.topic_filter.str() + "\t" + std::to_string(s.opts.qos) + "\t" + std::to_string(int(s.opts.no_local)) + "\t" + ids + group_text(s) + "\n");
+                v5.push_back("5 " + s.client_id + "\t" + s.topic_filter + "\t" + std::to_string(s.opts.qos) + "\t" + std::to_string(int(s.opts.no_local)) + "\t" + ids + group_text(s) + "\n");
             }
         }
         std::sort(v3.begin(), v3.end()); std::sort(v5.begin(), v5.end());
