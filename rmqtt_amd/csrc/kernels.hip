@@ -52,6 +52,9 @@ constexpr int kWalkWindow = RGR_WALK_WINDOW;
 #ifndef RGR_EXPAND_PER_THREAD
 #define RGR_EXPAND_PER_THREAD 2
 #endif
+// Timing diagnostics for the delivery variant of the expansion (tools/deliver_sweep.sh builds the library once per switch; the results
+// of such a build are WRONG by construction — they only tell where the time goes): RGR_DIAG_NO_ATTRS (no attribute gather: the sub id stands
+// in for the client index), RGR_DIAG_NO_PAIR_COUNTS (no per-pair candidate counts / per-topic atomics), RGR_DIAG_NO_CAND_STORE.
 #ifndef RGR_EXPAND_NT
 #define RGR_EXPAND_NT 1          // nontemporal tuple stores: the output is write-once, keep L2 for the subscriber runs
 #endif
@@ -696,24 +699,9 @@ __global__ __launch_bounds__(kThreads) void expand_kernel(const SubEntry* __rest
         src[j] = subs + (uint64_t(one ? rec.src : s_src[i]) + (live ? uint32_t(int32_t(pos) - (one ? 0 : s_off[i])) : 0u));
     }
     SubEntry se[kPer];
-    // The delivery variant needs the subscription's attributes (owner id: No Local; client index: v5 dedup) for its v5 hits.  Whether
-    // a hit is v5 is only known once its subscriber entry has arrived, so loading the attributes afterwards puts a second memory
-    // latency in front of the tuple stores of every tile — the kernel is bound by those stores.  When the epoch holds v5 subscriptions
-    // the attributes (same index as the entry: L2-resident for the hot runs) and the publisher id are therefore loaded WITH the entries.
-    const bool spec = kDeliver && da.cand != nullptr && da.attrs != nullptr;
-    uint32_t sown[kDeliver ? kPer : 1], scli[kDeliver ? kPer : 1], sfrom[kDeliver ? kPer : 1];
 #pragma unroll
-    for (int j = 0; j < kPer; ++j) se[j] = *src[j];
-    if (kDeliver) {
-#pragma unroll
-        for (int j = 0; j < kPer; ++j) {
-            sown[j] = kNone; scli[j] = kNone; sfrom[j] = kNone;
-            if (spec) {
-                const uint2 a2 = *reinterpret_cast<const uint2*>(da.attrs + (src[j] - subs));
-                sown[j] = a2.x; scli[j] = a2.y;
-                sfrom[j] = da.pub[topic[j]].from_id;
-            }
-        }
+    for (int j = 0; j < kPer; ++j) {
+        se[j] = *src[j];
     }
     uint32_t cslot[kDeliver ? kPer : 1], cclient[kDeliver ? kPer : 1];
     if (kDeliver) {
@@ -726,8 +714,12 @@ __global__ __launch_bounds__(kThreads) void expand_kernel(const SubEntry* __rest
                 PublishAttr pa{kNone, s_qr[pidx[j]]};
                 SubAttr at{kNone, kNone};
                 if ((fl & kSubV5) && da.attrs) {                         // v3 hits need neither
-                    at = spec ? SubAttr{sown[j], scli[j]} : da.attrs[src[j] - subs];
-                    if (fl & kSubNoLocal) pa.from_id = spec ? sfrom[j] : da.pub[topic[j]].from_id;
+#ifdef RGR_DIAG_NO_ATTRS
+                    at = SubAttr{kNone, se[j].sub_id};
+#else
+                    at = da.attrs[src[j] - subs];
+#endif
+                    if (fl & kSubNoLocal) pa.from_id = da.pub[topic[j]].from_id;
                 }
                 bool cand;
                 se[j].qos_flags = deliver_word(se[j].qos_flags, pa, at, cand);
@@ -768,6 +760,9 @@ __global__ __launch_bounds__(kThreads) void expand_kernel(const SubEntry* __rest
             wbase = __shfl(wbase, leader, 64);
             if (is) cslot[j] = wbase + uint32_t(__popcll(m & ((1ull << lane) - 1ull)));
             unsigned long long rest = m;
+#ifdef RGR_DIAG_NO_PAIR_COUNTS
+            rest = 0;
+#endif
             while (rest) {                                           // usually one or two pairs per wave
                 const int l0 = __ffsll(static_cast<long long>(rest)) - 1;
                 const uint32_t p0 = __shfl(pidx[j], l0, 64);
@@ -800,7 +795,11 @@ __global__ __launch_bounds__(kThreads) void expand_kernel(const SubEntry* __rest
         Cand* mine = da.cand + uint64_t(tile) * kTile;
 #pragma unroll
         for (int j = 0; j < kPer; ++j)
+#ifndef RGR_DIAG_NO_CAND_STORE
             if (cslot[j] != kNone)
+#else
+            if (cslot[j] != kNone && cclient[j] == 0x12345u)
+#endif
                 mine[cslot[j]] = Cand{uint32_t(base - hit_lo) + uint32_t(j) * kThreads + threadIdx.x, cclient[j], topic[j] - da.topic_lo, se[j].qos_flags};
     }
 }
