@@ -560,6 +560,28 @@ class Comm:
         tup = (np.concatenate(parts) if parts else np.zeros(0, dtype=TUPLE_DTYPE)) if collect else None
         return int(mine.value), int(allh.value), tup
 
+    def replicate_subs(self):
+        """Collective: every rank's subs[] on every rank (call after commit, before gather_runs_pass)."""
+        _check(lib().rgr_comm_replicate_subs(self._c))
+
+    def peer_subs(self, rank):
+        p, n = C.c_void_p(), C.c_uint64(0)
+        _check(lib().rgr_comm_peer_subs(self._c, rank, C.byref(p), C.byref(n)))
+        return device_to_host(p.value, int(n.value) * 8).view(SUB_ENTRY_DTYPE) if n.value else np.zeros(0, dtype=SUB_ENTRY_DTYPE)
+
+    def gather_runs_pass(self, batch, collect=False):
+        """All-gathered pass with run descriptors as the payload.  -> (my_runs, all_runs, all_hits, descriptors | None)"""
+        parts = []
+
+        def cb(user, d_runs, counts, world, n_total):
+            if collect and n_total:
+                parts.append(device_to_host(d_runs, int(n_total) * 16).view(RUN_DTYPE))
+        fn = GATHER_CONSUMER(cb)
+        mine, allr, allh = C.c_uint64(0), C.c_uint64(0), C.c_uint64(0)
+        _check(lib().rgr_comm_gather_runs_pass(self._c, batch._b, fn, None, C.byref(mine), C.byref(allr), C.byref(allh)))
+        got = (np.concatenate(parts) if parts else np.zeros(0, dtype=RUN_DTYPE)) if collect else None
+        return int(mine.value), int(allr.value), int(allh.value), got
+
 
 class Group:
     """Single-process multi-device router (rgr_group_*): one shard per entry of `devices`."""

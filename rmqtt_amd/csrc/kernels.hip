@@ -760,8 +760,8 @@ __global__ __launch_bounds__(kThreads) void expand_kernel(const SubEntry* __rest
             wbase = __shfl(wbase, leader, 64);
             if (is) cslot[j] = wbase + uint32_t(__popcll(m & ((1ull << lane) - 1ull)));
             unsigned long long rest = m;
-#ifdef RGR_DIAG_NO_PAIR_COUNTS
-            rest = 0;
+#if defined(RGR_DIAG_NO_PAIR_COUNTS) || !defined(RGR_DEDUP_EXACT_COUNTS)
+            rest = 0;             // (per-pair candidate counts are only needed by the exact-count variant, see below)
 #endif
             while (rest) {                                           // usually one or two pairs per wave
                 const int l0 = __ffsll(static_cast<long long>(rest)) - 1;
@@ -772,6 +772,7 @@ __global__ __launch_bounds__(kThreads) void expand_kernel(const SubEntry* __rest
             }
         }
         __syncthreads();
+#ifdef RGR_DEDUP_EXACT_COUNTS
         if (s_ncand) {   // per-topic candidate counts: the tile's pairs of one topic are adjacent, their first pair's lane sums them
             for (uint32_t i = threadIdx.x; i < np; i += kThreads) {
                 const uint32_t tp = s_topic[i];
@@ -791,6 +792,22 @@ __global__ __launch_bounds__(kThreads) void expand_kernel(const SubEntry* __rest
             __syncthreads();
         }
         if (threadIdx.x == 0) da.tile_ncand[tile] = s_ncand | (s_inside << 31);
+#else
+        // The topic pass sizes its tables from an UPPER BOUND of a topic's candidates (the candidate counts of the tiles it spans,
+        // dedup_classify_kernel), so no per-topic count is kept here (r3h: the per-pair counts + per-topic atomics were 0.10 ms of a
+        // window).  Bit 31 of the tile's count = "a whole topic may lie inside this tile": the tile holds pairs of more than one topic,
+        // or its single topic starts and ends here — only then has the tile-local dedup anything to do.
+        if (threadIdx.x == 0) {
+            uint32_t flag = 0;
+            if (s_ncand >= 2) {
+                const uint32_t t_first = s_topic[0], t_last = s_topic[np - 1];
+                flag = t_first != t_last ? 1u
+                       : (c.pair_off[a] == base && (a == pair_lo || c.pair_topic[a - 1] != t_first) && c.pair_off[b] <= base + kTile &&
+                          (b == pair_hi || c.pair_topic[b] != t_first)) ? 1u : 0u;
+            }
+            da.tile_ncand[tile] = s_ncand | (flag << 31);
+        }
+#endif
         // the tile's candidates go to the tile's own slice of the list: no global cursor
         Cand* mine = da.cand + uint64_t(tile) * kTile;
 #pragma unroll
@@ -985,14 +1002,26 @@ __global__ __launch_bounds__(256) void dedup_tile_kernel(const Cand* __restrict_
 }
 
 // One work item per part of every topic that spans tiles and has at least two candidates.
-__global__ __launch_bounds__(256) void dedup_classify_kernel(const uint32_t* __restrict__ topic_cand, uint32_t nt, const uint64_t* __restrict__ hit_off,
-                                                             uint64_t hit_lo, DedupItem* __restrict__ items, uint32_t* __restrict__ item_count) {
+__global__ __launch_bounds__(256) void dedup_classify_kernel(const uint32_t* __restrict__ topic_cand, const uint32_t* __restrict__ tile_ncand, uint32_t nt,
+                                                             const uint64_t* __restrict__ hit_off, uint64_t hit_lo, DedupItem* __restrict__ items,
+                                                             uint32_t* __restrict__ item_count) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= nt) return;
-    const uint32_t nc = topic_cand[t];
-    if (nc < 2) return;
     const uint64_t h0 = hit_off[t] - hit_lo, h1 = hit_off[t + 1] - hit_lo;
-    if (h0 / kTile == (h1 - 1) / kTile) return;                 // inside one tile: dedup_tile_kernel
+    if (h1 - h0 < 2) return;
+    const uint32_t tile0 = uint32_t(h0 / kTile), tile1 = uint32_t((h1 - 1) / kTile);
+    if (tile0 == tile1) return;                                 // inside one tile: dedup_tile_kernel
+#ifdef RGR_DEDUP_EXACT_COUNTS
+    (void)tile_ncand;
+    const uint32_t nc = topic_cand[t];
+#else
+    // upper bound of the topic's candidates: what its tiles hold (the first and the last tile are shared with neighbours), at most its hits
+    (void)topic_cand;
+    uint64_t sum = 0;
+    for (uint32_t tile = tile0; tile <= tile1; ++tile) sum += tile_ncand[tile] & 0x7FFFFFFFu;
+    const uint32_t nc = uint32_t(sum < h1 - h0 ? sum : h1 - h0);
+#endif
+    if (nc < 2) return;
     const uint32_t parts = (nc + kDedupTopicCap - 1) / kDedupTopicCap;
     const uint32_t at = atomicAdd(item_count, parts);
     for (uint32_t p = 0; p < parts; ++p) items[at + p] = DedupItem{t, p, parts, nc};
@@ -1303,7 +1332,7 @@ void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, uint32_t ntiles,
     hipStream_t s = static_cast<hipStream_t>(stream);
     (void)hipMemsetAsync(item_count, 0, 4, s);
     dedup_tile_kernel<<<std::min<uint32_t>(ntiles, 2048u), 256, 0, s>>>(cand, tile_ncand, ntiles, hit_off, hit_lo, tuples, stat);
-    dedup_classify_kernel<<<(nt + 255) / 256, 256, 0, s>>>(topic_cand, nt, hit_off, hit_lo, items, item_count);
+    dedup_classify_kernel<<<(nt + 255) / 256, 256, 0, s>>>(topic_cand, tile_ncand, nt, hit_off, hit_lo, items, item_count);
     // the item count stays on the device: a fixed grid of persistent blocks (4 per CU fit) strides over the items
     // RGR_DEDUP_TEST_SLOTS (tests only): a smaller table, so that parts overflow and the re-split path runs on ordinary inputs
     static const uint32_t max_slots = [] {

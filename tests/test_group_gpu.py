@@ -114,4 +114,15 @@ def test_rccl_communicator_world_of_one():
     assert np.array_equal(tup["sub_id"], exp["sub_ids"])
     ho = exp["hit_offsets"].astype(np.int64)
     assert np.array_equal(tup["topic_idx"], np.repeat((n - 1 - np.arange(n)).astype(np.uint32), np.diff(ho)))
+    # the run-descriptor exchange over the same RCCL communicator: replicate subs[] (all-gatherv of 8-byte entries), then descriptors
+    with pytest.raises(capi.RgrError) as e:
+        c.gather_runs_pass(b)                                   # refused until the subscriber entries were replicated for this epoch
+    assert e.value.code == capi.RGR_ESTATE
+    c.replicate_subs()
+    mine_r, all_r, all_h, runs = c.gather_runs_pass(b, collect=True)
+    assert mine_r == all_r == len(runs) and all_h == len(exp["sub_ids"]) and (runs["shard"] == 0).all()
+    subs = c.peer_subs(0)
+    sid = np.concatenate([subs["sub_id"][int(x["src"]):int(x["src"]) + int(x["len"])] for x in runs])
+    assert np.array_equal(sid, exp["sub_ids"])
+    assert np.array_equal(np.repeat(runs["topic"], runs["len"]), np.repeat((n - 1 - np.arange(n)).astype(np.uint32), np.diff(ho)))
     b.close(); c.close(); r.close()
