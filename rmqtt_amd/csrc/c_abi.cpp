@@ -201,7 +201,7 @@ struct rgr_batch {
     int format = kFmtTuple;              // rgr_batch_set_format
     bool has_topic_ids = false;          // rgr_batch_set_topic_ids
     DevBuf d_topic_ids;
-    DevBuf d_pub, cand, cand_count, topic_cand, dedup_items, dedup_scalars;   // dedup_scalars: u64 candidates of the pass, u32 work-item count
+    DevBuf d_pub, cand, cand_count, dedup_items, dedup_scalars;   // dedup_scalars: u64 candidates of the pass, u32 work-item count
     DevBuf rf_filter[2], rf_node[2], r_cnt, r_payload, r_ecnt, r_e0, r_e1, r_out_off, r_epos, r_end, r_depth;   // retain frontier rounds
     // pass state
     bool retain = false;             // batch of SUBSCRIBE filters against the retained-topic trie
@@ -1316,13 +1316,10 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
                     const uint64_t ntl = (nh + T - 1) / T;
                     b->cand.ensure(ntl * T * sizeof(Cand));
                     b->cand_count.ensure(ntl * 4);                       // per-tile counts (every tile writes its own)
-                    b->topic_cand.ensure((size_t(nt) + 1) * 4);
                     b->dedup_items.ensure((size_t(nt) + nh / dedup_topic_cap() + 2) * sizeof(DedupItem));
                     if (!b->dedup_scalars.p) { b->dedup_scalars.ensure(16); RGR_HIP(hipMemsetAsync(b->dedup_scalars.p, 0, 16, b->stream)); }
-                    RGR_HIP(hipMemsetAsync(b->topic_cand.p, 0, (size_t(nt) + 1) * 4, b->stream));
                     da.cand = b->cand.as<Cand>();
                     da.tile_ncand = b->cand_count.as<uint32_t>();
-                    da.topic_cand = b->topic_cand.as<uint32_t>();
                     da.topic_lo = b->c->begin + lc;
                 }
             }
@@ -1340,7 +1337,7 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
             if (dedup) {
                 // LDS tables (tile-local, then one block per spanning topic); stream-ordered, no host synchronisation
                 sp = b->span_begin(kSpanDedup);
-                launch_dedup(b->cand.as<Cand>(), b->cand_count.as<uint32_t>(), uint32_t((nh + T - 1) / T), outbuf.as<Tuple>(), b->topic_cand.as<uint32_t>(),
+                launch_dedup(b->cand.as<Cand>(), b->cand_count.as<uint32_t>(), uint32_t((nh + T - 1) / T), outbuf.as<Tuple>(),
                              le - lc, b->c->hit_off.as<uint64_t>() + lc, hit_lo, b->dedup_items.as<DedupItem>(),
                              reinterpret_cast<uint32_t*>(b->dedup_scalars.as<unsigned long long>() + 1), b->dedup_scalars.as<unsigned long long>(), b->stream);
                 b->span_end(sp);

@@ -54,7 +54,7 @@ constexpr int kWalkWindow = RGR_WALK_WINDOW;
 #endif
 // Timing diagnostics for the delivery variant of the expansion (tools/deliver_sweep.sh builds the library once per switch; the results
 // of such a build are WRONG by construction — they only tell where the time goes): RGR_DIAG_NO_ATTRS (no attribute gather: the sub id stands
-// in for the client index), RGR_DIAG_NO_PAIR_COUNTS (no per-pair candidate counts / per-topic atomics), RGR_DIAG_NO_CAND_STORE.
+// in for the client index), RGR_DIAG_NO_CAND_STORE.  (RGR_DIAG_NO_PAIR_COUNTS of profiles/r03h_deliver_sweep.txt became the product: r3j.)
 #ifndef RGR_EXPAND_NT
 #define RGR_EXPAND_NT 1          // nontemporal tuple stores: the output is write-once, keep L2 for the subscriber runs
 #endif
@@ -653,10 +653,9 @@ __global__ __launch_bounds__(kThreads) void expand_kernel(const SubEntry* __rest
     __shared__ int32_t s_off[kTile + 2];
     __shared__ uint32_t s_src[kTile + 2];
     __shared__ uint32_t s_topic[kTile + 2];
-    __shared__ uint32_t s_ncand, s_inside;
-    __shared__ uint32_t s_pc[kDeliver ? kTile + 2 : 1];   // dedup candidates per staged pair
+    __shared__ uint32_t s_ncand;
     __shared__ uint8_t s_qr[kDeliver ? kTile + 2 : 1];    // publish qos | retain<<2 of the pair's topic
-    if (kDeliver && threadIdx.x == 0) { s_ncand = 0; s_inside = 0; }
+    if (kDeliver && threadIdx.x == 0) s_ncand = 0;
 
     const uint32_t tile = blockIdx.x;
     const uint64_t base = hit_lo + uint64_t(tile) * kTile;
@@ -670,13 +669,13 @@ __global__ __launch_bounds__(kThreads) void expand_kernel(const SubEntry* __rest
     const bool one = np == 1;
     if (one) {
         if (kDeliver) {
-            if (threadIdx.x == 0) { s_off[0] = 0; s_src[0] = rec.src; s_topic[0] = rec.topic; s_qr[0] = uint8_t(rec.qr); s_pc[0] = 0; }
+            if (threadIdx.x == 0) { s_off[0] = 0; s_src[0] = rec.src; s_topic[0] = rec.topic; s_qr[0] = uint8_t(rec.qr); }
             __syncthreads();
         }
     } else {
         for (uint32_t i = threadIdx.x; i < np; i += kThreads) {
             tile_pair_view(c, a, i, base, s_off[i], s_src[i], s_topic[i]);
-            if (kDeliver) { s_qr[i] = c.pair_qr[a + i]; s_pc[i] = 0; }
+            if (kDeliver) s_qr[i] = c.pair_qr[a + i];
         }
         __syncthreads();
     }
@@ -746,8 +745,7 @@ __global__ __launch_bounds__(kThreads) void expand_kernel(const SubEntry* __rest
     // store stream back — the kernel is bound by those stores); the whole part is skipped (block-uniformly) when the epoch holds
     // no v5 subscription
     if (kDeliver && da.cand) {
-        // slots in the block's candidate list and per-pair counts, one LDS atomic per wave and
-        // per pair present in the wave instead of one per lane
+        // slots in the block's candidate list: one LDS atomic per wave instead of one per lane
         const int lane = threadIdx.x & 63;
 #pragma unroll
         for (int j = 0; j < kPer; ++j) {
@@ -759,40 +757,8 @@ __global__ __launch_bounds__(kThreads) void expand_kernel(const SubEntry* __rest
             if (lane == leader) wbase = atomicAdd(&s_ncand, uint32_t(__popcll(m)));
             wbase = __shfl(wbase, leader, 64);
             if (is) cslot[j] = wbase + uint32_t(__popcll(m & ((1ull << lane) - 1ull)));
-            unsigned long long rest = m;
-#if defined(RGR_DIAG_NO_PAIR_COUNTS) || !defined(RGR_DEDUP_EXACT_COUNTS)
-            rest = 0;             // (per-pair candidate counts are only needed by the exact-count variant, see below)
-#endif
-            while (rest) {                                           // usually one or two pairs per wave
-                const int l0 = __ffsll(static_cast<long long>(rest)) - 1;
-                const uint32_t p0 = __shfl(pidx[j], l0, 64);
-                const unsigned long long same = __ballot(is && pidx[j] == p0);
-                if (lane == l0) atomicAdd(&s_pc[p0], uint32_t(__popcll(same)));
-                rest &= ~same;
-            }
         }
         __syncthreads();
-#ifdef RGR_DEDUP_EXACT_COUNTS
-        if (s_ncand) {   // per-topic candidate counts: the tile's pairs of one topic are adjacent, their first pair's lane sums them
-            for (uint32_t i = threadIdx.x; i < np; i += kThreads) {
-                const uint32_t tp = s_topic[i];
-                if (i != 0 && s_topic[i - 1] == tp) continue;
-                uint32_t sum = 0, k = i;
-                for (; k < np && s_topic[k] == tp; ++k) sum += s_pc[k];
-                if (sum) atomicAdd(&da.topic_cand[tp - da.topic_lo], sum);
-                // Does this topic lie ENTIRELY inside the tile with at least two candidates?  Only then can the tile-local dedup
-                // find a duplicate here (topics that span tiles are the topic pass's): the tile pass skips every other tile.
-                if (sum >= 2) {
-                    bool inside = true;
-                    if (i == 0) inside = c.pair_off[a] == base && (a == pair_lo || c.pair_topic[a - 1] != tp);
-                    if (inside && k == np) inside = c.pair_off[b] <= base + kTile && (b == pair_hi || c.pair_topic[b] != tp);
-                    if (inside) s_inside = 1;
-                }
-            }
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) da.tile_ncand[tile] = s_ncand | (s_inside << 31);
-#else
         // The topic pass sizes its tables from an UPPER BOUND of a topic's candidates (the candidate counts of the tiles it spans,
         // dedup_classify_kernel), so no per-topic count is kept here (r3h: the per-pair counts + per-topic atomics were 0.10 ms of a
         // window).  Bit 31 of the tile's count = "a whole topic may lie inside this tile": the tile holds pairs of more than one topic,
@@ -807,7 +773,6 @@ __global__ __launch_bounds__(kThreads) void expand_kernel(const SubEntry* __rest
             }
             da.tile_ncand[tile] = s_ncand | (flag << 31);
         }
-#endif
         // the tile's candidates go to the tile's own slice of the list: no global cursor
         Cand* mine = da.cand + uint64_t(tile) * kTile;
 #pragma unroll
@@ -1002,7 +967,7 @@ __global__ __launch_bounds__(256) void dedup_tile_kernel(const Cand* __restrict_
 }
 
 // One work item per part of every topic that spans tiles and has at least two candidates.
-__global__ __launch_bounds__(256) void dedup_classify_kernel(const uint32_t* __restrict__ topic_cand, const uint32_t* __restrict__ tile_ncand, uint32_t nt,
+__global__ __launch_bounds__(256) void dedup_classify_kernel(const uint32_t* __restrict__ tile_ncand, uint32_t nt,
                                                              const uint64_t* __restrict__ hit_off, uint64_t hit_lo, DedupItem* __restrict__ items,
                                                              uint32_t* __restrict__ item_count) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
@@ -1011,16 +976,11 @@ __global__ __launch_bounds__(256) void dedup_classify_kernel(const uint32_t* __r
     if (h1 - h0 < 2) return;
     const uint32_t tile0 = uint32_t(h0 / kTile), tile1 = uint32_t((h1 - 1) / kTile);
     if (tile0 == tile1) return;                                 // inside one tile: dedup_tile_kernel
-#ifdef RGR_DEDUP_EXACT_COUNTS
-    (void)tile_ncand;
-    const uint32_t nc = topic_cand[t];
-#else
-    // upper bound of the topic's candidates: what its tiles hold (the first and the last tile are shared with neighbours), at most its hits
-    (void)topic_cand;
+    // upper bound of the topic's candidates: what its tiles hold (the first and the last tile are shared with neighbours), at most its hits.
+    // (r3j: exact per-topic counts needed per-pair counting and per-topic atomics in the expansion — 1.03 vs 0.95 ms per window.)
     uint64_t sum = 0;
     for (uint32_t tile = tile0; tile <= tile1; ++tile) sum += tile_ncand[tile] & 0x7FFFFFFFu;
     const uint32_t nc = uint32_t(sum < h1 - h0 ? sum : h1 - h0);
-#endif
     if (nc < 2) return;
     const uint32_t parts = (nc + kDedupTopicCap - 1) / kDedupTopicCap;
     const uint32_t at = atomicAdd(item_count, parts);
@@ -1326,13 +1286,13 @@ void launch_node_groups(const Tuple* tuples, const uint64_t* hit_off, uint64_t h
 
 uint32_t dedup_topic_cap() { return kDedupTopicCap; }
 
-void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, uint32_t ntiles, Tuple* tuples, const uint32_t* topic_cand, uint32_t nt,
+void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, uint32_t ntiles, Tuple* tuples, uint32_t nt,
                   const uint64_t* hit_off, uint64_t hit_lo, DedupItem* items, uint32_t* item_count, unsigned long long* stat, void* stream) {
     if (!ntiles) return;
     hipStream_t s = static_cast<hipStream_t>(stream);
     (void)hipMemsetAsync(item_count, 0, 4, s);
     dedup_tile_kernel<<<std::min<uint32_t>(ntiles, 2048u), 256, 0, s>>>(cand, tile_ncand, ntiles, hit_off, hit_lo, tuples, stat);
-    dedup_classify_kernel<<<(nt + 255) / 256, 256, 0, s>>>(topic_cand, tile_ncand, nt, hit_off, hit_lo, items, item_count);
+    dedup_classify_kernel<<<(nt + 255) / 256, 256, 0, s>>>(tile_ncand, nt, hit_off, hit_lo, items, item_count);
     // the item count stays on the device: a fixed grid of persistent blocks (4 per CU fit) strides over the items
     // RGR_DEDUP_TEST_SLOTS (tests only): a smaller table, so that parts overflow and the re-split path runs on ordinary inputs
     static const uint32_t max_slots = [] {

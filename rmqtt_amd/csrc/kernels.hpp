@@ -63,7 +63,6 @@ struct DeliverArgs {
     const SubAttr* attrs;        // parallel to TrieView::subs, may be null (no ids registered)
     Cand* cand;                  // dedup candidates of this window: tile i owns cand[i*tile_hits ..], null = none wanted
     uint32_t* tile_ncand;        // [tiles] candidates each tile wrote
-    uint32_t* topic_cand;        // [topics in window] candidates per topic (zeroed by the caller)
     uint32_t topic_lo;           // first topic of the window (batch-global index)
 };
 
@@ -240,11 +239,11 @@ void launch_expand_compact(const TrieView& t, const ChunkArrays& c, uint64_t pai
                            const TileRec* tile_first, int format, uint32_t* out_ids, uint8_t* out_qos, void* stream);
 // v5 per-client dedup over a window's candidates (match_core.hpp: LDS tile tables + LDS topic tables): first position per
 // (topic, client) wins, every other candidate gets kHitV5Dup.  hit_off points at the window's first topic (chunk-local
-// offsets, hit_lo = the window's first position); topic_cand[nt] = candidates per window topic (DeliverArgs); items must hold
+// offsets, hit_lo = the window's first position); nt = topics of the window; items must hold
 // nt + n_hits / dedup_topic_cap() + 1 entries; *stat accumulates the candidate count.  Everything is stream-ordered: no host sync.
 // work item of the topic pass: part `part` of `parts` of window topic `topic` (nc candidates in total)
 struct DedupItem { uint32_t topic, part, parts, nc; };
-void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, uint32_t ntiles, Tuple* tuples, const uint32_t* topic_cand, uint32_t nt,
+void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, uint32_t ntiles, Tuple* tuples, uint32_t nt,
                   const uint64_t* hit_off, uint64_t hit_lo, DedupItem* items, uint32_t* item_count, unsigned long long* stat, void* stream);
 uint32_t dedup_topic_cap();
 // Delivery results grouped by node (SubRelationsMap's shape, types.rs:486-497): stable partition of every topic's tuples by

@@ -3,7 +3,7 @@
 set -u
 O=gpurun_out/r3h
 mkdir -p $O
-for v in BASE NO_ATTRS NO_PAIR_COUNTS NO_CAND_STORE; do
+for v in BASE NO_ATTRS NO_CAND_STORE; do
   if [ $v = BASE ]; then export RGR_EXTRA_FLAGS=""; else export RGR_EXTRA_FLAGS="-DRGR_DIAG_$v"; fi
   python -c "from rmqtt_amd import build as b; b.build_gpu(force=True)" > $O/build_$v.log 2>&1
   ( timeout 300 python bench.py --config 3 --steps 2 --warmup 1 --no-pmc --no-secondary --no-d2h --deliver 0.1 > $O/deliver_$v.json 2> $O/deliver_$v.err )
