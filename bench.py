@@ -128,6 +128,7 @@ def build_table(r, W, blob, offs, sub_ids, qos, deliver_frac=-1.0):
             is5 = drng.random(n) < deliver_frac
             flags = (is5 * capi.RGR_SUB_V5 | (is5 & (drng.random(n) < 0.3)) * capi.RGR_SUB_NO_LOCAL |
                      (is5 & (drng.random(n) < 0.5)) * capi.RGR_SUB_RAP).astype(np.uint8)
+            W["deliver_flags"] = flags
         rej = r.subscribe_bulk(blob, offs, sub_ids, qos, flags)
         if deliver_frac >= 0:
             r.sub_attrs_bulk(W["client"].astype(np.uint32), W["client"].astype(np.uint32))     # one Id per client
@@ -235,6 +236,67 @@ def gpu_digests(batch, n_topics, retain, fmt=0, subs_len=0):
     return out, bool(structure_ok), info
 
 
+def delivery_parity(batch, W, pa, n_windows_wanted=3):
+    """Full-size check of the delivery stage, in the bench line: the delivery words of whole windows of the
+    timed pass — first, middle, last — against a restatement of the per-hit rules in torch on the device, independent of the
+    library's kernels: qos' = min(publish, subscription), Retain-As-Published, No Local (owner == publisher), and the v5
+    collector's first hit per (topic, client) in position order (types.rs:524-539) as a sort-free min-position reduction.
+    (The oracle's forwards() pins the same rules at small sizes: tests/test_deliver_parity.py.)"""
+    import torch
+    from rmqtt_amd import capi
+    qos = torch.from_numpy(np.ascontiguousarray(W["qos"]).astype(np.int64)).cuda()
+    flags = torch.from_numpy(W["deliver_flags"].astype(np.int64)).cuda()
+    client = torch.from_numpy(np.ascontiguousarray(W["client"]).astype(np.int64)).cuda()            # owner id == client index in this bench
+    p_from = torch.from_numpy(pa["from_id"].astype(np.int64)).cuda()
+    p_qr = torch.from_numpy(pa["qos_retain"].astype(np.int64)).cuda()
+    # which windows: count them first (cheap: the run-descriptor format expands nothing)
+    batch.set_publish_attrs(None)
+    batch.set_format(capi.RGR_FORMAT_RUNS)
+    _, nwin = batch.run()
+    batch.set_format(capi.RGR_FORMAT_TUPLE)
+    batch.set_publish_attrs(pa)
+    want = sorted({0, nwin // 2, nwin - 1})[:n_windows_wanted]
+    checked, bad, hits, dups, drops = [], 0, 0, 0, 0
+    batch.begin()
+    wi = -1
+    while True:
+        w = batch.next_window()
+        if w is None:
+            break
+        wi += 1
+        if wi not in want or not w.n_hits:
+            continue
+        torch.cuda.synchronize()
+        nh = int(w.n_hits)
+        t = torch.as_tensor(_DevArr(w.d_tuples, (nh, 3), "<i4"), device="cuda")
+        topic = t[:, 0].to(torch.int64) & 0xFFFFFFFF
+        sid = t[:, 1].to(torch.int64) & 0xFFFFFFFF
+        got = t[:, 2].to(torch.int64) & 0xFFFFFFFF
+        fl = flags[sid]
+        pq = p_qr[topic]
+        is5 = (fl & capi.RGR_SUB_V5) != 0
+        exp = (fl << 8) | torch.minimum(qos[sid], pq & 3)
+        exp = exp | torch.where(is5 & ((fl & capi.RGR_SUB_RAP) != 0) & ((pq & 4) != 0), capi.RGR_HIT_RETAIN, 0)
+        drop = is5 & ((fl & capi.RGR_SUB_NO_LOCAL) != 0) & (client[sid] == p_from[topic])
+        exp = exp | torch.where(drop, capi.RGR_HIT_NO_LOCAL, 0)
+        cand = torch.nonzero(is5 & ~drop).squeeze(1)
+        key = (topic[cand] - int(w.topic_begin)) * (int(client.max()) + 1) + client[sid[cand]]
+        uk, inv = torch.unique(key, return_inverse=True)
+        first = torch.full((uk.numel(),), nh, dtype=torch.int64, device="cuda").scatter_reduce(0, inv, cand, reduce="amin")
+        dup = first[inv] != cand
+        di = cand[dup]
+        exp.index_put_((di,), exp[di] | capi.RGR_HIT_V5_DUP)
+        node_free = got & 0xFFFF                                  # (bits 16-31 carry the node index: 0 for bulk-loaded tables)
+        bad += int((node_free != (exp & 0xFFFF)).sum()) + int(((got >> 16) != 0).sum())
+        hits += nh; dups += int(dup.sum()); drops += int(drop.sum())
+        checked.append(wi)
+        del t, topic, sid, got, fl, pq, is5, exp, drop, cand, key, uk, inv, first, dup, di
+        torch.cuda.synchronize()
+    return {"ok": bad == 0 and len(checked) > 0, "windows_checked": checked, "of_windows": int(nwin), "hits": int(hits), "v5_duplicates_flagged": int(dups),
+            "no_local_drops": int(drops), "mismatching_words": int(bad),
+            "what": "delivery words of whole windows of the timed batch (first / middle / last) vs a torch restatement of the per-hit rules on the device"}
+
+
 def parity_sample(r, o, W, batch, budget_hits, threads, primary, seed=20260921):
     """Full-size parity, in the bench line itself.
       1. ONE full pass of the timed batch per result format (tuple, soa, packed, runs); every window of every pass is
@@ -275,21 +337,30 @@ def parity_sample(r, o, W, batch, budget_hits, threads, primary, seed=20260921):
     hits_pt = D[:, 0]
     total_hits = int(hits_pt.sum())
     mean = max(1.0, total_hits / max(1, n))
-    # ---- strata
+    # ---- strata, each within its share of the oracle's budget (hits): the oracle's cost is its hits, and on the retained path it is
+    # ~10^3 x slower per query than the router's (r3i: an uncapped last-window stratum of 10 754 filters cost the bench 14 minutes)
     rng = np.random.default_rng(seed)
+    hits_cpu = hits_pt.cpu().numpy().astype(np.int64)
+
+    def within(idx, share):
+        """longest prefix of idx whose hits fit share * budget (at least one query)"""
+        idx = np.asarray(idx, dtype=np.int64)
+        if not len(idx):
+            return idx
+        c = np.cumsum(hits_cpu[idx])
+        return idx[:max(1, int(np.searchsorted(c, share * budget_hits, side="right")))]
     K = 1024 if primary else 256
     strata = {}
-    strata["heaviest_by_hits"] = torch.topk(hits_pt, min(K, n)).indices.cpu().numpy()
+    strata["heaviest_by_hits"] = within(torch.topk(hits_pt, min(K, n)).indices.cpu().numpy(), 0.10)
     if runs_pt is not None:
-        strata["most_matched_filters"] = torch.topk(runs_pt, min(K, n)).indices.cpu().numpy()
-    lw = np.arange(last_window[0], last_window[1])
-    strata["last_window"] = lw if len(lw) <= 30000 else lw[-30000:]
+        strata["most_matched_filters"] = within(torch.topk(runs_pt, min(K, n)).indices.cpu().numpy(), 0.10)
+    strata["last_window"] = within(np.arange(last_window[1] - 1, last_window[0] - 1, -1), 0.25)[::-1]      # the END of the pass's last window
     chunk = 1 << 21
-    strata["chunk_boundaries"] = np.concatenate([np.arange(max(0, c - 32), min(n, c + 32)) for c in range(chunk, n, chunk)] or [np.zeros(0, dtype=np.int64)]).astype(np.int64)
-    strata["prefix"] = np.arange(min(n, 2000 if primary else 500))
+    strata["chunk_boundaries"] = within(np.concatenate([np.arange(max(0, c - 32), min(n, c + 32)) for c in range(chunk, n, chunk)] or [np.zeros(0, dtype=np.int64)]), 0.05)
+    strata["prefix"] = within(np.arange(min(n, 2000 if primary else 500)), 0.05)
     fixed = np.unique(np.concatenate([v.astype(np.int64) for v in strata.values()]))
-    fixed_hits = int(hits_pt[torch.from_numpy(fixed).cuda()].sum()) if len(fixed) else 0
-    n_rand = int(min(n, max(256, (budget_hits - fixed_hits) / mean)))
+    fixed_hits = int(hits_cpu[fixed].sum()) if len(fixed) else 0
+    n_rand = int(min(n, max(64, (budget_hits - fixed_hits) / mean)))
     strata["random"] = np.sort(rng.choice(n, size=n_rand, replace=False)) if n_rand < n else np.arange(n)
     sel = np.unique(np.concatenate([fixed, strata["random"].astype(np.int64)]))
     # ---- oracle digests of the selected topics against the full table
@@ -646,6 +717,9 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
         rec["delivery_stage"] = {"v5_fraction": deliver, "dedup_ms_per_step": round(st["dedup_ms"] / K, 3),
                                  "dedup_candidates_per_step": int(st["dedup_candidates"] / K),
                                  "dedup_launches_per_step": int(st["dedup_launches"] / K)}
+        if not args.no_parity:
+            rec["parity_sample"] = delivery_parity(batch, W, pa)
+            log(f"config {cfg}: delivery parity {rec['parity_sample']}", 0)
 
     hits_per_topic = max(1.0, total_hits / max(1, total_topics))
     # ---- opt-in compact result formats (SURVEY 8(b)'s SoA result; rgr_batch_set_format), reported BESIDE the 12-byte
@@ -728,7 +802,7 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
             cpu["without_refcounting"] = plain
         rec["cpu_baseline"] = cpu
         if not args.no_parity:
-            rec["parity_sample"] = parity_sample(r, o, W, batch, 1.2e9 if primary else 4.0e8, cores, primary)
+            rec["parity_sample"] = parity_sample(r, o, W, batch, budget_hits, cores, primary)       # the oracle's budget of the CPU-baseline leg
             log(f"config {cfg}: parity_sample {rec['parity_sample']}", 0)
         del o
     else:
