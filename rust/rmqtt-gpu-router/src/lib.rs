@@ -2,11 +2,14 @@
 //! `extends.retain` at start(), the same way rmqtt-cluster-broadcast/src/lib.rs:141-142,
 //! rmqtt-cluster-raft/src/lib.rs:384 and rmqtt-retainer/src/lib.rs:191 install theirs.
 //!
-//! Configuration (environment; a plugin config file would carry the same keys):
-//!   RMQTT_GPU_DEVICES        comma-separated HIP device ordinals, one table shard per device (default "0")
-//!   RMQTT_GPU_MAX_BATCH      publishes per device pass at most (default 4096)
-//!   RMQTT_GPU_MAX_DELAY_US   micro-batcher deadline (default 150)
-//!   RMQTT_GPU_RETAIN         "1": also serve retained-message wildcard queries from the GPU (default off)
+//! Configuration: the plugin's own config file, read the way every rmqtt plugin reads its own
+//! (`scx.plugins.read_config_default::<PluginConfig>(&name)`, rmqtt/src/plugin.rs:692, as rmqtt-retainer/src/lib.rs:64 does) —
+//! `rmqtt-plugins/rmqtt-gpu-router.toml`:
+//!   devices = [0]           HIP device ordinals, one table shard per device
+//!   max_batch = 4096        publishes per device pass at most
+//!   max_delay_us = 150      micro-batcher deadline
+//!   retain = false          also serve retained-message wildcard queries from the GPU
+//! Environment variables of the same names in upper case with the `RMQTT_GPU_` prefix override the file (round 2 read only those).
 //! Source only — see Cargo.toml.
 mod batcher;
 mod ffi;
@@ -36,20 +39,35 @@ fn env_or<T: std::str::FromStr>(key: &str, default: T) -> T {
     std::env::var(key).ok().and_then(|s| s.parse().ok()).unwrap_or(default)
 }
 
+/// `rmqtt-plugins/rmqtt-gpu-router.toml` (every key optional)
+#[derive(Debug, Clone, serde::Deserialize)]
+#[serde(default)]
+struct PluginConfig {
+    devices: Vec<i32>,
+    max_batch: usize,
+    max_delay_us: u64,
+    retain: bool,
+}
+impl Default for PluginConfig {
+    fn default() -> Self {
+        Self { devices: vec![0], max_batch: 4096, max_delay_us: 150, retain: false }
+    }
+}
+
 impl GpuRouterPlugin {
-    async fn new<S: Into<String>>(scx: ServerContext, _name: S) -> Result<Self> {
-        let devices: Vec<i32> = std::env::var("RMQTT_GPU_DEVICES")
-            .unwrap_or_else(|_| "0".into())
-            .split(',')
-            .filter_map(|s| s.trim().parse().ok())
-            .collect();
-        let router = GpuRouter::new(
-            scx.clone(),
-            &devices,
-            env_or("RMQTT_GPU_MAX_BATCH", 4096usize),
-            Duration::from_micros(env_or("RMQTT_GPU_MAX_DELAY_US", 150u64)),
-        )?;
-        let retain = if env_or("RMQTT_GPU_RETAIN", 0u8) == 1 { Some(std::sync::Arc::new(GpuRetainStorage::new(devices[0])?)) } else { None };
+    async fn new<S: Into<String>>(scx: ServerContext, name: S) -> Result<Self> {
+        let name = name.into();
+        let mut cfg = scx.plugins.read_config_default::<PluginConfig>(&name)?;
+        if let Ok(d) = std::env::var("RMQTT_GPU_DEVICES") {
+            cfg.devices = d.split(',').filter_map(|s| s.trim().parse().ok()).collect();
+        }
+        if cfg.devices.is_empty() { cfg.devices = vec![0]; }
+        cfg.max_batch = env_or("RMQTT_GPU_MAX_BATCH", cfg.max_batch);
+        cfg.max_delay_us = env_or("RMQTT_GPU_MAX_DELAY_US", cfg.max_delay_us);
+        cfg.retain = env_or("RMQTT_GPU_RETAIN", cfg.retain as u8) == 1;
+        log::info!("{name} config: {cfg:?}");
+        let router = GpuRouter::new(scx.clone(), &cfg.devices, cfg.max_batch, Duration::from_micros(cfg.max_delay_us))?;
+        let retain = if cfg.retain { Some(std::sync::Arc::new(GpuRetainStorage::new(cfg.devices[0])?)) } else { None };
         Ok(Self { scx, router, retain })
     }
 }
