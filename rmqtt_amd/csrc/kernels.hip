@@ -925,7 +925,10 @@ static_assert(kTile <= (1 << kDedupIdxBits), "tile table packs position-in-tile 
 constexpr int kDedupTileSlots = 2 * kTile;            // u32 slots: 16 KiB
 constexpr int kDedupTopicSlots = 4096;                // u64 slots: 32 KiB -> 4 blocks of 512 threads per CU
 constexpr int kDedupTopicCap = kDedupTopicSlots / 2;  // candidates per part
-constexpr int kDedupTopicThreads = 512;
+#ifndef RGR_DEDUP_TOPIC_THREADS
+#define RGR_DEDUP_TOPIC_THREADS 512
+#endif
+constexpr int kDedupTopicThreads = RGR_DEDUP_TOPIC_THREADS;
 
 __global__ __launch_bounds__(256) void dedup_tile_kernel(const Cand* __restrict__ cand, const uint32_t* __restrict__ tile_ncand, uint32_t ntiles,
                                                          const uint64_t* __restrict__ hit_off, uint64_t hit_lo, Tuple* __restrict__ tuples,
@@ -1301,7 +1304,7 @@ void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, uint32_t ntiles,
         while (p2 < v && p2 < uint32_t(kDedupTopicSlots)) p2 <<= 1;
         return v ? p2 : uint32_t(kDedupTopicSlots);
     }();
-    dedup_topic_kernel<<<1024, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, hit_off, hit_lo, items, item_count, tuples, max_slots);
+    dedup_topic_kernel<<<kDedupTopicThreads >= 512 ? 1024 : 1280, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, hit_off, hit_lo, items, item_count, tuples, max_slots);
 }
 
 }  // namespace rgr

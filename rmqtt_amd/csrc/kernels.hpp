@@ -4,7 +4,7 @@
 //   edges[cap]   open-addressed CSR edge table, 32-byte records keyed by (parent node,
 //                level token); a record carries the child's id *and* the child's header
 //                (its '+' edge slot, the filter id of "child/#", the filter id ending at
-//                child, count + XOR of its literal out-edges = the probe miss filter), so one
+//                child, a 64-bit bitmap over its literal out-edges = the probe miss filter), so one
 //                32 B read per visited trie node serves both the edge lookup and the header.
 //   filt[nf]     per filter: [begin,count) of its subscriber run in subs[]
 //   subs[ns]     packed (sub_id, qos|flags<<8), grouped per filter, ascending sub_id
