@@ -9,7 +9,8 @@ form is already resident in HBM.  Workload at N=1: BASELINE.json configs[2] — 
 subscriptions with mixed '+'/'#' (seeded generator of SURVEY.md §8(d)), 10 M publishes,
 1x MI355X.  N>1: the same table hash-sharded by the first three topic levels, publishes
 routed to their owner rank (strong scaling: total work fixed); ranks exchange per-rank
-hit counts (all-gather over RCCL), tuples stay on the owning GPU unless --gather tuples.
+hit counts (all-gather over RCCL), tuples stay on the owning GPU unless --gather tuples; --gather runs adds
+the all-gatherv of 16-byte run descriptors (every rank then knows every rank's hits: DESIGN §7).
 
 One JSON line on rank 0:
   value         whole-job publish-topic matches/s, tuples left in HBM
@@ -565,6 +566,7 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
         return hits, nwin
 
     rank_hits = []          # per-rank hit counts of the last step (N>1, --gather counts): the shard imbalance
+    runs_replicated = False
 
     # N>1: the exchange step runs inside the library over RCCL (rgr_comm_*: ncclAllGather of the counts,
     # all-gatherv of the tuples as a send/recv group) — torch.distributed only ships the 128-byte communicator
@@ -620,6 +622,15 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
         if world > 1 and args.gather != "none":
             if comm is not None:
                 rank_hits[:] = [int(x) for x in comm.allgather_u64(hits)]
+                if args.gather == "runs":
+                    # BASELINE configs[3]'s "RCCL all-gatherv of subscriber hits" in the form that can run at this fan-out: the tuples stay
+                    # on the owning GPU (the pass above), and every rank additionally receives every rank's 16-byte run descriptors
+                    # (hits = the replicated subs[] of the owning rank, read in place): a second, expansion-free pass + the exchange
+                    nonlocal runs_replicated
+                    if not runs_replicated:
+                        comm.replicate_subs()
+                        runs_replicated = True
+                    comm.gather_runs_pass(batch)
             else:
                 cnt = torch.tensor([hits], dtype=torch.int64, device=cdev)
                 allc = [torch.zeros_like(cnt) for _ in range(world)]
