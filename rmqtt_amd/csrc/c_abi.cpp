@@ -154,12 +154,6 @@ struct ChunkSlot {
     bool ready = false;          // walked, counted, scanned, compacted
     bool inflight = false;       // prepared asynchronously on prep_stream: `done` tells when
     hipEvent_t done = nullptr;
-    // tile records of every window of the chunk, written by ONE launch when the chunk is entered (plan_tiles)
-    DevBuf tiles_all, d_plan;
-    PinnedBuf h_plan;
-    std::vector<WindowPlan> plan;
-    uint32_t win_idx = 0;        // windows of this chunk handed out so far
-    bool plan_ok = false;
     ~ChunkSlot() { if (done) (void)hipEventDestroy(done); }
 };
 
@@ -663,46 +657,6 @@ void prefetch_chunk(rgr_batch* b, uint32_t begin) {
     nx.inflight = true;
 }
 
-// Window plan of the current chunk (the same rule rgr_batch_next_window applies window by window) and the tile records of all its
-// windows in one launch.  next_window uses a window's slice when the plan agrees with what it computes, and falls back to the
-// per-window tiles_kernel otherwise.
-void plan_tiles(rgr_batch* b) {
-    ChunkSlot& cs = *b->c;
-    cs.plan.clear(); cs.win_idx = 0; cs.plan_ok = false;
-    if (b->format == kFmtRuns || cs.total_hits == 0 || std::getenv("RGR_TILES_PER_WINDOW")) return;
-    const uint32_t n = cs.n, T = expand_tile_hits();
-    const uint64_t cap = b->h->cfg.window_hits;
-    uint64_t tile_base = 0;
-    if (!cs.host_arrays) {
-        cs.plan.push_back(WindowPlan{0, 0, 0});
-        tile_base = (cs.total_hits + T - 1) / T;
-    } else {
-        const uint64_t* ho = cs.h_hit_off.as<uint64_t>();
-        const uint64_t* pb = cs.h_pair_base.as<uint64_t>();
-        for (uint32_t lc = 0; lc < n;) {
-            uint32_t le;
-            if (ho[n] - ho[lc] <= cap) le = n;
-            else {
-                le = uint32_t(std::upper_bound(ho + lc, ho + n + 1, ho[lc] + cap) - ho) - 1;
-                if (le <= lc) le = lc + 1;
-            }
-            cs.plan.push_back(WindowPlan{pb[lc], ho[lc], tile_base});
-            tile_base += (ho[le] - ho[lc] + T - 1) / T;
-            lc = le;
-        }
-    }
-    if (cs.plan.size() > (1u << 20)) { cs.plan.clear(); return; }      // (a chunk of a million windows: per-window launches are not the problem then)
-    cs.tiles_all.ensure(std::max<uint64_t>(1, tile_base) * sizeof(TileRec));
-    cs.d_plan.ensure(cs.plan.size() * sizeof(WindowPlan));
-    cs.h_plan.ensure(cs.plan.size() * sizeof(WindowPlan));
-    std::memcpy(cs.h_plan.p, cs.plan.data(), cs.plan.size() * sizeof(WindowPlan));
-    RGR_HIP(hipMemcpyAsync(cs.d_plan.p, cs.h_plan.p, cs.plan.size() * sizeof(WindowPlan), hipMemcpyHostToDevice, b->stream));
-    size_t sp = b->span_begin(kSpanScan);
-    launch_tiles_chunk(make_chunk_arrays(b, n), cs.total_pairs, cs.d_plan.as<WindowPlan>(), uint32_t(cs.plan.size()), cs.tiles_all.as<TileRec>(), b->stream);
-    b->span_end(sp);
-    cs.plan_ok = true;
-}
-
 // Make the chunk starting at `begin` the current one: adopt the prefetched slot when there is one, else prepare it now.
 void enter_chunk(rgr_batch* b, uint32_t begin) {
     ChunkSlot* o = b->other_slot();
@@ -728,7 +682,6 @@ void enter_chunk(rgr_batch* b, uint32_t begin) {
         b->c->ready = false;
         prepare_chunk(b, begin, false);
     }
-    plan_tiles(b);
     prefetch_chunk(b, b->c->begin + b->c->n);
 }
 
@@ -1344,19 +1297,11 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
             DevBuf& outbuf = b->alt_out ? b->out2 : b->out;
             const uint64_t ids_bytes = (nh * 4 + 255) & ~uint64_t(255);           // compact formats: sub ids, then the qos bytes
             outbuf.ensure(b->format == kFmtTuple ? nh * sizeof(Tuple) : ids_bytes + (b->format == kFmtSoa ? nh + 16 : 0));
+            b->tile_first.ensure(((nh + T - 1) / T) * sizeof(TileRec));
             ChunkArrays ca = make_chunk_arrays(b, n);
-            size_t sp;
-            const TileRec* tile_recs;
-            const uint32_t wi = b->c->win_idx;
-            if (b->c->plan_ok && wi < b->c->plan.size() && b->c->plan[wi].pair_lo == pair_lo && b->c->plan[wi].hit_lo == hit_lo) {
-                tile_recs = b->c->tiles_all.as<TileRec>() + b->c->plan[wi].tile_base;       // written when the chunk was entered
-            } else {
-                b->tile_first.ensure(((nh + T - 1) / T) * sizeof(TileRec));
-                sp = b->span_begin(kSpanScan);
-                launch_tiles(ca, pair_lo, pair_hi, hit_lo, b->tile_first.as<TileRec>(), b->stream);
-                b->span_end(sp);
-                tile_recs = b->tile_first.as<TileRec>();
-            }
+            size_t sp = b->span_begin(kSpanScan);
+            launch_tiles(ca, pair_lo, pair_hi, hit_lo, b->tile_first.as<TileRec>(), b->stream);
+            b->span_end(sp);
             // delivery stage: fused into the expansion; v5 hits additionally go through the per-client dedup
             DeliverArgs da{};
             const bool dedup = b->deliver && !b->retain && b->epoch->n_v5 > 0 && b->epoch->view.attrs != nullptr;
@@ -1380,10 +1325,10 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
             }
             sp = b->span_begin(kSpanExpand);
             if (b->format == kFmtTuple)
-                launch_expand(batch_view(b), ca, pair_lo, pair_hi, hit_lo, hit_hi, tile_recs, outbuf.as<Tuple>(), b->stream,
+                launch_expand(batch_view(b), ca, pair_lo, pair_hi, hit_lo, hit_hi, b->tile_first.as<TileRec>(), outbuf.as<Tuple>(), b->stream,
                               (b->deliver && !b->retain) ? &da : nullptr);
             else
-                launch_expand_compact(batch_view(b), ca, pair_lo, pair_hi, hit_lo, hit_hi, tile_recs, b->format,
+                launch_expand_compact(batch_view(b), ca, pair_lo, pair_hi, hit_lo, hit_hi, b->tile_first.as<TileRec>(), b->format,
                                       outbuf.as<uint32_t>(), outbuf.as<uint8_t>() + ids_bytes, b->stream);
             b->span_end(sp);
             // the chunk's accounting charged 20 B per hit (8 read + 12 written); the compact formats write 5 / 4
@@ -1451,7 +1396,6 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
         w->d_hit_offsets = b->c->hit_off.as<uint64_t>() + lc;
         w->offsets_bias = hit_lo;
         b->hits_before += nh;
-        b->c->win_idx++;
         b->cursor = b->c->begin + le;
         return RGR_OK;
     });

@@ -631,19 +631,6 @@ __global__ __launch_bounds__(256) void tiles_kernel(ChunkArrays c, uint64_t pair
     tiles_pair_rec(c, p, pair_lo, hit_lo, kTile, tile_first);
 }
 
-// The tile records of ALL windows of a chunk in one launch (r3: one tiles_kernel launch per window was 553 five-microsecond launches
-// and as many gaps per pass — 2 % of the tuple headline, 4 % of the packed format's pass): the window plan is known once the chunk's
-// totals are on the host; a pair finds its window by binary search over the (short) plan and writes into that window's slice.
-__global__ __launch_bounds__(256) void tiles_chunk_kernel(ChunkArrays c, uint64_t n_pairs, const WindowPlan* __restrict__ plan, uint32_t n_windows,
-                                                          TileRec* __restrict__ all) {
-    const uint64_t p = uint64_t(blockIdx.x) * 256 + threadIdx.x;
-    if (p >= n_pairs) return;
-    uint32_t lo = 0, hi = n_windows;                       // last window whose pair_lo <= p (empty windows share a pair_lo with their successor)
-    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (plan[mid].pair_lo <= p) lo = mid; else hi = mid; }
-    const WindowPlan w = plan[lo];
-    tiles_pair_rec(c, p, w.pair_lo, w.hit_lo, kTile, all + w.tile_base);
-}
-
 // --------------------------------------------------------------------------- run descriptors for the exchange step
 // One 16-byte descriptor per (topic, subscriber-run) pair of a window: what crosses xGMI in the run gather instead of the
 // 12-byte tuples themselves (at config-3 fan-out ~20 runs = 320 B per publish instead of 178 KB of tuples).
@@ -1261,11 +1248,6 @@ void launch_tiles(const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint
     if (pair_hi <= pair_lo) return;
     const uint64_t np = pair_hi - pair_lo;
     tiles_kernel<<<uint32_t((np + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(c, pair_lo, pair_hi, hit_lo, tile_first);
-}
-
-void launch_tiles_chunk(const ChunkArrays& c, uint64_t n_pairs, const WindowPlan* plan, uint32_t n_windows, TileRec* all, void* stream) {
-    if (!n_pairs || !n_windows) return;
-    tiles_chunk_kernel<<<uint32_t((n_pairs + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(c, n_pairs, plan, n_windows, all);
 }
 
 void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint64_t hit_hi,

@@ -231,10 +231,6 @@ void launch_compact(const TrieView& t, const ChunkArrays& c, uint32_t topic_base
 // high fan-out, starts its subscriber loads after a single 16-byte read instead of tile_first -> pair arrays -> LDS.
 struct alignas(16) TileRec { uint32_t first, src, topic, qr; };
 void launch_tiles(const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, TileRec* tile_first, void* stream);
-// the same for every window of a chunk at once: window w covers pairs [pair_lo, next window's pair_lo), its first hit is hit_lo, its
-// records go to all + tile_base
-struct WindowPlan { uint64_t pair_lo, hit_lo, tile_base; };
-void launch_tiles_chunk(const ChunkArrays& c, uint64_t n_pairs, const WindowPlan* plan, uint32_t n_windows, TileRec* all, void* stream);
 void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint64_t hit_hi,
                    const TileRec* tile_first, Tuple* out, void* stream, const DeliverArgs* deliver = nullptr);
 // compact result formats (rgr_batch_set_format): sub ids (+ a qos byte array) without the topic column
