@@ -26,6 +26,12 @@ def test_shard_rule_properties():
         # two-level keys (the SURVEY variant) still work
         f2 = shard.assign(*pack(filters), world, True, key_levels=2)
         assert list(f2 < 0) == [False, False, False, True, True, True, True, False, False, False, False, False, True, False, False]
+        # one level = SURVEY 8(e) / north_star's first-level rule (rgr_group_set_key_levels(1)): only a wildcard FIRST level replicates,
+        # and a filter lives with every topic that shares its first level
+        f1 = shard.assign(*pack(filters), world, True, key_levels=1)
+        t1 = shard.assign(*pack(topics), world, False, key_levels=1)
+        assert list(f1 < 0) == [False, False, False, False, False, True, True, False, False, False, False, False, True, False, False]
+        assert len({int(x) for x in f1[[0, 1, 2, 3, 4, 7, 11, 13, 14]]} | {int(x) for x in t1[[0, 1, 2, 6, 7, 8]]}) == 1      # everything under "a"
 
 
 def test_two_rank_gloo_sharded_match():
