@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py — publish-topic matches/sec of the MI355X topic matcher (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, or by itself: without
+                                                          WORLD_SIZE in the environment it spawns its own N ranks)
 
 A "step" is one pass of the hot path (trie walk + subscriber expansion into
 (topic_idx, sub_id, qos) tuples) over one batch of publish topics whose '/'-tokenised
@@ -20,9 +21,11 @@ One JSON line on rank 0:
                 read term is served by L2/MALL for hot filters, so alg_frac can exceed frac — and 1)
   parity_sample per-topic digests (count, sum, order-dependent sum, sum of squares of sub_id*4+qos) of EVERY window
                 of a full pass of the timed batch in each result format (tuple, soa, packed, runs): compact formats
-                vs the tuple format on all topics, tuple format vs the oracle on the FULL table for a stratified
-                sample (random over the batch, heaviest topics, most matched filters, the last window, chunk
-                boundaries, prefix); the line FAILS (exit 1) when anything differs
+                vs the tuple format on all topics, tuple format vs the oracle on the FULL table for EVERY topic of the
+                batch (the oracle composes a topic's digest from per-filter pre-reduced digests, O(matched filters) per
+                topic, and cross-checks that against its per-hit digest on a sample); N > 1: every rank digests its own
+                topics, rank 0 compares the assembled batch with the oracle on the UNSHARDED table; the line FAILS
+                (exit 1) when anything differs
   cpu_baseline  the oracle's DefaultRouter::_matches-shaped pass ("port") on this host's cores over a
                 bounded prefix of the same batch
   pcie_inclusive_matches_per_s   the same path with every window copied to pinned host memory
@@ -115,6 +118,22 @@ def sample(W, n, seed=20260922):
     return shard.take(W["tb"], W["to"], idx)
 
 
+def shard_inputs(W, world, rank):
+    """This rank's share of config `W` under the shard rule (rgr_shard_assign): the filters it owns plus the replicated
+    (wildcard-in-the-key-levels) ones, and the publish topics it owns.  -> (blob, offs, sub_ids, qos, topic blob, topic offs, keep_t)"""
+    from rmqtt_amd import shard
+    sub_ids = np.arange(W["n_sub"], dtype=np.uint32)
+    if world == 1:
+        return W["blob"], W["offs"], sub_ids, W["qos"], W["tb"], W["to"], None
+    f_owner = shard.assign(W["blob"], W["offs"], world, is_filter=True)
+    t_owner = shard.assign(W["tb"], W["to"], world, is_filter=False)
+    keep_f = np.nonzero((f_owner == rank) | (f_owner < 0))[0]
+    keep_t = np.nonzero(t_owner == rank)[0]
+    blob_r, offs_r = shard.take(W["blob"], W["offs"], keep_f)
+    tb_r, to_r = shard.take(W["tb"], W["to"], keep_t)
+    return blob_r, offs_r, sub_ids[keep_f], W["qos"][keep_f], tb_r, to_r, keep_t
+
+
 def build_table(r, W, blob, offs, sub_ids, qos, deliver_frac=-1.0):
     from rmqtt_amd import capi
     t = time.time()
@@ -146,7 +165,7 @@ class _DevArr:      # zero-copy torch view of library-owned device memory
 FORMAT_NAMES = ("tuple", "soa", "packed", "runs")      # == RGR_FORMAT_*
 
 
-def gpu_digests(batch, n_topics, retain, fmt=0, subs_len=0):
+def gpu_digests(batch, n_topics, retain, fmt=0, subs_len=0, topic_ids_dev=None):
     """Per-topic digests of EVERY window of one full pass in result format `fmt`, reduced on the device (torch is plumbing
     here: the hits were produced by the library's kernels; the per-topic sums are prefix-sum differences because a topic's
     hits are consecutive positions).  -> (int64 device tensor [n, 4] (router) / [n, 3] (retain) with the same definition as
@@ -183,6 +202,8 @@ def gpu_digests(batch, n_topics, retain, fmt=0, subs_len=0):
         if fmt == capi.RGR_FORMAT_TUPLE:
             t = torch.as_tensor(_DevArr(w.d_tuples, (nh, 3), "<i4"), device="cuda")
             owner = torch.repeat_interleave(torch.arange(tb_, te_, dtype=torch.int32, device="cuda"), cnt)
+            if topic_ids_dev is not None:              # sharded batch (rgr_batch_set_topic_ids): the column carries the GLOBAL publish index
+                owner = topic_ids_dev[owner.to(torch.int64)]
             structure_ok &= bool((t[:, 0] == owner).all())       # tuple i names the topic whose CSR range holds position i
             del owner
             sid = t[:, 1].to(torch.int64) & M32
@@ -298,108 +319,152 @@ def delivery_parity(batch, W, pa, n_windows_wanted=3):
             "what": "delivery words of whole windows of the timed batch (first / middle / last) vs a torch restatement of the per-hit rules on the device"}
 
 
-def parity_sample(r, o, W, batch, budget_hits, threads, primary, seed=20260921):
-    """Full-size parity, in the bench line itself.
-      1. ONE full pass of the timed batch per result format (tuple, soa, packed, runs); every window of every pass is
-         digested on the device per topic.  The compact formats' digests must equal the tuple format's for EVERY topic of the
-         batch, and each pass is checked structurally (windows tile the batch, topic columns restate the CSR offsets).
-      2. The tuple digests of a STRATIFIED sample of topics are compared with the oracle's digests of the same topics against
-         the full table: a seeded random sample over the whole batch, the heaviest topics by hit count, the topics with the
-         most matched filters that have subscribers, every topic of the pass's LAST window (end of the last chunk), the
-         topics on both sides of every chunk boundary, and a prefix.
-    Because the digests come from the real timed batch (not from a re-submitted subset), late windows, chunk boundaries and
-    the heaviest topics are checked where they actually ran."""
+def device_digests(r, batch, n, retain, formats=True, topic_ids=None):
+    """ONE full pass of the timed batch per result format (tuple, soa, packed, runs), every window digested per topic on the device.
+    The compact formats' digests must equal the tuple format's for EVERY topic, and each pass is checked structurally (windows
+    tile the batch, topic columns restate the CSR offsets; with `topic_ids` — a sharded batch — the tuple's topic column must
+    carry the caller's global index).  -> (tuple-format digests [n, ncol] on the device, per-format verdicts, info)"""
     import torch
-    from rmqtt_amd import capi, shard
-    retain = W["retain"]
-    n = W["n_pub"]
+    from rmqtt_amd import capi
     t0 = time.time()
     subs_len = 0 if retain else int(r.stats()["n_subs"])
-    D, fmt_ok, runs_pt = {}, {}, None
-    struct = {}
-    for fmt in (capi.RGR_FORMAT_TUPLE, capi.RGR_FORMAT_SOA, capi.RGR_FORMAT_PACKED, capi.RGR_FORMAT_RUNS):
+    ids_dev = torch.from_numpy(np.ascontiguousarray(topic_ids).astype(np.int32)).cuda() if topic_ids is not None else None
+    D, fmt_ok, struct, runs_pt, info0 = None, {}, {}, None, {}
+    fmts = (capi.RGR_FORMAT_TUPLE, capi.RGR_FORMAT_SOA, capi.RGR_FORMAT_PACKED, capi.RGR_FORMAT_RUNS) if formats else (capi.RGR_FORMAT_TUPLE,)
+    for fmt in fmts:
         name = FORMAT_NAMES[fmt]
+        if topic_ids is not None:          # only the tuple format's topic column is checked against the global ids; the other passes index locally
+            batch.set_topic_ids(topic_ids if fmt == capi.RGR_FORMAT_TUPLE else None)
         try:
-            d, ok_s, info = gpu_digests(batch, n, retain, fmt, subs_len)
+            d, ok_s, info = gpu_digests(batch, n, retain, fmt, subs_len, ids_dev if fmt == capi.RGR_FORMAT_TUPLE else None)
         except capi.RgrError as e:                   # (packed needs ids below 2^30)
             fmt_ok[name] = f"n/a: {e}"
             continue
         struct[name] = ok_s
         if fmt == capi.RGR_FORMAT_TUPLE:
-            D, last_window, n_windows = d, info["last_window"], info["windows"]
-            fmt_ok[name] = None                      # decided by the oracle comparison below
+            D, info0 = d, info
+            fmt_ok[name] = None                      # decided by the oracle comparison
         else:
-            same = bool((d == D).all())
-            fmt_ok[name] = "ok" if (same and ok_s) else "MISMATCH"
+            fmt_ok[name] = "ok" if (bool((d == D).all()) and ok_s) else "MISMATCH"
             if fmt == capi.RGR_FORMAT_RUNS:
                 runs_pt = info["runs_per_topic"]
             del d
-    gpu_s = time.time() - t0
-    hits_pt = D[:, 0]
-    total_hits = int(hits_pt.sum())
-    mean = max(1.0, total_hits / max(1, n))
-    # ---- strata, each within its share of the oracle's budget (hits): the oracle's cost is its hits, and on the retained path it is
-    # ~10^3 x slower per query than the router's (r3i: an uncapped last-window stratum of 10 754 filters cost the bench 14 minutes)
-    rng = np.random.default_rng(seed)
-    hits_cpu = hits_pt.cpu().numpy().astype(np.int64)
+    if topic_ids is not None:
+        batch.set_topic_ids(topic_ids)
+    return D, fmt_ok, {"structure_ok": struct, "windows": info0.get("windows", 0), "last_window": info0.get("last_window", (0, 0)),
+                       "runs_per_topic": runs_pt, "gpu_digest_s": round(time.time() - t0, 2)}
 
-    def within(idx, share):
-        """longest prefix of idx whose hits fit share * budget (at least one query)"""
-        idx = np.asarray(idx, dtype=np.int64)
-        if not len(idx):
-            return idx
-        c = np.cumsum(hits_cpu[idx])
-        return idx[:max(1, int(np.searchsorted(c, share * budget_hits, side="right")))]
-    K = 1024 if primary else 256
-    strata = {}
-    strata["heaviest_by_hits"] = within(torch.topk(hits_pt, min(K, n)).indices.cpu().numpy(), 0.10)
-    if runs_pt is not None:
-        strata["most_matched_filters"] = within(torch.topk(runs_pt, min(K, n)).indices.cpu().numpy(), 0.10)
-    strata["last_window"] = within(np.arange(last_window[1] - 1, last_window[0] - 1, -1), 0.25)[::-1]      # the END of the pass's last window
-    chunk = 1 << 21
-    strata["chunk_boundaries"] = within(np.concatenate([np.arange(max(0, c - 32), min(n, c + 32)) for c in range(chunk, n, chunk)] or [np.zeros(0, dtype=np.int64)]), 0.05)
-    strata["prefix"] = within(np.arange(min(n, 2000 if primary else 500)), 0.05)
-    fixed = np.unique(np.concatenate([v.astype(np.int64) for v in strata.values()]))
-    fixed_hits = int(hits_cpu[fixed].sum()) if len(fixed) else 0
-    n_rand = int(min(n, max(64, (budget_hits - fixed_hits) / mean)))
-    strata["random"] = np.sort(rng.choice(n, size=n_rand, replace=False)) if n_rand < n else np.arange(n)
-    sel = np.unique(np.concatenate([fixed, strata["random"].astype(np.int64)]))
-    # ---- oracle digests of the selected topics against the full table
-    sb, so = shard.take(W["tb"], W["to"], sel)
+
+def compare_with_oracle(o, W, got, gpu_status, fmt_ok, dinfo, threads, primary, seed=20260921, extra=None):
+    """EXHAUSTIVE full-size parity: the device's per-topic digests of the tuple format (`got`, uint64 [n, ncol], batch order) against
+    the oracle's digests of EVERY query of the batch on the FULL (unsharded) table.  The oracle composes a topic's digest from
+    per-filter pre-reduced digests (orc_router_match_digest_fast: O(matched filters) per topic; the retained path uses bottom-up
+    subtree aggregates for its '#' step, orc_retain_match_digest_fast) — held equal to its own O(hits) digest by
+    tests/test_oracle_digest.py and, in this very run, on a stratified cross-check sample (heaviest topics + a random draw)."""
+    from rmqtt_amd import shard
+    retain = W["retain"]
+    n = W["n_pub"]
     t1 = time.time()
-    status, exp = o.match_digest(sb, so, threads)
+    status, exp = o.match_digest(W["tb"], W["to"], threads, fast=True)
     cpu_s = time.time() - t1
-    got = D[torch.from_numpy(sel).cuda()].cpu().numpy().view(np.uint64)
-    gst = batch.status()[sel]
-    same_status = bool(np.array_equal(gst < 0, status < 0))
+    same_status = bool(np.array_equal(gpu_status < 0, status < 0))
     bad = np.nonzero((got != exp).any(axis=1))[0]
+    struct = dinfo["structure_ok"]
     tuple_ok = same_status and struct.get("tuple", False) and len(bad) == 0
+    fmt_ok = dict(fmt_ok)
     fmt_ok["tuple"] = "ok" if tuple_ok else "MISMATCH"
-    ok = tuple_ok and all(v == "ok" or str(v).startswith("n/a") for v in fmt_ok.values())
-    in_sel = {k: int(len(v)) for k, v in strata.items()}
-    rec = {"topics": int(len(sel)), "hits": int(exp[:, 0].sum()), "ok": bool(ok),
-           "strata": in_sel, "formats": fmt_ok,
-           "full_pass": {"topics_digested": int(n), "hits_digested": total_hits, "windows": int(n_windows),
+    # ---- the fast oracle digest against the oracle's own per-hit digest, on the heaviest queries and a random draw (bounded by hits)
+    rng = np.random.default_rng(seed)
+    hits = exp[:, 0].astype(np.int64)
+    budget = (2.0e7 if retain else 4.0e8) * max(1, threads) / 256 * (1.0 if primary else 0.5)
+    heavy = np.argsort(hits)[::-1][:64 if retain else 256]
+    heavy = heavy[:max(1, int(np.searchsorted(np.cumsum(hits[heavy]), 0.5 * budget, side="right")))]
+    n_rand = int(min(n, max(32, 0.5 * budget / max(1.0, float(hits.mean())))))
+    sel = np.unique(np.concatenate([heavy, rng.choice(n, size=n_rand, replace=False)]))
+    sb, so = shard.take(W["tb"], W["to"], sel)
+    t2 = time.time()
+    st_s, exp_s = o.match_digest(sb, so, threads)
+    cross_s = time.time() - t2
+    cross_ok = bool(np.array_equal(exp_s, exp[sel]) and np.array_equal(st_s < 0, status[sel] < 0))
+    ok = tuple_ok and cross_ok and all(v == "ok" or str(v).startswith("n/a") for v in fmt_ok.values())
+    rec = {"topics": int(n), "exhaustive": True, "hits": int(hits.sum()), "ok": bool(ok), "formats": fmt_ok,
+           "invalid_topics": int((status < 0).sum()),
+           "full_pass": {"topics_digested": int(n), "hits_digested": int(got[:, 0].astype(np.int64).sum()), "windows": int(dinfo["windows"]),
                          "what": "every window of one full pass of the timed batch per format, digested per topic on the device; compact formats "
-                                 "compared with the tuple format on ALL topics, tuple format compared with the oracle on the strata"},
-           "max_hits_in_sample": int(exp[:, 0].max()) if len(sel) else 0,
+                                 "compared with the tuple format on ALL topics; tuple format compared with the oracle on ALL topics"},
+           "oracle_cross_check": {"ok": cross_ok, "topics": int(len(sel)), "hits": int(exp_s[:, 0].sum()), "seconds": round(cross_s, 2),
+                                  "what": "orc_*_match_digest_fast (used for all topics) vs the oracle's per-hit digest on the heaviest queries + a seeded random draw"},
+           "max_hits_in_one_query": int(hits.max()) if n else 0,
            "digest": ("per filter: hits, sum(topic_id), sum(topic_id^2) mod 2^64 (set comparison: the reference's order is hash-map order)"
                       if retain else
                       "per topic: hits, sum(v), sum((k+1)*v) in canonical order, sum(v^2) mod 2^64, v = sub_id*4+qos"),
-           "table": "full", "oracle_s": round(cpu_s, 2), "gpu_digest_s": round(gpu_s, 2), "seed": seed}
+           "table": "full", "oracle_s": round(cpu_s, 2), "gpu_digest_s": dinfo["gpu_digest_s"], "seed": seed}
+    if extra:
+        rec.update(extra)
     if not ok:
-        rec["first_bad_topic"] = int(sel[bad[0]]) if len(bad) else None
+        rec["first_bad_topic"] = int(bad[0]) if len(bad) else None
+        rec["mismatching_topics"] = int(len(bad))
         rec["status_equal"] = same_status
         rec["structure_ok"] = struct
-    del D
     return rec
+
+
+def parity_sample(r, o, W, batch, threads, primary):
+    """N = 1: device digests of the whole timed batch in every format, then the exhaustive comparison with the oracle."""
+    D, fmt_ok, dinfo = device_digests(r, batch, W["n_pub"], W["retain"])
+    got = D.cpu().numpy().view(np.uint64)
+    del D
+    return compare_with_oracle(o, W, got, batch.status(), fmt_ok, dinfo, threads, primary)
+
+
+def sharded_digests(r, batch, keep_t, n_pub, world, rank, dist, cdev, formats=True):
+    """N > 1 (collective): every rank digests ITS topics on its device (all formats; the tuple pass also checks that the tuples carry
+    the global publish index), rank 0 receives every rank's rows and assembles the digests of the whole batch in batch order.
+    -> on rank 0: (uint64 [n_pub, 4], status int32 [n_pub], per-format verdicts, info); None elsewhere."""
+    import torch
+    my = len(keep_t)
+    D, fmt_ok, dinfo = device_digests(r, batch, my, False, formats=formats, topic_ids=keep_t.astype(np.uint32))
+    rows = torch.zeros((my, 6), dtype=torch.int64)
+    rows[:, 0] = torch.from_numpy(keep_t.astype(np.int64))
+    rows[:, 1] = torch.from_numpy(batch.status().astype(np.int64))
+    rows[:, 2:] = D.cpu()
+    del D
+    rows = rows.to(cdev)
+    flags = torch.tensor([my, int(all(dinfo["structure_ok"].values())), int(all(v in (None, "ok") or str(v).startswith("n/a") for v in fmt_ok.values())),
+                          int(dinfo["windows"])], dtype=torch.int64, device=cdev)
+    allf = [torch.zeros_like(flags) for _ in range(world)]
+    dist.all_gather(allf, flags)
+    counts = [int(f[0]) for f in allf]
+    pad = torch.zeros((max(counts + [1]), 6), dtype=torch.int64, device=cdev)
+    pad[:my] = rows
+    bufs = [torch.zeros_like(pad) for _ in range(world)] if rank == 0 else None
+    dist.gather(pad, bufs, dst=0)
+    if rank != 0:
+        return None
+    got = np.zeros((n_pub, 4), dtype=np.uint64)
+    status = np.zeros(n_pub, dtype=np.int32)
+    seen = np.zeros(n_pub, dtype=np.int32)
+    for b_, c_ in zip(bufs, counts):
+        x = b_[:c_].cpu().numpy()
+        ids = x[:, 0]
+        np.add.at(seen, ids, 1)
+        got[ids] = x[:, 2:].view(np.uint64)
+        status[ids] = x[:, 1].astype(np.int32)
+    fmt_all = {k: ("ok" if all(int(f[2]) for f in allf) else "MISMATCH") for k in fmt_ok if k != "tuple"}
+    fmt_all["tuple"] = None
+    info = {"structure_ok": {"tuple": bool(all(int(f[1]) for f in allf)) and bool((seen == 1).all())},
+            "windows": int(sum(int(f[3]) for f in allf)), "gpu_digest_s": dinfo["gpu_digest_s"]}
+    extra = {"sharded": {"ranks": world, "topics_per_rank": counts, "every_topic_owned_exactly_once": bool((seen == 1).all()),
+                         "what": "each rank digested its own topics on its device (tuples carry the global publish index); rank 0 compared the "
+                                 "assembled batch with the oracle on the UNSHARDED table"}}
+    return got, status, fmt_all, info, extra
 
 
 # ------------------------------------------------------------------------------------------- PMC traffic
 KCLASS = (("expand", ("expand_kernel",)), ("walk", ("walk_kernel<false>",)), ("retain", ("retain_",)))
 
 
-def run_pmc_children(args, phases):
+def run_pmc_children(args, phases, world=1, rank=0):
     """FETCH_SIZE and WRITE_SIZE of this run's kernels: two rocprofv3 passes (the TCC counters do not fit one)
     over `bench.py --pmc-child`, which replays ONE pass of every phase.  Counters only + kernel trace — no
     sys/hip/hsa trace domains.  -> {phase: {class: {"fetch_KiB", "write_KiB", "dispatches", "avg_us"}}} or None."""
@@ -414,11 +479,14 @@ def run_pmc_children(args, phases):
             meta = os.path.join(work, f"{counter}.json")
             cmd = [rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(work, counter), "-o", "pmc", "--",
                    sys.executable, os.path.abspath(__file__), "--pmc-child", meta, "--pmc-phases", ",".join(phases),
-                   "--config", str(args.config), "--scale", str(args.scale), "--pmc-topics", str(args.pmc_topics)]
+                   "--config", str(args.config), "--scale", str(args.scale), "--pmc-topics", str(args.pmc_topics),
+                   "--pmc-world", str(world), "--pmc-rank", str(rank)]
             if args.window_hits:
                 cmd += ["--window-hits", str(args.window_hits)]
             t = time.time()
             env = dict(os.environ, TMPDIR=tempfile.gettempdir())
+            for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+                env.pop(k, None)            # the child is a plain single-process replay
             p = subprocess.run(cmd, cwd=tempfile.gettempdir(), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
             log(f"pmc: {counter} pass rc={p.returncode} in {time.time() - t:.0f}s")
             if p.returncode != 0 or not os.path.exists(meta):
@@ -461,15 +529,18 @@ def run_pmc_children(args, phases):
 def pmc_child(args):
     """One pass per phase under rocprofv3's counters; writes how many dispatches of each kernel class every
     phase issued so that the parent can split the counter rows."""
-    from rmqtt_amd import capi
+    from rmqtt_amd import capi, shard
     phases = []
     for name in args.pmc_phases.split(","):
         cfg, scale = (args.config, args.scale) if name == "primary" else (int(name[6:]), 1.0)
         W = gen_workload(cfg, scale)
         r = capi.Router(device=0, window_hits=args.window_hits, collect_walk_stats=False)
-        build_table(r, W, W["blob"], W["offs"], np.arange(W["n_sub"], dtype=np.uint32), W["qos"])
-        n = min(W["n_pub"], args.pmc_topics)
-        sb, so = prefix(W, n) if n < W["n_pub"] else (W["tb"], W["to"])
+        world = args.pmc_world if name == "primary" else 1
+        blob_r, offs_r, sub_ids_r, qos_r, tb_r, to_r, _ = shard_inputs(W, world, args.pmc_rank if world > 1 else 0)
+        build_table(r, W, blob_r, offs_r, sub_ids_r, qos_r)
+        n_mine = len(to_r) - 1
+        n = min(n_mine, args.pmc_topics)
+        sb, so = shard.take(tb_r, to_r, np.arange(n)) if n < n_mine else (tb_r, to_r)
         b = r.retain_batch(sb, so) if W["retain"] else r.batch(sb, so)
         r.stats_reset()
         hits, _ = b.run()
@@ -502,19 +573,9 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
     W = gen_workload(cfg, scale, rank)
     c, n_sub, n_pub, retain = W["c"], W["n_sub"], W["n_pub"], W["retain"]
     blob, offs, tb, to, client, qos = W["blob"], W["offs"], W["tb"], W["to"], W["client"], W["qos"]
-    sub_ids = np.arange(n_sub, dtype=np.uint32)
     if world > 1 and retain:
         raise SystemExit("config 5 (retained path) is a single-GPU config")
-    if world > 1:
-        f_owner = shard.assign(blob, offs, world, is_filter=True)
-        t_owner = shard.assign(tb, to, world, is_filter=False)
-        keep_f = np.nonzero((f_owner == rank) | (f_owner < 0))[0]
-        keep_t = np.nonzero(t_owner == rank)[0]
-        blob_r, offs_r = shard.take(blob, offs, keep_f)
-        tb_r, to_r = shard.take(tb, to, keep_t)
-        sub_ids_r, qos_r = sub_ids[keep_f], qos[keep_f]
-    else:
-        blob_r, offs_r, tb_r, to_r, sub_ids_r, qos_r = blob, offs, tb, to, sub_ids, qos
+    blob_r, offs_r, sub_ids_r, qos_r, tb_r, to_r, keep_t = shard_inputs(W, world, rank)
     my_topics = len(to_r) - 1
 
     # ---- table build + device-resident batch
@@ -658,8 +719,23 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
     else:
         total_hits, total_topics = hits, my_topics
     st = r.stats()
+    comm_info = None
+    if comm is not None:
+        try:
+            comm_info = comm.info()                 # ncclCommCount / ncclCommUserRank of the communicator the steps above ran on
+        except Exception as e:      # noqa: BLE001   (reporting only)
+            log(f"rgr_comm_info failed: {e!r}", rank)
+    # ---- N > 1: per-topic digests of every rank's pass, assembled on rank 0 (collective), compared with the oracle below
+    gathered = None
+    if world > 1 and not args.no_parity:
+        gathered = sharded_digests(r, batch, keep_t, n_pub, world, rank, dist, cdev, formats=not args.no_formats)
     if comm is not None:
         comm.close()
+    if world > 1:
+        # every rank leaves the process group TOGETHER, here; rank 0's tail (oracle build, exhaustive comparison, PMC children) is solo
+        # work and must not leave peers waiting in a collective or a communicator half torn down
+        dist.barrier()
+        dist.destroy_process_group()
     if rank != 0:
         batch.close(); r.close()
         return None, None
@@ -701,7 +777,9 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
                                 f"BASELINE.json configs[{cfg - 1}]: {n_sub} subscriptions (p_plus/level {c['p_plus']}, p_hash {c['p_hash']}, "
                                 f"Zipf tokens s=1.1, Zipf clients s=1.0), {n_pub} publish topics, seeds 0x{wl.SUB_SEED + cfg:X}/0x{wl.PUB_SEED + cfg:X}"),
                    "subscriptions": n_sub, "publishes": n_pub, "sharding": f"hash of the first {shard.KEY_LEVELS} levels x{world}" if world > 1 else "none",
-                   "gather": args.gather if world > 1 else "n/a", "collective": collective, "windows_per_step": int(nwin)},
+                   "gather": args.gather if world > 1 else "n/a", "collective": collective,
+                   "rccl_ranks": comm_info["ranks"] if comm_info and comm_info["transport"] == "rccl" else None,
+                   "dist_backend": args.dist_backend if world > 1 else "n/a", "windows_per_step": int(nwin)},
         "hits_per_step": int(total_hits), "hits_per_s": round(total_hits * K / elapsed, 1),
         "mean_hits_per_topic": round(total_hits / max(1, total_topics), 2),
         "mean_visited_nodes_per_topic": round(st["visited_nodes"] / max(1, st["topics"]), 2),
@@ -774,7 +852,21 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
                                  "tuple_GBps": round(h2 * 12 / dt / 1e9, 2), "seconds": round(dt, 3)}
 
     # ---- CPU baseline (reference-shaped port) + parity sample against the oracle on the full table (N=1 only)
-    if args.cpu_sample != 0 and world == 1 and deliver < 0:
+    if world > 1 and gathered is not None and deliver < 0:
+        # N > 1: the oracle holds the UNSHARDED table; every topic of the batch is compared (the CPU baseline stays an N = 1 leg)
+        from oracle import oracle as orc
+        cores = args.cpu_threads or os.cpu_count() or 1
+        t = time.time()
+        o = orc.DefaultRouter()
+        o.add_bulk(blob, offs, client, qos)
+        log(f"config {cfg}: oracle table (unsharded) built in {time.time() - t:.1f}s", 0)
+        got, gst, fmt_all, dinfo, extra = gathered
+        rec["parity_sample"] = compare_with_oracle(o, W, got, gst, fmt_all, dinfo, cores, primary, extra=extra)
+        log(f"config {cfg}: parity_sample {rec['parity_sample']}", 0)
+        rec["cpu_baseline"] = None
+        rec["cpu_baseline_note"] = "timed at N = 1 only (python bench.py): same table, same batch"
+        del o, gathered
+    elif args.cpu_sample != 0 and world == 1 and deliver < 0:
         from oracle import oracle as orc
         cores = args.cpu_threads or os.cpu_count() or 1
         t = time.time()
@@ -813,7 +905,7 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
             cpu["without_refcounting"] = plain
         rec["cpu_baseline"] = cpu
         if not args.no_parity:
-            rec["parity_sample"] = parity_sample(r, o, W, batch, budget_hits, cores, primary)       # the oracle's budget of the CPU-baseline leg
+            rec["parity_sample"] = parity_sample(r, o, W, batch, cores, primary)
             log(f"config {cfg}: parity_sample {rec['parity_sample']}", 0)
         del o
     else:
@@ -999,6 +1091,24 @@ def measure_router_e2e(args):
     return 0
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-execute this script under torch.distributed.run with one rank per GPU
+    (exactly the command the driver uses for N > 1) and return its exit status; rank 0's JSON line goes to stdout unchanged."""
+    import socket
+    import torch
+    ndev = torch.cuda.device_count()
+    if args.dist_backend == "nccl" and ndev < args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: this node exposes {ndev} GPU(s); RCCL needs one device per rank "
+                         f"(logic runs with several ranks per GPU: add --dist-backend gloo)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("self-launch: " + " ".join(cmd))
+    return subprocess.call(cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1021,6 +1131,8 @@ def main():
     ap.add_argument("--pmc-topics", type=int, default=2_000_000, help="queries per phase replayed under the counters")
     ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)
     ap.add_argument("--pmc-phases", default="primary", help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-world", type=int, default=1, help=argparse.SUPPRESS)
+    ap.add_argument("--pmc-rank", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--deliver", type=float, default=-1.0, metavar="V5FRAC",
                     help="also run the delivery stage (SURVEY 8(f)-1): this fraction of the subscriptions is MQTT v5 "
                          "(No Local / RAP / per-client dedup); 0 = v3 only. Not the headline metric.")
@@ -1044,9 +1156,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)        # `python bench.py --gpus N` on its own: spawn the N ranks (one per GPU) and pass their line through
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started inside a {world}-rank job (WORLD_SIZE): launch it with --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     if args.dist_backend != "nccl":
@@ -1062,9 +1175,7 @@ def main():
 
     rec, phase = measure(args, args.config, args.scale, args.steps, args.warmup, True, rank, world, local_rank, dist, cdev)
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
-        return 0
+        return 0                           # (measure() left the process group together with every other rank)
 
     headline = world == 1 and args.deliver < 0
     secondary = []
@@ -1089,18 +1200,19 @@ def main():
             log(f"secondary delivery-stage record failed: {e!r}")
             secondary.append({"config": {"workload": "BASELINE.json configs[2] + delivery stage"}, "error": repr(e)})
 
-    if headline and not args.no_pmc:
+    if (headline or world > 1) and not args.no_pmc and args.deliver < 0:
+        # N > 1: rank 0's child replays RANK 0's shard (table + topics under the same shard rule) on its GPU: a per-rank roofline
         cal = load_calibration()
-        pmc = run_pmc_children(args, ["primary"] + list(sec_phases))
+        pmc = run_pmc_children(args, ["primary"] + list(sec_phases), world, 0)
         attach_traffic(rec, phase, pmc.get("primary") if pmc else None, cal)
+        if world > 1 and rec["roofline"].get("traffic") is not None:
+            rec["roofline"]["per_rank"] = f"rank 0 of {world}: its shard replayed under the counters; every rank runs the same kernels on its own shard"
         for name, (srec, sph) in sec_phases.items():
             attach_traffic(srec, sph, pmc.get(name) if pmc else None, cal)
     if secondary:
         rec["secondary"] = secondary
 
     print(json.dumps(rec), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
     bad = [r_ for r_ in [rec] + secondary if isinstance(r_.get("parity_sample"), dict) and not r_["parity_sample"]["ok"]]
     if bad:
         log("PARITY SAMPLE FAILED: the GPU's tuples differ from the oracle's")

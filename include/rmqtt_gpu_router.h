@@ -437,6 +437,11 @@ typedef struct rgr_comm rgr_comm;
 int32_t rgr_comm_unique_id(uint8_t* id /* [RGR_COMM_ID_BYTES] */);
 int32_t rgr_comm_create(rgr_handle* h, const uint8_t* id, uint32_t rank, uint32_t world, rgr_comm** out);
 void rgr_comm_destroy(rgr_comm* c);
+/* What the transport itself reports about this communicator (a launcher's evidence that N ranks really formed ONE RCCL world):
+ * ranks = ncclCommCount, rank = ncclCommUserRank, device = the handle's HIP ordinal; transport 1 = RCCL (xGMI / PCIe between
+ * devices), 0 = device copies between shards that share one GPU (single-process groups on a test rig). */
+typedef struct rgr_comm_info_t { uint32_t ranks, rank; int32_t device; int32_t transport; } rgr_comm_info_t;
+int32_t rgr_comm_info(rgr_comm* c, rgr_comm_info_t* out);
 /* every rank's value on every rank: all[world] */
 int32_t rgr_comm_allgather_u64(rgr_comm* c, uint64_t mine, uint64_t* all);
 /* One pass of batch `b` (created on the communicator's handle) whose windows are all-gathered: in every round

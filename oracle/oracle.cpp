@@ -8,6 +8,7 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <thread>
 
 namespace orc {
@@ -60,11 +61,12 @@ std::string topic_to_string(const Topic& t) {
 bool DefaultRouter::add(std::string_view topic_filter, const Id& id, const SubscriptionOptions& opts, uint32_t rel_id) {
     Topic topic;
     if (!parse_topic(topic_filter, topic)) return false;       // router.rs:436 (`?`)
+    ++mutations_;
     topics_.insert(topic, Unit{});                             // router.rs:438
     auto it = relations_.find(std::string(topic_filter));
     if (it == relations_.end()) {                              // router.rs:443-446
         topics_count_++;
-        it = relations_.emplace(std::string(topic_filter), FilterEntry{next_filter_id_++, {}}).first;
+        it = relations_.emplace(std::string(topic_filter), FilterEntry{next_filter_id_++, {}, {}}).first;
     }
     auto& rels = it->second.rels;
     auto old = rels.find(id.client_id);
@@ -80,6 +82,7 @@ int DefaultRouter::remove(std::string_view topic_filter, const Id& id) {
     auto r = rels.find(id.client_id);
     if (r == rels.end() || !(r->second.id == id)) return 1;    // router.rs:460-467
     rels.erase(r);
+    ++mutations_;
     relations_count_--;
     if (rels.empty()) {                                        // router.rs:484-490
         relations_.erase(it);
@@ -187,6 +190,57 @@ bool DefaultRouter::match_flat(uint32_t topic_idx, std::string_view topic_name, 
         std::sort(tmp.begin(), tmp.end(), [](const FlatHit& a, const FlatHit& b) { return a.sub_id < b.sub_id; });
         out.insert(out.end(), tmp.begin(), tmp.end());
         if (st) st->hits += tmp.size();
+    }
+    return true;
+}
+
+// ---- O(matched filters) digests (checker only) ------------------------------------------------------
+// match_flat lists, per matched filter in TopicTree::matches order, the filter's relations ascending by rel_id; the digest
+// of orc_router_match_digest over that list is a sum over hits, so it splits by filter: with `off` hits before filter f,
+//   count += n_f;  sum v += S1_f;  sum (k+1) v += off * S1_f + P_f;  sum v^2 += S2_f
+// where P_f = sum over f's own list of (j+1) * v_j.  The walk itself (parse, TopicTree::matches, join, relations lookup)
+// is the same code match_flat runs.
+void DefaultRouter::prepare_digests(int threads) {
+    if (digests_at_ == mutations_) return;
+    std::vector<FilterEntry*> all;
+    all.reserve(relations_.size());
+    for (auto& kv : relations_) all.push_back(&kv.second);
+    if (threads < 1) threads = 1;
+    std::atomic<size_t> next{0};
+    auto work = [&] {
+        std::vector<uint64_t> v;
+        for (;;) {
+            const size_t lo = next.fetch_add(4096), hi = std::min(all.size(), lo + 4096);
+            if (lo >= all.size()) break;
+            for (size_t i = lo; i < hi; ++i) {
+                v.clear();
+                for (auto& kv : all[i]->rels) v.push_back((uint64_t(kv.second.rel_id) << 8) | kv.second.opts.qos);
+                std::sort(v.begin(), v.end());                                  // ascending rel_id (rel ids are unique)
+                FilterDigest d;
+                for (size_t j = 0; j < v.size(); ++j) {
+                    const uint64_t x = (v[j] >> 8) * 4 + (v[j] & 0xFF);
+                    d.n++; d.s1 += x; d.p += uint64_t(j + 1) * x; d.s2 += x * x;
+                }
+                all[i]->dig = d;
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int k = 0; k < threads; ++k) th.emplace_back(work);
+    for (auto& t : th) t.join();
+    digests_at_ = mutations_;
+}
+
+bool DefaultRouter::match_digest_fast(std::string_view topic_name, uint64_t out[4]) const {
+    out[0] = out[1] = out[2] = out[3] = 0;
+    Topic topic;
+    if (!parse_topic(topic_name, topic)) return false;
+    for (auto& item : topics_.matches(topic, nullptr)) {
+        auto rit = relations_.find(join_levels(item.first));
+        if (rit == relations_.end()) continue;
+        const FilterDigest& d = rit->second.dig;
+        out[2] += out[0] * d.s1 + d.p;
+        out[0] += d.n; out[1] += d.s1; out[3] += d.s2;
     }
     return true;
 }
@@ -355,7 +409,8 @@ int orc_tree_is_match(void* t, const char* topic, uint64_t len) {
 
 // ---- RetainTree<i64> ------------------------------------------------------
 void* orc_retain_new() { return new RetainTree<int64_t>(); }
-void orc_retain_free(void* t) { delete static_cast<RetainTree<int64_t>*>(t); }
+void orc_retain_digest_table_drop(void* t);
+void orc_retain_free(void* t) { orc_retain_digest_table_drop(t); delete static_cast<RetainTree<int64_t>*>(t); }
 int orc_retain_insert(void* t, const char* s, uint64_t len, int64_t v) {
     Topic tp;
     if (!parse_topic(std::string_view(s, len), tp)) return -1;
@@ -667,6 +722,129 @@ void orc_router_match_digest(void* r, const char* blob, const uint64_t* offs, ui
     for (int k = 0; k < threads; ++k) th.emplace_back(work);
     for (auto& t : th) t.join();
 }
+
+// The same digests in O(matched filters) per topic (DefaultRouter::match_digest_fast): what lets bench.py compare EVERY topic
+// of a 10 M-publish batch.  tests/test_oracle_digest.py holds it equal to orc_router_match_digest.
+void orc_router_match_digest_fast(void* r, const char* blob, const uint64_t* offs, uint64_t n, int threads, int32_t* status, uint64_t* out) {
+    auto* rt = static_cast<DefaultRouter*>(r);
+    if (threads < 1) threads = 1;
+    rt->prepare_digests(threads);
+    std::atomic<uint64_t> next{0};
+    auto work = [&] {
+        for (;;) {
+            const uint64_t lo = next.fetch_add(256), hi = std::min<uint64_t>(n, lo + 256);
+            if (lo >= n) break;
+            for (uint64_t i = lo; i < hi; ++i)
+                status[i] = rt->match_digest_fast(std::string_view(blob + offs[i], offs[i + 1] - offs[i]), out + 4 * i) ? 0 : -1;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int k = 0; k < threads; ++k) th.emplace_back(work);
+    for (auto& t : th) t.join();
+}
+
+// ---- RetainTree::matches digests in O(visited nodes that are not under a '#') ------------------------------------------
+// A filter that ends in '#' returns a whole subtree (retain.rs:502-524), which costs the walk O(subtree).  The digest is a sum
+// over the returned values, so the '#' step can use a bottom-up aggregate instead.  For a node n with branches, let
+//   H(n) = digest of what RetainTree::walk(n, path = [.., '#'], i = last) emits when it is entered from its parent
+// following retain.rs literally:
+//   * n has a child stored under the literal key '#' (only possible for retained topic names that contain a '#' level; the
+//     exact-child branch, retain.rs:472-482, comes first): the walk descends THAT child with the path exhausted, which
+//     emits the child's own value and nothing else                              => H(n) = value('#'-child)
+//   * otherwise (retain.rs:502-524) every child c contributes its value, and H(c) when c has branches
+//                                                                                => H(n) = sum_c value(c) + [c has branches] H(c)
+// (The '$'-children are skipped only at the ROOT, retain.rs:505-509: the root is handled at query time, H(root) is never used.)
+// Everything that is not a '#' step (exact children, '+', parent matches, path end) is walked exactly as RetainTree::walk does.
+namespace {
+struct RAgg { uint64_t c = 0, s1 = 0, s2 = 0;
+    void add(const RAgg& o) { c += o.c; s1 += o.s1; s2 += o.s2; }
+    void addv(int64_t v) { const uint64_t x = uint64_t(v); c++; s1 += x; s2 += x * x; } };
+using RNode = RetainTree<int64_t>;
+struct RetainAggTable {
+    std::unordered_map<const RNode*, RAgg> h;
+    uint64_t nodes_at = ~0ull, values_at = ~0ull;
+    RAgg build(const RNode* n) {
+        RAgg a;
+        if (n->branches.empty()) return a;
+        static const Level multi{Kind::MultiWildcard, "#"};
+        auto lit = n->branches.find(multi);
+        for (auto& kv : n->branches) {
+            const RAgg sub = build(kv.second.get());                              // (children are always built: they are query entry points too)
+            if (lit != n->branches.end()) continue;
+            if (kv.second->value) a.addv(*kv.second->value);
+            if (!kv.second->branches.empty()) a.add(sub);
+        }
+        if (lit != n->branches.end() && lit->second->value) a.addv(*lit->second->value);
+        h.emplace(n, a);
+        return a;
+    }
+};
+std::mutex g_ragg_mu;
+std::unordered_map<const RNode*, std::unique_ptr<RetainAggTable>> g_ragg;       // per tree root (test infrastructure: trees are few)
+
+void retain_walk_digest(const RetainAggTable& T, const RNode* n, const Topic& path, size_t i, bool at_root, RAgg& out) {
+    const size_t rem = path.size() - i;
+    if (n->branches.empty() || rem == 0) {                                        // retain.rs:464-470
+        if (rem == 0 && n->value) out.addv(*n->value);
+        return;
+    }
+    const bool next_multi = rem > 1 && path[i + 1].kind == Kind::MultiWildcard;
+    auto e = n->branches.find(path[i]);
+    if (e != n->branches.end()) {                                                 // retain.rs:472-482
+        if (next_multi && e->second->value) out.addv(*e->second->value);
+        retain_walk_digest(T, e->second.get(), path, i + 1, false, out);
+    } else if (path[i].kind == Kind::SingleWildcard) {                            // retain.rs:483-501
+        for (auto& kv : n->branches) {
+            if (at_root && kv.first.kind != Kind::Blank && kv.first.is_metadata()) continue;
+            if (next_multi && kv.second->value) out.addv(*kv.second->value);
+            retain_walk_digest(T, kv.second.get(), path, i + 1, false, out);
+        }
+    } else if (path[i].kind == Kind::MultiWildcard) {                             // retain.rs:502-524, through the aggregates
+        if (!at_root) { out.add(T.h.at(n)); return; }
+        for (auto& kv : n->branches) {
+            if (kv.first.kind != Kind::Blank && kv.first.is_metadata()) continue;
+            if (kv.second->value) out.addv(*kv.second->value);
+            if (!kv.second->branches.empty()) out.add(T.h.at(kv.second.get()));
+        }
+    }
+}
+}  // namespace
+
+// Invalidate / rebuild: the table is rebuilt when the tree's node or value count changed since it was built (the checker
+// builds its tree once and then only queries it; a same-count mutation between two digest calls is not supported).
+void orc_retain_match_digest_fast(void* t, const char* blob, const uint64_t* offs, uint64_t n, int threads, int32_t* status, uint64_t* out) {
+    auto* tree = static_cast<RNode*>(t);
+    if (threads < 1) threads = 1;
+    RetainAggTable* T;
+    {
+        std::lock_guard<std::mutex> lk(g_ragg_mu);
+        auto& slot = g_ragg[tree];
+        if (!slot) slot = std::make_unique<RetainAggTable>();
+        T = slot.get();
+        const uint64_t nn = tree->nodes_size(), nv = tree->values_size();
+        if (T->nodes_at != nn || T->values_at != nv) { T->h.clear(); T->h.reserve(nn / 2 + 16); T->build(tree); T->nodes_at = nn; T->values_at = nv; }
+    }
+    std::atomic<uint64_t> next{0};
+    auto work = [&] {
+        for (;;) {
+            const uint64_t lo = next.fetch_add(64), hi = std::min<uint64_t>(n, lo + 64);
+            if (lo >= n) break;
+            for (uint64_t i = lo; i < hi; ++i) {
+                Topic tp;
+                out[3 * i] = out[3 * i + 1] = out[3 * i + 2] = 0;
+                if (!parse_topic(std::string_view(blob + offs[i], offs[i + 1] - offs[i]), tp)) { status[i] = -1; continue; }
+                status[i] = 0;
+                RAgg a;
+                retain_walk_digest(*T, tree, tp, 0, true, a);
+                out[3 * i] = a.c; out[3 * i + 1] = a.s1; out[3 * i + 2] = a.s2;
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int k = 0; k < threads; ++k) th.emplace_back(work);
+    for (auto& x : th) x.join();
+}
+void orc_retain_digest_table_drop(void* t) { std::lock_guard<std::mutex> lk(g_ragg_mu); g_ragg.erase(static_cast<RNode*>(t)); }
 
 // RetainTree::matches digests, per filter three u64: [0] hits, [1] sum of ids, [2] sum of id * id.
 // Order-independent only: the reference's own order is hash-map order (retain.rs:485, 504).

@@ -253,6 +253,14 @@ class DefaultRouter {   // router.rs:121-127
     int64_t relations_count() const { return relations_count_; }
     uint32_t filter_id_of(const std::string& f) const;
 
+    // Checker only (oracle.cpp: orc_router_match_digest_fast): the per-topic digest of match_flat's hit list in
+    // O(matched filters) instead of O(hits).  prepare_digests() pre-reduces every filter's relation list (sorted by
+    // rel_id, App. A.5) to FilterDigest; a topic's digest is then composed from the digests of its matched filters in
+    // TopicTree::matches order (the order-dependent term shifts by the number of hits that precede the filter).
+    struct FilterDigest { uint64_t n = 0, s1 = 0, p = 0, s2 = 0; };   // count, sum v, sum (j+1) v_j, sum v^2;  v = rel_id * 4 + qos
+    void prepare_digests(int threads);
+    bool match_digest_fast(std::string_view topic_name, uint64_t out[4]) const;
+
     // cpu_baseline only (oracle.cpp: orc_router_matches_timed): the reference's per-publish work without the
     // checker's canonicalisation; prepare_shaped() snapshots the relation maps with ref-counted strings.
     void prepare_shaped();
@@ -267,7 +275,7 @@ class DefaultRouter {   // router.rs:121-127
 
    private:
     struct Rel { Id id; SubscriptionOptions opts; uint32_t rel_id; };
-    struct FilterEntry { uint32_t filter_id; std::unordered_map<std::string, Rel> rels; };
+    struct FilterEntry { uint32_t filter_id; std::unordered_map<std::string, Rel> rels; FilterDigest dig; };
     struct ShapedEntry { std::shared_ptr<const std::string> client; const Rel* rel; };
     struct ShapedFilter { std::vector<ShapedEntry> rels; };
     SharedChoice shared_choice_;
@@ -277,6 +285,7 @@ class DefaultRouter {   // router.rs:121-127
     std::unordered_map<std::string, FilterEntry> relations_;   // AllRelationsMap, types.rs:476
     int64_t topics_count_ = 0, relations_count_ = 0;
     uint32_t next_filter_id_ = 0;
+    uint64_t mutations_ = 0, digests_at_ = ~0ull;   // prepare_digests() is valid for the mutation count it ran at
 };
 
 // ---------------------------------------------------------------- retain.rs

@@ -88,6 +88,8 @@ def lib():
         L.orc_retain_match_timed_dyn.restype = C.c_double
         L.orc_router_match_digest.argtypes = [vp, vp, vp, u64, C.c_int, vp, vp]; L.orc_router_match_digest.restype = None
         L.orc_retain_match_digest.argtypes = [vp, vp, vp, u64, C.c_int, vp, vp]; L.orc_retain_match_digest.restype = None
+        L.orc_router_match_digest_fast.argtypes = [vp, vp, vp, u64, C.c_int, vp, vp]; L.orc_router_match_digest_fast.restype = None
+        L.orc_retain_match_digest_fast.argtypes = [vp, vp, vp, u64, C.c_int, vp, vp]; L.orc_retain_match_digest_fast.restype = None
         _LIB = L
     return _LIB
 
@@ -218,13 +220,14 @@ class RetainTree:
         sec = fn(self._h, _ptr(blob), offsets.ctypes.data, len(offsets) - 1, threads, C.byref(h), C.byref(v))
         return float(sec), dict(hits=int(h.value), visited=int(v.value))
 
-    def match_digest(self, blob, offsets, threads=1):
-        """-> (status int32[n], digest uint64[n,3] = hits, sum of ids, sum of id^2 per filter)."""
+    def match_digest(self, blob, offsets, threads=1, fast=False):
+        """-> (status int32[n], digest uint64[n,3] = hits, sum of ids, sum of id^2 per filter).  fast: the same digests through
+        bottom-up subtree aggregates for the '#' step (orc_retain_match_digest_fast) — O(nodes walked outside a '#') per filter."""
         n = len(offsets) - 1
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         status = np.zeros(n, dtype=np.int32)
         out = np.zeros((n, 3), dtype=np.uint64)
-        lib().orc_retain_match_digest(self._h, _ptr(blob), offsets.ctypes.data, n, threads, status.ctypes.data, out.ctypes.data)
+        (lib().orc_retain_match_digest_fast if fast else lib().orc_retain_match_digest)(self._h, _ptr(blob), offsets.ctypes.data, n, threads, status.ctypes.data, out.ctypes.data)
         return status, out
 
     def match_batch(self, blob, offsets):
@@ -330,13 +333,14 @@ class DefaultRouter:
         sec = lib().orc_router_matches_timed(self._h, _ptr(blob), offsets.ctypes.data, len(offsets) - 1, threads, int(refcounted), C.byref(st))
         return float(sec), st.as_dict()
 
-    def match_digest(self, blob, offsets, threads=1):
-        """-> (status int32[n], digest uint64[n,4]) — see orc_router_match_digest (oracle.cpp)."""
+    def match_digest(self, blob, offsets, threads=1, fast=False):
+        """-> (status int32[n], digest uint64[n,4]) — see orc_router_match_digest (oracle.cpp).  fast: the same digests composed
+        from per-filter pre-reduced digests (orc_router_match_digest_fast) — O(matched filters) per topic instead of O(hits)."""
         n = len(offsets) - 1
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         status = np.zeros(n, dtype=np.int32)
         out = np.zeros((n, 4), dtype=np.uint64)
-        lib().orc_router_match_digest(self._h, _ptr(blob), offsets.ctypes.data, n, threads, status.ctypes.data, out.ctypes.data)
+        (lib().orc_router_match_digest_fast if fast else lib().orc_router_match_digest)(self._h, _ptr(blob), offsets.ctypes.data, n, threads, status.ctypes.data, out.ctypes.data)
         return status, out
 
 

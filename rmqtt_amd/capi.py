@@ -37,7 +37,7 @@ SYMBOLS = [
     "rgr_retain_topic_add", "rgr_retain_topic_remove", "rgr_retain_add_bulk", "rgr_retain_commit",
     "rgr_retain_match_batch", "rgr_retain_result_free", "rgr_retain_batch_create", "rgr_retain_batch_create_tier",
     "rgr_shard_assign", "rgr_stats_get", "rgr_stats_reset",
-    "rgr_comm_unique_id", "rgr_comm_create", "rgr_comm_destroy", "rgr_comm_allgather_u64", "rgr_comm_gather_pass",
+    "rgr_comm_unique_id", "rgr_comm_create", "rgr_comm_destroy", "rgr_comm_info", "rgr_comm_allgather_u64", "rgr_comm_gather_pass",
     "rgr_comm_replicate_subs", "rgr_comm_peer_subs", "rgr_comm_gather_runs_pass", "rgr_group_batch_gather_runs", "rgr_group_peer_subs",
     "rgr_group_create", "rgr_group_destroy", "rgr_group_size", "rgr_group_set_key_levels", "rgr_group_handle", "rgr_group_comm", "rgr_group_uses_rccl",
     "rgr_group_subscribe_bulk", "rgr_group_sub_attrs_bulk", "rgr_group_subscribe", "rgr_group_subscribe_ex", "rgr_group_unsubscribe", "rgr_group_commit",
@@ -48,6 +48,10 @@ GATHER_CONSUMER = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64
 RUN_DTYPE = np.dtype([("shard", np.uint32), ("src", np.uint32), ("len", np.uint32), ("topic", np.uint32)])      # == rgr_run
 SUB_ENTRY_DTYPE = np.dtype([("sub_id", np.uint32), ("qos_flags", np.uint32)])                                      # one subs[] entry
 RGR_COMM_ID_BYTES = 128
+
+
+class CommInfo(C.Structure):      # == rgr_comm_info_t
+    _fields_ = [("ranks", C.c_uint32), ("rank", C.c_uint32), ("device", C.c_int32), ("transport", C.c_int32)]
 
 
 class Config(C.Structure):
@@ -162,6 +166,7 @@ def lib():
         L.rgr_comm_create.argtypes = [vp, vp, u32, u32, C.POINTER(vp)]
         L.rgr_comm_destroy.argtypes = [vp]; L.rgr_comm_destroy.restype = None
         L.rgr_comm_allgather_u64.argtypes = [vp, u64, vp]
+        L.rgr_comm_info.argtypes = [vp, C.POINTER(CommInfo)]
         L.rgr_comm_gather_pass.argtypes = [vp, vp, GATHER_CONSUMER, vp, C.POINTER(u64), C.POINTER(u64)]
         L.rgr_group_create.argtypes = [C.POINTER(Config), vp, u32, C.POINTER(vp)]
         L.rgr_group_destroy.argtypes = [vp]; L.rgr_group_destroy.restype = None
@@ -540,6 +545,12 @@ class Comm:
         if self._c:
             lib().rgr_comm_destroy(self._c)
             self._c = C.c_void_p()
+
+    def info(self):
+        """What the transport reports: {"ranks": ncclCommCount, "rank": ncclCommUserRank, "device", "transport": "rccl" | "device copies"}."""
+        ci = CommInfo()
+        _check(lib().rgr_comm_info(self._c, C.byref(ci)))
+        return {"ranks": int(ci.ranks), "rank": int(ci.rank), "device": int(ci.device), "transport": "rccl" if ci.transport == 1 else "device copies"}
 
     def allgather_u64(self, mine):
         out = np.zeros(self.world, dtype=np.uint64)

@@ -175,6 +175,15 @@ extern "C" {
     pub fn rgr_comm_create(h: *mut rgr_handle, id: *const u8, rank: u32, world: u32, out: *mut *mut rgr_comm) -> i32;
     pub fn rgr_comm_destroy(c: *mut rgr_comm);
     pub fn rgr_comm_allgather_u64(c: *mut rgr_comm, mine: u64, all: *mut u64) -> i32;
+    pub fn rgr_comm_info(c: *mut rgr_comm, out: *mut rgr_comm_info_t) -> i32;
+}
+
+#[repr(C)]
+pub struct rgr_comm_info_t {
+    pub ranks: u32,
+    pub rank: u32,
+    pub device: i32,
+    pub transport: i32,
 }
 
 #[repr(C)]
