@@ -162,10 +162,10 @@ class _DevArr:      # zero-copy torch view of library-owned device memory
         self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
-FORMAT_NAMES = ("tuple", "soa", "packed", "runs")      # == RGR_FORMAT_*
+FORMAT_NAMES = ("tuple", "soa", "packed", "runs", "ids24")      # == RGR_FORMAT_*
 
 
-def gpu_digests(batch, n_topics, retain, fmt=0, subs_len=0, topic_ids_dev=None):
+def gpu_digests(batch, n_topics, retain, fmt=0, subs_len=0, topic_ids_dev=None, qos_by_sub=None):
     """Per-topic digests of EVERY window of one full pass in result format `fmt`, reduced on the device (torch is plumbing
     here: the hits were produced by the library's kernels; the per-topic sums are prefix-sum differences because a topic's
     hits are consecutive positions).  -> (int64 device tensor [n, 4] (router) / [n, 3] (retain) with the same definition as
@@ -214,6 +214,11 @@ def gpu_digests(batch, n_topics, retain, fmt=0, subs_len=0, topic_ids_dev=None):
         elif fmt == capi.RGR_FORMAT_PACKED:
             x = torch.as_tensor(_DevArr(w.d_sub_ids, (nh,), "<i4"), device="cuda").to(torch.int64) & M32
             sid, q = x & 0x3FFFFFFF, x >> 30
+        elif fmt == capi.RGR_FORMAT_IDS24:           # 3 little-endian bytes per hit; the qos is table data, looked up by sub id
+            x = torch.as_tensor(_DevArr(w.d_ids24, (nh, 3), "|u1"), device="cuda").to(torch.int64)
+            sid = x[:, 0] | (x[:, 1] << 8) | (x[:, 2] << 16)
+            q = qos_by_sub[sid] if qos_by_sub is not None else torch.zeros_like(sid)
+            del x
         else:                                        # runs: the hits are read in place from the epoch's subs[]
             nr = int(w.n_runs)
             src = torch.as_tensor(_DevArr(w.d_run_src, (nr,), "<i4"), device="cuda").to(torch.int64) & M32
@@ -319,7 +324,7 @@ def delivery_parity(batch, W, pa, n_windows_wanted=3):
             "what": "delivery words of whole windows of the timed batch (first / middle / last) vs a torch restatement of the per-hit rules on the device"}
 
 
-def device_digests(r, batch, n, retain, formats=True, topic_ids=None):
+def device_digests(r, batch, n, retain, formats=True, topic_ids=None, qos=None):
     """ONE full pass of the timed batch per result format (tuple, soa, packed, runs), every window digested per topic on the device.
     The compact formats' digests must equal the tuple format's for EVERY topic, and each pass is checked structurally (windows
     tile the batch, topic columns restate the CSR offsets; with `topic_ids` — a sharded batch — the tuple's topic column must
@@ -330,13 +335,14 @@ def device_digests(r, batch, n, retain, formats=True, topic_ids=None):
     subs_len = 0 if retain else int(r.stats()["n_subs"])
     ids_dev = torch.from_numpy(np.ascontiguousarray(topic_ids).astype(np.int32)).cuda() if topic_ids is not None else None
     D, fmt_ok, struct, runs_pt, info0 = None, {}, {}, None, {}
-    fmts = (capi.RGR_FORMAT_TUPLE, capi.RGR_FORMAT_SOA, capi.RGR_FORMAT_PACKED, capi.RGR_FORMAT_RUNS) if formats else (capi.RGR_FORMAT_TUPLE,)
+    fmts = (capi.RGR_FORMAT_TUPLE, capi.RGR_FORMAT_SOA, capi.RGR_FORMAT_PACKED, capi.RGR_FORMAT_RUNS, capi.RGR_FORMAT_IDS24) if formats else (capi.RGR_FORMAT_TUPLE,)
+    qos_by_sub = torch.from_numpy(np.ascontiguousarray(qos).astype(np.int64)).cuda() if (qos is not None and not retain) else None
     for fmt in fmts:
         name = FORMAT_NAMES[fmt]
         if topic_ids is not None:          # only the tuple format's topic column is checked against the global ids; the other passes index locally
             batch.set_topic_ids(topic_ids if fmt == capi.RGR_FORMAT_TUPLE else None)
         try:
-            d, ok_s, info = gpu_digests(batch, n, retain, fmt, subs_len, ids_dev if fmt == capi.RGR_FORMAT_TUPLE else None)
+            d, ok_s, info = gpu_digests(batch, n, retain, fmt, subs_len, ids_dev if fmt == capi.RGR_FORMAT_TUPLE else None, qos_by_sub)
         except capi.RgrError as e:                   # (packed needs ids below 2^30)
             fmt_ok[name] = f"n/a: {e}"
             continue
@@ -411,19 +417,19 @@ def compare_with_oracle(o, W, got, gpu_status, fmt_ok, dinfo, threads, primary, 
 
 def parity_sample(r, o, W, batch, threads, primary):
     """N = 1: device digests of the whole timed batch in every format, then the exhaustive comparison with the oracle."""
-    D, fmt_ok, dinfo = device_digests(r, batch, W["n_pub"], W["retain"])
+    D, fmt_ok, dinfo = device_digests(r, batch, W["n_pub"], W["retain"], qos=W["qos"])
     got = D.cpu().numpy().view(np.uint64)
     del D
     return compare_with_oracle(o, W, got, batch.status(), fmt_ok, dinfo, threads, primary)
 
 
-def sharded_digests(r, batch, keep_t, n_pub, world, rank, dist, cdev, formats=True):
+def sharded_digests(r, batch, keep_t, n_pub, world, rank, dist, cdev, formats=True, qos=None):
     """N > 1 (collective): every rank digests ITS topics on its device (all formats; the tuple pass also checks that the tuples carry
     the global publish index), rank 0 receives every rank's rows and assembles the digests of the whole batch in batch order.
     -> on rank 0: (uint64 [n_pub, 4], status int32 [n_pub], per-format verdicts, info); None elsewhere."""
     import torch
     my = len(keep_t)
-    D, fmt_ok, dinfo = device_digests(r, batch, my, False, formats=formats, topic_ids=keep_t.astype(np.uint32))
+    D, fmt_ok, dinfo = device_digests(r, batch, my, False, formats=formats, topic_ids=keep_t.astype(np.uint32), qos=qos)
     rows = torch.zeros((my, 6), dtype=torch.int64)
     rows[:, 0] = torch.from_numpy(keep_t.astype(np.int64))
     rows[:, 1] = torch.from_numpy(batch.status().astype(np.int64))
@@ -728,7 +734,7 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
     # ---- N > 1: per-topic digests of every rank's pass, assembled on rank 0 (collective), compared with the oracle below
     gathered = None
     if world > 1 and not args.no_parity:
-        gathered = sharded_digests(r, batch, keep_t, n_pub, world, rank, dist, cdev, formats=not args.no_formats)
+        gathered = sharded_digests(r, batch, keep_t, n_pub, world, rank, dist, cdev, formats=not args.no_formats, qos=qos)
     if comm is not None:
         comm.close()
     if world > 1:
@@ -816,6 +822,7 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
     if world == 1 and deliver < 0 and not args.no_formats:
         rec["compact_formats"] = []
         for name, fmt, bph in (("soa: sub_id u32[] + qos u8[]", capi.RGR_FORMAT_SOA, 5), ("packed: sub_id | qos << 30 u32[]", capi.RGR_FORMAT_PACKED, 4),
+                               ("ids24: sub_id as 3 little-endian bytes u8[3n] (the qos is table data, indexed by sub id)", capi.RGR_FORMAT_IDS24, 3),
                                ("runs: (topic, subscriber-run) descriptors, hits read in place from the epoch's subs[]", capi.RGR_FORMAT_RUNS, 0)):
             try:
                 batch.set_format(fmt)
@@ -1042,9 +1049,10 @@ def measure_router_e2e(args):
     L.hr_stale_expansions.argtypes = [vp]; L.hr_stale_expansions.restype = C.c_uint64
     L.hr_restore_bulk.argtypes = [vp, vp, vp, vp, vp, C.c_uint64]
     L.hr_e2e_run.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, vp, vp, vp, C.c_uint32, vp]
+    L.hr_e2e_run_async.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, vp, vp, vp, C.c_uint32, vp]
     cores = args.cpu_threads or os.cpu_count() or 1
     out = []
-    for cfg in (2, 3):
+    for cfg in [int(x) for x in args.e2e_configs.split(",")]:
         W = gen_workload(cfg, args.scale)
         n_t = int(min(W["n_pub"], 200_000))
         tb, to = prefix(W, n_t)
@@ -1072,6 +1080,28 @@ def measure_router_e2e(args):
                                "publishes": int(res[0]), "wall_s": round(wall.value, 2),
                                "latency_us": {"p50": round(float(l[len(l) // 2]), 1), "p99": round(float(l[int(len(l) * 0.99)]), 1)} if len(l) else None})
             log(f"router e2e config {cfg}: {rec['gpu'][-1]}")
+        # ---- the boundary at its design point: publishes submitted asynchronously (what tokio's task-level concurrency gives the
+        # reference's callers, shared.rs:772): a few submitter threads keep `outstanding` publishes in flight, up to `passes` device passes
+        # overlap, the completions (each publish's SubRelationsMap) are built on `workers` pool threads
+        rec["gpu_async"] = []
+        L.hr_set_match_mode(g, 1)
+        shapes = [(args.e2e_submitters, args.e2e_outstanding, args.e2e_workers or max(8, min(64, cores // 4)), args.e2e_passes)]
+        if args.e2e_sweep:
+            shapes += [(4, 8192, 32, 2), (8, 32768, 64, 3), (16, 65536, 96, 4), (8, 16384, 32, 1)]
+        for subm, outst, workers, passes in shapes:
+            res = (C.c_uint64 * 4)()
+            wall = C.c_double(0)
+            lat = np.zeros(400_000, dtype=np.float32)
+            nl = C.c_uint32(0)
+            L.hr_e2e_run_async(g, tb.ctypes.data, to.ctypes.data, n_t, subm, outst, workers, passes, 4096, 200, 1.0, res, C.byref(wall), None, 0, None)      # warm
+            L.hr_e2e_run_async(g, tb.ctypes.data, to.ctypes.data, n_t, subm, outst, workers, passes, 4096, 200, 5.0 if cfg == 2 else 4.0, res, C.byref(wall),
+                               lat.ctypes.data, len(lat), C.byref(nl))
+            l = np.sort(lat[:nl.value])
+            rec["gpu_async"].append({"submitters": subm, "outstanding": outst, "workers": workers, "passes_in_flight": passes,
+                                     "value": round(res[0] / wall.value, 1), "rows_per_s": round(res[1] / wall.value, 1), "device_passes": int(res[2]),
+                                     "publishes_per_pass": round(res[0] / max(1, res[2]), 1), "errors": int(res[3]), "wall_s": round(wall.value, 2),
+                                     "latency_us": {"p50": round(float(l[len(l) // 2]), 1), "p99": round(float(l[int(len(l) * 0.99)]), 1)} if len(l) else None})
+            log(f"router e2e config {cfg} async: {rec['gpu_async'][-1]}")
         L.hr_free(g)
         o = orc.DefaultRouter()
         o.add_bulk(W["blob"], W["offs"], W["client"], W["qos"])
@@ -1082,12 +1112,47 @@ def measure_router_e2e(args):
         rec["cpu_reference_port"] = {"value": round(n_c / sec, 1), "rows_per_s": round(ost["hits"] / sec, 1), "threads": cores, "kind": "port",
                                      "what": "oracle DefaultRouter::_matches-shaped pass (router.rs:174-265), per-hit ref-counted clones", "sample": n_c,
                                      "single_thread": round(max(50, n_c // cores * 2) / sec1, 1)}
-        best = max(x["value"] for x in rec["gpu"])
+        best = max(x["value"] for x in rec["gpu"] + rec["gpu_async"])
         rec["value"] = best
+        rec["value_blocking_callers"] = max(x["value"] for x in rec["gpu"])
+        rec["value_async_submit"] = max(x["value"] for x in rec["gpu_async"])
         rec["vs_cpu_port"] = round(best / rec["cpu_reference_port"]["value"], 2)
         del o
         out.append(rec)
         print(json.dumps(rec), flush=True)
+    return 0
+
+
+def time_format(args):
+    """--time-format NAME: build the config's table, then time `--steps` passes of ONE result format and nothing else (no parity, no
+    baseline, no secondaries) — the quick A/B line for kernel geometry sweeps, and the command to put under `rocprofv3 --kernel-trace`
+    (tools/trace_gaps.py turns the trace into busy time, idle gaps and per-kernel totals of a pass)."""
+    import torch
+    from rmqtt_amd import capi
+    W = gen_workload(args.config, args.scale)
+    fmt = FORMAT_NAMES.index(args.time_format)
+    r = capi.Router(device=0, window_hits=args.window_hits, collect_walk_stats=False)
+    build_table(r, W, W["blob"], W["offs"], np.arange(W["n_sub"], dtype=np.uint32), W["qos"])
+    batch = r.retain_batch(W["tb"], W["to"]) if W["retain"] else r.batch(W["tb"], W["to"])
+    batch.set_format(fmt)
+    for _ in range(args.warmup):
+        batch.run()
+    r.stats_reset()
+    torch.cuda.synchronize()
+    t = time.time()
+    for _ in range(args.steps):
+        hits, nwin = batch.run()
+    dt = time.time() - t
+    st = r.stats()
+    bph = {"tuple": 12, "soa": 5, "packed": 4, "runs": 0, "ids24": 3}[args.time_format]
+    print(json.dumps({"format": args.time_format, "config": args.config, "scale": args.scale, "window_hits": args.window_hits or "default",
+                      "value": round(W["n_pub"] * args.steps / dt, 1), "ms_per_step": round(dt * 1e3 / args.steps, 3), "windows_per_step": int(nwin),
+                      "hits_per_step": int(hits), "kernel_ms_per_step": {"walk": round(st["walk_ms"] / args.steps, 3), "scan_compact_tiles": round(st["scan_ms"] / args.steps, 3),
+                                                                          "expand": round(st["expand_ms"] / args.steps, 3)},
+                      "expand_avg_launch_ms": round(st["expand_ms"] / max(1, st["expand_launches"]), 4),
+                      "expand_store_GBps": round(hits * args.steps * bph / max(1e-9, st["expand_ms"] / 1e3) / 1e9, 1),
+                      "extra_flags": os.environ.get("RGR_EXTRA_FLAGS", "")}), flush=True)
+    batch.close(); r.close()
     return 0
 
 
@@ -1136,6 +1201,13 @@ def main():
     ap.add_argument("--deliver", type=float, default=-1.0, metavar="V5FRAC",
                     help="also run the delivery stage (SURVEY 8(f)-1): this fraction of the subscriptions is MQTT v5 "
                          "(No Local / RAP / per-client dedup); 0 = v3 only. Not the headline metric.")
+    ap.add_argument("--e2e-submitters", type=int, default=8)
+    ap.add_argument("--e2e-outstanding", type=int, default=16384)
+    ap.add_argument("--e2e-workers", type=int, default=0, help="completion pool threads (0 = cores / 4, at most 64)")
+    ap.add_argument("--e2e-passes", type=int, default=3, help="device passes in flight")
+    ap.add_argument("--e2e-sweep", action="store_true", help="--router-e2e: also run a few other (submitters, outstanding, workers, passes) shapes")
+    ap.add_argument("--e2e-configs", default="2,3")
+    ap.add_argument("--time-format", choices=list(FORMAT_NAMES), default=None, help="time passes of ONE result format only and exit (sweeps, kernel traces)")
     ap.add_argument("--router-e2e", action="store_true", help="time Router::matches through the host Router mirror + batcher beside the CPU port (configs 2 and 3)")
     ap.add_argument("--group", type=int, default=0, metavar="SHARDS",
                     help="run the single-process sharded router (rgr_group_*) with this many shards on the visible GPUs instead of the N=1 bench")
@@ -1145,6 +1217,8 @@ def main():
 
     if args.pmc_child:
         return pmc_child(args)
+    if args.time_format:
+        return time_format(args)
     if args.group > 0:
         return measure_group(args)
     if args.router_e2e:

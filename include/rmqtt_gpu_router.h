@@ -208,6 +208,7 @@ typedef struct rgr_window {
     const uint32_t* d_run_topic;      /* [n_runs] topic index (or rgr_batch_set_topic_ids' id) */
     const uint64_t* d_run_off;        /* [n_runs + 1]                                    */
     const uint64_t* d_subs;           /* the epoch's subscriber entries, 8 bytes each    */
+    const uint8_t* d_ids24;           /* [3 * n_hits] RGR_FORMAT_IDS24: sub ids as 3 little-endian bytes each; NULL otherwise */
 } rgr_window;
 
 /* Result format of a device-resident batch.  The 12-byte tuple is BASELINE.json's (topic_idx, subscriber_id,
@@ -219,9 +220,14 @@ enum {
     RGR_FORMAT_SOA = 1,               /* d_sub_ids u32[n_hits] + d_qos u8[n_hits], 5 B/hit                        */
     RGR_FORMAT_PACKED = 2,            /* d_sub_ids u32[n_hits] = sub_id | qos << 30, 4 B/hit; needs sub ids < 2^30
                                          (rgr_batch_begin fails with RGR_ECAPACITY otherwise)                  */
-    RGR_FORMAT_RUNS = 3               /* run descriptors only (d_run_*): a hit list is the concatenation of subscriber
+    RGR_FORMAT_RUNS = 3,              /* run descriptors only (d_run_*): a hit list is the concatenation of subscriber
                                          runs that already sit in HBM, so a device-side consumer (a fan-out kernel) can
                                          read them in place — 16 B per (topic, matched filter) instead of bytes per hit */
+    RGR_FORMAT_IDS24 = 4              /* d_ids24 u8[3 * n_hits]: the sub id of every hit as 3 little-endian bytes, 3 B/hit; needs
+                                         sub ids < 2^24 (rgr_batch_begin fails with RGR_ECAPACITY otherwise).  The qos is not
+                                         carried: it is a property of the subscription, which the consumer indexes by sub id.
+                                         At config-3 fan-out the bytes per hit ARE the pass: 592 GB per 10 M publishes at 4 B/hit
+                                         cannot leave the chip in under 94 ms at its ~6.3 TB/s store ceiling; 444 GB can. */
 };
 
 typedef struct rgr_stats {

@@ -223,13 +223,17 @@ struct rgr_batch {
         RGR_HIP(hipEventCreate(&e));
         return e;
     }
+    // RGR_SPAN_SAMPLE=0 (diagnostic): no event pairs around the per-window launches — what the per-kernel timing itself costs a pass
+    static bool spans_on() { static const bool on = [] { const char* e = std::getenv("RGR_SPAN_SAMPLE"); return !(e && e[0] == '0'); }(); return on; }
+    static constexpr size_t kNoSpan = ~size_t(0);
     size_t span_begin(int kind, hipStream_t on = nullptr) {
+        if (!spans_on()) return kNoSpan;
         Span s{get_event(), get_event(), kind};
         RGR_HIP(hipEventRecord(s.a, on ? on : stream));
         spans.push_back(s);
         return spans.size() - 1;
     }
-    void span_end(size_t i, hipStream_t on = nullptr) { RGR_HIP(hipEventRecord(spans[i].b, on ? on : stream)); }
+    void span_end(size_t i, hipStream_t on = nullptr) { if (i != kNoSpan) RGR_HIP(hipEventRecord(spans[i].b, on ? on : stream)); }
     ChunkSlot* other_slot() { return c == &cs[0] ? &cs[1] : &cs[0]; }
     void resolve_spans() {   // stream must be synchronised
         for (auto& s : spans) {
@@ -1199,10 +1203,10 @@ int32_t rgr_batch_set_topic_ids(rgr_batch* b, const uint32_t* ids) {
 }
 
 int32_t rgr_batch_set_format(rgr_batch* b, uint32_t format) {
-    if (!b || format > RGR_FORMAT_RUNS) return fail(RGR_EINVAL, "rgr_batch_set_format: bad argument");
+    if (!b || format > RGR_FORMAT_IDS24) return fail(RGR_EINVAL, "rgr_batch_set_format: bad argument");
     if (b->in_pass) return fail(RGR_ESTATE, "rgr_batch_set_format: inside a pass");
     if (format != RGR_FORMAT_TUPLE && b->deliver) return fail(RGR_ESTATE, "rgr_batch_set_format: the delivery stage needs RGR_FORMAT_TUPLE");
-    static_assert(RGR_FORMAT_TUPLE == kFmtTuple && RGR_FORMAT_SOA == kFmtSoa && RGR_FORMAT_PACKED == kFmtPacked && RGR_FORMAT_RUNS == kFmtRuns, "format constants");
+    static_assert(RGR_FORMAT_TUPLE == kFmtTuple && RGR_FORMAT_SOA == kFmtSoa && RGR_FORMAT_PACKED == kFmtPacked && RGR_FORMAT_RUNS == kFmtRuns && RGR_FORMAT_IDS24 == kFmtIds24, "format constants");
     b->format = int(format);
     return RGR_OK;
 }
@@ -1226,6 +1230,8 @@ int32_t rgr_batch_begin(rgr_batch* b) {
         }
         if (b->format == kFmtPacked && (b->retain ? b->repoch->max_id : b->epoch->max_sub_id) >= (1u << 30))
             return fail(RGR_ECAPACITY, "rgr_batch_begin: RGR_FORMAT_PACKED needs ids below 2^30");
+        if (b->format == kFmtIds24 && (b->retain ? b->repoch->max_id : b->epoch->max_sub_id) >= (1u << 24))
+            return fail(RGR_ECAPACITY, "rgr_batch_begin: RGR_FORMAT_IDS24 needs ids below 2^24");
         for (ChunkSlot& cs : b->cs) {          // a pass abandoned midway may have left a prefetch behind
             if (cs.inflight) { RGR_HIP(hipEventSynchronize(cs.done)); cs.inflight = false; }
             cs.ready = false;
@@ -1296,7 +1302,7 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
             const uint32_t T = expand_tile_hits();
             DevBuf& outbuf = b->alt_out ? b->out2 : b->out;
             const uint64_t ids_bytes = (nh * 4 + 255) & ~uint64_t(255);           // compact formats: sub ids, then the qos bytes
-            outbuf.ensure(b->format == kFmtTuple ? nh * sizeof(Tuple) : ids_bytes + (b->format == kFmtSoa ? nh + 16 : 0));
+            outbuf.ensure(b->format == kFmtTuple ? nh * sizeof(Tuple) : b->format == kFmtIds24 ? nh * 3 + 16 : ids_bytes + (b->format == kFmtSoa ? nh + 16 : 0));
             b->tile_first.ensure(((nh + T - 1) / T) * sizeof(TileRec));
             ChunkArrays ca = make_chunk_arrays(b, n);
             size_t sp = b->span_begin(kSpanScan);
@@ -1332,7 +1338,7 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
                                       outbuf.as<uint32_t>(), outbuf.as<uint8_t>() + ids_bytes, b->stream);
             b->span_end(sp);
             // the chunk's accounting charged 20 B per hit (8 read + 12 written); the compact formats write 5 / 4
-            if (b->format != kFmtTuple) b->local.alg_bytes_expand -= nh * (b->format == kFmtSoa ? 7 : 8);
+            if (b->format != kFmtTuple) b->local.alg_bytes_expand -= nh * (b->format == kFmtSoa ? 7 : b->format == kFmtIds24 ? 9 : 8);
             b->local.expand_launches++;
             if (dedup) {
                 // LDS tables (tile-local, then one block per spanning topic); stream-ordered, no host synchronisation
@@ -1392,6 +1398,7 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
             w->d_tuples = b->format == kFmtTuple ? reinterpret_cast<const rgr_tuple*>(op) : nullptr;
             w->d_sub_ids = (b->format == kFmtSoa || b->format == kFmtPacked) && nh ? static_cast<const uint32_t*>(op) : nullptr;
             w->d_qos = b->format == kFmtSoa && nh ? static_cast<const uint8_t*>(op) + ids_bytes : nullptr;
+            w->d_ids24 = b->format == kFmtIds24 && nh ? static_cast<const uint8_t*>(op) : nullptr;
         }
         w->d_hit_offsets = b->c->hit_off.as<uint64_t>() + lc;
         w->offsets_bias = hit_lo;

@@ -791,6 +791,9 @@ __global__ __launch_bounds__(kThreads) void expand_kernel(const SubEntry* __rest
 // position belongs to.  The compact formats write only what is new per hit (SURVEY.md §8(b)'s SoA result):
 //   kFmtSoa     out_ids[pos] = sub_id (u32), out_qos[pos] = qos | flags << 2 (u8)        5 B/hit
 //   kFmtPacked  out_ids[pos] = sub_id | qos << 30 (u32; sub ids < 2^30)                   4 B/hit
+//   kFmtIds24   bytes [3 pos, 3 pos + 3) = sub_id, little endian (sub ids < 2^24)          3 B/hit: a lane's four positions are 12
+//               contiguous bytes = ONE dwordx3 store, consecutive lanes on consecutive 12-byte groups — the store shape of the
+//               tuple kernel (the qos is table data the consumer indexes by sub id; at config 3 the bytes per hit ARE the pass)
 // Same tiles and staged pair view as expand_kernel, but a lane owns groups of FOUR CONSECUTIVE positions, so a
 // wave stores 1 KiB of sub ids with one dwordx4 per lane (and 256 B of qos bytes with one dword per lane)
 // instead of 768 B of strided 12-byte tuples.  With a third of the store bytes the kernel is no longer bound by
@@ -799,8 +802,33 @@ __global__ __launch_bounds__(kThreads) void expand_kernel(const SubEntry* __rest
 #ifndef RGR_COMPACT_THREADS
 #define RGR_COMPACT_THREADS 256      // threads per 2048-hit tile: 256 x two groups of four consecutive positions (sweep: profiles/)
 #endif
+#ifndef RGR_COMPACT_NT
+#define RGR_COMPACT_NT 1               // nontemporal stores of the compact formats
+#endif
+#ifndef RGR_COMPACT_TILES
+#define RGR_COMPACT_TILES 1            // consecutive tiles expanded by one block (sweep: profiles/r04*)
+#endif
 constexpr int kCompactThreads = RGR_COMPACT_THREADS;
+constexpr int kCompactTilesPerBlock = RGR_COMPACT_TILES;
 constexpr int kCompactGroups = kTile / (kCompactThreads * 4);
+// four 24-bit ids = three words at a 4-byte-aligned address (three dword stores that the backend merges into one dwordx3, as in the
+// tuple kernel)
+__device__ __forceinline__ void ids24_store(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint8_t* p) {
+    uint32_t* q = reinterpret_cast<uint32_t*>(p);
+    const uint32_t w0 = a | (b << 24), w1 = (b >> 8) | (c << 16), w2 = (c >> 16) | (d << 8);
+#if RGR_COMPACT_NT
+    __builtin_nontemporal_store(w0, q); __builtin_nontemporal_store(w1, q + 1); __builtin_nontemporal_store(w2, q + 2);
+#else
+    q[0] = w0; q[1] = w1; q[2] = w2;
+#endif
+}
+template <class T> __device__ __forceinline__ void compact_store(T v, T* p) {
+#if RGR_COMPACT_NT
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
 static_assert(kCompactGroups >= 1 && kCompactGroups * kCompactThreads * 4 == kTile, "compact expansion geometry must cover the tile");
 
 template <int FMT>
@@ -811,7 +839,7 @@ __global__ __launch_bounds__(kCompactThreads) void expand_compact_kernel(const S
                                                                          uint8_t* __restrict__ out_qos) {
     __shared__ int32_t s_off[kTile + 2];
     __shared__ uint32_t s_src[kTile + 2];
-    const uint32_t tile = blockIdx.x;
+  for (uint32_t tile = blockIdx.x * kCompactTilesPerBlock, tile_end = min(ntiles, (blockIdx.x + 1) * kCompactTilesPerBlock); tile < tile_end; ++tile) {
     const uint64_t base = hit_lo + uint64_t(tile) * kTile;
     const uint32_t len = (hit_hi - base) < uint64_t(kTile) ? uint32_t(hit_hi - base) : uint32_t(kTile);
     const TileRec rec = tile_first[tile];
@@ -838,24 +866,36 @@ __global__ __launch_bounds__(kCompactThreads) void expand_compact_kernel(const S
             uint32_t* o = out_ids + (base - hit_lo) + p0;
             if (p0 + 4 <= len) {
                 v4 v; uint32_t q;
+                if (FMT == kFmtIds24) {
+                    // a | b << 24,  b >> 8 | c << 16,  c >> 16 | d << 8: four 24-bit ids in three words
+                    const uint32_t a = x[g].v.x, b3 = x[g].v.z, c3 = y[g].v.x, d3 = y[g].v.z;
+                    ids24_store(a, b3, c3, d3, reinterpret_cast<uint8_t*>(out_ids) + ((base - hit_lo) + p0) * 3);
+                    continue;
+                }
                 if (FMT == kFmtPacked) { v.x = x[g].v.x | (x[g].v.y << 30); v.y = x[g].v.z | (x[g].v.w << 30); v.z = y[g].v.x | (y[g].v.y << 30); v.w = y[g].v.z | (y[g].v.w << 30); q = 0; }
                 else {
                     v.x = x[g].v.x; v.y = x[g].v.z; v.z = y[g].v.x; v.w = y[g].v.z;
                     auto qb = [](uint32_t qf) { return (qf & 3u) | (((qf >> 8) & 0x3Fu) << 2); };
                     q = qb(x[g].v.y) | (qb(x[g].v.w) << 8) | (qb(y[g].v.y) << 16) | (qb(y[g].v.w) << 24);
                 }
-                __builtin_nontemporal_store(v, reinterpret_cast<v4*>(o));
-                if (FMT == kFmtSoa) __builtin_nontemporal_store(q, reinterpret_cast<uint32_t*>(out_qos + (base - hit_lo) + p0));
+                compact_store(v, reinterpret_cast<v4*>(o));
+                if (FMT == kFmtSoa) compact_store(q, reinterpret_cast<uint32_t*>(out_qos + (base - hit_lo) + p0));
             } else {
                 for (uint32_t j = 0; p0 + j < len; ++j) {
                     const SubEntry se1 = run[p0 + j];
+                    if (FMT == kFmtIds24) {
+                        uint8_t* ob = reinterpret_cast<uint8_t*>(out_ids) + ((base - hit_lo) + p0 + j) * 3;
+                        ob[0] = uint8_t(se1.sub_id); ob[1] = uint8_t(se1.sub_id >> 8); ob[2] = uint8_t(se1.sub_id >> 16);
+                        continue;
+                    }
                     o[j] = FMT == kFmtPacked ? (se1.sub_id | (se1.qos_flags << 30)) : se1.sub_id;
                     if (FMT == kFmtSoa) out_qos[(base - hit_lo) + p0 + j] = uint8_t((se1.qos_flags & 3u) | (((se1.qos_flags >> 8) & 0x3Fu) << 2));
                 }
             }
         }
-        return;
+        continue;
     }
+    if (kCompactTilesPerBlock > 1) __syncthreads();                     // the previous tile's readers of s_off / s_src are done
     for (uint32_t i = threadIdx.x; i < np; i += kCompactThreads) {
         uint32_t topic_unused;
         tile_pair_view(c, a, i, base, s_off[i], s_src[i], topic_unused);
@@ -901,10 +941,19 @@ __global__ __launch_bounds__(kCompactThreads) void expand_compact_kernel(const S
             else { w[j] = se[g][j].sub_id; q |= ((qf & 3u) | (((qf >> 8) & 0x3Fu) << 2)) << (8 * j); }
         }
         uint32_t* o = out_ids + (base - hit_lo) + p0;
+        if (FMT == kFmtIds24) {
+            uint8_t* ob = reinterpret_cast<uint8_t*>(out_ids) + ((base - hit_lo) + p0) * 3;
+            if (p0 + 4 <= len) {
+                ids24_store(w[0], w[1], w[2], w[3], ob);
+            } else {
+                for (uint32_t j = 0; p0 + j < len; ++j) { ob[3 * j] = uint8_t(w[j]); ob[3 * j + 1] = uint8_t(w[j] >> 8); ob[3 * j + 2] = uint8_t(w[j] >> 16); }
+            }
+            continue;
+        }
         if (p0 + 4 <= len) {
             v4 v; v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
-            __builtin_nontemporal_store(v, reinterpret_cast<v4*>(o));
-            if (FMT == kFmtSoa) __builtin_nontemporal_store(q, reinterpret_cast<uint32_t*>(out_qos + (base - hit_lo) + p0));
+            compact_store(v, reinterpret_cast<v4*>(o));
+            if (FMT == kFmtSoa) compact_store(q, reinterpret_cast<uint32_t*>(out_qos + (base - hit_lo) + p0));
         } else {
             for (uint32_t j = 0; p0 + j < len; ++j) {
                 o[j] = w[j];
@@ -912,6 +961,7 @@ __global__ __launch_bounds__(kCompactThreads) void expand_compact_kernel(const S
             }
         }
     }
+  }
 }
 
 // --------------------------------------------------------------------------- v5 per-client dedup
@@ -1266,8 +1316,10 @@ void launch_expand_compact(const TrieView& t, const ChunkArrays& c, uint64_t pai
     if (hit_hi <= hit_lo) return;
     const uint32_t ntiles = uint32_t((hit_hi - hit_lo + kTile - 1) / kTile);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (format == kFmtPacked) expand_compact_kernel<kFmtPacked><<<ntiles, kCompactThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out_ids, out_qos);
-    else expand_compact_kernel<kFmtSoa><<<ntiles, kCompactThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out_ids, out_qos);
+    const uint32_t nblocks = (ntiles + kCompactTilesPerBlock - 1) / kCompactTilesPerBlock;
+    if (format == kFmtIds24) expand_compact_kernel<kFmtIds24><<<nblocks, kCompactThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out_ids, out_qos);
+    else if (format == kFmtPacked) expand_compact_kernel<kFmtPacked><<<nblocks, kCompactThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out_ids, out_qos);
+    else expand_compact_kernel<kFmtSoa><<<nblocks, kCompactThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out_ids, out_qos);
 }
 
 void launch_pack_runs(const uint32_t* src, const uint32_t* topic, const uint64_t* off, uint64_t n, uint32_t shard, RunDesc* out, void* stream) {
@@ -1298,7 +1350,8 @@ void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, uint32_t ntiles,
     dedup_classify_kernel<<<(nt + 255) / 256, 256, 0, s>>>(tile_ncand, nt, hit_off, hit_lo, items, item_count);
     // the item count stays on the device: a fixed grid of persistent blocks (4 per CU fit) strides over the items
     // RGR_DEDUP_TEST_SLOTS (tests only): a smaller table, so that parts overflow and the re-split path runs on ordinary inputs
-    static const uint32_t max_slots = [] {
+    // (read on every launch — it is one getenv — so that a test can set it after other tests of the same process have launched)
+    const uint32_t max_slots = [] {
         const char* e = std::getenv("RGR_DEDUP_TEST_SLOTS");
         uint32_t v = e ? uint32_t(std::atoi(e)) : 0u, p2 = 64;
         while (p2 < v && p2 < uint32_t(kDedupTopicSlots)) p2 <<= 1;

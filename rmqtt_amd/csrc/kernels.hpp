@@ -234,7 +234,7 @@ void launch_tiles(const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint
 void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint64_t hit_hi,
                    const TileRec* tile_first, Tuple* out, void* stream, const DeliverArgs* deliver = nullptr);
 // compact result formats (rgr_batch_set_format): sub ids (+ a qos byte array) without the topic column
-constexpr int kFmtTuple = 0, kFmtSoa = 1, kFmtPacked = 2, kFmtRuns = 3;     // == RGR_FORMAT_*
+constexpr int kFmtTuple = 0, kFmtSoa = 1, kFmtPacked = 2, kFmtRuns = 3, kFmtIds24 = 4;     // == RGR_FORMAT_*
 void launch_expand_compact(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint64_t hit_hi,
                            const TileRec* tile_first, int format, uint32_t* out_ids, uint8_t* out_qos, void* stream);
 // v5 per-client dedup over a window's candidates (match_core.hpp: LDS tile tables + LDS topic tables): first position per

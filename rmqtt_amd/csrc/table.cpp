@@ -155,13 +155,18 @@ void HostTable::rehash(uint64_t new_cap) {
         if (e.parent == kEdgeEmpty) continue;
         const uint32_t pc = nodes_[e.child].plus_child;
         e.plus_slot = pc == kNone ? kNone : nodes_[pc].slot;
-        e.lit_lo = e.lit_hi = 0;
     }
     const uint32_t rp = nodes_[0].plus_child;
     root_hdr_.plus_slot = rp == kNone ? kNone : nodes_[rp].slot;
+    rebuild_child_bitmaps();
+}
+
+// The 64-bit child-token bitmap of every node header, exactly, from the live literal edges.
+void HostTable::rebuild_child_bitmaps() {
+    for (EdgeEntry& e : edges_) if (e.parent != kEdgeEmpty) e.lit_lo = e.lit_hi = 0;
     root_hdr_.lit_lo = root_hdr_.lit_hi = 0;
     for (const EdgeEntry& e : edges_) {
-        if (e.parent == kEdgeEmpty || e.token < kTokFirst) continue;
+        if (e.parent == kEdgeEmpty || e.parent == kEdgeTomb || e.token < kTokFirst) continue;
         const uint32_t b = lit_bit(e.token), m = 1u << (b & 31u);
         if (e.parent == 0) ((b & 32u) ? root_hdr_.lit_hi : root_hdr_.lit_lo) |= m;
         else { EdgeEntry& p = edges_[nodes_[e.parent].slot]; ((b & 32u) ? p.lit_hi : p.lit_lo) |= m; }
@@ -629,7 +634,10 @@ bool HostTable::save(const std::string& path, std::string* err) const {
     SnapWriter w{f};
     SnapHeader h{};
     std::memcpy(h.magic, kSnapMagic, 8);
-    h.version = kSnapVersion; h.edge_bytes = sizeof(EdgeEntry); h.node_bytes = sizeof(Node); h.sub_bytes = sizeof(SubEntry);
+    // RGR_SNAPSHOT_WRITE_V1 (tests only): a version-1 file as round-2 builds wrote it — the last 8 bytes of every node header are
+    // not a child-token bitmap (here: a pattern that would break the walk if a loader trusted it)
+    const bool legacy = std::getenv("RGR_SNAPSHOT_WRITE_V1") != nullptr;
+    h.version = legacy ? 1 : kSnapVersion; h.edge_bytes = sizeof(EdgeEntry); h.node_bytes = sizeof(Node); h.sub_bytes = sizeof(SubEntry);
     h.n_filters = n_filters_; h.n_subs = n_subs_; h.n_nodes = n_nodes_; h.n_v5 = n_v5_; h.edge_used = edge_used_; h.edge_live = edge_live_;
     w.pod(h);
     dict_.save(w);
@@ -641,9 +649,12 @@ bool HostTable::save(const std::string& path, std::string* err) const {
         idx.reserve(edge_used_); recs.reserve(edge_used_);
         for (uint64_t i = 0; i < cap; ++i)
             if (edges_[i].parent != kEdgeEmpty) { idx.push_back(uint32_t(i)); recs.push_back(edges_[i]); }
+        if (legacy) for (EdgeEntry& e : recs) { e.lit_lo = 1; e.lit_hi = 0; }
         w.pod(cap); w.vec(idx); w.vec(recs);
     }
-    w.pod(root_hdr_);
+    NodeHeader root = root_hdr_;
+    if (legacy) { root.lit_lo = 1; root.lit_hi = 0; }
+    w.pod(root);
     std::vector<uint32_t> fnode(filters_.size());
     std::vector<FilterDesc> fdesc;
     std::vector<SubEntry> subs;
@@ -673,7 +684,9 @@ bool HostTable::load(const std::string& path, std::string* err) {
     r.left = uint64_t(size) - 8;
     SnapHeader h{};
     if (!r.pod(h) || std::memcmp(h.magic, kSnapMagic, 8) != 0) return bad("not a snapshot (bad magic)");
-    if (h.version != kSnapVersion || h.edge_bytes != sizeof(EdgeEntry) || h.node_bytes != sizeof(Node) || h.sub_bytes != sizeof(SubEntry))
+    // version 1 differs only in the last 8 bytes of an edge record ({lit_cnt, lit_xor} instead of the child-token bitmap), and those are
+    // derived data: a v1 file loads like a v2 one and has its bitmaps rebuilt below (an upgrade does not discard persisted snapshots)
+    if ((h.version != kSnapVersion && h.version != 1) || h.edge_bytes != sizeof(EdgeEntry) || h.node_bytes != sizeof(Node) || h.sub_bytes != sizeof(SubEntry))
         return bad("snapshot of an incompatible build");
     const bool prof = std::getenv("RGR_BULK_PROFILE") != nullptr;
     auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -752,6 +765,7 @@ bool HostTable::load(const std::string& path, std::string* err) {
         return bad("header counters do not match the arrays");
     t.n_filters_ = live_filters; t.n_subs_ = total; t.n_nodes_ = n_nodes; t.n_v5_ = n_v5; t.max_sub_id_ = max_sub; t.max_node_idx_ = max_node;
     t.edge_used_ = used; t.edge_live_ = live;
+    if (h.version == 1) t.rebuild_child_bitmaps();
     t.has_attrs_ = ha != 0;
     t.dict_gen_ = dict_gen_ + 1;
     t.delta_ = Delta{};

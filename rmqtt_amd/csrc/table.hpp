@@ -209,6 +209,7 @@ class HostTable {
     uint32_t find_slot(uint32_t parent, uint32_t token) const;
     uint32_t insert_edge(uint32_t parent, uint32_t token, uint32_t child);
     void rehash(uint64_t new_cap);
+    void rebuild_child_bitmaps();
     uint32_t new_node(uint32_t parent, uint32_t token);
     void set_plus_slot(uint32_t node, uint32_t slot);
     void set_hash_fid(uint32_t node, uint32_t fid);

@@ -87,7 +87,9 @@ Result<bool> GpuRouter::add(const std::string& topic_filter, const Id& id, const
     if (!g_) return Result<bool>::Err(create_error_);
     if (!valid_topic(topic_filter)) return Result<bool>::Err("invalid topic filter `" + topic_filter + "`");   // router.rs:436 (`?`)
     std::unique_lock<std::shared_mutex> g(mu_);
-    mutation_epoch_++;
+    // (no epoch bump: an add cannot make a sub id held by a pass in flight resolve to another relation — ids are recycled only out of
+    // the quarantine that remove() fills, and remove() bumps.  Bumping here sent every batched publish through the exclusive re-match
+    // path under ordinary subscribe churn: round-3 advisor.)
     auto it = relations_.find(topic_filter);
     if (it == relations_.end()) {
         topics_count_.inc();
@@ -244,20 +246,35 @@ Result<bool> GpuRouter::filters_pass(const std::vector<TopicName>& topics, Filte
     std::string blob;
     std::vector<uint64_t> offs(topics.size() + 1, 0);
     for (size_t i = 0; i < topics.size(); ++i) { blob += topics[i]; offs[i + 1] = blob.size(); }
-    // commit + device pass under the exclusive lock: the pass sees exactly the table of mutation epoch `pass.epoch` (add / remove
-    // wait for the pass — a fraction of a millisecond — as they wait for the trie's write lock in the reference, router.rs:438)
+    // The device pass runs under the SHARED lock: several passes (the Batcher's drivers) walk the same epoch at once, add / remove wait
+    // for them — a fraction of a millisecond, as they wait for the trie's write lock in the reference, router.rs:438.  Pending
+    // changes are committed first, under the exclusive lock; a writer slipping in between the two locks sends us round again, and
+    // after a few rounds the pass simply runs under the exclusive lock (no live-lock under subscribe churn: r3c).
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        {
+            std::shared_lock<std::shared_mutex> sh(mu_);
+            if (!dirty_) return device_pass(blob, offs, pass);
+        }
+        std::unique_lock<std::shared_mutex> x(mu_);
+        if (commit_if_dirty() != RGR_OK) return Result<bool>::Err(rgr_last_error());
+    }
     std::unique_lock<std::shared_mutex> x(mu_);
     return filters_pass_locked(blob, offs, pass);
 }
 
-// caller holds mu_ exclusively
-Result<bool> GpuRouter::filters_pass_locked(const std::string& blob, const std::vector<uint64_t>& offs, FilterPass& pass) {
-    if (commit_if_dirty() != RGR_OK) return Result<bool>::Err(rgr_last_error());
+// caller holds mu_ (shared or exclusive) and the table is committed
+Result<bool> GpuRouter::device_pass(const std::string& blob, const std::vector<uint64_t>& offs, FilterPass& pass) {
     pass.epoch = mutation_epoch_;
     rgr_filters_result_free(&pass.res);
     if (rgr_group_match_filter_subs(g_, reinterpret_cast<const uint8_t*>(blob.data()), offs.data(), uint32_t(offs.size() - 1), &pass.res) != RGR_OK)
         return Result<bool>::Err(rgr_last_error());
     return Result<bool>::Ok(true);
+}
+
+// caller holds mu_ exclusively
+Result<bool> GpuRouter::filters_pass_locked(const std::string& blob, const std::vector<uint64_t>& offs, FilterPass& pass) {
+    if (commit_if_dirty() != RGR_OK) return Result<bool>::Err(rgr_last_error());
+    return device_pass(blob, offs, pass);
 }
 
 // caller holds mu_ (shared) and the pass is current
@@ -300,24 +317,56 @@ std::optional<SubRelationsMap> GpuRouter::expand_locked(const rgr_filters_result
     return m;
 }
 
-std::optional<SubRelationsMap> GpuRouter::expand(const FilterPass& pass, size_t t, const Id& id, const TopicName& topic) {
+Result<SubRelationsMap> GpuRouter::expand(const FilterPass& pass, size_t t, const Id& id, const TopicName& topic) {
     {
         std::shared_lock<std::shared_mutex> g(mu_);
         if (pass.epoch == mutation_epoch_) {
             uint64_t hits = 0;
             auto m = expand_locked(pass.res, t, id, topic, &hits);
             mean_hits_ = 0.9 * std::min(mean_hits_.load(), 1e8) + 0.1 * double(hits);
-            return m;
+            if (!m) return Result<SubRelationsMap>::Err("invalid topic `" + topic + "`");
+            return Result<SubRelationsMap>::Ok(std::move(*m));
         }
     }
-    // the table changed since the pass ran (its sub ids may have been freed): match this publish again, alone, with the table held
-    // still from the commit to the end of the expansion — always current, no retry loop
+    return rematch(id, topic);
+}
+
+// The table lost a relation since the pass ran (its sub ids may have been freed): match this publish again, alone, with the table
+// held still from the commit to the end of the expansion — always current, no retry loop.  A device failure is reported as what it
+// is, not as an invalid topic (round-3 advisor).
+Result<SubRelationsMap> GpuRouter::rematch(const Id& id, const TopicName& topic) {
     stale_expansions_++;
     FilterPass fresh;
     const std::vector<uint64_t> offs{0, topic.size()};
     std::unique_lock<std::shared_mutex> x(mu_);
-    if (!filters_pass_locked(topic, offs, fresh).ok()) return std::nullopt;
-    return expand_locked(fresh.res, 0, id, topic, nullptr);
+    auto r = filters_pass_locked(topic, offs, fresh);
+    if (!r.ok()) return Result<SubRelationsMap>::Err(r.error);
+    auto m = expand_locked(fresh.res, 0, id, topic, nullptr);
+    if (!m) return Result<SubRelationsMap>::Err("invalid topic `" + topic + "`");
+    return Result<SubRelationsMap>::Ok(std::move(*m));
+}
+
+// A run of publishes of ONE pass expanded under one acquisition of the shared lock (the Batcher's workers: a shared_mutex taken
+// once per publish by dozens of threads is itself a hot cache line).
+void GpuRouter::expand_chunk(const FilterPass& pass, const size_t* index, const Id* const* ids, const TopicName* const* topics, size_t n,
+                             std::vector<Result<SubRelationsMap>>& out) {
+    out.clear();
+    out.reserve(n);
+    bool current;
+    {
+        std::shared_lock<std::shared_mutex> g(mu_);
+        current = pass.epoch == mutation_epoch_;
+        if (current) {
+            uint64_t hits = 0, h = 0;
+            for (size_t i = 0; i < n; ++i) {
+                auto m = expand_locked(pass.res, index[i], *ids[i], *topics[i], &h);
+                hits += h;
+                out.push_back(m ? Result<SubRelationsMap>::Ok(std::move(*m)) : Result<SubRelationsMap>::Err("invalid topic `" + *topics[i] + "`"));
+            }
+            if (n) mean_hits_ = 0.9 * std::min(mean_hits_.load(), 1e8) + 0.1 * double(hits) / double(n);
+        }
+    }
+    if (!current) for (size_t i = 0; i < n; ++i) out.push_back(rematch(*ids[i], *topics[i]));
 }
 
 Result<bool> GpuRouter::matches_batch(const std::vector<Id>& ids, const std::vector<TopicName>& topics,
@@ -329,7 +378,11 @@ Result<bool> GpuRouter::matches_batch(const std::vector<Id>& ids, const std::vec
     auto r = filters_pass(topics, pass);
     if (!r.ok()) return r;
     out.assign(topics.size(), std::nullopt);
-    for (size_t t = 0; t < topics.size(); ++t) out[t] = expand(pass, t, ids[t], topics[t]);
+    for (size_t t = 0; t < topics.size(); ++t) {
+        auto m = expand(pass, t, ids[t], topics[t]);
+        if (m.ok()) out[t] = std::move(*m.value);
+        else if (m.error.rfind("invalid topic", 0) != 0) return Result<bool>::Err(m.error);      // a device failure fails the call
+    }
     return Result<bool>::Ok(true);
 }
 
@@ -502,63 +555,134 @@ std::vector<std::string> GpuRouter::list_topics(size_t top) {
 namespace rmqtt {
 
 // ---------------------------------------------------------------------------------------------- Batcher
-Batcher::Batcher(GpuRouter& router, size_t max_batch, std::chrono::microseconds max_delay)
-    : router_(router), max_batch_(max_batch ? max_batch : 1), max_delay_(max_delay), driver_([this] { run(); }) {}
+namespace {
+size_t shard_of_this_thread(size_t n) {
+    static std::atomic<size_t> next{0};
+    thread_local size_t mine = next.fetch_add(1);
+    return mine % n;
+}
+}  // namespace
+
+Batcher::Batcher(GpuRouter& router, size_t max_batch, std::chrono::microseconds max_delay, unsigned passes_in_flight, unsigned workers)
+    : router_(router), max_batch_(max_batch ? max_batch : 1), max_delay_(max_delay) {
+    for (unsigned i = 0; i < std::max(1u, passes_in_flight); ++i) drivers_.emplace_back([this] { run(); });
+    for (unsigned i = 0; i < workers; ++i) workers_.emplace_back([this] { work(); });
+}
 
 Batcher::~Batcher() {
     { std::lock_guard<std::mutex> g(mu_); stop_ = true; }
     cv_req_.notify_all();
-    driver_.join();
+    for (auto& d : drivers_) d.join();
+    { std::lock_guard<std::mutex> g(task_mu_); task_stop_ = true; }
+    task_cv_.notify_all();
+    for (auto& w : workers_) w.join();
+}
+
+void Batcher::enqueue(Req* req) {
+    Shard& sh = shards_[shard_of_this_thread(kShards)];
+    { std::lock_guard<std::mutex> lk(sh.m); sh.q.push_back(req); }
+    requests_.fetch_add(1, std::memory_order_relaxed);
+    const size_t before = pending_.fetch_add(1, std::memory_order_acq_rel);
+    // wake a driver for the first request of a batch and when the batch is full; everything in between rides on its deadline
+    if (before == 0 || before + 1 == max_batch_) { { std::lock_guard<std::mutex> g(mu_); } cv_req_.notify_one(); }
 }
 
 Result<SubRelationsMap> Batcher::matches(const Id& id, const TopicName& topic) {
     Req req;
     req.id = id; req.topic = topic;
-    {
-        std::lock_guard<std::mutex> lk(mu_);
-        if (stop_) return Result<SubRelationsMap>::Err("batcher stopped");
-        queue_.push_back(&req);
-        requests_++;
-    }
-    cv_req_.notify_one();
+    { std::lock_guard<std::mutex> lk(mu_); if (stop_) return Result<SubRelationsMap>::Err("batcher stopped"); }
+    enqueue(&req);
     {
         std::unique_lock<std::mutex> lk(req.m);
         req.cv.wait(lk, [&] { return req.done; });
     }
     if (!req.err.empty()) return Result<SubRelationsMap>::Err(req.err);
     // the expansion (router.rs:194-261) runs HERE, on the caller's thread: N callers expand in parallel, like N tokio workers
-    auto m = router_.expand(*req.pass, req.index, id, topic);
-    if (!m) return Result<SubRelationsMap>::Err("invalid topic `" + topic + "`");
-    return Result<SubRelationsMap>::Ok(std::move(*m));
+    return router_.expand(*req.pass, req.index, id, topic);
+}
+
+void Batcher::submit(Id id, TopicName topic, Callback cb) {
+    auto* req = new Req;
+    req->id = std::move(id); req->topic = std::move(topic); req->cb = std::move(cb);
+    { std::lock_guard<std::mutex> lk(mu_); if (stop_) { req->cb(Result<SubRelationsMap>::Err("batcher stopped")); delete req; return; } }
+    enqueue(req);
 }
 
 void Batcher::run() {
-    std::unique_lock<std::mutex> lk(mu_);
     for (;;) {
-        cv_req_.wait(lk, [&] { return stop_ || !queue_.empty(); });
-        if (queue_.empty()) { if (stop_) return; continue; }
-        // deadline counted from the first request of the batch
-        const auto deadline = std::chrono::steady_clock::now() + max_delay_;
-        cv_req_.wait_until(lk, deadline, [&] { return stop_ || queue_.size() >= max_batch_; });
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_req_.wait(lk, [&] { return stop_ || pending_.load(std::memory_order_acquire) > 0; });
+            if (pending_.load(std::memory_order_acquire) == 0) { if (stop_) return; continue; }
+            // deadline counted from (about) the first request of the batch
+            const auto deadline = std::chrono::steady_clock::now() + max_delay_;
+            cv_req_.wait_until(lk, deadline, [&] { return stop_ || pending_.load(std::memory_order_acquire) >= max_batch_; });
+        }
         std::vector<Req*> reqs;
-        reqs.swap(queue_);
-        if (reqs.size() > max_batch_) { queue_.assign(reqs.begin() + max_batch_, reqs.end()); reqs.resize(max_batch_); }
-        lk.unlock();                                              // callers keep enqueueing during the device pass
+        for (size_t k = 0; k < kShards && reqs.size() < max_batch_; ++k) {
+            Shard& sh = shards_[k];
+            std::lock_guard<std::mutex> lk(sh.m);
+            const size_t take = std::min(sh.q.size(), max_batch_ - reqs.size());
+            reqs.insert(reqs.end(), sh.q.begin(), sh.q.begin() + take);
+            sh.q.erase(sh.q.begin(), sh.q.begin() + take);
+        }
+        if (reqs.empty()) continue;                               // another driver took them
+        if (pending_.fetch_sub(reqs.size(), std::memory_order_acq_rel) > reqs.size()) cv_req_.notify_one();     // more are waiting: next driver
         std::vector<TopicName> topics;
+        topics.reserve(reqs.size());
         for (Req* r : reqs) topics.push_back(r->topic);
         auto pass = std::make_shared<GpuRouter::FilterPass>();
         auto res = router_.filters_pass(topics, *pass);
+        passes_.fetch_add(1, std::memory_order_relaxed);
+        // asynchronous requests go to the workers in runs of kTaskRun (one shared-lock acquisition per run); blocking callers are woken
+        Task task;
+        auto flush = [&] {
+            if (task.reqs.empty()) return;
+            task.pass = pass;
+            if (workers_.empty()) run_task(task);                 // no pool configured: complete on the driver
+            else { { std::lock_guard<std::mutex> g(task_mu_); tasks_.push_back(std::move(task)); } task_cv_.notify_one(); }
+            task = Task{};
+        };
         for (size_t i = 0; i < reqs.size(); ++i) {
             Req* r = reqs[i];
-            {
-                std::lock_guard<std::mutex> g(r->m);
-                if (!res.ok()) r->err = res.error; else { r->pass = pass; r->index = i; }
-                r->done = true;
-                r->cv.notify_one();             // under r->m: the caller cannot destroy the request before this returns
+            if (r->cb) {
+                if (!res.ok()) { r->cb(Result<SubRelationsMap>::Err(res.error)); delete r; continue; }
+                r->index = i;
+                task.reqs.push_back(r);
+                if (task.reqs.size() >= kTaskRun) flush();
+                continue;
             }
+            std::lock_guard<std::mutex> g(r->m);
+            if (!res.ok()) r->err = res.error; else { r->pass = pass; r->index = i; }
+            r->done = true;
+            r->cv.notify_one();             // under r->m: the caller cannot destroy the request before this returns
         }
-        lk.lock();
-        passes_++;
+        flush();
+    }
+}
+
+void Batcher::run_task(Task& t) {
+    const size_t n = t.reqs.size();
+    std::vector<size_t> index(n);
+    std::vector<const Id*> ids(n);
+    std::vector<const TopicName*> topics(n);
+    for (size_t i = 0; i < n; ++i) { index[i] = t.reqs[i]->index; ids[i] = &t.reqs[i]->id; topics[i] = &t.reqs[i]->topic; }
+    std::vector<Result<SubRelationsMap>> out;
+    router_.expand_chunk(*t.pass, index.data(), ids.data(), topics.data(), n, out);
+    for (size_t i = 0; i < n; ++i) { t.reqs[i]->cb(std::move(out[i])); delete t.reqs[i]; }
+}
+
+void Batcher::work() {
+    for (;;) {
+        Task t;
+        {
+            std::unique_lock<std::mutex> lk(task_mu_);
+            task_cv_.wait(lk, [&] { return task_stop_ || !tasks_.empty(); });
+            if (tasks_.empty()) return;                           // (stop: the drivers are gone, nothing more can arrive)
+            t = std::move(tasks_.front());
+            tasks_.pop_front();
+        }
+        run_task(t);
     }
 }
 

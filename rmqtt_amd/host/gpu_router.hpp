@@ -27,6 +27,7 @@
 #pragma once
 #include <atomic>
 #include <condition_variable>
+#include <deque>
 #include <cstdint>
 #include <functional>
 #include <map>
@@ -179,8 +180,11 @@ class GpuRouter final : public Router {
         ~FilterPass() { rgr_filters_result_free(&res); }
     };
     Result<bool> filters_pass(const std::vector<TopicName>& topics, FilterPass& pass);
-    // nullopt: the reference would return Err (invalid topic name)
-    std::optional<SubRelationsMap> expand(const FilterPass& pass, size_t t, const Id& id, const TopicName& topic);
+    // Err: what the reference returns for an invalid topic name ("invalid topic ..."), or a device failure of the re-match
+    Result<SubRelationsMap> expand(const FilterPass& pass, size_t t, const Id& id, const TopicName& topic);
+    // n publishes of one pass (index[i] = position inside the pass) under ONE acquisition of the table lock
+    void expand_chunk(const FilterPass& pass, const size_t* index, const Id* const* ids, const TopicName* const* topics, size_t n,
+                      std::vector<Result<SubRelationsMap>>& out);
     uint64_t stale_expansions() const { return stale_expansions_; }
     bool is_online(NodeId node, const std::string& client) override { return is_online_ ? is_online_(node, client) : true; }   // session state lives in the broker
     std::vector<Route> gets(size_t limit) override;
@@ -220,11 +224,11 @@ class GpuRouter final : public Router {
     uint64_t shared_rels_ = 0;           // relations that are $share members (their picks need the ungrouped hit order)
     bool bulk_loaded_ = false;           // relations loaded by restore(): the tuples' node bits are not populated
     // add / remove / restore / commit: exclusive; a device pass and the host expansion of its result: shared (the reference:
-    // DashMap + a trie RwLock).  A sub id freed by remove() is quarantined until the next commit has dropped it from the device
-    // table, and a pass remembers the mutation epoch it ran at: expand() re-runs a publish whose pass is older than the last
-    // mutation, so a recycled id can never resolve to a relation the device did not match.
+    // DashMap + a trie RwLock) — so several passes walk the same committed table at once.  A sub id freed by remove() is
+    // quarantined until the next commit has dropped it from the device table, and a pass remembers the mutation epoch it ran at
+    // (bumped by remove / restore only: an add never recycles an id a pass in flight may hold): expand() re-runs a publish whose
+    // pass is older than the last removal, so a recycled id can never resolve to a relation the device did not match.
     std::shared_mutex mu_;
-    std::mutex commit_mu_;
     std::atomic<uint64_t> mutation_epoch_{0};
     std::atomic<uint64_t> stale_expansions_{0};
     std::vector<uint32_t> quarantined_sub_ids_;
@@ -241,38 +245,59 @@ class GpuRouter final : public Router {
 
     int32_t commit_if_dirty();           // caller holds mu_ exclusively
     Result<bool> filters_pass_locked(const std::string& blob, const std::vector<uint64_t>& offs, FilterPass& pass);   // mu_ held exclusively
+    Result<bool> device_pass(const std::string& blob, const std::vector<uint64_t>& offs, FilterPass& pass);           // mu_ held, table committed
+    Result<SubRelationsMap> rematch(const Id& id, const TopicName& topic);
     Result<bool> matches_batch_deliver(const std::vector<Id>& ids, const std::vector<TopicName>& topics, std::vector<std::optional<SubRelationsMap>>& out);
     std::optional<SubRelationsMap> expand_locked(const rgr_filters_result& res, size_t t, const Id& id, const TopicName& topic, uint64_t* hits);
 };
 
-// Deadline micro-batcher in front of GpuRouter::matches_batch: Router::matches is called once per PUBLISH
-// from many threads (rmqtt/src/shared.rs:772); callers enqueue (id, topic) and block on their own slot; one
-// driver thread drains the queue when it holds max_batch publishes or max_delay has passed since the first
-// one, runs ONE device pass and hands every caller its SubRelationsMap.  No lock of the router is held while
-// callers wait.
+// Deadline micro-batcher in front of the batched device pass: Router::matches is called once per PUBLISH (rmqtt/src/shared.rs:772).
+//   matches()  blocking form: the caller enqueues (id, topic), sleeps on its own slot and expands its publish itself.
+//   submit()   asynchronous form — what a tokio task awaiting `matches` is: enqueue and return; the completion (the publish's
+//              SubRelationsMap) is delivered through `cb` on one of `workers` pool threads (the tokio workers' stand-in), which
+//              expand runs of publishes of one pass under one acquisition of the table lock.  Tens of thousands of publishes
+//              can be outstanding from a handful of threads, so batches fill to max_batch instead of to the thread count.
+// `passes_in_flight` driver threads each collect a batch (max_batch publishes, or max_delay after its first one) and run ONE
+// device pass for it; the library gives every pass its own stream and workspace, so the next batch is collected and walked while
+// the previous one is still on the device (r4; r3 ran one pass at a time: 241 k publishes/s at config 2).  No lock of the router
+// is held while callers wait.  Rust twin: rust/rmqtt-gpu-router/src/batcher.rs (MAX_IN_FLIGHT; tokio's own workers).
 class Batcher {
    public:
-    Batcher(GpuRouter& router, size_t max_batch, std::chrono::microseconds max_delay);
+    using Callback = std::function<void(Result<SubRelationsMap>&&)>;
+    Batcher(GpuRouter& router, size_t max_batch, std::chrono::microseconds max_delay, unsigned passes_in_flight = 3, unsigned workers = 0);
     ~Batcher();
     Result<SubRelationsMap> matches(const Id& id, const TopicName& topic);
+    void submit(Id id, TopicName topic, Callback cb);
     uint64_t passes() const { return passes_; }
     uint64_t requests() const { return requests_; }
 
    private:
-    // the driver thread runs ONE device pass per batch; every caller then expands its own publish from the shared pass
-    // (every request is woken through its own condition variable: one shared cv made 256 callers fight for one mutex per pass)
-    struct Req { Id id; TopicName topic; std::shared_ptr<GpuRouter::FilterPass> pass; size_t index = 0; std::string err; bool done = false;
+    // blocking requests live on their caller's stack and are woken through their own condition variable (one shared cv made 256
+    // callers fight for one mutex per pass); asynchronous ones are heap objects that end with their callback
+    struct Req { Id id; TopicName topic; Callback cb; std::shared_ptr<GpuRouter::FilterPass> pass; size_t index = 0; std::string err; bool done = false;
                  std::mutex m; std::condition_variable cv; };
+    struct Shard { std::mutex m; std::vector<Req*> q; };
+    struct Task { std::shared_ptr<GpuRouter::FilterPass> pass; std::vector<Req*> reqs; };
+    static constexpr size_t kShards = 16;      // submission queues (a submitter sticks to one)
+    static constexpr size_t kTaskRun = 64;     // publishes per worker task
     GpuRouter& router_;
     size_t max_batch_;
     std::chrono::microseconds max_delay_;
-    std::mutex mu_;
+    Shard shards_[kShards];
+    std::atomic<size_t> pending_{0};
+    std::mutex mu_;                            // drivers sleep here
     std::condition_variable cv_req_;
-    std::vector<Req*> queue_;
     bool stop_ = false;
-    uint64_t passes_ = 0, requests_ = 0;
-    std::thread driver_;
+    std::atomic<uint64_t> passes_{0}, requests_{0};
+    std::mutex task_mu_;
+    std::condition_variable task_cv_;
+    std::deque<Task> tasks_;
+    bool task_stop_ = false;
+    std::vector<std::thread> drivers_, workers_;
+    void enqueue(Req* r);
     void run();
+    void work();
+    void run_task(Task& t);
 };
 
 }  // namespace rmqtt

@@ -4,6 +4,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -151,6 +153,94 @@ int hr_e2e_run(void* r, const uint8_t* blob, const uint64_t* offs, uint32_t n, u
     out[0] = pubs; out[1] = hits; out[2] = passes;
     if (n_lat_out) *n_lat_out = lat_n;
     return 0;
+}
+// The boundary at its design point: what tokio's task-level concurrency gives the reference's callers (shared.rs:772 is awaited by
+// one task per PUBLISH, tens of thousands of them in flight on a few worker threads).  `n_submitters` threads keep `outstanding`
+// publishes in flight in total through Batcher::submit; the completions (each publish's SubRelationsMap) run on `workers` pool
+// threads.  out[0] = publishes completed, out[1] = rows of the returned maps, out[2] = device passes, out[3] = errors; lat_us:
+// submit -> completion latencies of submitter 0's publishes, in microseconds.
+int hr_e2e_run_async(void* r, const uint8_t* blob, const uint64_t* offs, uint32_t n, uint32_t n_submitters, uint32_t outstanding, uint32_t workers,
+                     uint32_t passes_in_flight, uint32_t max_batch, uint32_t max_delay_us, double seconds, uint64_t* out, double* wall_s,
+                     float* lat_us, uint32_t n_lat, uint32_t* n_lat_out) {
+    auto* router = static_cast<GpuRouter*>(r);
+    struct Ctx { std::atomic<int64_t> inflight{0}; std::atomic<uint64_t> pubs{0}, rows{0}, errs{0}; std::mutex m; std::condition_variable cv; };
+    std::vector<std::unique_ptr<Ctx>> ctx;
+    for (uint32_t k = 0; k < n_submitters; ++k) ctx.push_back(std::make_unique<Ctx>());
+    const int64_t cap = std::max<int64_t>(1, outstanding / std::max(1u, n_submitters));
+    std::atomic<bool> stop{false};
+    std::atomic<uint32_t> lat_n{0};
+    uint64_t passes = 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    double wall = 0;
+    {
+        Batcher b(*router, max_batch, std::chrono::microseconds(max_delay_us), passes_in_flight, workers);
+        std::vector<std::thread> th;
+        for (uint32_t k = 0; k < n_submitters; ++k)
+            th.emplace_back([&, k] {
+                Ctx& c = *ctx[k];
+                Id id; id.node_id = 1; id.client_id = "publisher" + std::to_string(k);
+                for (uint64_t i = k; !stop.load(std::memory_order_relaxed); i += n_submitters) {
+                    if (c.inflight.load(std::memory_order_acquire) >= cap) {
+                        std::unique_lock<std::mutex> lk(c.m);
+                        c.cv.wait_for(lk, std::chrono::microseconds(200), [&] { return c.inflight.load(std::memory_order_acquire) < cap || stop.load(); });
+                        continue;
+                    }
+                    const uint32_t t = uint32_t(i % n);
+                    c.inflight.fetch_add(1, std::memory_order_acq_rel);
+                    const auto a = std::chrono::steady_clock::now();
+                    b.submit(id, std::string(reinterpret_cast<const char*>(blob) + offs[t], offs[t + 1] - offs[t]), [&c, a, k, lat_us, n_lat, &lat_n, cap](Result<SubRelationsMap>&& res) {
+                        uint64_t rows = 0;
+                        if (res.ok()) for (auto& kv : *res.value) rows += kv.second.size();
+                        else if (res.error.rfind("invalid topic", 0) != 0) c.errs.fetch_add(1, std::memory_order_relaxed);
+                        c.rows.fetch_add(rows, std::memory_order_relaxed);
+                        c.pubs.fetch_add(1, std::memory_order_relaxed);
+                        if (k == 0 && lat_us) {
+                            const uint32_t j = lat_n.fetch_add(1, std::memory_order_relaxed);
+                            if (j < n_lat) lat_us[j] = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - a).count();
+                        }
+                        if (c.inflight.fetch_sub(1, std::memory_order_acq_rel) == cap) { { std::lock_guard<std::mutex> g(c.m); } c.cv.notify_one(); }
+                    });
+                }
+            });
+        std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
+        stop = true;
+        for (auto& t : th) t.join();
+        for (auto& c : ctx) while (c->inflight.load(std::memory_order_acquire) > 0) std::this_thread::sleep_for(std::chrono::microseconds(100));
+        wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        passes = b.passes();
+    }
+    if (wall_s) *wall_s = wall;
+    out[0] = out[1] = out[3] = 0;
+    for (auto& c : ctx) { out[0] += c->pubs; out[1] += c->rows; out[3] += c->errs; }
+    out[2] = passes;
+    if (n_lat_out) *n_lat_out = std::min(lat_n.load(), n_lat);
+    return 0;
+}
+// n publishes submitted asynchronously (Batcher::submit) from n_threads threads, completions on `workers` pool threads: dumps joined by
+// '\x1e' as in hr_batcher_run.  The parity form of the asynchronous path.
+char* hr_batcher_run_async(void* r, const hr_id* ids, const char* const* topics, const uint32_t* lens, uint32_t n, uint32_t n_threads,
+                           uint32_t max_batch, uint32_t max_delay_us, uint32_t passes_in_flight, uint32_t workers, uint64_t* passes) {
+    auto* router = static_cast<GpuRouter*>(r);
+    std::vector<std::string> outs(n);
+    std::atomic<uint32_t> done{0};
+    {
+        Batcher b(*router, max_batch, std::chrono::microseconds(max_delay_us), passes_in_flight, workers);
+        std::vector<std::thread> th;
+        for (uint32_t k = 0; k < n_threads; ++k)
+            th.emplace_back([&, k] {
+                for (uint32_t i = k; i < n; i += n_threads)
+                    b.submit(mk_id(&ids[i]), std::string(topics[i], lens[i]), [&outs, &done, i](Result<SubRelationsMap>&& res) {
+                        outs[i] = res.ok() ? dump(*res.value) : std::string("!ERR");
+                        done.fetch_add(1, std::memory_order_release);
+                    });
+            });
+        for (auto& t : th) t.join();
+        while (done.load(std::memory_order_acquire) < n) std::this_thread::sleep_for(std::chrono::microseconds(100));
+        if (passes) *passes = b.passes();
+    }
+    std::string all;
+    for (uint32_t i = 0; i < n; ++i) { if (i) all.push_back('\x1e'); all += outs[i]; }
+    return dup_str(all);
 }
 // n publishes issued from n_threads threads through a Batcher (max_batch / max_delay_us): dumps joined by '\x1e'
 // ("!ERR" where matches returned Err); *passes = device passes the batcher needed.

@@ -2,8 +2,10 @@
 //! rmqtt/src/shared.rs:772) and the batched device pass (`rgr_group_match_filter_subs`).
 //!
 //! Callers enqueue `(topic, oneshot)` and await; ONE driver task drains the queue when it holds `max_batch`
-//! publishes or `max_delay` has passed since the first one, runs one device pass on a blocking thread and hands
-//! every caller its own slice of the result: per matched filter (in `TopicTree::matches` order) the sub id of the
+//! publishes or `max_delay` has passed since the first one and hands the batch to a pass task; up to `MAX_IN_FLIGHT`
+//! passes run at once, each on its own blocking thread (the library gives every one-shot call its own stream and
+//! workspace), so the driver is already collecting the next batch while the device walks this one (r4: with one pass
+//! at a time the boundary was capped at one batch per pass latency).  Every caller gets its own slice of the result: per matched filter (in `TopicTree::matches` order) the sub id of the
 //! filter's first subscriber.  The per-client loop of `_matches` (router.rs:194-231) then runs in the CALLER's task
 //! over `DefaultRouter::relations` — N tokio workers expand N publishes in parallel, exactly as in the reference; what
 //! crosses PCIe is 4 bytes per matched FILTER instead of 12 per hit (at config-3 fan-out: 80 B instead of 178 KB per
@@ -13,7 +15,10 @@ use std::sync::atomic::{AtomicU64, Ordering};
 use std::sync::Arc;
 use std::time::Duration;
 
-use tokio::sync::{mpsc, oneshot};
+use tokio::sync::{mpsc, oneshot, Semaphore};
+
+/// device passes in flight at once (C++ twin: `Batcher`'s driver threads)
+pub const MAX_IN_FLIGHT: usize = 3;
 
 use crate::ffi::*;
 
@@ -50,6 +55,7 @@ impl Batcher {
     {
         let (tx, mut rx) = mpsc::unbounded_channel::<MatchRequest>();
         let before_pass = Arc::new(before_pass);
+        let in_flight = Arc::new(Semaphore::new(MAX_IN_FLIGHT));
         tokio::spawn(async move {
             while let Some(first) = rx.recv().await {
                 let mut reqs = vec![first];
@@ -63,20 +69,25 @@ impl Batcher {
                 }
                 let work: Vec<String> = reqs.iter().map(|r| r.topic.clone()).collect();
                 let bp = before_pass.clone();
-                let res = tokio::task::spawn_blocking(move || {
-                    let epoch = bp()?;
-                    unsafe { match_many(g, &work, epoch) }
-                })
-                .await;
-                match res {
-                    Ok(Ok(per_topic)) => {
-                        for (req, hits) in reqs.into_iter().zip(per_topic) {
-                            let _ = req.reply.send(hits);
+                // wait for a free pass slot, then let the pass run on its own task: this loop goes straight back to collecting
+                let Ok(permit) = in_flight.clone().acquire_owned().await else { break };
+                tokio::spawn(async move {
+                    let res = tokio::task::spawn_blocking(move || {
+                        let epoch = bp()?;
+                        unsafe { match_many(g, &work, epoch) }
+                    })
+                    .await;
+                    drop(permit);
+                    match res {
+                        Ok(Ok(per_topic)) => {
+                            for (req, hits) in reqs.into_iter().zip(per_topic) {
+                                let _ = req.reply.send(hits);
+                            }
                         }
+                        Ok(Err(e)) => reqs.into_iter().for_each(|r| { let _ = r.reply.send(Err(e.clone())); }),
+                        Err(e) => reqs.into_iter().for_each(|r| { let _ = r.reply.send(Err(e.to_string())); }),
                     }
-                    Ok(Err(e)) => reqs.into_iter().for_each(|r| { let _ = r.reply.send(Err(e.clone())); }),
-                    Err(e) => reqs.into_iter().for_each(|r| { let _ = r.reply.send(Err(e.to_string())); }),
-                }
+                });
             }
         });
         Self { tx }
@@ -117,7 +128,8 @@ pub unsafe fn match_many(g: GroupPtr, work: &[String], epoch: u64) -> Result<Vec
     Ok(out)
 }
 
-/// Monotonic counter of table mutations (every mirrored add / remove bumps it).
+/// Monotonic counter of the table mutations that can invalidate a pass in flight (every mirrored remove / resync bumps it;
+/// an add does not: see `GpuRouter::mirror_add`).
 #[derive(Default)]
 pub struct MutationEpoch(AtomicU64);
 impl MutationEpoch {

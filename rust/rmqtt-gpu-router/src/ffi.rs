@@ -119,6 +119,7 @@ pub const RGR_FORMAT_TUPLE: u32 = 0;
 pub const RGR_FORMAT_SOA: u32 = 1;
 pub const RGR_FORMAT_PACKED: u32 = 2;
 pub const RGR_FORMAT_RUNS: u32 = 3;
+pub const RGR_FORMAT_IDS24: u32 = 4;
 pub const RGR_TOPIC_INVALID: i32 = -2;
 pub const RGR_PACKET_MALFORMED: i32 = -8;
 pub const RGR_COMM_ID_BYTES: usize = 128;
@@ -139,6 +140,7 @@ pub struct rgr_window {
     pub d_run_topic: *const u32,
     pub d_run_off: *const u64,
     pub d_subs: *const u64,
+    pub d_ids24: *const u8,
 }
 
 #[repr(C)]

@@ -15,8 +15,9 @@
 //!   equality, `$share` members, the v3/v5 collector) runs in the caller's task over `inner.relations`, the source
 //!   of truth — N tokio workers expand N publishes in parallel, as in the reference;
 //! * a sub id freed by `remove` is QUARANTINED until the next commit has dropped it from the device table, and every
-//!   pass carries the mutation epoch it ran at: a publish whose pass is older than the last mutation is matched again
-//!   on its own, so a recycled id can never resolve to a relation the device did not match (round-2 advisor finding);
+//!   pass carries the mutation epoch it ran at (bumped by `remove` / `resync` only — an `add` never recycles an id that a
+//!   pass in flight may hold): a publish whose pass is older than the last removal is matched again on its own, so a
+//!   recycled id can never resolve to a relation the device did not match (round-2 / round-3 advisor findings);
 //! * `$share` members (router.rs:202-213) are collected per (filter, group) while one filter's relations go by
 //!   and `SharedSubscription::choice` picks one (router.rs:236-255) — same place, same arguments.
 //!
@@ -105,6 +106,8 @@ pub struct GpuRouter {
     slab: Arc<RwLock<Slab>>,
     dirty: Arc<AtomicBool>,
     epoch: Arc<MutationEpoch>,
+    /// serialises [epoch read + commit] of every pass and of `match_one_exclusive`; lock order: commit_lock, then `slab`
+    commit_lock: Arc<std::sync::Mutex<()>>,
     batcher: Arc<Batcher>,
 }
 
@@ -134,18 +137,24 @@ impl GpuRouter {
         let dirty = Arc::new(AtomicBool::new(false));
         let epoch = Arc::new(MutationEpoch::default());
         let slab = Arc::new(RwLock::new(Slab::default()));
-        let commit = Self::committer(GroupPtr(g.0), dirty.clone(), epoch.clone(), slab.clone());
+        let commit_lock = Arc::new(std::sync::Mutex::new(()));
+        let commit = Self::committer(GroupPtr(g.0), dirty.clone(), epoch.clone(), slab.clone(), commit_lock.clone());
         // pending subscription changes become visible right before the next pass, on the batcher's blocking thread
         let batcher = Batcher::spawn(GroupPtr(g.0), max_batch, max_delay, commit);
-        Ok(Self { inner: DefaultRouter::new(Some(scx.clone())), scx, g, slab, dirty, epoch, batcher: Arc::new(batcher) })
+        Ok(Self { inner: DefaultRouter::new(Some(scx.clone())), scx, g, slab, dirty, epoch, commit_lock, batcher: Arc::new(batcher) })
     }
 
     /// What runs right before a device pass: the mutation epoch the pass may claim (read BEFORE the commit, so a
     /// mutation racing with the commit makes the pass look older than it is, never newer), then `rgr_group_commit`;
     /// the sub ids freed before this commit leave quarantine once it succeeded.
-    fn committer(gp: GroupPtr, dirty: Arc<AtomicBool>, epoch: Arc<MutationEpoch>, slab: Arc<RwLock<Slab>>)
+    fn committer(gp: GroupPtr, dirty: Arc<AtomicBool>, epoch: Arc<MutationEpoch>, slab: Arc<RwLock<Slab>>, commit_lock: Arc<std::sync::Mutex<()>>)
                  -> impl Fn() -> std::result::Result<u64, String> + Send + Sync + Clone + 'static {
+        // Several passes may be in flight (batcher.rs MAX_IN_FLIGHT): the epoch read and the commit it may trigger are ONE critical
+        // section, so a pass can only start on the table of a finished commit.  Without it pass B could skip the commit that pass A
+        // is still running (dirty already swapped), walk the previous device epoch, and come back with a removed sub id after A's
+        // commit has released that id to a new subscription — under an unchanged mutation epoch.
         move || {
+            let _one_at_a_time = commit_lock.lock().unwrap();
             let e = epoch.get();
             if dirty.swap(false, Ordering::AcqRel) {
                 let released = std::mem::take(&mut slab.write().unwrap().quarantine);
@@ -160,13 +169,16 @@ impl GpuRouter {
         }
     }
 
-    /// sub id of each matched filter's first subscriber -> the filter strings, in `TopicTree::matches` order
-    fn filters_of(s: &Slab, first_subs: &[u32]) -> Vec<TopicFilter> {
-        first_subs.iter().filter_map(|sid| s.slots.get(*sid as usize).and_then(|x| x.as_ref()).map(|(f, _, _)| f.clone())).collect()
+    /// sub id of each matched filter's first subscriber -> the filter strings, in `TopicTree::matches` order.
+    /// `None`: an id of the pass does not resolve.  Under an equal epoch that cannot happen; if it ever does the publish is
+    /// matched again (callers) instead of silently losing that filter's subscribers (round-3 advisor).
+    fn filters_of(s: &Slab, first_subs: &[u32]) -> Option<Vec<TopicFilter>> {
+        first_subs.iter().map(|sid| s.slots.get(*sid as usize).and_then(|x| x.as_ref()).map(|(f, _, _)| f.clone())).collect()
     }
 
     /// Commit, match ONE topic and resolve its filters while holding the slab exclusively (blocking: call under `spawn_blocking`).
     fn match_one_exclusive(&self, topic: &str) -> std::result::Result<Vec<TopicFilter>, String> {
+        let _one_at_a_time = self.commit_lock.lock().unwrap();
         let mut s = self.slab.write().unwrap();
         if self.dirty.swap(false, Ordering::AcqRel) {
             if unsafe { rgr_group_commit(self.g.0) } != RGR_OK {
@@ -177,7 +189,8 @@ impl GpuRouter {
             s.free.extend(released);
         }
         let hits = unsafe { match_many(GroupPtr(self.g.0), &[topic.to_string()], self.epoch.get()) }?.remove(0)?;
-        Ok(Self::filters_of(&s, &hits.first_subs))
+        // committed and matched with the slab held: every id resolves, or the table and the slab disagree — an error, not a drop
+        Self::filters_of(&s, &hits.first_subs).ok_or_else(|| format!("device table out of step with the sub id slab for topic `{topic}`"))
     }
 
     pub fn _inner(&self) -> &DefaultRouter {
@@ -223,7 +236,9 @@ impl GpuRouter {
                                    node_idx, owner_id, client_idx)
         };
         if rc != RGR_OK { return Err(anyhow::anyhow!("rgr_group_subscribe_ex: {}", last_error())); }
-        self.epoch.bump();
+        // NO epoch bump: an add cannot make a sub id of a pass in flight resolve to another relation — ids are only recycled
+        // out of the quarantine that `mirror_remove` fills, and that bumps.  (Bumping here sent every batched publish through
+        // the exclusive re-match path under plain subscribe churn: round-3 advisor.)
         self.dirty.store(true, Ordering::Release);
         Ok(())
     }
@@ -244,8 +259,11 @@ impl GpuRouter {
         };
         let rc = unsafe { rgr_group_unsubscribe(self.g.0, topic_filter.as_ptr() as _, topic_filter.len() as u32, sid, last as i32) };
         if rc != RGR_OK { return Err(anyhow::anyhow!("rgr_group_unsubscribe: {}", last_error())); }
-        self.epoch.bump();
+        // dirty BEFORE the bump (round-3 advisor): the committer reads the epoch first and `dirty` second, so a pass that
+        // claims the bumped epoch is guaranteed to have seen dirty == true and committed the removal.  The other order let a
+        // pass claim epoch E+1 while the device still answered with the removed id.
         self.dirty.store(true, Ordering::Release);
+        self.epoch.bump();
         Ok(())
     }
 
@@ -291,8 +309,8 @@ impl GpuRouter {
         if unsafe { rgr_group_sub_attrs_bulk(self.g.0, sub_ids.as_ptr(), owners.as_ptr(), clients.as_ptr(), n) } != RGR_OK {
             return Err(anyhow::anyhow!("rgr_group_sub_attrs_bulk: {}", last_error()));
         }
+        self.dirty.store(true, Ordering::Release); // (before the bump: see mirror_remove)
         self.epoch.bump();
-        self.dirty.store(true, Ordering::Release);
         Ok(())
     }
 }
@@ -320,7 +338,7 @@ impl Router for GpuRouter {
         // add / remove has happened since the pass: otherwise this publish is matched again on its own (rare).
         let resolved: Option<Vec<TopicFilter>> = {
             let s = self.slab.read().unwrap();
-            (self.epoch.get() == hits.epoch).then(|| Self::filters_of(&s, &hits.first_subs))
+            if self.epoch.get() == hits.epoch { Self::filters_of(&s, &hits.first_subs) } else { None }
         };
         let filters = match resolved {
             Some(f) => f,

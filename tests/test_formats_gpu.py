@@ -41,8 +41,13 @@ def windows(batch, fmt):
             assert not w.d_sub_ids and not w.d_qos
             a = d2h(w.d_tuples, nh * 12).view(capi.TUPLE_DTYPE) if nh else np.zeros(0, dtype=capi.TUPLE_DTYPE)
             b = None
+        elif fmt == capi.RGR_FORMAT_IDS24:
+            assert not w.d_tuples and not w.d_sub_ids and not w.d_qos
+            raw = d2h(w.d_ids24, nh * 3).reshape(-1, 3).astype(np.uint32) if nh else np.zeros((0, 3), dtype=np.uint32)
+            a = raw[:, 0] | (raw[:, 1] << 8) | (raw[:, 2] << 16)
+            b = None
         else:
-            assert not w.d_tuples
+            assert not w.d_tuples and not w.d_ids24
             a = d2h(w.d_sub_ids, nh * 4).view(np.uint32) if nh else np.zeros(0, dtype=np.uint32)
             b = (d2h(w.d_qos, nh) if nh else np.zeros(0, dtype=np.uint8)) if fmt == capi.RGR_FORMAT_SOA else None
             assert (fmt == capi.RGR_FORMAT_SOA) == bool(w.d_qos) or nh == 0
@@ -66,11 +71,13 @@ def test_compact_formats_equal_tuples(window_hits):
     ref = windows(batch, capi.RGR_FORMAT_TUPLE)
     soa = windows(batch, capi.RGR_FORMAT_SOA)
     pk = windows(batch, capi.RGR_FORMAT_PACKED)
-    assert len(ref) == len(soa) == len(pk) and len(ref) > (3 if window_hits < (1 << 20) else 0)
+    i24 = windows(batch, capi.RGR_FORMAT_IDS24)
+    assert len(ref) == len(soa) == len(pk) == len(i24) and len(ref) > (3 if window_hits < (1 << 20) else 0)
     total = 0
-    for (tb0, te0, o0, t, _), (tb1, te1, o1, ids, q), (tb2, te2, o2, pw, _) in zip(ref, soa, pk):
-        assert (tb0, te0) == (tb1, te1) == (tb2, te2) and np.array_equal(o0, o1) and np.array_equal(o0, o2)
+    for (tb0, te0, o0, t, _), (tb1, te1, o1, ids, q), (tb2, te2, o2, pw, _), (tb3, te3, o3, i3, _) in zip(ref, soa, pk, i24):
+        assert (tb0, te0) == (tb1, te1) == (tb2, te2) == (tb3, te3) and np.array_equal(o0, o1) and np.array_equal(o0, o2) and np.array_equal(o0, o3)
         assert np.array_equal(ids, t["sub_id"])
+        assert np.array_equal(i3, t["sub_id"])                      # 3-byte ids: same hits, same order
         qf = t["qos_flags"]
         assert np.array_equal(q, ((qf & 3) | (((qf >> 8) & 0x3F) << 2)).astype(np.uint8))
         assert np.array_equal(pw, t["sub_id"] | ((qf & 3) << 30))
@@ -92,8 +99,10 @@ def test_compact_formats_retain_and_limits():
     b = r.retain_batch(fb, fo)
     ref = windows(b, capi.RGR_FORMAT_TUPLE)
     soa = windows(b, capi.RGR_FORMAT_SOA)
-    for (_, _, o0, t, _), (_, _, o1, ids, q) in zip(ref, soa):
+    i24 = windows(b, capi.RGR_FORMAT_IDS24)
+    for (_, _, o0, t, _), (_, _, o1, ids, q), (_, _, o2, i3, _) in zip(ref, soa, i24):
         assert np.array_equal(o0, o1) and np.array_equal(ids, t["sub_id"]) and not q.any()
+        assert np.array_equal(o0, o2) and np.array_equal(i3, t["sub_id"])
     assert sum(len(x[3]) for x in ref) == 3001 + 3000 + 2 + 3002
     b.close()
     # delivery stage and compact formats exclude each other; PACKED needs ids below 2^30
@@ -103,6 +112,10 @@ def test_compact_formats_retain_and_limits():
     tb, to = capi.pack(["a/b"])
     pb = r.batch(tb, to)
     pb.set_format(capi.RGR_FORMAT_PACKED)
+    with pytest.raises(capi.RgrError) as e:
+        pb.begin()
+    assert e.value.code == capi.RGR_ECAPACITY
+    pb.set_format(capi.RGR_FORMAT_IDS24)                             # ... and IDS24 below 2^24
     with pytest.raises(capi.RgrError) as e:
         pb.begin()
     assert e.value.code == capi.RGR_ECAPACITY

@@ -42,6 +42,9 @@ def hr():
     L.hr_batcher_run.argtypes = [vp, C.POINTER(HrId), C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                  C.POINTER(C.c_uint64)]
     L.hr_batcher_run.restype = vp
+    L.hr_batcher_run_async.argtypes = [vp, C.POINTER(HrId), C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                       C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+    L.hr_batcher_run_async.restype = vp
     L.hr_add.argtypes = [vp, C.c_char_p, C.c_uint32, C.POINTER(HrId), C.POINTER(HrOpts)]
     L.hr_remove.argtypes = [vp, C.c_char_p, C.c_uint32, C.POINTER(HrId)]
     L.hr_matches.argtypes = [vp, C.POINTER(HrId), C.c_char_p, C.c_uint32]; L.hr_matches.restype = vp
@@ -337,6 +340,80 @@ def test_batcher_many_threads_one_pass_per_batch(hr):
         exp = _strip_rel(o.matches(ids_o[i], t))
         assert got[i] == ("!ERR" if exp is None else exp), (i, t)
     assert 1 <= passes.value < n / 3
+    hr.hr_free(g)
+
+
+@pytest.mark.parametrize("workers", [0, 4])
+def test_batcher_async_submit_pipelined_passes(hr, workers):
+    """The asynchronous form of the boundary (Batcher::submit: what a tokio task awaiting `matches` is): publishes submitted without
+    waiting from 4 threads, up to 3 device passes in flight, completions on pool threads (or on the drivers when there is no pool).
+    Every publish gets exactly what the unbatched trait call returns."""
+    g = hr.hr_new(1, 0)
+    o = orc.DefaultRouter()
+    hr.hr_set_shared_policy(g, 1)
+    o.set_shared_policy(1)
+    hr.hr_set_match_mode(g, 1)
+    rng = random.Random(4242)
+    _random_world(hr, g, o, rng, n_ops=600)
+    topics = _topics(rng, 900)
+    n = len(topics)
+    ids_h, ids_o = zip(*[_id(rng.choice([1, 2]), f"c{rng.randint(0, 25)}", rng.randint(0, 1)) for _ in range(n)])
+    arr_ids = (HrId * n)(*ids_h)
+    enc = [t.encode() for t in topics]
+    arr_t = (C.c_char_p * n)(*enc)
+    arr_l = (C.c_uint32 * n)(*[len(e) for e in enc])
+    passes = C.c_uint64(0)
+    got = _take(hr, hr.hr_batcher_run_async(g, arr_ids, arr_t, arr_l, n, 4, 128, 500, 3, workers, C.byref(passes))).split("\x1e")
+    assert len(got) == n
+    for i, t in enumerate(topics):
+        exp = _strip_rel(o.matches(ids_o[i], t))
+        assert got[i] == ("!ERR" if exp is None else exp), (i, t)
+    assert 1 <= passes.value < n / 3
+    hr.hr_free(g)
+
+
+@pytest.mark.gpu
+def test_plain_subscribes_do_not_invalidate_passes_in_flight(hr):
+    """Round-3 advisor: add() used to bump the mutation epoch, so under ordinary subscribe churn (no unsubscribe at all) nearly every
+    batched publish fell into the exclusive one-publish re-match.  Only remove / restore bump it now: with a subscriber thread that
+    only ADDS, no expansion may go stale — and every stable relation is still delivered."""
+    import threading
+    g = hr.hr_new(1, 0)
+    hr.hr_set_match_mode(g, 1)
+    stable = [("s/+/x", "keep1"), ("s/#", "keep2"), ("s/a/x", "keep3")]
+    for f, c in stable:
+        hid, _ = _id(1, c)
+        assert hr.hr_add(g, f.encode(), len(f), C.byref(hid), C.byref(HrOpts())) == 0
+    stop = threading.Event()
+
+    def churn():
+        k = 0
+        while not stop.is_set():
+            f = f"t/{k % 97}/+"
+            hid, _ = _id(1, f"adder{k}")
+            hr.hr_add(g, f.encode(), len(f), C.byref(hid), C.byref(HrOpts()))
+            k += 1
+    th = threading.Thread(target=churn)
+    th.start()
+    try:
+        topics = ["s/a/x", "t/5/y", "u/q", "s/b/x"] * 100
+        n = len(topics)
+        ids_h = [_id(1, f"pub{i % 5}")[0] for i in range(n)]
+        arr_ids = (HrId * n)(*ids_h)
+        enc = [t.encode() for t in topics]
+        arr_t = (C.c_char_p * n)(*enc)
+        arr_l = (C.c_uint32 * n)(*[len(e) for e in enc])
+        passes = C.c_uint64(0)
+        for _ in range(3):
+            out = _take(hr, hr.hr_batcher_run(g, arr_ids, arr_t, arr_l, n, 6, 64, 300, C.byref(passes))).split("\x1e")
+            for t, dump in zip(topics, out):
+                got = {(ln.split("\t")[0][2:], ln.split("\t")[1]) for ln in dump.split("\n") if ln.startswith("3 ")}
+                for f, c in stable:
+                    assert ((f, c) in got) == brute.filter_matches(f, t), (f, c, t)
+    finally:
+        stop.set()
+        th.join()
+    assert hr.hr_stale_expansions(g) == 0
     hr.hr_free(g)
 
 

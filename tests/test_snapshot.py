@@ -102,3 +102,29 @@ def test_bad_snapshots_are_rejected_and_leave_the_table_alone(kind, tmp_path):
     b.snapshot_load(good)                                            # and the good one still loads
     b.commit()
     assert np.array_equal(b.match_batch(blob, offs)["tuples"], before["tuples"])
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_version_1_snapshots_still_load(kind, tmp_path, monkeypatch):
+    """Round-3 advisor: the snapshot version went 1 -> 2 when the last 8 bytes of an edge record became the child-token bitmap, and v1
+    files were refused although those bytes are derived data.  A v1 file (written through the test-only RGR_SNAPSHOT_WRITE_V1 switch,
+    with header bytes that are NOT a valid bitmap) must load, have its bitmaps rebuilt, and match like the table it was saved from."""
+    b = make_backend(kind)
+    for i in range(400):
+        b.sub_add(b.filter_add(f"x/{i % 37}/y{i}/+"), i, i % 3)
+        b.sub_add(b.filter_add(f"lvl{i}/#"), 1000 + i, 1)
+    b.commit()
+    blob, offs = pack([f"x/{i % 37}/y{i}/z" for i in range(0, 400, 7)] + [f"lvl{i}/a/b" for i in range(0, 400, 11)] + ["nope/x"])
+    exp = b.match_batch(blob, offs)
+    assert len(exp["tuples"]) > 80
+    path = str(tmp_path / "v1.rgrsnap")
+    monkeypatch.setenv("RGR_SNAPSHOT_WRITE_V1", "1")
+    b.snapshot_save(path)
+    monkeypatch.delenv("RGR_SNAPSHOT_WRITE_V1")
+    import struct
+    assert struct.unpack_from("<I", open(path, "rb").read(), 8)[0] == 1
+    c = make_backend(kind)
+    c.snapshot_load(path)
+    c.commit()
+    got = c.match_batch(blob, offs)
+    assert np.array_equal(got["tuples"], exp["tuples"]) and np.array_equal(got["hit_offsets"], exp["hit_offsets"])
