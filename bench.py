@@ -134,6 +134,18 @@ def shard_inputs(W, world, rank):
     return blob_r, offs_r, sub_ids[keep_f], W["qos"][keep_f], tb_r, to_r, keep_t
 
 
+def deliver_flags(n, deliver_frac):
+    """RGR_SUB_* flags of the delivery-stage workload: `deliver_frac` of the subscriptions are MQTT v5, 30 % of those No Local, 50 % RAP (seeded)."""
+    from rmqtt_amd import capi
+    drng = np.random.default_rng(11)
+    is5 = drng.random(n) < deliver_frac
+    return (is5 * capi.RGR_SUB_V5 | (is5 & (drng.random(n) < 0.3)) * capi.RGR_SUB_NO_LOCAL | (is5 & (drng.random(n) < 0.5)) * capi.RGR_SUB_RAP).astype(np.uint8)
+
+
+DELIVER_SECONDARY_V5 = 0.1          # v5 fraction of the delivery-stage secondary record
+_ORACLES = {}                       # (cfg, scale) -> oracle DefaultRouter kept for the delivery record of the same run (its build is 30 s at config 3)
+
+
 def build_table(r, W, blob, offs, sub_ids, qos, deliver_frac=-1.0):
     from rmqtt_amd import capi
     t = time.time()
@@ -143,11 +155,7 @@ def build_table(r, W, blob, offs, sub_ids, qos, deliver_frac=-1.0):
     else:
         flags = None
         if deliver_frac >= 0:
-            drng = np.random.default_rng(11)
-            n = len(offs) - 1
-            is5 = drng.random(n) < deliver_frac
-            flags = (is5 * capi.RGR_SUB_V5 | (is5 & (drng.random(n) < 0.3)) * capi.RGR_SUB_NO_LOCAL |
-                     (is5 & (drng.random(n) < 0.5)) * capi.RGR_SUB_RAP).astype(np.uint8)
+            flags = deliver_flags(len(offs) - 1, deliver_frac)
             W["deliver_flags"] = flags
         rej = r.subscribe_bulk(blob, offs, sub_ids, qos, flags)
         if deliver_frac >= 0:
@@ -415,6 +423,71 @@ def compare_with_oracle(o, W, got, gpu_status, fmt_ok, dinfo, threads, primary, 
     return rec
 
 
+def delivery_oracle_sample(o, W, batch, pa, threads, seed=20260923):
+    """Delivery words of the timed batch against the ORACLE at full table size: one more full pass; per topic the digest of
+    x = sub_id * 32 + (word & 31) over its hits in position order, reduced on the device, compared with DefaultRouter::deliver_digest
+    (which hits are delivered comes from the oracle's matches(): the restated _matches + collector) for a stratified sample — the
+    heaviest topics, the topics of the first / last window ends, and a seeded random draw — bounded by the oracle's cost (O(hits) with
+    a row per delivered hit)."""
+    import torch
+    from rmqtt_amd import shard
+    n = W["n_pub"]
+    t0 = time.time()
+    D = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+    batch.begin()
+    while True:
+        w = batch.next_window()
+        if w is None:
+            break
+        nh, tb_, te_ = int(w.n_hits), int(w.topic_begin), int(w.topic_end)
+        torch.cuda.synchronize()
+        if not nh:
+            continue
+        d_off = torch.as_tensor(_DevArr(w.d_hit_offsets, (te_ - tb_ + 1,), "<i8"), device="cuda") - int(w.offsets_bias)
+        start, end = d_off[:-1], d_off[1:]
+        t = torch.as_tensor(_DevArr(w.d_tuples, (nh, 3), "<i4"), device="cuda")
+        x = (t[:, 1].to(torch.int64) & 0xFFFFFFFF) * 32 + (t[:, 2].to(torch.int64) & 31)
+
+        def seg(v):
+            cs = torch.cumsum(v, 0)
+            hi_ = torch.where(end > 0, cs[(end - 1).clamp(min=0)], torch.zeros_like(end))
+            lo_ = torch.where(start > 0, cs[(start - 1).clamp(min=0)], torch.zeros_like(start))
+            return hi_ - lo_
+        acc = D[tb_:te_]
+        acc[:, 0] = end - start
+        s1 = seg(x)
+        acc[:, 1] = s1
+        acc[:, 2] = seg(torch.arange(1, nh + 1, dtype=torch.int64, device="cuda") * x) - start * s1
+        acc[:, 3] = seg(x * x)
+        del t, x, s1, d_off, start, end
+        torch.cuda.synchronize()
+    gpu_s = time.time() - t0
+    hits = D[:, 0].cpu().numpy()
+    rng = np.random.default_rng(seed)
+    budget = 2.5e8 * max(1, threads) / 256
+    heavy = np.argsort(hits)[::-1][:256]
+    heavy = heavy[:max(1, int(np.searchsorted(np.cumsum(hits[heavy]), 0.25 * budget, side="right")))]
+    n_rand = int(min(n, max(64, 0.7 * budget / max(1.0, float(hits.mean())))))
+    sel = np.unique(np.concatenate([heavy, np.arange(min(n, 64)), np.arange(max(0, n - 64), n), rng.choice(n, size=n_rand, replace=False)]))
+    sb, so = shard.take(W["tb"], W["to"], sel)
+    t1 = time.time()
+    st, exp = o.deliver_digest(sb, so, pa["from_id"][sel], pa["qos_retain"][sel].astype(np.uint8), threads)
+    cpu_s = time.time() - t1
+    got = D[torch.from_numpy(sel).cuda()].cpu().numpy().view(np.uint64)
+    gst = batch.status()[sel]
+    bad = np.nonzero((got != exp).any(axis=1))[0]
+    ok = bool(np.array_equal(gst < 0, st < 0) and len(bad) == 0)
+    rec = {"ok": ok, "topics": int(len(sel)), "hits": int(exp[:, 0].sum()), "max_hits_in_one_topic": int(exp[:, 0].max()) if len(sel) else 0,
+           "oracle_s": round(cpu_s, 2), "gpu_digest_s": round(gpu_s, 2),
+           "what": "per topic: hits, sum x, sum (k+1) x, sum x^2 with x = sub_id*32 + (delivery word & 31), device vs the oracle's DefaultRouter::deliver_digest "
+                   "(delivered hits = the rows of its matches()) on the heaviest topics, both ends of the batch and a seeded random draw; full table"}
+    if not ok:
+        rec["first_bad_topic"] = int(sel[bad[0]]) if len(bad) else None
+        rec["mismatching_topics"] = int(len(bad))
+    del D
+    return rec
+
+
 def parity_sample(r, o, W, batch, threads, primary):
     """N = 1: device digests of the whole timed batch in every format, then the exhaustive comparison with the oracle."""
     D, fmt_ok, dinfo = device_digests(r, batch, W["n_pub"], W["retain"], qos=W["qos"])
@@ -538,16 +611,23 @@ def pmc_child(args):
     from rmqtt_amd import capi, shard
     phases = []
     for name in args.pmc_phases.split(","):
-        cfg, scale = (args.config, args.scale) if name == "primary" else (int(name[6:]), 1.0)
+        deliver = name == "deliver"           # the delivery-stage secondary: config 3 with v5 subscriptions and publish attributes
+        cfg, scale = (args.config, args.scale) if name == "primary" else ((3, 1.0) if deliver else (int(name[6:]), 1.0))
         W = gen_workload(cfg, scale)
         r = capi.Router(device=0, window_hits=args.window_hits, collect_walk_stats=False)
         world = args.pmc_world if name == "primary" else 1
         blob_r, offs_r, sub_ids_r, qos_r, tb_r, to_r, _ = shard_inputs(W, world, args.pmc_rank if world > 1 else 0)
-        build_table(r, W, blob_r, offs_r, sub_ids_r, qos_r)
+        build_table(r, W, blob_r, offs_r, sub_ids_r, qos_r, DELIVER_SECONDARY_V5 if deliver else -1.0)
         n_mine = len(to_r) - 1
         n = min(n_mine, args.pmc_topics)
         sb, so = shard.take(tb_r, to_r, np.arange(n)) if n < n_mine else (tb_r, to_r)
         b = r.retain_batch(sb, so) if W["retain"] else r.batch(sb, so)
+        if deliver:
+            pa = np.zeros(n, dtype=capi.PUBLISH_ATTR_DTYPE)
+            prng = np.random.default_rng(12)
+            pa["from_id"] = prng.choice(W["client"].astype(np.uint32), size=n)
+            pa["qos_retain"] = prng.integers(0, 3, size=n) | (prng.integers(0, 2, size=n) << 2)
+            b.set_publish_attrs(pa)
         r.stats_reset()
         hits, _ = b.run()
         st = r.stats()
@@ -815,6 +895,33 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
         if not args.no_parity:
             rec["parity_sample"] = delivery_parity(batch, W, pa)
             log(f"config {cfg}: delivery parity {rec['parity_sample']}", 0)
+        if args.cpu_sample != 0 and world == 1:
+            # the oracle's side of the delivery record: its own delivery verdicts for a stratified sample of publishes (digests of the
+            # per-hit words in canonical order, DefaultRouter::deliver_digest) against the device's, and the reference-shaped
+            # _matches + collector + forwards_to pass as the CPU baseline
+            from oracle import oracle as orc
+            cores = args.cpu_threads or os.cpu_count() or 1
+            o = _ORACLES.pop((cfg, scale, deliver), None)
+            if o is None:
+                t = time.time()
+                o = orc.DefaultRouter()
+                o.add_bulk_ex(blob, offs, client, qos, W["deliver_flags"])
+                log(f"config {cfg}: oracle table with v5 flags built in {time.time() - t:.1f}s", 0)
+            if not args.no_parity:
+                rec["parity_sample"]["oracle"] = delivery_oracle_sample(o, W, batch, pa, cores)
+                rec["parity_sample"]["ok"] = bool(rec["parity_sample"]["ok"] and rec["parity_sample"]["oracle"]["ok"])
+                log(f"config {cfg}: delivery oracle sample {rec['parity_sample']['oracle']}", 0)
+            hpt = max(1.0, total_hits / max(1, total_topics))
+            n_s = int(min(n_pub, max(500, 4.0e8 * cores / 256 / hpt)))
+            idx = np.sort(np.random.default_rng(20260922).choice(n_pub, size=n_s, replace=False))
+            sb, so = shard.take(tb, to, idx)
+            sec, ost = o.forwards_timed(sb, so, pa["from_id"][idx], pa["qos_retain"][idx].astype(np.uint8), cores)
+            rec["cpu_baseline"] = {"value": round(n_s / sec, 1), "unit": rec["unit"], "cores": cores, "kind": "port",
+                                   "what": "DefaultRouter::_matches with the v3 / v5 collector (router.rs:174-265, types.rs:510-540: No Local, first hit per v5 client) + "
+                                           "forwards_to's per-recipient qos / retain transform (shared.rs:886-908); ref-counted clones, no canonicalising sort",
+                                   "sample": f"{n_s} publishes drawn at random (seeded) from the same batch, {ost['hits']} relations visited, {ost['rows']} rows delivered, {sec:.2f}s wall",
+                                   "hits_per_s": round(ost["hits"] / sec, 1)}
+            del o
 
     hits_per_topic = max(1.0, total_hits / max(1, total_topics))
     # ---- opt-in compact result formats (SURVEY 8(b)'s SoA result; rgr_batch_set_format), reported BESIDE the 12-byte
@@ -857,6 +964,19 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
         rec["pcie_inclusive_matches_per_s"] = round(n_d / dt, 1)
         rec["pcie_inclusive"] = {"sample": f"first {n_d} topics of the batch, every window streamed to pinned host memory (rgr_batch_run_to_host)",
                                  "tuple_GBps": round(h2 * 12 / dt / 1e9, 2), "seconds": round(dt, 3)}
+        if retain:
+            # the retained path's dense answer (rgr_retain_match_ranges): per filter the ranges of the host-mirrored preorder value array —
+            # host strings in, host-resident answer out, for the WHOLE batch (the tuple form above can only afford a prefix)
+            r.retain_match_ranges(*prefix(W, min(n_pub, 1000)), flatten=False)
+            t = time.time()
+            rg = r.retain_match_ranges(tb, to, flatten=False)
+            dt = time.time() - t
+            rec["pcie_inclusive_ranges"] = {"matches_per_s": round(n_pub / dt, 1), "seconds": round(dt, 3), "filters": int(n_pub), "ranges": rg["n_ranges"],
+                                            "entries_described": rg["n_entries"], "equals_hits_of_the_timed_pass": bool(rg["n_entries"] == total_hits),
+                                            "bytes_over_pcie": rg["n_ranges"] * 16, "vs_tuple_bytes": int(rg["n_entries"]) * 12,
+                                            "speedup_vs_tuples_to_host": round((n_pub / dt) / max(1e-9, rec["pcie_inclusive_matches_per_s"]), 1),
+                                            "what": "rgr_retain_match_ranges over the full batch: filter strings from host memory -> per filter the ranges of "
+                                                    "the value array the library mirrors on the host (16 B per range over PCIe; `a/#` is one range)"}
 
     # ---- CPU baseline (reference-shaped port) + parity sample against the oracle on the full table (N=1 only)
     if world > 1 and gathered is not None and deliver < 0:
@@ -882,7 +1002,12 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
             o.insert_bulk(blob, offs)
         else:
             o = orc.DefaultRouter()
-            o.add_bulk(blob, offs, client, qos)
+            keep = primary and cfg == 3 and scale == 1.0 and not args.no_secondary
+            if keep:        # the delivery-stage secondary of this run reuses this table: same subscriptions, its v5 flags ride along (they
+                            # change nothing here: the digests read rel ids and qos, the timed pass's publisher matches no subscriber Id)
+                o.add_bulk_ex(blob, offs, client, qos, deliver_flags(n_sub, DELIVER_SECONDARY_V5))
+            else:
+                o.add_bulk(blob, offs, client, qos)
         log(f"config {cfg}: oracle table built in {time.time() - t:.1f}s; cpu_baseline on {cores} threads", 0)
         # bounded sample: ~15 s of CPU work at the oracle's measured rates (primary), ~5 s (secondary)
         budget_hits = (3.5e7 if retain else 1.2e9) * cores / 256 * (1.0 if primary else 0.3)
@@ -914,9 +1039,11 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
         if not args.no_parity:
             rec["parity_sample"] = parity_sample(r, o, W, batch, cores, primary)
             log(f"config {cfg}: parity_sample {rec['parity_sample']}", 0)
+        if not retain and primary and cfg == 3 and scale == 1.0 and not args.no_secondary:
+            _ORACLES[(cfg, scale, DELIVER_SECONDARY_V5)] = o
         del o
     else:
-        rec["cpu_baseline"] = None
+        rec.setdefault("cpu_baseline", None)      # (the delivery record set its own above)
 
     phase = {"st": st, "dominant": dominant, "retain": retain}
     batch.close(); r.close()
@@ -1171,7 +1298,14 @@ def self_launch(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     log("self-launch: " + " ".join(cmd))
-    return subprocess.call(cmd)
+    # stdout carries ONE JSON line (rank 0's); whatever else the ranks' libraries print there (gloo's connection banner) goes to stderr
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
+    for line in p.stdout:
+        if line.startswith("{") and line.rstrip().endswith("}"):
+            sys.stdout.write(line); sys.stdout.flush()
+        else:
+            sys.stderr.write(line)
+    return p.wait()
 
 
 def main():
@@ -1268,8 +1402,9 @@ def main():
         # the delivery stage on the headline workload with 10 % MQTT v5 subscriptions: delivery words fused into the
         # expansion + per-client first-hit dedup; a record of its own so that the driver's run times it
         try:
-            drec, _ = measure(args, 3, 1.0, max(2, args.secondary_steps // 2), 1, False, deliver_frac=0.1)
+            drec, dph = measure(args, 3, 1.0, max(2, args.secondary_steps // 2), 1, False, deliver_frac=DELIVER_SECONDARY_V5)
             secondary.append(drec)
+            sec_phases["deliver"] = (drec, dph)
         except Exception as e:
             log(f"secondary delivery-stage record failed: {e!r}")
             secondary.append({"config": {"workload": "BASELINE.json configs[2] + delivery stage"}, "error": repr(e)})

@@ -413,6 +413,33 @@ int32_t rgr_retain_batch_create(rgr_handle* h, const uint8_t* filters_blob, cons
                                 rgr_batch** out);
 void rgr_retain_result_free(rgr_retain_result* r);
 
+/* ---- the retained path's DENSE answer: ranges of the preorder value array ----------------------------------------------------------
+ * A consumer of RetainStorage::get (rmqtt-retainer/src/storage.rs:604-611; DefaultRetainStorage::get_message retain.rs:250-267)
+ * needs the matched TOPIC IDS, nothing per hit from the device.  The compiled image lays the retained topics out in trie preorder
+ * (DESIGN §3), so `a/#` is ONE contiguous range of the value array and a `+` level a handful: the answer of a filter is a short list of
+ * ranges into an array the host already mirrors (8 bytes per retained topic, refreshed at rgr_retain_commit).  What crosses PCIe is
+ * 16 bytes per RANGE instead of 12 per hit — at BASELINE configs[4] 25.9 k hits per filter travel as ~10 ranges.
+ *   hits of filter i  =  for r in ranges[range_offsets[i] .. range_offsets[i+1]):  vals[tier(r)][r.begin .. r.begin + len(r))
+ * in the order rgr_retain_match_batch returns them; tier(r) = r.len >> 31 (1 = the delta tier of the two-tier mode), len(r) =
+ * r.len & 0x7fffffff.  Entries whose flags carry RGR_RETAIN_HIT_DEAD were removed / replaced after the base tier was compiled: skip
+ * them (rgr_retain_match_batch does the same).  `vals` stay valid until rgr_retain_ranges_free, across later commits. */
+typedef struct rgr_id_range { uint32_t begin, len; } rgr_id_range;
+typedef struct rgr_retain_val { uint32_t topic_id, flags; } rgr_retain_val;
+typedef struct rgr_retain_ranges {
+    uint32_t n_filters;
+    uint64_t n_ranges;
+    uint64_t n_entries;             /* sum of the ranges' lengths (dead entries included)   */
+    int32_t* status;                /* [n_filters]                                          */
+    uint64_t* range_offsets;        /* [n_filters+1]                                        */
+    rgr_id_range* ranges;           /* [n_ranges]                                           */
+    const rgr_retain_val* vals[2];  /* host mirrors of the value arrays: [0] base, [1] delta tier (NULL without one) */
+    uint64_t n_vals[2];
+    void* _owner;
+} rgr_retain_ranges;
+int32_t rgr_retain_match_ranges(rgr_handle* h, const uint8_t* filters_blob, const uint64_t* filter_offsets, uint32_t n,
+                                rgr_retain_ranges* out);
+void rgr_retain_ranges_free(rgr_retain_ranges* r);
+
 /* ---- multi-GPU sharding rule (host-side helper, no device work) -------------------------
  * Table and publishes shard by a hash of the first `key_levels` topic levels (SURVEY.md §8(e):
  * a first-level-only hash is far too skewed under Zipf level-0 tokens; 3 levels keep the

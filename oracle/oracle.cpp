@@ -245,6 +245,75 @@ bool DefaultRouter::match_digest_fast(std::string_view topic_name, uint64_t out[
     return true;
 }
 
+bool DefaultRouter::deliver_digest(const Id& this_id, std::string_view topic_name, uint8_t pub_qos, bool pub_retain, uint64_t out[4]) const {
+    out[0] = out[1] = out[2] = out[3] = 0;
+    SubRelationsMap m;
+    if (!matches(this_id, topic_name, m)) return false;
+    std::vector<uint32_t> delivered;
+    for (auto& kv : m) for (auto& row : kv.second) delivered.push_back(row.rel_id);
+    std::sort(delivered.begin(), delivered.end());
+    Topic topic;
+    parse_topic(topic_name, topic);
+    std::vector<const Rel*> ordered;
+    uint64_t k = 0;
+    for (auto& item : topics_.matches(topic, nullptr)) {
+        auto rit = relations_.find(join_levels(item.first));
+        if (rit == relations_.end()) continue;
+        ordered.clear();
+        for (auto& kv : rit->second.rels) ordered.push_back(&kv.second);
+        std::sort(ordered.begin(), ordered.end(), [](const Rel* a, const Rel* b) { return a->rel_id < b->rel_id; });
+        for (const Rel* rel : ordered) {
+            uint64_t w = std::min<uint8_t>(pub_qos, rel->opts.qos);
+            if (rel->opts.v5 && rel->opts.retain_as_published && pub_retain) w |= 4;
+            if (!std::binary_search(delivered.begin(), delivered.end(), rel->rel_id))
+                w |= (rel->opts.v5 && rel->opts.no_local && this_id == rel->id) ? 8 : 16;
+            const uint64_t x = uint64_t(rel->rel_id) * 32 + w;
+            ++k;
+            out[0]++; out[1] += x; out[2] += k * x; out[3] += x * x;
+        }
+    }
+    return true;
+}
+
+// _matches with the collector + forwards_to's per-recipient transform, reference-shaped (container order, ref-counted clones)
+uint64_t DefaultRouter::forwards_shaped(const Id& this_id, std::string_view topic_name, uint8_t pub_qos, bool pub_retain, WalkStats* st, ShapedScratch* scratch) const {
+    using Out = ShapedScratch::OutFwd;
+    Topic topic;
+    if (!parse_topic(topic_name, topic)) { if (st) st->invalid++; return 0; }
+    if (st) st->levels += topic.size();
+    ShapedScratch local;
+    auto& cm = (scratch ? scratch : &local)->fwd;
+    for (auto& kv : cm) { kv.second.rows.clear(); kv.second.v5_index.clear(); }
+    uint64_t hits = 0;
+    for (auto& item : topics_.matches(topic, st)) {
+        const auto filter = std::make_shared<const std::string>(join_levels(item.first));            // router.rs:179
+        auto rit = shaped_.find(*filter);                                                            // router.rs:194
+        if (rit == shaped_.end()) continue;
+        for (auto& e : rit->second.rels) {
+            const Rel& rel = *e.rel;
+            ++hits;
+            auto nl = rel.opts.opt_no_local();
+            if (nl && *nl && this_id == rel.id) continue;                                            // router.rs:196-201
+            auto& node = cm[rel.id.node_id];
+            if (rel.opts.is_v3()) { node.rows.push_back(Out{filter, e.client, rel.opts, {}, 0, false}); continue; }      // types.rs:519-521
+            auto it = node.v5_index.find(std::string_view(*e.client));                                // types.rs:524-539
+            if (it != node.v5_index.end()) { if (rel.opts.sub_ident) node.rows[it->second].sub_ids.push_back(rel.opts.sub_ident); continue; }
+            node.v5_index.emplace(std::string_view(*e.client), node.rows.size());
+            node.rows.push_back(Out{filter, e.client, rel.opts, rel.opts.sub_ident ? std::vector<uint32_t>{rel.opts.sub_ident} : std::vector<uint32_t>{}, 0, false});
+        }
+    }
+    uint64_t rows = 0;
+    for (auto& kv : cm)                                                                              // shared.rs:886-908, per recipient
+        for (auto& r : kv.second.rows) {
+            r.retain = r.opts.v5 ? (r.opts.retain_as_published && pub_retain) : false;
+            r.qos = std::min<uint8_t>(pub_qos, r.opts.qos);
+            ++rows;
+        }
+    if (st) st->hits += hits;
+    for (auto& kv : cm) { kv.second.rows.clear(); kv.second.v5_index.clear(); }                     // the result is dropped here
+    return rows;
+}
+
 // Reference-shaped publish match for the cpu_baseline leg (see orc_router_matches_timed): the work
 // of router.rs:174-265 per hit, results dropped at the end of the call like the caller's map.
 void DefaultRouter::prepare_shaped() {
@@ -576,6 +645,78 @@ int orc_router_add_bulk(void* r, const char* blob, const uint64_t* offs, uint64_
     return bad;
 }
 
+struct orc_stats { uint64_t levels, visited, matched, hits, invalid; };
+
+// Bulk add with per-subscription v5 flags (the bench's delivery-stage workload): flags bit 0 = v5, bit 1 = No Local, bit 3 = Retain As
+// Published (the RGR_SUB_* bits); Id = { node 1, client "c<client[i]>" }, rel_id = i.
+int orc_router_add_bulk_ex(void* r, const char* blob, const uint64_t* offs, uint64_t n, const uint32_t* client, const uint8_t* qos, const uint8_t* flags) {
+    auto* rt = static_cast<DefaultRouter*>(r);
+    int bad = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        Id id; id.node_id = 1; id.client_id = "c" + std::to_string(client[i]);
+        SubscriptionOptions o; o.qos = qos[i];
+        if (flags) { o.v5 = flags[i] & 1; o.no_local = o.v5 && (flags[i] & 2); o.retain_as_published = o.v5 && (flags[i] & 8); }
+        if (!rt->add(std::string_view(blob + offs[i], offs[i + 1] - offs[i]), id, o, uint32_t(i))) ++bad;
+    }
+    return bad;
+}
+
+// Delivery-stage digests (DefaultRouter::deliver_digest) of a batch: publisher of topic i = client pub_client[i] (0xFFFFFFFF: nobody
+// the table knows), pub_qr[i] = publish qos | retain << 2.  out: [4 n].
+void orc_router_deliver_digest(void* r, const char* blob, const uint64_t* offs, uint64_t n, const uint32_t* pub_client, const uint8_t* pub_qr, int threads,
+                               int32_t* status, uint64_t* out) {
+    auto* rt = static_cast<DefaultRouter*>(r);
+    if (threads < 1) threads = 1;
+    std::atomic<uint64_t> next{0};
+    auto work = [&] {
+        for (;;) {
+            const uint64_t lo = next.fetch_add(4), hi = std::min<uint64_t>(n, lo + 4);
+            if (lo >= n) break;
+            for (uint64_t i = lo; i < hi; ++i) {
+                Id id; id.node_id = pub_client[i] == 0xFFFFFFFFu ? 0 : 1; id.client_id = "c" + std::to_string(pub_client[i]);
+                status[i] = rt->deliver_digest(id, std::string_view(blob + offs[i], offs[i + 1] - offs[i]), pub_qr[i] & 3, (pub_qr[i] & 4) != 0, out + 4 * i) ? 0 : -1;
+            }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int k = 0; k < threads; ++k) th.emplace_back(work);
+    for (auto& t : th) t.join();
+}
+
+// cpu_baseline of the delivery stage: DefaultRouter::forwards_shaped per publish on `threads` threads, chunks of 16 from an atomic cursor.
+// stats->hits = relations visited, *rows = rows delivered (after No Local and the v5 collector).
+double orc_router_forwards_timed(void* r, const char* blob, const uint64_t* offs, uint64_t n, const uint32_t* pub_client, const uint8_t* pub_qr, int threads,
+                                 orc_stats* stats, uint64_t* rows_out) {
+    auto* rt = static_cast<DefaultRouter*>(r);
+    if (threads < 1) threads = 1;
+    rt->prepare_shaped();
+    std::vector<WalkStats> sts(threads);
+    std::vector<uint64_t> rows(threads, 0);
+    std::atomic<uint64_t> next{0};
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::thread> th;
+    for (int k = 0; k < threads; ++k) {
+        th.emplace_back([&, k] {
+            DefaultRouter::ShapedScratch scratch;
+            for (;;) {
+                const uint64_t lo = next.fetch_add(16), hi = std::min<uint64_t>(n, lo + 16);
+                if (lo >= n) break;
+                for (uint64_t i = lo; i < hi; ++i) {
+                    Id id; id.node_id = pub_client[i] == 0xFFFFFFFFu ? 0 : 1; id.client_id = "c" + std::to_string(pub_client[i]);
+                    rows[k] += rt->forwards_shaped(id, std::string_view(blob + offs[i], offs[i + 1] - offs[i]), pub_qr[i] & 3, (pub_qr[i] & 4) != 0, &sts[k], &scratch);
+                }
+            }
+        });
+    }
+    for (auto& t : th) t.join();
+    double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    WalkStats tot;
+    for (auto& s : sts) tot.add(s);
+    if (stats) *stats = orc_stats{tot.levels, tot.visited, tot.matched, tot.hits, tot.invalid};
+    if (rows_out) { *rows_out = 0; for (auto x : rows) *rows_out += x; }
+    return sec;
+}
+
 // Canonical dump of DefaultRouter::matches (App. A.5): per node id ascending,
 //   "N <node>\n" then "3 <filter>\t<client>\t<qos>\t<rel_id>\n" rows sorted, then
 //   "5 <client>\t<first filter>\t<qos>\t<nl>\t<sorted sub ids,>\n" rows sorted by client.
@@ -632,8 +773,6 @@ char* orc_router_forwards(void* r, const orc_id* this_id, const char* topic, uin
     }
     return dup_str(out);
 }
-
-struct orc_stats { uint64_t levels, visited, matched, hits, invalid; };
 
 // Flat id-level match of a batch (single thread): status[n] (0 / -1), hit_offsets[n+1],
 // and per hit filter_id / sub_id / qos / flags.  Arrays are malloc'ed (orc_free).

@@ -261,6 +261,15 @@ class DefaultRouter {   // router.rs:121-127
     void prepare_digests(int threads);
     bool match_digest_fast(std::string_view topic_name, uint64_t out[4]) const;
 
+    // Checker for the delivery stage at sizes where the text dump of forwards() is too big: per publish the digest of
+    // the per-hit delivery verdicts in canonical hit order (filters in TopicTree::matches order, rel_id ascending inside a filter).
+    // WHICH hits are delivered comes from matches() itself — the restated _matches + collector (router.rs:174-265, types.rs:510-540):
+    // a hit is delivered iff its rel_id is a row of the returned SubRelationsMap (a v5 row carries the rel_id of the client's FIRST
+    // hit, types.rs:535-538).  Per hit x = rel_id * 32 + w, w = min(publish qos, subscription qos) (shared.rs:902) | 4 if v5 &&
+    // retain_as_published && publish.retain (shared.rs:886-897) | 8 if dropped by No Local (router.rs:196-201) | 16 if a later v5 hit
+    // of a client already collected (types.rs:526-534).  out = { hits, sum x, sum (k+1) x, sum x^2 } mod 2^64.
+    bool deliver_digest(const Id& this_id, std::string_view topic_name, uint8_t pub_qos, bool pub_retain, uint64_t out[4]) const;
+
     // cpu_baseline only (oracle.cpp: orc_router_matches_timed): the reference's per-publish work without the
     // checker's canonicalisation; prepare_shaped() snapshots the relation maps with ref-counted strings.
     void prepare_shaped();
@@ -269,7 +278,13 @@ class DefaultRouter {   // router.rs:121-127
         struct OutPlain { const std::string* filter; const std::string* client; SubscriptionOptions opts; };
         std::unordered_map<NodeId, std::vector<OutRc>> rc;
         std::unordered_map<NodeId, std::vector<OutPlain>> plain;
+        struct OutFwd { std::shared_ptr<const std::string> filter, client; SubscriptionOptions opts; std::vector<uint32_t> sub_ids; uint8_t qos; bool retain; };
+        struct NodeFwd { std::vector<OutFwd> rows; std::unordered_map<std::string_view, size_t> v5_index; };
+        std::unordered_map<NodeId, NodeFwd> fwd;
     };
+    // cpu_baseline of the delivery stage: _matches with the v3 / v5 collector (no canonicalising sort) + forwards_to's per-recipient
+    // transform (shared.rs:886-908); returns the rows delivered.
+    uint64_t forwards_shaped(const Id& this_id, std::string_view topic_name, uint8_t pub_qos, bool pub_retain, WalkStats* st, ShapedScratch* scratch) const;
     uint64_t matches_shaped(const Id& this_id, std::string_view topic_name, WalkStats* st, bool refcounted = true, ShapedScratch* scratch = nullptr) const;
     uint64_t matches_shaped_plain(const Id& this_id, std::string_view topic_name, WalkStats* st, ShapedScratch* scratch = nullptr) const;
 

@@ -88,6 +88,10 @@ def lib():
         L.orc_retain_match_timed_dyn.restype = C.c_double
         L.orc_router_match_digest.argtypes = [vp, vp, vp, u64, C.c_int, vp, vp]; L.orc_router_match_digest.restype = None
         L.orc_retain_match_digest.argtypes = [vp, vp, vp, u64, C.c_int, vp, vp]; L.orc_retain_match_digest.restype = None
+        L.orc_router_add_bulk_ex.argtypes = [vp, vp, vp, u64, vp, vp, vp]
+        L.orc_router_deliver_digest.argtypes = [vp, vp, vp, u64, vp, vp, C.c_int, vp, vp]; L.orc_router_deliver_digest.restype = None
+        L.orc_router_forwards_timed.argtypes = [vp, vp, vp, u64, vp, vp, C.c_int, C.POINTER(OrcStats), C.POINTER(u64)]
+        L.orc_router_forwards_timed.restype = C.c_double
         L.orc_router_match_digest_fast.argtypes = [vp, vp, vp, u64, C.c_int, vp, vp]; L.orc_router_match_digest_fast.restype = None
         L.orc_retain_match_digest_fast.argtypes = [vp, vp, vp, u64, C.c_int, vp, vp]; L.orc_retain_match_digest_fast.restype = None
         _LIB = L
@@ -332,6 +336,33 @@ class DefaultRouter:
         st = OrcStats()
         sec = lib().orc_router_matches_timed(self._h, _ptr(blob), offsets.ctypes.data, len(offsets) - 1, threads, int(refcounted), C.byref(st))
         return float(sec), st.as_dict()
+
+    def add_bulk_ex(self, blob, offsets, client, qos, flags):
+        """add_bulk with per-subscription RGR_SUB_* flag bits (v5 = 1, No Local = 2, Retain As Published = 8)."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        client = np.ascontiguousarray(client, dtype=np.uint32); qos = np.ascontiguousarray(qos, dtype=np.uint8)
+        flags = np.ascontiguousarray(flags, dtype=np.uint8)
+        return int(lib().orc_router_add_bulk_ex(self._h, _ptr(blob), offsets.ctypes.data, len(offsets) - 1, client.ctypes.data, qos.ctypes.data, flags.ctypes.data))
+
+    def deliver_digest(self, blob, offsets, pub_client, pub_qos_retain, threads=1):
+        """-> (status, uint64[n,4]): per publish the digest of the delivery verdicts of its hits (DefaultRouter::deliver_digest, oracle.hpp)."""
+        n = len(offsets) - 1
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        pc = np.ascontiguousarray(pub_client, dtype=np.uint32); pq = np.ascontiguousarray(pub_qos_retain, dtype=np.uint8)
+        status = np.zeros(n, dtype=np.int32)
+        out = np.zeros((n, 4), dtype=np.uint64)
+        lib().orc_router_deliver_digest(self._h, _ptr(blob), offsets.ctypes.data, n, pc.ctypes.data, pq.ctypes.data, threads, status.ctypes.data, out.ctypes.data)
+        return status, out
+
+    def forwards_timed(self, blob, offsets, pub_client, pub_qos_retain, threads=1):
+        """cpu_baseline of the delivery stage: _matches + collector + forwards_to's per-recipient transform.  -> (seconds, stats + rows)"""
+        n = len(offsets) - 1
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        pc = np.ascontiguousarray(pub_client, dtype=np.uint32); pq = np.ascontiguousarray(pub_qos_retain, dtype=np.uint8)
+        st = OrcStats(); rows = C.c_uint64(0)
+        sec = lib().orc_router_forwards_timed(self._h, _ptr(blob), offsets.ctypes.data, n, pc.ctypes.data, pq.ctypes.data, threads, C.byref(st), C.byref(rows))
+        d = st.as_dict(); d["rows"] = int(rows.value)
+        return float(sec), d
 
     def match_digest(self, blob, offsets, threads=1, fast=False):
         """-> (status int32[n], digest uint64[n,4]) — see orc_router_match_digest (oracle.cpp).  fast: the same digests composed

@@ -35,7 +35,7 @@ SYMBOLS = [
     "rgr_batch_set_format", "rgr_batch_set_topic_ids", "rgr_batch_begin", "rgr_batch_next_window",
     "rgr_window_to_host", "rgr_batch_run", "rgr_batch_run_to_host",
     "rgr_retain_topic_add", "rgr_retain_topic_remove", "rgr_retain_add_bulk", "rgr_retain_commit",
-    "rgr_retain_match_batch", "rgr_retain_result_free", "rgr_retain_batch_create", "rgr_retain_batch_create_tier",
+    "rgr_retain_match_batch", "rgr_retain_result_free", "rgr_retain_match_ranges", "rgr_retain_ranges_free", "rgr_retain_batch_create", "rgr_retain_batch_create_tier",
     "rgr_shard_assign", "rgr_stats_get", "rgr_stats_reset",
     "rgr_comm_unique_id", "rgr_comm_create", "rgr_comm_destroy", "rgr_comm_info", "rgr_comm_allgather_u64", "rgr_comm_gather_pass",
     "rgr_comm_replicate_subs", "rgr_comm_peer_subs", "rgr_comm_gather_runs_pass", "rgr_group_batch_gather_runs", "rgr_group_peer_subs",
@@ -77,6 +77,16 @@ class FiltersResult(C.Structure):
 class RetainResult(C.Structure):
     _fields_ = [("n_filters", C.c_uint32), ("n_hits", C.c_uint64), ("status", C.c_void_p),
                 ("hit_offsets", C.c_void_p), ("topic_ids", C.c_void_p), ("_owner", C.c_void_p)]
+
+
+class RetainRanges(C.Structure):      # == rgr_retain_ranges
+    _fields_ = [("n_filters", C.c_uint32), ("n_ranges", C.c_uint64), ("n_entries", C.c_uint64), ("status", C.c_void_p),
+                ("range_offsets", C.c_void_p), ("ranges", C.c_void_p), ("vals", C.c_void_p * 2), ("n_vals", C.c_uint64 * 2), ("_owner", C.c_void_p)]
+
+
+RANGE_DTYPE = np.dtype([("begin", np.uint32), ("len", np.uint32)])               # == rgr_id_range
+RETAIN_VAL_DTYPE = np.dtype([("topic_id", np.uint32), ("flags", np.uint32)])     # == rgr_retain_val
+RGR_RETAIN_HIT_DEAD = 1
 
 
 class Window(C.Structure):
@@ -158,6 +168,8 @@ def lib():
         L.rgr_retain_commit.argtypes = [vp]
         L.rgr_retain_match_batch.argtypes = [vp, vp, vp, u32, C.POINTER(RetainResult)]
         L.rgr_retain_result_free.argtypes = [C.POINTER(RetainResult)]; L.rgr_retain_result_free.restype = None
+        L.rgr_retain_match_ranges.argtypes = [vp, vp, vp, u32, C.POINTER(RetainRanges)]
+        L.rgr_retain_ranges_free.argtypes = [C.POINTER(RetainRanges)]; L.rgr_retain_ranges_free.restype = None
         L.rgr_retain_batch_create.argtypes = [vp, vp, vp, u32, C.POINTER(vp)]
         L.rgr_retain_batch_create_tier.argtypes = [vp, vp, vp, u32, u32, C.POINTER(vp)]
         L.rgr_shard_assign.argtypes = [vp, vp, u64, u32, i32, u32, vp]
@@ -413,6 +425,37 @@ class Router:
                         topic_ids=_copy(r.topic_ids, r.n_hits, np.uint32))
         finally:
             lib().rgr_retain_result_free(C.byref(r))
+
+    def retain_match_ranges(self, blob, offsets, flatten=True):
+        """rgr_retain_match_ranges: per filter the matched retained topics as ranges of the host-mirrored value array.
+        -> dict(status, range_offsets, ranges, n_entries[, hit_offsets, topic_ids: the ranges resolved through the mirror, dead entries
+        dropped — what rgr_retain_match_batch returns])."""
+        n = len(offsets) - 1
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        r = RetainRanges()
+        bp, bk = _blob_ptr(blob)
+        _check(lib().rgr_retain_match_ranges(self._h, bp, offsets.ctypes.data, n, C.byref(r)))
+        try:
+            out = dict(status=_copy(r.status, n, np.int32), range_offsets=_copy(r.range_offsets, n + 1, np.uint64),
+                       ranges=_copy(r.ranges, r.n_ranges, RANGE_DTYPE), n_entries=int(r.n_entries), n_ranges=int(r.n_ranges))
+            if flatten:
+                vals = [np.ctypeslib.as_array(C.cast(r.vals[t], C.POINTER(C.c_uint32)), shape=(int(r.n_vals[t]) * 2,)).reshape(-1, 2)
+                        if r.vals[t] else np.zeros((0, 2), dtype=np.uint32) for t in range(2)]
+                rg = out["ranges"]
+                ln = (rg["len"] & 0x7FFFFFFF).astype(np.int64)
+                tier = (rg["len"] >> 31).astype(np.int64)
+                ids, cnt = [], np.zeros(n, dtype=np.int64)
+                ro = out["range_offsets"].astype(np.int64)
+                for i in range(n):
+                    for k in range(ro[i], ro[i + 1]):
+                        v = vals[tier[k]][int(rg["begin"][k]):int(rg["begin"][k]) + int(ln[k])]
+                        live = v[(v[:, 1] & RGR_RETAIN_HIT_DEAD) == 0, 0]
+                        ids.append(live.copy()); cnt[i] += len(live)
+                out["topic_ids"] = np.concatenate(ids) if ids else np.zeros(0, dtype=np.uint32)
+                out["hit_offsets"] = np.concatenate([[0], np.cumsum(cnt)]).astype(np.uint64)
+            return out
+        finally:
+            lib().rgr_retain_ranges_free(C.byref(r))
 
     # ---- stats
     def stats(self):

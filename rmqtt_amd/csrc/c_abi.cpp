@@ -95,6 +95,9 @@ struct RetainEpoch {
     TrieView tv{};       // filt = run descriptors, subs = values: what count/compact/expand read
     uint64_t id = 0, n_topics = 0, n_nodes = 0, bytes = 0, table_version = 0;
     uint32_t max_id = 0;              // upper bound of the topic ids ever added
+    // host mirror of vals[] (rgr_retain_match_ranges hands out pointers into it): immutable once published; the two-tier commit
+    // replaces it copy-on-write when it marks entries dead.  Read / replaced under rgr_handle::epoch_mu.
+    std::shared_ptr<const std::vector<SubEntry>> h_vals;
 };
 
 enum SpanKind { kSpanWalk = 0, kSpanScan = 1, kSpanExpand = 2, kSpanDedup = 3 };

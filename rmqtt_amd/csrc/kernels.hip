@@ -813,13 +813,18 @@ constexpr int kCompactTilesPerBlock = RGR_COMPACT_TILES;
 constexpr int kCompactGroups = kTile / (kCompactThreads * 4);
 // four 24-bit ids = three words at a 4-byte-aligned address (three dword stores that the backend merges into one dwordx3, as in the
 // tuple kernel)
+// ONE dwordx3 store per group, explicitly: left as three dword stores the backend merged only the first group of a lane and split the
+// second into dword + dwordx2 — store instructions whose lanes do not cover contiguous bytes, the 5.5x-slower shape of DESIGN §10
+// (ids24 ran at 2.6 TB/s instead of the tuple kernel's 5.5: profiles/r04b_sweep_packed_ids24.jsonl).
+typedef uint32_t ids24_v3 __attribute__((ext_vector_type(3)));
+typedef ids24_v3 ids24_v3u __attribute__((aligned(4)));     // the 12-byte groups are only 4-byte aligned
 __device__ __forceinline__ void ids24_store(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint8_t* p) {
-    uint32_t* q = reinterpret_cast<uint32_t*>(p);
-    const uint32_t w0 = a | (b << 24), w1 = (b >> 8) | (c << 16), w2 = (c >> 16) | (d << 8);
+    ids24_v3 t;
+    t.x = a | (b << 24); t.y = (b >> 8) | (c << 16); t.z = (c >> 16) | (d << 8);
 #if RGR_COMPACT_NT
-    __builtin_nontemporal_store(w0, q); __builtin_nontemporal_store(w1, q + 1); __builtin_nontemporal_store(w2, q + 2);
+    __builtin_nontemporal_store(t, reinterpret_cast<ids24_v3u*>(p));
 #else
-    q[0] = w0; q[1] = w1; q[2] = w2;
+    *reinterpret_cast<ids24_v3u*>(p) = t;
 #endif
 }
 template <class T> __device__ __forceinline__ void compact_store(T v, T* p) {

@@ -5,6 +5,19 @@
 
 namespace rmqtt {
 
+namespace {
+// The dense answer of one filter (rgr_retain_match_ranges): every live topic id of its ranges, in hit order.  What came over PCIe
+// is 16 bytes per RANGE; the ids are read from the library's host mirror of the value arrays.
+template <class Fn> void for_each_hit(const rgr_retain_ranges& res, uint32_t filter, Fn&& fn) {
+    for (uint64_t k = res.range_offsets[filter]; k < res.range_offsets[filter + 1]; ++k) {
+        const rgr_id_range r = res.ranges[k];
+        const rgr_retain_val* v = res.vals[r.len >> 31] + r.begin;
+        for (uint32_t i = 0, n = r.len & 0x7FFFFFFFu; i < n; ++i)
+            if (!(v[i].flags & RGR_RETAIN_HIT_DEAD)) fn(v[i].topic_id);
+    }
+}
+}  // namespace
+
 GpuRetainStorage::GpuRetainStorage(int device, uint32_t retain_delta_max) {
     rgr_config cfg{};
     cfg.device = device;
@@ -56,16 +69,16 @@ Result<std::vector<std::pair<TopicName, Retain>>> GpuRetainStorage::get(const To
     std::lock_guard<std::mutex> g(mu_);
     if (dirty_) { if (rgr_retain_commit(h_) != RGR_OK) return R::Err(rgr_last_error()); dirty_ = false; }
     const uint64_t offs[2] = {0, f.size()};
-    rgr_retain_result res{};
-    if (rgr_retain_match_batch(h_, reinterpret_cast<const uint8_t*>(f.data()), offs, 1, &res) != RGR_OK) return R::Err(rgr_last_error());
+    rgr_retain_ranges res{};
+    if (rgr_retain_match_ranges(h_, reinterpret_cast<const uint8_t*>(f.data()), offs, 1, &res) != RGR_OK) return R::Err(rgr_last_error());
     std::vector<std::pair<TopicName, Retain>> out;
     const bool bad = res.status[0] != RGR_TOPIC_OK;
-    for (uint64_t k = 0; !bad && k < res.n_hits; ++k) {
-        const Entry& e = slab_[res.topic_ids[k]];
-        if (!e.live || (e.expire_at && now_ms >= e.expire_at)) continue;      // TimedValue::is_expired
+    if (!bad) for_each_hit(res, 0, [&](uint32_t id) {
+        const Entry& e = slab_[id];
+        if (!e.live || (e.expire_at && now_ms >= e.expire_at)) return;        // TimedValue::is_expired
         out.emplace_back(e.topic, e.retain);
-    }
-    rgr_retain_result_free(&res);
+    });
+    rgr_retain_ranges_free(&res);
     if (bad) return R::Err("invalid topic filter `" + f + "`");
     return R::Ok(std::move(out));
 }
@@ -148,12 +161,12 @@ Result<std::vector<MsgID>> GpuMessageIndex::get(const TopicFilter& f) {
     const bool multi = f == "#" || (f.size() >= 2 && f.compare(f.size() - 2, 2, "/#") == 0);
     const std::string q = multi ? f : f + "/+";
     const uint64_t offs[2] = {0, q.size()};
-    rgr_retain_result res{};
-    if (rgr_retain_match_batch(h_, reinterpret_cast<const uint8_t*>(q.data()), offs, 1, &res) != RGR_OK) return R::Err(rgr_last_error());
+    rgr_retain_ranges res{};
+    if (rgr_retain_match_ranges(h_, reinterpret_cast<const uint8_t*>(q.data()), offs, 1, &res) != RGR_OK) return R::Err(rgr_last_error());
     const bool bad = res.status[0] != RGR_TOPIC_OK;
     std::vector<MsgID> out;
-    for (uint64_t k = 0; !bad && k < res.n_hits; ++k) out.push_back(slab_[res.topic_ids[k]]);
-    rgr_retain_result_free(&res);
+    if (!bad) for_each_hit(res, 0, [&](uint32_t id) { out.push_back(slab_[id]); });
+    rgr_retain_ranges_free(&res);
     if (bad) return R::Err("invalid topic filter `" + f + "`");
     std::sort(out.begin(), out.end());
     return R::Ok(std::move(out));

@@ -287,7 +287,8 @@ class Batcher {
     std::atomic<size_t> pending_{0};
     std::mutex mu_;                            // drivers sleep here
     std::condition_variable cv_req_;
-    bool stop_ = false;
+    std::atomic<bool> stop_{false};
+    std::atomic<int> sleepers_{0};             // drivers inside a condition-variable wait (submitters only notify when there is one)
     std::atomic<uint64_t> passes_{0}, requests_{0};
     std::mutex task_mu_;
     std::condition_variable task_cv_;

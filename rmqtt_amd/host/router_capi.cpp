@@ -167,6 +167,9 @@ int hr_e2e_run_async(void* r, const uint8_t* blob, const uint64_t* offs, uint32_
     std::vector<std::unique_ptr<Ctx>> ctx;
     for (uint32_t k = 0; k < n_submitters; ++k) ctx.push_back(std::make_unique<Ctx>());
     const int64_t cap = std::max<int64_t>(1, outstanding / std::max(1u, n_submitters));
+    // a submitter at its cap sleeps until a quarter of its publishes have completed (one wake per cap / 4 completions, not one per
+    // completion: r4b's first cut woke the submitter — a futex + a context switch — for every single completion)
+    const int64_t low = cap - std::max<int64_t>(1, cap / 4);
     std::atomic<bool> stop{false};
     std::atomic<uint32_t> lat_n{0};
     uint64_t passes = 0;
@@ -182,13 +185,13 @@ int hr_e2e_run_async(void* r, const uint8_t* blob, const uint64_t* offs, uint32_
                 for (uint64_t i = k; !stop.load(std::memory_order_relaxed); i += n_submitters) {
                     if (c.inflight.load(std::memory_order_acquire) >= cap) {
                         std::unique_lock<std::mutex> lk(c.m);
-                        c.cv.wait_for(lk, std::chrono::microseconds(200), [&] { return c.inflight.load(std::memory_order_acquire) < cap || stop.load(); });
+                        c.cv.wait_for(lk, std::chrono::microseconds(500), [&] { return c.inflight.load(std::memory_order_acquire) <= low || stop.load(); });
                         continue;
                     }
                     const uint32_t t = uint32_t(i % n);
                     c.inflight.fetch_add(1, std::memory_order_acq_rel);
                     const auto a = std::chrono::steady_clock::now();
-                    b.submit(id, std::string(reinterpret_cast<const char*>(blob) + offs[t], offs[t + 1] - offs[t]), [&c, a, k, lat_us, n_lat, &lat_n, cap](Result<SubRelationsMap>&& res) {
+                    b.submit(id, std::string(reinterpret_cast<const char*>(blob) + offs[t], offs[t + 1] - offs[t]), [&c, a, k, lat_us, n_lat, &lat_n, low](Result<SubRelationsMap>&& res) {
                         uint64_t rows = 0;
                         if (res.ok()) for (auto& kv : *res.value) rows += kv.second.size();
                         else if (res.error.rfind("invalid topic", 0) != 0) c.errs.fetch_add(1, std::memory_order_relaxed);
@@ -198,7 +201,7 @@ int hr_e2e_run_async(void* r, const uint8_t* blob, const uint64_t* offs, uint32_
                             const uint32_t j = lat_n.fetch_add(1, std::memory_order_relaxed);
                             if (j < n_lat) lat_us[j] = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - a).count();
                         }
-                        if (c.inflight.fetch_sub(1, std::memory_order_acq_rel) == cap) { { std::lock_guard<std::mutex> g(c.m); } c.cv.notify_one(); }
+                        if (c.inflight.fetch_sub(1, std::memory_order_acq_rel) == low + 1) { { std::lock_guard<std::mutex> g(c.m); } c.cv.notify_one(); }
                     });
                 }
             });

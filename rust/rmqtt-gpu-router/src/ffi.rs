@@ -178,6 +178,36 @@ extern "C" {
     pub fn rgr_comm_destroy(c: *mut rgr_comm);
     pub fn rgr_comm_allgather_u64(c: *mut rgr_comm, mine: u64, all: *mut u64) -> i32;
     pub fn rgr_comm_info(c: *mut rgr_comm, out: *mut rgr_comm_info_t) -> i32;
+    pub fn rgr_retain_match_ranges(h: *mut rgr_handle, blob: *const u8, offsets: *const u64, n: u32, out: *mut rgr_retain_ranges) -> i32;
+    pub fn rgr_retain_ranges_free(r: *mut rgr_retain_ranges);
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct rgr_id_range {
+    pub begin: u32,
+    pub len: u32, // bit 31: the delta tier's value array
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct rgr_retain_val {
+    pub topic_id: u32,
+    pub flags: u32, // RGR_RETAIN_HIT_DEAD: removed / replaced since the base tier was compiled
+}
+pub const RGR_RETAIN_HIT_DEAD: u32 = 1;
+
+#[repr(C)]
+pub struct rgr_retain_ranges {
+    pub n_filters: u32,
+    pub n_ranges: u64,
+    pub n_entries: u64,
+    pub status: *mut i32,
+    pub range_offsets: *mut u64,
+    pub ranges: *mut rgr_id_range,
+    pub vals: [*const rgr_retain_val; 2],
+    pub n_vals: [u64; 2],
+    pub _owner: *mut c_void,
 }
 
 #[repr(C)]

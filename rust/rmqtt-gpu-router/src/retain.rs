@@ -3,7 +3,7 @@
 //!
 //! The messages stay on the host in a slab keyed by a dense `topic_id`; the device holds only the trie of
 //! retained topic NAMES (`rgr_retain_topic_add` / `_remove`) and answers a SUBSCRIBE filter with the ids of
-//! the matching topics (`rgr_retain_match_batch`).  This is the in-memory storage (`DefaultRetainStorage`,
+//! the matching topics (`rgr_retain_match_ranges`: ranges of the host-mirrored preorder value array).  This is the in-memory storage (`DefaultRetainStorage`,
 //! retain.rs:200-330); the retainer plugin's KV variants do the same around their store — match first, then one
 //! KV get per matched topic (rmqtt-plugins/rmqtt-retainer/src/storage.rs:576-641) — and can call
 //! `GpuRetainIndex::query` in place of their `RetainTree` lookup (storage.rs:604-611).
@@ -86,19 +86,35 @@ impl GpuRetainIndex {
             blob.extend_from_slice(f.as_bytes());
             offs.push(blob.len() as u64);
         }
-        let mut res: rgr_retain_result = unsafe { std::mem::zeroed() };
-        if unsafe { rgr_retain_match_batch(self.h.0, blob.as_ptr(), offs.as_ptr(), filters.len() as u32, &mut res) } != RGR_OK {
-            return Err(anyhow::anyhow!("rgr_retain_match_batch: {}", last_error()));
+        // the dense answer: per filter a short list of RANGES of the preorder value array, which the library mirrors on the host —
+        // `a/#` is one range.  16 bytes per range cross PCIe instead of 12 per hit (r4: rgr_retain_match_batch shipped tuples).
+        let mut res: rgr_retain_ranges = unsafe { std::mem::zeroed() };
+        if unsafe { rgr_retain_match_ranges(self.h.0, blob.as_ptr(), offs.as_ptr(), filters.len() as u32, &mut res) } != RGR_OK {
+            return Err(anyhow::anyhow!("rgr_retain_match_ranges: {}", last_error()));
         }
         let out = unsafe {
             let status = std::slice::from_raw_parts(res.status, filters.len());
-            let ho = std::slice::from_raw_parts(res.hit_offsets, filters.len() + 1);
-            let ids = if res.n_hits == 0 { &[][..] } else { std::slice::from_raw_parts(res.topic_ids, res.n_hits as usize) };
+            let ro = std::slice::from_raw_parts(res.range_offsets, filters.len() + 1);
+            let ranges = if res.n_ranges == 0 { &[][..] } else { std::slice::from_raw_parts(res.ranges, res.n_ranges as usize) };
+            let vals: [&[rgr_retain_val]; 2] = [0, 1].map(|t| {
+                if res.vals[t].is_null() { &[][..] } else { std::slice::from_raw_parts(res.vals[t], res.n_vals[t] as usize) }
+            });
             (0..filters.len())
-                .map(|i| if status[i] != RGR_TOPIC_OK { Err(format!("invalid topic filter `{}`", filters[i])) } else { Ok(ids[ho[i] as usize..ho[i + 1] as usize].to_vec()) })
+                .map(|i| {
+                    if status[i] != RGR_TOPIC_OK {
+                        return Err(format!("invalid topic filter `{}`", filters[i]));
+                    }
+                    let mut ids = Vec::new();
+                    for r in &ranges[ro[i] as usize..ro[i + 1] as usize] {
+                        let (tier, len) = ((r.len >> 31) as usize, (r.len & 0x7fff_ffff) as usize);
+                        // entries removed / replaced since the base tier was compiled carry RGR_RETAIN_HIT_DEAD: skipped
+                        ids.extend(vals[tier][r.begin as usize..r.begin as usize + len].iter().filter(|v| v.flags & RGR_RETAIN_HIT_DEAD == 0).map(|v| v.topic_id));
+                    }
+                    Ok(ids)
+                })
                 .collect()
         };
-        unsafe { rgr_retain_result_free(&mut res) };
+        unsafe { rgr_retain_ranges_free(&mut res) };
         Ok(out)
     }
 }

@@ -14,6 +14,7 @@ import pytest
 
 from oracle import oracle as orc
 from rmqtt_amd import capi
+from rmqtt_amd import workload as wl
 from tests.parity import make_backend, pack
 
 BACKENDS = ["emu", pytest.param("hip", marks=pytest.mark.gpu)]
@@ -333,3 +334,48 @@ def test_delivery_stage_property(subs, pubs, window, slot_cap):
             assert got["status"][i] < 0 and lo == hi
         else:
             assert w.fold(got["tuples"][lo:hi], i) == exp, (topic, ids[i])
+
+
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_oracle_delivery_digest_equals_the_delivery_words(kind):
+    """bench.py checks the delivery stage at full size through DefaultRouter::deliver_digest (oracle.hpp): per publish a digest of the
+    per-hit verdicts, where WHICH hits are delivered comes from the oracle's matches() (the restated _matches + collector).  Here the
+    same digest is computed from a backend's delivery words (emu on the CPU, the kernels under -m gpu) on a table with v5 / No Local /
+    Retain-As-Published subscriptions — so the digest definition is pinned on the words that the text-level test above pins on forwards()."""
+    rng = np.random.default_rng(77)
+    c = wl.CONFIGS[3]
+    n_sub = 12_000
+    blob, offs, client, qos = wl.gen_subs(n_sub, wl.SUB_SEED + 3, c["p_plus"], c["p_hash"], c["p_sys"])
+    is5 = rng.random(n_sub) < 0.35
+    flags = (is5 * capi.RGR_SUB_V5 | (is5 & (rng.random(n_sub) < 0.4)) * capi.RGR_SUB_NO_LOCAL | (is5 & (rng.random(n_sub) < 0.5)) * capi.RGR_SUB_RAP).astype(np.uint8)
+    o = orc.DefaultRouter()
+    assert o.add_bulk_ex(blob, offs, client, qos, flags) == 0
+    b = make_backend(kind)
+    raw = bytes(blob)
+    for i in range(n_sub):                                                        # owner id == client index: Id{node 1, "c<j>"}
+        fid = b.filter_add(raw[int(offs[i]):int(offs[i + 1])].decode())
+        b.sub_add_ex(fid, i, int(qos[i]), int(flags[i]), 0, int(client[i]), int(client[i]))
+    b.commit()
+    tb, to = wl.gen_topics(1_200, wl.PUB_SEED + 3, 0.01, c["p_blank"])
+    n = len(to) - 1
+    attrs = np.zeros(n, dtype=capi.PUBLISH_ATTR_DTYPE)
+    attrs["from_id"] = rng.choice(client.astype(np.uint32), size=n)
+    attrs["from_id"][::17] = capi.ID_NONE                                         # publishers the table does not know
+    attrs["qos_retain"] = rng.integers(0, 3, size=n) | (rng.integers(0, 2, size=n) << 2)
+    got = b.match_batch_deliver(tb, to, attrs)
+    st, exp = o.deliver_digest(tb, to, attrs["from_id"], attrs["qos_retain"].astype(np.uint8), threads=3)
+    assert np.array_equal(st < 0, got["status"] < 0)
+    ho = got["hit_offsets"].astype(np.int64)
+    M = (1 << 64) - 1
+    n_dup = n_drop = 0
+    for i in range(n):
+        t = got["tuples"][ho[i]:ho[i + 1]]
+        x = [int(s) * 32 + (int(w) & 31) for s, w in zip(t["sub_id"], t["qos_flags"])]
+        d = (len(x), sum(x) & M, sum((k + 1) * v for k, v in enumerate(x)) & M, sum(v * v for v in x) & M)
+        assert tuple(int(z) for z in exp[i]) == d, i
+        n_dup += sum(1 for w in t["qos_flags"] if int(w) & capi.RGR_HIT_V5_DUP)
+        n_drop += sum(1 for w in t["qos_flags"] if int(w) & capi.RGR_HIT_NO_LOCAL)
+    assert n_dup > 50 and n_drop > 5 and int(exp[:, 0].sum()) > 20_000
+    # the reference-shaped timed pass (cpu_baseline of the delivery record) delivers exactly the hits that are neither dropped nor duplicates
+    sec, stt = o.forwards_timed(tb, to, attrs["from_id"], attrs["qos_retain"].astype(np.uint8), threads=2)
+    assert stt["hits"] == int(exp[:, 0].sum()) and stt["rows"] == int(exp[:, 0].sum()) - n_dup - n_drop and sec > 0

@@ -249,3 +249,36 @@ def test_repeated_commits_on_one_table(kind):
         b.retain_commit()
         check(b, t, filters)
     assert len(live) > 20
+
+
+@pytest.mark.gpu
+def test_dense_range_answer_equals_the_hit_list():
+    """rgr_retain_match_ranges (SURVEY 8(a) `get_message` consumers need topic ids only): per filter a short list of ranges of the
+    preorder value array, mirrored on the host — `a/#` is one range.  Resolved through the mirror it must be rgr_retain_match_batch's
+    answer (same ids, same order) and the oracle's RetainTree::matches as a set; and it must be SHORT: far fewer ranges than hits."""
+    from rmqtt_amd import capi
+    c = wl.CONFIGS[5]
+    blob, offs = wl.gen_topics(60_000, wl.PUB_SEED + 5, 0.01, c["p_blank"], c["fixed_depth"], distinct=True)
+    fb, fo, _, _ = wl.gen_subs(1_500, wl.SUB_SEED + 5, c["p_plus"], c["p_hash"], c["p_sys"], 0, c["fixed_depth"], force_wildcard=True)
+    r = capi.Router(device=0, window_hits=20_000)                   # several windows per pass
+    t = orc.RetainTree()
+    assert r.retain_add_bulk(blob, offs) == t.insert_bulk(blob, offs)
+    r.retain_commit()
+    extra = pack(["#", "+/#", "$SYS/#", "l0x0/#", "+/+/+", "bad/#/x", "nope/#", "/#"])
+    for b_, o_ in ((fb, fo), extra):
+        ref = r.retain_match_batch(b_, o_)
+        rg = r.retain_match_ranges(b_, o_)
+        assert np.array_equal(rg["status"], ref["status"]) and np.array_equal(rg["hit_offsets"], ref["hit_offsets"])
+        assert np.array_equal(rg["topic_ids"], ref["topic_ids"])
+        st, eo, ev, _ = t.match_batch(b_, o_)
+        assert np.array_equal(st < 0, rg["status"] < 0) and np.array_equal(eo, rg["hit_offsets"])
+        for a, b in zip(eo[:-1], eo[1:]):
+            assert sorted(rg["topic_ids"][int(a):int(b)].tolist()) == sorted(ev[int(a):int(b)].tolist())
+        assert rg["n_entries"] == len(ref["topic_ids"])
+    assert rg["n_ranges"] * 20 < rg["n_entries"]                     # '#' near the root: tens of thousands of hits in a handful of ranges
+    # results stay valid across a later commit (they hold the mirror they index), and a new commit is seen by the next call
+    assert r.retain_add("brand/new/topic", 999_999) == 0
+    r.retain_commit()
+    rg2 = r.retain_match_ranges(*pack(["brand/#", "#"]))
+    assert rg2["topic_ids"][:1].tolist() == [999_999] and int(rg2["hit_offsets"][2] - rg2["hit_offsets"][1]) == int(eo[1] - eo[0]) + 1
+    r.close()

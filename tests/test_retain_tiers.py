@@ -168,6 +168,10 @@ def test_tiers_random_churn_hip(delta_max):
         assert np.array_equal(got["hit_offsets"], eo)
         for a, b in zip(eo[:-1], eo[1:]):
             assert sorted(got["topic_ids"][int(a):int(b)].tolist()) == sorted(ev[int(a):int(b)].tolist())
+        # the dense answer (ranges of the host-mirrored value arrays of both tiers, dead entries flagged) resolves to the same hits
+        rg = r.retain_match_ranges(blob, offs)
+        assert np.array_equal(rg["status"] < 0, st_ < 0) and np.array_equal(rg["hit_offsets"], eo)
+        assert np.array_equal(rg["topic_ids"], got["topic_ids"])             # same order as rgr_retain_match_batch, too
         st = r.stats()
         assert st["retain_topics"] == len(live)
     st = r.stats()
