@@ -1216,7 +1216,7 @@ def measure_router_e2e(args):
         if args.e2e_sweep:
             shapes += [(4, 8192, 32, 2), (8, 32768, 64, 3), (16, 65536, 96, 4), (8, 16384, 32, 1)]
         for subm, outst, workers, passes in shapes:
-            res = (C.c_uint64 * 4)()
+            res = (C.c_uint64 * 10)()
             wall = C.c_double(0)
             lat = np.zeros(400_000, dtype=np.float32)
             nl = C.c_uint32(0)
@@ -1227,6 +1227,9 @@ def measure_router_e2e(args):
             rec["gpu_async"].append({"submitters": subm, "outstanding": outst, "workers": workers, "passes_in_flight": passes,
                                      "value": round(res[0] / wall.value, 1), "rows_per_s": round(res[1] / wall.value, 1), "device_passes": int(res[2]),
                                      "publishes_per_pass": round(res[0] / max(1, res[2]), 1), "errors": int(res[3]), "wall_s": round(wall.value, 2),
+                                     "batcher_ms_per_pass": {"collect": round(res[4] / max(1, res[2]) / 1e6, 3), "device_pass": round(res[5] / max(1, res[2]) / 1e6, 3),
+                                                             "dispatch": round(res[6] / max(1, res[2]) / 1e6, 3)},
+                                     "worker_task_us": round(res[7] / max(1, res[8]) / 1e3, 1), "worker_tasks": int(res[8]), "max_task_queue": int(res[9]),
                                      "latency_us": {"p50": round(float(l[len(l) // 2]), 1), "p99": round(float(l[int(len(l) * 0.99)]), 1)} if len(l) else None})
             log(f"router e2e config {cfg} async: {rec['gpu_async'][-1]}")
         L.hr_free(g)

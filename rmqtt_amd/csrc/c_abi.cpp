@@ -106,6 +106,7 @@ enum SpanKind { kSpanWalk = 0, kSpanScan = 1, kSpanExpand = 2, kSpanDedup = 3 };
 
 struct rgr_handle {
     rgr_config cfg{};
+    bool cfg_window_explicit = false;   // the caller chose window_hits (then every pass uses it as given)
     std::shared_mutex table_mu;     // HostTable: shared for tokenising, exclusive for mutation
     HostTable table;
     std::mutex epoch_mu;
@@ -187,6 +188,15 @@ struct rgr_batch {
     PinnedBuf h_ring[2];                 // pinned staging for streamed windows
     bool alt_out = false;                // next_window expands into out2 instead of out
     bool want_host_offsets = false;      // host-out entry points: fetch the per-topic offsets with the chunk's totals
+    bool host_out = false;               // the pass streams its windows to the host (pinned staging is sized per window)
+    // Hits per window of THIS pass.  The handle's default (2^30, r4) is for device-resident passes, where a window is only a unit of
+    // launches: at config 3 the pass needs 139 windows instead of 553 and saves ~8 ms of tiles_kernel launches and gaps
+    // (profiles/r04a_packed_vs_window_size.jsonl).  Passes that stage windows in pinned host memory, and the delivery stage (whose
+    // candidate lists are sized per window), keep 2^28 unless the caller configured something smaller.
+    uint64_t window_cap() const {
+        const uint64_t c = h->cfg.window_hits;
+        return (host_out || deliver) ? std::min<uint64_t>(c, h->cfg_window_explicit ? c : (1ull << 28)) : c;
+    }
     // streamed passes (rgr_batch_run_to_host, rgr_match_batch): copy stream + per-slot events, created once
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_expanded[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
@@ -598,7 +608,7 @@ void prepare_chunk(rgr_batch* b, uint32_t begin, bool walk_only) {
         const uint64_t H = tot[0], P = tot[1];
         b->c->total_hits = H; b->c->total_pairs = P;
         b->c->host_arrays = false;
-        if (H > h->cfg.window_hits || b->want_host_offsets) fetch_host_arrays(b);
+        if (H > b->window_cap() || b->want_host_offsets) fetch_host_arrays(b);
         b->c->pair_src.ensure(std::max<uint64_t>(1, P) * 4);
         b->c->pair_topic.ensure(std::max<uint64_t>(1, P) * 4);
         b->c->pair_off.ensure((P + 1) * 8);
@@ -713,7 +723,8 @@ int32_t rgr_create(const rgr_config* cfg, rgr_handle** out) {
         if (cfg) h->cfg = *cfg;
         if (h->cfg.device < 0 || h->cfg.device >= ndev) return fail(RGR_EDEVICE, "rgr_create: bad device ordinal");
         if (!h->cfg.slot_cap) h->cfg.slot_cap = 64;
-        if (!h->cfg.window_hits) h->cfg.window_hits = 1ull << 28;
+        h->cfg_window_explicit = h->cfg.window_hits != 0;
+        if (!h->cfg.window_hits) h->cfg.window_hits = 1ull << 30;
         if (!h->cfg.chunk_topics) h->cfg.chunk_topics = 1u << 21;
         RGR_HIP(hipSetDevice(h->cfg.device));
         // epoch 0: the empty table
@@ -1275,7 +1286,7 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
         if (!b->c->ready || b->cursor >= b->c->begin + b->c->n) enter_chunk(b, b->cursor);
         const uint32_t n = b->c->n;
         const uint32_t lc = b->cursor - b->c->begin;
-        const uint64_t cap = h->cfg.window_hits;
+        const uint64_t cap = b->window_cap();
         uint32_t le;
         uint64_t hit_lo, hit_hi, pair_lo, pair_hi;
         if (!b->c->host_arrays) {            // the whole chunk is one window (its totals fit): no per-topic arrays needed
@@ -1324,11 +1335,12 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
                     const uint32_t nt = le - lc;
                     const uint64_t ntl = (nh + T - 1) / T;
                     b->cand.ensure(ntl * T * sizeof(Cand));
-                    b->cand_count.ensure(ntl * 4);                       // per-tile counts (every tile writes its own)
+                    b->cand_count.ensure(ntl * 4 * 3);                   // per-tile counts (every tile writes its own), then the tiles' topic ranges
                     b->dedup_items.ensure((size_t(nt) + nh / dedup_topic_cap() + 2) * sizeof(DedupItem));
                     if (!b->dedup_scalars.p) { b->dedup_scalars.ensure(16); RGR_HIP(hipMemsetAsync(b->dedup_scalars.p, 0, 16, b->stream)); }
                     da.cand = b->cand.as<Cand>();
                     da.tile_ncand = b->cand_count.as<uint32_t>();
+                    da.tile_trange = b->cand_count.as<uint32_t>() + ntl;
                     da.topic_lo = b->c->begin + lc;
                 }
             }
@@ -1346,7 +1358,7 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
             if (dedup) {
                 // LDS tables (tile-local, then one block per spanning topic); stream-ordered, no host synchronisation
                 sp = b->span_begin(kSpanDedup);
-                launch_dedup(b->cand.as<Cand>(), b->cand_count.as<uint32_t>(), uint32_t((nh + T - 1) / T), outbuf.as<Tuple>(),
+                launch_dedup(b->cand.as<Cand>(), b->cand_count.as<uint32_t>(), b->cand_count.as<uint32_t>() + (nh + T - 1) / T, uint32_t((nh + T - 1) / T), outbuf.as<Tuple>(),
                              le - lc, b->c->hit_off.as<uint64_t>() + lc, hit_lo, b->dedup_items.as<DedupItem>(),
                              reinterpret_cast<uint32_t*>(b->dedup_scalars.as<unsigned long long>() + 1), b->dedup_scalars.as<unsigned long long>(), b->stream);
                 b->span_end(sp);
@@ -1458,6 +1470,7 @@ extern "C++" {
 template <class Dst, class Done>
 static int32_t stream_windows(rgr_batch* b, Dst dst, Done done, uint64_t* n_hits, uint32_t* n_windows) {
     b->ensure_stream_state();
+    struct HostOut { rgr_batch* b; ~HostOut() { b->host_out = false; } } host_out_guard{b};
     struct Pending { bool live = false; rgr_window w{}; rgr_tuple* host = nullptr; } pend[2];
     uint64_t hits = 0;
     uint32_t nw = 0;
@@ -1496,7 +1509,9 @@ static int32_t stream_windows(rgr_batch* b, Dst dst, Done done, uint64_t* n_hits
 
 int32_t rgr_batch_run_to_host(rgr_batch* b, rgr_window_consumer consume, void* user, uint64_t* n_hits, uint32_t* n_windows) {
     if (b && b->format != kFmtTuple) return fail(RGR_ESTATE, "rgr_batch_run_to_host: RGR_FORMAT_TUPLE only");
+    if (b) b->host_out = true;           // (before the pass is planned: its windows are sized for pinned staging; stream_windows clears it)
     int32_t rc = rgr_batch_begin(b);
+    if (rc != RGR_OK && b) b->host_out = false;
     if (rc != RGR_OK) return rc;
     return guarded([&]() -> int32_t {
         return stream_windows(
@@ -1559,8 +1574,9 @@ static int32_t match_batch_impl(rgr_handle* h, const uint8_t* blob, const uint64
         b->group_by_node = groups != nullptr && attrs != nullptr;
         struct ClearGrouping { rgr_batch* b; ~ClearGrouping() { b->group_by_node = false; } } clear_grouping{b};
         if (b->group_by_node) own->grp_off.assign(size_t(n) + 1, 0);
+        b->host_out = true;
         r = rgr_batch_begin(b);
-        if (r != RGR_OK) return r;
+        if (r != RGR_OK) { b->host_out = false; return r; }
         // Windows are expanded and copied in a two-deep pipeline straight into the result block.  The block is
         // sized when a chunk's totals are known (one chunk = up to rgr_config.chunk_topics topics: the whole
         // batch for any realistic call); only a batch of several chunks can make it grow, and it grows with no

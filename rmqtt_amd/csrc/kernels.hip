@@ -772,6 +772,8 @@ __global__ __launch_bounds__(kThreads) void expand_kernel(const SubEntry* __rest
                           (b == pair_hi || c.pair_topic[b] != t_first)) ? 1u : 0u;
             }
             da.tile_ncand[tile] = s_ncand | (flag << 31);
+            // (with rgr_batch_set_topic_ids the pairs carry the CALLER's ids, not batch indices: then the whole window is the bound)
+            if (flag) { da.tile_trange[2 * tile] = c.topic_ids ? 0u : s_topic[0] - da.topic_lo; da.tile_trange[2 * tile + 1] = c.topic_ids ? kNone : s_topic[np - 1] - da.topic_lo; }
         }
         // the tile's candidates go to the tile's own slice of the list: no global cursor
         Cand* mine = da.cand + uint64_t(tile) * kTile;
@@ -782,7 +784,7 @@ __global__ __launch_bounds__(kThreads) void expand_kernel(const SubEntry* __rest
 #else
             if (cslot[j] != kNone && cclient[j] == 0x12345u)
 #endif
-                mine[cslot[j]] = Cand{uint32_t(base - hit_lo) + uint32_t(j) * kThreads + threadIdx.x, cclient[j], topic[j] - da.topic_lo, se[j].qos_flags};
+                mine[cslot[j]] = Cand{uint32_t(base - hit_lo) + uint32_t(j) * kThreads + threadIdx.x, cclient[j]};
     }
 }
 
@@ -985,12 +987,14 @@ constexpr int kDedupTopicCap = kDedupTopicSlots / 2;  // candidates per part
 #endif
 constexpr int kDedupTopicThreads = RGR_DEDUP_TOPIC_THREADS;
 
-__global__ __launch_bounds__(256) void dedup_tile_kernel(const Cand* __restrict__ cand, const uint32_t* __restrict__ tile_ncand, uint32_t ntiles,
-                                                         const uint64_t* __restrict__ hit_off, uint64_t hit_lo, Tuple* __restrict__ tuples,
+__global__ __launch_bounds__(256) void dedup_tile_kernel(const Cand* __restrict__ cand, const uint32_t* __restrict__ tile_ncand,
+                                                         const uint32_t* __restrict__ tile_trange, uint32_t ntiles,
+                                                         const uint64_t* __restrict__ hit_off, uint64_t hit_lo, uint32_t nt, Tuple* __restrict__ tuples,
                                                          unsigned long long* __restrict__ stat) {
     __shared__ uint32_t s_topic[kTile], s_client[kTile], s_pos[kTile];
     __shared__ uint32_t s_tab[kDedupTileSlots];
     unsigned long long seen = 0;                                  // candidates of the tiles this block visited (rgr_stats)
+    auto h_off = [&](uint32_t t) { return uint32_t(hit_off[t] - hit_lo); };      // (windows of the delivery stage hold < 2^32 hits)
     // a fixed grid strides over the tiles: all but a few are skipped after one 4-byte read (bit 31 of tile_ncand, set by the
     // expansion, says whether a whole topic with two or more candidates lies inside the tile)
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -1002,11 +1006,16 @@ __global__ __launch_bounds__(256) void dedup_tile_kernel(const Cand* __restrict_
         const uint64_t lo = uint64_t(tile) * kTile, hi = lo + kTile;
         __syncthreads();                                          // the previous tile's lookups are done
         for (uint32_t i = threadIdx.x; i < uint32_t(kDedupTileSlots); i += 256) s_tab[i] = kNone;
+        // the expansion left the window topics of the tile's first and last pair: they bound every candidate's search for its topic
+        // (a handful of steps; r4d's first cut searched all topics of the window from every flagged tile: 146 us per window instead of 72)
+        const uint32_t t_lo = tile_trange[2 * tile], t_hi = min(tile_trange[2 * tile + 1], nt - 1);
+        __syncthreads();
         for (uint32_t i = threadIdx.x; i < n; i += 256) {
             const Cand c = list[i];
-            const uint64_t h0 = hit_off[c.topic] - hit_lo, h1 = hit_off[c.topic + 1] - hit_lo;
+            const uint32_t t = topic_of_pos(c.pos, t_lo, t_hi, h_off);
+            const uint64_t h0 = hit_off[t] - hit_lo, h1 = hit_off[t + 1] - hit_lo;
             const bool in = h0 >= lo && h1 <= hi;                  // the topic lies entirely inside this tile
-            s_topic[i] = in ? c.topic : kNone; s_client[i] = c.client_idx; s_pos[i] = c.pos;
+            s_topic[i] = in ? t : kNone; s_client[i] = c.client_idx; s_pos[i] = c.pos;
         }
         __syncthreads();
         auto key_topic = [&](uint32_t k) { return s_topic[k]; };
@@ -1019,7 +1028,7 @@ __global__ __launch_bounds__(256) void dedup_tile_kernel(const Cand* __restrict_
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < n; i += 256)
             if (s_topic[i] != kNone && dedup_tile_is_dup(i, uint32_t(kDedupTileSlots - 1), key_topic, key_client, tab_load))
-                tuples[s_pos[i]].qos_flags = list[i].word | kHitV5Dup;          // the candidate carries its delivery word: a store, not a read-modify-write
+                tuples[s_pos[i]].qos_flags |= kHitV5Dup;          // (this lane is the only writer of that word)
     }
     if (threadIdx.x == 0 && seen) atomicAdd(stat, seen);
 }
@@ -1069,30 +1078,27 @@ __global__ __launch_bounds__(kDedupTopicThreads) void dedup_topic_kernel(const C
                 for (uint32_t i = threadIdx.x; i <= mask; i += kDedupTopicThreads) s_tab[i] = kDedupEmpty;
                 if (threadIdx.x == 0) s_over = 0;
                 __syncthreads();
-                // every wave takes whole tiles: a tile's list is read by 64 lanes with a stride of 64
+                // every wave takes whole tiles: a tile's list is read by 64 lanes with a stride of 64.  ONE pass (r4): an insertion
+                // returns the position that just lost to a smaller one of the same client (dedup_topic_insert_once), and that position
+                // is flagged on the spot — duplicates are a fraction of a percent of the hits, so the flag is an atomic OR on the
+                // tuple word instead of a second pass over every candidate list (r3: 0.41 ms per window, bound by those reads).
                 for (uint32_t tile = tile0 + wave; tile <= tile1; tile += kWaves) {
                     const uint32_t n = tile_ncand[tile] & 0x7FFFFFFFu;
                     const Cand* list = cand + uint64_t(tile) * kTile;
                     for (uint32_t i = lane; i < n; i += 64) {
                         const Cand c = list[i];
-                        if (c.topic != item.topic || (nparts > 1 && dedup_part(c.client_idx, nparts) != mine)) continue;
-                        if (!dedup_topic_insert(c.client_idx, c.pos, mask, [&](uint32_t sl, unsigned long long v) { return atomicCAS(&s_tab[sl], kDedupEmpty, v); },
-                                                [&](uint32_t sl, unsigned long long v) { atomicMin(&s_tab[sl], v); }))
-                            s_over = 1;
+                        if (c.pos < h0 || c.pos >= h1 || (nparts > 1 && dedup_part(c.client_idx, nparts) != mine)) continue;      // (first / last tile: a neighbour's hit)
+                        bool full = false;
+                        const uint32_t loser = dedup_topic_insert_once(c.client_idx, c.pos, mask,
+                                                                       [&](uint32_t sl, unsigned long long v) { return atomicCAS(&s_tab[sl], kDedupEmpty, v); },
+                                                                       [&](uint32_t sl, unsigned long long v) { return atomicMin(&s_tab[sl], v); }, full);
+                        if (full) s_over = 1;
+                        else if (loser != kNone) atomicOr(&tuples[loser].qos_flags, kHitV5Dup);
                     }
                 }
                 __syncthreads();
                 over = s_over != 0;
                 if (over) break;
-                for (uint32_t tile = tile0 + wave; tile <= tile1; tile += kWaves) {
-                    const uint32_t n = tile_ncand[tile] & 0x7FFFFFFFu;
-                    const Cand* list = cand + uint64_t(tile) * kTile;
-                    for (uint32_t i = lane; i < n; i += 64) {
-                        const Cand c = list[i];
-                        if (c.topic != item.topic || (nparts > 1 && dedup_part(c.client_idx, nparts) != mine)) continue;
-                        if (dedup_topic_is_dup(c.client_idx, c.pos, mask, [&](uint32_t sl) { return s_tab[sl]; })) tuples[c.pos].qos_flags = c.word | kHitV5Dup;
-                    }
-                }
             }
             if (!over) break;
         }
@@ -1346,12 +1352,12 @@ void launch_node_groups(const Tuple* tuples, const uint64_t* hit_off, uint64_t h
 
 uint32_t dedup_topic_cap() { return kDedupTopicCap; }
 
-void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, uint32_t ntiles, Tuple* tuples, uint32_t nt,
+void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, const uint32_t* tile_trange, uint32_t ntiles, Tuple* tuples, uint32_t nt,
                   const uint64_t* hit_off, uint64_t hit_lo, DedupItem* items, uint32_t* item_count, unsigned long long* stat, void* stream) {
     if (!ntiles) return;
     hipStream_t s = static_cast<hipStream_t>(stream);
     (void)hipMemsetAsync(item_count, 0, 4, s);
-    dedup_tile_kernel<<<std::min<uint32_t>(ntiles, 2048u), 256, 0, s>>>(cand, tile_ncand, ntiles, hit_off, hit_lo, tuples, stat);
+    dedup_tile_kernel<<<std::min<uint32_t>(ntiles, 2048u), 256, 0, s>>>(cand, tile_ncand, tile_trange, ntiles, hit_off, hit_lo, nt, tuples, stat);
     dedup_classify_kernel<<<(nt + 255) / 256, 256, 0, s>>>(tile_ncand, nt, hit_off, hit_lo, items, item_count);
     // the item count stays on the device: a fixed grid of persistent blocks (4 per CU fit) strides over the items
     // RGR_DEDUP_TEST_SLOTS (tests only): a smaller table, so that parts overflow and the re-split path runs on ordinary inputs

@@ -54,8 +54,10 @@ struct Tuple { uint32_t topic_idx, sub_id, qos_flags; };   // == rgr_tuple
 // per-publish attributes parallel to the batch's topics.
 struct SubAttr { uint32_t owner_id, client_idx; };
 struct PublishAttr { uint32_t from_id, qos_retain; };       // == rgr_publish_attr
-struct alignas(16) Cand { uint32_t pos, client_idx, topic, word; };   // v5 hit that may be a per-client duplicate: window-relative position, topic,
-                                                                      // and its delivery word (the dedup flags it with a plain store)
+// v5 hit that may be a per-client duplicate: window-relative position + client.  (r3: 16 bytes with the topic and the delivery word; the
+// topic is implied by the position — a topic's hits are consecutive — and duplicates are rare, so flagging one is a read-modify-write
+// of its tuple word instead of 8 more bytes written and read per candidate: r4.)
+struct alignas(8) Cand { uint32_t pos, client_idx; };
 constexpr uint32_t kSubV5 = 1u << 0, kSubNoLocal = 1u << 1, kSubShared = 1u << 2, kSubRap = 1u << 3;   // RGR_SUB_*
 constexpr uint32_t kHitRetain = 1u << 2, kHitNoLocal = 1u << 3, kHitV5Dup = 1u << 4;                    // RGR_HIT_*
 struct DeliverArgs {
@@ -63,6 +65,8 @@ struct DeliverArgs {
     const SubAttr* attrs;        // parallel to TrieView::subs, may be null (no ids registered)
     Cand* cand;                  // dedup candidates of this window: tile i owns cand[i*tile_hits ..], null = none wanted
     uint32_t* tile_ncand;        // [tiles] candidates each tile wrote
+    uint32_t* tile_trange;       // [2 * tiles] window-relative first / last topic with hits in the tile (written with the tile's flag: bounds the
+                                 // tile-local dedup's search for a candidate's topic)
     uint32_t topic_lo;           // first topic of the window (batch-global index)
 };
 
@@ -243,7 +247,7 @@ void launch_expand_compact(const TrieView& t, const ChunkArrays& c, uint64_t pai
 // nt + n_hits / dedup_topic_cap() + 1 entries; *stat accumulates the candidate count.  Everything is stream-ordered: no host sync.
 // work item of the topic pass: part `part` of `parts` of window topic `topic` (nc candidates in total)
 struct DedupItem { uint32_t topic, part, parts, nc; };
-void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, uint32_t ntiles, Tuple* tuples, uint32_t nt,
+void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, const uint32_t* tile_trange, uint32_t ntiles, Tuple* tuples, uint32_t nt,
                   const uint64_t* hit_off, uint64_t hit_lo, DedupItem* items, uint32_t* item_count, unsigned long long* stat, void* stream);
 uint32_t dedup_topic_cap();
 // Delivery results grouped by node (SubRelationsMap's shape, types.rs:486-497): stable partition of every topic's tuples by

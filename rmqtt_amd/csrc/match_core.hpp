@@ -501,6 +501,34 @@ RGR_HD inline bool dedup_topic_insert(uint32_t client, uint32_t pos, uint32_t ma
         if (++steps > mask) return false;
     }
 }
+// Single pass (r4): insert and learn at once who LOST.  tab_min returns the slot's value from before the min.  Every candidate that
+// is not its client's first position loses exactly once — either on arrival (a smaller position is already there: it is the loser
+// itself) or later, when a smaller position arrives and gets it back as the old value — so flagging the returned position flags
+// exactly the duplicates, without a second pass over the candidate lists.  Returns kNone when nobody lost; full = the table has no
+// room (the caller re-splits the part; flags set so far stay valid).
+template <class Cas, class Min>
+RGR_HD inline uint32_t dedup_topic_insert_once(uint32_t client, uint32_t pos, uint32_t mask, Cas tab_cas, Min tab_min, bool& full) {
+    const unsigned long long mine = (static_cast<unsigned long long>(client) << 32) | pos;
+    uint32_t steps = 0;
+    for (uint32_t s = mix32(client) & mask;; s = (s + 1) & mask) {
+        const unsigned long long prev = tab_cas(s, mine);
+        if (prev == kDedupEmpty) return kNone;
+        if (uint32_t(prev >> 32) == client) {
+            const unsigned long long old = tab_min(s, mine);
+            return old < mine ? pos : uint32_t(old);
+        }
+        if (++steps > mask) { full = true; return kNone; }
+    }
+}
+// window topic of a window-relative position: the last t in [t_lo, t_hi] with hit_off(t) <= pos (hit_off: window-relative first positions)
+template <class HitOff>
+RGR_HD inline uint32_t topic_of_pos(uint32_t pos, uint32_t t_lo, uint32_t t_hi, HitOff hit_off) {
+    while (t_lo < t_hi) {
+        const uint32_t mid = t_lo + (t_hi - t_lo + 1) / 2;
+        if (hit_off(mid) <= pos) t_lo = mid; else t_hi = mid - 1;
+    }
+    return t_lo;
+}
 template <class Load>
 RGR_HD inline bool dedup_topic_is_dup(uint32_t client, uint32_t pos, uint32_t mask, Load tab_load) {
     for (uint32_t s = mix32(client) & mask;; s = (s + 1) & mask) {

@@ -242,10 +242,14 @@ struct Collector {
 
 // ---- Filters path: device walk -> one sub id per matched filter -> host expansion from relations_ (router.rs:194-231)
 Result<bool> GpuRouter::filters_pass(const std::vector<TopicName>& topics, FilterPass& pass) {
-    if (!g_) return Result<bool>::Err(create_error_);
     std::string blob;
     std::vector<uint64_t> offs(topics.size() + 1, 0);
     for (size_t i = 0; i < topics.size(); ++i) { blob += topics[i]; offs[i + 1] = blob.size(); }
+    return filters_pass(blob, offs, pass);
+}
+
+Result<bool> GpuRouter::filters_pass(const std::string& blob, const std::vector<uint64_t>& offs, FilterPass& pass) {
+    if (!g_) return Result<bool>::Err(create_error_);
     // The device pass runs under the SHARED lock: several passes (the Batcher's drivers) walk the same epoch at once, add / remove wait
     // for them — a fraction of a millisecond, as they wait for the trie's write lock in the reference, router.rs:438.  Pending
     // changes are committed first, under the exclusive lock; a writer slipping in between the two locks sends us round again, and
@@ -576,10 +580,11 @@ Batcher::~Batcher() {
     { std::lock_guard<std::mutex> g(task_mu_); task_stop_ = true; }
     task_cv_.notify_all();
     for (auto& w : workers_) w.join();
+    for (Shard& sh : shards_) for (Req* r : sh.free) delete r;
 }
 
 void Batcher::enqueue(Req* req) {
-    Shard& sh = shards_[shard_of_this_thread(kShards)];
+    Shard& sh = shards_[req->cb ? req->shard : shard_of_this_thread(kShards)];
     { std::lock_guard<std::mutex> lk(sh.m); sh.q.push_back(req); }
     requests_.fetch_add(1, std::memory_order_relaxed);
     const size_t before = pending_.fetch_add(1, std::memory_order_seq_cst);
@@ -603,11 +608,28 @@ Result<SubRelationsMap> Batcher::matches(const Id& id, const TopicName& topic) {
     return router_.expand(*req.pass, req.index, id, topic);
 }
 
-void Batcher::submit(Id id, TopicName topic, Callback cb) {
-    auto* req = new Req;
-    req->id = std::move(id); req->topic = std::move(topic); req->cb = std::move(cb);
-    if (stop_.load(std::memory_order_acquire)) { req->cb(Result<SubRelationsMap>::Err("batcher stopped")); delete req; return; }
+void Batcher::submit(const Id& id, std::string_view topic, Callback cb, void* user, uint64_t tag) {
+    if (stop_.load(std::memory_order_acquire)) { cb(user, tag, Result<SubRelationsMap>::Err("batcher stopped")); return; }
+    const uint32_t shard = uint32_t(shard_of_this_thread(kShards));
+    Shard& sh = shards_[shard];
+    Req* req = nullptr;
+    { std::lock_guard<std::mutex> lk(sh.m); if (!sh.free.empty()) { req = sh.free.back(); sh.free.pop_back(); } }
+    if (!req) req = new Req;
+    req->id = id; req->topic.assign(topic.data(), topic.size());      // (recycled objects: the strings' capacity is reused)
+    req->cb = cb; req->user = user; req->tag = tag; req->shard = shard;
+    req->pass.reset(); req->err.clear(); req->done = false;
     enqueue(req);
+}
+
+// finished asynchronous requests of one task go back to their shards' free lists, one lock per shard touched
+void Batcher::recycle(std::vector<Req*>& reqs) {
+    for (size_t i = 0; i < reqs.size();) {
+        const uint32_t shard = reqs[i]->shard;
+        std::lock_guard<std::mutex> lk(shards_[shard].m);
+        auto& fl = shards_[shard].free;
+        for (; i < reqs.size() && reqs[i]->shard == shard; ++i) { if (fl.size() < kFreeMax) fl.push_back(reqs[i]); else delete reqs[i]; }
+    }
+    reqs.clear();
 }
 
 void Batcher::run() {
@@ -622,24 +644,40 @@ void Batcher::run() {
             cv_req_.wait_until(lk, deadline, [&] { return stop_.load() || pending_.load(std::memory_order_seq_cst) >= max_batch_; });
             sleepers_.fetch_sub(1, std::memory_order_seq_cst);
         }
+        const auto t_collect = std::chrono::steady_clock::now();
         std::vector<Req*> reqs;
-        for (size_t k = 0; k < kShards && reqs.size() < max_batch_; ++k) {
-            Shard& sh = shards_[k];
-            std::lock_guard<std::mutex> lk(sh.m);
-            const size_t take = std::min(sh.q.size(), max_batch_ - reqs.size());
-            reqs.insert(reqs.end(), sh.q.begin(), sh.q.begin() + take);
-            sh.q.erase(sh.q.begin(), sh.q.begin() + take);
-        }
+        // the shards are visited round-robin from a rotating start and each gives an equal share first, so that a batch that cannot
+        // take everything does not starve the submitters on the later shards (r4c: always starting at shard 0 left a 45-90 ms p99)
+        const size_t first = next_shard_.fetch_add(1, std::memory_order_relaxed);
+        for (int round = 0; round < 2 && reqs.size() < max_batch_; ++round)
+            for (size_t k = 0; k < kShards && reqs.size() < max_batch_; ++k) {
+                Shard& sh = shards_[(first + k) % kShards];
+                std::lock_guard<std::mutex> lk(sh.m);
+                const size_t share = round == 0 ? std::max<size_t>(1, max_batch_ / kShards) : max_batch_;
+                const size_t take = std::min({sh.q.size(), max_batch_ - reqs.size(), share});
+                reqs.insert(reqs.end(), sh.q.begin(), sh.q.begin() + take);
+                sh.q.erase(sh.q.begin(), sh.q.begin() + take);
+            }
         if (reqs.empty()) continue;                               // another driver took them
         if (pending_.fetch_sub(reqs.size(), std::memory_order_acq_rel) > reqs.size() && sleepers_.load() > 0) cv_req_.notify_one();     // more are waiting: next driver
-        std::vector<TopicName> topics;
-        topics.reserve(reqs.size());
-        for (Req* r : reqs) topics.push_back(r->topic);
+        std::string blob;
+        std::vector<uint64_t> offs(reqs.size() + 1, 0);
+        {
+            size_t bytes = 0;
+            for (Req* r : reqs) bytes += r->topic.size();
+            blob.reserve(bytes);
+            for (size_t i = 0; i < reqs.size(); ++i) { blob += reqs[i]->topic; offs[i + 1] = blob.size(); }
+        }
         auto pass = std::make_shared<GpuRouter::FilterPass>();
-        auto res = router_.filters_pass(topics, *pass);
+        const auto t_pass = std::chrono::steady_clock::now();
+        auto res = router_.filters_pass(blob, offs, *pass);
+        const auto t_done = std::chrono::steady_clock::now();
         passes_.fetch_add(1, std::memory_order_relaxed);
+        collect_ns_.fetch_add(uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(t_pass - t_collect).count()), std::memory_order_relaxed);
+        pass_ns_.fetch_add(uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(t_done - t_pass).count()), std::memory_order_relaxed);
         // asynchronous requests go to the workers in runs of kTaskRun (one shared-lock acquisition per run); blocking callers are woken
         Task task;
+        std::vector<Req*> failed;
         auto flush = [&] {
             if (task.reqs.empty()) return;
             task.pass = pass;
@@ -650,7 +688,7 @@ void Batcher::run() {
         for (size_t i = 0; i < reqs.size(); ++i) {
             Req* r = reqs[i];
             if (r->cb) {
-                if (!res.ok()) { r->cb(Result<SubRelationsMap>::Err(res.error)); delete r; continue; }
+                if (!res.ok()) { r->cb(r->user, r->tag, Result<SubRelationsMap>::Err(res.error)); failed.push_back(r); continue; }
                 r->index = i;
                 task.reqs.push_back(r);
                 if (task.reqs.size() >= kTaskRun) flush();
@@ -662,10 +700,16 @@ void Batcher::run() {
             r->cv.notify_one();             // under r->m: the caller cannot destroy the request before this returns
         }
         flush();
+        if (!failed.empty()) recycle(failed);
+        dispatch_ns_.fetch_add(uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_done).count()), std::memory_order_relaxed);
     }
 }
 
 void Batcher::run_task(Task& t) {
+    const auto t0 = std::chrono::steady_clock::now();
+    struct Timed { Batcher* b; std::chrono::steady_clock::time_point t0; ~Timed() {
+        b->task_ns_.fetch_add(uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count()), std::memory_order_relaxed);
+        b->tasks_run_.fetch_add(1, std::memory_order_relaxed); } } timed{this, t0};
     const size_t n = t.reqs.size();
     std::vector<size_t> index(n);
     std::vector<const Id*> ids(n);
@@ -673,7 +717,8 @@ void Batcher::run_task(Task& t) {
     for (size_t i = 0; i < n; ++i) { index[i] = t.reqs[i]->index; ids[i] = &t.reqs[i]->id; topics[i] = &t.reqs[i]->topic; }
     std::vector<Result<SubRelationsMap>> out;
     router_.expand_chunk(*t.pass, index.data(), ids.data(), topics.data(), n, out);
-    for (size_t i = 0; i < n; ++i) { t.reqs[i]->cb(std::move(out[i])); delete t.reqs[i]; }
+    for (size_t i = 0; i < n; ++i) t.reqs[i]->cb(t.reqs[i]->user, t.reqs[i]->tag, std::move(out[i]));
+    recycle(t.reqs);
 }
 
 void Batcher::work() {
@@ -683,6 +728,7 @@ void Batcher::work() {
             std::unique_lock<std::mutex> lk(task_mu_);
             task_cv_.wait(lk, [&] { return task_stop_ || !tasks_.empty(); });
             if (tasks_.empty()) return;                           // (stop: the drivers are gone, nothing more can arrive)
+            if (tasks_.size() > max_task_queue_) max_task_queue_ = tasks_.size();
             t = std::move(tasks_.front());
             tasks_.pop_front();
         }

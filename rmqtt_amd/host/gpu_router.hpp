@@ -37,6 +37,7 @@
 #include <optional>
 #include <shared_mutex>
 #include <string>
+#include <string_view>
 #include <unordered_map>
 #include <vector>
 
@@ -180,6 +181,7 @@ class GpuRouter final : public Router {
         ~FilterPass() { rgr_filters_result_free(&res); }
     };
     Result<bool> filters_pass(const std::vector<TopicName>& topics, FilterPass& pass);
+    Result<bool> filters_pass(const std::string& blob, const std::vector<uint64_t>& offs, FilterPass& pass);      // topics already packed
     // Err: what the reference returns for an invalid topic name ("invalid topic ..."), or a device failure of the re-match
     Result<SubRelationsMap> expand(const FilterPass& pass, size_t t, const Id& id, const TopicName& topic);
     // n publishes of one pass (index[i] = position inside the pass) under ONE acquisition of the table lock
@@ -263,20 +265,31 @@ class GpuRouter final : public Router {
 // is held while callers wait.  Rust twin: rust/rmqtt-gpu-router/src/batcher.rs (MAX_IN_FLIGHT; tokio's own workers).
 class Batcher {
    public:
-    using Callback = std::function<void(Result<SubRelationsMap>&&)>;
+    // completion of an asynchronous publish: `user` and `tag` are the caller's (a plain function pointer + two words instead of a
+    // std::function: no heap allocation per publish — r4d: allocator and cache-line traffic between submitters and workers, not the
+    // device, capped the boundary at 2.3 M publishes/s)
+    using Callback = void (*)(void* user, uint64_t tag, Result<SubRelationsMap>&& result);
     Batcher(GpuRouter& router, size_t max_batch, std::chrono::microseconds max_delay, unsigned passes_in_flight = 3, unsigned workers = 0);
     ~Batcher();
     Result<SubRelationsMap> matches(const Id& id, const TopicName& topic);
-    void submit(Id id, TopicName topic, Callback cb);
+    void submit(const Id& id, std::string_view topic, Callback cb, void* user, uint64_t tag);
     uint64_t passes() const { return passes_; }
     uint64_t requests() const { return requests_; }
+    // where the drivers' and workers' time went (nanoseconds summed over threads): collecting a batch (incl. the deadline wait's tail
+    // and packing the topics), the device pass (GpuRouter::filters_pass), handing the results on, and the workers' expansion tasks
+    struct Timing { uint64_t collect_ns, pass_ns, dispatch_ns, task_ns, tasks, max_task_queue; };
+    Timing timing() const { return Timing{collect_ns_, pass_ns_, dispatch_ns_, task_ns_, tasks_run_, max_task_queue_}; }
 
    private:
     // blocking requests live on their caller's stack and are woken through their own condition variable (one shared cv made 256
     // callers fight for one mutex per pass); asynchronous ones are heap objects that end with their callback
-    struct Req { Id id; TopicName topic; Callback cb; std::shared_ptr<GpuRouter::FilterPass> pass; size_t index = 0; std::string err; bool done = false;
+    struct Req { Id id; TopicName topic; Callback cb = nullptr; void* user = nullptr; uint64_t tag = 0; uint32_t shard = 0;
+                 std::shared_ptr<GpuRouter::FilterPass> pass; size_t index = 0; std::string err; bool done = false;
                  std::mutex m; std::condition_variable cv; };
-    struct Shard { std::mutex m; std::vector<Req*> q; };
+    // a submitter sticks to one shard: its queue, and the free list its asynchronous requests are recycled through (a finished
+    // request goes back to the shard it came from, so request objects — and the capacity of their strings — stay with their submitter
+    // instead of crossing the allocator's arenas on every publish)
+    struct alignas(64) Shard { std::mutex m; std::vector<Req*> q; std::vector<Req*> free; };
     struct Task { std::shared_ptr<GpuRouter::FilterPass> pass; std::vector<Req*> reqs; };
     static constexpr size_t kShards = 16;      // submission queues (a submitter sticks to one)
     static constexpr size_t kTaskRun = 64;     // publishes per worker task
@@ -290,12 +303,17 @@ class Batcher {
     std::atomic<bool> stop_{false};
     std::atomic<int> sleepers_{0};             // drivers inside a condition-variable wait (submitters only notify when there is one)
     std::atomic<uint64_t> passes_{0}, requests_{0};
+    std::atomic<uint64_t> collect_ns_{0}, pass_ns_{0}, dispatch_ns_{0}, task_ns_{0}, tasks_run_{0};
+    std::atomic<size_t> next_shard_{0};
+    size_t max_task_queue_ = 0;                // (under task_mu_)
     std::mutex task_mu_;
     std::condition_variable task_cv_;
     std::deque<Task> tasks_;
     bool task_stop_ = false;
     std::vector<std::thread> drivers_, workers_;
+    static constexpr size_t kFreeMax = 1 << 16;      // recycled request objects kept per shard
     void enqueue(Req* r);
+    void recycle(std::vector<Req*>& reqs);
     void run();
     void work();
     void run_task(Task& t);

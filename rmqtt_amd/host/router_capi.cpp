@@ -163,7 +163,10 @@ int hr_e2e_run_async(void* r, const uint8_t* blob, const uint64_t* offs, uint32_
                      uint32_t passes_in_flight, uint32_t max_batch, uint32_t max_delay_us, double seconds, uint64_t* out, double* wall_s,
                      float* lat_us, uint32_t n_lat, uint32_t* n_lat_out) {
     auto* router = static_cast<GpuRouter*>(r);
-    struct Ctx { std::atomic<int64_t> inflight{0}; std::atomic<uint64_t> pubs{0}, rows{0}, errs{0}; std::mutex m; std::condition_variable cv; };
+    // per submitter: counters on their own cache lines (the completions run on the worker pool)
+    struct alignas(64) Ctx { std::atomic<int64_t> inflight{0}; char pad0[56]; std::atomic<uint64_t> pubs{0}, rows{0}, errs{0}; char pad1[40];
+                             std::mutex m; std::condition_variable cv; int64_t low = 0; float* lat = nullptr; uint32_t n_lat = 0; std::atomic<uint32_t> lat_n{0};
+                             std::chrono::steady_clock::time_point t0; };
     std::vector<std::unique_ptr<Ctx>> ctx;
     for (uint32_t k = 0; k < n_submitters; ++k) ctx.push_back(std::make_unique<Ctx>());
     const int64_t cap = std::max<int64_t>(1, outstanding / std::max(1u, n_submitters));
@@ -171,10 +174,25 @@ int hr_e2e_run_async(void* r, const uint8_t* blob, const uint64_t* offs, uint32_
     // completion: r4b's first cut woke the submitter — a futex + a context switch — for every single completion)
     const int64_t low = cap - std::max<int64_t>(1, cap / 4);
     std::atomic<bool> stop{false};
-    std::atomic<uint32_t> lat_n{0};
     uint64_t passes = 0;
     const auto t0 = std::chrono::steady_clock::now();
+    for (auto& c : ctx) { c->low = low; c->t0 = t0; }
+    ctx[0]->lat = lat_us; ctx[0]->n_lat = lat_us ? n_lat : 0;
     double wall = 0;
+    // completion: tag = submit time in ns since t0
+    const Batcher::Callback done = [](void* user, uint64_t tag, Result<SubRelationsMap>&& res) {
+        Ctx& c = *static_cast<Ctx*>(user);
+        uint64_t rows = 0;
+        if (res.ok()) for (auto& kv : *res.value) rows += kv.second.size();
+        else if (res.error.rfind("invalid topic", 0) != 0) c.errs.fetch_add(1, std::memory_order_relaxed);
+        if (rows) c.rows.fetch_add(rows, std::memory_order_relaxed);
+        c.pubs.fetch_add(1, std::memory_order_relaxed);
+        if (c.lat) {
+            const uint32_t j = c.lat_n.fetch_add(1, std::memory_order_relaxed);
+            if (j < c.n_lat) c.lat[j] = float(double(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - c.t0).count() - int64_t(tag)) / 1e3);
+        }
+        if (c.inflight.fetch_sub(1, std::memory_order_acq_rel) == c.low + 1) { { std::lock_guard<std::mutex> g(c.m); } c.cv.notify_one(); }
+    };
     {
         Batcher b(*router, max_batch, std::chrono::microseconds(max_delay_us), passes_in_flight, workers);
         std::vector<std::thread> th;
@@ -190,19 +208,8 @@ int hr_e2e_run_async(void* r, const uint8_t* blob, const uint64_t* offs, uint32_
                     }
                     const uint32_t t = uint32_t(i % n);
                     c.inflight.fetch_add(1, std::memory_order_acq_rel);
-                    const auto a = std::chrono::steady_clock::now();
-                    b.submit(id, std::string(reinterpret_cast<const char*>(blob) + offs[t], offs[t + 1] - offs[t]), [&c, a, k, lat_us, n_lat, &lat_n, low](Result<SubRelationsMap>&& res) {
-                        uint64_t rows = 0;
-                        if (res.ok()) for (auto& kv : *res.value) rows += kv.second.size();
-                        else if (res.error.rfind("invalid topic", 0) != 0) c.errs.fetch_add(1, std::memory_order_relaxed);
-                        c.rows.fetch_add(rows, std::memory_order_relaxed);
-                        c.pubs.fetch_add(1, std::memory_order_relaxed);
-                        if (k == 0 && lat_us) {
-                            const uint32_t j = lat_n.fetch_add(1, std::memory_order_relaxed);
-                            if (j < n_lat) lat_us[j] = std::chrono::duration<float, std::micro>(std::chrono::steady_clock::now() - a).count();
-                        }
-                        if (c.inflight.fetch_sub(1, std::memory_order_acq_rel) == low + 1) { { std::lock_guard<std::mutex> g(c.m); } c.cv.notify_one(); }
-                    });
+                    const uint64_t now_ns = uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count());
+                    b.submit(id, std::string_view(reinterpret_cast<const char*>(blob) + offs[t], offs[t + 1] - offs[t]), done, &c, now_ns);
                 }
             });
         std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
@@ -211,12 +218,14 @@ int hr_e2e_run_async(void* r, const uint8_t* blob, const uint64_t* offs, uint32_
         for (auto& c : ctx) while (c->inflight.load(std::memory_order_acquire) > 0) std::this_thread::sleep_for(std::chrono::microseconds(100));
         wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         passes = b.passes();
+        const Batcher::Timing tm = b.timing();      // out[4..9]: where the batcher's threads spent their time (ns summed over threads)
+        out[4] = tm.collect_ns; out[5] = tm.pass_ns; out[6] = tm.dispatch_ns; out[7] = tm.task_ns; out[8] = tm.tasks; out[9] = tm.max_task_queue;
     }
     if (wall_s) *wall_s = wall;
     out[0] = out[1] = out[3] = 0;
     for (auto& c : ctx) { out[0] += c->pubs; out[1] += c->rows; out[3] += c->errs; }
     out[2] = passes;
-    if (n_lat_out) *n_lat_out = std::min(lat_n.load(), n_lat);
+    if (n_lat_out) *n_lat_out = std::min(ctx[0]->lat_n.load(), ctx[0]->n_lat);
     return 0;
 }
 // n publishes submitted asynchronously (Batcher::submit) from n_threads threads, completions on `workers` pool threads: dumps joined by
@@ -224,18 +233,21 @@ int hr_e2e_run_async(void* r, const uint8_t* blob, const uint64_t* offs, uint32_
 char* hr_batcher_run_async(void* r, const hr_id* ids, const char* const* topics, const uint32_t* lens, uint32_t n, uint32_t n_threads,
                            uint32_t max_batch, uint32_t max_delay_us, uint32_t passes_in_flight, uint32_t workers, uint64_t* passes) {
     auto* router = static_cast<GpuRouter*>(r);
-    std::vector<std::string> outs(n);
-    std::atomic<uint32_t> done{0};
+    struct Sink { std::vector<std::string> outs; std::atomic<uint32_t> done{0}; } sink;
+    sink.outs.resize(n);
+    std::vector<std::string>& outs = sink.outs;
+    std::atomic<uint32_t>& done = sink.done;
+    const Batcher::Callback cb = [](void* user, uint64_t tag, Result<SubRelationsMap>&& res) {
+        Sink& s = *static_cast<Sink*>(user);
+        s.outs[tag] = res.ok() ? dump(*res.value) : std::string("!ERR");
+        s.done.fetch_add(1, std::memory_order_release);
+    };
     {
         Batcher b(*router, max_batch, std::chrono::microseconds(max_delay_us), passes_in_flight, workers);
         std::vector<std::thread> th;
         for (uint32_t k = 0; k < n_threads; ++k)
             th.emplace_back([&, k] {
-                for (uint32_t i = k; i < n; i += n_threads)
-                    b.submit(mk_id(&ids[i]), std::string(topics[i], lens[i]), [&outs, &done, i](Result<SubRelationsMap>&& res) {
-                        outs[i] = res.ok() ? dump(*res.value) : std::string("!ERR");
-                        done.fetch_add(1, std::memory_order_release);
-                    });
+                for (uint32_t i = k; i < n; i += n_threads) b.submit(mk_id(&ids[i]), std::string_view(topics[i], lens[i]), cb, &sink, i);
             });
         for (auto& t : th) t.join();
         while (done.load(std::memory_order_acquire) < n) std::this_thread::sleep_for(std::chrono::microseconds(100));

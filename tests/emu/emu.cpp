@@ -213,7 +213,7 @@ int32_t run_pipeline(Emu* e, uint32_t n, const std::vector<uint64_t>& tok_off, c
                             }
                             bool is_cand;
                             se.qos_flags = deliver_word(se.qos_flags, pa, at, is_cand);
-                            if (is_cand && at.client_idx != kNone) cand.push_back(Cand{uint32_t(base - hit_lo) + pos, at.client_idx, s_topic[i] - (begin + lc), se.qos_flags});
+                            if (is_cand && at.client_idx != kNone) cand.push_back(Cand{uint32_t(base - hit_lo) + pos, at.client_idx});
                         }
                         out[(base - hit_lo) + pos] = rgr_tuple{s_topic[i], se.sub_id, se.qos_flags};
                     }
@@ -222,21 +222,35 @@ int32_t run_pipeline(Emu* e, uint32_t n, const std::vector<uint64_t>& tok_off, c
                     const uint32_t topic_lo = begin + lc, nt = le - lc;
                     std::vector<std::vector<Cand>> lists(ntiles);     // DeliverArgs::cand: every tile's own list, in arbitrary order
                     std::vector<uint32_t> topic_cand(nt, 0);          // DeliverArgs::topic_cand
+                    auto h_off = [&](uint32_t t) { return hit_off[lc + t] - hit_lo; };       // window-relative first position of window topic t
+                    auto h_off32 = [&](uint32_t t) { return uint32_t(h_off(t)); };
+                    // a candidate carries its position only: its topic is the one whose hit range holds that position (topic_of_pos,
+                    // match_core.hpp — what dedup_tile_kernel does); it must be the topic the tuple at that position names
+                    auto topic_of = [&](const Cand& c) { return topic_of_pos(c.pos, 0u, nt - 1, h_off32); };
                     for (const Cand& c : cand) {
-                        if (c.topic != out[c.pos].topic_idx - topic_lo) return RGR_ESTATE;
+                        if (topic_of(c) != out[c.pos].topic_idx - topic_lo) return RGR_ESTATE;
                         lists[c.pos / T].push_back(c);
-                        topic_cand[c.topic]++;
+                        topic_cand[topic_of(c)]++;
                     }
                     for (auto& l : lists) std::reverse(l.begin(), l.end());
-                    auto h_off = [&](uint32_t t) { return hit_off[lc + t] - hit_lo; };       // window-relative first position of window topic t
                     std::map<uint64_t, uint32_t> first;                // independent statement of types.rs:524-539
                     auto key_of = [&](const Cand& c) { return (uint64_t(out[c.pos].topic_idx) << 32) | c.client_idx; };
                     for (const Cand& c : cand) { auto it = first.find(key_of(c)); if (it == first.end() || c.pos < it->second) first[key_of(c)] = c.pos; }
                     std::vector<uint8_t> decided(nh, 0);
                     auto flag = [&](const Cand& c, bool dup) {
                         if (dup != (first[key_of(c)] != c.pos)) return false;
-                        if (dup) out[c.pos].qos_flags = c.word | kHitV5Dup;
+                        if (dup) out[c.pos].qos_flags |= kHitV5Dup;
                         decided[c.pos] = 1;
+                        return true;
+                    };
+                    // the single-pass topic tables flag a LOSER by position (dedup_topic_insert_once): it must be a candidate that is not
+                    // its client's first hit of the topic
+                    std::map<uint32_t, const Cand*> by_pos;
+                    for (const Cand& c : cand) by_pos[c.pos] = &c;
+                    auto flag_loser = [&](uint32_t pos) {
+                        auto it = by_pos.find(pos);
+                        if (it == by_pos.end() || first[key_of(*it->second)] == pos) return false;
+                        out[pos].qos_flags |= kHitV5Dup;
                         return true;
                     };
                     // dedup_tile_kernel
@@ -248,9 +262,12 @@ int32_t run_pipeline(Emu* e, uint32_t n, const std::vector<uint64_t>& tok_off, c
                         const uint64_t lo = uint64_t(tile) * T, hi = lo + T;
                         std::vector<uint32_t> k_topic(l.size()), tab(tslots, kNone);
                         uint32_t inside = 0;
+                        const uint32_t t_lo = topic_of_pos(uint32_t(lo), 0u, nt - 1, h_off32), t_hi = topic_of_pos(uint32_t(std::min<uint64_t>(hi, nh) - 1), 0u, nt - 1, h_off32);
                         for (size_t i = 0; i < l.size(); ++i) {
-                            const bool in = h_off(l[i].topic) >= lo && h_off(l[i].topic + 1) <= hi;
-                            k_topic[i] = in ? l[i].topic : kNone; inside += in;
+                            const uint32_t ti = topic_of_pos(l[i].pos, t_lo, t_hi, h_off32);       // the tile kernel's bounded search
+                            if (ti != topic_of(l[i])) return RGR_ESTATE;
+                            const bool in = h_off(ti) >= lo && h_off(ti + 1) <= hi;
+                            k_topic[i] = in ? ti : kNone; inside += in;
                         }
                         if (inside < 2) continue;
                         auto kt = [&](uint32_t k) { return k_topic[k]; };
@@ -282,16 +299,26 @@ int32_t run_pipeline(Emu* e, uint32_t n, const std::vector<uint64_t>& tok_off, c
                                     const uint64_t nparts = uint64_t(parts) * S;
                                     const uint32_t mine = part * S + sub;
                                     std::vector<unsigned long long> tab(size_t(mask) + 1, kDedupEmpty);
-                                    auto sel = [&](const Cand& c) { return c.topic == t && (nparts == 1 || dedup_part(c.client_idx, nparts) == mine); };
+                                    auto sel = [&](const Cand& c) { return c.pos >= h0 && c.pos < h1 && (nparts == 1 || dedup_part(c.client_idx, nparts) == mine); };
+                                    // dedup_topic_kernel's single pass: every insertion names the position that just lost
                                     for (uint32_t tile = tile0; tile <= tile1 && !over; ++tile)
-                                        for (const Cand& c : lists[tile])
-                                            if (sel(c) && !dedup_topic_insert(c.client_idx, c.pos, mask,
-                                                                              [&](uint32_t sl, unsigned long long v) { const unsigned long long o = tab[sl]; if (o == kDedupEmpty) tab[sl] = v; return o; },
-                                                                              [&](uint32_t sl, unsigned long long v) { tab[sl] = std::min(tab[sl], v); })) { over = true; break; }
+                                        for (const Cand& c : lists[tile]) {
+                                            if (!sel(c)) continue;
+                                            bool full = false;
+                                            const uint32_t loser = dedup_topic_insert_once(c.client_idx, c.pos, mask,
+                                                [&](uint32_t sl, unsigned long long v) { const unsigned long long o = tab[sl]; if (o == kDedupEmpty) tab[sl] = v; return o; },
+                                                [&](uint32_t sl, unsigned long long v) { const unsigned long long o = tab[sl]; tab[sl] = std::min(o, v); return o; }, full);
+                                            if (full) { over = true; break; }
+                                            if (loser != kNone && !flag_loser(loser)) return RGR_ESTATE;
+                                        }
                                     if (over) break;
+                                    // the part is complete: exactly the non-first hits of its clients carry the flag
                                     for (uint32_t tile = tile0; tile <= tile1; ++tile)
                                         for (const Cand& c : lists[tile])
-                                            if (sel(c) && !flag(c, dedup_topic_is_dup(c.client_idx, c.pos, mask, [&](uint32_t sl) { return tab[sl]; }))) return RGR_ESTATE;
+                                            if (sel(c)) {
+                                                if (((out[c.pos].qos_flags & kHitV5Dup) != 0) != (first[key_of(c)] != c.pos)) return RGR_ESTATE;
+                                                decided[c.pos] = 1;
+                                            }
                                 }
                                 if (!over) break;
                                 if (S > (1u << 20)) return RGR_ESTATE;
@@ -300,7 +327,7 @@ int32_t run_pipeline(Emu* e, uint32_t n, const std::vector<uint64_t>& tok_off, c
                     }
                     // every candidate of a topic with at least two candidates was decided by exactly one of the two passes' rules
                     for (const Cand& c : cand)
-                        if (!decided[c.pos] && topic_cand[c.topic] >= 2 && first[key_of(c)] != c.pos) return RGR_ESTATE;
+                        if (!decided[c.pos] && topic_cand[topic_of(c)] >= 2 && first[key_of(c)] != c.pos) return RGR_ESTATE;
                 }
             }
             lc = le;
