@@ -1158,7 +1158,7 @@ def measure_group(args):
     return 0
 
 
-def measure_router_e2e(args):
+def measure_router_e2e(args, quick=False):
     """What a broker sees through the drop-in boundary: N host threads call Router::matches (one publish per call, as
     DefaultShared::forwards does, shared.rs:772) on the C++ twin of the GpuRouter through its deadline micro-batcher; beside it
     the oracle's DefaultRouter::_matches-shaped pass on the same number of threads of the same host.  Both build the full
@@ -1199,7 +1199,9 @@ def measure_router_e2e(args):
             wall = C.c_double(0)
             lat = np.zeros(200_000, dtype=np.float32)
             nl = C.c_uint32(0)
-            secs = 6.0 if mode == 1 else 4.0
+            if quick and mode == 2:
+                continue
+            secs = 2.5 if quick else (6.0 if mode == 1 else 4.0)
             L.hr_e2e_run(g, tb.ctypes.data, to.ctypes.data, n_t, cores, 4096, 200, 1.0, res, C.byref(wall), None, 0, None)      # warm
             L.hr_e2e_run(g, tb.ctypes.data, to.ctypes.data, n_t, cores, 4096, 200, secs, res, C.byref(wall), lat.ctypes.data, len(lat), C.byref(nl))
             l = np.sort(lat[:nl.value])
@@ -1221,7 +1223,7 @@ def measure_router_e2e(args):
             lat = np.zeros(400_000, dtype=np.float32)
             nl = C.c_uint32(0)
             L.hr_e2e_run_async(g, tb.ctypes.data, to.ctypes.data, n_t, subm, outst, workers, passes, 4096, 200, 1.0, res, C.byref(wall), None, 0, None)      # warm
-            L.hr_e2e_run_async(g, tb.ctypes.data, to.ctypes.data, n_t, subm, outst, workers, passes, 4096, 200, 5.0 if cfg == 2 else 4.0, res, C.byref(wall),
+            L.hr_e2e_run_async(g, tb.ctypes.data, to.ctypes.data, n_t, subm, outst, workers, passes, 4096, 200, 3.0 if quick else (5.0 if cfg == 2 else 4.0), res, C.byref(wall),
                                lat.ctypes.data, len(lat), C.byref(nl))
             l = np.sort(lat[:nl.value])
             rec["gpu_async"].append({"submitters": subm, "outstanding": outst, "workers": workers, "passes_in_flight": passes,
@@ -1249,8 +1251,9 @@ def measure_router_e2e(args):
         rec["vs_cpu_port"] = round(best / rec["cpu_reference_port"]["value"], 2)
         del o
         out.append(rec)
-        print(json.dumps(rec), flush=True)
-    return 0
+        if not quick:
+            print(json.dumps(rec), flush=True)
+    return out if quick else 0
 
 
 def time_format(args):
@@ -1411,6 +1414,17 @@ def main():
         except Exception as e:
             log(f"secondary delivery-stage record failed: {e!r}")
             secondary.append({"config": {"workload": "BASELINE.json configs[2] + delivery stage"}, "error": repr(e)})
+
+    if headline and not args.no_secondary and args.config == 3 and args.scale == 1.0:
+        # the drop-in boundary end to end: Router::matches through the C++ twin's batcher at config 2 — 256 blocked callers and
+        # the asynchronous shape (a few submitters, 16 k publishes outstanding, 3 passes in flight) — beside the CPU port on the same host
+        try:
+            args.e2e_configs = "2"
+            for erec in measure_router_e2e(args, quick=True):
+                secondary.append(erec)
+        except Exception as e:
+            log(f"secondary router-e2e record failed: {e!r}")
+            secondary.append({"config": {"workload": "BASELINE.json configs[1] through Router::matches"}, "error": repr(e)})
 
     if (headline or world > 1) and not args.no_pmc and args.deliver < 0:
         # N > 1: rank 0's child replays RANK 0's shard (table + topics under the same shard rule) on its GPU: a per-rank roofline

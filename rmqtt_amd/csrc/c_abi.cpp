@@ -75,7 +75,9 @@ struct DictImage {   // device copy of a StringDict for the device tokeniser
 // in-flight pass still reads alive.
 struct EdgeImage { DevBuf buf; uint64_t cap = 0; std::vector<uint32_t> pending; bool need_full = true; };
 struct FiltImage { DevBuf buf; uint64_t cap = 0; std::vector<uint32_t> pending; bool need_full = true; };
-struct SubsPool { DevBuf buf, attr_buf; uint64_t used = 0, cap = 0; bool has_attrs = false; };   // attr_buf: SubAttr parallel to buf
+// attr_buf: SubAttr parallel to buf; packed_buf: sub_id | qos << 30 parallel to buf (TrieView::subs_packed), filled on the device
+// for every range of entries a commit uploads
+struct SubsPool { DevBuf buf, attr_buf, packed_buf; uint64_t used = 0, cap = 0; bool has_attrs = false; };
 
 struct Epoch {
     std::shared_ptr<DictImage> dict;
@@ -98,6 +100,9 @@ struct RetainEpoch {
     // host mirror of vals[] (rgr_retain_match_ranges hands out pointers into it): immutable once published; the two-tier commit
     // replaces it copy-on-write when it marks entries dead.  Read / replaced under rgr_handle::epoch_mu.
     std::shared_ptr<const std::vector<SubEntry>> h_vals;
+    DevBuf vals_packed;                // TrieView::subs_packed of the retained values (single-tier epochs only)
+    const uint32_t* tv_packed = nullptr;
+    uint32_t max_id_hint = 0xFFFFFFFFu;
 };
 
 enum SpanKind { kSpanWalk = 0, kSpanScan = 1, kSpanExpand = 2, kSpanDedup = 3 };
@@ -233,7 +238,10 @@ struct rgr_batch {
     hipEvent_t get_event() {
         if (!event_pool.empty()) { hipEvent_t e = event_pool.back(); event_pool.pop_back(); return e; }
         hipEvent_t e;
-        RGR_HIP(hipEventCreate(&e));
+        // timing only: no system-scope fence when the event completes (the default flags make every record a cache-flushing release;
+        // 4 records per window were 1.8 ms of a 116 ms packed pass, profiles/r04b_*).  RGR_SPAN_FENCE=1 restores the default events.
+        static const bool fence = std::getenv("RGR_SPAN_FENCE") != nullptr;
+        RGR_HIP(hipEventCreateWithFlags(&e, fence ? hipEventDefault : hipEventDisableSystemFence));
         return e;
     }
     // RGR_SPAN_SAMPLE=0 (diagnostic): no event pairs around the per-window launches — what the per-kernel timing itself costs a pass
@@ -940,6 +948,8 @@ int32_t rgr_commit(rgr_handle* h) {
                 np->buf.ensure(np->cap * sizeof(SubEntry));
                 if (!subs.empty()) RGR_HIP(hipMemcpy(np->buf.p, subs.data(), subs.size() * sizeof(SubEntry), hipMemcpyHostToDevice));
                 np->used = subs.size();
+                np->packed_buf.ensure(np->cap * 4);
+                launch_pack_subs(np->buf.as<SubEntry>(), np->used, np->packed_buf.as<uint32_t>(), nullptr);
                 if (want_attrs) {
                     np->attr_buf.ensure(np->cap * sizeof(SubAttr));
                     const auto at = gather_attrs(subs);
@@ -961,7 +971,10 @@ int32_t rgr_commit(rgr_handle* h) {
                     if (v) stage.insert(stage.end(), v->begin(), v->end());
                 }
                 if (!stage.empty())
+                {
                     RGR_HIP(hipMemcpy(h->sub_pool->buf.as<SubEntry>() + h->sub_pool->used, stage.data(), stage.size() * sizeof(SubEntry), hipMemcpyHostToDevice));
+                    launch_pack_subs(h->sub_pool->buf.as<SubEntry>() + h->sub_pool->used, stage.size(), h->sub_pool->packed_buf.as<uint32_t>() + h->sub_pool->used, nullptr);
+                }
                 if (!stage.empty() && h->sub_pool->has_attrs) {
                     const auto at = gather_attrs(stage);
                     RGR_HIP(hipMemcpy(h->sub_pool->attr_buf.as<SubAttr>() + h->sub_pool->used, at.data(), at.size() * sizeof(SubAttr), hipMemcpyHostToDevice));
@@ -1002,12 +1015,14 @@ int32_t rgr_commit(rgr_handle* h) {
             ep->view.attrs = h->sub_pool->has_attrs ? h->sub_pool->attr_buf.as<SubAttr>() : nullptr;
             ep->n_v5 = h->table.n_v5_subs();
             ep->max_sub_id = h->table.max_sub_id();
+            ep->view.subs_packed = ep->max_sub_id < (1u << 30) ? h->sub_pool->packed_buf.as<uint32_t>() : nullptr;
+            RGR_HIP(hipDeviceSynchronize());            // (the pack kernels above ran on the null stream; the epoch is published below)
             ep->max_node_idx = h->table.max_node_idx();
             ep->n_filters = h->table.n_filters();
             ep->n_subs = h->table.n_subs();
             ep->n_nodes = h->table.n_nodes();
             ep->edge_slots = edges.size();
-            ep->bytes = ei.buf.bytes + fi.buf.bytes + h->sub_pool->buf.bytes + h->sub_pool->attr_buf.bytes;
+            ep->bytes = ei.buf.bytes + fi.buf.bytes + h->sub_pool->buf.bytes + h->sub_pool->attr_buf.bytes + h->sub_pool->packed_buf.bytes;
         }
         recover.armed = false;
         std::lock_guard<std::mutex> g(h->epoch_mu);

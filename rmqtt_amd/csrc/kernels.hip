@@ -788,6 +788,12 @@ __global__ __launch_bounds__(kThreads) void expand_kernel(const SubEntry* __rest
     }
 }
 
+// packed side array of the subscriber entries (TrieView::subs_packed)
+__global__ __launch_bounds__(256) void pack_subs_kernel(const SubEntry* __restrict__ subs, uint64_t n, uint32_t* __restrict__ packed) {
+    const uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < n) { const SubEntry e = subs[i]; packed[i] = e.sub_id | ((e.qos_flags & 3u) << 30); }
+}
+
 // --------------------------------------------------------------------------- expand, compact result formats
 // The 12-byte tuple repeats the topic index on every hit although d_hit_offsets already says which topic a
 // position belongs to.  The compact formats write only what is new per hit (SURVEY.md §8(b)'s SoA result):
@@ -808,10 +814,13 @@ __global__ __launch_bounds__(kThreads) void expand_kernel(const SubEntry* __rest
 #define RGR_COMPACT_NT 1               // nontemporal stores of the compact formats
 #endif
 #ifndef RGR_COMPACT_TILES
-#define RGR_COMPACT_TILES 1            // consecutive tiles expanded by one block (sweep: profiles/r04*)
+#define RGR_COMPACT_TILES 1            // consecutive tiles expanded by one block, SOA / PACKED (sweep: profiles/r04g_*: 1 is best for 4 B/hit)
+#endif
+#ifndef RGR_IDS24_TILES
+#define RGR_IDS24_TILES 4              // ... IDS24: 4 tiles, software-pipelined: 0.69 vs 0.77 ms per 2^30-hit window (2: 0.75, 8: 0.82)
 #endif
 constexpr int kCompactThreads = RGR_COMPACT_THREADS;
-constexpr int kCompactTilesPerBlock = RGR_COMPACT_TILES;
+constexpr int kCompactTiles = RGR_COMPACT_TILES, kIds24Tiles = RGR_IDS24_TILES;
 constexpr int kCompactGroups = kTile / (kCompactThreads * 4);
 // four 24-bit ids = three words at a 4-byte-aligned address (three dword stores that the backend merges into one dwordx3, as in the
 // tuple kernel)
@@ -838,15 +847,79 @@ template <class T> __device__ __forceinline__ void compact_store(T v, T* p) {
 }
 static_assert(kCompactGroups >= 1 && kCompactGroups * kCompactThreads * 4 == kTile, "compact expansion geometry must cover the tile");
 
-template <int FMT>
+template <int FMT, int kCompactTilesPerBlock>
 __global__ __launch_bounds__(kCompactThreads) void expand_compact_kernel(const SubEntry* __restrict__ subs, ChunkArrays c,
                                                                          uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo,
                                                                          uint64_t hit_hi, const TileRec* __restrict__ tile_first,
                                                                          uint32_t ntiles, uint32_t* __restrict__ out_ids,
-                                                                         uint8_t* __restrict__ out_qos) {
+                                                                         uint8_t* __restrict__ out_qos, const uint32_t* __restrict__ packed) {
     __shared__ int32_t s_off[kTile + 2];
     __shared__ uint32_t s_src[kTile + 2];
+    // PACKED / IDS24 with the table's packed side array: 4 bytes read per hit instead of an 8-byte entry (block-uniform choice)
+    const bool use_packed = (FMT == kFmtPacked || FMT == kFmtIds24) && packed != nullptr;
+    typedef uint32_t pk4 __attribute__((ext_vector_type(4)));
+    typedef pk4 pk4u __attribute__((aligned(4)));                        // runs start at any entry: 4-byte aligned
+    // Several tiles per block, software-pipelined (RGR_COMPACT_TILES > 1, packed reads): the single-run tiles of the block have ALL
+    // their records read, then ALL their entry loads issued, then all their stores — the dependent chain record -> entries -> stores is
+    // paid once per block instead of once per tile.  (The kernel is bound by that chain times the resident waves, not by bytes: with
+    // one tile per block PACKED and IDS24 take the same time although one writes 4 and the other 3 bytes per hit, and reading 4 instead
+    // of 8 bytes per hit gained 4 %: profiles/r04f_*.)  Tiles that hold several runs take the general path below, one after the other.
+    uint32_t done_mask = 0;
+    if (kCompactTilesPerBlock > 1 && use_packed) {
+        constexpr int T = kCompactTilesPerBlock;
+        const uint32_t t0 = blockIdx.x * T;
+        uint32_t first[T], nxt[T], src[T];
+#pragma unroll
+        for (int k = 0; k < T; ++k) {
+            const uint32_t t = t0 + k;
+            first[k] = nxt[k] = src[k] = 0;
+            if (t < ntiles) {
+                const TileRec r = tile_first[t];
+                first[k] = r.first; src[k] = r.src;
+                nxt[k] = (t + 1 < ntiles) ? tile_first[t + 1].first + 1 : uint32_t(pair_hi - pair_lo);
+            }
+        }
+        pk4 v[T][kCompactGroups];
+#pragma unroll
+        for (int k = 0; k < T; ++k) {
+            const uint32_t t = t0 + k;
+            if (t >= ntiles || nxt[k] - first[k] != 1) continue;
+            done_mask |= 1u << k;
+            const uint64_t base = hit_lo + uint64_t(t) * kTile;
+            const uint32_t len = (hit_hi - base) < uint64_t(kTile) ? uint32_t(hit_hi - base) : uint32_t(kTile);
+            const uint32_t* prun = packed + src[k];
+#pragma unroll
+            for (int g = 0; g < kCompactGroups; ++g) {
+                const uint32_t p0 = (uint32_t(g) * kCompactThreads + threadIdx.x) * 4;
+                v[k][g] = *reinterpret_cast<const pk4u*>(prun + (p0 + 4 <= len ? p0 : 0u));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < T; ++k) {
+            if (!(done_mask & (1u << k))) continue;
+            const uint32_t t = t0 + k;
+            const uint64_t base = hit_lo + uint64_t(t) * kTile;
+            const uint32_t len = (hit_hi - base) < uint64_t(kTile) ? uint32_t(hit_hi - base) : uint32_t(kTile);
+            const uint32_t* prun = packed + src[k];
+#pragma unroll
+            for (int g = 0; g < kCompactGroups; ++g) {
+                const uint32_t p0 = (uint32_t(g) * kCompactThreads + threadIdx.x) * 4;
+                if (p0 >= len) continue;
+                if (p0 + 4 <= len) {
+                    if (FMT == kFmtIds24) ids24_store(v[k][g].x & 0xFFFFFFu, v[k][g].y & 0xFFFFFFu, v[k][g].z & 0xFFFFFFu, v[k][g].w & 0xFFFFFFu, reinterpret_cast<uint8_t*>(out_ids) + ((base - hit_lo) + p0) * 3);
+                    else compact_store(v[k][g], reinterpret_cast<pk4*>(out_ids + (base - hit_lo) + p0));
+                } else {
+                    for (uint32_t j = 0; p0 + j < len; ++j) {
+                        const uint32_t w1 = prun[p0 + j];
+                        if (FMT == kFmtIds24) { uint8_t* ob = reinterpret_cast<uint8_t*>(out_ids) + ((base - hit_lo) + p0 + j) * 3; ob[0] = uint8_t(w1); ob[1] = uint8_t(w1 >> 8); ob[2] = uint8_t(w1 >> 16); }
+                        else out_ids[(base - hit_lo) + p0 + j] = w1;
+                    }
+                }
+            }
+        }
+    }
   for (uint32_t tile = blockIdx.x * kCompactTilesPerBlock, tile_end = min(ntiles, (blockIdx.x + 1) * kCompactTilesPerBlock); tile < tile_end; ++tile) {
+    if (done_mask & (1u << (tile - blockIdx.x * kCompactTilesPerBlock))) continue;
     const uint64_t base = hit_lo + uint64_t(tile) * kTile;
     const uint32_t len = (hit_hi - base) < uint64_t(kTile) ? uint32_t(hit_hi - base) : uint32_t(kTile);
     const TileRec rec = tile_first[tile];
@@ -858,6 +931,31 @@ __global__ __launch_bounds__(kCompactThreads) void expand_compact_kernel(const S
         // of the tile is subs[rec.src + pos]
         typedef uint32_t v4 __attribute__((ext_vector_type(4)));
         struct __attribute__((packed, aligned(8))) V4 { v4 v; };
+        if (use_packed) {
+            const uint32_t* prun = packed + rec.src;
+            pk4 v[kCompactGroups];
+#pragma unroll
+            for (int g = 0; g < kCompactGroups; ++g) {
+                const uint32_t p0 = (uint32_t(g) * kCompactThreads + threadIdx.x) * 4;
+                v[g] = *reinterpret_cast<const pk4u*>(prun + (p0 + 4 <= len ? p0 : 0u));      // (a partial last group re-reads the tile's head: discarded)
+            }
+#pragma unroll
+            for (int g = 0; g < kCompactGroups; ++g) {
+                const uint32_t p0 = (uint32_t(g) * kCompactThreads + threadIdx.x) * 4;
+                if (p0 >= len) continue;
+                if (p0 + 4 <= len) {
+                    if (FMT == kFmtIds24) ids24_store(v[g].x & 0xFFFFFFu, v[g].y & 0xFFFFFFu, v[g].z & 0xFFFFFFu, v[g].w & 0xFFFFFFu, reinterpret_cast<uint8_t*>(out_ids) + ((base - hit_lo) + p0) * 3);
+                    else compact_store(v[g], reinterpret_cast<pk4*>(out_ids + (base - hit_lo) + p0));
+                } else {
+                    for (uint32_t j = 0; p0 + j < len; ++j) {
+                        const uint32_t w1 = prun[p0 + j];
+                        if (FMT == kFmtIds24) { uint8_t* ob = reinterpret_cast<uint8_t*>(out_ids) + ((base - hit_lo) + p0 + j) * 3; ob[0] = uint8_t(w1); ob[1] = uint8_t(w1 >> 8); ob[2] = uint8_t(w1 >> 16); }
+                        else out_ids[(base - hit_lo) + p0 + j] = w1;
+                    }
+                }
+            }
+            continue;
+        }
         const SubEntry* run = subs + rec.src;
         V4 x[kCompactGroups], y[kCompactGroups];
 #pragma unroll
@@ -920,6 +1018,21 @@ __global__ __launch_bounds__(kCompactThreads) void expand_compact_kernel(const S
         const uint32_t p0 = (uint32_t(g) * kCompactThreads + threadIdx.x) * 4;
         // owner of the group's first position by binary search, of the next three by stepping
         uint32_t i = (np == 1 || p0 >= len) ? 0u : locate_pair([&](uint32_t m) { return s_off[m]; }, np, int32_t(p0));
+        if (use_packed) {       // se[g][j].sub_id carries the packed word, qos_flags stays 0 (the word already holds the qos)
+            if (p0 + 4 <= len && s_off[i + 1] > int32_t(p0 + 3)) {
+                const pk4 v = *reinterpret_cast<const pk4u*>(packed + (uint64_t(s_src[i]) + uint32_t(int32_t(p0) - s_off[i])));
+                se[g][0] = SubEntry{v.x, 0}; se[g][1] = SubEntry{v.y, 0}; se[g][2] = SubEntry{v.z, 0}; se[g][3] = SubEntry{v.w, 0};
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t pos = p0 + j;
+                    const bool live = pos < len;
+                    while (live && s_off[i + 1] <= int32_t(pos)) ++i;
+                    se[g][j] = SubEntry{packed[uint64_t(s_src[i]) + (live ? uint32_t(int32_t(pos) - s_off[i]) : 0u)], 0};
+                }
+            }
+            continue;
+        }
         if (p0 + 4 <= len && s_off[i + 1] > int32_t(p0 + 3)) {
             const SubEntry* p = subs + (uint64_t(s_src[i]) + uint32_t(int32_t(p0) - s_off[i]));
             const V4 x = *reinterpret_cast<const V4*>(p), y = *reinterpret_cast<const V4*>(p + 2);
@@ -944,7 +1057,8 @@ __global__ __launch_bounds__(kCompactThreads) void expand_compact_kernel(const S
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t qf = se[g][j].qos_flags;
-            if (FMT == kFmtPacked) w[j] = se[g][j].sub_id | (qf << 30);
+            if (FMT == kFmtPacked) w[j] = se[g][j].sub_id | (qf << 30);                // (from the packed array: qf == 0, the word is complete)
+            else if (FMT == kFmtIds24) w[j] = se[g][j].sub_id & 0xFFFFFFu;
             else { w[j] = se[g][j].sub_id; q |= ((qf & 3u) | (((qf >> 8) & 0x3Fu) << 2)) << (8 * j); }
         }
         uint32_t* o = out_ids + (base - hit_lo) + p0;
@@ -1327,10 +1441,16 @@ void launch_expand_compact(const TrieView& t, const ChunkArrays& c, uint64_t pai
     if (hit_hi <= hit_lo) return;
     const uint32_t ntiles = uint32_t((hit_hi - hit_lo + kTile - 1) / kTile);
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const uint32_t nblocks = (ntiles + kCompactTilesPerBlock - 1) / kCompactTilesPerBlock;
-    if (format == kFmtIds24) expand_compact_kernel<kFmtIds24><<<nblocks, kCompactThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out_ids, out_qos);
-    else if (format == kFmtPacked) expand_compact_kernel<kFmtPacked><<<nblocks, kCompactThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out_ids, out_qos);
-    else expand_compact_kernel<kFmtSoa><<<nblocks, kCompactThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out_ids, out_qos);
+    static const bool no_packed_reads = std::getenv("RGR_NO_PACKED_READS") != nullptr;       // A/B switch: 8-byte entry loads as in r3
+    const uint32_t* pk = no_packed_reads ? nullptr : t.subs_packed;
+    const uint32_t nb1 = (ntiles + kCompactTiles - 1) / kCompactTiles, nb24 = (ntiles + kIds24Tiles - 1) / kIds24Tiles;
+    if (format == kFmtIds24) expand_compact_kernel<kFmtIds24, kIds24Tiles><<<nb24, kCompactThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out_ids, out_qos, pk);
+    else if (format == kFmtPacked) expand_compact_kernel<kFmtPacked, kCompactTiles><<<nb1, kCompactThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out_ids, out_qos, pk);
+    else expand_compact_kernel<kFmtSoa, kCompactTiles><<<nb1, kCompactThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out_ids, out_qos, nullptr);
+}
+
+void launch_pack_subs(const SubEntry* subs, uint64_t n, uint32_t* packed, void* stream) {
+    if (n) pack_subs_kernel<<<uint32_t((n + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(subs, n, packed);
 }
 
 void launch_pack_runs(const uint32_t* src, const uint32_t* topic, const uint64_t* off, uint64_t n, uint32_t shard, RunDesc* out, void* stream) {

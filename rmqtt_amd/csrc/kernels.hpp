@@ -112,6 +112,9 @@ struct TrieView {
     const FilterDesc* filt;
     const SubEntry* subs;
     const SubAttr* attrs = nullptr;   // parallel to subs (delivery stage), null when no ids were registered
+    // parallel to subs: sub_id | (qos & 3) << 30, 4 bytes per entry (null when some id needs 31+ bits or the array was not built).
+    // What RGR_FORMAT_PACKED writes per hit, and RGR_FORMAT_IDS24 after masking: those expansions read 4 bytes per hit instead of 8.
+    const uint32_t* subs_packed = nullptr;
 };
 
 // ---- RetainTree twin (rmqtt/src/retain.rs): trie of concrete retained topics, nodes numbered
@@ -239,6 +242,8 @@ void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, ui
                    const TileRec* tile_first, Tuple* out, void* stream, const DeliverArgs* deliver = nullptr);
 // compact result formats (rgr_batch_set_format): sub ids (+ a qos byte array) without the topic column
 constexpr int kFmtTuple = 0, kFmtSoa = 1, kFmtPacked = 2, kFmtRuns = 3, kFmtIds24 = 4;     // == RGR_FORMAT_*
+// packed[i] = subs[i].sub_id | (subs[i].qos_flags & 3) << 30 for i in [0, n)
+void launch_pack_subs(const SubEntry* subs, uint64_t n, uint32_t* packed, void* stream);
 void launch_expand_compact(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint64_t hit_hi,
                            const TileRec* tile_first, int format, uint32_t* out_ids, uint8_t* out_qos, void* stream);
 // v5 per-client dedup over a window's candidates (match_core.hpp: LDS tile tables + LDS topic tables): first position per
