@@ -1223,7 +1223,7 @@ def measure_router_e2e(args, quick=False):
             lat = np.zeros(400_000, dtype=np.float32)
             nl = C.c_uint32(0)
             L.hr_e2e_run_async(g, tb.ctypes.data, to.ctypes.data, n_t, subm, outst, workers, passes, 4096, 200, 1.0, res, C.byref(wall), None, 0, None)      # warm
-            L.hr_e2e_run_async(g, tb.ctypes.data, to.ctypes.data, n_t, subm, outst, workers, passes, 4096, 200, 3.0 if quick else (5.0 if cfg == 2 else 4.0), res, C.byref(wall),
+            L.hr_e2e_run_async(g, tb.ctypes.data, to.ctypes.data, n_t, subm, outst, workers, passes, 4096, 200, 4.0 if quick else (5.0 if cfg == 2 else 4.0), res, C.byref(wall),
                                lat.ctypes.data, len(lat), C.byref(nl))
             l = np.sort(lat[:nl.value])
             rec["gpu_async"].append({"submitters": subm, "outstanding": outst, "workers": workers, "passes_in_flight": passes,
@@ -1239,10 +1239,16 @@ def measure_router_e2e(args, quick=False):
         o.add_bulk(W["blob"], W["offs"], W["client"], W["qos"])
         n_c = n_t if cfg == 2 else int(min(n_t, 80_000 * cores / 256 + 2000))
         cb, co = prefix(W, n_c)
-        sec, ost = o.matches_timed(cb, co, cores)
+        # (at config 2 one sweep over the sample takes tens of milliseconds on 256 threads — thread start-up dominates and single sweeps
+        # read anywhere between 2.3 and 9 M/s — so the sample is swept until ~2 s have gone by and the total is what counts)
+        o.matches_timed(cb, co, cores)
+        sec, ost, reps = 0.0, {"hits": 0}, 0
+        while sec < 2.0 and reps < 400:
+            s1, o1 = o.matches_timed(cb, co, cores)
+            sec += s1; ost["hits"] += o1["hits"]; reps += 1
         sec1, ost1 = o.matches_timed(*prefix(W, max(50, n_c // cores * 2)), 1)
-        rec["cpu_reference_port"] = {"value": round(n_c / sec, 1), "rows_per_s": round(ost["hits"] / sec, 1), "threads": cores, "kind": "port",
-                                     "what": "oracle DefaultRouter::_matches-shaped pass (router.rs:174-265), per-hit ref-counted clones", "sample": n_c,
+        rec["cpu_reference_port"] = {"value": round(n_c * reps / sec, 1), "rows_per_s": round(ost["hits"] / sec, 1), "threads": cores, "kind": "port",
+                                     "what": "oracle DefaultRouter::_matches-shaped pass (router.rs:174-265), per-hit ref-counted clones", "sample": n_c, "sweeps": reps,
                                      "single_thread": round(max(50, n_c // cores * 2) / sec1, 1)}
         best = max(x["value"] for x in rec["gpu"] + rec["gpu_async"])
         rec["value"] = best
