@@ -1265,34 +1265,74 @@ def measure_router_e2e(args, quick=False):
 def time_format(args):
     """--time-format NAME: build the config's table, then time `--steps` passes of ONE result format and nothing else (no parity, no
     baseline, no secondaries) — the quick A/B line for kernel geometry sweeps, and the command to put under `rocprofv3 --kernel-trace`
-    (tools/trace_gaps.py turns the trace into busy time, idle gaps and per-kernel totals of a pass)."""
+    (tools/trace_gaps.py turns the trace into busy time, idle gaps and per-kernel totals of a pass).
+    --ab-env NAME=v1,v2,...: the same table and batch timed once per value of an environment switch the library reads per launch
+    (RGR_COMPACT_LP); one JSON line per value, then — unless --no-ab-check — one more line: per-topic digests of a full pass under the
+    FASTEST value against a full pass under the FIRST value (every topic of the batch)."""
     import torch
     from rmqtt_amd import capi
     W = gen_workload(args.config, args.scale)
-    fmt = FORMAT_NAMES.index(args.time_format)
     r = capi.Router(device=0, window_hits=args.window_hits, collect_walk_stats=False)
     build_table(r, W, W["blob"], W["offs"], np.arange(W["n_sub"], dtype=np.uint32), W["qos"])
     batch = r.retain_batch(W["tb"], W["to"]) if W["retain"] else r.batch(W["tb"], W["to"])
-    batch.set_format(fmt)
-    for _ in range(args.warmup):
-        batch.run()
-    r.stats_reset()
-    torch.cuda.synchronize()
-    t = time.time()
-    for _ in range(args.steps):
-        hits, nwin = batch.run()
-    dt = time.time() - t
-    st = r.stats()
-    bph = {"tuple": 12, "soa": 5, "packed": 4, "runs": 0, "ids24": 3}[args.time_format]
-    print(json.dumps({"format": args.time_format, "config": args.config, "scale": args.scale, "window_hits": args.window_hits or "default",
-                      "value": round(W["n_pub"] * args.steps / dt, 1), "ms_per_step": round(dt * 1e3 / args.steps, 3), "windows_per_step": int(nwin),
-                      "hits_per_step": int(hits), "kernel_ms_per_step": {"walk": round(st["walk_ms"] / args.steps, 3), "scan_compact_tiles": round(st["scan_ms"] / args.steps, 3),
-                                                                          "expand": round(st["expand_ms"] / args.steps, 3)},
-                      "expand_avg_launch_ms": round(st["expand_ms"] / max(1, st["expand_launches"]), 4),
-                      "expand_store_GBps": round(hits * args.steps * bph / max(1e-9, st["expand_ms"] / 1e3) / 1e9, 1),
-                      "extra_flags": os.environ.get("RGR_EXTRA_FLAGS", "")}), flush=True)
+    ab_name, ab_values = None, [None]
+    if args.ab_env:
+        ab_name, vals = args.ab_env.split("=", 1)
+        ab_values = vals.split(",")
+    for name in args.time_format.split(","):           # (several formats: one table build for all of them)
+        _time_one_format(args, W, r, batch, name, ab_name, ab_values)
     batch.close(); r.close()
     return 0
+
+
+def _time_one_format(args, W, r, batch, name, ab_name, ab_values):
+    import torch
+    from rmqtt_amd import capi
+    fmt = FORMAT_NAMES.index(name)
+    batch.set_format(fmt)
+    bph = {"tuple": 12, "soa": 5, "packed": 4, "runs": 0, "ids24": 3}[name]
+    results = []
+    for val in ab_values:
+        if ab_name:
+            os.environ[ab_name] = val
+        for _ in range(args.warmup):
+            batch.run()
+        r.stats_reset()
+        torch.cuda.synchronize()
+        t = time.time()
+        for _ in range(args.steps):
+            hits, nwin = batch.run()
+        dt = time.time() - t
+        st = r.stats()
+        rec = {"format": name, "config": args.config, "scale": args.scale, "window_hits": args.window_hits or "default",
+               "value": round(W["n_pub"] * args.steps / dt, 1), "ms_per_step": round(dt * 1e3 / args.steps, 3), "windows_per_step": int(nwin),
+               "hits_per_step": int(hits), "kernel_ms_per_step": {"walk": round(st["walk_ms"] / args.steps, 3), "scan_compact_tiles": round(st["scan_ms"] / args.steps, 3),
+                                                                   "expand": round(st["expand_ms"] / args.steps, 3)},
+               "expand_avg_launch_ms": round(st["expand_ms"] / max(1, st["expand_launches"]), 4),
+               "expand_store_GBps": round(hits * args.steps * bph / max(1e-9, st["expand_ms"] / 1e3) / 1e9, 1),
+               "extra_flags": os.environ.get("RGR_EXTRA_FLAGS", "")}
+        if ab_name:
+            rec["env"] = {ab_name: val}
+        results.append(rec)
+        print(json.dumps(rec), flush=True)
+    if ab_name and len(ab_values) > 1 and not args.no_ab_check and fmt != capi.RGR_FORMAT_RUNS:
+        best = max(range(len(results)), key=lambda i: results[i]["value"])
+        if best == 0:
+            best = max(range(1, len(results)), key=lambda i: results[i]["value"])
+        qos_by_sub = torch.as_tensor(np.ascontiguousarray(W["qos"]).astype(np.int64), device="cuda") if not W["retain"] else None
+        t0 = time.time()
+        os.environ[ab_name] = ab_values[0]
+        d0, ok0, _ = gpu_digests(batch, W["n_pub"], W["retain"], fmt, qos_by_sub=qos_by_sub)
+        os.environ[ab_name] = ab_values[best]
+        d1, ok1, info = gpu_digests(batch, W["n_pub"], W["retain"], fmt, qos_by_sub=qos_by_sub)
+        same = bool((d0 == d1).all())
+        print(json.dumps({"ab_check": {ab_name: [ab_values[0], ab_values[best]]}, "format": name, "topics": int(W["n_pub"]),
+                          "hits": int(d1[:, 0].sum()), "windows": int(info["windows"]), "structure_ok": bool(ok0 and ok1), "digests_equal": same,
+                          "ok": bool(same and ok0 and ok1), "seconds": round(time.time() - t0, 1),
+                          "what": "per-topic digests (hits, sum, order-weighted sum, sum of squares) of every window of a full pass, reduced on the device, under both values"}),
+              flush=True)
+        del d0, d1
+    batch.set_format(capi.RGR_FORMAT_TUPLE)
 
 
 def self_launch(args):
@@ -1353,7 +1393,9 @@ def main():
     ap.add_argument("--e2e-passes", type=int, default=3, help="device passes in flight")
     ap.add_argument("--e2e-sweep", action="store_true", help="--router-e2e: also run a few other (submitters, outstanding, workers, passes) shapes")
     ap.add_argument("--e2e-configs", default="2,3")
-    ap.add_argument("--time-format", choices=list(FORMAT_NAMES), default=None, help="time passes of ONE result format only and exit (sweeps, kernel traces)")
+    ap.add_argument("--time-format", default=None, help="time passes of ONE result format only (or several, comma-separated: one table build) and exit (sweeps, kernel traces): " + ", ".join(FORMAT_NAMES))
+    ap.add_argument("--ab-env", default=None, help="with --time-format: NAME=v1,v2,...: time the same batch once per value of an environment switch the library reads per launch")
+    ap.add_argument("--no-ab-check", action="store_true", help="with --ab-env: skip the full-pass digest comparison of the fastest value against the first")
     ap.add_argument("--router-e2e", action="store_true", help="time Router::matches through the host Router mirror + batcher beside the CPU port (configs 2 and 3)")
     ap.add_argument("--group", type=int, default=0, metavar="SHARDS",
                     help="run the single-process sharded router (rgr_group_*) with this many shards on the visible GPUs instead of the N=1 bench")

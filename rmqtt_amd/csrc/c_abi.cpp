@@ -957,7 +957,7 @@ int32_t rgr_commit(rgr_handle* h) {
                 np->buf.ensure(np->cap * sizeof(SubEntry));
                 if (!subs.empty()) RGR_HIP(hipMemcpy(np->buf.p, subs.data(), subs.size() * sizeof(SubEntry), hipMemcpyHostToDevice));
                 np->used = subs.size();
-                np->packed_buf.ensure(np->cap * 4);
+                np->packed_buf.ensure((np->cap + kPackedPad) * 4);     // (+ padding: expand_compact_lp_kernel reads four entries at a run's start without asking how long the run is)
                 launch_pack_subs(np->buf.as<SubEntry>(), np->used, np->packed_buf.as<uint32_t>(), nullptr);
                 if (want_attrs) {
                     np->attr_buf.ensure(np->cap * sizeof(SubAttr));

@@ -794,296 +794,7 @@ __global__ __launch_bounds__(256) void pack_subs_kernel(const SubEntry* __restri
     if (i < n) { const SubEntry e = subs[i]; packed[i] = e.sub_id | ((e.qos_flags & 3u) << 30); }
 }
 
-// --------------------------------------------------------------------------- expand, compact result formats
-// The 12-byte tuple repeats the topic index on every hit although d_hit_offsets already says which topic a
-// position belongs to.  The compact formats write only what is new per hit (SURVEY.md §8(b)'s SoA result):
-//   kFmtSoa     out_ids[pos] = sub_id (u32), out_qos[pos] = qos | flags << 2 (u8)        5 B/hit
-//   kFmtPacked  out_ids[pos] = sub_id | qos << 30 (u32; sub ids < 2^30)                   4 B/hit
-//   kFmtIds24   bytes [3 pos, 3 pos + 3) = sub_id, little endian (sub ids < 2^24)          3 B/hit: a lane's four positions are 12
-//               contiguous bytes = ONE dwordx3 store, consecutive lanes on consecutive 12-byte groups — the store shape of the
-//               tuple kernel (the qos is table data the consumer indexes by sub id; at config 3 the bytes per hit ARE the pass)
-// Same tiles and staged pair view as expand_kernel, but a lane owns groups of FOUR CONSECUTIVE positions, so a
-// wave stores 1 KiB of sub ids with one dwordx4 per lane (and 256 B of qos bytes with one dword per lane)
-// instead of 768 B of strided 12-byte tuples.  With a third of the store bytes the kernel is no longer bound by
-// the store stream but by the per-tile dependent chain (tile_first -> pair arrays -> LDS -> subscriber loads), so
-// it runs 256-thread blocks (8 per CU) rather than the tuple kernel's 512.
-#ifndef RGR_COMPACT_THREADS
-#define RGR_COMPACT_THREADS 256      // threads per 2048-hit tile: 256 x two groups of four consecutive positions (sweep: profiles/)
-#endif
-#ifndef RGR_COMPACT_NT
-#define RGR_COMPACT_NT 1               // nontemporal stores of the compact formats
-#endif
-#ifndef RGR_COMPACT_TILES
-#define RGR_COMPACT_TILES 1            // consecutive tiles expanded by one block, SOA / PACKED (sweep: profiles/r04g_*: 1 is best for 4 B/hit)
-#endif
-#ifndef RGR_IDS24_TILES
-#define RGR_IDS24_TILES 4              // ... IDS24: 4 tiles, software-pipelined: 0.69 vs 0.77 ms per 2^30-hit window (2: 0.75, 8: 0.82)
-#endif
-constexpr int kCompactThreads = RGR_COMPACT_THREADS;
-constexpr int kCompactTiles = RGR_COMPACT_TILES, kIds24Tiles = RGR_IDS24_TILES;
-constexpr int kCompactGroups = kTile / (kCompactThreads * 4);
-// four 24-bit ids = three words at a 4-byte-aligned address (three dword stores that the backend merges into one dwordx3, as in the
-// tuple kernel)
-// ONE dwordx3 store per group, explicitly: left as three dword stores the backend merged only the first group of a lane and split the
-// second into dword + dwordx2 — store instructions whose lanes do not cover contiguous bytes, the 5.5x-slower shape of DESIGN §10
-// (ids24 ran at 2.6 TB/s instead of the tuple kernel's 5.5: profiles/r04b_sweep_packed_ids24.jsonl).
-typedef uint32_t ids24_v3 __attribute__((ext_vector_type(3)));
-typedef ids24_v3 ids24_v3u __attribute__((aligned(4)));     // the 12-byte groups are only 4-byte aligned
-__device__ __forceinline__ void ids24_store(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint8_t* p) {
-    ids24_v3 t;
-    t.x = a | (b << 24); t.y = (b >> 8) | (c << 16); t.z = (c >> 16) | (d << 8);
-#if RGR_COMPACT_NT
-    __builtin_nontemporal_store(t, reinterpret_cast<ids24_v3u*>(p));
-#else
-    *reinterpret_cast<ids24_v3u*>(p) = t;
-#endif
-}
-template <class T> __device__ __forceinline__ void compact_store(T v, T* p) {
-#if RGR_COMPACT_NT
-    __builtin_nontemporal_store(v, p);
-#else
-    *p = v;
-#endif
-}
-static_assert(kCompactGroups >= 1 && kCompactGroups * kCompactThreads * 4 == kTile, "compact expansion geometry must cover the tile");
-
-template <int FMT, int kCompactTilesPerBlock>
-__global__ __launch_bounds__(kCompactThreads) void expand_compact_kernel(const SubEntry* __restrict__ subs, ChunkArrays c,
-                                                                         uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo,
-                                                                         uint64_t hit_hi, const TileRec* __restrict__ tile_first,
-                                                                         uint32_t ntiles, uint32_t* __restrict__ out_ids,
-                                                                         uint8_t* __restrict__ out_qos, const uint32_t* __restrict__ packed) {
-    __shared__ int32_t s_off[kTile + 2];
-    __shared__ uint32_t s_src[kTile + 2];
-    // PACKED / IDS24 with the table's packed side array: 4 bytes read per hit instead of an 8-byte entry (block-uniform choice)
-    const bool use_packed = (FMT == kFmtPacked || FMT == kFmtIds24) && packed != nullptr;
-    typedef uint32_t pk4 __attribute__((ext_vector_type(4)));
-    typedef pk4 pk4u __attribute__((aligned(4)));                        // runs start at any entry: 4-byte aligned
-    // Several tiles per block, software-pipelined (RGR_COMPACT_TILES > 1, packed reads): the single-run tiles of the block have ALL
-    // their records read, then ALL their entry loads issued, then all their stores — the dependent chain record -> entries -> stores is
-    // paid once per block instead of once per tile.  (The kernel is bound by that chain times the resident waves, not by bytes: with
-    // one tile per block PACKED and IDS24 take the same time although one writes 4 and the other 3 bytes per hit, and reading 4 instead
-    // of 8 bytes per hit gained 4 %: profiles/r04f_*.)  Tiles that hold several runs take the general path below, one after the other.
-    uint32_t done_mask = 0;
-    if (kCompactTilesPerBlock > 1 && use_packed) {
-        constexpr int T = kCompactTilesPerBlock;
-        const uint32_t t0 = blockIdx.x * T;
-        uint32_t first[T], nxt[T], src[T];
-#pragma unroll
-        for (int k = 0; k < T; ++k) {
-            const uint32_t t = t0 + k;
-            first[k] = nxt[k] = src[k] = 0;
-            if (t < ntiles) {
-                const TileRec r = tile_first[t];
-                first[k] = r.first; src[k] = r.src;
-                nxt[k] = (t + 1 < ntiles) ? tile_first[t + 1].first + 1 : uint32_t(pair_hi - pair_lo);
-            }
-        }
-        pk4 v[T][kCompactGroups];
-#pragma unroll
-        for (int k = 0; k < T; ++k) {
-            const uint32_t t = t0 + k;
-            if (t >= ntiles || nxt[k] - first[k] != 1) continue;
-            done_mask |= 1u << k;
-            const uint64_t base = hit_lo + uint64_t(t) * kTile;
-            const uint32_t len = (hit_hi - base) < uint64_t(kTile) ? uint32_t(hit_hi - base) : uint32_t(kTile);
-            const uint32_t* prun = packed + src[k];
-#pragma unroll
-            for (int g = 0; g < kCompactGroups; ++g) {
-                const uint32_t p0 = (uint32_t(g) * kCompactThreads + threadIdx.x) * 4;
-                v[k][g] = *reinterpret_cast<const pk4u*>(prun + (p0 + 4 <= len ? p0 : 0u));
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < T; ++k) {
-            if (!(done_mask & (1u << k))) continue;
-            const uint32_t t = t0 + k;
-            const uint64_t base = hit_lo + uint64_t(t) * kTile;
-            const uint32_t len = (hit_hi - base) < uint64_t(kTile) ? uint32_t(hit_hi - base) : uint32_t(kTile);
-            const uint32_t* prun = packed + src[k];
-#pragma unroll
-            for (int g = 0; g < kCompactGroups; ++g) {
-                const uint32_t p0 = (uint32_t(g) * kCompactThreads + threadIdx.x) * 4;
-                if (p0 >= len) continue;
-                if (p0 + 4 <= len) {
-                    if (FMT == kFmtIds24) ids24_store(v[k][g].x & 0xFFFFFFu, v[k][g].y & 0xFFFFFFu, v[k][g].z & 0xFFFFFFu, v[k][g].w & 0xFFFFFFu, reinterpret_cast<uint8_t*>(out_ids) + ((base - hit_lo) + p0) * 3);
-                    else compact_store(v[k][g], reinterpret_cast<pk4*>(out_ids + (base - hit_lo) + p0));
-                } else {
-                    for (uint32_t j = 0; p0 + j < len; ++j) {
-                        const uint32_t w1 = prun[p0 + j];
-                        if (FMT == kFmtIds24) { uint8_t* ob = reinterpret_cast<uint8_t*>(out_ids) + ((base - hit_lo) + p0 + j) * 3; ob[0] = uint8_t(w1); ob[1] = uint8_t(w1 >> 8); ob[2] = uint8_t(w1 >> 16); }
-                        else out_ids[(base - hit_lo) + p0 + j] = w1;
-                    }
-                }
-            }
-        }
-    }
-  for (uint32_t tile = blockIdx.x * kCompactTilesPerBlock, tile_end = min(ntiles, (blockIdx.x + 1) * kCompactTilesPerBlock); tile < tile_end; ++tile) {
-    if (done_mask & (1u << (tile - blockIdx.x * kCompactTilesPerBlock))) continue;
-    const uint64_t base = hit_lo + uint64_t(tile) * kTile;
-    const uint32_t len = (hit_hi - base) < uint64_t(kTile) ? uint32_t(hit_hi - base) : uint32_t(kTile);
-    const TileRec rec = tile_first[tile];
-    const uint64_t a = pair_lo + rec.first;
-    const uint64_t b = (tile + 1 < ntiles) ? pair_lo + tile_first[tile + 1].first + 1 : pair_hi;
-    const uint32_t np = uint32_t(b - a);
-    if (np == 1) {
-        // the tile lies inside ONE run (the common case at high fan-out): no pair arrays, no LDS, no barrier — position pos
-        // of the tile is subs[rec.src + pos]
-        typedef uint32_t v4 __attribute__((ext_vector_type(4)));
-        struct __attribute__((packed, aligned(8))) V4 { v4 v; };
-        if (use_packed) {
-            const uint32_t* prun = packed + rec.src;
-            pk4 v[kCompactGroups];
-#pragma unroll
-            for (int g = 0; g < kCompactGroups; ++g) {
-                const uint32_t p0 = (uint32_t(g) * kCompactThreads + threadIdx.x) * 4;
-                v[g] = *reinterpret_cast<const pk4u*>(prun + (p0 + 4 <= len ? p0 : 0u));      // (a partial last group re-reads the tile's head: discarded)
-            }
-#pragma unroll
-            for (int g = 0; g < kCompactGroups; ++g) {
-                const uint32_t p0 = (uint32_t(g) * kCompactThreads + threadIdx.x) * 4;
-                if (p0 >= len) continue;
-                if (p0 + 4 <= len) {
-                    if (FMT == kFmtIds24) ids24_store(v[g].x & 0xFFFFFFu, v[g].y & 0xFFFFFFu, v[g].z & 0xFFFFFFu, v[g].w & 0xFFFFFFu, reinterpret_cast<uint8_t*>(out_ids) + ((base - hit_lo) + p0) * 3);
-                    else compact_store(v[g], reinterpret_cast<pk4*>(out_ids + (base - hit_lo) + p0));
-                } else {
-                    for (uint32_t j = 0; p0 + j < len; ++j) {
-                        const uint32_t w1 = prun[p0 + j];
-                        if (FMT == kFmtIds24) { uint8_t* ob = reinterpret_cast<uint8_t*>(out_ids) + ((base - hit_lo) + p0 + j) * 3; ob[0] = uint8_t(w1); ob[1] = uint8_t(w1 >> 8); ob[2] = uint8_t(w1 >> 16); }
-                        else out_ids[(base - hit_lo) + p0 + j] = w1;
-                    }
-                }
-            }
-            continue;
-        }
-        const SubEntry* run = subs + rec.src;
-        V4 x[kCompactGroups], y[kCompactGroups];
-#pragma unroll
-        for (int g = 0; g < kCompactGroups; ++g) {
-            const uint32_t p0 = (uint32_t(g) * kCompactThreads + threadIdx.x) * 4;
-            const uint32_t q0 = p0 + 4 <= len ? p0 : 0u;                  // (a partial last group re-reads the tile's head: discarded)
-            x[g] = *reinterpret_cast<const V4*>(run + q0); y[g] = *reinterpret_cast<const V4*>(run + q0 + 2);
-        }
-#pragma unroll
-        for (int g = 0; g < kCompactGroups; ++g) {
-            const uint32_t p0 = (uint32_t(g) * kCompactThreads + threadIdx.x) * 4;
-            if (p0 >= len) continue;
-            uint32_t* o = out_ids + (base - hit_lo) + p0;
-            if (p0 + 4 <= len) {
-                v4 v; uint32_t q;
-                if (FMT == kFmtIds24) {
-                    // a | b << 24,  b >> 8 | c << 16,  c >> 16 | d << 8: four 24-bit ids in three words
-                    const uint32_t a = x[g].v.x, b3 = x[g].v.z, c3 = y[g].v.x, d3 = y[g].v.z;
-                    ids24_store(a, b3, c3, d3, reinterpret_cast<uint8_t*>(out_ids) + ((base - hit_lo) + p0) * 3);
-                    continue;
-                }
-                if (FMT == kFmtPacked) { v.x = x[g].v.x | (x[g].v.y << 30); v.y = x[g].v.z | (x[g].v.w << 30); v.z = y[g].v.x | (y[g].v.y << 30); v.w = y[g].v.z | (y[g].v.w << 30); q = 0; }
-                else {
-                    v.x = x[g].v.x; v.y = x[g].v.z; v.z = y[g].v.x; v.w = y[g].v.z;
-                    auto qb = [](uint32_t qf) { return (qf & 3u) | (((qf >> 8) & 0x3Fu) << 2); };
-                    q = qb(x[g].v.y) | (qb(x[g].v.w) << 8) | (qb(y[g].v.y) << 16) | (qb(y[g].v.w) << 24);
-                }
-                compact_store(v, reinterpret_cast<v4*>(o));
-                if (FMT == kFmtSoa) compact_store(q, reinterpret_cast<uint32_t*>(out_qos + (base - hit_lo) + p0));
-            } else {
-                for (uint32_t j = 0; p0 + j < len; ++j) {
-                    const SubEntry se1 = run[p0 + j];
-                    if (FMT == kFmtIds24) {
-                        uint8_t* ob = reinterpret_cast<uint8_t*>(out_ids) + ((base - hit_lo) + p0 + j) * 3;
-                        ob[0] = uint8_t(se1.sub_id); ob[1] = uint8_t(se1.sub_id >> 8); ob[2] = uint8_t(se1.sub_id >> 16);
-                        continue;
-                    }
-                    o[j] = FMT == kFmtPacked ? (se1.sub_id | (se1.qos_flags << 30)) : se1.sub_id;
-                    if (FMT == kFmtSoa) out_qos[(base - hit_lo) + p0 + j] = uint8_t((se1.qos_flags & 3u) | (((se1.qos_flags >> 8) & 0x3Fu) << 2));
-                }
-            }
-        }
-        continue;
-    }
-    if (kCompactTilesPerBlock > 1) __syncthreads();                     // the previous tile's readers of s_off / s_src are done
-    for (uint32_t i = threadIdx.x; i < np; i += kCompactThreads) {
-        uint32_t topic_unused;
-        tile_pair_view(c, a, i, base, s_off[i], s_src[i], topic_unused);
-    }
-    if (threadIdx.x == 0) s_off[np] = 0x7FFFFFFF;                       // sentinel: no pair starts after the last one
-    __syncthreads();
-    // a lane owns kCompactGroups groups of four consecutive positions; all its subscriber loads are issued before
-    // its first store.  Runs are long, so the four positions of a group almost always lie in ONE run: then the four
-    // 8-byte entries are 32 contiguous bytes and are fetched with two dwordx4 loads instead of four dwordx2.
-    typedef uint32_t v4 __attribute__((ext_vector_type(4)));
-    struct __attribute__((packed, aligned(8))) V4 { v4 v; };            // subs[] entries are 8-byte aligned, not 16
-    SubEntry se[kCompactGroups][4];
-#pragma unroll
-    for (int g = 0; g < kCompactGroups; ++g) {
-        const uint32_t p0 = (uint32_t(g) * kCompactThreads + threadIdx.x) * 4;
-        // owner of the group's first position by binary search, of the next three by stepping
-        uint32_t i = (np == 1 || p0 >= len) ? 0u : locate_pair([&](uint32_t m) { return s_off[m]; }, np, int32_t(p0));
-        if (use_packed) {       // se[g][j].sub_id carries the packed word, qos_flags stays 0 (the word already holds the qos)
-            if (p0 + 4 <= len && s_off[i + 1] > int32_t(p0 + 3)) {
-                const pk4 v = *reinterpret_cast<const pk4u*>(packed + (uint64_t(s_src[i]) + uint32_t(int32_t(p0) - s_off[i])));
-                se[g][0] = SubEntry{v.x, 0}; se[g][1] = SubEntry{v.y, 0}; se[g][2] = SubEntry{v.z, 0}; se[g][3] = SubEntry{v.w, 0};
-            } else {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t pos = p0 + j;
-                    const bool live = pos < len;
-                    while (live && s_off[i + 1] <= int32_t(pos)) ++i;
-                    se[g][j] = SubEntry{packed[uint64_t(s_src[i]) + (live ? uint32_t(int32_t(pos) - s_off[i]) : 0u)], 0};
-                }
-            }
-            continue;
-        }
-        if (p0 + 4 <= len && s_off[i + 1] > int32_t(p0 + 3)) {
-            const SubEntry* p = subs + (uint64_t(s_src[i]) + uint32_t(int32_t(p0) - s_off[i]));
-            const V4 x = *reinterpret_cast<const V4*>(p), y = *reinterpret_cast<const V4*>(p + 2);
-            se[g][0] = SubEntry{x.v.x, x.v.y}; se[g][1] = SubEntry{x.v.z, x.v.w};
-            se[g][2] = SubEntry{y.v.x, y.v.y}; se[g][3] = SubEntry{y.v.z, y.v.w};
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t pos = p0 + j;
-                const bool live = pos < len;
-                while (live && s_off[i + 1] <= int32_t(pos)) ++i;
-                se[g][j] = subs[uint64_t(s_src[i]) + (live ? uint32_t(int32_t(pos) - s_off[i]) : 0u)];
-            }
-        }
-    }
-#pragma unroll
-    for (int g = 0; g < kCompactGroups; ++g) {
-        const uint32_t p0 = (uint32_t(g) * kCompactThreads + threadIdx.x) * 4;
-        if (p0 >= len) continue;
-        uint32_t w[4];
-        uint32_t q = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t qf = se[g][j].qos_flags;
-            if (FMT == kFmtPacked) w[j] = se[g][j].sub_id | (qf << 30);                // (from the packed array: qf == 0, the word is complete)
-            else if (FMT == kFmtIds24) w[j] = se[g][j].sub_id & 0xFFFFFFu;
-            else { w[j] = se[g][j].sub_id; q |= ((qf & 3u) | (((qf >> 8) & 0x3Fu) << 2)) << (8 * j); }
-        }
-        uint32_t* o = out_ids + (base - hit_lo) + p0;
-        if (FMT == kFmtIds24) {
-            uint8_t* ob = reinterpret_cast<uint8_t*>(out_ids) + ((base - hit_lo) + p0) * 3;
-            if (p0 + 4 <= len) {
-                ids24_store(w[0], w[1], w[2], w[3], ob);
-            } else {
-                for (uint32_t j = 0; p0 + j < len; ++j) { ob[3 * j] = uint8_t(w[j]); ob[3 * j + 1] = uint8_t(w[j] >> 8); ob[3 * j + 2] = uint8_t(w[j] >> 16); }
-            }
-            continue;
-        }
-        if (p0 + 4 <= len) {
-            v4 v; v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
-            compact_store(v, reinterpret_cast<v4*>(o));
-            if (FMT == kFmtSoa) compact_store(q, reinterpret_cast<uint32_t*>(out_qos + (base - hit_lo) + p0));
-        } else {
-            for (uint32_t j = 0; p0 + j < len; ++j) {
-                o[j] = w[j];
-                if (FMT == kFmtSoa) out_qos[(base - hit_lo) + p0 + j] = uint8_t(q >> (8 * j));
-            }
-        }
-    }
-  }
-}
+#include "expand_compact.inc"
 
 // --------------------------------------------------------------------------- v5 per-client dedup
 // types.rs:524-539: of a topic's v5 hits for one client the FIRST (in filter order = position order) keeps filter +
@@ -1436,6 +1147,17 @@ void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, ui
     else expand_kernel<false, kExpandThreads, kExpandPerThread><<<ntiles, kExpandThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, DeliverArgs{});
 }
 
+// tiles per block of the lane-held compact expansion; 0 = the tile-per-block kernel.  Default: RGR_COMPACT_LP_DEFAULT (build), overridden by
+// the environment variable RGR_COMPACT_LP (1, 2 or 4; 0 switches it off)
+#ifndef RGR_COMPACT_LP_DEFAULT
+#define RGR_COMPACT_LP_DEFAULT 0
+#endif
+int compact_lp_tiles() {
+    const char* e = std::getenv("RGR_COMPACT_LP");
+    const int v = e ? std::atoi(e) : RGR_COMPACT_LP_DEFAULT;
+    return v <= 0 ? 0 : v == 1 ? 1 : v < 4 ? 2 : 4;
+}
+
 void launch_expand_compact(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint64_t hit_hi,
                            const TileRec* tile_first, int format, uint32_t* out_ids, uint8_t* out_qos, void* stream) {
     if (hit_hi <= hit_lo) return;
@@ -1444,6 +1166,17 @@ void launch_expand_compact(const TrieView& t, const ChunkArrays& c, uint64_t pai
     static const bool no_packed_reads = std::getenv("RGR_NO_PACKED_READS") != nullptr;       // A/B switch: 8-byte entry loads as in r3
     const uint32_t* pk = no_packed_reads ? nullptr : t.subs_packed;
     const uint32_t nb1 = (ntiles + kCompactTiles - 1) / kCompactTiles, nb24 = (ntiles + kIds24Tiles - 1) / kIds24Tiles;
+    // RGR_COMPACT_LP=T (A/B switch, read per launch): PACKED / IDS24 through expand_compact_lp_kernel with T tiles per block (pairs held in
+    // lanes, expand_compact.inc) instead of the tile-per-block kernel; needs the packed side array
+    const int lp = compact_lp_tiles();
+    if (lp && pk && (format == kFmtIds24 || format == kFmtPacked)) {
+        const uint32_t nb = (ntiles + uint32_t(lp) - 1) / uint32_t(lp);
+#define RGR_LP_LAUNCH(F, TT) expand_compact_lp_kernel<F, TT><<<nb, kCompactThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out_ids, out_qos, pk)
+        if (format == kFmtIds24) { if (lp == 1) RGR_LP_LAUNCH(kFmtIds24, 1); else if (lp == 2) RGR_LP_LAUNCH(kFmtIds24, 2); else RGR_LP_LAUNCH(kFmtIds24, 4); }
+        else { if (lp == 1) RGR_LP_LAUNCH(kFmtPacked, 1); else if (lp == 2) RGR_LP_LAUNCH(kFmtPacked, 2); else RGR_LP_LAUNCH(kFmtPacked, 4); }
+#undef RGR_LP_LAUNCH
+        return;
+    }
     if (format == kFmtIds24) expand_compact_kernel<kFmtIds24, kIds24Tiles><<<nb24, kCompactThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out_ids, out_qos, pk);
     else if (format == kFmtPacked) expand_compact_kernel<kFmtPacked, kCompactTiles><<<nb1, kCompactThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out_ids, out_qos, pk);
     else expand_compact_kernel<kFmtSoa, kCompactTiles><<<nb1, kCompactThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out_ids, out_qos, nullptr);

@@ -243,6 +243,7 @@ void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, ui
 // compact result formats (rgr_batch_set_format): sub ids (+ a qos byte array) without the topic column
 constexpr int kFmtTuple = 0, kFmtSoa = 1, kFmtPacked = 2, kFmtRuns = 3, kFmtIds24 = 4;     // == RGR_FORMAT_*
 // packed[i] = subs[i].sub_id | (subs[i].qos_flags & 3) << 30 for i in [0, n)
+constexpr uint32_t kPackedPad = 16;      // entries allocated past the end of a packed side array (never read for their value)
 void launch_pack_subs(const SubEntry* subs, uint64_t n, uint32_t* packed, void* stream);
 void launch_expand_compact(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint64_t hit_hi,
                            const TileRec* tile_first, int format, uint32_t* out_ids, uint8_t* out_qos, void* stream);

@@ -1,0 +1,76 @@
+"""ctypes binding of tests/hipsim — TEST INFRASTRUCTURE ONLY (kernel SOURCES of rmqtt_amd/csrc run on the host, one OS thread per GPU
+thread; see hipsim.hpp).  Needs the ROCm clang (host compilation of HIP-style vector types and builtins)."""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+_LIB = None
+SUB_DTYPE = np.dtype([("sub_id", np.uint32), ("qos_flags", np.uint32)])
+FMT_SOA, FMT_PACKED, FMT_IDS24 = 1, 2, 4
+
+
+def clang():
+    for c in ("/opt/rocm/lib/llvm/bin/clang++", shutil.which("amdclang++"), shutil.which("clang++")):
+        if c and os.path.exists(c):
+            return c
+    return None
+
+
+def build(extra=(), name="libhipsim_expand.so"):
+    so = os.path.join(HERE, name)
+    csrc = os.path.join(ROOT, "rmqtt_amd", "csrc")
+    deps = [os.path.join(HERE, f) for f in ("sim_expand_compact.cpp", "hipsim.hpp")] + \
+           [os.path.join(csrc, f) for f in ("expand_compact.inc", "match_core.hpp", "kernels.hpp")]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        cc = clang()
+        if cc is None:
+            raise RuntimeError("hipsim needs clang++ (vector extensions of the kernel sources)")
+        tmp = f"{so}.tmp{os.getpid()}"
+        subprocess.check_call([cc, "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", *extra, "-I", os.path.join(ROOT, "include"), "-I", csrc,
+                               os.path.join(HERE, "sim_expand_compact.cpp"), "-o", tmp])
+        os.replace(tmp, so)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        vp, i32, u64 = C.c_void_p, C.c_int32, C.c_uint64
+        L.sim_expand_compact.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, u64, u64, vp, vp]
+        L.sim_expand_compact.restype = i32
+        _LIB = L
+    return _LIB
+
+
+def expand_compact(variant, fmt, tiles_per_block, subs, pair_src, pair_off, pair_lo, pair_hi, use_packed=True, guard=4096):
+    """Run one window through an expansion kernel of expand_compact.inc.  Returns (ids bytes or u32 array, qos array or None), and checks
+    that nothing outside the window's output was written."""
+    subs = np.ascontiguousarray(subs, dtype=SUB_DTYPE)
+    pair_src = np.ascontiguousarray(pair_src, dtype=np.uint32)
+    pair_off = np.ascontiguousarray(pair_off, dtype=np.uint64)
+    pair_topic = np.zeros(len(pair_src), dtype=np.uint32)
+    # what pack_subs_kernel leaves (+ the padding the lane-held kernel's dummy loads rely on)
+    packed = np.zeros(len(subs) + 16, dtype=np.uint32)
+    packed[:len(subs)] = subs["sub_id"] | ((subs["qos_flags"] & 3) << 30)
+    hits = int(pair_off[pair_hi] - pair_off[pair_lo])
+    bph = 3 if fmt == FMT_IDS24 else 4
+    out = np.full(hits * bph + 2 * guard, 0xA5, dtype=np.uint8)
+    qos = np.full(hits + 2 * guard, 0xA5, dtype=np.uint8)
+    rc = lib().sim_expand_compact(variant, fmt, tiles_per_block, subs.ctypes.data, packed.ctypes.data if use_packed else None,
+                                  pair_src.ctypes.data, pair_topic.ctypes.data, pair_off.ctypes.data, pair_lo, pair_hi,
+                                  out.ctypes.data + guard, qos.ctypes.data + guard)
+    if rc != 0:
+        raise ValueError(f"sim_expand_compact: unknown combination variant={variant} fmt={fmt} T={tiles_per_block}")
+    assert (out[:guard] == 0xA5).all() and (out[guard + hits * bph:] == 0xA5).all(), "write outside the window's ids"
+    body = out[guard:guard + hits * bph]
+    if fmt == FMT_SOA:
+        assert (qos[:guard] == 0xA5).all() and (qos[guard + hits:] == 0xA5).all(), "write outside the window's qos bytes"
+        return body.view(np.uint32).copy(), qos[guard:guard + hits].copy()
+    assert (qos == 0xA5).all(), "qos bytes written by a format that has none"
+    return (body.copy() if fmt == FMT_IDS24 else body.view(np.uint32).copy()), None

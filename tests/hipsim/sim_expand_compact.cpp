@@ -1,0 +1,64 @@
+// TEST INFRASTRUCTURE ONLY — the compact expansions of rmqtt_amd/csrc/expand_compact.inc run on the host (hipsim.hpp).
+//
+// One window: the pair arrays (source, chunk-local output offset) of its pairs, the tile records tiles_kernel leaves (the same
+// tiles_pair_rec, match_core.hpp), then one of the expansion kernels block by block.  tests/test_hipsim_expand.py compares the
+// result with a numpy expansion of the same pair list.
+#include "hipsim.hpp"
+
+#include "kernels.hpp"
+#include "match_core.hpp"
+
+namespace rgr {
+namespace {
+constexpr int kTile = 2048;
+#define RGR_COMPACT_NT 0            // plain stores: a nontemporal vector store has alignment rules of its own on x86
+#include "expand_compact.inc"
+}  // namespace
+}  // namespace rgr
+
+using namespace rgr;
+
+extern "C" {
+
+// variant 0: expand_compact_kernel (one tile per block, or the round-4 pipelined form for tiles_per_block > 1)
+// variant 1: expand_compact_lp_kernel (pairs held in lanes)
+// fmt: 1 SOA, 2 PACKED, 4 IDS24.  packed may be null (8-byte entry reads; variant 0 only).  Returns 0, or -1 for an unknown combination.
+int32_t sim_expand_compact(int32_t variant, int32_t fmt, int32_t tiles_per_block, const SubEntry* subs, const uint32_t* packed,
+                           const uint32_t* pair_src, const uint32_t* pair_topic, const uint64_t* pair_off, uint64_t pair_lo, uint64_t pair_hi,
+                           uint32_t* out_ids, uint8_t* out_qos) {
+    ChunkArrays c{};
+    c.pair_src = const_cast<uint32_t*>(pair_src);
+    c.pair_topic = const_cast<uint32_t*>(pair_topic);
+    c.pair_off = const_cast<uint64_t*>(pair_off);
+    const uint64_t hit_lo = pair_off[pair_lo], hit_hi = pair_off[pair_hi];
+    if (hit_hi <= hit_lo) return 0;
+    const uint32_t ntiles = uint32_t((hit_hi - hit_lo + kTile - 1) / kTile);
+    std::vector<TileRec> rec(ntiles);
+    for (uint64_t p = pair_lo; p < pair_hi; ++p) tiles_pair_rec(c, p, pair_lo, hit_lo, kTile, rec.data());
+    const TileRec* tf = rec.data();
+    const uint32_t T = uint32_t(tiles_per_block), nb = (ntiles + T - 1) / T;
+#define SIM_RUN(K, F, TT) hipsim::run(nb, kCompactThreads, [&] { K<F, TT>(subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tf, ntiles, out_ids, out_qos, packed); })
+    if (variant == 0) {
+        if (fmt == kFmtSoa && T == 1) SIM_RUN(expand_compact_kernel, kFmtSoa, 1);
+        else if (fmt == kFmtPacked && T == 1) SIM_RUN(expand_compact_kernel, kFmtPacked, 1);
+        else if (fmt == kFmtPacked && T == 4) SIM_RUN(expand_compact_kernel, kFmtPacked, 4);
+        else if (fmt == kFmtIds24 && T == 1) SIM_RUN(expand_compact_kernel, kFmtIds24, 1);
+        else if (fmt == kFmtIds24 && T == 4) SIM_RUN(expand_compact_kernel, kFmtIds24, 4);
+        else return -1;
+    } else if (variant == 1) {
+        if (!packed) return -1;
+        if (fmt == kFmtPacked && T == 1) SIM_RUN(expand_compact_lp_kernel, kFmtPacked, 1);
+        else if (fmt == kFmtPacked && T == 2) SIM_RUN(expand_compact_lp_kernel, kFmtPacked, 2);
+        else if (fmt == kFmtPacked && T == 4) SIM_RUN(expand_compact_lp_kernel, kFmtPacked, 4);
+        else if (fmt == kFmtIds24 && T == 1) SIM_RUN(expand_compact_lp_kernel, kFmtIds24, 1);
+        else if (fmt == kFmtIds24 && T == 2) SIM_RUN(expand_compact_lp_kernel, kFmtIds24, 2);
+        else if (fmt == kFmtIds24 && T == 4) SIM_RUN(expand_compact_lp_kernel, kFmtIds24, 4);
+        else return -1;
+    } else {
+        return -1;
+    }
+#undef SIM_RUN
+    return 0;
+}
+
+}  // extern "C"

@@ -234,3 +234,54 @@ def test_chunk_prefetch_and_arena_regrow(prefetch, monkeypatch):
     h2, w2 = b.run()                                  # ... and start over
     assert h1 == h2 == len(ref["tuples"]) and w1 == w2 and r.stats()["overflow_topics"] > 0
     b.close(); r.close()
+
+
+def _hot_and_cold_table(r, rng):
+    """Filters whose subscriber runs are long (thousands: tiles inside ONE run), medium, short and single — and topics that match
+    several of each, so that an expansion tile holds anything from one run to dozens of them."""
+    sid = 0
+
+    def sub(filt, n):
+        nonlocal sid
+        fid = r.filter_add(filt)
+        for _ in range(n):
+            r.sub_add(fid, sid, int(rng.integers(0, 3)))
+            sid += 1
+
+    sub("a/#", 9000); sub("+/#", 2371); sub("a/b/#", 5000); sub("a/+/c", 2048); sub("a/b/c", 700); sub("+/b/c", 64); sub("+/+/c", 5)
+    for i in range(40):
+        sub(f"a/b/c/x{i}/#", int(rng.integers(1, 4)))
+    sub("a/b/+", 1); sub("#", 3); sub("a/+/+", 2); sub("+/b/+", 1)
+    topics = []
+    for i in range(60):
+        topics += ["a/b/c", "a/b/c/x%d/y" % (i % 40), "a/q/c", "z/b/c", "a/b", "q", "a/b/c/x%d" % ((7 * i) % 40)]
+    return topics
+
+
+@pytest.mark.parametrize("window_hits", [50_000, 1 << 20, 8 * 2048])
+def test_lane_held_expansion_equals_tile_kernel(window_hits, monkeypatch):
+    """expand_compact_lp_kernel (RGR_COMPACT_LP = tiles per block; pairs held in lanes, expand_compact.inc) against the tile-per-block
+    kernel and the tuples, PACKED and IDS24, on a table with long, medium, short and single-subscriber runs (tiles with one run, a
+    handful, and more than a wave holds: the staged fallback).  The host twin of this test is tests/test_hipsim_expand.py."""
+    rng = np.random.default_rng(11)
+    r = capi.Router(device=0, window_hits=window_hits)
+    topics = _hot_and_cold_table(r, rng)
+    r.commit()
+    tb, to = capi.pack(topics)
+    batch = r.batch(tb, to)
+    monkeypatch.setenv("RGR_COMPACT_LP", "0")
+    ref = windows(batch, capi.RGR_FORMAT_TUPLE)
+    base = {f: windows(batch, f) for f in (capi.RGR_FORMAT_PACKED, capi.RGR_FORMAT_IDS24)}
+    assert sum(len(w[3]) for w in ref) > 1_000_000
+    for lp in ("1", "2", "4"):
+        monkeypatch.setenv("RGR_COMPACT_LP", lp)
+        for f in (capi.RGR_FORMAT_PACKED, capi.RGR_FORMAT_IDS24):
+            got = windows(batch, f)
+            assert len(got) == len(ref)
+            for (tb0, te0, o0, t, _), (tb1, te1, o1, a, _), (_, _, _, a0, _) in zip(ref, got, base[f]):
+                assert (tb0, te0) == (tb1, te1) and np.array_equal(o0, o1)
+                want = t["sub_id"] | ((t["qos_flags"] & 3) << 30) if f == capi.RGR_FORMAT_PACKED else t["sub_id"]
+                assert np.array_equal(a0, want), (lp, f, "tile-per-block kernel")
+                bad = np.flatnonzero(a != want)
+                assert bad.size == 0, (lp, f, bad[:8], len(a))
+    batch.close(); r.close()
