@@ -1266,23 +1266,33 @@ def time_format(args):
     """--time-format NAME: build the config's table, then time `--steps` passes of ONE result format and nothing else (no parity, no
     baseline, no secondaries) — the quick A/B line for kernel geometry sweeps, and the command to put under `rocprofv3 --kernel-trace`
     (tools/trace_gaps.py turns the trace into busy time, idle gaps and per-kernel totals of a pass).
-    --ab-env NAME=v1,v2,...: the same table and batch timed once per value of an environment switch the library reads per launch
-    (RGR_COMPACT_LP); one JSON line per value, then — unless --no-ab-check — one more line: per-topic digests of a full pass under the
-    FASTEST value against a full pass under the FIRST value (every topic of the batch)."""
+    --ab-env A=1,A=2,A=2+B=7: the same table and batch timed once per variant of environment switches the library reads per launch
+    (RGR_COMPACT_LP, RGR_WINDOW_HITS); one JSON line per variant, then — unless --no-ab-check — one more line: per-topic digests of a
+    full pass under the FASTEST variant against a full pass under the FIRST (every topic of the batch)."""
     import torch
     from rmqtt_amd import capi
     W = gen_workload(args.config, args.scale)
     r = capi.Router(device=0, window_hits=args.window_hits, collect_walk_stats=False)
     build_table(r, W, W["blob"], W["offs"], np.arange(W["n_sub"], dtype=np.uint32), W["qos"])
     batch = r.retain_batch(W["tb"], W["to"]) if W["retain"] else r.batch(W["tb"], W["to"])
+    # --ab-env "A=1,A=2,A=2+B=7": one variant per comma, a variant is one or more NAME=value joined by '+'; names a variant does not
+    # set are unset for it
     ab_name, ab_values = None, [None]
     if args.ab_env:
-        ab_name, vals = args.ab_env.split("=", 1)
-        ab_values = vals.split(",")
+        ab_values = [dict(kv.split("=", 1) for kv in item.split("+")) for item in args.ab_env.split(",")]
+        ab_name = sorted({k for v in ab_values for k in v})
     for name in args.time_format.split(","):           # (several formats: one table build for all of them)
         _time_one_format(args, W, r, batch, name, ab_name, ab_values)
     batch.close(); r.close()
     return 0
+
+
+def _set_variant(names, variant):
+    """Environment of one --ab-env variant: its assignments, every other name of the sweep unset."""
+    for k in names or ():
+        os.environ.pop(k, None)
+    for k, v in (variant or {}).items():
+        os.environ[k] = v
 
 
 def _time_one_format(args, W, r, batch, name, ab_name, ab_values):
@@ -1293,8 +1303,7 @@ def _time_one_format(args, W, r, batch, name, ab_name, ab_values):
     bph = {"tuple": 12, "soa": 5, "packed": 4, "runs": 0, "ids24": 3}[name]
     results = []
     for val in ab_values:
-        if ab_name:
-            os.environ[ab_name] = val
+        _set_variant(ab_name, val)
         for _ in range(args.warmup):
             batch.run()
         r.stats_reset()
@@ -1312,7 +1321,7 @@ def _time_one_format(args, W, r, batch, name, ab_name, ab_values):
                "expand_store_GBps": round(hits * args.steps * bph / max(1e-9, st["expand_ms"] / 1e3) / 1e9, 1),
                "extra_flags": os.environ.get("RGR_EXTRA_FLAGS", "")}
         if ab_name:
-            rec["env"] = {ab_name: val}
+            rec["env"] = val
         results.append(rec)
         print(json.dumps(rec), flush=True)
     if ab_name and len(ab_values) > 1 and not args.no_ab_check and fmt != capi.RGR_FORMAT_RUNS:
@@ -1321,12 +1330,13 @@ def _time_one_format(args, W, r, batch, name, ab_name, ab_values):
             best = max(range(1, len(results)), key=lambda i: results[i]["value"])
         qos_by_sub = torch.as_tensor(np.ascontiguousarray(W["qos"]).astype(np.int64), device="cuda") if not W["retain"] else None
         t0 = time.time()
-        os.environ[ab_name] = ab_values[0]
+        _set_variant(ab_name, ab_values[0])
         d0, ok0, _ = gpu_digests(batch, W["n_pub"], W["retain"], fmt, qos_by_sub=qos_by_sub)
-        os.environ[ab_name] = ab_values[best]
+        _set_variant(ab_name, ab_values[best])
         d1, ok1, info = gpu_digests(batch, W["n_pub"], W["retain"], fmt, qos_by_sub=qos_by_sub)
         same = bool((d0 == d1).all())
-        print(json.dumps({"ab_check": {ab_name: [ab_values[0], ab_values[best]]}, "format": name, "topics": int(W["n_pub"]),
+        _set_variant(ab_name, None)
+        print(json.dumps({"ab_check": [ab_values[0], ab_values[best]], "format": name, "topics": int(W["n_pub"]),
                           "hits": int(d1[:, 0].sum()), "windows": int(info["windows"]), "structure_ok": bool(ok0 and ok1), "digests_equal": same,
                           "ok": bool(same and ok0 and ok1), "seconds": round(time.time() - t0, 1),
                           "what": "per-topic digests (hits, sum, order-weighted sum, sum of squares) of every window of a full pass, reduced on the device, under both values"}),
@@ -1394,7 +1404,7 @@ def main():
     ap.add_argument("--e2e-sweep", action="store_true", help="--router-e2e: also run a few other (submitters, outstanding, workers, passes) shapes")
     ap.add_argument("--e2e-configs", default="2,3")
     ap.add_argument("--time-format", default=None, help="time passes of ONE result format only (or several, comma-separated: one table build) and exit (sweeps, kernel traces): " + ", ".join(FORMAT_NAMES))
-    ap.add_argument("--ab-env", default=None, help="with --time-format: NAME=v1,v2,...: time the same batch once per value of an environment switch the library reads per launch")
+    ap.add_argument("--ab-env", default=None, help="with --time-format: 'A=1,A=2,A=2+B=7': time the same batch once per variant (comma-separated; '+' joins assignments) of environment switches the library reads per launch")
     ap.add_argument("--no-ab-check", action="store_true", help="with --ab-env: skip the full-pass digest comparison of the fastest value against the first")
     ap.add_argument("--router-e2e", action="store_true", help="time Router::matches through the host Router mirror + batcher beside the CPU port (configs 2 and 3)")
     ap.add_argument("--group", type=int, default=0, metavar="SHARDS",

@@ -199,7 +199,10 @@ struct rgr_batch {
     // (profiles/r04a_packed_vs_window_size.jsonl).  Passes that stage windows in pinned host memory, and the delivery stage (whose
     // candidate lists are sized per window), keep 2^28 unless the caller configured something smaller.
     uint64_t window_cap() const {
-        const uint64_t c = h->cfg.window_hits;
+        uint64_t c = h->cfg.window_hits;
+        // RGR_WINDOW_HITS (A/B switch of bench.py --ab-env, read per window): hits per window of a device-resident pass whose handle took the default
+        if (!h->cfg_window_explicit && !host_out && !deliver)
+            if (const char* e = std::getenv("RGR_WINDOW_HITS")) { const unsigned long long v = std::strtoull(e, nullptr, 10); if (v >= 4096 && v <= (1ull << 32) - 4096) c = v; }
         return (host_out || deliver) ? std::min<uint64_t>(c, h->cfg_window_explicit ? c : (1ull << 28)) : c;
     }
     // streamed passes (rgr_batch_run_to_host, rgr_match_batch): copy stream + per-slot events, created once

@@ -5,7 +5,7 @@
 // block are 256 OS threads, __syncthreads() is a pthread barrier, __shared__ is a function-local static, cross-lane reads of a wave
 // (RGR_LANES_PUT / RGR_LANES_GET in the kernel source: ds_bpermute on the device) go through a per-wave mirror.  What this checks on a
 // machine without a GPU: the index arithmetic, the control flow around partial / multi-run / straddling cases, the LDS protocol (a
-// missing barrier is a data race ThreadSanitizer reports: tools/hipsim_tsan.sh).  It is NOT a CPU fallback: the product library neither
+// missing barrier is a data race ThreadSanitizer reports: tools/hipsim_sanitizers.sh).  It is NOT a CPU fallback: the product library neither
 // contains nor links any of this, and nothing here is timed.
 #pragma once
 #include <pthread.h>

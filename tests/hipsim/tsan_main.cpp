@@ -1,6 +1,8 @@
-// TEST INFRASTRUCTURE ONLY — the hipsim expansion under ThreadSanitizer (tools/hipsim_tsan.sh): a missing __syncthreads() around the
-// LDS-staged pair views, or a lane mirror overwritten while a slower lane still reads it, is a data race between the OS threads that
-// stand for GPU threads.  Also compares every output with a scalar expansion.
+// TEST INFRASTRUCTURE ONLY — the hipsim expansion under ThreadSanitizer and AddressSanitizer (tools/hipsim_sanitizers.sh).  TSAN: a
+// missing __syncthreads() around the LDS-staged pair views, or a lane mirror overwritten while a slower lane still reads it, is a data
+// race between the OS threads that stand for GPU threads.  ASAN: every array has its exact product size (the packed side array with
+// its kPackedPad entries, the output without any slack, the last run ending where the pool ends), so a load or store the device would
+// do outside an allocation is reported here.  Also compares every output with a scalar expansion.
 #include "sim_expand_compact.cpp"
 
 #include <cstdio>
@@ -10,7 +12,7 @@ int main() {
     std::mt19937_64 rng(20260921);
     const size_t pool = 1 << 16;
     std::vector<SubEntry> subs(pool);
-    std::vector<uint32_t> packed(pool + 16, 0);
+    std::vector<uint32_t> packed(pool + kPackedPad, 0);
     for (size_t i = 0; i < pool; ++i) { subs[i] = SubEntry{uint32_t(rng() & 0xFFFFFF), uint32_t(rng() % 3) | uint32_t((rng() & 63) << 8)}; packed[i] = subs[i].sub_id | ((subs[i].qos_flags & 3u) << 30); }
     // run lengths: long runs, bursts of singletons (more than 64 pairs in a tile), short runs (straddling groups)
     std::vector<uint32_t> len;
@@ -22,6 +24,7 @@ int main() {
     std::vector<uint64_t> off(len.size() + 1);
     off[0] = first;
     for (size_t p = 0; p < len.size(); ++p) { src[p] = uint32_t(rng() % (pool - len[p])); off[p + 1] = off[p] + len[p]; }
+    src.back() = uint32_t(pool - len.back());            // the last run ends where the pool ends: a read past a partial last tile's run leaves the allocation (ASAN)
     const uint64_t hits = off.back() - first;
     std::vector<uint32_t> want(hits);
     { uint64_t k = 0; for (size_t p = 0; p < len.size(); ++p) for (uint32_t j = 0; j < len[p]; ++j) want[k++] = packed[src[p] + j]; }
@@ -29,7 +32,7 @@ int main() {
     struct K { int variant, fmt, tiles; bool pk; } ks[] = {{0, 1, 1, false}, {0, 2, 1, true}, {0, 4, 4, true}, {0, 2, 4, true}, {1, 2, 1, true}, {1, 2, 2, true},
                                                           {1, 2, 4, true}, {1, 4, 1, true}, {1, 4, 2, true}, {1, 4, 4, true}};
     for (const K& k : ks) {
-        std::vector<uint8_t> out(hits * 4 + 64, 0), qos(hits + 64, 0);
+        std::vector<uint8_t> out(hits * (k.fmt == 4 ? 3 : 4), 0), qos(hits, 0);      // exact sizes: a store past the window is an ASAN report
         const int rc = sim_expand_compact(k.variant, k.fmt, k.tiles, subs.data(), k.pk ? packed.data() : nullptr, src.data(), topic.data(), off.data(), 0,
                                           len.size(), reinterpret_cast<uint32_t*>(out.data()), qos.data());
         uint64_t diff = 0;
