@@ -1147,14 +1147,21 @@ void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, ui
     else expand_kernel<false, kExpandThreads, kExpandPerThread><<<ntiles, kExpandThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, DeliverArgs{});
 }
 
-// tiles per block of the lane-held compact expansion; 0 = the tile-per-block kernel.  Default: RGR_COMPACT_LP_DEFAULT (build), overridden by
-// the environment variable RGR_COMPACT_LP (1, 2 or 4; 0 switches it off)
-#ifndef RGR_COMPACT_LP_DEFAULT
-#define RGR_COMPACT_LP_DEFAULT 0
+// Tiles per block of the lane-held compact expansion (expand_compact_lp_kernel); 0 = the tile-per-block kernel.  Measured at config 3
+// (profiles/r04n_ab_lane_held_ids24_packed.jsonl, one table, full passes): IDS24 98.97 M matches/s with the tile-per-block kernel,
+// 105.6 / 104.1 / 105.0 M with 1 / 2 / 4 tiles per block lane-held (all 148 150 579 430 hits digested equal); PACKED 89.4 M against
+// 85.4 / 83.0 / 81.0 M — its 16-byte stores already run at the store stream's rate, the search through ds_bpermute only adds to it.
+// So IDS24 takes the lane-held kernel with one tile per block, PACKED stays.  RGR_COMPACT_LP (0, 1, 2, 4; read per launch) overrides
+// both: the A/B switch of bench.py --ab-env and of the tests.
+#ifndef RGR_COMPACT_LP_IDS24
+#define RGR_COMPACT_LP_IDS24 1
 #endif
-int compact_lp_tiles() {
+#ifndef RGR_COMPACT_LP_PACKED
+#define RGR_COMPACT_LP_PACKED 0
+#endif
+int compact_lp_tiles(int format) {
     const char* e = std::getenv("RGR_COMPACT_LP");
-    const int v = e ? std::atoi(e) : RGR_COMPACT_LP_DEFAULT;
+    const int v = e ? std::atoi(e) : format == kFmtIds24 ? RGR_COMPACT_LP_IDS24 : RGR_COMPACT_LP_PACKED;
     return v <= 0 ? 0 : v == 1 ? 1 : v < 4 ? 2 : 4;
 }
 
@@ -1168,7 +1175,7 @@ void launch_expand_compact(const TrieView& t, const ChunkArrays& c, uint64_t pai
     const uint32_t nb1 = (ntiles + kCompactTiles - 1) / kCompactTiles, nb24 = (ntiles + kIds24Tiles - 1) / kIds24Tiles;
     // RGR_COMPACT_LP=T (A/B switch, read per launch): PACKED / IDS24 through expand_compact_lp_kernel with T tiles per block (pairs held in
     // lanes, expand_compact.inc) instead of the tile-per-block kernel; needs the packed side array
-    const int lp = compact_lp_tiles();
+    const int lp = compact_lp_tiles(format);
     if (lp && pk && (format == kFmtIds24 || format == kFmtPacked)) {
         const uint32_t nb = (ntiles + uint32_t(lp) - 1) / uint32_t(lp);
 #define RGR_LP_LAUNCH(F, TT) expand_compact_lp_kernel<F, TT><<<nb, kCompactThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out_ids, out_qos, pk)
