@@ -7,6 +7,7 @@
 // oracle without a GPU.  It is NOT a CPU fallback: the product library neither contains
 // nor links this file, and rgr_create fails without a HIP device.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -153,6 +154,17 @@ int32_t run_pipeline(Emu* e, uint32_t n, const std::vector<uint64_t>& tok_off, c
         std::vector<uint8_t> pair_qr(P + 1, 0xEE);
         if (pub) { ca.pub = pub; ca.pair_qr = pair_qr.data(); }
         for (uint32_t t = 0; t < cn; ++t) compact_topic(tv, ca, begin, t);
+        // EMU_DUMP_PAIRS=<file> (tests): the chunk's dense pair arrays as the expansion kernels see them — tests/hipsim runs the kernel
+        // sources over them (u64 P, then P u32 sources, then P + 1 u64 offsets; one record per chunk, appended)
+        if (const char* dump = std::getenv("EMU_DUMP_PAIRS")) {
+            if (FILE* f = std::fopen(dump, "ab")) {
+                std::fwrite(&P, 8, 1, f);
+                std::fwrite(pair_src.data(), 4, P, f);
+                pair_off[P] = H;
+                std::fwrite(pair_off.data(), 8, P + 1, f);
+                std::fclose(f);
+            }
+        }
         e->pairs += P;
         for (uint32_t t = 0; t < cn; ++t) {
             for (uint32_t j = 0; j < pair_cnt[t]; ++j) pair_fids.push_back(pair_fid(ca, t, pair_cnt[t], j));
