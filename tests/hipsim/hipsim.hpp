@@ -9,6 +9,7 @@
 // contains nor links any of this, and nothing here is timed.
 #pragma once
 #include <pthread.h>
+#include <time.h>
 
 #include <cstdint>
 #include <cstdlib>
@@ -29,26 +30,59 @@ namespace hipsim {
 struct Dim { unsigned x; };
 constexpr int kWave = 64;
 constexpr int kMaxWaves = 16;
+// A barrier that gives up: a cross-lane read executed by only some lanes of a wave (the hardware would hand the readers ZERO for
+// every source lane that is switched off — ds_bpermute honours EXEC on both sides) shows up here as lanes that never arrive.  After
+// kGiveUpMs the wait fails, the run is flagged (hipsim::diverged()) and every later barrier lets its callers through.
+constexpr int kGiveUpMs = 4000;
+inline bool g_diverged = false;
+struct TimedBarrier {
+    pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+    pthread_cond_t cv = PTHREAD_COND_INITIALIZER;
+    unsigned n = 0, waiting = 0, generation = 0;
+    void init(unsigned count) { n = count; waiting = 0; generation = 0; }
+    void wait() {
+        pthread_mutex_lock(&mu);
+        if (g_diverged) { pthread_mutex_unlock(&mu); return; }
+        const unsigned gen = generation;
+        if (++waiting == n) {
+            waiting = 0; ++generation;
+            pthread_cond_broadcast(&cv);
+        } else {
+            timespec ts;
+            clock_gettime(CLOCK_REALTIME, &ts);
+            ts.tv_sec += kGiveUpMs / 1000; ts.tv_nsec += long(kGiveUpMs % 1000) * 1000000L;
+            if (ts.tv_nsec >= 1000000000L) { ts.tv_sec++; ts.tv_nsec -= 1000000000L; }
+            while (gen == generation && !g_diverged)
+                if (pthread_cond_timedwait(&cv, &mu, &ts) != 0 && gen == generation) { g_diverged = true; pthread_cond_broadcast(&cv); }
+        }
+        pthread_mutex_unlock(&mu);
+    }
+};
 struct Wave {
-    pthread_barrier_t bar;
+    TimedBarrier bar;
     uint32_t mirror[4][kWave];
 };
 struct BlockCtx {
-    pthread_barrier_t bar;
+    TimedBarrier bar;
     Wave waves[kMaxWaves];
 };
 inline BlockCtx* g_block = nullptr;
 inline thread_local unsigned t_tid = 0;
-inline void syncthreads() { pthread_barrier_wait(&g_block->bar); }
-inline void wave_sync() { pthread_barrier_wait(&g_block->waves[t_tid / kWave].bar); }
+inline bool diverged() { return g_diverged; }
+inline void syncthreads() { g_block->bar.wait(); }
+inline void wave_sync() { g_block->waves[t_tid / kWave].bar.wait(); }
 // lane's value published to the wave: convergent (every lane of the wave), like the instruction it stands for
 inline void lanes_put(int slot, uint32_t v) {
     Wave& w = g_block->waves[t_tid / kWave];
     w.mirror[slot][t_tid % kWave] = v;
-    pthread_barrier_wait(&w.bar);
+    w.bar.wait();
 }
-inline uint32_t lanes_get(int slot, uint32_t lane) { return g_block->waves[t_tid / kWave].mirror[slot][lane % kWave]; }
-
+// lane `lane`'s published value.  EVERY lane of the wave must execute the read (the barrier checks it): see TimedBarrier
+inline uint32_t lanes_get(int slot, uint32_t lane) {
+    Wave& w = g_block->waves[t_tid / kWave];
+    w.bar.wait();
+    return w.mirror[slot][lane % kWave];
+}
 }  // namespace hipsim
 
 inline thread_local hipsim::Dim threadIdx{0}, blockIdx{0};
@@ -58,31 +92,32 @@ inline uint32_t min(uint32_t a, uint32_t b) { return a < b ? a : b; }
 inline uint32_t max(uint32_t a, uint32_t b) { return a > b ? a : b; }
 
 namespace hipsim {
-template <class F> void run(unsigned nblocks, unsigned nthreads, F kernel) {
-    BlockCtx ctx;
-    pthread_barrier_init(&ctx.bar, nullptr, nthreads);
+template <class F> bool run(unsigned nblocks, unsigned nthreads, F kernel) {
+    BlockCtx* ctx = new BlockCtx();
+    ctx->bar.init(nthreads);
     const unsigned nw = (nthreads + kWave - 1) / kWave;
     for (unsigned w = 0; w < nw; ++w) {
         const unsigned lanes = (w + 1) * kWave <= nthreads ? kWave : nthreads - w * kWave;
-        pthread_barrier_init(&ctx.waves[w].bar, nullptr, lanes);
-        std::memset(ctx.waves[w].mirror, 0, sizeof(ctx.waves[w].mirror));
+        ctx->waves[w].bar.init(lanes);
+        std::memset(ctx->waves[w].mirror, 0, sizeof(ctx->waves[w].mirror));
     }
-    g_block = &ctx;
+    g_diverged = false;
+    g_block = ctx;
     std::vector<std::thread> th;
     th.reserve(nthreads);
     for (unsigned t = 0; t < nthreads; ++t)
         th.emplace_back([&, t] {
             t_tid = t;
             threadIdx.x = t;
-            for (unsigned b = 0; b < nblocks; ++b) {
+            for (unsigned b = 0; b < nblocks && !g_diverged; ++b) {
                 blockIdx.x = b;
                 kernel();
-                pthread_barrier_wait(&ctx.bar);          // the next block reuses the statics that stand for LDS
+                ctx->bar.wait();          // the next block reuses the statics that stand for LDS
             }
         });
     for (auto& t : th) t.join();
-    for (unsigned w = 0; w < nw; ++w) pthread_barrier_destroy(&ctx.waves[w].bar);
-    pthread_barrier_destroy(&ctx.bar);
     g_block = nullptr;
+    delete ctx;
+    return !g_diverged;            // false: some lanes skipped a convergent operation (barrier, cross-lane read)
 }
 }  // namespace hipsim

@@ -65,6 +65,9 @@ def expand_compact(variant, fmt, tiles_per_block, subs, pair_src, pair_off, pair
     rc = lib().sim_expand_compact(variant, fmt, tiles_per_block, subs.ctypes.data, packed.ctypes.data if use_packed else None,
                                   pair_src.ctypes.data, pair_topic.ctypes.data, pair_off.ctypes.data, pair_lo, pair_hi,
                                   out.ctypes.data + guard, qos.ctypes.data + guard)
+    if rc == -2:
+        raise AssertionError("hipsim: threads of a wave / block diverged around a convergent operation (__syncthreads, cross-lane read): "
+                             "on the device a cross-lane read returns 0 for lanes that are switched off")
     if rc != 0:
         raise ValueError(f"sim_expand_compact: unknown combination variant={variant} fmt={fmt} T={tiles_per_block}")
     assert (out[:guard] == 0xA5).all() and (out[guard + hits * bph:] == 0xA5).all(), "write outside the window's ids"

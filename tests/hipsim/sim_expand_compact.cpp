@@ -22,7 +22,7 @@ extern "C" {
 
 // variant 0: expand_compact_kernel (one tile per block, or the round-4 pipelined form for tiles_per_block > 1)
 // variant 1: expand_compact_lp_kernel (pairs held in lanes)
-// fmt: 1 SOA, 2 PACKED, 4 IDS24.  packed may be null (8-byte entry reads; variant 0 only).  Returns 0, or -1 for an unknown combination.
+// fmt: 1 SOA, 2 PACKED, 4 IDS24.  packed may be null (8-byte entry reads; variant 0 only).  Returns 0, -1 for an unknown combination, -2 when threads diverged around a barrier or a cross-lane read.
 int32_t sim_expand_compact(int32_t variant, int32_t fmt, int32_t tiles_per_block, const SubEntry* subs, const uint32_t* packed,
                            const uint32_t* pair_src, const uint32_t* pair_topic, const uint64_t* pair_off, uint64_t pair_lo, uint64_t pair_hi,
                            uint32_t* out_ids, uint8_t* out_qos) {
@@ -37,7 +37,8 @@ int32_t sim_expand_compact(int32_t variant, int32_t fmt, int32_t tiles_per_block
     for (uint64_t p = pair_lo; p < pair_hi; ++p) tiles_pair_rec(c, p, pair_lo, hit_lo, kTile, rec.data());
     const TileRec* tf = rec.data();
     const uint32_t T = uint32_t(tiles_per_block), nb = (ntiles + T - 1) / T;
-#define SIM_RUN(K, F, TT) hipsim::run(nb, kCompactThreads, [&] { K<F, TT>(subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tf, ntiles, out_ids, out_qos, packed); })
+    bool converged = true;
+#define SIM_RUN(K, F, TT) converged = hipsim::run(nb, kCompactThreads, [&] { K<F, TT>(subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tf, ntiles, out_ids, out_qos, packed); })
     if (variant == 0) {
         if (fmt == kFmtSoa && T == 1) SIM_RUN(expand_compact_kernel, kFmtSoa, 1);
         else if (fmt == kFmtPacked && T == 1) SIM_RUN(expand_compact_kernel, kFmtPacked, 1);
@@ -58,7 +59,7 @@ int32_t sim_expand_compact(int32_t variant, int32_t fmt, int32_t tiles_per_block
         return -1;
     }
 #undef SIM_RUN
-    return 0;
+    return converged ? 0 : -2;         // -2: lanes of a wave (or threads of a block) took different paths around a convergent operation
 }
 
 }  // extern "C"

@@ -60,6 +60,9 @@ CASES = {
     "singletons": lambda rng: make_case(rng, [1] * (TILE + 900) + [3000] + [1, 2, 1, 3] * 40, pair_lo=1),                 # > 64 pairs per tile: staged fallback
     "short_runs": lambda rng: make_case(rng, [int(x) for x in rng.integers(1, 7, size=3000)], tail_pairs=1),              # every group straddles
     "mid_fanout": lambda rng: make_case(rng, [int(x) for x in rng.integers(30, 200, size=200)], pair_lo=7, first_off=999),  # 20-60 pairs per tile
+    # 62-64 pairs in a tile, singletons at its end: the lanes that own the last pairs look past lane 63 for the runs after theirs
+    "lane_list_full": lambda rng: make_case(rng, [700] + [30] * 20 + [1] * 41 + [707] + [900] + [25] * 40 + [1] * 23 + [125] + [640] + [40] * 31 + [1] * 31 + [137] + [5000],
+                                            pair_lo=2, first_off=77),
     "tiny_window": lambda rng: make_case(rng, [3], pair_lo=1, tail_pairs=1),
     "exact_tiles": lambda rng: make_case(rng, [TILE - 1, 1, TILE - 2, 2, 1, TILE - 1, 4 * TILE]),
 }
