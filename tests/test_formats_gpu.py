@@ -252,9 +252,27 @@ def _hot_and_cold_table(r, rng):
     for i in range(40):
         sub(f"a/b/c/x{i}/#", int(rng.integers(1, 4)))
     sub("a/b/+", 1); sub("#", 3); sub("a/+/+", 2); sub("+/b/+", 1)
+    # Families of filters with one or two subscribers that all match ONE topic (every literal / '+' pattern of its levels below the
+    # first, every '#' ending): 56 .. 62 tiny runs in a row (plus the '+/#' and '#' runs and the neighbours' ends), cut by the tile
+    # boundaries at a different place in every repetition — pair lists of every length around the 64 a wave holds (62..64 is where
+    # a lane looks past lane 63 for the runs after its own: profiles/r04p_*), and one family of 95 for the staged fallback
+    def family(first, names, count):
+        pats = []
+        for mask in range(1 << len(names)):                       # exact depth: the first level literal, the others literal or '+'
+            pats.append("/".join([first] + [names[j] if (mask >> j) & 1 else "+" for j in range(len(names))]))
+        for k in range(0, len(names) + 1):                        # '#' endings below a prefix of k further levels
+            for mask in range(1 << k):
+                pats.append("/".join([first] + [names[j] if (mask >> j) & 1 else "+" for j in range(k)] + ["#"]))
+        for i, f in enumerate(pats[:count]):
+            sub(f, 1 + i % 2)
+        return "/".join([first] + names)
+
+    fam = [family("u%d" % j, ["b%d" % j, "c", "d", "e", "f"], 56 + j) for j in range(7)] + [family("m", ["n", "o", "p", "q", "r"], 95)]
     topics = []
     for i in range(60):
-        topics += ["a/b/c", "a/b/c/x%d/y" % (i % 40), "a/q/c", "z/b/c", "a/b", "q", "a/b/c/x%d" % ((7 * i) % 40)]
+        topics += ["a/b/c", "a/b/c/x%d/y" % (i % 40), "a/q/c", "z/b/c", "a/b", "q", "a/b/c/x%d" % ((7 * i) % 40), fam[i % 8]]
+        if i % 3 == 0:
+            topics += [fam[(i + 3) % 8], "z/b/c", fam[(i + 5) % 8], "q", fam[(i + 6) % 8]]
     return topics
 
 
