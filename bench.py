@@ -946,6 +946,10 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
                     "ms_per_step": round(dt * 1e3 / steps, 3), "hits_per_s": round(h2 * steps / dt, 1),
                     "expand_avg_launch_ms": round(s2["expand_ms"] / max(1, s2["expand_launches"]), 4),
                     "expand_store_GBps": round(h2 * steps * bph / max(1e-9, s2["expand_ms"] / 1e3) / 1e9, 1),
+                    # the two halves of north_star in one record: matches/s (value) and the share of the 8 TB/s HBM peak the format's
+                    # own stores reach — inside its expansion kernel, and over the whole pass (preparation, launches and gaps included)
+                    "frac_of_hbm_peak_stores_kernel": round(h2 * steps * bph / max(1e-9, s2["expand_ms"] / 1e3) / 8.0e12, 3),
+                    "frac_of_hbm_peak_stores_whole_pass": round(h2 * steps * bph / dt / 8.0e12, 3),
                     "speedup_vs_tuple": round((my_topics * steps / dt) / value, 3)})
             except capi.RgrError as e:
                 rec["compact_formats"].append({"format": name, "error": str(e)})
