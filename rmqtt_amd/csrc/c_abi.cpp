@@ -203,6 +203,8 @@ struct rgr_batch {
         // RGR_WINDOW_HITS (A/B switch of bench.py --ab-env, read per window): hits per window of a device-resident pass whose handle took the default
         if (!h->cfg_window_explicit && !host_out && !deliver)
             if (const char* e = std::getenv("RGR_WINDOW_HITS")) { const unsigned long long v = std::strtoull(e, nullptr, 10); if (v >= 4096 && v <= (1ull << 32) - 4096) c = v; }
+        if (deliver && !host_out && !h->cfg_window_explicit)      // RGR_DELIVER_WINDOW_HITS (A/B switch): device-resident delivery passes, default 2^28
+            if (const char* e = std::getenv("RGR_DELIVER_WINDOW_HITS")) { const unsigned long long v = std::strtoull(e, nullptr, 10); if (v >= 4096 && v <= (1ull << 32) - 4096) return v; }
         return (host_out || deliver) ? std::min<uint64_t>(c, h->cfg_window_explicit ? c : (1ull << 28)) : c;
     }
     // streamed passes (rgr_batch_run_to_host, rgr_match_batch): copy stream + per-slot events, created once

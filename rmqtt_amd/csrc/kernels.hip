@@ -796,139 +796,7 @@ __global__ __launch_bounds__(256) void pack_subs_kernel(const SubEntry* __restri
 
 #include "expand_compact.inc"
 
-// --------------------------------------------------------------------------- v5 per-client dedup
-// types.rs:524-539: of a topic's v5 hits for one client the FIRST (in filter order = position order) keeps filter +
-// options, later ones only contribute their subscription identifier.  Min-position-per-(topic, client), resolved in LDS
-// (match_core.hpp): dedup_tile_kernel for topics inside one tile, dedup_classify_kernel + dedup_topic_kernel for topics
-// that span tiles.  No global table, no device-scope atomics per candidate, no host synchronisation per window (r2: one
-// atomicCAS + atomicMin through the fabric per candidate and a stream sync for the table size — 2.14 ms per 2^28-hit
-// window at config 3 with 10 % v5, profiles/r02h_bench_config3_deliver_v5frac0.1_512x4.json).
-static_assert(kTile <= (1 << kDedupIdxBits), "tile table packs position-in-tile and candidate index into 11 bits each");
-constexpr int kDedupTileSlots = 2 * kTile;            // u32 slots: 16 KiB
-constexpr int kDedupTopicSlots = 4096;                // u64 slots: 32 KiB -> 4 blocks of 512 threads per CU
-constexpr int kDedupTopicCap = kDedupTopicSlots / 2;  // candidates per part
-#ifndef RGR_DEDUP_TOPIC_THREADS
-#define RGR_DEDUP_TOPIC_THREADS 512
-#endif
-constexpr int kDedupTopicThreads = RGR_DEDUP_TOPIC_THREADS;
-
-__global__ __launch_bounds__(256) void dedup_tile_kernel(const Cand* __restrict__ cand, const uint32_t* __restrict__ tile_ncand,
-                                                         const uint32_t* __restrict__ tile_trange, uint32_t ntiles,
-                                                         const uint64_t* __restrict__ hit_off, uint64_t hit_lo, uint32_t nt, Tuple* __restrict__ tuples,
-                                                         unsigned long long* __restrict__ stat) {
-    __shared__ uint32_t s_topic[kTile], s_client[kTile], s_pos[kTile];
-    __shared__ uint32_t s_tab[kDedupTileSlots];
-    unsigned long long seen = 0;                                  // candidates of the tiles this block visited (rgr_stats)
-    auto h_off = [&](uint32_t t) { return uint32_t(hit_off[t] - hit_lo); };      // (windows of the delivery stage hold < 2^32 hits)
-    // a fixed grid strides over the tiles: all but a few are skipped after one 4-byte read (bit 31 of tile_ncand, set by the
-    // expansion, says whether a whole topic with two or more candidates lies inside the tile)
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const uint32_t raw = tile_ncand[tile];
-        const uint32_t n = raw & 0x7FFFFFFFu;
-        seen += n;
-        if (!(raw >> 31)) continue;
-        const Cand* list = cand + uint64_t(tile) * kTile;
-        const uint64_t lo = uint64_t(tile) * kTile, hi = lo + kTile;
-        __syncthreads();                                          // the previous tile's lookups are done
-        for (uint32_t i = threadIdx.x; i < uint32_t(kDedupTileSlots); i += 256) s_tab[i] = kNone;
-        // the expansion left the window topics of the tile's first and last pair: they bound every candidate's search for its topic
-        // (a handful of steps; r4d's first cut searched all topics of the window from every flagged tile: 146 us per window instead of 72)
-        const uint32_t t_lo = tile_trange[2 * tile], t_hi = min(tile_trange[2 * tile + 1], nt - 1);
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n; i += 256) {
-            const Cand c = list[i];
-            const uint32_t t = topic_of_pos(c.pos, t_lo, t_hi, h_off);
-            const uint64_t h0 = hit_off[t] - hit_lo, h1 = hit_off[t + 1] - hit_lo;
-            const bool in = h0 >= lo && h1 <= hi;                  // the topic lies entirely inside this tile
-            s_topic[i] = in ? t : kNone; s_client[i] = c.client_idx; s_pos[i] = c.pos;
-        }
-        __syncthreads();
-        auto key_topic = [&](uint32_t k) { return s_topic[k]; };
-        auto key_client = [&](uint32_t k) { return s_client[k]; };
-        auto tab_load = [&](uint32_t sl) { return s_tab[sl]; };
-        for (uint32_t i = threadIdx.x; i < n; i += 256)
-            if (s_topic[i] != kNone)
-                dedup_tile_insert(i, s_pos[i] - uint32_t(lo), uint32_t(kDedupTileSlots - 1), key_topic, key_client, tab_load,
-                                  [&](uint32_t sl, uint32_t v) { return atomicCAS(&s_tab[sl], kNone, v); }, [&](uint32_t sl, uint32_t v) { atomicMin(&s_tab[sl], v); });
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < n; i += 256)
-            if (s_topic[i] != kNone && dedup_tile_is_dup(i, uint32_t(kDedupTileSlots - 1), key_topic, key_client, tab_load))
-                tuples[s_pos[i]].qos_flags |= kHitV5Dup;          // (this lane is the only writer of that word)
-    }
-    if (threadIdx.x == 0 && seen) atomicAdd(stat, seen);
-}
-
-// One work item per part of every topic that spans tiles and has at least two candidates.
-__global__ __launch_bounds__(256) void dedup_classify_kernel(const uint32_t* __restrict__ tile_ncand, uint32_t nt,
-                                                             const uint64_t* __restrict__ hit_off, uint64_t hit_lo, DedupItem* __restrict__ items,
-                                                             uint32_t* __restrict__ item_count) {
-    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= nt) return;
-    const uint64_t h0 = hit_off[t] - hit_lo, h1 = hit_off[t + 1] - hit_lo;
-    if (h1 - h0 < 2) return;
-    const uint32_t tile0 = uint32_t(h0 / kTile), tile1 = uint32_t((h1 - 1) / kTile);
-    if (tile0 == tile1) return;                                 // inside one tile: dedup_tile_kernel
-    // upper bound of the topic's candidates: what its tiles hold (the first and the last tile are shared with neighbours), at most its hits.
-    // (r3j: exact per-topic counts needed per-pair counting and per-topic atomics in the expansion — 1.03 vs 0.95 ms per window.)
-    uint64_t sum = 0;
-    for (uint32_t tile = tile0; tile <= tile1; ++tile) sum += tile_ncand[tile] & 0x7FFFFFFFu;
-    const uint32_t nc = uint32_t(sum < h1 - h0 ? sum : h1 - h0);
-    if (nc < 2) return;
-    const uint32_t parts = (nc + kDedupTopicCap - 1) / kDedupTopicCap;
-    const uint32_t at = atomicAdd(item_count, parts);
-    for (uint32_t p = 0; p < parts; ++p) items[at + p] = DedupItem{t, p, parts, nc};
-}
-
-__global__ __launch_bounds__(kDedupTopicThreads) void dedup_topic_kernel(const Cand* __restrict__ cand, const uint32_t* __restrict__ tile_ncand,
-                                                                         const uint64_t* __restrict__ hit_off, uint64_t hit_lo,
-                                                                         const DedupItem* __restrict__ items, const uint32_t* __restrict__ item_count,
-                                                                         Tuple* __restrict__ tuples, uint32_t max_slots) {
-    __shared__ unsigned long long s_tab[kDedupTopicSlots];
-    __shared__ uint32_t s_over;
-    const uint32_t ni = *item_count;
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    constexpr uint32_t kWaves = kDedupTopicThreads / 64;
-    for (uint32_t it = blockIdx.x; it < ni; it += gridDim.x) {
-        const DedupItem item = items[it];
-        const uint64_t h0 = hit_off[item.topic] - hit_lo, h1 = hit_off[item.topic + 1] - hit_lo;
-        const uint32_t tile0 = uint32_t(h0 / kTile), tile1 = uint32_t((h1 - 1) / kTile);
-        const uint32_t mask = dedup_topic_slots(item.nc, item.parts, max_slots) - 1;
-        // sub-parts: 1 unless the part's distinct clients overflow the table (then doubled and redone: the flags are idempotent)
-        for (uint32_t S = 1;; S <<= 1) {
-            bool over = false;
-            for (uint32_t sub = 0; sub < S && !over; ++sub) {
-                const uint64_t nparts = uint64_t(item.parts) * S;
-                const uint32_t mine = item.part * S + sub;
-                __syncthreads();
-                for (uint32_t i = threadIdx.x; i <= mask; i += kDedupTopicThreads) s_tab[i] = kDedupEmpty;
-                if (threadIdx.x == 0) s_over = 0;
-                __syncthreads();
-                // every wave takes whole tiles: a tile's list is read by 64 lanes with a stride of 64.  ONE pass (r4): an insertion
-                // returns the position that just lost to a smaller one of the same client (dedup_topic_insert_once), and that position
-                // is flagged on the spot — duplicates are a fraction of a percent of the hits, so the flag is an atomic OR on the
-                // tuple word instead of a second pass over every candidate list (r3: 0.41 ms per window, bound by those reads).
-                for (uint32_t tile = tile0 + wave; tile <= tile1; tile += kWaves) {
-                    const uint32_t n = tile_ncand[tile] & 0x7FFFFFFFu;
-                    const Cand* list = cand + uint64_t(tile) * kTile;
-                    for (uint32_t i = lane; i < n; i += 64) {
-                        const Cand c = list[i];
-                        if (c.pos < h0 || c.pos >= h1 || (nparts > 1 && dedup_part(c.client_idx, nparts) != mine)) continue;      // (first / last tile: a neighbour's hit)
-                        bool full = false;
-                        const uint32_t loser = dedup_topic_insert_once(c.client_idx, c.pos, mask,
-                                                                       [&](uint32_t sl, unsigned long long v) { return atomicCAS(&s_tab[sl], kDedupEmpty, v); },
-                                                                       [&](uint32_t sl, unsigned long long v) { return atomicMin(&s_tab[sl], v); }, full);
-                        if (full) s_over = 1;
-                        else if (loser != kNone) atomicOr(&tuples[loser].qos_flags, kHitV5Dup);
-                    }
-                }
-                __syncthreads();
-                over = s_over != 0;
-                if (over) break;
-            }
-            if (!over) break;
-        }
-    }
-}
+#include "dedup.inc"
 
 // --------------------------------------------------------------------------- delivery results grouped by node
 // SubRelationsMap is keyed by node (types.rs:486-497; router.rs:258-261 builds it from one collector per node): the host glue
@@ -1228,7 +1096,21 @@ void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, const uint32_t* 
         while (p2 < v && p2 < uint32_t(kDedupTopicSlots)) p2 <<= 1;
         return v ? p2 : uint32_t(kDedupTopicSlots);
     }();
-    dedup_topic_kernel<<<kDedupTopicThreads >= 512 ? 1024 : 1280, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, hit_off, hit_lo, items, item_count, tuples, max_slots);
+    // RGR_DEDUP_PIPE=1 (A/B switch, read per launch): the software-pipelined topic pass (dedup.inc)
+    const char* pipe = std::getenv("RGR_DEDUP_PIPE");
+    if (pipe && pipe[0] == '1') {
+        // a grid of exactly the blocks the chip holds at once (the kernel walks the items with a stride of the grid; its look-ahead
+        // registers cost it a block per CU against the kernel below)
+        static const uint32_t resident = [] {
+            int per_cu = 0, dev = 0;
+            hipDeviceProp_t prop{};
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dedup_topic_pipe_kernel, kDedupTopicThreads, 0) != hipSuccess || per_cu <= 0) per_cu = 2;
+            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount <= 0) return uint32_t(512);
+            return uint32_t(per_cu) * uint32_t(prop.multiProcessorCount);
+        }();
+        dedup_topic_pipe_kernel<<<resident, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, hit_off, hit_lo, items, item_count, tuples, max_slots);
+    } else
+        dedup_topic_kernel<<<kDedupTopicThreads >= 512 ? 1024 : 1280, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, hit_off, hit_lo, items, item_count, tuples, max_slots);
 }
 
 }  // namespace rgr

@@ -86,6 +86,20 @@ inline uint32_t lanes_get(int slot, uint32_t lane) {
 }  // namespace hipsim
 
 inline thread_local hipsim::Dim threadIdx{0}, blockIdx{0};
+inline hipsim::Dim gridDim{1};          // (set by hipsim::run)
+
+// LDS / global atomics of the kernels (every "GPU thread" is an OS thread: real atomics)
+template <class T> inline T atomicCAS(T* p, T expected, T desired) {
+    __atomic_compare_exchange_n(p, &expected, desired, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
+    return expected;
+}
+template <class T> inline T atomicMin(T* p, T v) {
+    T cur = __atomic_load_n(p, __ATOMIC_SEQ_CST);
+    while (v < cur && !__atomic_compare_exchange_n(p, &cur, v, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST)) {}
+    return cur;
+}
+template <class T> inline T atomicOr(T* p, T v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
+template <class T> inline T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
 #define __syncthreads() hipsim::syncthreads()
 
 inline uint32_t min(uint32_t a, uint32_t b) { return a < b ? a : b; }
@@ -103,6 +117,7 @@ template <class F> bool run(unsigned nblocks, unsigned nthreads, F kernel) {
     }
     g_diverged = false;
     g_block = ctx;
+    gridDim.x = nblocks;
     std::vector<std::thread> th;
     th.reserve(nthreads);
     for (unsigned t = 0; t < nthreads; ++t)

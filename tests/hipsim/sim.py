@@ -77,3 +77,69 @@ def expand_compact(variant, fmt, tiles_per_block, subs, pair_src, pair_off, pair
         return body.view(np.uint32).copy(), qos[guard:guard + hits].copy()
     assert (qos == 0xA5).all(), "qos bytes written by a format that has none"
     return (body.copy() if fmt == FMT_IDS24 else body.view(np.uint32).copy()), None
+
+
+# ---------------------------------------------------------------------------------------------- v5 per-client dedup (dedup.inc)
+CAND_DTYPE = np.dtype([("pos", np.uint32), ("client_idx", np.uint32)])
+TUPLE_DTYPE = np.dtype([("topic_idx", np.uint32), ("sub_id", np.uint32), ("qos_flags", np.uint32)])
+_DLIB = None
+
+
+def dedup_lib():
+    global _DLIB
+    if _DLIB is None:
+        so = os.path.join(HERE, "libhipsim_dedup.so")
+        csrc = os.path.join(ROOT, "rmqtt_amd", "csrc")
+        deps = [os.path.join(HERE, f) for f in ("sim_dedup.cpp", "hipsim.hpp")] + [os.path.join(csrc, f) for f in ("dedup.inc", "match_core.hpp", "kernels.hpp")]
+        if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+            tmp = f"{so}.tmp{os.getpid()}"
+            subprocess.check_call([clang(), "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I", os.path.join(ROOT, "include"), "-I", csrc,
+                                   os.path.join(HERE, "sim_dedup.cpp"), "-o", tmp])
+            os.replace(tmp, so)
+        L = C.CDLL(so)
+        vp, i32, u32, u64 = C.c_void_p, C.c_int32, C.c_uint32, C.c_uint64
+        L.sim_dedup.argtypes = [i32, u32, u32, vp, vp, vp, u32, vp, u32, vp, u64, vp]
+        L.sim_dedup.restype = i32
+        _DLIB = L
+    return _DLIB
+
+
+def dedup(variant, hit_off, cand_pos, cand_client, tile=2048, grid_topic=1024, max_slots=4096):
+    """One window through dedup_tile / dedup_classify / dedup_topic[_pipe].  hit_off: the window's per-topic offsets (n + 1, absolute);
+    candidates: window-relative positions + client indices (any order).  Lays the candidates out as the expansion does (tile i owns
+    cand[i * tile ...], its count carries bit 31 when a whole topic with candidates may lie inside it, tile_trange bounds its topics) and
+    returns (the positions the kernels flagged kHitV5Dup, number of topic-pass items)."""
+    hit_off = np.ascontiguousarray(hit_off, dtype=np.uint64)
+    nt = len(hit_off) - 1
+    hit_lo = int(hit_off[0])
+    nh = int(hit_off[-1]) - hit_lo
+    ntiles = (nh + tile - 1) // tile
+    pos = np.asarray(cand_pos, dtype=np.int64)
+    cl = np.asarray(cand_client, dtype=np.uint32)
+    cand = np.zeros(ntiles * tile, dtype=CAND_DTYPE)
+    ncand = np.zeros(ntiles, dtype=np.uint32)
+    trange = np.zeros(2 * ntiles, dtype=np.uint32)
+    rel = hit_off.astype(np.int64) - hit_lo
+    t_of = np.searchsorted(rel, pos, side="right") - 1
+    order = np.argsort(pos // tile, kind="stable")
+    for i in order:
+        tl = int(pos[i]) // tile
+        cand[tl * tile + int(ncand[tl])] = (pos[i], cl[i])
+        ncand[tl] += 1
+    for tl in range(ntiles):
+        lo, hi = tl * tile, min(nh, (tl + 1) * tile)
+        t_first = int(np.searchsorted(rel, lo, side="right") - 1)
+        t_last = int(np.searchsorted(rel, hi - 1, side="right") - 1)
+        whole = t_first != t_last or (rel[t_first] >= lo and rel[t_first + 1] <= lo + tile)
+        if ncand[tl] >= 2 and whole:
+            ncand[tl] |= 1 << 31
+            trange[2 * tl], trange[2 * tl + 1] = t_first, t_last
+    tuples = np.zeros(nh, dtype=TUPLE_DTYPE)
+    n_items = C.c_uint32(0)
+    rc = dedup_lib().sim_dedup(variant, grid_topic, max_slots, cand.ctypes.data, ncand.ctypes.data, trange.ctypes.data, ntiles, tuples.ctypes.data, nt,
+                               hit_off.ctypes.data, hit_lo, C.byref(n_items))
+    if rc == -2:
+        raise AssertionError("hipsim: threads diverged around a convergent operation in the dedup kernels")
+    assert rc == 0
+    assert not (tuples["qos_flags"] & ~np.uint32(16)).any() and not tuples["topic_idx"].any() and not tuples["sub_id"].any()
+    return np.flatnonzero(tuples["qos_flags"] & 16), int(n_items.value), t_of

@@ -9,6 +9,8 @@ hold (sub_id -> relation) and compares text for text.
 """
 import random
 
+import os
+
 import numpy as np
 import pytest
 
@@ -232,6 +234,18 @@ def test_v5_dedup_topics_spanning_tiles_in_parts(kind, test_slots, monkeypatch):
         if i % 2:
             w.add("q/r/+", c, 0, 2, True, False, True, 7)
     w.check(14)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("test_slots", [0, 64])
+@pytest.mark.skipif(not os.environ.get("RMQTT_TEST_EXPERIMENTAL"), reason="A/B variants that no GPU session has measured yet: RMQTT_TEST_EXPERIMENTAL=1")
+def test_v5_dedup_pipelined_topic_pass(test_slots, monkeypatch):
+    """RGR_DEDUP_PIPE=1: the software-pipelined topic pass (dedup_topic_pipe_kernel, dedup.inc; host twin tests/test_hipsim_dedup.py)
+    on the worlds of the two tests above, plus larger delivery windows (RGR_DELIVER_WINDOW_HITS)."""
+    monkeypatch.setenv("RGR_DEDUP_PIPE", "1")
+    monkeypatch.setenv("RGR_DELIVER_WINDOW_HITS", str(1 << 30))
+    test_v5_dedup_topics_spanning_tiles_in_parts("hip", test_slots, monkeypatch)
+    test_v5_dedup_many_candidates("hip")
 
 
 @pytest.mark.parametrize("n_nodes", [1, 3, 300])
