@@ -1276,16 +1276,30 @@ def time_format(args):
     import torch
     from rmqtt_amd import capi
     W = gen_workload(args.config, args.scale)
+    names = args.time_format.split(",")
+    deliver = "deliver" in names                       # the delivery stage (tuples + delivery words + v5 dedup): `--deliver V5FRAC`, default 0.1
+    if deliver and (len(names) > 1 or W["retain"]):
+        raise SystemExit("--time-format deliver stands alone (the table carries the delivery flags) and needs a router config")
     r = capi.Router(device=0, window_hits=args.window_hits, collect_walk_stats=False)
-    build_table(r, W, W["blob"], W["offs"], np.arange(W["n_sub"], dtype=np.uint32), W["qos"])
+    v5 = (args.deliver if args.deliver >= 0 else DELIVER_SECONDARY_V5) if deliver else -1.0
+    build_table(r, W, W["blob"], W["offs"], np.arange(W["n_sub"], dtype=np.uint32), W["qos"], deliver_frac=v5)
     batch = r.retain_batch(W["tb"], W["to"]) if W["retain"] else r.batch(W["tb"], W["to"])
+    W["publish_attrs"] = None
+    if deliver:
+        pa = np.zeros(W["n_pub"], dtype=capi.PUBLISH_ATTR_DTYPE)
+        prng = np.random.default_rng(12)
+        pa["from_id"] = prng.choice(W["client"].astype(np.uint32), size=W["n_pub"])
+        pa["qos_retain"] = prng.integers(0, 3, size=W["n_pub"]) | (prng.integers(0, 2, size=W["n_pub"]) << 2)
+        batch.set_publish_attrs(pa)
+        W["publish_attrs"] = pa
+        W["v5_frac"] = v5
     # --ab-env "A=1,A=2,A=2+B=7": one variant per comma, a variant is one or more NAME=value joined by '+'; names a variant does not
     # set are unset for it
     ab_name, ab_values = None, [None]
     if args.ab_env:
         ab_values = [dict(kv.split("=", 1) for kv in item.split("+")) for item in args.ab_env.split(",")]
         ab_name = sorted({k for v in ab_values for k in v})
-    for name in args.time_format.split(","):           # (several formats: one table build for all of them)
+    for name in names:                                 # (several formats: one table build for all of them)
         _time_one_format(args, W, r, batch, name, ab_name, ab_values)
     batch.close(); r.close()
     return 0
@@ -1302,9 +1316,10 @@ def _set_variant(names, variant):
 def _time_one_format(args, W, r, batch, name, ab_name, ab_values):
     import torch
     from rmqtt_amd import capi
-    fmt = FORMAT_NAMES.index(name)
+    deliver = name == "deliver"
+    fmt = capi.RGR_FORMAT_TUPLE if deliver else FORMAT_NAMES.index(name)
     batch.set_format(fmt)
-    bph = {"tuple": 12, "soa": 5, "packed": 4, "runs": 0, "ids24": 3}[name]
+    bph = {"tuple": 12, "soa": 5, "packed": 4, "runs": 0, "ids24": 3, "deliver": 12}[name]
     results = []
     for val in ab_values:
         _set_variant(ab_name, val)
@@ -1324,6 +1339,10 @@ def _time_one_format(args, W, r, batch, name, ab_name, ab_values):
                "expand_avg_launch_ms": round(st["expand_ms"] / max(1, st["expand_launches"]), 4),
                "expand_store_GBps": round(hits * args.steps * bph / max(1e-9, st["expand_ms"] / 1e3) / 1e9, 1),
                "extra_flags": os.environ.get("RGR_EXTRA_FLAGS", "")}
+        if deliver:
+            rec["v5_frac"] = W["v5_frac"]
+            rec["kernel_ms_per_step"]["dedup"] = round(st["dedup_ms"] / args.steps, 3)
+            rec["dedup_avg_launch_ms"] = round(st["dedup_ms"] / max(1, st["dedup_launches"]), 4)
         if ab_name:
             rec["env"] = val
         results.append(rec)
@@ -1332,6 +1351,16 @@ def _time_one_format(args, W, r, batch, name, ab_name, ab_values):
         best = max(range(len(results)), key=lambda i: results[i]["value"])
         if best == 0:
             best = max(range(1, len(results)), key=lambda i: results[i]["value"])
+        if deliver:
+            # the delivery words of whole windows (first, middle, last) of a pass under the fastest variant against the torch
+            # restatement of the per-hit rules + the v5 first-hit-per-client rule (delivery_parity)
+            t0 = time.time()
+            _set_variant(ab_name, ab_values[best])
+            dp = delivery_parity(batch, W, W["publish_attrs"])
+            _set_variant(ab_name, None)
+            print(json.dumps({"ab_check": [ab_values[0], ab_values[best]], "format": name, "ok": bool(dp["ok"]), "delivery_parity": dp, "seconds": round(time.time() - t0, 1)}), flush=True)
+            batch.set_format(capi.RGR_FORMAT_TUPLE)
+            return
         qos_by_sub = torch.as_tensor(np.ascontiguousarray(W["qos"]).astype(np.int64), device="cuda") if not W["retain"] else None
         t0 = time.time()
         _set_variant(ab_name, ab_values[0])
@@ -1407,7 +1436,7 @@ def main():
     ap.add_argument("--e2e-passes", type=int, default=3, help="device passes in flight")
     ap.add_argument("--e2e-sweep", action="store_true", help="--router-e2e: also run a few other (submitters, outstanding, workers, passes) shapes")
     ap.add_argument("--e2e-configs", default="2,3")
-    ap.add_argument("--time-format", default=None, help="time passes of ONE result format only (or several, comma-separated: one table build) and exit (sweeps, kernel traces): " + ", ".join(FORMAT_NAMES))
+    ap.add_argument("--time-format", default=None, help="time passes of ONE result format only (or several, comma-separated: one table build) and exit (sweeps, kernel traces): " + ", ".join(FORMAT_NAMES) + "; or `deliver` alone: the delivery stage (--deliver V5FRAC, default 0.1)")
     ap.add_argument("--ab-env", default=None, help="with --time-format: 'A=1,A=2,A=2+B=7': time the same batch once per variant (comma-separated; '+' joins assignments) of environment switches the library reads per launch")
     ap.add_argument("--no-ab-check", action="store_true", help="with --ab-env: skip the full-pass digest comparison of the fastest value against the first")
     ap.add_argument("--router-e2e", action="store_true", help="time Router::matches through the host Router mirror + batcher beside the CPU port (configs 2 and 3)")

@@ -640,153 +640,7 @@ __global__ __launch_bounds__(256) void pack_runs_kernel(const uint32_t* __restri
     if (r < n) out[r] = RunDesc{shard, src[r], uint32_t(off[r + 1] - off[r]), topic[r]};
 }
 
-// --------------------------------------------------------------------------- expand
-// kDeliver: the delivery stage fused into the expansion — the tuple's third word becomes the
-// delivery word (deliver_word, match_core.hpp) and v5 hits that may be per-client duplicates are
-// appended to the window's candidate list (one global atomic per block that has any).
-template <bool kDeliver, int kThreads, int kPer>
-__global__ __launch_bounds__(kThreads) void expand_kernel(const SubEntry* __restrict__ subs, ChunkArrays c,
-                                                                uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo,
-                                                                uint64_t hit_hi, const TileRec* __restrict__ tile_first,
-                                                                uint32_t ntiles, Tuple* __restrict__ out, DeliverArgs da) {
-    static_assert(kThreads * kPer == kTile, "expand geometry must cover the tile");
-    __shared__ int32_t s_off[kTile + 2];
-    __shared__ uint32_t s_src[kTile + 2];
-    __shared__ uint32_t s_topic[kTile + 2];
-    __shared__ uint32_t s_ncand;
-    __shared__ uint8_t s_qr[kDeliver ? kTile + 2 : 1];    // publish qos | retain<<2 of the pair's topic
-    if (kDeliver && threadIdx.x == 0) s_ncand = 0;
-
-    const uint32_t tile = blockIdx.x;
-    const uint64_t base = hit_lo + uint64_t(tile) * kTile;
-    const uint32_t len = (hit_hi - base) < uint64_t(kTile) ? uint32_t(hit_hi - base) : uint32_t(kTile);
-    const TileRec rec = tile_first[tile];
-    const uint64_t a = pair_lo + rec.first;
-    const uint64_t b = (tile + 1 < ntiles) ? pair_lo + tile_first[tile + 1].first + 1 : pair_hi;
-    const uint32_t np = uint32_t(b - a);
-    // a tile that lies inside ONE run (the common case at high fan-out) needs nothing but its record: the plain kernel
-    // then skips the pair arrays, the LDS staging and the barrier; the delivery variant keeps its LDS bookkeeping
-    const bool one = np == 1;
-    if (one) {
-        if (kDeliver) {
-            if (threadIdx.x == 0) { s_off[0] = 0; s_src[0] = rec.src; s_topic[0] = rec.topic; s_qr[0] = uint8_t(rec.qr); }
-            __syncthreads();
-        }
-    } else {
-        for (uint32_t i = threadIdx.x; i < np; i += kThreads) {
-            tile_pair_view(c, a, i, base, s_off[i], s_src[i], s_topic[i]);
-            if (kDeliver) s_qr[i] = c.pair_qr[a + i];
-        }
-        __syncthreads();
-    }
-    Tuple* o = out + (base - hit_lo);
-    // three phases so that the 8 subscriber loads of a lane are all in flight before the first
-    // store: (1) owner pair of each strided position (LDS binary search; free when one run
-    // covers the whole tile), (2) 8-byte subscriber loads, (3) 12-byte tuple stores — a wave
-    // stores 768 contiguous bytes per instruction.
-    uint32_t topic[kPer];
-    uint32_t pidx[kPer];
-    const SubEntry* src[kPer];
-#pragma unroll
-    for (int j = 0; j < kPer; ++j) {
-        const uint32_t pos = uint32_t(j) * kThreads + threadIdx.x;
-        const bool live = pos < len;
-        const uint32_t i = (one || !live) ? 0u : locate_pair([&](uint32_t m) { return s_off[m]; }, np, int32_t(pos));
-        topic[j] = one ? rec.topic : s_topic[i];
-        pidx[j] = i;
-        // dead tail positions read (and discard) the tile's first entry: keeps the loads branch-free
-        src[j] = subs + (uint64_t(one ? rec.src : s_src[i]) + (live ? uint32_t(int32_t(pos) - (one ? 0 : s_off[i])) : 0u));
-    }
-    SubEntry se[kPer];
-#pragma unroll
-    for (int j = 0; j < kPer; ++j) {
-        se[j] = *src[j];
-    }
-    uint32_t cslot[kDeliver ? kPer : 1], cclient[kDeliver ? kPer : 1];
-    if (kDeliver) {
-#pragma unroll
-        for (int j = 0; j < kPer; ++j) {
-            const uint32_t pos = uint32_t(j) * kThreads + threadIdx.x;
-            cslot[j] = kNone; cclient[j] = kNone;
-            if (pos < len) {
-                const uint32_t fl = se[j].qos_flags >> 8;
-                PublishAttr pa{kNone, s_qr[pidx[j]]};
-                SubAttr at{kNone, kNone};
-                if ((fl & kSubV5) && da.attrs) {                         // v3 hits need neither
-#ifdef RGR_DIAG_NO_ATTRS
-                    at = SubAttr{kNone, se[j].sub_id};
-#else
-                    at = da.attrs[src[j] - subs];
-#endif
-                    if (fl & kSubNoLocal) pa.from_id = da.pub[topic[j]].from_id;
-                }
-                bool cand;
-                se[j].qos_flags = deliver_word(se[j].qos_flags, pa, at, cand);
-                if (cand && da.cand && at.client_idx != kNone) cclient[j] = at.client_idx;
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < kPer; ++j) {
-        const uint32_t pos = uint32_t(j) * kThreads + threadIdx.x;
-        if (pos < len) {
-#if RGR_EXPAND_NT
-            __builtin_nontemporal_store(topic[j], &o[pos].topic_idx);
-            __builtin_nontemporal_store(se[j].sub_id, &o[pos].sub_id);
-            __builtin_nontemporal_store(se[j].qos_flags, &o[pos].qos_flags);
-#else
-            Tuple tp;
-            tp.topic_idx = topic[j]; tp.sub_id = se[j].sub_id; tp.qos_flags = se[j].qos_flags;
-            o[pos] = tp;
-#endif
-        }
-    }
-    // candidate bookkeeping AFTER the tuple stores were issued (r3: it used to sit between the loads and the stores and held the
-    // store stream back — the kernel is bound by those stores); the whole part is skipped (block-uniformly) when the epoch holds
-    // no v5 subscription
-    if (kDeliver && da.cand) {
-        // slots in the block's candidate list: one LDS atomic per wave instead of one per lane
-        const int lane = threadIdx.x & 63;
-#pragma unroll
-        for (int j = 0; j < kPer; ++j) {
-            const bool is = cclient[j] != kNone;
-            const unsigned long long m = __ballot(is);
-            if (!m) continue;
-            const int leader = __ffsll(static_cast<long long>(m)) - 1;
-            uint32_t wbase = 0;
-            if (lane == leader) wbase = atomicAdd(&s_ncand, uint32_t(__popcll(m)));
-            wbase = __shfl(wbase, leader, 64);
-            if (is) cslot[j] = wbase + uint32_t(__popcll(m & ((1ull << lane) - 1ull)));
-        }
-        __syncthreads();
-        // The topic pass sizes its tables from an UPPER BOUND of a topic's candidates (the candidate counts of the tiles it spans,
-        // dedup_classify_kernel), so no per-topic count is kept here (r3h: the per-pair counts + per-topic atomics were 0.10 ms of a
-        // window).  Bit 31 of the tile's count = "a whole topic may lie inside this tile": the tile holds pairs of more than one topic,
-        // or its single topic starts and ends here — only then has the tile-local dedup anything to do.
-        if (threadIdx.x == 0) {
-            uint32_t flag = 0;
-            if (s_ncand >= 2) {
-                const uint32_t t_first = s_topic[0], t_last = s_topic[np - 1];
-                flag = t_first != t_last ? 1u
-                       : (c.pair_off[a] == base && (a == pair_lo || c.pair_topic[a - 1] != t_first) && c.pair_off[b] <= base + kTile &&
-                          (b == pair_hi || c.pair_topic[b] != t_first)) ? 1u : 0u;
-            }
-            da.tile_ncand[tile] = s_ncand | (flag << 31);
-            // (with rgr_batch_set_topic_ids the pairs carry the CALLER's ids, not batch indices: then the whole window is the bound)
-            if (flag) { da.tile_trange[2 * tile] = c.topic_ids ? 0u : s_topic[0] - da.topic_lo; da.tile_trange[2 * tile + 1] = c.topic_ids ? kNone : s_topic[np - 1] - da.topic_lo; }
-        }
-        // the tile's candidates go to the tile's own slice of the list: no global cursor
-        Cand* mine = da.cand + uint64_t(tile) * kTile;
-#pragma unroll
-        for (int j = 0; j < kPer; ++j)
-#ifndef RGR_DIAG_NO_CAND_STORE
-            if (cslot[j] != kNone)
-#else
-            if (cslot[j] != kNone && cclient[j] == 0x12345u)
-#endif
-                mine[cslot[j]] = Cand{uint32_t(base - hit_lo) + uint32_t(j) * kThreads + threadIdx.x, cclient[j]};
-    }
-}
+#include "expand_tuple.inc"
 
 // packed side array of the subscriber entries (TrieView::subs_packed)
 __global__ __launch_bounds__(256) void pack_subs_kernel(const SubEntry* __restrict__ subs, uint64_t n, uint32_t* __restrict__ packed) {
@@ -1011,7 +865,10 @@ void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, ui
     hipStream_t s = static_cast<hipStream_t>(stream);
     // the plain kernel runs 1024 x 2 (with the single-run fast path: +3 % over 512 x 4, profiles/r02f_sweep_*); the delivery
     // variant keeps 512 x 4 — its per-wave candidate bookkeeping was 19 % slower at 1024 x 2 (profiles/r02g_bench_config3_deliver_*)
-    if (deliver) expand_kernel<true, kTile / 4, 4><<<ntiles, kTile / 4, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, *deliver);
+    // RGR_DELIVER_EARLY=1 (A/B switch, read per launch): the delivery variant with its loads issued early (expand_tuple.inc)
+    const char* early = deliver ? std::getenv("RGR_DELIVER_EARLY") : nullptr;
+    if (early && early[0] == '1') expand_deliver_early_kernel<kTile / 4, 4><<<ntiles, kTile / 4, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, *deliver);
+    else if (deliver) expand_kernel<true, kTile / 4, 4><<<ntiles, kTile / 4, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, *deliver);
     else expand_kernel<false, kExpandThreads, kExpandPerThread><<<ntiles, kExpandThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, DeliverArgs{});
 }
 

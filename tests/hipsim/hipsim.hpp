@@ -100,6 +100,23 @@ template <class T> inline T atomicMin(T* p, T v) {
 }
 template <class T> inline T atomicOr(T* p, T v) { return __atomic_fetch_or(p, v, __ATOMIC_SEQ_CST); }
 template <class T> inline T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_SEQ_CST); }
+
+// wave-level votes and shuffles (convergent: every lane of the wave, like the instructions)
+inline unsigned long long __ballot(int pred) {
+    hipsim::lanes_put(2, pred ? 1u : 0u);
+    unsigned long long m = 0;
+    for (unsigned l = 0; l < hipsim::kWave; ++l) m |= static_cast<unsigned long long>(hipsim::g_block->waves[hipsim::t_tid / hipsim::kWave].mirror[2][l] & 1u) << l;
+    hipsim::wave_sync();
+    return m;
+}
+inline uint32_t __shfl(uint32_t v, int src_lane, int /*width*/) {
+    hipsim::lanes_put(3, v);
+    const uint32_t r = hipsim::g_block->waves[hipsim::t_tid / hipsim::kWave].mirror[3][unsigned(src_lane) % hipsim::kWave];
+    hipsim::wave_sync();
+    return r;
+}
+inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 #define __syncthreads() hipsim::syncthreads()
 
 inline uint32_t min(uint32_t a, uint32_t b) { return a < b ? a : b; }

@@ -143,3 +143,63 @@ def dedup(variant, hit_off, cand_pos, cand_client, tile=2048, grid_topic=1024, m
     assert rc == 0
     assert not (tuples["qos_flags"] & ~np.uint32(16)).any() and not tuples["topic_idx"].any() and not tuples["sub_id"].any()
     return np.flatnonzero(tuples["qos_flags"] & 16), int(n_items.value), t_of
+
+
+# ---------------------------------------------------------------------------------------------- tuple expansions (expand_tuple.inc)
+ATTR_DTYPE = np.dtype([("owner_id", np.uint32), ("client_idx", np.uint32)])
+PUB_DTYPE = np.dtype([("from_id", np.uint32), ("qos_retain", np.uint32)])
+_TLIB = None
+
+
+def tuple_lib():
+    global _TLIB
+    if _TLIB is None:
+        so = os.path.join(HERE, "libhipsim_expand_tuple.so")
+        csrc = os.path.join(ROOT, "rmqtt_amd", "csrc")
+        deps = [os.path.join(HERE, f) for f in ("sim_expand_tuple.cpp", "hipsim.hpp")] + [os.path.join(csrc, f) for f in ("expand_tuple.inc", "match_core.hpp", "kernels.hpp")]
+        if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+            tmp = f"{so}.tmp{os.getpid()}"
+            subprocess.check_call([clang(), "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I", os.path.join(ROOT, "include"), "-I", csrc,
+                                   os.path.join(HERE, "sim_expand_tuple.cpp"), "-o", tmp])
+            os.replace(tmp, so)
+        L = C.CDLL(so)
+        vp, i32, u32, u64 = C.c_void_p, C.c_int32, C.c_uint32, C.c_uint64
+        L.sim_expand_tuple.argtypes = [i32, vp, vp, vp, vp, vp, vp, vp, u64, u64, u32, vp, vp, vp, vp]
+        L.sim_expand_tuple.restype = i32
+        _TLIB = L
+    return _TLIB
+
+
+def expand_tuple(variant, subs, attrs, pub, pair_src, pair_topic, pair_off, pair_qr, pair_lo, pair_hi, topic_lo, want_cand=True, tile=2048):
+    """One window through a tuple expansion kernel.  -> (tuples, per-tile candidate lists [(pos, client) sorted], tile_ncand raw words,
+    tile_trange) — the last three None for variant 0 / want_cand False."""
+    subs = np.ascontiguousarray(subs, dtype=SUB_DTYPE)
+    attrs = None if attrs is None else np.ascontiguousarray(attrs, dtype=ATTR_DTYPE)
+    pub = np.ascontiguousarray(pub, dtype=PUB_DTYPE)
+    pair_src = np.ascontiguousarray(pair_src, dtype=np.uint32)
+    pair_topic = np.ascontiguousarray(pair_topic, dtype=np.uint32)
+    pair_off = np.ascontiguousarray(pair_off, dtype=np.uint64)
+    pair_qr = np.ascontiguousarray(pair_qr, dtype=np.uint8)
+    nh = int(pair_off[pair_hi] - pair_off[pair_lo])
+    ntiles = (nh + tile - 1) // tile
+    out = np.zeros(nh + 1, dtype=TUPLE_DTYPE)
+    out[nh] = (0xA5A5A5A5, 0xA5A5A5A5, 0xA5A5A5A5)
+    deliver = variant != 0
+    cand = np.full(ntiles * tile, 0xFFFFFFFF, dtype=np.uint64).view(CAND_DTYPE) if deliver and want_cand else None
+    ncand = np.full(ntiles, 0xDEADBEEF, dtype=np.uint32) if deliver and want_cand else None
+    trange = np.full(2 * ntiles, 0xDEADBEEF, dtype=np.uint32) if deliver and want_cand else None
+    p = lambda a: None if a is None else a.ctypes.data
+    rc = tuple_lib().sim_expand_tuple(variant, subs.ctypes.data, p(attrs), pub.ctypes.data, pair_src.ctypes.data, pair_topic.ctypes.data, pair_off.ctypes.data,
+                                      pair_qr.ctypes.data, pair_lo, pair_hi, topic_lo, out.ctypes.data, p(cand), p(ncand), p(trange))
+    if rc == -2:
+        raise AssertionError("hipsim: threads diverged around a convergent operation in the tuple expansion")
+    assert rc == 0
+    assert tuple(out[nh]) == (0xA5A5A5A5, 0xA5A5A5A5, 0xA5A5A5A5), "write past the window's tuples"
+    lists = None
+    if cand is not None:
+        lists = []
+        for t in range(ntiles):
+            n = int(ncand[t] & 0x7FFFFFFF)
+            sl = cand[t * tile:t * tile + n]
+            lists.append(sorted(zip(sl["pos"].tolist(), sl["client_idx"].tolist())))
+    return out[:nh].copy(), lists, ncand, trange

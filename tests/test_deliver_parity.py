@@ -240,9 +240,11 @@ def test_v5_dedup_topics_spanning_tiles_in_parts(kind, test_slots, monkeypatch):
 @pytest.mark.parametrize("test_slots", [0, 64])
 @pytest.mark.skipif(not os.environ.get("RMQTT_TEST_EXPERIMENTAL"), reason="A/B variants that no GPU session has measured yet: RMQTT_TEST_EXPERIMENTAL=1")
 def test_v5_dedup_pipelined_topic_pass(test_slots, monkeypatch):
-    """RGR_DEDUP_PIPE=1: the software-pipelined topic pass (dedup_topic_pipe_kernel, dedup.inc; host twin tests/test_hipsim_dedup.py)
-    on the worlds of the two tests above, plus larger delivery windows (RGR_DELIVER_WINDOW_HITS)."""
+    """RGR_DEDUP_PIPE=1: the software-pipelined topic pass (dedup_topic_pipe_kernel, dedup.inc; host twin tests/test_hipsim_dedup.py),
+    RGR_DELIVER_EARLY=1: the delivery expansion with its loads issued early (expand_deliver_early_kernel, expand_tuple.inc; host twin
+    tests/test_hipsim_expand_tuple.py) on the worlds of the two tests above, plus larger delivery windows (RGR_DELIVER_WINDOW_HITS)."""
     monkeypatch.setenv("RGR_DEDUP_PIPE", "1")
+    monkeypatch.setenv("RGR_DELIVER_EARLY", "1")
     monkeypatch.setenv("RGR_DELIVER_WINDOW_HITS", str(1 << 30))
     test_v5_dedup_topics_spanning_tiles_in_parts("hip", test_slots, monkeypatch)
     test_v5_dedup_many_candidates("hip")
