@@ -624,6 +624,8 @@ __global__ __launch_bounds__(256) void compact_big_kernel(TrieView tv, ChunkArra
     }
 }
 
+#include "prep_batched.inc"
+
 // --------------------------------------------------------------------------- tiles
 __global__ __launch_bounds__(256) void tiles_kernel(ChunkArrays c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, TileRec* __restrict__ tile_first) {
     const uint64_t p = pair_lo + uint64_t(blockIdx.x) * 256 + threadIdx.x;
@@ -828,11 +830,15 @@ void launch_pairs_dense(const TrieView& t, const ChunkArrays& c, const uint64_t*
     else pairs_dense_kernel<false><<<(c.n + 255) / 256, 256, 0, s>>>(t, c, off, out);
 }
 
+static bool prep_batched() { const char* e = std::getenv("RGR_PREP_BATCH"); return e && e[0] == '1'; }
+
 void launch_count(const TrieView& t, const ChunkArrays& c, void* stream) {
     if (c.n == 0) return;
     hipStream_t s = static_cast<hipStream_t>(stream);
     (void)hipMemsetAsync(c.big_count, 0, 4, s);
-    count_kernel<<<(c.n + 255) / 256, 256, 0, s>>>(t, c);
+    // RGR_PREP_BATCH=1 (A/B switch, read per launch): count / compact with their gathers in batches (prep_batched.inc)
+    if (prep_batched()) count_batched_kernel<<<(c.n + 255) / 256, 256, 0, s>>>(t, c);
+    else count_kernel<<<(c.n + 255) / 256, 256, 0, s>>>(t, c);
     count_big_kernel<<<512, 256, 0, s>>>(t, c);
 }
 
@@ -848,7 +854,8 @@ void launch_scan(const ChunkArrays& c, uint64_t* block_tmp, void* stream) {
 void launch_compact(const TrieView& t, const ChunkArrays& c, uint32_t topic_base, void* stream) {
     if (c.n == 0) return;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    compact_kernel<<<(c.n + kCompactWave - 1) / kCompactWave, kCompactWave, 0, s>>>(t, c, topic_base);
+    if (prep_batched()) compact_batched_kernel<<<(c.n + kCompactWave - 1) / kCompactWave, kCompactWave, 0, s>>>(t, c, topic_base);
+    else compact_kernel<<<(c.n + kCompactWave - 1) / kCompactWave, kCompactWave, 0, s>>>(t, c, topic_base);
     compact_big_kernel<<<512, 256, 0, s>>>(t, c, topic_base);
 }
 

@@ -203,3 +203,54 @@ def expand_tuple(variant, subs, attrs, pub, pair_src, pair_topic, pair_off, pair
             sl = cand[t * tile:t * tile + n]
             lists.append(sorted(zip(sl["pos"].tolist(), sl["client_idx"].tolist())))
     return out[:nh].copy(), lists, ncand, trange
+
+
+# ---------------------------------------------------------------------------------------------- count / compact, batched (prep_batched.inc)
+DESC_DTYPE = np.dtype([("begin", np.uint32), ("count", np.uint32)])
+_PLIB = None
+
+
+def prep_lib():
+    global _PLIB
+    if _PLIB is None:
+        so = os.path.join(HERE, "libhipsim_prep.so")
+        csrc = os.path.join(ROOT, "rmqtt_amd", "csrc")
+        deps = [os.path.join(HERE, f) for f in ("sim_prep.cpp", "hipsim.hpp")] + [os.path.join(csrc, f) for f in ("prep_batched.inc", "match_core.hpp", "kernels.hpp")]
+        if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+            tmp = f"{so}.tmp{os.getpid()}"
+            subprocess.check_call([clang(), "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", "-I", os.path.join(ROOT, "include"), "-I", csrc,
+                                   os.path.join(HERE, "sim_prep.cpp"), "-o", tmp])
+            os.replace(tmp, so)
+        L = C.CDLL(so)
+        vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
+        L.sim_prep.argtypes = [u32, u32, vp, vp, vp, vp, u64, vp, u32, vp, vp, vp]
+        L.sim_prep.restype = C.c_int64
+        _PLIB = L
+    return _PLIB
+
+
+def prep(lists, filt, slot_cap, topic_base=0, pub=None):
+    """lists: per topic the matched filter ids in order.  Lays them out as the walk does (the first slot_cap-sized lists j-major in the
+    slot array, longer ones in the overflow arena) and runs the batched count / compact kernels beside the shared per-topic functions.
+    -> (differing words, pairs, hits)."""
+    n = len(lists)
+    cnt = np.array([len(x) for x in lists], dtype=np.uint32)
+    slots = np.full(max(1, slot_cap) * n, 0xDEADBEEF, dtype=np.uint32)
+    ovf_base = np.zeros(n, dtype=np.uint64)
+    arena = []
+    for t, ids in enumerate(lists):
+        if len(ids) <= slot_cap:
+            for j, f in enumerate(ids):
+                slots[j * n + t] = f
+        else:
+            ovf_base[t] = len(arena)
+            arena += list(ids)
+    arena = np.asarray(arena + [0xDEADBEEF], dtype=np.uint32)
+    filt = np.ascontiguousarray(filt, dtype=DESC_DTYPE)
+    pub_arr = None if pub is None else np.ascontiguousarray(pub, dtype=PUB_DTYPE)
+    npairs, nhits = C.c_uint64(0), C.c_uint64(0)
+    d = prep_lib().sim_prep(n, slot_cap, slots.ctypes.data, cnt.ctypes.data, ovf_base.ctypes.data, arena.ctypes.data, len(arena), filt.ctypes.data, topic_base,
+                            None if pub_arr is None else pub_arr.ctypes.data, C.byref(npairs), C.byref(nhits))
+    if d == -2:
+        raise AssertionError("hipsim: threads diverged around a barrier in the batched count / compact kernels")
+    return int(d), int(npairs.value), int(nhits.value)

@@ -245,6 +245,7 @@ def test_v5_dedup_pipelined_topic_pass(test_slots, monkeypatch):
     tests/test_hipsim_expand_tuple.py) on the worlds of the two tests above, plus larger delivery windows (RGR_DELIVER_WINDOW_HITS)."""
     monkeypatch.setenv("RGR_DEDUP_PIPE", "1")
     monkeypatch.setenv("RGR_DELIVER_EARLY", "1")
+    monkeypatch.setenv("RGR_PREP_BATCH", "1")          # count / compact with their gathers in batches (prep_batched.inc; tests/test_hipsim_prep.py)
     monkeypatch.setenv("RGR_DELIVER_WINDOW_HITS", str(1 << 30))
     test_v5_dedup_topics_spanning_tiles_in_parts("hip", test_slots, monkeypatch)
     test_v5_dedup_many_candidates("hip")
