@@ -163,35 +163,39 @@ int hr_e2e_run_async(void* r, const uint8_t* blob, const uint64_t* offs, uint32_
                      uint32_t passes_in_flight, uint32_t max_batch, uint32_t max_delay_us, double seconds, uint64_t* out, double* wall_s,
                      float* lat_us, uint32_t n_lat, uint32_t* n_lat_out) {
     auto* router = static_cast<GpuRouter*>(r);
-    // per submitter: counters on their own cache lines (the completions run on the worker pool)
-    struct alignas(64) Ctx { std::atomic<int64_t> inflight{0}; char pad0[56]; std::atomic<uint64_t> pubs{0}, rows{0}, errs{0}; char pad1[40];
-                             std::mutex m; std::condition_variable cv; int64_t low = 0; float* lat = nullptr; uint32_t n_lat = 0; std::atomic<uint32_t> lat_n{0};
-                             std::chrono::steady_clock::time_point t0; };
+    // Per submitter: what its completions count, spread over per-worker cache lines.  (r4: `pubs`, `rows` and `inflight` used to be one
+    // atomic each per submitter — every completion of every worker did three read-modify-writes on lines all 64 workers and the
+    // submitter shared; the harness's own bookkeeping, not the batcher, was what a publish cost.  Now a completion adds to the line of
+    // ITS worker thread; the submitter sums the lines only when its own count of submissions says it may be at its cap.)
+    constexpr uint32_t kLanes = 128;                                  // worker threads hash onto lanes (two workers on one lane: still correct, atomics)
+    struct alignas(64) Lane { std::atomic<uint64_t> pubs{0}, rows{0}, errs{0}; char pad[40]; };
+    struct alignas(64) Ctx { Lane lane[kLanes]; uint64_t submitted = 0, seen_done = 0; float* lat = nullptr; uint32_t n_lat = 0; std::atomic<uint32_t> lat_n{0};
+                             std::chrono::steady_clock::time_point t0;
+                             uint64_t done() const { uint64_t d = 0; for (const Lane& l : lane) d += l.pubs.load(std::memory_order_acquire); return d; } };
     std::vector<std::unique_ptr<Ctx>> ctx;
     for (uint32_t k = 0; k < n_submitters; ++k) ctx.push_back(std::make_unique<Ctx>());
-    const int64_t cap = std::max<int64_t>(1, outstanding / std::max(1u, n_submitters));
-    // a submitter at its cap sleeps until a quarter of its publishes have completed (one wake per cap / 4 completions, not one per
-    // completion: r4b's first cut woke the submitter — a futex + a context switch — for every single completion)
-    const int64_t low = cap - std::max<int64_t>(1, cap / 4);
+    const uint64_t cap = std::max<uint64_t>(1, outstanding / std::max(1u, n_submitters));
     std::atomic<bool> stop{false};
     uint64_t passes = 0;
     const auto t0 = std::chrono::steady_clock::now();
-    for (auto& c : ctx) { c->low = low; c->t0 = t0; }
+    for (auto& c : ctx) c->t0 = t0;
     ctx[0]->lat = lat_us; ctx[0]->n_lat = lat_us ? n_lat : 0;
     double wall = 0;
     // completion: tag = submit time in ns since t0
     const Batcher::Callback done = [](void* user, uint64_t tag, Result<SubRelationsMap>&& res) {
+        static std::atomic<uint32_t> next_lane{0};
+        thread_local const uint32_t my_lane = next_lane.fetch_add(1, std::memory_order_relaxed) % kLanes;
         Ctx& c = *static_cast<Ctx*>(user);
+        Lane& l = c.lane[my_lane];
         uint64_t rows = 0;
         if (res.ok()) for (auto& kv : *res.value) rows += kv.second.size();
-        else if (res.error.rfind("invalid topic", 0) != 0) c.errs.fetch_add(1, std::memory_order_relaxed);
-        if (rows) c.rows.fetch_add(rows, std::memory_order_relaxed);
-        c.pubs.fetch_add(1, std::memory_order_relaxed);
+        else if (res.error.rfind("invalid topic", 0) != 0) l.errs.fetch_add(1, std::memory_order_relaxed);
+        if (rows) l.rows.fetch_add(rows, std::memory_order_relaxed);
         if (c.lat) {
             const uint32_t j = c.lat_n.fetch_add(1, std::memory_order_relaxed);
             if (j < c.n_lat) c.lat[j] = float(double(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - c.t0).count() - int64_t(tag)) / 1e3);
         }
-        if (c.inflight.fetch_sub(1, std::memory_order_acq_rel) == c.low + 1) { { std::lock_guard<std::mutex> g(c.m); } c.cv.notify_one(); }
+        l.pubs.fetch_add(1, std::memory_order_release);               // last: the publish is complete
     };
     {
         Batcher b(*router, max_batch, std::chrono::microseconds(max_delay_us), passes_in_flight, workers);
@@ -201,13 +205,12 @@ int hr_e2e_run_async(void* r, const uint8_t* blob, const uint64_t* offs, uint32_
                 Ctx& c = *ctx[k];
                 Id id; id.node_id = 1; id.client_id = "publisher" + std::to_string(k);
                 for (uint64_t i = k; !stop.load(std::memory_order_relaxed); i += n_submitters) {
-                    if (c.inflight.load(std::memory_order_acquire) >= cap) {
-                        std::unique_lock<std::mutex> lk(c.m);
-                        c.cv.wait_for(lk, std::chrono::microseconds(500), [&] { return c.inflight.load(std::memory_order_acquire) <= low || stop.load(); });
-                        continue;
+                    if (c.submitted - c.seen_done >= cap) {                      // maybe at the cap: look at what has completed since
+                        c.seen_done = c.done();
+                        if (c.submitted - c.seen_done >= cap) { std::this_thread::sleep_for(std::chrono::microseconds(50)); i -= n_submitters; continue; }
                     }
                     const uint32_t t = uint32_t(i % n);
-                    c.inflight.fetch_add(1, std::memory_order_acq_rel);
+                    ++c.submitted;
                     const uint64_t now_ns = uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count());
                     b.submit(id, std::string_view(reinterpret_cast<const char*>(blob) + offs[t], offs[t + 1] - offs[t]), done, &c, now_ns);
                 }
@@ -215,7 +218,7 @@ int hr_e2e_run_async(void* r, const uint8_t* blob, const uint64_t* offs, uint32_
         std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
         stop = true;
         for (auto& t : th) t.join();
-        for (auto& c : ctx) while (c->inflight.load(std::memory_order_acquire) > 0) std::this_thread::sleep_for(std::chrono::microseconds(100));
+        for (auto& c : ctx) while (c->done() < c->submitted) std::this_thread::sleep_for(std::chrono::microseconds(100));
         wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         passes = b.passes();
         const Batcher::Timing tm = b.timing();      // out[4..9]: where the batcher's threads spent their time (ns summed over threads)
@@ -223,7 +226,7 @@ int hr_e2e_run_async(void* r, const uint8_t* blob, const uint64_t* offs, uint32_
     }
     if (wall_s) *wall_s = wall;
     out[0] = out[1] = out[3] = 0;
-    for (auto& c : ctx) { out[0] += c->pubs; out[1] += c->rows; out[3] += c->errs; }
+    for (auto& c : ctx) for (const auto& l : c->lane) { out[0] += l.pubs.load(); out[1] += l.rows.load(); out[3] += l.errs.load(); }
     out[2] = passes;
     if (n_lat_out) *n_lat_out = std::min(ctx[0]->lat_n.load(), ctx[0]->n_lat);
     return 0;
