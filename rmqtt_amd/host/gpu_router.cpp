@@ -585,8 +585,7 @@ Batcher::~Batcher() {
 
 void Batcher::enqueue(Req* req) {
     Shard& sh = shards_[req->cb ? req->shard : shard_of_this_thread(kShards)];
-    { std::lock_guard<std::mutex> lk(sh.m); sh.q.push_back(req); }
-    requests_.fetch_add(1, std::memory_order_relaxed);
+    { std::lock_guard<std::mutex> lk(sh.m); sh.q.push_back(req); ++sh.requests; }      // (counted per shard, under the lock already held: one shared atomic less per publish)
     const size_t before = pending_.fetch_add(1, std::memory_order_seq_cst);
     // wake a driver for the first request of a batch and when the batch is full; everything in between rides on its deadline.  Only
     // when a driver is actually asleep: under load the drivers find work without sleeping and a submit stays a queue push (r4b: a

@@ -274,7 +274,7 @@ class Batcher {
     Result<SubRelationsMap> matches(const Id& id, const TopicName& topic);
     void submit(const Id& id, std::string_view topic, Callback cb, void* user, uint64_t tag);
     uint64_t passes() const { return passes_; }
-    uint64_t requests() const { return requests_; }
+    uint64_t requests() const { uint64_t n = 0; for (const Shard& sh : shards_) { std::lock_guard<std::mutex> g(sh.m); n += sh.requests; } return n; }
     // where the drivers' and workers' time went (nanoseconds summed over threads): collecting a batch (incl. the deadline wait's tail
     // and packing the topics), the device pass (GpuRouter::filters_pass), handing the results on, and the workers' expansion tasks
     struct Timing { uint64_t collect_ns, pass_ns, dispatch_ns, task_ns, tasks, max_task_queue; };
@@ -289,7 +289,7 @@ class Batcher {
     // a submitter sticks to one shard: its queue, and the free list its asynchronous requests are recycled through (a finished
     // request goes back to the shard it came from, so request objects — and the capacity of their strings — stay with their submitter
     // instead of crossing the allocator's arenas on every publish)
-    struct alignas(64) Shard { std::mutex m; std::vector<Req*> q; std::vector<Req*> free; };
+    struct alignas(64) Shard { mutable std::mutex m; std::vector<Req*> q; std::vector<Req*> free; uint64_t requests = 0; };
     struct Task { std::shared_ptr<GpuRouter::FilterPass> pass; std::vector<Req*> reqs; };
     static constexpr size_t kShards = 16;      // submission queues (a submitter sticks to one)
     static constexpr size_t kTaskRun = 64;     // publishes per worker task
@@ -302,7 +302,7 @@ class Batcher {
     std::condition_variable cv_req_;
     std::atomic<bool> stop_{false};
     std::atomic<int> sleepers_{0};             // drivers inside a condition-variable wait (submitters only notify when there is one)
-    std::atomic<uint64_t> passes_{0}, requests_{0};
+    std::atomic<uint64_t> passes_{0};
     std::atomic<uint64_t> collect_ns_{0}, pass_ns_{0}, dispatch_ns_{0}, task_ns_{0}, tasks_run_{0};
     std::atomic<size_t> next_shard_{0};
     size_t max_task_queue_ = 0;                // (under task_mu_)
