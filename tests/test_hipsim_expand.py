@@ -85,3 +85,31 @@ def test_expand_compact_source_on_host(case, variant, fmt, tiles, use_packed):
     assert bad.size == 0, f"{bad.size} differing elements, first at {bad[:8]} of {ids.size}"
     if want_qos is not None:
         assert (qos == want_qos).all()
+
+
+# ---- property: ANY pair list (runs of 1 .. 5 000 entries, 1 .. 150 runs) expands like numpy does, through every lane-held variant
+try:
+    from hypothesis import HealthCheck, given, settings
+    from hypothesis import strategies as st
+    HAVE_HYPOTHESIS = True
+except ImportError:                                     # pragma: no cover
+    HAVE_HYPOTHESIS = False
+
+if HAVE_HYPOTHESIS:
+    run_len = st.one_of(st.integers(1, 4), st.integers(1, 70), st.integers(1, 5000), st.sampled_from([2047, 2048, 2049, 4096]))
+
+    @settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(lens=st.lists(run_len, min_size=1, max_size=150), tiles=st.sampled_from([1, 2, 4]), fmt=st.sampled_from([sim.FMT_PACKED, sim.FMT_IDS24]),
+           pair_lo=st.integers(0, 3), first=st.integers(0, 1 << 40), seed=st.integers(0, 1 << 16))
+    def test_lane_held_expansion_any_pair_list(lens, tiles, fmt, pair_lo, first, seed):
+        total = 0
+        kept = []
+        for n in lens:                                   # at most ~30 tiles per example: the host run stays in the tens of milliseconds
+            if total + n > 30 * TILE:
+                break
+            kept.append(n); total += n
+        rng = np.random.default_rng(seed)
+        subs, src, off, lo, hi = make_case(rng, kept, pool=1 << 14, pair_lo=pair_lo, tail_pairs=1, first_off=first)
+        ids, _ = sim.expand_compact(1, fmt, tiles, subs, src, off, lo, hi)
+        want, _ = reference(fmt, subs, src, off, lo, hi)
+        assert np.array_equal(ids, want)
