@@ -907,6 +907,14 @@ void launch_expand_compact(const TrieView& t, const ChunkArrays& c, uint64_t pai
     const uint32_t nb1 = (ntiles + kCompactTiles - 1) / kCompactTiles, nb24 = (ntiles + kIds24Tiles - 1) / kIds24Tiles;
     // RGR_COMPACT_LP=T (A/B switch, read per launch): PACKED / IDS24 through expand_compact_lp_kernel with T tiles per block (pairs held in
     // lanes, expand_compact.inc) instead of the tile-per-block kernel; needs the packed side array
+    // RGR_IDS24_X4=1 (A/B switch, read per launch; not measured yet): IDS24 through 16-byte stores, two lane-held tiles per block
+    if (format == kFmtIds24 && pk) {
+        const char* x4 = std::getenv("RGR_IDS24_X4");
+        if (x4 && x4[0] == '1') {
+            expand_ids24_x4_kernel<<<(ntiles + 1) / 2, kCompactThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out_ids, out_qos, pk);
+            return;
+        }
+    }
     const int lp = compact_lp_tiles(format);
     if (lp && pk && (format == kFmtIds24 || format == kFmtPacked)) {
         const uint32_t nb = (ntiles + uint32_t(lp) - 1) / uint32_t(lp);

@@ -21,7 +21,7 @@ using namespace rgr;
 extern "C" {
 
 // variant 0: expand_compact_kernel (one tile per block, or the round-4 pipelined form for tiles_per_block > 1)
-// variant 1: expand_compact_lp_kernel (pairs held in lanes)
+// variant 1: expand_compact_lp_kernel (pairs held in lanes); variant 2: expand_ids24_x4_kernel (the same, IDS24 through 16-byte stores)
 // fmt: 1 SOA, 2 PACKED, 4 IDS24.  packed may be null (8-byte entry reads; variant 0 only).  Returns 0, -1 for an unknown combination, -2 when threads diverged around a barrier or a cross-lane read.
 int32_t sim_expand_compact(int32_t variant, int32_t fmt, int32_t tiles_per_block, const SubEntry* subs, const uint32_t* packed,
                            const uint32_t* pair_src, const uint32_t* pair_topic, const uint64_t* pair_off, uint64_t pair_lo, uint64_t pair_hi,
@@ -55,6 +55,9 @@ int32_t sim_expand_compact(int32_t variant, int32_t fmt, int32_t tiles_per_block
         else if (fmt == kFmtIds24 && T == 2) SIM_RUN(expand_compact_lp_kernel, kFmtIds24, 2);
         else if (fmt == kFmtIds24 && T == 4) SIM_RUN(expand_compact_lp_kernel, kFmtIds24, 4);
         else return -1;
+    } else if (variant == 2) {                  // IDS24 through 16-byte stores (two lane-held tiles per block)
+        if (!packed || fmt != kFmtIds24) return -1;
+        converged = hipsim::run((ntiles + 1) / 2, kCompactThreads, [&] { expand_ids24_x4_kernel(subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tf, ntiles, out_ids, out_qos, packed); });
     } else {
         return -1;
     }

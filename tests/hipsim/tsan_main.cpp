@@ -30,7 +30,7 @@ int main() {
     { uint64_t k = 0; for (size_t p = 0; p < len.size(); ++p) for (uint32_t j = 0; j < len[p]; ++j) want[k++] = packed[src[p] + j]; }
     int bad = 0;
     struct K { int variant, fmt, tiles; bool pk; } ks[] = {{0, 1, 1, false}, {0, 2, 1, true}, {0, 4, 4, true}, {0, 2, 4, true}, {1, 2, 1, true}, {1, 2, 2, true},
-                                                          {1, 2, 4, true}, {1, 4, 1, true}, {1, 4, 2, true}, {1, 4, 4, true}};
+                                                          {1, 2, 4, true}, {1, 4, 1, true}, {1, 4, 2, true}, {1, 4, 4, true}, {2, 4, 2, true}};
     for (const K& k : ks) {
         std::vector<uint8_t> out(hits * (k.fmt == 4 ? 3 : 4), 0), qos(hits, 0);      // exact sizes: a store past the window is an ASAN report
         const int rc = sim_expand_compact(k.variant, k.fmt, k.tiles, subs.data(), k.pk ? packed.data() : nullptr, src.data(), topic.data(), off.data(), 0,

@@ -2,6 +2,7 @@
 the same hits in the same order as the 12-byte tuples, without the topic column — checked word for word
 against the tuple format of the same pass, which the parity suites pin against the oracle."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -302,4 +303,10 @@ def test_lane_held_expansion_equals_tile_kernel(window_hits, monkeypatch):
                 assert np.array_equal(a0, want), (lp, f, "tile-per-block kernel")
                 bad = np.flatnonzero(a != want)
                 assert bad.size == 0, (lp, f, bad[:8], len(a))
+    if os.environ.get("RMQTT_TEST_EXPERIMENTAL"):       # A/B variants no GPU session has measured yet
+        monkeypatch.setenv("RGR_IDS24_X4", "1")          # IDS24 through 16-byte stores (expand_ids24_x4_kernel; host twin: tests/test_hipsim_expand.py)
+        got = windows(batch, capi.RGR_FORMAT_IDS24)
+        for (_, _, _, t, _), (_, _, _, a, _) in zip(ref, got):
+            assert np.array_equal(a, t["sub_id"]), "RGR_IDS24_X4"
+        monkeypatch.delenv("RGR_IDS24_X4")
     batch.close(); r.close()

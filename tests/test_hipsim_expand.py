@@ -66,11 +66,12 @@ CASES = {
     "tiny_window": lambda rng: make_case(rng, [3], pair_lo=1, tail_pairs=1),
     "exact_tiles": lambda rng: make_case(rng, [TILE - 1, 1, TILE - 2, 2, 1, TILE - 1, 4 * TILE]),
 }
-# (variant, format, tiles per block, packed side array): 0 = expand_compact_kernel, 1 = expand_compact_lp_kernel
+# (variant, format, tiles per block, packed side array): 0 = expand_compact_kernel, 1 = expand_compact_lp_kernel, 2 = expand_ids24_x4_kernel
 KERNELS = [(0, sim.FMT_SOA, 1, False), (0, sim.FMT_PACKED, 1, True), (0, sim.FMT_PACKED, 1, False), (0, sim.FMT_IDS24, 4, True),
            (0, sim.FMT_IDS24, 1, False), (0, sim.FMT_PACKED, 4, True),
            (1, sim.FMT_PACKED, 1, True), (1, sim.FMT_PACKED, 2, True), (1, sim.FMT_PACKED, 4, True),
-           (1, sim.FMT_IDS24, 1, True), (1, sim.FMT_IDS24, 2, True), (1, sim.FMT_IDS24, 4, True)]
+           (1, sim.FMT_IDS24, 1, True), (1, sim.FMT_IDS24, 2, True), (1, sim.FMT_IDS24, 4, True),
+           (2, sim.FMT_IDS24, 2, True)]            # variant 2: expand_ids24_x4_kernel (RGR_IDS24_X4)
 
 
 @pytest.mark.parametrize("case", sorted(CASES))
@@ -100,8 +101,8 @@ if HAVE_HYPOTHESIS:
 
     @settings(max_examples=40, deadline=None, suppress_health_check=list(HealthCheck))
     @given(lens=st.lists(run_len, min_size=1, max_size=150), tiles=st.sampled_from([1, 2, 4]), fmt=st.sampled_from([sim.FMT_PACKED, sim.FMT_IDS24]),
-           pair_lo=st.integers(0, 3), first=st.integers(0, 1 << 40), seed=st.integers(0, 1 << 16))
-    def test_lane_held_expansion_any_pair_list(lens, tiles, fmt, pair_lo, first, seed):
+           pair_lo=st.integers(0, 3), first=st.integers(0, 1 << 40), seed=st.integers(0, 1 << 16), x4=st.booleans())
+    def test_lane_held_expansion_any_pair_list(lens, tiles, fmt, pair_lo, first, seed, x4):
         total = 0
         kept = []
         for n in lens:                                   # at most ~30 tiles per example: the host run stays in the tens of milliseconds
@@ -110,6 +111,8 @@ if HAVE_HYPOTHESIS:
             kept.append(n); total += n
         rng = np.random.default_rng(seed)
         subs, src, off, lo, hi = make_case(rng, kept, pool=1 << 14, pair_lo=pair_lo, tail_pairs=1, first_off=first)
-        ids, _ = sim.expand_compact(1, fmt, tiles, subs, src, off, lo, hi)
+        if x4:
+            fmt, tiles = sim.FMT_IDS24, 2
+        ids, _ = sim.expand_compact(2 if x4 else 1, fmt, tiles, subs, src, off, lo, hi)
         want, _ = reference(fmt, subs, src, off, lo, hi)
         assert np.array_equal(ids, want)
