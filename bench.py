@@ -865,7 +865,8 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
                    "subscriptions": n_sub, "publishes": n_pub, "sharding": f"hash of the first {shard.KEY_LEVELS} levels x{world}" if world > 1 else "none",
                    "gather": args.gather if world > 1 else "n/a", "collective": collective,
                    "rccl_ranks": comm_info["ranks"] if comm_info and comm_info["transport"] == "rccl" else None,
-                   "dist_backend": args.dist_backend if world > 1 else "n/a", "windows_per_step": int(nwin)},
+                   "dist_backend": args.dist_backend if world > 1 else "n/a", "windows_per_step": int(nwin),
+                   "library": capi.lib().rgr_version().decode()},                 # names the expansion kernels the formats run on
         "hits_per_step": int(total_hits), "hits_per_s": round(total_hits * K / elapsed, 1),
         "mean_hits_per_topic": round(total_hits / max(1, total_topics), 2),
         "mean_visited_nodes_per_topic": round(st["visited_nodes"] / max(1, st["topics"]), 2),

@@ -731,7 +731,7 @@ extern "C" {
 
 const char* rgr_last_error(void) { return g_last_error.c_str(); }
 const char* rgr_version(void) {
-    static const std::string v = std::string("rmqtt_gpu_router 0.2 (gfx950; tuple expansion: ") + expand_tuple_kernel_name() + ")";
+    static const std::string v = std::string("rmqtt_gpu_router 0.2 (gfx950; tuple expansion: ") + expand_tuple_kernel_name() + "; ids24 expansion: " + expand_ids24_kernel_name() + ")";
     return v.c_str();
 }
 

@@ -754,6 +754,7 @@ __global__ __launch_bounds__(64 * kNodeWaves) void node_groups_kernel(const Tupl
 // ------------------------------------------------------------------------------ launchers
 uint32_t expand_tile_hits() { return kTile; }
 const char* expand_tuple_kernel_name() { return "expand_kernel"; }
+
 uint32_t scan_block_topics() { return kScanBlock; }
 
 void launch_scatter_edges(EdgeEntry* dst, const uint32_t* slots, const EdgeEntry* recs, uint32_t n, void* stream) {
@@ -891,6 +892,10 @@ void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, ui
 #ifndef RGR_COMPACT_LP_PACKED
 #define RGR_COMPACT_LP_PACKED 0
 #endif
+#define RGR_STR2(x) #x
+#define RGR_STR(x) RGR_STR2(x)
+#define RGR_COMPACT_LP_IDS24_NAME (RGR_COMPACT_LP_IDS24 ? "expand_compact_lp_kernel<ids24, " RGR_STR(RGR_COMPACT_LP_IDS24) ">" : "expand_compact_kernel<ids24>")
+const char* expand_ids24_kernel_name() { return RGR_COMPACT_LP_IDS24_NAME; }
 int compact_lp_tiles(int format) {
     const char* e = std::getenv("RGR_COMPACT_LP");
     const int v = e ? std::atoi(e) : format == kFmtIds24 ? RGR_COMPACT_LP_IDS24 : RGR_COMPACT_LP_PACKED;

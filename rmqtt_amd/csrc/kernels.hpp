@@ -266,6 +266,7 @@ void launch_node_groups(const Tuple* tuples, const uint64_t* hit_off, uint64_t h
 struct RunDesc { uint32_t shard, src, len, topic; };
 void launch_pack_runs(const uint32_t* src, const uint32_t* topic, const uint64_t* off, uint64_t n, uint32_t shard, RunDesc* out, void* stream);
 uint32_t expand_tile_hits();
+const char* expand_ids24_kernel_name();      // ... 3-byte-id windows by default (RGR_COMPACT_LP overrides per launch)
 const char* expand_tuple_kernel_name();      // which kernel expands plain 12-byte tuple windows (profilers see this name)
 uint32_t scan_block_topics();
 
