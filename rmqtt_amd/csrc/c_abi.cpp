@@ -189,6 +189,13 @@ struct rgr_batch {
     hipStream_t prep_stream = nullptr;
     hipEvent_t ev_windows_done = nullptr;   // recorded on `stream` after the last window launch of a chunk
     DevBuf tile_first, out, scan_tmp;
+    // RGR_TILES_FUSED=1 (A/B switch, not measured yet): the tile records of window k + 1 are written by extra blocks at the end of the
+    // grid that expands window k (two record buffers, window k uses buffer k & 1), so that consecutive expansions of a chunk follow each
+    // other without a tiles_kernel launch — and its gap — in between (~20 us of a 0.65 ms ids24 window).  No second stream, no events:
+    // the records are complete when the kernel that wrote them is.
+    DevBuf tile_buf[2];
+    struct TilePlan { bool valid = false; const void* chunk = nullptr; uint32_t lc = 0, le = 0; uint64_t hit_lo = 0, pair_lo = 0, pair_hi = 0; int slot = 0; } tile_plan;
+    uint32_t win_seq = 0;                // windows expanded so far in this pass
     DevBuf out2;                         // second window buffer (rgr_batch_run_to_host double-buffers)
     PinnedBuf h_ring[2];                 // pinned staging for streamed windows
     bool alt_out = false;                // next_window expands into out2 instead of out
@@ -1284,6 +1291,8 @@ int32_t rgr_batch_begin(rgr_batch* b) {
         b->in_pass = true;
         b->cursor = 0;
         b->hits_before = 0;
+        b->tile_plan.valid = false;
+        b->win_seq = 0;
         b->local.topics += b->n;
         b->local.invalid_topics += b->n - b->valid_topics;
         b->local.levels += b->valid_levels;
@@ -1346,11 +1355,47 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
             DevBuf& outbuf = b->alt_out ? b->out2 : b->out;
             const uint64_t ids_bytes = (nh * 4 + 255) & ~uint64_t(255);           // compact formats: sub ids, then the qos bytes
             outbuf.ensure(b->format == kFmtTuple ? nh * sizeof(Tuple) : b->format == kFmtIds24 ? nh * 3 + 16 : ids_bytes + (b->format == kFmtSoa ? nh + 16 : 0));
-            b->tile_first.ensure(((nh + T - 1) / T) * sizeof(TileRec));
             ChunkArrays ca = make_chunk_arrays(b, n);
-            size_t sp = b->span_begin(kSpanScan);
-            launch_tiles(ca, pair_lo, pair_hi, hit_lo, b->tile_first.as<TileRec>(), b->stream);
-            b->span_end(sp);
+            size_t sp;
+            const char* fused_env = std::getenv("RGR_TILES_FUSED");
+            const bool fused = fused_env && fused_env[0] == '1' && !b->deliver && b->format == kFmtIds24;
+            TileRec* tile_recs;
+            NextTiles next_tiles{};
+            rgr_batch::TilePlan next_plan;
+            if (fused) {
+                const int slot = int(b->win_seq & 1u);
+                const rgr_batch::TilePlan& tp = b->tile_plan;
+                if (!(tp.valid && tp.chunk == b->c && tp.lc == lc && tp.le == le && tp.hit_lo == hit_lo && tp.pair_lo == pair_lo && tp.pair_hi == pair_hi && tp.slot == slot)) {
+                    b->tile_buf[slot].ensure(((nh + T - 1) / T) * sizeof(TileRec));         // (first window of a chunk, or a plan that does not fit)
+                    sp = b->span_begin(kSpanScan);
+                    launch_tiles(ca, pair_lo, pair_hi, hit_lo, b->tile_buf[slot].as<TileRec>(), b->stream);
+                    b->span_end(sp);
+                }
+                b->tile_plan.valid = false;
+                tile_recs = b->tile_buf[slot].as<TileRec>();
+                if (b->c->host_arrays && le < n) {             // the next window of this chunk: planned now, its records ride on this window's expansion
+                    const uint64_t* ho = b->c->h_hit_off.as<uint64_t>();
+                    const uint64_t* pb = b->c->h_pair_base.as<uint64_t>();
+                    uint32_t nle;
+                    if (ho[n] - ho[le] <= cap) nle = n;
+                    else {
+                        nle = uint32_t(std::upper_bound(ho + le, ho + n + 1, ho[le] + cap) - ho) - 1;
+                        if (nle <= le) nle = le + 1;
+                    }
+                    if (ho[nle] > ho[le] && pb[nle] > pb[le]) {
+                        b->tile_buf[slot ^ 1].ensure(((ho[nle] - ho[le] + T - 1) / T) * sizeof(TileRec));
+                        next_tiles = NextTiles{pb[le], pb[nle], ho[le], b->tile_buf[slot ^ 1].as<TileRec>()};
+                        next_plan.valid = true; next_plan.chunk = b->c; next_plan.lc = le; next_plan.le = nle;
+                        next_plan.hit_lo = ho[le]; next_plan.pair_lo = pb[le]; next_plan.pair_hi = pb[nle]; next_plan.slot = slot ^ 1;
+                    }
+                }
+            } else {
+                b->tile_first.ensure(((nh + T - 1) / T) * sizeof(TileRec));
+                sp = b->span_begin(kSpanScan);
+                launch_tiles(ca, pair_lo, pair_hi, hit_lo, b->tile_first.as<TileRec>(), b->stream);
+                b->span_end(sp);
+                tile_recs = b->tile_first.as<TileRec>();
+            }
             // delivery stage: fused into the expansion; v5 hits additionally go through the per-client dedup
             DeliverArgs da{};
             const bool dedup = b->deliver && !b->retain && b->epoch->n_v5 > 0 && b->epoch->view.attrs != nullptr;
@@ -1375,12 +1420,13 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
             }
             sp = b->span_begin(kSpanExpand);
             if (b->format == kFmtTuple)
-                launch_expand(batch_view(b), ca, pair_lo, pair_hi, hit_lo, hit_hi, b->tile_first.as<TileRec>(), outbuf.as<Tuple>(), b->stream,
+                launch_expand(batch_view(b), ca, pair_lo, pair_hi, hit_lo, hit_hi, tile_recs, outbuf.as<Tuple>(), b->stream,
                               (b->deliver && !b->retain) ? &da : nullptr);
-            else
-                launch_expand_compact(batch_view(b), ca, pair_lo, pair_hi, hit_lo, hit_hi, b->tile_first.as<TileRec>(), b->format,
-                                      outbuf.as<uint32_t>(), outbuf.as<uint8_t>() + ids_bytes, b->stream);
+            else if (launch_expand_compact(batch_view(b), ca, pair_lo, pair_hi, hit_lo, hit_hi, tile_recs, b->format,
+                                           outbuf.as<uint32_t>(), outbuf.as<uint8_t>() + ids_bytes, b->stream, next_tiles.out ? &next_tiles : nullptr))
+                b->tile_plan = next_plan;                      // the expansion wrote the next window's records as well
             b->span_end(sp);
+            b->win_seq++;
             // the chunk's accounting charged 20 B per hit (8 read + 12 written); the compact formats write 5 / 4
             if (b->format != kFmtTuple) b->local.alg_bytes_expand -= nh * (b->format == kFmtSoa ? 7 : b->format == kFmtIds24 ? 9 : 8);
             b->local.expand_launches++;

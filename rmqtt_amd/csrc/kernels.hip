@@ -902,9 +902,9 @@ int compact_lp_tiles(int format) {
     return v <= 0 ? 0 : v == 1 ? 1 : v < 4 ? 2 : 4;
 }
 
-void launch_expand_compact(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint64_t hit_hi,
-                           const TileRec* tile_first, int format, uint32_t* out_ids, uint8_t* out_qos, void* stream) {
-    if (hit_hi <= hit_lo) return;
+bool launch_expand_compact(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint64_t hit_hi,
+                           const TileRec* tile_first, int format, uint32_t* out_ids, uint8_t* out_qos, void* stream, const NextTiles* next) {
+    if (hit_hi <= hit_lo) return false;
     const uint32_t ntiles = uint32_t((hit_hi - hit_lo + kTile - 1) / kTile);
     hipStream_t s = static_cast<hipStream_t>(stream);
     static const bool no_packed_reads = std::getenv("RGR_NO_PACKED_READS") != nullptr;       // A/B switch: 8-byte entry loads as in r3
@@ -917,21 +917,29 @@ void launch_expand_compact(const TrieView& t, const ChunkArrays& c, uint64_t pai
         const char* x4 = std::getenv("RGR_IDS24_X4");
         if (x4 && x4[0] == '1') {
             expand_ids24_x4_kernel<<<(ntiles + 1) / 2, kCompactThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out_ids, out_qos, pk);
-            return;
+            return false;
         }
     }
     const int lp = compact_lp_tiles(format);
+    if (next && next->out && lp == 1 && pk && format == kFmtIds24 && next->pair_hi > next->pair_lo) {
+        // RGR_TILES_FUSED: the lane-held IDS24 expansion (one tile per block) followed, in the same grid, by the blocks that write the
+        // NEXT window's tile records
+        const uint32_t nb_tiles = uint32_t((next->pair_hi - next->pair_lo + kCompactThreads - 1) / kCompactThreads);
+        expand_ids24_lp_tiles_kernel<<<ntiles + nb_tiles, kCompactThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out_ids, out_qos, pk, *next);
+        return true;
+    }
     if (lp && pk && (format == kFmtIds24 || format == kFmtPacked)) {
         const uint32_t nb = (ntiles + uint32_t(lp) - 1) / uint32_t(lp);
 #define RGR_LP_LAUNCH(F, TT) expand_compact_lp_kernel<F, TT><<<nb, kCompactThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out_ids, out_qos, pk)
         if (format == kFmtIds24) { if (lp == 1) RGR_LP_LAUNCH(kFmtIds24, 1); else if (lp == 2) RGR_LP_LAUNCH(kFmtIds24, 2); else RGR_LP_LAUNCH(kFmtIds24, 4); }
         else { if (lp == 1) RGR_LP_LAUNCH(kFmtPacked, 1); else if (lp == 2) RGR_LP_LAUNCH(kFmtPacked, 2); else RGR_LP_LAUNCH(kFmtPacked, 4); }
 #undef RGR_LP_LAUNCH
-        return;
+        return false;
     }
     if (format == kFmtIds24) expand_compact_kernel<kFmtIds24, kIds24Tiles><<<nb24, kCompactThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out_ids, out_qos, pk);
     else if (format == kFmtPacked) expand_compact_kernel<kFmtPacked, kCompactTiles><<<nb1, kCompactThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out_ids, out_qos, pk);
     else expand_compact_kernel<kFmtSoa, kCompactTiles><<<nb1, kCompactThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out_ids, out_qos, nullptr);
+    return false;
 }
 
 void launch_pack_subs(const SubEntry* subs, uint64_t n, uint32_t* packed, void* stream) {

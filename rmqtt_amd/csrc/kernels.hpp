@@ -245,8 +245,11 @@ constexpr int kFmtTuple = 0, kFmtSoa = 1, kFmtPacked = 2, kFmtRuns = 3, kFmtIds2
 // packed[i] = subs[i].sub_id | (subs[i].qos_flags & 3) << 30 for i in [0, n)
 constexpr uint32_t kPackedPad = 16;      // entries allocated past the end of a packed side array (never read for their value)
 void launch_pack_subs(const SubEntry* subs, uint64_t n, uint32_t* packed, void* stream);
-void launch_expand_compact(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint64_t hit_hi,
-                           const TileRec* tile_first, int format, uint32_t* out_ids, uint8_t* out_qos, void* stream);
+// RGR_TILES_FUSED: the pair range of the NEXT window of the chunk and where its tile records go (written by extra blocks of the expansion)
+struct NextTiles { uint64_t pair_lo, pair_hi, hit_lo; TileRec* out; };
+// -> true when `next` was given AND its records were written by this launch (only the lane-held IDS24 expansion does that)
+bool launch_expand_compact(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint64_t hit_hi,
+                           const TileRec* tile_first, int format, uint32_t* out_ids, uint8_t* out_qos, void* stream, const NextTiles* next = nullptr);
 // v5 per-client dedup over a window's candidates (match_core.hpp: LDS tile tables + LDS topic tables): first position per
 // (topic, client) wins, every other candidate gets kHitV5Dup.  hit_off points at the window's first topic (chunk-local
 // offsets, hit_lo = the window's first position); nt = topics of the window; items must hold

@@ -44,6 +44,8 @@ def lib():
         vp, i32, u64 = C.c_void_p, C.c_int32, C.c_uint64
         L.sim_expand_compact.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, u64, u64, vp, vp]
         L.sim_expand_compact.restype = i32
+        L.sim_expand_ids24_fused.argtypes = [vp, vp, vp, vp, vp, u64, u64, u64, vp]
+        L.sim_expand_ids24_fused.restype = C.c_int64
         _LIB = L
     return _LIB
 
@@ -77,6 +79,25 @@ def expand_compact(variant, fmt, tiles_per_block, subs, pair_src, pair_off, pair
         return body.view(np.uint32).copy(), qos[guard:guard + hits].copy()
     assert (qos == 0xA5).all(), "qos bytes written by a format that has none"
     return (body.copy() if fmt == FMT_IDS24 else body.view(np.uint32).copy()), None
+
+
+def expand_ids24_fused(subs, pair_src, pair_off, pair_lo, pair_mid, pair_hi):
+    """expand_ids24_lp_tiles_kernel (RGR_TILES_FUSED): the window [pair_lo, pair_mid) expanded to 3-byte ids while the tail blocks of
+    the same grid write the tile records of [pair_mid, pair_hi).  -> (ids bytes, differing records of the next window)."""
+    subs = np.ascontiguousarray(subs, dtype=SUB_DTYPE)
+    pair_src = np.ascontiguousarray(pair_src, dtype=np.uint32)
+    pair_off = np.ascontiguousarray(pair_off, dtype=np.uint64)
+    pair_topic = np.arange(len(pair_src), dtype=np.uint32)
+    packed = np.zeros(len(subs) + 16, dtype=np.uint32)
+    packed[:len(subs)] = subs["sub_id"] | ((subs["qos_flags"] & 3) << 30)
+    hits = int(pair_off[pair_mid] - pair_off[pair_lo])
+    out = np.full(hits * 3 + 64, 0xA5, dtype=np.uint8)
+    d = lib().sim_expand_ids24_fused(subs.ctypes.data, packed.ctypes.data, pair_src.ctypes.data, pair_topic.ctypes.data, pair_off.ctypes.data,
+                                     pair_lo, pair_mid, pair_hi, out.ctypes.data)
+    if d == -2:
+        raise AssertionError("hipsim: divergence in expand_ids24_lp_tiles_kernel")
+    assert (out[hits * 3:] == 0xA5).all(), "write past the window's ids"
+    return out[:hits * 3].copy(), int(d)
 
 
 # ---------------------------------------------------------------------------------------------- v5 per-client dedup (dedup.inc)

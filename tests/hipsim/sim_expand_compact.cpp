@@ -65,4 +65,27 @@ int32_t sim_expand_compact(int32_t variant, int32_t fmt, int32_t tiles_per_block
     return converged ? 0 : -2;         // -2: lanes of a wave (or threads of a block) took different paths around a convergent operation
 }
 
+// RGR_TILES_FUSED: expand_ids24_lp_tiles_kernel over the window [pair_lo, pair_mid) while its tail blocks write the tile records of the
+// next window [pair_mid, pair_hi).  Returns the number of those records that differ from tiles_pair_rec on the host (0 = equal), -2 on
+// divergence; out_ids receives the first window's 3-byte ids.
+int64_t sim_expand_ids24_fused(const SubEntry* subs, const uint32_t* packed, const uint32_t* pair_src, const uint32_t* pair_topic, const uint64_t* pair_off,
+                               uint64_t pair_lo, uint64_t pair_mid, uint64_t pair_hi, uint32_t* out_ids) {
+    ChunkArrays c{};
+    c.pair_src = const_cast<uint32_t*>(pair_src);
+    c.pair_topic = const_cast<uint32_t*>(pair_topic);
+    c.pair_off = const_cast<uint64_t*>(pair_off);
+    const uint64_t hit_lo = pair_off[pair_lo], hit_hi = pair_off[pair_mid], nhit_hi = pair_off[pair_hi];
+    const uint32_t ntiles = uint32_t((hit_hi - hit_lo + kTile - 1) / kTile), ntiles_next = uint32_t((nhit_hi - hit_hi + kTile - 1) / kTile);
+    std::vector<TileRec> rec(ntiles), want(ntiles_next, TileRec{0xDEADBEEF, 0, 0, 0}), got(ntiles_next, TileRec{0xDEADBEEF, 0, 0, 0});
+    for (uint64_t p = pair_lo; p < pair_mid; ++p) tiles_pair_rec(c, p, pair_lo, hit_lo, kTile, rec.data());
+    for (uint64_t p = pair_mid; p < pair_hi; ++p) tiles_pair_rec(c, p, pair_mid, hit_hi, kTile, want.data());
+    const NextTiles nx{pair_mid, pair_hi, hit_hi, got.data()};
+    const uint32_t nb_tiles = uint32_t((pair_hi - pair_mid + kCompactThreads - 1) / kCompactThreads);
+    const TileRec* tf = rec.data();
+    const bool ok = hipsim::run(ntiles + nb_tiles, kCompactThreads, [&] { expand_ids24_lp_tiles_kernel(subs, c, pair_lo, pair_mid, hit_lo, hit_hi, tf, ntiles, out_ids, nullptr, packed, nx); });
+    int64_t diff = 0;
+    for (uint32_t k = 0; k < ntiles_next; ++k) diff += got[k].first != want[k].first || got[k].src != want[k].src || got[k].topic != want[k].topic || got[k].qr != want[k].qr;
+    return ok ? diff : -2;
+}
+
 }  // extern "C"

@@ -309,4 +309,9 @@ def test_lane_held_expansion_equals_tile_kernel(window_hits, monkeypatch):
         for (_, _, _, t, _), (_, _, _, a, _) in zip(ref, got):
             assert np.array_equal(a, t["sub_id"]), "RGR_IDS24_X4"
         monkeypatch.delenv("RGR_IDS24_X4")
+        monkeypatch.setenv("RGR_TILES_FUSED", "1")       # the next window's tile records written by the tail blocks of this window's expansion
+        got = windows(batch, capi.RGR_FORMAT_IDS24)
+        for (_, _, _, t, _), (_, _, _, a, _) in zip(ref, got):
+            assert np.array_equal(a, t["sub_id"]), "RGR_TILES_FUSED"
+        monkeypatch.delenv("RGR_TILES_FUSED")
     batch.close(); r.close()

@@ -116,3 +116,16 @@ if HAVE_HYPOTHESIS:
         ids, _ = sim.expand_compact(2 if x4 else 1, fmt, tiles, subs, src, off, lo, hi)
         want, _ = reference(fmt, subs, src, off, lo, hi)
         assert np.array_equal(ids, want)
+
+
+@pytest.mark.parametrize("case", ["config3_like", "mid_fanout", "lane_list_full", "short_runs"])
+def test_fused_tile_records_of_the_next_window(case):
+    """RGR_TILES_FUSED: the lane-held IDS24 expansion of a window and, in the same grid, the tile records of the chunk's next window
+    (what tiles_kernel would have written for it)."""
+    rng = np.random.default_rng(sum(map(ord, case)) + 1)
+    subs, src, off, lo, hi = CASES[case](rng)
+    mid = lo + max(1, (hi - lo) * 2 // 3)
+    ids, bad_records = sim.expand_ids24_fused(subs, src, off, lo, mid, hi)
+    want, _ = reference(sim.FMT_IDS24, subs, src, off, lo, mid)
+    assert np.array_equal(ids, want)
+    assert bad_records == 0
