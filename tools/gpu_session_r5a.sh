@@ -11,8 +11,9 @@ D="X=0,RGR_DEDUP_PIPE=1,RGR_DELIVER_EARLY=1,RGR_DEDUP_PIPE=1+RGR_DELIVER_EARLY=1
 timeout 400 python bench.py --time-format deliver --steps 3 --warmup 1 --ab-env "$D" > $O/ab_deliver.jsonl 2> $O/ab_deliver.err; echo "deliver rc=$?"
 # 3. batched preparation under the compact formats and the tuple headline
 timeout 300 python bench.py --time-format ids24,packed,tuple --steps 4 --warmup 2 --ab-env "X=0,RGR_PREP_BATCH=1" > $O/ab_prep.jsonl 2> $O/ab_prep.err; echo "prep rc=$?"
-# 3b. IDS24 through 16-byte stores; tile records of the next window fused into the expansion
-timeout 200 python bench.py --time-format ids24 --steps 5 --warmup 2 --ab-env "X=0,RGR_IDS24_X4=1,RGR_TILES_FUSED=1,RGR_TILES_FUSED=1+RGR_PREP_BATCH=1,RGR_COMPACT_LP=2,RGR_COMPACT_LP=0" > $O/ab_ids24_x4.jsonl 2> $O/ab_ids24_x4.err; echo "x4 rc=$?"
+# 3b. IDS24 through 16-byte stores; tile records of the next window fused into the expansion (last: its host-side window plan is the one
+#     piece of new code no test has run — a fault there must not cost the other variants their numbers)
+timeout 200 python bench.py --time-format ids24 --steps 5 --warmup 2 --ab-env "X=0,RGR_IDS24_X4=1,RGR_COMPACT_LP=2,RGR_COMPACT_LP=0,RGR_TILES_FUSED=1,RGR_TILES_FUSED=1+RGR_PREP_BATCH=1" > $O/ab_ids24_x4.jsonl 2> $O/ab_ids24_x4.err; echo "x4 rc=$?"
 # 4. the lane-held IDS24 kernel where every tile holds many runs (config 3 at 1/10 scale: ~100 hits per run)
 timeout 200 python bench.py --scale 0.1 --time-format ids24 --steps 6 --warmup 2 --ab-env "RGR_COMPACT_LP=0,RGR_COMPACT_LP=1,RGR_COMPACT_LP=4" > $O/ab_lp_scale0.1.jsonl 2> $O/ab_lp_scale0.1.err; echo "scale0.1 rc=$?"
 python - <<'PY'
