@@ -1404,6 +1404,126 @@ def self_launch(args):
     return p.wait()
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The ONE stdout line.  Round 4's driver run (BENCH_r04.json) printed a 27 KB line — every record in full, with its prose notes — and
+# the driver's parser returned `parsed: null` for it (round 3's 18.7 KB line still parsed).  The stdout line is now the contract's
+# keys + the numbers of every record (a few KB); the full record (all notes, samples, per-format detail) goes to
+# gpurun_out/bench_detail_n<N>.json and, as one `[bench detail]` line, to stderr.
+# ---------------------------------------------------------------------------------------------------------------------------------
+LINE_BUDGET = 8000
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+def _short(s, n=90):
+    return s if not isinstance(s, str) or len(s) <= n else s[: n - 1] + "\u2026"
+
+def compact_roofline(r):
+    if not isinstance(r, dict):
+        return r
+    out = _pick(r, ["bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launches", "avg_launch_ms", "alg_bytes_per_launch",
+                    "alg_achieved", "alg_frac", "frac_stores_only", "hits_per_launch", "per_rank"])
+    if "traffic_source" in r:
+        out["traffic_source"] = _short(r["traffic_source"], 60)
+    return out
+
+def compact_cpu_baseline(c):
+    if not isinstance(c, dict):
+        return c
+    out = _pick(c, ["value", "unit", "cores", "kind"])
+    if "sample" in c:
+        out["sample"] = _short(str(c["sample"]), 110)
+    if isinstance(c.get("single_thread"), dict):
+        out["single_thread"] = c["single_thread"].get("value")
+    return out
+
+def compact_parity(p):
+    if not isinstance(p, dict):
+        return p
+    out = _pick(p, ["ok", "topics", "exhaustive", "hits", "formats", "oracle_s", "windows_checked", "of_windows", "mismatching_words", "every_topic_owned_exactly_once"])
+    if isinstance(p.get("oracle_cross_check"), dict):
+        out["oracle_cross_check"] = _pick(p["oracle_cross_check"], ["ok", "topics", "hits"])
+    if isinstance(p.get("oracle_sample"), dict):
+        out["oracle_sample"] = _pick(p["oracle_sample"], ["ok", "topics", "hits"])
+    return out
+
+def compact_formats(fl):
+    out = []
+    for f in fl or []:
+        e = {"format": str(f.get("format", "")).split(":")[0].split(" ")[0]}
+        e.update(_pick(f, ["bytes_written_per_hit", "value", "ms_per_step", "expand_avg_launch_ms", "expand_store_GBps", "frac_of_hbm_peak_stores_kernel"]))
+        out.append(e)
+    return out
+
+def compact_record(r, top):
+    if "error" in r:
+        return {"config": r.get("config"), "error": _short(r["error"], 200)}
+    keys = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"]
+    out = _pick(r, keys if top else ["metric", "value", "unit", "steps", "warmup", "ms_per_step"])
+    cfg = r.get("config") or {}
+    out["config"] = dict(cfg) if top else {"workload": _short(str(cfg.get("workload", "")), 60)}
+    out.update(_pick(r, ["hits_per_step", "hits_per_s", "kernel_ms_per_step", "pcie_inclusive_matches_per_s", "shard_hits", "shard_imbalance",
+                         "value_blocking_callers", "value_async_submit", "vs_cpu_port", "threads"]))
+    if top:
+        out.update(_pick(r, ["table", "mean_hits_per_topic"]))
+        if isinstance(r.get("h2d_inclusive"), dict):
+            out["h2d_inclusive_matches_per_s"] = r["h2d_inclusive"].get("matches_per_s")
+    if "roofline" in r:
+        out["roofline"] = compact_roofline(r["roofline"])
+        if not top:
+            out["roofline"] = _pick(out["roofline"], ["bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launches", "avg_launch_ms", "alg_bytes_per_launch"])
+    if "cpu_baseline" in r:
+        out["cpu_baseline"] = compact_cpu_baseline(r["cpu_baseline"])
+        if not top and isinstance(out["cpu_baseline"], dict):
+            out["cpu_baseline"].pop("sample", None)
+    if "cpu_reference_port" in r:
+        out["cpu_baseline"] = _pick(r["cpu_reference_port"], ["value", "threads", "kind"])
+    if "parity_sample" in r:
+        out["parity_sample"] = compact_parity(r["parity_sample"])
+    if r.get("compact_formats"):
+        cf = compact_formats(r["compact_formats"])
+        out["compact_formats"] = cf if top else {e["format"]: e.get("value") for e in cf}
+    if isinstance(r.get("pcie_inclusive_ranges"), dict):
+        out["pcie_inclusive_ranges_matches_per_s"] = r["pcie_inclusive_ranges"].get("matches_per_s")
+    if isinstance(r.get("delivery_stage"), dict):
+        out["delivery_stage"] = _pick(r["delivery_stage"], ["v5_fraction", "dedup_ms_per_step"])
+    if isinstance(r.get("gpu_async"), list) and r["gpu_async"]:
+        out["latency_us"] = r["gpu_async"][0].get("latency_us")
+    return out
+
+def compact_line(rec, detail_path=None):
+    out = compact_record(rec, True)
+    if rec.get("secondary"):
+        out["secondary"] = [compact_record(s, False) for s in rec["secondary"]]
+    if detail_path:
+        out["detail"] = detail_path
+    line = json.dumps(out, separators=(", ", ": "))
+    if len(line) > LINE_BUDGET and "secondary" in out:        # never let a long line cost the headline: shed secondary detail first
+        for s in out["secondary"]:
+            for k in ("cpu_baseline", "compact_formats", "kernel_ms_per_step", "config", "latency_us", "delivery_stage"):
+                s.pop(k, None)
+        line = json.dumps(out, separators=(", ", ": "))
+    if len(line) > LINE_BUDGET:
+        out.pop("secondary", None); out.pop("table", None)
+        line = json.dumps(out, separators=(", ", ": "))
+    return line
+
+def emit_line(rec, args):
+    """Full record -> gpurun_out/bench_detail_n<N>.json + one stderr line; compact record -> the one stdout line."""
+    detail_path = None
+    try:
+        ddir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpurun_out")
+        os.makedirs(ddir, exist_ok=True)
+        detail_path = os.path.join("gpurun_out", f"bench_detail_n{rec.get('n_gpus', 1)}.json")
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), detail_path), "w") as f:
+            json.dump(rec, f)
+    except OSError as e:
+        log(f"bench detail file not written: {e!r}")
+        detail_path = None
+    print("[bench detail] " + json.dumps(rec), file=sys.stderr, flush=True)
+    print(compact_line(rec, detail_path), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1530,7 +1650,7 @@ def main():
     if secondary:
         rec["secondary"] = secondary
 
-    print(json.dumps(rec), flush=True)
+    emit_line(rec, args)
     bad = [r_ for r_ in [rec] + secondary if isinstance(r_.get("parity_sample"), dict) and not r_["parity_sample"]["ok"]]
     if bad:
         log("PARITY SAMPLE FAILED: the GPU's tuples differ from the oracle's")

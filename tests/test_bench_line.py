@@ -1,0 +1,73 @@
+"""bench.py's ONE stdout line stays small enough for the driver's parser and keeps the contract's keys.
+
+Round 4's driver run printed the full record (27 KB) and BENCH_r04.json recorded `parsed: null`; the line is now the compact record
+(bench.compact_line) and the full record goes to gpurun_out/bench_detail_n<N>.json.  The fixture is the full record of round 4's default
+run (profiles/r04i_bench_default.json)."""
+import importlib.util
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FULL = os.path.join(ROOT, "profiles", "r04i_bench_default.json")
+
+CONTRACT = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"]
+
+
+@pytest.fixture(scope="module")
+def bench():
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def strict_loads(s):
+    def bad(c):
+        raise ValueError(f"non-standard JSON constant {c}")
+    return json.loads(s, parse_constant=bad)
+
+
+def test_compact_line_of_the_full_default_record(bench):
+    full = json.load(open(FULL))
+    line = bench.compact_line(full, "gpurun_out/bench_detail_n1.json")
+    assert "\n" not in line
+    assert len(line) <= bench.LINE_BUDGET
+    d = strict_loads(line)
+    for k in CONTRACT:
+        assert k in d and d[k] == full[k], k
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert r[k] == full["roofline"][k]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c
+    assert d["parity_sample"]["ok"] is True and d["parity_sample"]["exhaustive"] is True
+    assert d["parity_sample"]["topics"] == full["config"]["publishes"]
+    assert [f["format"] for f in d["compact_formats"]] == ["soa", "packed", "ids24", "runs"]
+    assert len(d["secondary"]) == len(full["secondary"])
+    for s, fs in zip(d["secondary"], full["secondary"]):
+        assert s["value"] == fs["value"] and s["metric"] == fs["metric"]
+        if "roofline" in fs:
+            assert s["roofline"]["frac"] == fs["roofline"]["frac"]
+        if "cpu_baseline" in fs:
+            assert s["cpu_baseline"]["value"] == fs["cpu_baseline"]["value"]
+
+
+def test_compact_line_sheds_secondary_detail_before_it_outgrows_the_budget(bench):
+    full = json.load(open(FULL))
+    full["secondary"] = full["secondary"] * 6          # far more than any run produces
+    line = bench.compact_line(full, None)
+    assert len(line) <= bench.LINE_BUDGET
+    d = strict_loads(line)
+    for k in CONTRACT + ["roofline", "cpu_baseline", "parity_sample"]:
+        assert k in d
+
+
+def test_error_secondary_survives(bench):
+    full = json.load(open(FULL))
+    full["secondary"] = [{"config": {"workload": "x"}, "error": "RuntimeError('boom')"}]
+    d = strict_loads(bench.compact_line(full, None))
+    assert d["secondary"][0]["error"].startswith("RuntimeError")
