@@ -831,13 +831,15 @@ void launch_pairs_dense(const TrieView& t, const ChunkArrays& c, const uint64_t*
     else pairs_dense_kernel<false><<<(c.n + 255) / 256, 256, 0, s>>>(t, c, off, out);
 }
 
-static bool prep_batched() { const char* e = std::getenv("RGR_PREP_BATCH"); return e && e[0] == '1'; }
+// count / compact with their gathers in batches (prep_batched.inc) are the default since r5a: 7.7 -> 6.0 ms of preparation per 10 M topics at
+// config 3, ids24 105.9 -> 108.1 M matches/s, packed 88.6 -> 90.1 M, tuples 30.39 -> 30.50 M, all digests equal
+// (profiles/r05a_ab_prep.jsonl).  RGR_PREP_BATCH=0 (read per launch) selects the one-gather-at-a-time kernels.
+static bool prep_batched() { const char* e = std::getenv("RGR_PREP_BATCH"); return !(e && e[0] == '0'); }
 
 void launch_count(const TrieView& t, const ChunkArrays& c, void* stream) {
     if (c.n == 0) return;
     hipStream_t s = static_cast<hipStream_t>(stream);
     (void)hipMemsetAsync(c.big_count, 0, 4, s);
-    // RGR_PREP_BATCH=1 (A/B switch, read per launch): count / compact with their gathers in batches (prep_batched.inc)
     if (prep_batched()) count_batched_kernel<<<(c.n + 255) / 256, 256, 0, s>>>(t, c);
     else count_kernel<<<(c.n + 255) / 256, 256, 0, s>>>(t, c);
     count_big_kernel<<<512, 256, 0, s>>>(t, c);
@@ -873,9 +875,11 @@ void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, ui
     hipStream_t s = static_cast<hipStream_t>(stream);
     // the plain kernel runs 1024 x 2 (with the single-run fast path: +3 % over 512 x 4, profiles/r02f_sweep_*); the delivery
     // variant keeps 512 x 4 — its per-wave candidate bookkeeping was 19 % slower at 1024 x 2 (profiles/r02g_bench_config3_deliver_*)
-    // RGR_DELIVER_EARLY=1 (A/B switch, read per launch): the delivery variant with its loads issued early (expand_tuple.inc)
+    // the delivery variant with its loads issued early (expand_tuple.inc) is the default since r5a: 0.876 -> 0.860 ms per 2^28-hit window,
+    // 13.82 -> 14.03 M matches/s, whole-window delivery parity ok (profiles/r05a_ab_deliver.jsonl).  RGR_DELIVER_EARLY=0 (read per
+    // launch) selects expand_kernel<true>.
     const char* early = deliver ? std::getenv("RGR_DELIVER_EARLY") : nullptr;
-    if (early && early[0] == '1') expand_deliver_early_kernel<kTile / 4, 4><<<ntiles, kTile / 4, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, *deliver);
+    if (deliver && !(early && early[0] == '0')) expand_deliver_early_kernel<kTile / 4, 4><<<ntiles, kTile / 4, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, *deliver);
     else if (deliver) expand_kernel<true, kTile / 4, 4><<<ntiles, kTile / 4, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, *deliver);
     else expand_kernel<false, kExpandThreads, kExpandPerThread><<<ntiles, kExpandThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, DeliverArgs{});
 }

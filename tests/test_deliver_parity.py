@@ -236,17 +236,23 @@ def test_v5_dedup_topics_spanning_tiles_in_parts(kind, test_slots, monkeypatch):
     w.check(14)
 
 
+SWITCH_SETS = {
+    # the kernels that were the defaults until the r5a session measured their replacements (profiles/r05a_ab_*.jsonl)
+    "r4_defaults": {"RGR_DELIVER_EARLY": "0", "RGR_PREP_BATCH": "0", "RGR_DELIVER_OVERLAP": "0"},
+    # measured and not adopted: the software-pipelined topic pass, 2^30-hit delivery windows
+    "dedup_pipe": {"RGR_DEDUP_PIPE": "1", "RGR_DELIVER_WINDOW_HITS": str(1 << 30)},
+}
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("test_slots", [0, 64])
-@pytest.mark.skipif(not os.environ.get("RMQTT_TEST_EXPERIMENTAL"), reason="A/B variants that no GPU session has measured yet: RMQTT_TEST_EXPERIMENTAL=1")
-def test_v5_dedup_pipelined_topic_pass(test_slots, monkeypatch):
-    """RGR_DEDUP_PIPE=1: the software-pipelined topic pass (dedup_topic_pipe_kernel, dedup.inc; host twin tests/test_hipsim_dedup.py),
-    RGR_DELIVER_EARLY=1: the delivery expansion with its loads issued early (expand_deliver_early_kernel, expand_tuple.inc; host twin
-    tests/test_hipsim_expand_tuple.py) on the worlds of the two tests above, plus larger delivery windows (RGR_DELIVER_WINDOW_HITS)."""
-    monkeypatch.setenv("RGR_DEDUP_PIPE", "1")
-    monkeypatch.setenv("RGR_DELIVER_EARLY", "1")
-    monkeypatch.setenv("RGR_PREP_BATCH", "1")          # count / compact with their gathers in batches (prep_batched.inc; tests/test_hipsim_prep.py)
-    monkeypatch.setenv("RGR_DELIVER_WINDOW_HITS", str(1 << 30))
+@pytest.mark.parametrize("switches", sorted(SWITCH_SETS))
+def test_v5_dedup_under_the_library_switches(switches, test_slots, monkeypatch):
+    """The worlds of the two tests above under the library's environment switches (read per launch / per pass): the round-4 default
+    kernels (expand_kernel<true>, count_kernel / compact_kernel one gather at a time, dedup in stream order) and the variants that
+    were measured and not adopted (dedup_topic_pipe_kernel, dedup.inc; host twin tests/test_hipsim_dedup.py)."""
+    for k, v in SWITCH_SETS[switches].items():
+        monkeypatch.setenv(k, v)
     test_v5_dedup_topics_spanning_tiles_in_parts("hip", test_slots, monkeypatch)
     test_v5_dedup_many_candidates("hip")
 

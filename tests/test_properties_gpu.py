@@ -237,6 +237,59 @@ def test_delivery_stage_properties_at_scale():
     assert np.array_equal(batch.window_to_host(w)[0]["qos_flags"], plain[0]["qos_flags"])
 
 
+def test_delivery_windows_device_resident_equal_host_out(monkeypatch):
+    """Device-resident delivery passes over small windows and small chunks — several windows per chunk, several chunks, passes
+    abandoned midway and begun again (buffers reused) — equal the host-out call, whose delivery words tests/test_deliver_parity.py
+    pins on the oracle's forwards().  Written for the r5b experiment (the v5 dedup of window k on a second stream beside the
+    expansion of window k + 1: correct, no gain — both kernels are bound by the waves a CU holds; tools/dropped/r5b_*.patch);
+    RGR_DELIVER_OVERLAP is not read by the library any more, the test keeps both passes."""
+    cfg = 3
+    c = wl.CONFIGS[cfg]
+    n_sub, n_pub = 60_000, 9_000
+    blob, offs, client, qos = wl.gen_subs(n_sub, wl.SUB_SEED + cfg, c["p_plus"], c["p_hash"], c["p_sys"])
+    tb, to = wl.gen_topics(n_pub, wl.PUB_SEED + cfg, 0.01, c["p_blank"])
+    rng = np.random.default_rng(11)
+    v5 = rng.random(n_sub) < 0.4
+    flags = (v5 * capi.RGR_SUB_V5 | (v5 & (rng.random(n_sub) < 0.3)) * capi.RGR_SUB_NO_LOCAL |
+             (v5 & (rng.random(n_sub) < 0.5)) * capi.RGR_SUB_RAP).astype(np.uint8)
+    client = (client.astype(np.uint32) % 5000).astype(np.uint32)          # few clients: many duplicates per topic
+    r = capi.Router(device=0, window_hits=60_000, chunk_topics=2_000)
+    assert r.subscribe_bulk(blob, offs, None, qos, flags) == 0
+    r.sub_attrs_bulk(client, client)
+    r.commit()
+    attrs = np.zeros(n_pub, dtype=capi.PUBLISH_ATTR_DTYPE)
+    attrs["from_id"] = rng.choice(client, size=n_pub)
+    attrs["qos_retain"] = rng.integers(0, 3, size=n_pub) | (rng.integers(0, 2, size=n_pub) << 2)
+    host = r.match_batch_deliver(tb, to, attrs)
+    assert (host["tuples"]["qos_flags"] & capi.RGR_HIT_V5_DUP).any()
+    batch = r.batch(tb, to)
+    batch.set_publish_attrs(attrs)
+
+    def device_pass(stop_after=None):
+        parts, ranges = [], []
+        batch.begin()
+        while (w := batch.next_window()) is not None:
+            parts.append(batch.window_to_host(w)[0])
+            ranges.append((w.topic_begin, w.topic_end))
+            if stop_after is not None and len(parts) == stop_after:
+                return None, ranges
+        return np.concatenate(parts), ranges
+
+    monkeypatch.setenv("RGR_DELIVER_OVERLAP", "0")
+    in_order, ranges0 = device_pass()
+    monkeypatch.delenv("RGR_DELIVER_OVERLAP")
+    assert len(ranges0) > 20 and len({a // 2_000 for a, _ in ranges0}) >= 4          # many windows, several chunks
+    assert np.array_equal(in_order, host["tuples"])
+    for stop in (None, 3, None, 1, 2, None):                 # full passes (buffers reused) and passes abandoned after a few windows
+        got, ranges = device_pass(stop)
+        if stop is None:
+            assert ranges == ranges0
+            assert np.array_equal(got, in_order)
+    st = r.stats()
+    assert st["dedup_launches"] > 0
+    batch.close(); r.close()
+
+
 def test_config5_full_size_sampled_oracle():
     """BASELINE configs[4] at its FULL size (5 M retained topics x 1 M wildcard SUBSCRIBE filters, not
     scaled by RMQTT_TEST_SCALE): every window of the full batch is checked structurally, and a random
