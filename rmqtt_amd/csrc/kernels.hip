@@ -985,21 +985,7 @@ void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, const uint32_t* 
         while (p2 < v && p2 < uint32_t(kDedupTopicSlots)) p2 <<= 1;
         return v ? p2 : uint32_t(kDedupTopicSlots);
     }();
-    // RGR_DEDUP_PIPE=1 (A/B switch, read per launch): the software-pipelined topic pass (dedup.inc)
-    const char* pipe = std::getenv("RGR_DEDUP_PIPE");
-    if (pipe && pipe[0] == '1') {
-        // a grid of exactly the blocks the chip holds at once (the kernel walks the items with a stride of the grid; its look-ahead
-        // registers cost it a block per CU against the kernel below)
-        static const uint32_t resident = [] {
-            int per_cu = 0, dev = 0;
-            hipDeviceProp_t prop{};
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, dedup_topic_pipe_kernel, kDedupTopicThreads, 0) != hipSuccess || per_cu <= 0) per_cu = 2;
-            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount <= 0) return uint32_t(512);
-            return uint32_t(per_cu) * uint32_t(prop.multiProcessorCount);
-        }();
-        dedup_topic_pipe_kernel<<<resident, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, hit_off, hit_lo, items, item_count, tuples, max_slots);
-    } else
-        dedup_topic_kernel<<<kDedupTopicThreads >= 512 ? 1024 : 1280, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, hit_off, hit_lo, items, item_count, tuples, max_slots);
+    dedup_topic_kernel<<<kDedupTopicThreads >= 512 ? 1024 : 1280, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, hit_off, hit_lo, items, item_count, tuples, max_slots);
 }
 
 }  // namespace rgr

@@ -239,8 +239,8 @@ def test_v5_dedup_topics_spanning_tiles_in_parts(kind, test_slots, monkeypatch):
 SWITCH_SETS = {
     # the kernels that were the defaults until the r5a session measured their replacements (profiles/r05a_ab_*.jsonl)
     "r4_defaults": {"RGR_DELIVER_EARLY": "0", "RGR_PREP_BATCH": "0", "RGR_DELIVER_OVERLAP": "0"},
-    # measured and not adopted: the software-pipelined topic pass, 2^30-hit delivery windows
-    "dedup_pipe": {"RGR_DEDUP_PIPE": "1", "RGR_DELIVER_WINDOW_HITS": str(1 << 30)},
+    # measured and not adopted: 2^30-hit delivery windows
+    "large_windows": {"RGR_DELIVER_WINDOW_HITS": str(1 << 30)},
 }
 
 
@@ -250,7 +250,7 @@ SWITCH_SETS = {
 def test_v5_dedup_under_the_library_switches(switches, test_slots, monkeypatch):
     """The worlds of the two tests above under the library's environment switches (read per launch / per pass): the round-4 default
     kernels (expand_kernel<true>, count_kernel / compact_kernel one gather at a time, dedup in stream order) and the variants that
-    were measured and not adopted (dedup_topic_pipe_kernel, dedup.inc; host twin tests/test_hipsim_dedup.py)."""
+    were measured and not adopted."""
     for k, v in SWITCH_SETS[switches].items():
         monkeypatch.setenv(k, v)
     test_v5_dedup_topics_spanning_tiles_in_parts("hip", test_slots, monkeypatch)
