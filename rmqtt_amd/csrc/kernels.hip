@@ -974,18 +974,25 @@ void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, const uint32_t* 
     if (!ntiles) return;
     hipStream_t s = static_cast<hipStream_t>(stream);
     (void)hipMemsetAsync(item_count, 0, 4, s);
+    const uint32_t slots = uint32_t(kDedupTopicSlots);
     dedup_tile_kernel<<<std::min<uint32_t>(ntiles, 2048u), 256, 0, s>>>(cand, tile_ncand, tile_trange, ntiles, hit_off, hit_lo, nt, tuples, stat);
-    dedup_classify_kernel<<<(nt + 255) / 256, 256, 0, s>>>(tile_ncand, nt, hit_off, hit_lo, items, item_count);
-    // the item count stays on the device: a fixed grid of persistent blocks (4 per CU fit) strides over the items
     // RGR_DEDUP_TEST_SLOTS (tests only): a smaller table, so that parts overflow and the re-split path runs on ordinary inputs
     // (read on every launch — it is one getenv — so that a test can set it after other tests of the same process have launched)
-    const uint32_t max_slots = [] {
+    const uint32_t max_slots = [&] {
         const char* e = std::getenv("RGR_DEDUP_TEST_SLOTS");
         uint32_t v = e ? uint32_t(std::atoi(e)) : 0u, p2 = 64;
-        while (p2 < v && p2 < uint32_t(kDedupTopicSlots)) p2 <<= 1;
-        return v ? p2 : uint32_t(kDedupTopicSlots);
+        while (p2 < v && p2 < slots) p2 <<= 1;
+        return v ? p2 : slots;
     }();
-    dedup_topic_kernel<<<kDedupTopicThreads >= 512 ? 1024 : 1280, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, hit_off, hit_lo, items, item_count, tuples, max_slots);
+    dedup_classify_kernel<<<(nt + 255) / 256, 256, 0, s>>>(tile_ncand, nt, hit_off, hit_lo, items, item_count);
+    // the item count stays on the device: a fixed grid of persistent blocks (4 per CU fit) strides over the items.
+    // RGR_DEDUP_PROBE=0 (A/B switch, read per launch): linear probing and 8-byte table clears, the topic pass as it was until r5f
+    // (0.396 -> 0.358 ms per 2^28-hit window with double hashing + 16-byte clears; template parameter — as a kernel argument the same
+    // instructions cost 0.515 ms)
+    const char* pe = std::getenv("RGR_DEDUP_PROBE");
+    const uint32_t grid = kDedupTopicThreads >= 512 ? 1024 : 1280;
+    if (pe && pe[0] == '0') dedup_topic_kernel<0><<<grid, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, hit_off, hit_lo, items, item_count, tuples, max_slots);
+    else dedup_topic_kernel<3><<<grid, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, hit_off, hit_lo, items, item_count, tuples, max_slots);
 }
 
 }  // namespace rgr

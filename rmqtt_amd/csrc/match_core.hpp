@@ -506,11 +506,15 @@ RGR_HD inline bool dedup_topic_insert(uint32_t client, uint32_t pos, uint32_t ma
 // itself) or later, when a smaller position arrives and gets it back as the old value — so flagging the returned position flags
 // exactly the duplicates, without a second pass over the candidate lists.  Returns kNone when nobody lost; full = the table has no
 // room (the caller re-splits the part; flags set so far stay valid).
+// step_mode 0: linear probing; 1: double hashing — an odd step taken from the upper half of the client's mix (the table length is a power of
+// two, so every odd step visits every slot): no primary clustering, shorter worst probe of a wave's 64 lanes.
 template <class Cas, class Min>
-RGR_HD inline uint32_t dedup_topic_insert_once(uint32_t client, uint32_t pos, uint32_t mask, Cas tab_cas, Min tab_min, bool& full) {
+RGR_HD inline uint32_t dedup_topic_insert_once(uint32_t client, uint32_t pos, uint32_t mask, Cas tab_cas, Min tab_min, bool& full, uint32_t step_mode = 0) {
     const unsigned long long mine = (static_cast<unsigned long long>(client) << 32) | pos;
     uint32_t steps = 0;
-    for (uint32_t s = mix32(client) & mask;; s = (s + 1) & mask) {
+    const uint32_t hm = mix32(client);
+    const uint32_t step = step_mode ? ((hm >> 16) | 1u) : 1u;
+    for (uint32_t s = hm & mask;; s = (s + step) & mask) {
         const unsigned long long prev = tab_cas(s, mine);
         if (prev == kDedupEmpty) return kNone;
         if (uint32_t(prev >> 32) == client) {

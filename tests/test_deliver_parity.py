@@ -238,7 +238,7 @@ def test_v5_dedup_topics_spanning_tiles_in_parts(kind, test_slots, monkeypatch):
 
 SWITCH_SETS = {
     # the kernels that were the defaults until the r5a session measured their replacements (profiles/r05a_ab_*.jsonl)
-    "r4_defaults": {"RGR_DELIVER_EARLY": "0", "RGR_PREP_BATCH": "0", "RGR_DELIVER_OVERLAP": "0"},
+    "r4_defaults": {"RGR_DELIVER_EARLY": "0", "RGR_PREP_BATCH": "0", "RGR_DEDUP_PROBE": "0"},
     # measured and not adopted: 2^30-hit delivery windows
     "large_windows": {"RGR_DELIVER_WINDOW_HITS": str(1 << 30)},
 }
