@@ -27,6 +27,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 #include "kernels.hpp"
 #include "match_core.hpp"
@@ -879,7 +880,10 @@ void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, ui
     // 13.82 -> 14.03 M matches/s, whole-window delivery parity ok (profiles/r05a_ab_deliver.jsonl).  RGR_DELIVER_EARLY=0 (read per
     // launch) selects expand_kernel<true>.
     const char* early = deliver ? std::getenv("RGR_DELIVER_EARLY") : nullptr;
-    if (deliver && !(early && early[0] == '0')) expand_deliver_early_kernel<kTile / 4, 4><<<ntiles, kTile / 4, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, *deliver);
+    // r5g: the variant that compacts every wave's v5 hits before it runs the v5 path (expand_tuple.inc), behind RGR_DELIVER_LEAN (read per launch)
+    const char* lean = deliver ? std::getenv("RGR_DELIVER_LEAN") : nullptr;
+    if (deliver && lean && lean[0] == '1') expand_deliver_lean_kernel<kTile / 4, 4><<<ntiles, kTile / 4, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, *deliver);
+    else if (deliver && !(early && early[0] == '0')) expand_deliver_early_kernel<kTile / 4, 4><<<ntiles, kTile / 4, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, *deliver);
     else if (deliver) expand_kernel<true, kTile / 4, 4><<<ntiles, kTile / 4, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, *deliver);
     else expand_kernel<false, kExpandThreads, kExpandPerThread><<<ntiles, kExpandThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, DeliverArgs{});
 }
@@ -991,7 +995,8 @@ void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, const uint32_t* 
     // instructions cost 0.515 ms)
     const char* pe = std::getenv("RGR_DEDUP_PROBE");
     const uint32_t grid = kDedupTopicThreads >= 512 ? 1024 : 1280;
-    if (pe && pe[0] == '0') dedup_topic_kernel<0><<<grid, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, hit_off, hit_lo, items, item_count, tuples, max_slots);
+    if (pe && pe[0] == '7') dedup_topic_kernel<7><<<grid, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, hit_off, hit_lo, items, item_count, tuples, max_slots);      // r5g: + flat probe loop
+    else if (pe && pe[0] == '0') dedup_topic_kernel<0><<<grid, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, hit_off, hit_lo, items, item_count, tuples, max_slots);
     else dedup_topic_kernel<3><<<grid, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, hit_off, hit_lo, items, item_count, tuples, max_slots);
 }
 

@@ -88,6 +88,9 @@ CASES = {
     "topic_fills_tile_exactly": lambda rng: make_window(rng, [[TILE - 20, 20], [TILE], [5, TILE - 5], [TILE + 1], [TILE - 1], [1, TILE], [700]], v5_frac=0.4, pair_lo=0, first=TILE * 7),
     "no_attrs": lambda rng: make_window(rng, config3_like(rng, 2), attrs=False),
     "all_v3": lambda rng: make_window(rng, config3_like(rng, 2), v5_frac=0.0),
+    # more than 128 v5 hits among a wave's 256 positions: the lean variant's two-round path; all v5: every list full
+    "mostly_v5": lambda rng: make_window(rng, config3_like(rng, 2), v5_frac=0.8),
+    "all_v5": lambda rng: make_window(rng, [[TILE + 700, 3, 900]], v5_frac=1.0),
 }
 
 
@@ -121,3 +124,11 @@ def test_tuple_expansions_source_on_host(case):
     # an epoch without v5 candidates wanted: tuples only
     t3, _, _, _ = sim.expand_tuple(2, *args, want_cand=False)
     assert np.array_equal(t3, t1)
+    # ... and the variant that compacts every wave's v5 hits first (RGR_DELIVER_LEAN): the same words, the same candidate SETS per tile,
+    # the same count words / flags / topic ranges
+    t4, l4, n4, r4 = sim.expand_tuple(3, *args)
+    assert np.array_equal(t4, t1)
+    assert l4 == l1 and np.array_equal(n4, n1)
+    assert np.array_equal(r4.reshape(-1, 2)[flagged], r1.reshape(-1, 2)[flagged])
+    t5, _, _, _ = sim.expand_tuple(3, *args, want_cand=False)
+    assert np.array_equal(t5, t1)
