@@ -880,9 +880,14 @@ void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, ui
     // 13.82 -> 14.03 M matches/s, whole-window delivery parity ok (profiles/r05a_ab_deliver.jsonl).  RGR_DELIVER_EARLY=0 (read per
     // launch) selects expand_kernel<true>.
     const char* early = deliver ? std::getenv("RGR_DELIVER_EARLY") : nullptr;
-    // r5g: the variant that compacts every wave's v5 hits before it runs the v5 path (expand_tuple.inc), behind RGR_DELIVER_LEAN (read per launch)
+    // r5g-r5i: the variant that compacts every wave's v5 hits before it runs the v5 path ONCE per wave (expand_deliver_lean_kernel,
+    // expand_tuple.inc) is the default: 0.855 -> 0.727 ms per 2^28-hit window, delivery stage 14.59 -> 16.14 M matches/s on one table,
+    // whole-window delivery parity ok (profiles/r05i_ab_deliver_lean_512x4_vs_256x8_and_2e30_windows.jsonl; SQ counters before / after:
+    // r05c_*, r05h_*: 385 -> 228 vector and 253 -> 169 scalar instructions per wave).  256 threads x 8 positions (RGR_DELIVER_LEAN=2)
+    // measures the same (0.736); RGR_DELIVER_LEAN=0 (read per launch) selects the kernels above.
     const char* lean = deliver ? std::getenv("RGR_DELIVER_LEAN") : nullptr;
-    if (deliver && lean && lean[0] == '1') expand_deliver_lean_kernel<kTile / 4, 4><<<ntiles, kTile / 4, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, *deliver);
+    if (deliver && lean && lean[0] == '2') expand_deliver_lean_kernel<kTile / 8, 8><<<ntiles, kTile / 8, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, *deliver);
+    else if (deliver && !(lean && lean[0] == '0')) expand_deliver_lean_kernel<kTile / 4, 4><<<ntiles, kTile / 4, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, *deliver);
     else if (deliver && !(early && early[0] == '0')) expand_deliver_early_kernel<kTile / 4, 4><<<ntiles, kTile / 4, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, *deliver);
     else if (deliver) expand_kernel<true, kTile / 4, 4><<<ntiles, kTile / 4, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, *deliver);
     else expand_kernel<false, kExpandThreads, kExpandPerThread><<<ntiles, kExpandThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, DeliverArgs{});
@@ -995,8 +1000,7 @@ void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, const uint32_t* 
     // instructions cost 0.515 ms)
     const char* pe = std::getenv("RGR_DEDUP_PROBE");
     const uint32_t grid = kDedupTopicThreads >= 512 ? 1024 : 1280;
-    if (pe && pe[0] == '7') dedup_topic_kernel<7><<<grid, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, hit_off, hit_lo, items, item_count, tuples, max_slots);      // r5g: + flat probe loop
-    else if (pe && pe[0] == '0') dedup_topic_kernel<0><<<grid, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, hit_off, hit_lo, items, item_count, tuples, max_slots);
+    if (pe && pe[0] == '0') dedup_topic_kernel<0><<<grid, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, hit_off, hit_lo, items, item_count, tuples, max_slots);
     else dedup_topic_kernel<3><<<grid, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, hit_off, hit_lo, items, item_count, tuples, max_slots);
 }
 

@@ -17,7 +17,7 @@ using namespace rgr;
 
 extern "C" {
 
-// variant 3: dedup_topic_kernel<3> (the product: double hashing, 16-byte clears), 7: + the flat probe loop (r5g), 0: dedup_topic_kernel<0> (RGR_DEDUP_PROBE=0).  grid_topic:
+// variant 3: dedup_topic_kernel<3> (the product: double hashing, 16-byte clears), 0: dedup_topic_kernel<0> (RGR_DEDUP_PROBE=0).  grid_topic:
 // blocks of the topic pass (the product launches 1024; fewer blocks make every block walk several items).  Returns 0, -2 when threads diverged around a barrier.
 int32_t sim_dedup(int32_t variant, uint32_t grid_topic, uint32_t max_slots, const Cand* cand, const uint32_t* tile_ncand, const uint32_t* tile_trange,
                   uint32_t ntiles, Tuple* tuples, uint32_t nt, const uint64_t* hit_off, uint64_t hit_lo, uint32_t* n_items_out) {
@@ -27,9 +27,8 @@ int32_t sim_dedup(int32_t variant, uint32_t grid_topic, uint32_t max_slots, cons
     bool ok = true;
     ok &= hipsim::run(ntiles < 64 ? ntiles : 64, 256, [&] { dedup_tile_kernel(cand, tile_ncand, tile_trange, ntiles, hit_off, hit_lo, nt, tuples, &stat); });
     ok &= hipsim::run((nt + 255) / 256, 256, [&] { dedup_classify_kernel(tile_ncand, nt, hit_off, hit_lo, items.data(), &item_count); });
-    if (variant != 0 && variant != 3 && variant != 7) return -3;        // variant = the topic pass's probe_mode (bit 0: double hashing, bit 1: 16-byte clears)
-    if (variant == 7) ok &= hipsim::run(grid_topic, kDedupTopicThreads, [&] { dedup_topic_kernel<7>(cand, tile_ncand, hit_off, hit_lo, items.data(), &item_count, tuples, max_slots); });
-    else if (variant == 3) ok &= hipsim::run(grid_topic, kDedupTopicThreads, [&] { dedup_topic_kernel<3>(cand, tile_ncand, hit_off, hit_lo, items.data(), &item_count, tuples, max_slots); });
+    if (variant != 0 && variant != 3) return -3;        // variant = the topic pass's probe_mode (bit 0: double hashing, bit 1: 16-byte clears)
+    if (variant == 3) ok &= hipsim::run(grid_topic, kDedupTopicThreads, [&] { dedup_topic_kernel<3>(cand, tile_ncand, hit_off, hit_lo, items.data(), &item_count, tuples, max_slots); });
     else ok &= hipsim::run(grid_topic, kDedupTopicThreads, [&] { dedup_topic_kernel<0>(cand, tile_ncand, hit_off, hit_lo, items.data(), &item_count, tuples, max_slots); });
     if (n_items_out) *n_items_out = item_count;
     return ok ? 0 : -2;

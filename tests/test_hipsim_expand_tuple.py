@@ -126,9 +126,10 @@ def test_tuple_expansions_source_on_host(case):
     assert np.array_equal(t3, t1)
     # ... and the variant that compacts every wave's v5 hits first (RGR_DELIVER_LEAN): the same words, the same candidate SETS per tile,
     # the same count words / flags / topic ranges
-    t4, l4, n4, r4 = sim.expand_tuple(3, *args)
-    assert np.array_equal(t4, t1)
-    assert l4 == l1 and np.array_equal(n4, n1)
-    assert np.array_equal(r4.reshape(-1, 2)[flagged], r1.reshape(-1, 2)[flagged])
-    t5, _, _, _ = sim.expand_tuple(3, *args, want_cand=False)
-    assert np.array_equal(t5, t1)
+    for lean in (3, 4):                                    # 512 threads x 4 positions, 256 x 8
+        t4, l4, n4, r4 = sim.expand_tuple(lean, *args)
+        assert np.array_equal(t4, t1)
+        assert l4 == l1 and np.array_equal(n4, n1)
+        assert np.array_equal(r4.reshape(-1, 2)[flagged], r1.reshape(-1, 2)[flagged])
+        t5, _, _, _ = sim.expand_tuple(lean, *args, want_cand=False)
+        assert np.array_equal(t5, t1)
