@@ -40,6 +40,10 @@ CASES = {
     "overflow": (lambda rng: rng.integers(3000, 9000, size=10), 0.2, 5000, 2, 64),                 # tables too small: re-split on the fly
     "one_block": (lambda rng: rng.integers(2100, 20000, size=9), 0.12, 100, 1, 4096),
     "more_blocks_than_items": (lambda rng: np.array([5000, 3, 9000]), 0.15, 64, 64, 4096),
+    # the measured regime: duplicates are a percent of the candidates ...
+    "rare_duplicates": (lambda rng: rng.integers(9000, 34000, size=10), 0.1, 150000, 4, 4096),
+    # ... and its opposite: thousands of distinct duplicated clients per topic
+    "many_duplicated_clients": (lambda rng: np.array([60000, 50000]), 0.5, 9000, 2, 4096),
 }
 
 
