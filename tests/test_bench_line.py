@@ -71,3 +71,20 @@ def test_error_secondary_survives(bench):
     full["secondary"] = [{"config": {"workload": "x"}, "error": "RuntimeError('boom')"}]
     d = strict_loads(bench.compact_line(full, None))
     assert d["secondary"][0]["error"].startswith("RuntimeError")
+
+
+def test_pmc_kernel_classes_cover_every_tuple_expansion_the_library_launches(bench):
+    """The PMC replay attributes dispatches to classes by kernel name; a default kernel whose name matches no needle loses the run's whole
+    roofline record (round 5: expand_deliver_lean_kernel).  Every kernel launch_expand() can launch must be an "expand" dispatch, no compact
+    expansion and no preparation kernel may be."""
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rmqtt_amd", "csrc", "kernels.hip")).read()
+    body = src[src.index("void launch_expand("):]
+    body = body[:body.index("\n}\n")]
+    launched = set(re.findall(r"(\w+_kernel)<[^;]*?><<<", body))
+    assert {"expand_kernel", "expand_deliver_early_kernel", "expand_deliver_lean_kernel"} <= launched
+    needles = dict(bench.KCLASS)["expand"]
+    for k in launched:
+        assert any(nd in k + "<512, 4>" for nd in needles), k
+    for other in ("expand_compact_kernel<2, 1>", "expand_compact_lp_kernel<4, 1>", "walk_kernel<false>", "tiles_kernel", "dedup_topic_kernel<3u>"):
+        assert not any(nd in other for nd in needles), other
