@@ -204,14 +204,19 @@ struct rgr_batch {
     // Hits per window of THIS pass.  The handle's default (2^30, r4) is for device-resident passes, where a window is only a unit of
     // launches: at config 3 the pass needs 139 windows instead of 553 and saves ~8 ms of tiles_kernel launches and gaps
     // (profiles/r04a_packed_vs_window_size.jsonl).  Passes that stage windows in pinned host memory, and the delivery stage (whose
-    // candidate lists are sized per window), keep 2^28 unless the caller configured something smaller.
+    // candidate lists are sized per window), keep 2^28 (device-resident delivery passes: 2^27, r5r) unless the caller configured something smaller.
     uint64_t window_cap() const {
         uint64_t c = h->cfg.window_hits;
         // RGR_WINDOW_HITS (A/B switch of bench.py --ab-env, read per window): hits per window of a device-resident pass whose handle took the default
         if (!h->cfg_window_explicit && !host_out && !deliver)
             if (const char* e = std::getenv("RGR_WINDOW_HITS")) { const unsigned long long v = std::strtoull(e, nullptr, 10); if (v >= 4096 && v <= (1ull << 32) - 4096) c = v; }
-        if (deliver && !host_out && !h->cfg_window_explicit)      // RGR_DELIVER_WINDOW_HITS (A/B switch): device-resident delivery passes, default 2^28
+        if (deliver && !host_out && !h->cfg_window_explicit) {    // RGR_DELIVER_WINDOW_HITS (A/B switch): device-resident delivery passes
             if (const char* e = std::getenv("RGR_DELIVER_WINDOW_HITS")) { const unsigned long long v = std::strtoull(e, nullptr, 10); if (v >= 4096 && v <= (1ull << 32) - 4096) return v; }
+            // r5q / r5r: 2^27 — the delivery expansion runs 0.328 ms per 2^27-hit window against 0.733 per 2^28 (its tile records, count
+            // words and candidate slices of a window stay closer to L2), the dedup's four launches per window cost 0.187 against 0.352:
+            // 16.31 -> 16.84 M matches/s; 2^26: 15.0 M, 2^29: 15.4 M, 2^30: 15.0 M (profiles/r05r_*, r05q_*, r05i_*)
+            return std::min<uint64_t>(c, 1ull << 27);
+        }
         return (host_out || deliver) ? std::min<uint64_t>(c, h->cfg_window_explicit ? c : (1ull << 28)) : c;
     }
     // streamed passes (rgr_batch_run_to_host, rgr_match_batch): copy stream + per-slot events, created once
@@ -1435,7 +1440,7 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
                 sp = b->span_begin(kSpanDedup);
                 launch_dedup(b->cand.as<Cand>(), b->cand_count.as<uint32_t>(), b->cand_count.as<uint32_t>() + (nh + T - 1) / T, uint32_t((nh + T - 1) / T), outbuf.as<Tuple>(),
                              le - lc, b->c->hit_off.as<uint64_t>() + lc, hit_lo, b->dedup_items.as<DedupItem>(),
-                             reinterpret_cast<uint32_t*>(b->dedup_scalars.as<unsigned long long>() + 1), b->dedup_scalars.as<unsigned long long>(), b->stream);
+                             reinterpret_cast<uint32_t*>(b->dedup_scalars.as<unsigned long long>() + 1), b->win_seq & 1u, b->dedup_scalars.as<unsigned long long>(), b->stream);
                 b->span_end(sp);
                 b->local.dedup_launches++;
             }

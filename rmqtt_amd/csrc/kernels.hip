@@ -979,12 +979,14 @@ void launch_node_groups(const Tuple* tuples, const uint64_t* hit_off, uint64_t h
 uint32_t dedup_topic_cap() { return kDedupTopicCap; }
 
 void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, const uint32_t* tile_trange, uint32_t ntiles, Tuple* tuples, uint32_t nt,
-                  const uint64_t* hit_off, uint64_t hit_lo, DedupItem* items, uint32_t* item_count, unsigned long long* stat, void* stream) {
-    if (!ntiles) return;
+                  const uint64_t* hit_off, uint64_t hit_lo, DedupItem* items, uint32_t* item_counts, uint32_t parity, unsigned long long* stat, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
-    (void)hipMemsetAsync(item_count, 0, 4, s);
+    if (!ntiles) { (void)hipMemsetAsync(item_counts + (parity ^ 1u), 0, 4, s); return; }      // (the next window's counter: what this window's launch would have zeroed)
     const uint32_t slots = uint32_t(kDedupTopicSlots);
-    dedup_tile_kernel<<<std::min<uint32_t>(ntiles, 2048u), 256, 0, s>>>(cand, tile_ncand, tile_trange, ntiles, hit_off, hit_lo, nt, tuples, stat);
+    // tile pass + classification in one launch (dedup.inc); item_counts[parity] is this window's item counter
+    const uint32_t tile_blocks = std::min<uint32_t>(ntiles, 2048u);
+    dedup_tile_kernel<<<tile_blocks + (nt + 255) / 256, 256, 0, s>>>(cand, tile_ncand, tile_trange, ntiles, hit_off, hit_lo, nt, tuples, stat, tile_blocks, items, item_counts, parity);
+    uint32_t* item_count = item_counts + parity;
     // RGR_DEDUP_TEST_SLOTS (tests only): a smaller table, so that parts overflow and the re-split path runs on ordinary inputs
     // (read on every launch — it is one getenv — so that a test can set it after other tests of the same process have launched)
     const uint32_t max_slots = [&] {
@@ -993,7 +995,6 @@ void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, const uint32_t* 
         while (p2 < v && p2 < slots) p2 <<= 1;
         return v ? p2 : slots;
     }();
-    dedup_classify_kernel<<<(nt + 255) / 256, 256, 0, s>>>(tile_ncand, nt, hit_off, hit_lo, items, item_count);
     // the item count stays on the device: a fixed grid of persistent blocks (4 per CU fit) strides over the items.
     // RGR_DEDUP_PROBE=0 (A/B switch, read per launch): linear probing and 8-byte table clears, the topic pass as it was until r5f
     // (0.396 -> 0.358 ms per 2^28-hit window with double hashing + 16-byte clears; template parameter — as a kernel argument the same

@@ -257,7 +257,8 @@ bool launch_expand_compact(const TrieView& t, const ChunkArrays& c, uint64_t pai
 // work item of the topic pass: part `part` of `parts` of window topic `topic` (nc candidates in total)
 struct DedupItem { uint32_t topic, part, parts, nc; };
 void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, const uint32_t* tile_trange, uint32_t ntiles, Tuple* tuples, uint32_t nt,
-                  const uint64_t* hit_off, uint64_t hit_lo, DedupItem* items, uint32_t* item_count, unsigned long long* stat, void* stream);
+                  const uint64_t* hit_off, uint64_t hit_lo, DedupItem* items, uint32_t* item_counts /* two words, zero when the pass begins */,
+                  uint32_t parity /* window & 1 */, unsigned long long* stat, void* stream);
 uint32_t dedup_topic_cap();
 // Delivery results grouped by node (SubRelationsMap's shape, types.rs:486-497): stable partition of every topic's tuples by
 // one byte (`shift` = 16 or 24) of the delivery word's node index; then the directory of the node groups — called twice: with
