@@ -838,8 +838,9 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
     walk_gbs = st["alg_bytes_walk"] / walk_s / 1e9 if walk_s > 0 else 0.0
     is_exp = exp_s >= walk_s
     exp_name = "expand_kernel"
-    if deliver >= 0:
-        exp_name = "expand_kernel<true>"
+    if deliver >= 0:        # the library's choice (kernels.hip launch_expand): the lean delivery expansion unless a switch says otherwise
+        exp_name = ("expand_deliver_lean_kernel" if os.environ.get("RGR_DELIVER_LEAN", "1") != "0" else
+                    "expand_deliver_early_kernel" if os.environ.get("RGR_DELIVER_EARLY", "1") != "0" else "expand_kernel<true>")
     dominant = exp_name if is_exp else ("retain_rounds" if retain else "walk_kernel")
     launches = st["expand_launches"] if is_exp else st["walk_launches"]
     dom_s = exp_s if is_exp else walk_s
