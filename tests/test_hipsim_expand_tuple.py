@@ -133,3 +133,42 @@ def test_tuple_expansions_source_on_host(case):
         assert np.array_equal(r4.reshape(-1, 2)[flagged], r1.reshape(-1, 2)[flagged])
         t5, _, _, _ = sim.expand_tuple(lean, *args, want_cand=False)
         assert np.array_equal(t5, t1)
+
+
+# ---- property: ANY window (topics of 0 .. 12 runs of 1 .. 5 000 hits, any v5 fraction) through the lean delivery expansion equals the
+# restated per-hit rules: words, candidate sets, count words
+try:
+    from hypothesis import HealthCheck, given, settings
+    from hypothesis import strategies as st
+    HAVE_HYPOTHESIS = True
+except ImportError:                                     # pragma: no cover
+    HAVE_HYPOTHESIS = False
+
+if HAVE_HYPOTHESIS:
+    run_len = st.one_of(st.integers(1, 4), st.integers(1, 70), st.integers(1, 5000), st.sampled_from([2047, 2048, 2049]))
+
+    @settings(max_examples=25, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(topics=st.lists(st.lists(run_len, min_size=0, max_size=12), min_size=1, max_size=25), v5=st.sampled_from([0.0, 0.05, 0.3, 0.7, 1.0]),
+           pair_lo=st.integers(0, 3), first=st.integers(0, 1 << 40), seed=st.integers(0, 1 << 16), geometry=st.sampled_from([3, 4]), attrs=st.booleans())
+    def test_lean_delivery_expansion_any_window(topics, v5, pair_lo, first, seed, geometry, attrs):
+        total, kept = 0, []
+        for t in topics:                                 # at most ~12 tiles per example
+            t = list(t)
+            while t and total + sum(t) > 12 * TILE:
+                t.pop()
+            kept.append(t); total += sum(t)
+        if total == 0:
+            kept[0] = [3]
+        rng = np.random.default_rng(seed)
+        W = make_window(rng, kept, pool=1 << 14, v5_frac=v5, pair_lo=pair_lo, first=first, attrs=attrs)
+        args = (W["subs"], W["attrs"], W["pub"], W["src"], W["topic"], W["off"], W["qr"], W["lo"], W["hi"], W["topic_lo"])
+        topic, sid, w, (cpos, ccl) = reference(W, True)
+        t4, l4, n4, _ = sim.expand_tuple(geometry, *args)
+        assert np.array_equal(t4["topic_idx"], topic) and np.array_equal(t4["sub_id"], sid)
+        bad = np.flatnonzero(t4["qos_flags"] != w)
+        assert bad.size == 0, (bad[:5], t4["qos_flags"][bad[:5]], w[bad[:5]])
+        want_lists = [[] for _ in l4]
+        for p, c in zip(cpos.tolist(), ccl.tolist()):
+            want_lists[p // TILE].append((p, c))
+        assert l4 == want_lists
+        assert np.array_equal(n4 & 0x7FFFFFFF, np.array([len(x) for x in want_lists], dtype=np.uint32))
