@@ -984,7 +984,11 @@ void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, const uint32_t* 
     if (!ntiles) { (void)hipMemsetAsync(item_counts + (parity ^ 1u), 0, 4, s); return; }      // (the next window's counter: what this window's launch would have zeroed)
     const uint32_t slots = uint32_t(kDedupTopicSlots);
     // tile pass + classification in one launch (dedup.inc); item_counts[parity] is this window's item counter
+#ifdef RGR_DIAG_TILE_BLOCKS_PER        /* diagnostic builds (r5x): tiles per block of the tile pass instead of a fixed grid of 2 048 blocks */
+    const uint32_t tile_blocks = std::max<uint32_t>(1u, (ntiles + RGR_DIAG_TILE_BLOCKS_PER - 1) / RGR_DIAG_TILE_BLOCKS_PER);
+#else
     const uint32_t tile_blocks = std::min<uint32_t>(ntiles, 2048u);
+#endif
     dedup_tile_kernel<<<tile_blocks + (nt + 255) / 256, 256, 0, s>>>(cand, tile_ncand, tile_trange, ntiles, hit_off, hit_lo, nt, tuples, stat, tile_blocks, items, item_counts, parity);
     uint32_t* item_count = item_counts + parity;
     // RGR_DEDUP_TEST_SLOTS (tests only): a smaller table, so that parts overflow and the re-split path runs on ordinary inputs
