@@ -456,12 +456,7 @@ RGR_HD inline uint32_t deliver_word(uint32_t qos_flags, PublishAttr pa, SubAttr 
 //                client (dedup_part: a range partition of a bijective mix of the client index, so no client is in two
 //                parts); a part that still overflows (distinct clients > slots) is re-split on the fly.
 // The same functions run in kernels.hip (LDS, ds atomics) and in tests/emu (plain memory).
-RGR_HD inline uint32_t mix32(uint32_t x) {           // bijective
-    x ^= x >> 16; x *= 0x7feb352du;
-    x ^= x >> 15; x *= 0x846ca68bu;
-    x ^= x >> 16;
-    return x;
-}
+// (mix32: kernels.hpp)
 RGR_HD inline uint32_t dedup_part(uint32_t client, uint64_t nparts) { return uint32_t((uint64_t(mix32(client)) * nparts) >> 32); }
 
 constexpr uint32_t kDedupIdxBits = 11;               // candidates per tile (and positions per tile) <= 2048

@@ -28,18 +28,21 @@ def assign(blob, offsets, n_shards, is_filter, key_levels=KEY_LEVELS):
     return out
 
 
-def allgatherv_tuples(local, world, rank, dist, device):
-    """all-gatherv of (topic_idx, sub_id, qos) tuples: local is an int32/uint32 tensor [n,3].
-    RCCL has no native allgatherv: gather the counts, then one padded all_gather; returns the
-    concatenation in rank order.  (world_size-2 gloo test: tests/test_distributed.py.)"""
+def allgatherv_rows(local, world, rank, dist, device):
+    """all-gatherv of fixed-width rows: local is a tensor [n, k] ((topic_idx, sub_id, qos) tuples: k = 3; run descriptors
+    {shard, src, len, topic}: k = 4).  RCCL has no native allgatherv: gather the counts, then one padded all_gather; returns the
+    concatenation in rank order and the per-rank counts.  (world_size-2 gloo test: tests/test_distributed.py.)"""
     import torch
     cnt = torch.tensor([local.shape[0]], dtype=torch.int64, device=device)
     counts = [torch.zeros_like(cnt) for _ in range(world)]
     dist.all_gather(counts, cnt)
     counts = [int(x.item()) for x in counts]
     mx = max(counts) if counts else 0
-    pad = torch.zeros((mx, 3), dtype=local.dtype, device=device)
+    pad = torch.zeros((mx, local.shape[1]), dtype=local.dtype, device=device)
     pad[: local.shape[0]] = local
     bufs = [torch.zeros_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad)
     return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0), counts
+
+
+allgatherv_tuples = allgatherv_rows

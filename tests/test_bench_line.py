@@ -88,3 +88,32 @@ def test_pmc_kernel_classes_cover_every_tuple_expansion_the_library_launches(ben
         assert any(nd in k + "<512, 4>" for nd in needles), k
     for other in ("expand_compact_kernel<2, 1>", "expand_compact_lp_kernel<4, 1>", "walk_kernel<false>", "tiles_kernel", "dedup_topic_kernel<3u>"):
         assert not any(nd in other for nd in needles), other
+
+
+@pytest.mark.gpu
+def test_two_rank_line_is_creditable():
+    """`python bench.py --gpus 2` (self-launch; gloo because the box has one GPU) at 1/50 scale: the N > 1 line carries what the N = 1 line
+    does — a CPU baseline timed on rank 0's host against the unsharded table, an exhaustive parity sample — and the exchange step is
+    BASELINE configs[3]'s all-gatherv of subscriber hits in its run-descriptor form BY DEFAULT, with its bytes and milliseconds reported."""
+    import subprocess
+    import sys
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dist-backend", "gloo", "--scale", "0.02", "--steps", "2", "--warmup", "1", "--no-pmc"]
+    p = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = strict_loads(lines[0])
+    for k in CONTRACT:
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["config"]["ranks"] == 2
+    assert d["config"]["gather"] == "runs" and d["config"]["collective"] == "torch.distributed" and d["config"]["dist_backend"] == "gloo"
+    assert "rccl_ranks" in d["config"]                      # null under gloo; ncclCommCount of the library's communicator under nccl
+    c = d["cpu_baseline"]
+    assert c and c["value"] > 0 and c["cores"] >= 1 and c["kind"] == "port" and c["single_thread"] > 0
+    ps = d["parity_sample"]
+    assert ps["ok"] is True and ps["exhaustive"] is True and ps["topics"] == d["config"]["publishes"]
+    x = d["exchange"]
+    assert x["describes_every_hit"] is True and x["hits_described"] == d["hits_per_step"]
+    assert x["ms_per_step"] > 0 and x["bytes_all_ranks_per_step"] == x["runs_all_ranks"] * 16
+    assert len(d["shard_hits"]) == 2 and sum(d["shard_hits"]) == d["hits_per_step"]
+    assert d["roofline"]["alg_frac"] > 0 and d["roofline"]["hits_per_launch"] > 0

@@ -236,11 +236,96 @@ def test_v5_dedup_topics_spanning_tiles_in_parts(kind, test_slots, monkeypatch):
     w.check(14)
 
 
+@pytest.mark.parametrize("kind", BACKENDS)
+def test_v5_dedup_with_exempt_runs(kind, monkeypatch):
+    """(r6) Runs long enough to get a client index at commit (kernels.hpp kExemptMinRun; 2 049 here): per topic the longest such run stays out of
+    the candidate lists and the topic pass asks its index instead.  Overlapping filters with thousands of v5 clients each, publishers that
+    hold No Local subscriptions in the long runs (a dropped exempt hit neither is nor makes a duplicate), subscription churn on the long runs
+    (the incremental commit re-indexes exactly the rewritten runs), everything against the oracle's forwards(); on the device additionally
+    word for word against the same pass with RGR_DELIVER_EXEMPT=0, whose candidate count must be the larger one."""
+    monkeypatch.setenv("RGR_EXEMPT_MIN_RUN", "2049")
+    w = World(kind, 33)
+    w.clients = [f"k{i}" for i in range(2600)]
+    w.client_node = {c: w.nodes[i % 3] for i, c in enumerate(w.clients)}
+    filters = ["a/#", "a/b/c", "+/+/+", "a/b/+", "#"]
+    for i, c in enumerate(w.clients):
+        for j, f in enumerate(filters):
+            if j >= 3 and (i + j) % 6:            # "a/b/+" and "#": short runs beside the three long ones
+                continue
+            if (i + 3 * j) % 11 != 5:
+                w.add(f, c, 0, (i + j) % 3, (i + j) % 4 != 0, (i % 3) == 0, (j % 2) == 0, (i * 7 + j) % 150)
+    w.check(16)
+    if kind == "hip":
+        st = w.backend.stats()
+        blob, offs = pack(["a/b/c", "a/b", "x/y/z", "a/b/c"])
+        attrs = np.zeros(4, dtype=capi.PUBLISH_ATTR_DTYPE)
+        attrs["from_id"] = [w.owner_ids[(w.client_node["k3"], "k3", 0)], capi.ID_NONE, w.owner_ids[(w.client_node["k9"], "k9", 0)], capi.ID_NONE]
+        attrs["qos_retain"] = [2, 1 | 4, 0, 2 | 4]
+        w.backend.stats_reset()
+        on = w.backend.match_batch_deliver(blob, offs, attrs)
+        c_on = w.backend.stats()["dedup_candidates"]
+        monkeypatch.setenv("RGR_DELIVER_EXEMPT", "0")
+        w.backend.stats_reset()
+        off = w.backend.match_batch_deliver(blob, offs, attrs)
+        c_off = w.backend.stats()["dedup_candidates"]
+        monkeypatch.delenv("RGR_DELIVER_EXEMPT")
+        assert np.array_equal(on["tuples"], off["tuples"]) and np.array_equal(on["hit_offsets"], off["hit_offsets"])
+        assert (on["tuples"]["qos_flags"] & capi.RGR_HIT_V5_DUP).any() and (on["tuples"]["qos_flags"] & capi.RGR_HIT_NO_LOCAL).any()
+        assert 0 < c_on < 0.7 * c_off, (c_on, c_off)
+        del st
+    # churn on the long runs: the incremental commit appends the rewritten runs and their indices
+    for rnd in range(3):
+        for i in range(rnd, 2600, 37):
+            c = w.clients[i]
+            for f in ("a/#", "+/+/+"):
+                if (f, c) in w.sub_of and (i + rnd) % 2:
+                    w.remove(f, c, 0)
+                else:
+                    w.add(f, c, 0, (i + rnd) % 3, (i + rnd) % 3 != 0, (i % 2) == 0, rnd % 2 == 0, (i + rnd) % 99)
+        w.check(8)
+
+
+@pytest.mark.gpu
+def test_run_with_a_repeated_client_gets_no_index(monkeypatch):
+    """A caller whose table breaks the reference's one-relation-per-(filter, client) rule (types.rs:476: the relations of a filter are a map keyed
+    by ClientId) — two subscriptions of ONE client on one filter: rgr_commit refuses that run's index, all its hits stay candidates, and the
+    answer equals the pass without exempt runs (first position of the client wins, inside the run too)."""
+    monkeypatch.setenv("RGR_EXEMPT_MIN_RUN", "2049")
+    r = capi.Router(device=0)
+    big, other = r.filter_add("a/#"), r.filter_add("a/b")
+    n = 3000
+    for i in range(n):
+        r.sub_add_ex(big, i, i % 3, capi.RGR_SUB_V5, 0, i % (n - 7), i % (n - 7))        # the last seven clients repeat the first seven
+    for i in range(40):
+        r.sub_add_ex(other, n + i, 1, capi.RGR_SUB_V5, 0, 5 * i, 5 * i)
+    r.commit()
+    blob, offs = pack(["a/b", "a/c"])
+    attrs = np.zeros(2, dtype=capi.PUBLISH_ATTR_DTYPE)
+    attrs["from_id"] = capi.ID_NONE
+    attrs["qos_retain"] = 2
+    on = r.match_batch_deliver(blob, offs, attrs)
+    monkeypatch.setenv("RGR_DELIVER_EXEMPT", "0")
+    off = r.match_batch_deliver(blob, offs, attrs)
+    assert np.array_equal(on["tuples"], off["tuples"])
+    dup = on["tuples"][(on["tuples"]["qos_flags"] & capi.RGR_HIT_V5_DUP) != 0]
+    # topic 0: a/b's 40 clients come first (exact filter before "a/#"? no: TopicTree order — whichever comes first, 40 of the two runs' hits
+    # and the seven repeats inside the long run are duplicates); topic 1: only the seven repeats
+    assert (dup["topic_idx"] == 0).sum() == 47 and (dup["topic_idx"] == 1).sum() == 7
+    r.close()
+
+
 SWITCH_SETS = {
-    # the kernels that were the defaults until the r5a session measured their replacements (profiles/r05a_ab_*.jsonl)
-    "r4_defaults": {"RGR_DELIVER_EARLY": "0", "RGR_PREP_BATCH": "0", "RGR_DEDUP_PROBE": "0"},
+    # the kernels that were the defaults until the r5a session measured their replacements (profiles/r05a_ab_*.jsonl); RGR_DELIVER_LEAN=0 or the
+    # lean expansion (checked first by launch_expand) would still be the one that runs: this set reaches expand_kernel<true>
+    "r4_defaults": {"RGR_DELIVER_LEAN": "0", "RGR_DELIVER_EARLY": "0", "RGR_PREP_BATCH": "0", "RGR_DEDUP_PROBE": "0"},
+    # round 5's first default: the delivery expansion with its loads issued early
+    "early_loads": {"RGR_DELIVER_LEAN": "0"},
+    # the lean expansion's other geometry (256 threads x 8 positions)
+    "lean_256x8": {"RGR_DELIVER_LEAN": "2"},
     # measured and not adopted (DESIGN section 10): 2^30-hit delivery windows
     "large_windows": {"RGR_DELIVER_WINDOW_HITS": str(1 << 30)},
+    # every v5 hit through the candidate lists, as until round 5
+    "no_exempt_runs": {"RGR_DELIVER_EXEMPT": "0", "RGR_EXEMPT_MIN_RUN": "2049"},
 }
 
 
@@ -255,6 +340,8 @@ def test_v5_dedup_under_the_library_switches(switches, test_slots, monkeypatch):
         monkeypatch.setenv(k, v)
     test_v5_dedup_topics_spanning_tiles_in_parts("hip", test_slots, monkeypatch)
     test_v5_dedup_many_candidates("hip")
+    if switches in ("lean_256x8", "large_windows") and not test_slots:
+        test_v5_dedup_with_exempt_runs("hip", monkeypatch)
 
 
 @pytest.mark.parametrize("n_nodes", [1, 3, 300])

@@ -303,15 +303,15 @@ def test_lane_held_expansion_equals_tile_kernel(window_hits, monkeypatch):
                 assert np.array_equal(a0, want), (lp, f, "tile-per-block kernel")
                 bad = np.flatnonzero(a != want)
                 assert bad.size == 0, (lp, f, bad[:8], len(a))
-    if True:       # the library's switches (measured in session r5a: X4 not adopted, fused tile records within noise; both stay selectable)
-        monkeypatch.setenv("RGR_IDS24_X4", "1")          # IDS24 through 16-byte stores (expand_ids24_x4_kernel; host twin: tests/test_hipsim_expand.py)
-        got = windows(batch, capi.RGR_FORMAT_IDS24)
-        for (_, _, _, t, _), (_, _, _, a, _) in zip(ref, got):
-            assert np.array_equal(a, t["sub_id"]), "RGR_IDS24_X4"
-        monkeypatch.delenv("RGR_IDS24_X4")
-        monkeypatch.setenv("RGR_TILES_FUSED", "1")       # the next window's tile records written by the tail blocks of this window's expansion
-        got = windows(batch, capi.RGR_FORMAT_IDS24)
-        for (_, _, _, t, _), (_, _, _, a, _) in zip(ref, got):
-            assert np.array_equal(a, t["sub_id"]), "RGR_TILES_FUSED"
-        monkeypatch.delenv("RGR_TILES_FUSED")
+    # the library's switches (measured in session r5a: X4 not adopted, fused tile records within noise; both stay selectable)
+    monkeypatch.setenv("RGR_IDS24_X4", "1")          # IDS24 through 16-byte stores (expand_ids24_x4_kernel; host twin: tests/test_hipsim_expand.py)
+    got = windows(batch, capi.RGR_FORMAT_IDS24)
+    for (_, _, _, t, _), (_, _, _, a, _) in zip(ref, got):
+        assert np.array_equal(a, t["sub_id"]), "RGR_IDS24_X4"
+    monkeypatch.delenv("RGR_IDS24_X4")
+    monkeypatch.setenv("RGR_TILES_FUSED", "1")       # the next window's tile records written by the tail blocks of this window's expansion
+    got = windows(batch, capi.RGR_FORMAT_IDS24)
+    for (_, _, _, t, _), (_, _, _, a, _) in zip(ref, got):
+        assert np.array_equal(a, t["sub_id"]), "RGR_TILES_FUSED"
+    monkeypatch.delenv("RGR_TILES_FUSED")
     batch.close(); r.close()
