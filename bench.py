@@ -229,7 +229,8 @@ class _DevArr:      # zero-copy torch view of library-owned device memory
         self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (int(ptr), False), "version": 2}
 
 
-FORMAT_NAMES = ("tuple", "soa", "packed", "runs", "ids24")      # == RGR_FORMAT_*
+FORMAT_NAMES = ("tuple", "soa", "packed", "runs", "ids24")      # == RGR_FORMAT_* (plain passes)
+DELIVERY_FORMAT_NAMES = {0: "tuple12: (topic_idx, sub_id, delivery word)", 5: "hits8: (sub_id, delivery word), topic implied by the CSR offsets"}
 
 
 def gpu_digests(batch, n_topics, retain, fmt=0, subs_len=0, topic_ids_dev=None, qos_by_sub=None):
@@ -330,7 +331,22 @@ def gpu_digests(batch, n_topics, retain, fmt=0, subs_len=0, topic_ids_dev=None, 
     return out, bool(structure_ok), info
 
 
-def delivery_parity(batch, W, pa, n_windows_wanted=3):
+def _delivery_window_columns(w, fmt):
+    """(topic, sub_id, word) int64 device columns of one delivery window in either delivery format: 12-byte tuples carry the topic, 8-byte hits
+    (RGR_FORMAT_DELIVER8) leave it to the CSR offsets."""
+    import torch
+    from rmqtt_amd import capi
+    nh, tb_, te_ = int(w.n_hits), int(w.topic_begin), int(w.topic_end)
+    if fmt == capi.RGR_FORMAT_DELIVER8:
+        t = torch.as_tensor(_DevArr(w.d_hits8, (nh, 2), "<i4"), device="cuda")
+        d_off = torch.as_tensor(_DevArr(w.d_hit_offsets, (te_ - tb_ + 1,), "<i8"), device="cuda") - int(w.offsets_bias)
+        topic = torch.repeat_interleave(torch.arange(tb_, te_, dtype=torch.int64, device="cuda"), d_off[1:] - d_off[:-1])
+        return topic, t[:, 0].to(torch.int64) & 0xFFFFFFFF, t[:, 1].to(torch.int64) & 0xFFFFFFFF
+    t = torch.as_tensor(_DevArr(w.d_tuples, (nh, 3), "<i4"), device="cuda")
+    return t[:, 0].to(torch.int64) & 0xFFFFFFFF, t[:, 1].to(torch.int64) & 0xFFFFFFFF, t[:, 2].to(torch.int64) & 0xFFFFFFFF
+
+
+def delivery_parity(batch, W, pa, n_windows_wanted=3, fmt=0):
     """Full-size check of the delivery stage, in the bench line: the delivery words of whole windows of the
     timed pass — first, middle, last — against a restatement of the per-hit rules in torch on the device, independent of the
     library's kernels: qos' = min(publish, subscription), Retain-As-Published, No Local (owner == publisher), and the v5
@@ -346,6 +362,7 @@ def delivery_parity(batch, W, pa, n_windows_wanted=3):
     # which windows: count them with a pass of the SAME kind (a delivery pass has its own window size — 2^27 hits, a plain device-resident
     # pass 2^30: round 5's record counted the windows of a plain pass and so checked windows 0 / 69 / 138 of 1 106, all in the first eighth)
     batch.set_publish_attrs(pa)
+    batch.set_format(fmt)
     _, nwin = batch.run()
     want = sorted({0, nwin // 2, nwin - 1})[:n_windows_wanted]
     checked, bad, hits, dups, drops = [], 0, 0, 0, 0
@@ -364,10 +381,7 @@ def delivery_parity(batch, W, pa, n_windows_wanted=3):
             continue
         torch.cuda.synchronize()
         nh = int(w.n_hits)
-        t = torch.as_tensor(_DevArr(w.d_tuples, (nh, 3), "<i4"), device="cuda")
-        topic = t[:, 0].to(torch.int64) & 0xFFFFFFFF
-        sid = t[:, 1].to(torch.int64) & 0xFFFFFFFF
-        got = t[:, 2].to(torch.int64) & 0xFFFFFFFF
+        topic, sid, got = _delivery_window_columns(w, fmt)
         fl = flags[sid]
         pq = p_qr[topic]
         is5 = (fl & capi.RGR_SUB_V5) != 0
@@ -390,9 +404,9 @@ def delivery_parity(batch, W, pa, n_windows_wanted=3):
             last_window_topics = [int(w.topic_begin), int(w.topic_end)]
             last_is_partial = bool(int(w.topic_end) == W["n_pub"] and nh < max_hits_seen)
         max_hits_seen = max(max_hits_seen, nh)
-        del t, topic, sid, got, fl, pq, is5, exp, drop, cand, key, uk, inv, first, dup, di
+        del topic, sid, got, fl, pq, is5, exp, drop, cand, key, uk, inv, first, dup, di
         torch.cuda.synchronize()
-    return {"ok": bad == 0 and len(checked) == len(want) and wi + 1 == nwin, "windows_checked": checked, "of_windows": int(nwin), "windows_counted_by": "a delivery pass of the same batch",
+    return {"format": DELIVERY_FORMAT_NAMES.get(fmt, fmt), "ok": bad == 0 and len(checked) == len(want) and wi + 1 == nwin, "windows_checked": checked, "of_windows": int(nwin), "windows_counted_by": "a delivery pass of the same batch",
             "last_window": {"index": int(nwin) - 1, "topics": last_window_topics, "ends_the_batch_and_is_partial": last_is_partial},
             "hits": int(hits), "v5_duplicates_flagged": int(dups),
             "no_local_drops": int(drops), "mismatching_words": int(bad),
@@ -491,17 +505,18 @@ def compare_with_oracle(o, W, got, gpu_status, fmt_ok, dinfo, threads, primary, 
     return rec
 
 
-def delivery_oracle_sample(o, W, batch, pa, threads, seed=20260923):
+def delivery_oracle_sample(o, W, batch, pa, threads, seed=20260923, fmt=0):
     """Delivery words of the timed batch against the ORACLE at full table size: one more full pass; per topic the digest of
     x = sub_id * 32 + (word & 31) over its hits in position order, reduced on the device, compared with DefaultRouter::deliver_digest
     (which hits are delivered comes from the oracle's matches(): the restated _matches + collector) for a stratified sample — the
     heaviest topics, the topics of the first / last window ends, and a seeded random draw — bounded by the oracle's cost (O(hits) with
     a row per delivered hit)."""
     import torch
-    from rmqtt_amd import shard
+    from rmqtt_amd import capi, shard
     n = W["n_pub"]
     t0 = time.time()
     D = torch.zeros((n, 4), dtype=torch.int64, device="cuda")
+    batch.set_format(fmt)
     batch.begin()
     while True:
         w = batch.next_window()
@@ -513,8 +528,12 @@ def delivery_oracle_sample(o, W, batch, pa, threads, seed=20260923):
             continue
         d_off = torch.as_tensor(_DevArr(w.d_hit_offsets, (te_ - tb_ + 1,), "<i8"), device="cuda") - int(w.offsets_bias)
         start, end = d_off[:-1], d_off[1:]
-        t = torch.as_tensor(_DevArr(w.d_tuples, (nh, 3), "<i4"), device="cuda")
-        x = (t[:, 1].to(torch.int64) & 0xFFFFFFFF) * 32 + (t[:, 2].to(torch.int64) & 31)
+        if fmt == capi.RGR_FORMAT_DELIVER8:
+            t = torch.as_tensor(_DevArr(w.d_hits8, (nh, 2), "<i4"), device="cuda")
+            x = (t[:, 0].to(torch.int64) & 0xFFFFFFFF) * 32 + (t[:, 1].to(torch.int64) & 31)
+        else:
+            t = torch.as_tensor(_DevArr(w.d_tuples, (nh, 3), "<i4"), device="cuda")
+            x = (t[:, 1].to(torch.int64) & 0xFFFFFFFF) * 32 + (t[:, 2].to(torch.int64) & 31)
 
         def seg(v):
             cs = torch.cumsum(v, 0)
@@ -548,7 +567,7 @@ def delivery_oracle_sample(o, W, batch, pa, threads, seed=20260923):
     gst = batch.status()[sel]
     bad = np.nonzero((got != exp).any(axis=1))[0]
     ok = bool(np.array_equal(gst < 0, st < 0) and len(bad) == 0)
-    rec = {"ok": ok, "topics": int(len(sel)), "hits": int(exp[:, 0].sum()), "max_hits_in_one_topic": int(exp[:, 0].max()) if len(sel) else 0,
+    rec = {"format": DELIVERY_FORMAT_NAMES.get(fmt, fmt), "ok": ok, "topics": int(len(sel)), "hits": int(exp[:, 0].sum()), "max_hits_in_one_topic": int(exp[:, 0].max()) if len(sel) else 0,
            "share_of_hits": round(float(exp[:, 0].sum()) / max(1.0, total), 5), "share_of_topics": round(len(sel) / max(1, n), 5),
            "oracle_s": round(cpu_s, 2), "gpu_digest_s": round(gpu_s, 2),
            "what": "per topic: hits, sum x, sum (k+1) x, sum x^2 with x = sub_id*32 + (delivery word & 31), device vs the oracle's DefaultRouter::deliver_digest "
@@ -634,7 +653,7 @@ def run_pmc_children(args, phases, world=1, rank=0):
             cmd = [rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(work, counter), "-o", "pmc", "--",
                    sys.executable, os.path.abspath(__file__), "--pmc-child", meta, "--pmc-phases", ",".join(phases),
                    "--config", str(args.config), "--scale", str(args.scale), "--pmc-topics", str(args.pmc_topics),
-                   "--pmc-world", str(world), "--pmc-rank", str(rank)]
+                   "--pmc-world", str(world), "--pmc-rank", str(rank), "--deliver-format", args.deliver_format]
             if args.window_hits:
                 cmd += ["--window-hits", str(args.window_hits)]
             t = time.time()
@@ -705,6 +724,8 @@ def pmc_child(args):
             pa["from_id"] = prng.choice(W["client"].astype(np.uint32), size=n)
             pa["qos_retain"] = prng.integers(0, 3, size=n) | (prng.integers(0, 2, size=n) << 2)
             b.set_publish_attrs(pa)
+            if args.deliver_format == "hits8":
+                b.set_format(capi.RGR_FORMAT_DELIVER8)
         r.stats_reset()
         hits, _ = b.run()
         st = r.stats()
@@ -755,12 +776,17 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
     batch = r.retain_batch(tb_r, to_r) if retain else r.batch(tb_r, to_r)
     batch_create_s = time.time() - t
     log(f"config {cfg}: batch: {my_topics} topics tokenised + uploaded in {batch_create_s:.1f}s", rank)
+    dfmt = capi.RGR_FORMAT_TUPLE
     if deliver >= 0:
         pa = np.zeros(my_topics, dtype=capi.PUBLISH_ATTR_DTYPE)
         prng = np.random.default_rng(12)
         pa["from_id"] = prng.choice(client.astype(np.uint32), size=my_topics)
         pa["qos_retain"] = prng.integers(0, 3, size=my_topics) | (prng.integers(0, 2, size=my_topics) << 2)
         batch.set_publish_attrs(pa)
+        # the delivery stage's answer: 8-byte hits {sub_id, delivery word} by default (RGR_FORMAT_DELIVER8: the topic is implied by the CSR
+        # offsets, as in the compact formats of plain passes), the 12-byte tuple form timed beside it
+        dfmt = capi.RGR_FORMAT_DELIVER8 if args.deliver_format == "hits8" else capi.RGR_FORMAT_TUPLE
+        batch.set_format(dfmt)
 
     def barrier():
         if world > 1:
@@ -995,7 +1021,7 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
                 "walk_alg_GBps": round(walk_gbs, 1), "expand_alg_GBps": round(exp_gbs, 1)}
 
     rec = {
-        "metric": f"publish-topic matches/sec with delivery stage (config {cfg}, scale {scale}, v5 fraction {deliver})" if deliver >= 0 else
+        "metric": f"publish-topic matches/sec with delivery stage (config {cfg}, scale {scale}, v5 fraction {deliver}, {'8-byte hits' if dfmt == capi.RGR_FORMAT_DELIVER8 else '12-byte tuples'})" if deliver >= 0 else
                   "publish-topic matches/sec @10M subs" if cfg in (3, 4) and scale == 1.0 else
                   (f"retained-path SUBSCRIBE-filter matches/sec (config 5, scale {scale})" if retain else
                    f"publish-topic matches/sec (config {cfg}, scale {scale})"),
@@ -1053,12 +1079,38 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
     except Exception as e:      # reporting only: never fail the bench line over it
         log(f"shard imbalance not reported: {e}", 0)
     if deliver >= 0:
-        rec["delivery_stage"] = {"v5_fraction": deliver, "dedup_ms_per_step": round(st["dedup_ms"] / K, 3),
+        bph = 8 if dfmt == capi.RGR_FORMAT_DELIVER8 else 12
+        rec["delivery_stage"] = {"v5_fraction": deliver, "format": DELIVERY_FORMAT_NAMES[dfmt], "bytes_written_per_hit": bph,
+                                 "dedup_ms_per_step": round(st["dedup_ms"] / K, 3),
                                  "dedup_candidates_per_step": int(st["dedup_candidates"] / K),
-                                 "dedup_launches_per_step": int(st["dedup_launches"] / K)}
+                                 "dedup_launches_per_step": int(st["dedup_launches"] / K),
+                                 "expand_store_GBps": round(total_hits * K * bph / max(1e-9, st["expand_ms"] / 1e3) / 1e9, 1),
+                                 "frac_of_hbm_peak_stores_kernel": round(total_hits * K * bph / max(1e-9, st["expand_ms"] / 1e3) / 8.0e12, 3)}
+        roofline["bytes_written_per_hit"] = bph
+        if dfmt == capi.RGR_FORMAT_DELIVER8:
+            # the same batch, same table, in the 12-byte tuple form (what rounds 2-5 reported as the delivery record)
+            batch.set_format(capi.RGR_FORMAT_TUPLE)
+            batch.run()
+            r.stats_reset()
+            torch.cuda.synchronize()
+            t = time.time()
+            for _ in range(steps):
+                batch.run()
+            dt = time.time() - t
+            s12 = r.stats()
+            rec["delivery_stage"]["tuple12"] = {"value": round(my_topics * steps / dt, 1), "unit": rec["unit"], "ms_per_step": round(dt * 1e3 / steps, 3),
+                                                "expand_avg_launch_ms": round(s12["expand_ms"] / max(1, s12["expand_launches"]), 4),
+                                                "dedup_ms_per_step": round(s12["dedup_ms"] / steps, 3),
+                                                "expand_store_GBps": round(total_hits * steps * 12 / max(1e-9, s12["expand_ms"] / 1e3) / 1e9, 1)}
+            batch.set_format(dfmt)
         if not args.no_parity:
-            rec["parity_sample"] = delivery_parity(batch, W, pa)
+            rec["parity_sample"] = delivery_parity(batch, W, pa, fmt=dfmt)
             log(f"config {cfg}: delivery parity {rec['parity_sample']}", 0)
+            if dfmt == capi.RGR_FORMAT_DELIVER8:
+                p12 = delivery_parity(batch, W, pa, fmt=capi.RGR_FORMAT_TUPLE)
+                rec["parity_sample"]["tuple12"] = _pick(p12, ["ok", "windows_checked", "of_windows", "hits", "mismatching_words"])
+                rec["parity_sample"]["ok"] = bool(rec["parity_sample"]["ok"] and p12["ok"])
+                batch.set_format(dfmt)
         if args.cpu_sample != 0 and world == 1:
             # the oracle's side of the delivery record: its own delivery verdicts for a stratified sample of publishes (digests of the
             # per-hit words in canonical order, DefaultRouter::deliver_digest) against the device's, and the reference-shaped
@@ -1072,7 +1124,7 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
                 o.add_bulk_ex(blob, offs, client, qos, W["deliver_flags"])
                 log(f"config {cfg}: oracle table with v5 flags built in {time.time() - t:.1f}s", 0)
             if not args.no_parity:
-                rec["parity_sample"]["oracle"] = delivery_oracle_sample(o, W, batch, pa, cores)
+                rec["parity_sample"]["oracle"] = delivery_oracle_sample(o, W, batch, pa, cores, fmt=dfmt)
                 rec["parity_sample"]["ok"] = bool(rec["parity_sample"]["ok"] and rec["parity_sample"]["oracle"]["ok"])
                 log(f"config {cfg}: delivery oracle sample {rec['parity_sample']['oracle']}", 0)
             hpt = max(1.0, total_hits / max(1, total_topics))
@@ -1419,9 +1471,9 @@ def time_format(args):
     from rmqtt_amd import capi
     W = gen_workload(args.config, args.scale)
     names = args.time_format.split(",")
-    deliver = "deliver" in names                       # the delivery stage (tuples + delivery words + v5 dedup): `--deliver V5FRAC`, default 0.1
-    if deliver and (len(names) > 1 or W["retain"]):
-        raise SystemExit("--time-format deliver stands alone (the table carries the delivery flags) and needs a router config")
+    deliver = any(nm in ("deliver", "deliver8") for nm in names)        # the delivery stage (delivery words + v5 dedup) as 12-byte tuples / 8-byte hits: `--deliver V5FRAC`, default 0.1
+    if deliver and (any(nm not in ("deliver", "deliver8") for nm in names) or W["retain"]):
+        raise SystemExit("--time-format deliver / deliver8 stand alone (the table carries the delivery flags) and need a router config")
     r = capi.Router(device=0, window_hits=args.window_hits, collect_walk_stats=False)
     v5 = (args.deliver if args.deliver >= 0 else DELIVER_SECONDARY_V5) if deliver else -1.0
     build_table(r, W, W["blob"], W["offs"], np.arange(W["n_sub"], dtype=np.uint32), W["qos"], deliver_frac=v5)
@@ -1458,10 +1510,10 @@ def _set_variant(names, variant):
 def _time_one_format(args, W, r, batch, name, ab_name, ab_values):
     import torch
     from rmqtt_amd import capi
-    deliver = name == "deliver"
-    fmt = capi.RGR_FORMAT_TUPLE if deliver else FORMAT_NAMES.index(name)
+    deliver = name in ("deliver", "deliver8")
+    fmt = capi.RGR_FORMAT_DELIVER8 if name == "deliver8" else capi.RGR_FORMAT_TUPLE if deliver else FORMAT_NAMES.index(name)
     batch.set_format(fmt)
-    bph = {"tuple": 12, "soa": 5, "packed": 4, "runs": 0, "ids24": 3, "deliver": 12}[name]
+    bph = {"tuple": 12, "soa": 5, "packed": 4, "runs": 0, "ids24": 3, "deliver": 12, "deliver8": 8}[name]
     results = []
     for val in ab_values:
         _set_variant(ab_name, val)
@@ -1498,7 +1550,7 @@ def _time_one_format(args, W, r, batch, name, ab_name, ab_values):
             # restatement of the per-hit rules + the v5 first-hit-per-client rule (delivery_parity)
             t0 = time.time()
             _set_variant(ab_name, ab_values[best])
-            dp = delivery_parity(batch, W, W["publish_attrs"])
+            dp = delivery_parity(batch, W, W["publish_attrs"], fmt=fmt)
             _set_variant(ab_name, None)
             print(json.dumps({"ab_check": [ab_values[0], ab_values[best]], "format": name, "ok": bool(dp["ok"]), "delivery_parity": dp, "seconds": round(time.time() - t0, 1)}), flush=True)
             batch.set_format(capi.RGR_FORMAT_TUPLE)
@@ -1631,7 +1683,9 @@ def compact_record(r, top):
     if isinstance(r.get("pcie_inclusive_ranges"), dict):
         out["pcie_inclusive_ranges_matches_per_s"] = r["pcie_inclusive_ranges"].get("matches_per_s")
     if isinstance(r.get("delivery_stage"), dict):
-        out["delivery_stage"] = _pick(r["delivery_stage"], ["v5_fraction", "dedup_ms_per_step"])
+        out["delivery_stage"] = _pick(r["delivery_stage"], ["v5_fraction", "bytes_written_per_hit", "dedup_ms_per_step", "expand_store_GBps"])
+        if isinstance(r["delivery_stage"].get("tuple12"), dict):
+            out["delivery_stage"]["tuple12"] = _pick(r["delivery_stage"]["tuple12"], ["value", "ms_per_step"])
     if isinstance(r.get("gpu_async"), list) and r["gpu_async"]:
         out["latency_us"] = r["gpu_async"][0].get("latency_us")
     return out
@@ -1699,6 +1753,9 @@ def main():
     ap.add_argument("--deliver", type=float, default=-1.0, metavar="V5FRAC",
                     help="also run the delivery stage (SURVEY 8(f)-1): this fraction of the subscriptions is MQTT v5 "
                          "(No Local / RAP / per-client dedup); 0 = v3 only. Not the headline metric.")
+    ap.add_argument("--deliver-format", choices=["hits8", "tuple12"], default="hits8",
+                    help="answer format of the delivery stage's records: 8-byte hits {sub_id, delivery word} (RGR_FORMAT_DELIVER8; the 12-byte form is timed "
+                         "beside it) or 12-byte tuples only")
     ap.add_argument("--e2e-submitters", type=int, default=8)
     ap.add_argument("--e2e-outstanding", type=int, default=16384)
     ap.add_argument("--e2e-workers", type=int, default=0, help="completion pool threads (0 = cores / 4, at most 64)")

@@ -20,7 +20,7 @@ RGR_SUB_V5, RGR_SUB_NO_LOCAL, RGR_SUB_SHARED, RGR_SUB_RAP = 1, 2, 4, 8
 RGR_HIT_QOS_MASK, RGR_HIT_RETAIN, RGR_HIT_NO_LOCAL, RGR_HIT_V5_DUP = 3, 4, 8, 16
 ID_NONE = 0xFFFFFFFF
 RGR_SUB_TABLE_SHIFT, RGR_SUB_TABLE_MASK = 4, 0xF0     # flags bits 4-7: caller-defined table id
-RGR_FORMAT_TUPLE, RGR_FORMAT_SOA, RGR_FORMAT_PACKED, RGR_FORMAT_RUNS, RGR_FORMAT_IDS24 = 0, 1, 2, 3, 4
+RGR_FORMAT_TUPLE, RGR_FORMAT_SOA, RGR_FORMAT_PACKED, RGR_FORMAT_RUNS, RGR_FORMAT_IDS24, RGR_FORMAT_DELIVER8 = 0, 1, 2, 3, 4, 5
 
 TUPLE_DTYPE = np.dtype([("topic_idx", np.uint32), ("sub_id", np.uint32), ("qos_flags", np.uint32)])
 PUBLISH_ATTR_DTYPE = np.dtype([("from_id", np.uint32), ("qos_retain", np.uint32)])
@@ -94,7 +94,7 @@ class Window(C.Structure):
                 ("hit_base", C.c_uint64), ("d_tuples", C.c_void_p), ("d_hit_offsets", C.c_void_p),
                 ("offsets_bias", C.c_uint64), ("d_sub_ids", C.c_void_p), ("d_qos", C.c_void_p),
                 ("n_runs", C.c_uint64), ("d_run_src", C.c_void_p), ("d_run_topic", C.c_void_p), ("d_run_off", C.c_void_p), ("d_subs", C.c_void_p),
-                ("d_ids24", C.c_void_p)]
+                ("d_ids24", C.c_void_p), ("d_hits8", C.c_void_p)]
 
 
 class Stats(C.Structure):
@@ -523,7 +523,7 @@ class Batch:
 
     def set_format(self, fmt):
         """RGR_FORMAT_TUPLE (12 B/hit) | RGR_FORMAT_SOA (sub ids + qos bytes, 5 B/hit) | RGR_FORMAT_PACKED (4 B/hit) | RGR_FORMAT_RUNS |
-        RGR_FORMAT_IDS24 (3-byte sub ids, 3 B/hit)."""
+        RGR_FORMAT_IDS24 (3-byte sub ids, 3 B/hit) | RGR_FORMAT_DELIVER8 (delivery passes: {sub_id, delivery word}, 8 B/hit)."""
         _check(lib().rgr_batch_set_format(self._b, fmt))
 
     def run(self):

@@ -1346,8 +1346,8 @@ int32_t rgr_batch_set_publish_attrs(rgr_batch* b, const rgr_publish_attr* attrs)
         if (!b) return fail(RGR_EINVAL, "rgr_batch_set_publish_attrs: bad argument");
         if (b->in_pass) return fail(RGR_ESTATE, "rgr_batch_set_publish_attrs: inside a pass");
         if (b->retain) return fail(RGR_ESTATE, "rgr_batch_set_publish_attrs: not a publish batch");
-        if (!attrs) { b->deliver = false; return RGR_OK; }
-        if (b->format != kFmtTuple) return fail(RGR_ESTATE, "rgr_batch_set_publish_attrs: the delivery stage needs RGR_FORMAT_TUPLE");
+        if (!attrs) { b->deliver = false; if (b->format == kFmtDeliver8) b->format = kFmtTuple; return RGR_OK; }
+        if (b->format != kFmtTuple && b->format != kFmtDeliver8) return fail(RGR_ESTATE, "rgr_batch_set_publish_attrs: the delivery stage needs RGR_FORMAT_TUPLE or RGR_FORMAT_DELIVER8");
         if (b->has_topic_ids) return fail(RGR_ESTATE, "rgr_batch_set_publish_attrs: not together with rgr_batch_set_topic_ids");
         RGR_HIP(hipSetDevice(b->h->cfg.device));
         static_assert(sizeof(rgr_publish_attr) == sizeof(PublishAttr), "rgr_publish_attr layout");
@@ -1375,10 +1375,13 @@ int32_t rgr_batch_set_topic_ids(rgr_batch* b, const uint32_t* ids) {
 }
 
 int32_t rgr_batch_set_format(rgr_batch* b, uint32_t format) {
-    if (!b || format > RGR_FORMAT_IDS24) return fail(RGR_EINVAL, "rgr_batch_set_format: bad argument");
+    if (!b || format > RGR_FORMAT_DELIVER8) return fail(RGR_EINVAL, "rgr_batch_set_format: bad argument");
     if (b->in_pass) return fail(RGR_ESTATE, "rgr_batch_set_format: inside a pass");
-    if (format != RGR_FORMAT_TUPLE && b->deliver) return fail(RGR_ESTATE, "rgr_batch_set_format: the delivery stage needs RGR_FORMAT_TUPLE");
-    static_assert(RGR_FORMAT_TUPLE == kFmtTuple && RGR_FORMAT_SOA == kFmtSoa && RGR_FORMAT_PACKED == kFmtPacked && RGR_FORMAT_RUNS == kFmtRuns && RGR_FORMAT_IDS24 == kFmtIds24, "format constants");
+    if (format != RGR_FORMAT_TUPLE && format != RGR_FORMAT_DELIVER8 && b->deliver) return fail(RGR_ESTATE, "rgr_batch_set_format: the delivery stage needs RGR_FORMAT_TUPLE or RGR_FORMAT_DELIVER8");
+    if (format == RGR_FORMAT_DELIVER8 && (!b->deliver || b->retain)) return fail(RGR_ESTATE, "rgr_batch_set_format: RGR_FORMAT_DELIVER8 is the delivery stage's format (attach publish attributes first)");
+    static_assert(RGR_FORMAT_TUPLE == kFmtTuple && RGR_FORMAT_SOA == kFmtSoa && RGR_FORMAT_PACKED == kFmtPacked && RGR_FORMAT_RUNS == kFmtRuns && RGR_FORMAT_IDS24 == kFmtIds24 &&
+                  RGR_FORMAT_DELIVER8 == kFmtDeliver8, "format constants");
+    static_assert(sizeof(rgr_hit8) == 8, "rgr_hit8 layout");
     b->format = int(format);
     return RGR_OK;
 }
@@ -1485,7 +1488,7 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
             const uint32_t T = expand_tile_hits();
             DevBuf& outbuf = b->alt_out ? b->out2 : b->out;
             const uint64_t ids_bytes = (nh * 4 + 255) & ~uint64_t(255);           // compact formats: sub ids, then the qos bytes
-            outbuf.ensure(b->format == kFmtTuple ? nh * sizeof(Tuple) : b->format == kFmtIds24 ? nh * 3 + 16 : ids_bytes + (b->format == kFmtSoa ? nh + 16 : 0));
+            outbuf.ensure(b->format == kFmtTuple ? nh * sizeof(Tuple) : b->format == kFmtDeliver8 ? nh * 8 : b->format == kFmtIds24 ? nh * 3 + 16 : ids_bytes + (b->format == kFmtSoa ? nh + 16 : 0));
             ChunkArrays ca = make_chunk_arrays(b, n);
             size_t sp;
             const char* fused_env = std::getenv("RGR_TILES_FUSED");
@@ -1550,23 +1553,23 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
                 }
             }
             sp = b->span_begin(kSpanExpand);
-            if (b->format == kFmtTuple)
+            if (b->format == kFmtTuple || b->format == kFmtDeliver8)
                 launch_expand(batch_view(b), ca, pair_lo, pair_hi, hit_lo, hit_hi, tile_recs, outbuf.as<Tuple>(), b->stream,
-                              (b->deliver && !b->retain) ? &da : nullptr);
+                              (b->deliver && !b->retain) ? &da : nullptr, b->format == kFmtDeliver8);
             else if (launch_expand_compact(batch_view(b), ca, pair_lo, pair_hi, hit_lo, hit_hi, tile_recs, b->format,
                                            outbuf.as<uint32_t>(), outbuf.as<uint8_t>() + ids_bytes, b->stream, next_tiles.out ? &next_tiles : nullptr))
                 b->tile_plan = next_plan;                      // the expansion wrote the next window's records as well
             b->span_end(sp);
             b->win_seq++;
             // the chunk's accounting charged 20 B per hit (8 read + 12 written); the compact formats write 5 / 4
-            if (b->format != kFmtTuple) b->local.alg_bytes_expand -= nh * (b->format == kFmtSoa ? 7 : b->format == kFmtIds24 ? 9 : 8);
+            if (b->format != kFmtTuple) b->local.alg_bytes_expand -= nh * (b->format == kFmtSoa ? 7 : b->format == kFmtIds24 ? 9 : b->format == kFmtDeliver8 ? 4 : 8);
             b->local.expand_launches++;
             if (dedup) {
                 // LDS tables (tile-local, then one block per spanning topic); stream-ordered, no host synchronisation
                 sp = b->span_begin(kSpanDedup);
                 const DedupExempt dx{b->exempt ? b->c->topic_ex.as<TopicEx>() + lc : nullptr, b->c->pair_off.as<uint64_t>(), b->epoch->view.run_index};
-                launch_dedup(b->cand.as<Cand>(), b->cand_count.as<uint32_t>(), b->cand_count.as<uint32_t>() + (nh + T - 1) / T, uint32_t((nh + T - 1) / T), outbuf.as<Tuple>(),
-                             le - lc, b->c->hit_off.as<uint64_t>() + lc, hit_lo, b->dedup_items.as<DedupItem>(),
+                launch_dedup(b->cand.as<Cand>(), b->cand_count.as<uint32_t>(), b->cand_count.as<uint32_t>() + (nh + T - 1) / T, uint32_t((nh + T - 1) / T),
+                             b->format == kFmtDeliver8 ? hit8_words(outbuf.p) : tuple_words(outbuf.as<Tuple>()), le - lc, b->c->hit_off.as<uint64_t>() + lc, hit_lo, b->dedup_items.as<DedupItem>(),
                              reinterpret_cast<uint32_t*>(b->dedup_scalars.as<unsigned long long>() + 1), b->dedup_seq & 1u, b->dedup_scalars.as<unsigned long long>(), b->stream,
                              b->exempt ? &dx : nullptr);
                 b->dedup_seq++;            // (its own counter, advanced exactly where a launch consumed the parity: ADVICE r5)
@@ -1623,6 +1626,7 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
             w->d_sub_ids = (b->format == kFmtSoa || b->format == kFmtPacked) && nh ? static_cast<const uint32_t*>(op) : nullptr;
             w->d_qos = b->format == kFmtSoa && nh ? static_cast<const uint8_t*>(op) + ids_bytes : nullptr;
             w->d_ids24 = b->format == kFmtIds24 && nh ? static_cast<const uint8_t*>(op) : nullptr;
+            w->d_hits8 = b->format == kFmtDeliver8 && nh ? static_cast<const rgr_hit8*>(op) : nullptr;
         }
         w->d_hit_offsets = b->c->hit_off.as<uint64_t>() + lc;
         w->offsets_bias = hit_lo;

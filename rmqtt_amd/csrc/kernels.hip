@@ -635,7 +635,7 @@ __global__ __launch_bounds__(256) void compact_big_kernel(TrieView tv, ChunkArra
 __global__ __launch_bounds__(256) void exempt_select_kernel(TrieView tv, ChunkArrays c) {
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= c.n) return;
-    TopicEx best{kNone, 0, 0, 0};
+    TopicEx best{kNone, 0, 0, 0, 0};
     const uint64_t p0 = c.pair_base[t], p1 = c.pair_base[t + 1];
     if (c.hit_off[t + 1] - c.hit_off[t] >= tv.run_min) {
         uint64_t o = p0 < p1 ? c.pair_off[p0] : 0;
@@ -648,7 +648,7 @@ __global__ __launch_bounds__(256) void exempt_select_kernel(TrieView tv, ChunkAr
             for (uint32_t s = run_dir_hash(src) & tv.run_dir_mask;; s = (s + 1) & tv.run_dir_mask) {
                 const RunDirEntry e = tv.run_dir[s];
                 if (e.src == kNone) break;
-                if (e.src == src) { best = TopicEx{uint32_t(p), e.idx_begin, e.idx_mask, uint32_t(len)}; break; }
+                if (e.src == src) { best = TopicEx{uint32_t(p), e.idx_begin, e.idx_mask, uint32_t(len), o1 - len}; break; }
             }
         }
     }
@@ -903,10 +903,16 @@ void launch_tiles(const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint
 }
 
 void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint64_t hit_hi,
-                   const TileRec* tile_first, Tuple* out, void* stream, const DeliverArgs* deliver) {
+                   const TileRec* tile_first, Tuple* out, void* stream, const DeliverArgs* deliver, bool hits8) {
     if (hit_hi <= hit_lo) return;
     const uint32_t ntiles = uint32_t((hit_hi - hit_lo + kTile - 1) / kTile);
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (deliver && hits8) {          // RGR_FORMAT_DELIVER8 (r6): the lean expansion writing {sub_id, word} per hit
+        const char* g = std::getenv("RGR_DELIVER_LEAN");
+        if (g && g[0] == '2') expand_deliver_lean_kernel<kTile / 8, 8, true><<<ntiles, kTile / 8, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, *deliver);
+        else expand_deliver_lean_kernel<kTile / 4, 4, true><<<ntiles, kTile / 4, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, *deliver);
+        return;
+    }
     // the plain kernel runs 1024 x 2 (with the single-run fast path: +3 % over 512 x 4, profiles/r02f_sweep_*); the delivery
     // variant keeps 512 x 4 — its per-wave candidate bookkeeping was 19 % slower at 1024 x 2 (profiles/r02g_bench_config3_deliver_*)
     // the delivery variant with its loads issued early (expand_tuple.inc) is the default since r5a: 0.876 -> 0.860 ms per 2^28-hit window,
@@ -1011,7 +1017,7 @@ void launch_node_groups(const Tuple* tuples, const uint64_t* hit_off, uint64_t h
 
 uint32_t dedup_topic_cap() { return kDedupTopicCap; }
 
-void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, const uint32_t* tile_trange, uint32_t ntiles, Tuple* tuples, uint32_t nt,
+void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, const uint32_t* tile_trange, uint32_t ntiles, HitWords tuples, uint32_t nt,
                   const uint64_t* hit_off, uint64_t hit_lo, DedupItem* items, uint32_t* item_counts, uint32_t parity, unsigned long long* stat, void* stream,
                   const DedupExempt* ex) {
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -1024,8 +1030,14 @@ void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, const uint32_t* 
     const uint32_t tile_blocks = std::min<uint32_t>(ntiles, 2048u);
 #endif
     const bool has_ex = ex && ex->topic_ex && ex->run_index;
-    dedup_tile_kernel<<<tile_blocks + (nt + 255) / 256, 256, 0, s>>>(cand, tile_ncand, tile_trange, ntiles, hit_off, hit_lo, nt, tuples, stat, tile_blocks, items, item_counts, parity,
-                                                                     has_ex ? ex->topic_ex : nullptr);
+    DedupExempt dx = has_ex ? *ex : DedupExempt{nullptr, nullptr, nullptr};
+    // RGR_DIAG_EX_NOPROBE=1 (timing diagnostic, read per launch; WRONG flags by construction): the exempt runs stay out of the lists but nobody asks
+    // their indices — what the candidates' absence alone is worth
+    if (has_ex && std::getenv("RGR_DIAG_EX_NOPROBE")) dx.run_index = nullptr;
+    // exempt runs: probe blocks behind the classification's (four tiles' candidate lists per wave at a full 2^27-hit window)
+    const uint32_t probe_blocks = has_ex ? std::min<uint32_t>((ntiles + 3) / 4, 4096u) : 0u;
+    dedup_tile_kernel<<<tile_blocks + (nt + 255) / 256 + probe_blocks, 256, 0, s>>>(cand, tile_ncand, tile_trange, ntiles, hit_off, hit_lo, nt, tuples, stat, tile_blocks, items, item_counts,
+                                                                                    parity, dx);
     uint32_t* item_count = item_counts + parity;
     // RGR_DEDUP_TEST_SLOTS (tests only): a smaller table, so that parts overflow and the re-split path runs on ordinary inputs
     // (read on every launch — it is one getenv — so that a test can set it after other tests of the same process have launched)
@@ -1041,7 +1053,6 @@ void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, const uint32_t* 
     // instructions cost 0.515 ms)
     const char* pe = std::getenv("RGR_DEDUP_PROBE");
     const uint32_t grid = kDedupTopicThreads >= 512 ? 1024 : 1280;
-    const DedupExempt dx = has_ex ? *ex : DedupExempt{nullptr, nullptr, nullptr};
     if (pe && pe[0] == '0') {
         if (has_ex) dedup_topic_kernel<0, true><<<grid, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, hit_off, hit_lo, items, item_count, tuples, max_slots, dx);
         else dedup_topic_kernel<0, false><<<grid, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, hit_off, hit_lo, items, item_count, tuples, max_slots, dx);

@@ -84,7 +84,8 @@ constexpr uint32_t kExemptMinRun = 4096;      // > one expansion tile (2 048 hit
 constexpr uint32_t kPairExempt = 8u;          // bit of ChunkArrays::pair_qr / TileRec::qr
 constexpr unsigned long long kRunIndexEmpty = ~0ull;
 struct alignas(16) RunDirEntry { uint32_t src, idx_begin, idx_mask, n_keys; };      // src == kNone: empty slot
-struct alignas(16) TopicEx { uint32_t pair, idx_begin, idx_mask, len; };            // pair: chunk-local index of the exempt pair, kNone = none
+// pair: chunk-local index of the exempt pair (kNone = none); off: chunk-local output offset of the run's first hit (its window position is off - hit_lo)
+struct alignas(8) TopicEx { uint32_t pair, idx_begin, idx_mask, len; uint64_t off; };
 RGR_HD inline uint32_t mix32(uint32_t x) {           // bijective
     x ^= x >> 16; x *= 0x7feb352du;
     x ^= x >> 15; x *= 0x846ca68bu;
@@ -280,10 +281,11 @@ struct alignas(16) TileRec { uint32_t first, src, topic, qr; };
 // delivery passes, after the compaction: per topic the longest run that has a client index -> c.topic_ex[t], bit kPairExempt of its pair_qr
 void launch_exempt_select(const TrieView& t, const ChunkArrays& c, void* stream);
 void launch_tiles(const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, TileRec* tile_first, void* stream);
+// hits8: `out` receives 8-byte hits {sub_id, delivery word} (delivery passes in RGR_FORMAT_DELIVER8; lean expansion only)
 void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint64_t hit_hi,
-                   const TileRec* tile_first, Tuple* out, void* stream, const DeliverArgs* deliver = nullptr);
+                   const TileRec* tile_first, Tuple* out, void* stream, const DeliverArgs* deliver = nullptr, bool hits8 = false);
 // compact result formats (rgr_batch_set_format): sub ids (+ a qos byte array) without the topic column
-constexpr int kFmtTuple = 0, kFmtSoa = 1, kFmtPacked = 2, kFmtRuns = 3, kFmtIds24 = 4;     // == RGR_FORMAT_*
+constexpr int kFmtTuple = 0, kFmtSoa = 1, kFmtPacked = 2, kFmtRuns = 3, kFmtIds24 = 4, kFmtDeliver8 = 5;     // == RGR_FORMAT_*
 // packed[i] = subs[i].sub_id | (subs[i].qos_flags & 3) << 30 for i in [0, n)
 constexpr uint32_t kPackedPad = 16;      // entries allocated past the end of a packed side array (never read for their value)
 void launch_pack_subs(const SubEntry* subs, uint64_t n, uint32_t* packed, void* stream);
@@ -298,9 +300,16 @@ bool launch_expand_compact(const TrieView& t, const ChunkArrays& c, uint64_t pai
 // nt + n_hits / dedup_topic_cap() + 1 entries; *stat accumulates the candidate count.  Everything is stream-ordered: no host sync.
 // work item of the topic pass: part `part` of `parts` of window topic `topic` (nc candidates in total)
 struct DedupItem { uint32_t topic, part, parts, nc; };
+// where the delivery word of window position p lives: the third word of a 12-byte tuple, or the second of an 8-byte hit (RGR_FORMAT_DELIVER8)
+struct HitWords {
+    uint32_t* first; uint32_t stride;        // in 32-bit words
+    RGR_HD uint32_t& at(uint32_t pos) const { return first[uint64_t(pos) * stride]; }
+};
+inline HitWords tuple_words(Tuple* t) { return HitWords{t ? &t->qos_flags : nullptr, 3}; }
+inline HitWords hit8_words(void* p) { return HitWords{p ? static_cast<uint32_t*>(p) + 1 : nullptr, 2}; }
 // ex (optional): the window's exempt runs — topic_ex points at the window's first topic, pair_off is the chunk's array, run_index the epoch's
 struct DedupExempt { const TopicEx* topic_ex; const uint64_t* pair_off; const unsigned long long* run_index; };
-void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, const uint32_t* tile_trange, uint32_t ntiles, Tuple* tuples, uint32_t nt,
+void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, const uint32_t* tile_trange, uint32_t ntiles, HitWords words, uint32_t nt,
                   const uint64_t* hit_off, uint64_t hit_lo, DedupItem* items, uint32_t* item_counts /* two words, zero when the pass begins */,
                   uint32_t parity /* window & 1 */, unsigned long long* stat, void* stream, const DedupExempt* ex = nullptr);
 uint32_t dedup_topic_cap();

@@ -120,6 +120,7 @@ pub const RGR_FORMAT_SOA: u32 = 1;
 pub const RGR_FORMAT_PACKED: u32 = 2;
 pub const RGR_FORMAT_RUNS: u32 = 3;
 pub const RGR_FORMAT_IDS24: u32 = 4;
+pub const RGR_FORMAT_DELIVER8: u32 = 5;
 pub const RGR_TOPIC_INVALID: i32 = -2;
 pub const RGR_PACKET_MALFORMED: i32 = -8;
 pub const RGR_COMM_ID_BYTES: usize = 128;
@@ -141,6 +142,15 @@ pub struct rgr_window {
     pub d_run_off: *const u64,
     pub d_subs: *const u64,
     pub d_ids24: *const u8,
+    pub d_hits8: *const rgr_hit8,
+}
+
+/// One hit of a delivery pass in RGR_FORMAT_DELIVER8: relation + delivery word (the topic is implied by the CSR offsets).
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct rgr_hit8 {
+    pub sub_id: u32,
+    pub word: u32,
 }
 
 #[repr(C)]

@@ -103,6 +103,7 @@ def expand_ids24_fused(subs, pair_src, pair_off, pair_lo, pair_mid, pair_hi):
 # ---------------------------------------------------------------------------------------------- v5 per-client dedup (dedup.inc)
 CAND_DTYPE = np.dtype([("pos", np.uint32), ("client_idx", np.uint32)])
 TUPLE_DTYPE = np.dtype([("topic_idx", np.uint32), ("sub_id", np.uint32), ("qos_flags", np.uint32)])
+HIT8_DTYPE = np.dtype([("sub_id", np.uint32), ("word", np.uint32)])
 _DLIB = None
 
 
@@ -125,7 +126,7 @@ def dedup_lib():
     return _DLIB
 
 
-TOPIC_EX_DTYPE = np.dtype([("pair", np.uint32), ("idx_begin", np.uint32), ("idx_mask", np.uint32), ("len", np.uint32)])
+TOPIC_EX_DTYPE = np.dtype([("pair", np.uint32), ("idx_begin", np.uint32), ("idx_mask", np.uint32), ("len", np.uint32), ("off", np.uint64)])
 _M32 = 0xFFFFFFFF
 
 
@@ -185,9 +186,10 @@ def dedup(variant, hit_off, cand_pos, cand_client, tile=2048, grid_topic=1024, m
         t_first = int(np.searchsorted(rel, lo, side="right") - 1)
         t_last = int(np.searchsorted(rel, hi - 1, side="right") - 1)
         whole = t_first != t_last or (rel[t_first] >= lo and rel[t_first + 1] <= lo + tile)
+        if ncand[tl]:                               # (r6: the topic range of every tile with candidates — the exempt runs' probe blocks use it)
+            trange[2 * tl], trange[2 * tl + 1] = t_first, t_last
         if ncand[tl] >= 2 and whole:
             ncand[tl] |= 1 << 31
-            trange[2 * tl], trange[2 * tl + 1] = t_first, t_last
     tuples = np.zeros(nh, dtype=TUPLE_DTYPE)
     drop = np.asarray(sorted(dropped), dtype=np.int64)
     tuples["qos_flags"][drop] = 8
@@ -200,7 +202,7 @@ def dedup(variant, hit_off, cand_pos, cand_client, tile=2048, grid_topic=1024, m
         offs, tabs, at = [], [np.full(3, 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)], 3          # (index pool with some leading garbage)
         for k, (t, (pos0, clients)) in enumerate(sorted(exempt.items())):
             tab = run_index(clients)
-            ex_arr[t] = (k, at, len(tab) - 1, len(clients))
+            ex_arr[t] = (k, at, len(tab) - 1, len(clients), hit_lo + pos0)
             offs.append(hit_lo + pos0)
             tabs.append(tab); at += len(tab)
         pair_off = np.asarray(offs + [0], dtype=np.uint64)
@@ -253,8 +255,9 @@ def expand_tuple(variant, subs, attrs, pub, pair_src, pair_topic, pair_off, pair
     pair_qr = np.ascontiguousarray(pair_qr, dtype=np.uint8)
     nh = int(pair_off[pair_hi] - pair_off[pair_lo])
     ntiles = (nh + tile - 1) // tile
-    out = np.zeros(nh + 1, dtype=TUPLE_DTYPE)
-    out[nh] = (0xA5A5A5A5, 0xA5A5A5A5, 0xA5A5A5A5)
+    hits8 = variant in (5, 6)                       # 8-byte hits {sub_id, word}: the buffer is sized for them and guarded right behind
+    out = np.zeros(nh + 1, dtype=HIT8_DTYPE if hits8 else TUPLE_DTYPE)
+    out[nh] = (0xA5A5A5A5, 0xA5A5A5A5) if hits8 else (0xA5A5A5A5, 0xA5A5A5A5, 0xA5A5A5A5)
     deliver = variant != 0
     cand = np.full(ntiles * tile, 0xFFFFFFFF, dtype=np.uint64).view(CAND_DTYPE) if deliver and want_cand else None
     ncand = np.full(ntiles, 0xDEADBEEF, dtype=np.uint32) if deliver and want_cand else None
@@ -265,7 +268,7 @@ def expand_tuple(variant, subs, attrs, pub, pair_src, pair_topic, pair_off, pair
     if rc == -2:
         raise AssertionError("hipsim: threads diverged around a convergent operation in the tuple expansion")
     assert rc == 0
-    assert tuple(out[nh]) == (0xA5A5A5A5, 0xA5A5A5A5, 0xA5A5A5A5), "write past the window's tuples"
+    assert all(int(x) == 0xA5A5A5A5 for x in out[nh]), "write past the window's tuples"
     lists = None
     if cand is not None:
         lists = []

@@ -31,16 +31,18 @@ int32_t sim_dedup(int32_t variant, uint32_t grid_topic, uint32_t max_slots, cons
     const uint32_t tile_blocks = ntiles < 64 ? ntiles : 64;
     const DedupExempt dx{topic_ex, pair_off, run_index};
     // tile pass + classification: one launch (blocks behind the tile pass's classify 256 window topics each)
-    ok &= hipsim::run(tile_blocks + (nt + 255) / 256, 256, [&] { dedup_tile_kernel(cand, tile_ncand, tile_trange, ntiles, hit_off, hit_lo, nt, tuples, &stat, tile_blocks, items.data(), item_counts, 1u, topic_ex); });
+    // (+ the exempt runs' probe blocks: fewer blocks than tiles / 4, so that waves walk several tiles)
+    const uint32_t probe_blocks = topic_ex ? (ntiles + 11) / 12 : 0;
+    ok &= hipsim::run(tile_blocks + (nt + 255) / 256 + probe_blocks, 256, [&] { dedup_tile_kernel(cand, tile_ncand, tile_trange, ntiles, hit_off, hit_lo, nt, tuple_words(tuples), &stat, tile_blocks, items.data(), item_counts, 1u, dx); });
     if (item_counts[0] != 0) return -4;          // the next window's counter was not zeroed
     uint32_t& item_count = item_counts[1];
     if (variant != 0 && variant != 3) return -3;        // variant = the topic pass's probe_mode (bit 0: double hashing, bit 1: 16-byte clears)
     if (topic_ex) {
-        if (variant == 3) ok &= hipsim::run(grid_topic, kDedupTopicThreads, [&] { dedup_topic_kernel<3, true>(cand, tile_ncand, hit_off, hit_lo, items.data(), &item_count, tuples, max_slots, dx); });
-        else ok &= hipsim::run(grid_topic, kDedupTopicThreads, [&] { dedup_topic_kernel<0, true>(cand, tile_ncand, hit_off, hit_lo, items.data(), &item_count, tuples, max_slots, dx); });
+        if (variant == 3) ok &= hipsim::run(grid_topic, kDedupTopicThreads, [&] { dedup_topic_kernel<3, true>(cand, tile_ncand, hit_off, hit_lo, items.data(), &item_count, tuple_words(tuples), max_slots, dx); });
+        else ok &= hipsim::run(grid_topic, kDedupTopicThreads, [&] { dedup_topic_kernel<0, true>(cand, tile_ncand, hit_off, hit_lo, items.data(), &item_count, tuple_words(tuples), max_slots, dx); });
     } else {
-        if (variant == 3) ok &= hipsim::run(grid_topic, kDedupTopicThreads, [&] { dedup_topic_kernel<3, false>(cand, tile_ncand, hit_off, hit_lo, items.data(), &item_count, tuples, max_slots, dx); });
-        else ok &= hipsim::run(grid_topic, kDedupTopicThreads, [&] { dedup_topic_kernel<0, false>(cand, tile_ncand, hit_off, hit_lo, items.data(), &item_count, tuples, max_slots, dx); });
+        if (variant == 3) ok &= hipsim::run(grid_topic, kDedupTopicThreads, [&] { dedup_topic_kernel<3, false>(cand, tile_ncand, hit_off, hit_lo, items.data(), &item_count, tuple_words(tuples), max_slots, dx); });
+        else ok &= hipsim::run(grid_topic, kDedupTopicThreads, [&] { dedup_topic_kernel<0, false>(cand, tile_ncand, hit_off, hit_lo, items.data(), &item_count, tuple_words(tuples), max_slots, dx); });
     }
     if (n_items_out) *n_items_out = item_count;
     return ok ? 0 : -2;

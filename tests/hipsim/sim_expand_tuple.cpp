@@ -20,7 +20,7 @@ using namespace rgr;
 extern "C" {
 
 // variant 0: expand_kernel<false, 1024, 2> (tuples only), 1: expand_kernel<true, 512, 4>, 2: expand_deliver_early_kernel<512, 4>,
-// 3: expand_deliver_lean_kernel<512, 4> (r5: v5 hits compacted per wave), 4: expand_deliver_lean_kernel<256, 8>.
+// 3: expand_deliver_lean_kernel<512, 4> (r5: v5 hits compacted per wave), 4: expand_deliver_lean_kernel<256, 8>, 5 / 6: the same two with 8-byte hits.
 // cand / tile_ncand / tile_trange may be null (an epoch without v5 subscriptions).  Returns 0, -1 unknown variant, -2 divergence.
 int32_t sim_expand_tuple(int32_t variant, const SubEntry* subs, const SubAttr* attrs, const PublishAttr* pub, const uint32_t* pair_src,
                          const uint32_t* pair_topic, const uint64_t* pair_off, const uint8_t* pair_qr, uint64_t pair_lo, uint64_t pair_hi, uint32_t topic_lo,
@@ -45,6 +45,9 @@ int32_t sim_expand_tuple(int32_t variant, const SubEntry* subs, const SubAttr* a
     else if (variant == 2) ok = hipsim::run(ntiles, 512, [&] { expand_deliver_early_kernel<512, 4>(subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tf, ntiles, out, da); });
     else if (variant == 3) ok = hipsim::run(ntiles, 512, [&] { expand_deliver_lean_kernel<512, 4>(subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tf, ntiles, out, da); });
     else if (variant == 4) ok = hipsim::run(ntiles, 256, [&] { expand_deliver_lean_kernel<256, 8>(subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tf, ntiles, out, da); });
+    // 5 / 6: the lean variants writing 8-byte hits {sub_id, delivery word} (RGR_FORMAT_DELIVER8) into the same buffer
+    else if (variant == 5) ok = hipsim::run(ntiles, 512, [&] { expand_deliver_lean_kernel<512, 4, true>(subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tf, ntiles, out, da); });
+    else if (variant == 6) ok = hipsim::run(ntiles, 256, [&] { expand_deliver_lean_kernel<256, 8, true>(subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tf, ntiles, out, da); });
     else return -1;
     return ok ? 0 : -2;
 }

@@ -9,6 +9,7 @@ hold (sub_id -> relation) and compares text for text.
 """
 import random
 
+import ctypes as C
 import os
 
 import numpy as np
@@ -489,3 +490,75 @@ def test_oracle_delivery_digest_equals_the_delivery_words(kind):
     # the reference-shaped timed pass (cpu_baseline of the delivery record) delivers exactly the hits that are neither dropped nor duplicates
     sec, stt = o.forwards_timed(tb, to, attrs["from_id"], attrs["qos_retain"].astype(np.uint8), threads=2)
     assert stt["hits"] == int(exp[:, 0].sum()) and stt["rows"] == int(exp[:, 0].sum()) - n_dup - n_drop and sec > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("window_hits", [0, 5000])
+def test_deliver8_windows_equal_the_delivery_tuples(window_hits, monkeypatch):
+    """RGR_FORMAT_DELIVER8 (r6): a device-resident delivery pass answers with 8-byte hits {sub_id, delivery word}; window for window they are the
+    12-byte delivery tuples without the topic column (which the CSR offsets imply) — v5 duplicates, No Local drops and exempt runs included.
+    The format is the delivery stage's own: without publish attributes it is refused, detaching them returns the batch to tuples."""
+    monkeypatch.setenv("RGR_EXEMPT_MIN_RUN", "2049")
+    rng = np.random.default_rng(5)
+    r = capi.Router(device=0, window_hits=window_hits)
+    filters = ["a/#", "a/b/c", "+/+/+", "a/b/+", "#", "x/y"]
+    sid = 0
+    for j, f in enumerate(filters):
+        fid = r.filter_add(f)
+        for c in rng.choice(4000, size=[3000, 2500, 2200, 300, 40, 9][j], replace=False):
+            v5 = rng.random() < 0.5
+            flags = (capi.RGR_SUB_V5 | (capi.RGR_SUB_NO_LOCAL if rng.random() < 0.3 else 0) | (capi.RGR_SUB_RAP if rng.random() < 0.5 else 0)) if v5 else 0
+            r.sub_add_ex(fid, sid, int(rng.integers(0, 3)), flags, int(c) % 3, int(c), int(c))
+            sid += 1
+    r.commit()
+    topics = ["a/b/c", "x/y", "a/b", "nothing", "a/b/c", "q/r/s", "a/b/c/d"] * 3
+    blob, offs = pack(topics)
+    b = r.batch(blob, offs)
+    with pytest.raises(capi.RgrError):
+        b.set_format(capi.RGR_FORMAT_DELIVER8)               # not without publish attributes
+    attrs = np.zeros(len(topics), dtype=capi.PUBLISH_ATTR_DTYPE)
+    attrs["from_id"] = rng.integers(0, 4000, size=len(topics))
+    attrs["qos_retain"] = rng.integers(0, 3, size=len(topics)) | (rng.integers(0, 2, size=len(topics)) << 2)
+    b.set_publish_attrs(attrs)
+
+    def windows(fmt):
+        out = []
+        b.set_format(fmt)
+        b.begin()
+        while True:
+            w = b.next_window()
+            if w is None:
+                return out
+            nh = int(w.n_hits)
+            offs_ = np.zeros(w.topic_end - w.topic_begin + 1, dtype=np.uint64)
+            # (rgr_window_to_host synchronises the batch's stream: the window's expansion and dedup are stream-ordered, not finished, when
+            # rgr_batch_next_window returns; without host_tuples it fetches the offsets only, in any format)
+            assert capi.lib().rgr_window_to_host(b._b, C.byref(w), None, offs_.ctypes.data) == 0
+            if fmt == capi.RGR_FORMAT_DELIVER8:
+                assert not w.d_tuples
+                h = capi.device_to_host(w.d_hits8, nh * 8).view(np.dtype([("sub_id", np.uint32), ("word", np.uint32)])) if nh else None
+            else:
+                assert not w.d_hits8
+                h = capi.device_to_host(w.d_tuples, nh * 12).view(capi.TUPLE_DTYPE) if nh else None
+            out.append((int(w.topic_begin), int(w.topic_end), nh, offs_.copy(), None if h is None else h.copy()))
+    ref = windows(capi.RGR_FORMAT_TUPLE)
+    got = windows(capi.RGR_FORMAT_DELIVER8)
+    assert len(ref) == len(got) and sum(x[2] for x in ref) > 40000
+    seen_dup = seen_drop = False
+    for (tb0, te0, n0, o0, t), (tb1, te1, n1, o1, h) in zip(ref, got):
+        assert (tb0, te0, n0) == (tb1, te1, n1) and np.array_equal(o0, o1)
+        if n0:
+            assert np.array_equal(t["sub_id"], h["sub_id"]) and np.array_equal(t["qos_flags"], h["word"])
+            assert np.array_equal(t["topic_idx"], np.repeat(np.arange(tb0, te0, dtype=np.uint32), np.diff(o0).astype(np.int64)))
+            seen_dup |= bool((h["word"] & capi.RGR_HIT_V5_DUP).any()); seen_drop |= bool((h["word"] & capi.RGR_HIT_NO_LOCAL).any())
+    assert seen_dup
+    del seen_drop            # (a No Local drop needs the publisher among the subscribers: not guaranteed by this draw)
+    with pytest.raises(capi.RgrError):
+        b.set_format(capi.RGR_FORMAT_PACKED)                 # plain compact formats carry no delivery word
+    b.set_publish_attrs(None)                                # detaching the attributes: back to tuples
+    b.begin()
+    w = b.next_window()
+    assert w.d_tuples and not w.d_hits8
+    while b.next_window() is not None:
+        pass
+    b.close(); r.close()

@@ -133,6 +133,10 @@ def test_tuple_expansions_source_on_host(case):
         assert np.array_equal(r4.reshape(-1, 2)[flagged], r1.reshape(-1, 2)[flagged])
         t5, _, _, _ = sim.expand_tuple(lean, *args, want_cand=False)
         assert np.array_equal(t5, t1)
+        # ... and the same kernel writing 8-byte hits {sub_id, delivery word} (RGR_FORMAT_DELIVER8): the tuples without their topic column
+        h8, l8, n8, r8 = sim.expand_tuple(lean + 2, *args)
+        assert np.array_equal(h8["sub_id"], t1["sub_id"]) and np.array_equal(h8["word"], t1["qos_flags"])
+        assert l8 == l1 and np.array_equal(n8, n1) and np.array_equal(r8.reshape(-1, 2)[flagged], r1.reshape(-1, 2)[flagged])
 
 
 # ---- property: ANY window (topics of 0 .. 12 runs of 1 .. 5 000 hits, any v5 fraction) through the lean delivery expansion equals the
