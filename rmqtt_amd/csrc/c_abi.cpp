@@ -15,7 +15,6 @@
 #include <shared_mutex>
 #include <string>
 #include <thread>
-#include <unordered_map>
 #include <vector>
 
 #include "device.hpp"
@@ -80,14 +79,7 @@ struct FiltImage { DevBuf buf; uint64_t cap = 0; std::vector<uint32_t> pending; 
 // for every range of entries a commit uploads
 struct SubsPool { DevBuf buf, attr_buf, packed_buf; uint64_t used = 0, cap = 0; bool has_attrs = false; };
 
-// Client indices of the long subscriber runs (kernels.hpp, kExemptMinRun): u64 slots, append-only like the runs themselves (an index is
-// never overwritten, so older epochs stay valid); the directory (one RunDirEntry per indexed run) is small and replaced whole.
-struct RunIndexPool { DevBuf slots; uint64_t used = 0, cap = 0; };
-struct RunDirImage { DevBuf buf; uint32_t mask = 0, n_runs = 0; };
-
 struct Epoch {
-    std::shared_ptr<RunIndexPool> run_idx;
-    std::shared_ptr<RunDirImage> run_dir;
     std::shared_ptr<DictImage> dict;
     std::shared_ptr<EdgeImage> edges;
     std::shared_ptr<FiltImage> filt;
@@ -132,12 +124,6 @@ struct rgr_handle {
     std::shared_ptr<SubsPool> sub_pool;
     std::vector<FilterDesc> host_desc;     // per filter id: its run in the pool
     uint64_t pool_garbage = 0;
-    // exempt runs of the v5 dedup (guarded by commit_mu): filter id -> its run's client index in idx_pool
-    std::shared_ptr<RunIndexPool> idx_pool;
-    std::shared_ptr<RunDirImage> run_dir;
-    std::unordered_map<uint32_t, RunDirEntry> idx_of;
-    uint64_t idx_garbage = 0, idx_refused = 0;     // idx_refused: long runs in which a client sits twice (no index: every hit stays a candidate)
-    bool run_dir_stale = true;
     int cur_img = 1;
     uint64_t commits_full = 0, commits_delta = 0;
     std::mutex stats_mu;
@@ -169,7 +155,6 @@ struct rgr_handle {
 struct ChunkSlot {
     DevBuf slots, pair_cnt, hit_cnt, pair_live, hit_off, pair_base, ovf_list, ovf_base, scalars, arena;
     DevBuf pair_src, pair_topic, pair_off, pair_qr, r_big, scan_tmp;
-    DevBuf topic_ex;             // delivery passes over an epoch with indexed runs: TopicEx per chunk topic
     PinnedBuf h_hit_off, h_pair_base, h_scalars;
     uint64_t arena_cap = 0;
     uint32_t begin = 0, n = 0;
@@ -245,7 +230,6 @@ struct rgr_batch {
     }
     // delivery stage (rgr_batch_set_publish_attrs)
     bool deliver = false;
-    bool exempt = false;                 // this pass: the topics' longest indexed runs stay out of the dedup's candidate lists (decided in rgr_batch_begin)
     bool group_by_node = false;          // host-out deliver calls: partition every topic's tuples by node + directory (rgr_node_groups)
     DevBuf node_tmp[2], grp_cnt, grp_off, grp_node, grp_begin;      // node_tmp: one per window slot (the D2H copy of window k overlaps window k+1)
     std::vector<uint64_t> h_grp_off, h_grp_begin;     // directory of the window rgr_batch_next_window returned last
@@ -480,7 +464,7 @@ ChunkArrays make_chunk_arrays(rgr_batch* b, uint32_t n) {
     c.pair_src = b->c->pair_src.as<uint32_t>();
     c.pair_topic = b->c->pair_topic.as<uint32_t>();
     c.pair_off = b->c->pair_off.as<uint64_t>();
-    if (b->deliver && !b->retain) { c.pub = b->d_pub.as<PublishAttr>(); c.pair_qr = b->c->pair_qr.as<uint8_t>(); if (b->exempt) c.topic_ex = b->c->topic_ex.as<TopicEx>(); }
+    if (b->deliver && !b->retain) { c.pub = b->d_pub.as<PublishAttr>(); c.pair_qr = b->c->pair_qr.as<uint8_t>(); }
     else if (b->has_topic_ids) c.topic_ids = b->d_topic_ids.as<uint32_t>();
     return c;
 }
@@ -497,7 +481,6 @@ void ensure_chunk_buffers(rgr_batch* b, uint32_t n) {
     b->c->ovf_base.ensure(size_t(n) * 8);
     b->c->scalars.ensure(sizeof(Scalars));
     b->c->r_big.ensure(size_t(n) * 4);
-    if (b->exempt) b->c->topic_ex.ensure(std::max<size_t>(1, n) * sizeof(TopicEx));
     if (b->c->arena_cap == 0) {
         const char* e = std::getenv("RGR_ARENA_INIT");        // tests shrink it to exercise the grow-and-redo paths
         b->c->arena_cap = e && std::atoll(e) > 0 ? uint64_t(std::atoll(e)) : (1u << 20);
@@ -667,7 +650,6 @@ void prepare_chunk(rgr_batch* b, uint32_t begin, bool walk_only) {
         ca = make_chunk_arrays(b, n);
         sp = b->span_begin(kSpanScan);
         launch_compact(tv, ca, begin, b->stream);
-        launch_exempt_select(tv, ca, b->stream);
         b->span_end(sp);
         account_chunk(b);
         b->c->ready = true;
@@ -717,7 +699,6 @@ void prefetch_chunk(rgr_batch* b, uint32_t begin) {
     launch_count(tv, ca, ps);
     launch_scan(ca, nx.scan_tmp.as<uint64_t>(), ps);
     launch_compact(tv, ca, begin, ps);
-    launch_exempt_select(tv, ca, ps);
     b->span_end(sp, ps);
     RGR_HIP(hipMemcpyAsync(nx.h_scalars.p, nx.scalars.p, sizeof(Scalars), hipMemcpyDeviceToHost, ps));
     RGR_HIP(hipMemcpyAsync(nx.h_hit_off.p, nx.hit_off.p, (size_t(n) + 1) * 8, hipMemcpyDeviceToHost, ps));
@@ -900,7 +881,6 @@ int32_t rgr_snapshot_load(rgr_handle* h, const char* path) {
         h->sub_pool.reset();
         h->host_desc.clear();
         h->pool_garbage = 0;
-        h->idx_pool.reset(); h->run_dir.reset(); h->idx_of.clear(); h->idx_garbage = 0; h->run_dir_stale = true;
         return RGR_OK;
     });
 }
@@ -921,8 +901,7 @@ int32_t rgr_commit(rgr_handle* h) {
                 if (!armed) return;
                 for (int k = 0; k < 2; ++k) { if (h->edge_img[k]) h->edge_img[k]->need_full = true; if (h->filt_img[k]) h->filt_img[k]->need_full = true; }
                 h->sub_pool.reset(); h->host_desc.clear(); h->pool_garbage = 0;
-                h->idx_pool.reset(); h->run_dir.reset(); h->idx_of.clear(); h->idx_garbage = 0; h->run_dir_stale = true;
-            }
+                    }
         } recover{h};
         const bool prof = std::getenv("RGR_COMMIT_PROFILE") != nullptr;
         double t_prev = now_ms();
@@ -1029,102 +1008,6 @@ int32_t rgr_commit(rgr_handle* h) {
                 h->sub_pool->used += stage.size();
             }
             lap("subscriber runs");
-            // ---- client indices of the long runs (exempt runs of the v5 dedup, kernels.hpp): rebuilt for exactly the runs that were rewritten
-            {
-                uint32_t run_min = kExemptMinRun;
-                if (const char* e = std::getenv("RGR_EXEMPT_MIN_RUN")) run_min = std::max<uint32_t>(expand_tile_hits() + 1, uint32_t(std::atoll(e)));      // (tests)
-                const bool want_idx = want_attrs && h->table.n_v5_subs() > 0 && !std::getenv("RGR_NO_RUN_INDEX");
-                std::vector<unsigned long long> stage;      // new index slots, appended behind idx_pool->used
-                auto build = [&](uint32_t f, const std::vector<SubEntry>& run, uint64_t at) -> bool {
-                    // one slot per v5, non-shared entry with a client: client << 32 | entry number.  false: a client sits twice in the run — the
-                    // caller's table breaks the reference's one-relation-per-(filter, client) rule (types.rs:476), so the run gets no index
-                    uint32_t keys = 0;
-                    for (const SubEntry& e : run) {
-                        const uint32_t fl = (e.qos_flags >> 8) & 0xFFu;
-                        keys += (fl & kSubV5) && !(fl & kSubShared) && h->table.sub_attr(e.sub_id).client_idx != kNone;
-                    }
-                    uint32_t slots = 16;
-                    while (slots < 2 * keys) slots <<= 1;
-                    const size_t base = stage.size();
-                    stage.resize(base + slots, kRunIndexEmpty);
-                    const uint32_t mask = slots - 1;
-                    for (uint32_t i = 0; i < run.size(); ++i) {
-                        const uint32_t fl = (run[i].qos_flags >> 8) & 0xFFu;
-                        if (!(fl & kSubV5) || (fl & kSubShared)) continue;
-                        const uint32_t client = h->table.sub_attr(run[i].sub_id).client_idx;
-                        if (client == kNone) continue;
-                        for (uint32_t sl = mix32(client) & mask;; sl = (sl + 1) & mask) {
-                            unsigned long long& v = stage[base + sl];
-                            if (v == kRunIndexEmpty) { v = (static_cast<unsigned long long>(client) << 32) | i; break; }
-                            if (uint32_t(v >> 32) == client) { stage.resize(base); h->idx_refused++; return false; }
-                        }
-                    }
-                    h->idx_of[f] = RunDirEntry{h->host_desc[f].begin, uint32_t(at + base), mask, keys};
-                    return true;
-                };
-                auto drop = [&](uint32_t f) {
-                    auto it = h->idx_of.find(f);
-                    if (it != h->idx_of.end()) { h->idx_garbage += uint64_t(it->second.idx_mask) + 1; h->idx_of.erase(it); h->run_dir_stale = true; }
-                };
-                if (!want_idx) {
-                    if (!h->idx_of.empty() || h->run_dir) { h->idx_of.clear(); h->idx_pool.reset(); h->run_dir.reset(); h->idx_garbage = 0; h->run_dir_stale = true; }
-                } else {
-                    bool all = rebuild || !h->idx_pool || h->idx_garbage > (h->idx_pool->used / 2 + (1u << 16));
-                    if (!all) {
-                        uint64_t need = 0;
-                        for (uint32_t f : fids) { const auto* v = h->table.filter_subs(f); if (v && v->size() >= run_min) need += 4 * v->size() + 32; }
-                        if (h->idx_pool->used + need > h->idx_pool->cap) all = true;
-                    }
-                    if (all) {
-                        h->idx_of.clear(); h->idx_garbage = 0; h->run_dir_stale = true;
-                        for (uint32_t f = 0; f < nf; ++f) {
-                            const auto* v = h->table.filter_subs(f);
-                            if (v && v->size() >= run_min && uint64_t(stage.size()) + 4 * v->size() < 0xFFFFFF00ull) build(f, *v, 0);
-                        }
-                        auto np = std::make_shared<RunIndexPool>();
-                        np->cap = stage.size() + stage.size() / 2 + (1u << 16);
-                        np->slots.ensure(np->cap * 8);
-                        if (!stage.empty()) RGR_HIP(hipMemcpy(np->slots.p, stage.data(), stage.size() * 8, hipMemcpyHostToDevice));
-                        np->used = stage.size();
-                        h->idx_pool = np;
-                    } else {
-                        for (uint32_t f : fids) {
-                            drop(f);
-                            const auto* v = h->table.filter_subs(f);
-                            if (v && v->size() >= run_min && build(f, *v, h->idx_pool->used)) h->run_dir_stale = true;
-                        }
-                        if (!stage.empty()) {
-                            RGR_HIP(hipMemcpy(h->idx_pool->slots.as<unsigned long long>() + h->idx_pool->used, stage.data(), stage.size() * 8, hipMemcpyHostToDevice));
-                            h->idx_pool->used += stage.size();
-                        }
-                    }
-                    if (h->run_dir_stale || !h->run_dir) {
-                        auto nd = std::make_shared<RunDirImage>();
-                        uint32_t slots = 16;
-                        while (slots < 2 * h->idx_of.size() + 2) slots <<= 1;
-                        std::vector<RunDirEntry> dir(slots, RunDirEntry{kNone, 0, 0, 0});
-                        for (const auto& kv : h->idx_of) {
-                            uint32_t sl = run_dir_hash(kv.second.src) & (slots - 1);
-                            while (dir[sl].src != kNone) sl = (sl + 1) & (slots - 1);
-                            dir[sl] = kv.second;
-                        }
-                        nd->buf.ensure(size_t(slots) * sizeof(RunDirEntry));
-                        RGR_HIP(hipMemcpy(nd->buf.p, dir.data(), size_t(slots) * sizeof(RunDirEntry), hipMemcpyHostToDevice));
-                        nd->mask = slots - 1; nd->n_runs = uint32_t(h->idx_of.size());
-                        h->run_dir = nd;
-                        h->run_dir_stale = false;
-                    }
-                }
-                ep->run_idx = h->idx_pool;
-                ep->run_dir = (h->run_dir && h->run_dir->n_runs) ? h->run_dir : nullptr;
-                if (ep->run_dir && ep->run_idx) {
-                    ep->view.run_index = ep->run_idx->slots.as<unsigned long long>();
-                    ep->view.run_dir = ep->run_dir->buf.as<RunDirEntry>();
-                    ep->view.run_dir_mask = ep->run_dir->mask;
-                    ep->view.run_min = run_min;
-                }
-            }
-            lap("run indices");
             FiltImage& fi = *h->filt_img[tgt];
             if (fi.need_full || fi.cap < nf || fi.pending.size() > nf / 4) {
                 fi.cap = nf + nf / 4 + 1024;
@@ -1412,14 +1295,6 @@ int32_t rgr_batch_begin(rgr_batch* b) {
             cs.ready = false;
         }
         b->c = &b->cs[0];
-        {
-            // exempt runs (kernels.hpp): only the default delivery expansion (expand_deliver_lean_kernel) knows the pair bit.
-            // RGR_DELIVER_EXEMPT=0 (A/B switch, read per pass): every v5 hit goes through the candidate lists as until r5
-            const char* ex = std::getenv("RGR_DELIVER_EXEMPT");
-            const char* lean = std::getenv("RGR_DELIVER_LEAN");
-            b->exempt = b->deliver && !b->retain && b->epoch->view.run_dir != nullptr && b->epoch->view.attrs != nullptr && b->epoch->n_v5 > 0 &&
-                        !(ex && ex[0] == '0') && !(lean && lean[0] == '0');
-        }
         if (b->dedup_scalars.p) RGR_HIP(hipMemsetAsync(b->dedup_scalars.p, 0, 16, b->stream));     // (a pass abandoned midway leaves its count behind)
         b->in_pass = true;
         b->cursor = 0;
@@ -1567,11 +1442,9 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
             if (dedup) {
                 // LDS tables (tile-local, then one block per spanning topic); stream-ordered, no host synchronisation
                 sp = b->span_begin(kSpanDedup);
-                const DedupExempt dx{b->exempt ? b->c->topic_ex.as<TopicEx>() + lc : nullptr, b->c->pair_off.as<uint64_t>(), b->epoch->view.run_index};
                 launch_dedup(b->cand.as<Cand>(), b->cand_count.as<uint32_t>(), b->cand_count.as<uint32_t>() + (nh + T - 1) / T, uint32_t((nh + T - 1) / T),
                              b->format == kFmtDeliver8 ? hit8_words(outbuf.p) : tuple_words(outbuf.as<Tuple>()), le - lc, b->c->hit_off.as<uint64_t>() + lc, hit_lo, b->dedup_items.as<DedupItem>(),
-                             reinterpret_cast<uint32_t*>(b->dedup_scalars.as<unsigned long long>() + 1), b->dedup_seq & 1u, b->dedup_scalars.as<unsigned long long>(), b->stream,
-                             b->exempt ? &dx : nullptr);
+                             reinterpret_cast<uint32_t*>(b->dedup_scalars.as<unsigned long long>() + 1), b->dedup_seq & 1u, b->dedup_scalars.as<unsigned long long>(), b->stream);
                 b->dedup_seq++;            // (its own counter, advanced exactly where a launch consumed the parity: ADVICE r5)
                 b->span_end(sp);
                 b->local.dedup_launches++;

@@ -627,35 +627,6 @@ __global__ __launch_bounds__(256) void compact_big_kernel(TrieView tv, ChunkArra
 
 #include "prep_batched.inc"
 
-// --------------------------------------------------------------------------- exempt runs of the v5 dedup (kernels.hpp)
-// One lane per chunk topic: among its runs of at least tv.run_min hits, the longest one the epoch's directory has a client index for.
-// Reads the dense pair arrays the compaction just wrote (a run's length is the difference of two neighbouring offsets); a topic has a
-// handful of such runs at most, so the directory is probed a handful of times per topic.  Marks the chosen pair (kPairExempt in pair_qr:
-// the tile records and the expansion's LDS staging carry the byte along).
-__global__ __launch_bounds__(256) void exempt_select_kernel(TrieView tv, ChunkArrays c) {
-    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= c.n) return;
-    TopicEx best{kNone, 0, 0, 0, 0};
-    const uint64_t p0 = c.pair_base[t], p1 = c.pair_base[t + 1];
-    if (c.hit_off[t + 1] - c.hit_off[t] >= tv.run_min) {
-        uint64_t o = p0 < p1 ? c.pair_off[p0] : 0;
-        for (uint64_t p = p0; p < p1; ++p) {
-            const uint64_t o1 = c.pair_off[p + 1];
-            const uint64_t len = o1 - o;
-            o = o1;
-            if (len < tv.run_min || len <= best.len) continue;
-            const uint32_t src = c.pair_src[p];
-            for (uint32_t s = run_dir_hash(src) & tv.run_dir_mask;; s = (s + 1) & tv.run_dir_mask) {
-                const RunDirEntry e = tv.run_dir[s];
-                if (e.src == kNone) break;
-                if (e.src == src) { best = TopicEx{uint32_t(p), e.idx_begin, e.idx_mask, uint32_t(len), o1 - len}; break; }
-            }
-        }
-    }
-    c.topic_ex[t] = best;
-    if (best.pair != kNone) c.pair_qr[best.pair] |= uint8_t(kPairExempt);
-}
-
 // --------------------------------------------------------------------------- tiles
 __global__ __launch_bounds__(256) void tiles_kernel(ChunkArrays c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, TileRec* __restrict__ tile_first) {
     const uint64_t p = pair_lo + uint64_t(blockIdx.x) * 256 + threadIdx.x;
@@ -892,10 +863,6 @@ void launch_compact(const TrieView& t, const ChunkArrays& c, uint32_t topic_base
     compact_big_kernel<<<512, 256, 0, s>>>(t, c, topic_base);
 }
 
-void launch_exempt_select(const TrieView& t, const ChunkArrays& c, void* stream) {
-    if (c.n && c.topic_ex && c.pair_qr && t.run_dir) exempt_select_kernel<<<(c.n + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(t, c);
-}
-
 void launch_tiles(const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, TileRec* tile_first, void* stream) {
     if (pair_hi <= pair_lo) return;
     const uint64_t np = pair_hi - pair_lo;
@@ -1018,8 +985,7 @@ void launch_node_groups(const Tuple* tuples, const uint64_t* hit_off, uint64_t h
 uint32_t dedup_topic_cap() { return kDedupTopicCap; }
 
 void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, const uint32_t* tile_trange, uint32_t ntiles, HitWords tuples, uint32_t nt,
-                  const uint64_t* hit_off, uint64_t hit_lo, DedupItem* items, uint32_t* item_counts, uint32_t parity, unsigned long long* stat, void* stream,
-                  const DedupExempt* ex) {
+                  const uint64_t* hit_off, uint64_t hit_lo, DedupItem* items, uint32_t* item_counts, uint32_t parity, unsigned long long* stat, void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (!ntiles) { (void)hipMemsetAsync(item_counts + (parity ^ 1u), 0, 4, s); return; }      // (the next window's counter: what this window's launch would have zeroed)
     const uint32_t slots = uint32_t(kDedupTopicSlots);
@@ -1029,15 +995,7 @@ void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, const uint32_t* 
 #else
     const uint32_t tile_blocks = std::min<uint32_t>(ntiles, 2048u);
 #endif
-    const bool has_ex = ex && ex->topic_ex && ex->run_index;
-    DedupExempt dx = has_ex ? *ex : DedupExempt{nullptr, nullptr, nullptr};
-    // RGR_DIAG_EX_NOPROBE=1 (timing diagnostic, read per launch; WRONG flags by construction): the exempt runs stay out of the lists but nobody asks
-    // their indices — what the candidates' absence alone is worth
-    if (has_ex && std::getenv("RGR_DIAG_EX_NOPROBE")) dx.run_index = nullptr;
-    // exempt runs: probe blocks behind the classification's (four tiles' candidate lists per wave at a full 2^27-hit window)
-    const uint32_t probe_blocks = has_ex ? std::min<uint32_t>((ntiles + 3) / 4, 4096u) : 0u;
-    dedup_tile_kernel<<<tile_blocks + (nt + 255) / 256 + probe_blocks, 256, 0, s>>>(cand, tile_ncand, tile_trange, ntiles, hit_off, hit_lo, nt, tuples, stat, tile_blocks, items, item_counts,
-                                                                                    parity, dx);
+    dedup_tile_kernel<<<tile_blocks + (nt + 255) / 256, 256, 0, s>>>(cand, tile_ncand, tile_trange, ntiles, hit_off, hit_lo, nt, tuples, stat, tile_blocks, items, item_counts, parity);
     uint32_t* item_count = item_counts + parity;
     // RGR_DEDUP_TEST_SLOTS (tests only): a smaller table, so that parts overflow and the re-split path runs on ordinary inputs
     // (read on every launch — it is one getenv — so that a test can set it after other tests of the same process have launched)
@@ -1053,11 +1011,8 @@ void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, const uint32_t* 
     // instructions cost 0.515 ms)
     const char* pe = std::getenv("RGR_DEDUP_PROBE");
     const uint32_t grid = kDedupTopicThreads >= 512 ? 1024 : 1280;
-    if (pe && pe[0] == '0') {
-        if (has_ex) dedup_topic_kernel<0, true><<<grid, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, hit_off, hit_lo, items, item_count, tuples, max_slots, dx);
-        else dedup_topic_kernel<0, false><<<grid, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, hit_off, hit_lo, items, item_count, tuples, max_slots, dx);
-    } else if (has_ex) dedup_topic_kernel<3, true><<<grid, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, hit_off, hit_lo, items, item_count, tuples, max_slots, dx);
-    else dedup_topic_kernel<3, false><<<grid, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, hit_off, hit_lo, items, item_count, tuples, max_slots, dx);
+    if (pe && pe[0] == '0') dedup_topic_kernel<0><<<grid, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, hit_off, hit_lo, items, item_count, tuples, max_slots);
+    else dedup_topic_kernel<3><<<grid, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, hit_off, hit_lo, items, item_count, tuples, max_slots);
 }
 
 }  // namespace rgr

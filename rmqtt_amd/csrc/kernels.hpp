@@ -70,30 +70,12 @@ struct alignas(8) Cand { uint32_t pos, client_idx; };
 #endif
 constexpr uint32_t kSubV5 = 1u << 0, kSubNoLocal = 1u << 1, kSubShared = 1u << 2, kSubRap = 1u << 3;   // RGR_SUB_*
 constexpr uint32_t kHitRetain = 1u << 2, kHitNoLocal = 1u << 3, kHitV5Dup = 1u << 4;                    // RGR_HIT_*
-// ---- exempt runs of the v5 dedup (r6) ---------------------------------------------------------------------------------------------
-// The reference keeps ONE relation per (filter, client): AllRelationsMap's value is a HashMap<ClientId, ...> per filter (types.rs:476) and
-// Router::add replaces an existing entry (router.rs:440-450).  So a client appears at most once inside one subscriber run, and a topic's
-// per-client duplicates (types.rs:524-539) only ever pair hits of DIFFERENT runs.  At config-3 fan-out a topic's largest run holds 70 % of
-// its hits (profiles/r05n_*): those hits need not go through the candidate lists at all if the few candidates of the topic's OTHER runs
-// can ask "does this client also sit in the large run, and where?".  rgr_commit builds that question's answer for every run of at least
-// kExemptMinRun entries whose clients are indeed distinct: an open-addressed index client -> entry number (RunIndex slots, u64 =
-// client << 32 | entry), and a small directory keyed by the run's first subs[] index.  Per delivery pass exempt_select_kernel picks, per
-// topic, its longest indexed run (TopicEx) and marks that pair (bit 3 of pair_qr); the expansion writes no candidates for its hits; the
-// topic pass probes the index once per remaining candidate and flags whichever of the two positions is the later one.
-constexpr uint32_t kExemptMinRun = 4096;      // > one expansion tile (2 048 hits): a topic with such a run is never a tile-local topic
-constexpr uint32_t kPairExempt = 8u;          // bit of ChunkArrays::pair_qr / TileRec::qr
-constexpr unsigned long long kRunIndexEmpty = ~0ull;
-struct alignas(16) RunDirEntry { uint32_t src, idx_begin, idx_mask, n_keys; };      // src == kNone: empty slot
-// pair: chunk-local index of the exempt pair (kNone = none); off: chunk-local output offset of the run's first hit (its window position is off - hit_lo)
-struct alignas(8) TopicEx { uint32_t pair, idx_begin, idx_mask, len; uint64_t off; };
 RGR_HD inline uint32_t mix32(uint32_t x) {           // bijective
     x ^= x >> 16; x *= 0x7feb352du;
     x ^= x >> 15; x *= 0x846ca68bu;
     x ^= x >> 16;
     return x;
 }
-RGR_HD inline uint32_t run_dir_hash(uint32_t src) { uint32_t x = src * 0x9E3779B1u; return x ^ (x >> 15); }
-
 struct DeliverArgs {
     const PublishAttr* pub;      // [n_batch]
     const SubAttr* attrs;        // parallel to TrieView::subs, may be null (no ids registered)
@@ -149,11 +131,6 @@ struct TrieView {
     // parallel to subs: sub_id | (qos & 3) << 30, 4 bytes per entry (null when some id needs 31+ bits or the array was not built).
     // What RGR_FORMAT_PACKED writes per hit, and RGR_FORMAT_IDS24 after masking: those expansions read 4 bytes per hit instead of 8.
     const uint32_t* subs_packed = nullptr;
-    // client indices of the long subscriber runs (see kExemptMinRun above); null / 0 when the epoch has none
-    const unsigned long long* run_index = nullptr;
-    const RunDirEntry* run_dir = nullptr;
-    uint32_t run_dir_mask = 0;
-    uint32_t run_min = kExemptMinRun;        // shortest run that may have an index in this epoch (> one expansion tile)
 };
 
 // ---- RetainTree twin (rmqtt/src/retain.rs): trie of concrete retained topics, nodes numbered
@@ -227,8 +204,6 @@ struct ChunkArrays {
     uint8_t* pair_qr;            // [P]
     // rgr_batch_set_topic_ids: value written into rgr_tuple.topic_idx for batch topic i (null: i itself)
     const uint32_t* topic_ids = nullptr;
-    // delivery passes over an epoch with indexed runs: per chunk topic its exempt pair (written by exempt_select_kernel), else null
-    TopicEx* topic_ex = nullptr;
 };
 
 // incremental epoch update: patch `n` edge records / filter descriptors of a device image
@@ -278,8 +253,6 @@ void launch_compact(const TrieView& t, const ChunkArrays& c, uint32_t topic_base
 // subs[] the tile starts reading, which topic it belongs to) — so a tile that lies inside ONE run, the common case at
 // high fan-out, starts its subscriber loads after a single 16-byte read instead of tile_first -> pair arrays -> LDS.
 struct alignas(16) TileRec { uint32_t first, src, topic, qr; };
-// delivery passes, after the compaction: per topic the longest run that has a client index -> c.topic_ex[t], bit kPairExempt of its pair_qr
-void launch_exempt_select(const TrieView& t, const ChunkArrays& c, void* stream);
 void launch_tiles(const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, TileRec* tile_first, void* stream);
 // hits8: `out` receives 8-byte hits {sub_id, delivery word} (delivery passes in RGR_FORMAT_DELIVER8; lean expansion only)
 void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint64_t hit_hi,
@@ -307,11 +280,9 @@ struct HitWords {
 };
 inline HitWords tuple_words(Tuple* t) { return HitWords{t ? &t->qos_flags : nullptr, 3}; }
 inline HitWords hit8_words(void* p) { return HitWords{p ? static_cast<uint32_t*>(p) + 1 : nullptr, 2}; }
-// ex (optional): the window's exempt runs — topic_ex points at the window's first topic, pair_off is the chunk's array, run_index the epoch's
-struct DedupExempt { const TopicEx* topic_ex; const uint64_t* pair_off; const unsigned long long* run_index; };
 void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, const uint32_t* tile_trange, uint32_t ntiles, HitWords words, uint32_t nt,
                   const uint64_t* hit_off, uint64_t hit_lo, DedupItem* items, uint32_t* item_counts /* two words, zero when the pass begins */,
-                  uint32_t parity /* window & 1 */, unsigned long long* stat, void* stream, const DedupExempt* ex = nullptr);
+                  uint32_t parity /* dedup launches so far in the pass & 1 */, unsigned long long* stat, void* stream);
 uint32_t dedup_topic_cap();
 // Delivery results grouped by node (SubRelationsMap's shape, types.rs:486-497): stable partition of every topic's tuples by
 // one byte (`shift` = 16 or 24) of the delivery word's node index; then the directory of the node groups — called twice: with

@@ -120,50 +120,17 @@ def dedup_lib():
             os.replace(tmp, so)
         L = C.CDLL(so)
         vp, i32, u32, u64 = C.c_void_p, C.c_int32, C.c_uint32, C.c_uint64
-        L.sim_dedup.argtypes = [i32, u32, u32, vp, vp, vp, u32, vp, u32, vp, u64, vp, vp, vp, vp]
+        L.sim_dedup.argtypes = [i32, u32, u32, vp, vp, vp, u32, vp, u32, vp, u64, vp]
         L.sim_dedup.restype = i32
         _DLIB = L
     return _DLIB
 
 
-TOPIC_EX_DTYPE = np.dtype([("pair", np.uint32), ("idx_begin", np.uint32), ("idx_mask", np.uint32), ("len", np.uint32), ("off", np.uint64)])
-_M32 = 0xFFFFFFFF
-
-
-def mix32(x):
-    """kernels.hpp mix32"""
-    x &= _M32
-    x ^= x >> 16; x = (x * 0x7feb352d) & _M32
-    x ^= x >> 15; x = (x * 0x846ca68b) & _M32
-    x ^= x >> 16
-    return x
-
-
-def run_index(clients):
-    """The client index rgr_commit builds for one run (c_abi.cpp): `clients[i]` = client of entry i, or None for an entry that is not a v5,
-    non-shared subscription with a client.  -> u64 slots (client << 32 | entry, ~0 = empty); a client may sit in a run once."""
-    keys = [(c, i) for i, c in enumerate(clients) if c is not None]
-    slots = 16
-    while slots < 2 * len(keys):
-        slots <<= 1
-    tab = np.full(slots, 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)
-    for c, i in keys:
-        sl = mix32(int(c)) & (slots - 1)
-        while tab[sl] != 0xFFFFFFFFFFFFFFFF:
-            assert int(tab[sl]) >> 32 != int(c), "a client sits twice in the run"
-            sl = (sl + 1) & (slots - 1)
-        tab[sl] = (int(c) << 32) | i
-    return tab
-
-
-def dedup(variant, hit_off, cand_pos, cand_client, tile=2048, grid_topic=1024, max_slots=4096, exempt=None, dropped=()):
+def dedup(variant, hit_off, cand_pos, cand_client, tile=2048, grid_topic=1024, max_slots=4096):
     """One window through dedup_tile / dedup_classify / dedup_topic[_pipe].  hit_off: the window's per-topic offsets (n + 1, absolute);
     candidates: window-relative positions + client indices (any order).  Lays the candidates out as the expansion does (tile i owns
     cand[i * tile ...], its count carries bit 31 when a whole topic with candidates may lie inside it, tile_trange bounds its topics) and
-    returns (the positions the kernels flagged kHitV5Dup, number of topic-pass items).
-    exempt: {window topic: (first window-relative position of its exempt run, [client or None per entry])} — those hits are NOT among the
-    candidates; the topic pass finds them through the run's client index.  dropped: window-relative positions whose word carries
-    kHitNoLocal before the pass (exempt hits the expansion dropped)."""
+    returns (the positions the kernels flagged kHitV5Dup, number of topic-pass items)."""
     hit_off = np.ascontiguousarray(hit_off, dtype=np.uint64)
     nt = len(hit_off) - 1
     hit_lo = int(hit_off[0])
@@ -186,35 +153,17 @@ def dedup(variant, hit_off, cand_pos, cand_client, tile=2048, grid_topic=1024, m
         t_first = int(np.searchsorted(rel, lo, side="right") - 1)
         t_last = int(np.searchsorted(rel, hi - 1, side="right") - 1)
         whole = t_first != t_last or (rel[t_first] >= lo and rel[t_first + 1] <= lo + tile)
-        if ncand[tl]:                               # (r6: the topic range of every tile with candidates — the exempt runs' probe blocks use it)
-            trange[2 * tl], trange[2 * tl + 1] = t_first, t_last
         if ncand[tl] >= 2 and whole:
             ncand[tl] |= 1 << 31
+            trange[2 * tl], trange[2 * tl + 1] = t_first, t_last
     tuples = np.zeros(nh, dtype=TUPLE_DTYPE)
-    drop = np.asarray(sorted(dropped), dtype=np.int64)
-    tuples["qos_flags"][drop] = 8
     n_items = C.c_uint32(0)
-    ex_arr = pair_off = index = None
-    if exempt is not None:
-        # one "pair" per exempt run; pair_off holds absolute offsets like the chunk's array (the kernel subtracts hit_lo)
-        ex_arr = np.zeros(nt, dtype=TOPIC_EX_DTYPE)
-        ex_arr["pair"] = 0xFFFFFFFF
-        offs, tabs, at = [], [np.full(3, 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)], 3          # (index pool with some leading garbage)
-        for k, (t, (pos0, clients)) in enumerate(sorted(exempt.items())):
-            tab = run_index(clients)
-            ex_arr[t] = (k, at, len(tab) - 1, len(clients), hit_lo + pos0)
-            offs.append(hit_lo + pos0)
-            tabs.append(tab); at += len(tab)
-        pair_off = np.asarray(offs + [0], dtype=np.uint64)
-        index = np.concatenate(tabs)
-    p = lambda a: None if a is None else a.ctypes.data
     rc = dedup_lib().sim_dedup(variant, grid_topic, max_slots, cand.ctypes.data, ncand.ctypes.data, trange.ctypes.data, ntiles, tuples.ctypes.data, nt,
-                               hit_off.ctypes.data, hit_lo, C.byref(n_items), p(ex_arr), p(pair_off), p(index))
+                               hit_off.ctypes.data, hit_lo, C.byref(n_items))
     if rc == -2:
         raise AssertionError("hipsim: threads diverged around a convergent operation in the dedup kernels")
     assert rc == 0
-    assert not (tuples["qos_flags"] & ~np.uint32(16 | 8)).any() and not tuples["topic_idx"].any() and not tuples["sub_id"].any()
-    assert np.array_equal(np.flatnonzero(tuples["qos_flags"] & 8), drop)
+    assert not (tuples["qos_flags"] & ~np.uint32(16)).any() and not tuples["topic_idx"].any() and not tuples["sub_id"].any()
     return np.flatnonzero(tuples["qos_flags"] & 16), int(n_items.value), t_of
 
 

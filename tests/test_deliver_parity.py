@@ -238,13 +238,11 @@ def test_v5_dedup_topics_spanning_tiles_in_parts(kind, test_slots, monkeypatch):
 
 
 @pytest.mark.parametrize("kind", BACKENDS)
-def test_v5_dedup_with_exempt_runs(kind, monkeypatch):
-    """(r6) Runs long enough to get a client index at commit (kernels.hpp kExemptMinRun; 2 049 here): per topic the longest such run stays out of
-    the candidate lists and the topic pass asks its index instead.  Overlapping filters with thousands of v5 clients each, publishers that
-    hold No Local subscriptions in the long runs (a dropped exempt hit neither is nor makes a duplicate), subscription churn on the long runs
-    (the incremental commit re-indexes exactly the rewritten runs), everything against the oracle's forwards(); on the device additionally
-    word for word against the same pass with RGR_DELIVER_EXEMPT=0, whose candidate count must be the larger one."""
-    monkeypatch.setenv("RGR_EXEMPT_MIN_RUN", "2049")
+def test_v5_dedup_long_runs_with_churn(kind):
+    """Runs of thousands of subscribers (longer than an expansion tile, so a topic's largest run spans tiles on its own): overlapping filters
+    with thousands of v5 clients each, publishers that hold No Local subscriptions inside the long runs (a dropped hit neither is nor makes a
+    duplicate), subscription churn on the long runs through the incremental commit — everything against the oracle's forwards().  (Written
+    for round 6's exempt-run experiment, tools/dropped/r6_exempt_runs.diff; kept as the parity world with the longest runs.)"""
     w = World(kind, 33)
     w.clients = [f"k{i}" for i in range(2600)]
     w.client_node = {c: w.nodes[i % 3] for i, c in enumerate(w.clients)}
@@ -256,25 +254,6 @@ def test_v5_dedup_with_exempt_runs(kind, monkeypatch):
             if (i + 3 * j) % 11 != 5:
                 w.add(f, c, 0, (i + j) % 3, (i + j) % 4 != 0, (i % 3) == 0, (j % 2) == 0, (i * 7 + j) % 150)
     w.check(16)
-    if kind == "hip":
-        st = w.backend.stats()
-        blob, offs = pack(["a/b/c", "a/b", "x/y/z", "a/b/c"])
-        attrs = np.zeros(4, dtype=capi.PUBLISH_ATTR_DTYPE)
-        attrs["from_id"] = [w.owner_ids[(w.client_node["k3"], "k3", 0)], capi.ID_NONE, w.owner_ids[(w.client_node["k9"], "k9", 0)], capi.ID_NONE]
-        attrs["qos_retain"] = [2, 1 | 4, 0, 2 | 4]
-        w.backend.stats_reset()
-        on = w.backend.match_batch_deliver(blob, offs, attrs)
-        c_on = w.backend.stats()["dedup_candidates"]
-        monkeypatch.setenv("RGR_DELIVER_EXEMPT", "0")
-        w.backend.stats_reset()
-        off = w.backend.match_batch_deliver(blob, offs, attrs)
-        c_off = w.backend.stats()["dedup_candidates"]
-        monkeypatch.delenv("RGR_DELIVER_EXEMPT")
-        assert np.array_equal(on["tuples"], off["tuples"]) and np.array_equal(on["hit_offsets"], off["hit_offsets"])
-        assert (on["tuples"]["qos_flags"] & capi.RGR_HIT_V5_DUP).any() and (on["tuples"]["qos_flags"] & capi.RGR_HIT_NO_LOCAL).any()
-        assert 0 < c_on < 0.7 * c_off, (c_on, c_off)
-        del st
-    # churn on the long runs: the incremental commit appends the rewritten runs and their indices
     for rnd in range(3):
         for i in range(rnd, 2600, 37):
             c = w.clients[i]
@@ -287,11 +266,9 @@ def test_v5_dedup_with_exempt_runs(kind, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_run_with_a_repeated_client_gets_no_index(monkeypatch):
+def test_a_client_twice_in_one_run_is_deduplicated_too():
     """A caller whose table breaks the reference's one-relation-per-(filter, client) rule (types.rs:476: the relations of a filter are a map keyed
-    by ClientId) — two subscriptions of ONE client on one filter: rgr_commit refuses that run's index, all its hits stay candidates, and the
-    answer equals the pass without exempt runs (first position of the client wins, inside the run too)."""
-    monkeypatch.setenv("RGR_EXEMPT_MIN_RUN", "2049")
+    by ClientId) — two subscriptions of ONE client on one filter: the device's rule is still "first position of the client wins", inside a run too."""
     r = capi.Router(device=0)
     big, other = r.filter_add("a/#"), r.filter_add("a/b")
     n = 3000
@@ -304,13 +281,9 @@ def test_run_with_a_repeated_client_gets_no_index(monkeypatch):
     attrs = np.zeros(2, dtype=capi.PUBLISH_ATTR_DTYPE)
     attrs["from_id"] = capi.ID_NONE
     attrs["qos_retain"] = 2
-    on = r.match_batch_deliver(blob, offs, attrs)
-    monkeypatch.setenv("RGR_DELIVER_EXEMPT", "0")
-    off = r.match_batch_deliver(blob, offs, attrs)
-    assert np.array_equal(on["tuples"], off["tuples"])
-    dup = on["tuples"][(on["tuples"]["qos_flags"] & capi.RGR_HIT_V5_DUP) != 0]
-    # topic 0: a/b's 40 clients come first (exact filter before "a/#"? no: TopicTree order — whichever comes first, 40 of the two runs' hits
-    # and the seven repeats inside the long run are duplicates); topic 1: only the seven repeats
+    got = r.match_batch_deliver(blob, offs, attrs)
+    dup = got["tuples"][(got["tuples"]["qos_flags"] & capi.RGR_HIT_V5_DUP) != 0]
+    # topic 0: 3 040 hits of 2 993 distinct clients -> 47 duplicates; topic 1: only the seven repeats inside the long run
     assert (dup["topic_idx"] == 0).sum() == 47 and (dup["topic_idx"] == 1).sum() == 7
     r.close()
 
@@ -325,8 +298,6 @@ SWITCH_SETS = {
     "lean_256x8": {"RGR_DELIVER_LEAN": "2"},
     # measured and not adopted: 2^30-hit delivery windows
     "large_windows": {"RGR_DELIVER_WINDOW_HITS": str(1 << 30)},
-    # every v5 hit through the candidate lists, as until round 5
-    "no_exempt_runs": {"RGR_DELIVER_EXEMPT": "0", "RGR_EXEMPT_MIN_RUN": "2049"},
 }
 
 
@@ -342,7 +313,7 @@ def test_v5_dedup_under_the_library_switches(switches, test_slots, monkeypatch):
     test_v5_dedup_topics_spanning_tiles_in_parts("hip", test_slots, monkeypatch)
     test_v5_dedup_many_candidates("hip")
     if switches in ("lean_256x8", "large_windows") and not test_slots:
-        test_v5_dedup_with_exempt_runs("hip", monkeypatch)
+        test_v5_dedup_long_runs_with_churn("hip")
 
 
 @pytest.mark.parametrize("n_nodes", [1, 3, 300])
@@ -494,11 +465,10 @@ def test_oracle_delivery_digest_equals_the_delivery_words(kind):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("window_hits", [0, 5000])
-def test_deliver8_windows_equal_the_delivery_tuples(window_hits, monkeypatch):
+def test_deliver8_windows_equal_the_delivery_tuples(window_hits):
     """RGR_FORMAT_DELIVER8 (r6): a device-resident delivery pass answers with 8-byte hits {sub_id, delivery word}; window for window they are the
-    12-byte delivery tuples without the topic column (which the CSR offsets imply) — v5 duplicates, No Local drops and exempt runs included.
+    12-byte delivery tuples without the topic column (which the CSR offsets imply) — v5 duplicates and No Local drops included.
     The format is the delivery stage's own: without publish attributes it is refused, detaching them returns the batch to tuples."""
-    monkeypatch.setenv("RGR_EXEMPT_MIN_RUN", "2049")
     rng = np.random.default_rng(5)
     r = capi.Router(device=0, window_hits=window_hits)
     filters = ["a/#", "a/b/c", "+/+/+", "a/b/+", "#", "x/y"]

@@ -177,39 +177,3 @@ if HAVE_HYPOTHESIS:
         assert l4 == want_lists
         assert np.array_equal(n4 & 0x7FFFFFFF, np.array([len(x) for x in want_lists], dtype=np.uint32))
 
-
-@pytest.mark.parametrize("lean", [3, 4])
-def test_lean_expansion_leaves_exempt_pairs_out_of_the_candidate_lists(lean):
-    """(r6) A pair whose qr byte carries bit 3 (kPairExempt: its topic's longest run with a client index, kernels.hpp) gets the same delivery
-    words as ever, but its v5 hits go to NO candidate list — the dedup's topic pass finds them through the run's index.  Single-run tiles
-    (the record carries the byte) and tiles that stage several pairs in LDS both have to honour it."""
-    rng = np.random.default_rng(606 + lean)
-    topics = [[700, 3 * TILE + 11, 40, 5], [9], [2 * TILE + 100, 2 * TILE + 3], [TILE + 9, 30, 2 * TILE + 500, 1, 1, 64], [120, 4500]]
-    W = make_window(rng, topics, pool=1 << 16, v5_frac=0.35)
-    lo = W["lo"]
-    lens = np.diff(W["off"].astype(np.int64))
-    exempt_pairs = []
-    at = lo
-    for runs in topics:                                   # per topic: its longest run, when it is longer than a tile
-        k = int(np.argmax(runs))
-        if runs[k] > TILE:
-            exempt_pairs.append(at + k)
-        at += len(runs)
-    assert len(exempt_pairs) == 4
-    qr = W["qr"].copy()
-    qr[exempt_pairs] |= 8
-    args = (W["subs"], W["attrs"], W["pub"], W["src"], W["topic"], W["off"], qr, W["lo"], W["hi"], W["topic_lo"])
-    topic, sid, w, (cpos, ccl) = reference(W, True)
-    t, lists, n, _ = sim.expand_tuple(lean, *args)
-    assert np.array_equal(t["topic_idx"], topic) and np.array_equal(t["sub_id"], sid) and np.array_equal(t["qos_flags"], w)
-    first = int(W["off"][lo])
-    in_exempt = np.zeros(len(topic), dtype=bool)
-    for p in exempt_pairs:
-        in_exempt[int(W["off"][p]) - first:int(W["off"][p]) - first + int(lens[p])] = True
-    assert in_exempt[cpos].any() and not in_exempt[cpos].all()
-    want_lists = [[] for _ in lists]
-    for p, c in zip(cpos.tolist(), ccl.tolist()):
-        if not in_exempt[p]:
-            want_lists[p // TILE].append((p, c))
-    assert lists == want_lists
-    assert np.array_equal(n & 0x7FFFFFFF, np.array([len(x) for x in want_lists], dtype=np.uint32))
