@@ -233,7 +233,7 @@ FORMAT_NAMES = ("tuple", "soa", "packed", "runs", "ids24")      # == RGR_FORMAT_
 DELIVERY_FORMAT_NAMES = {0: "tuple12: (topic_idx, sub_id, delivery word)", 5: "hits8: (sub_id, delivery word), topic implied by the CSR offsets"}
 
 
-def gpu_digests(batch, n_topics, retain, fmt=0, subs_len=0, topic_ids_dev=None, qos_by_sub=None):
+def gpu_digests(batch, n_topics, retain, fmt=0, subs_len=0, topic_ids_dev=None, qos_by_sub=None, retain_vals_dev=None):
     """Per-topic digests of EVERY window of one full pass in result format `fmt`, reduced on the device (torch is plumbing
     here: the hits were produced by the library's kernels; the per-topic sums are prefix-sum differences because a topic's
     hits are consecutive positions).  -> (int64 device tensor [n, 4] (router) / [n, 3] (retain) with the same definition as
@@ -276,6 +276,8 @@ def gpu_digests(batch, n_topics, retain, fmt=0, subs_len=0, topic_ids_dev=None, 
             del owner
             sid = t[:, 1].to(torch.int64) & M32
             q = t[:, 2].to(torch.int64) & 0xFF
+            if retain_vals_dev is not None:            # retained path answering with positions (rgr_batch_set_retain_positions): id = vals[position]
+                sid = retain_vals_dev[sid]
         elif fmt == capi.RGR_FORMAT_SOA:
             sid = torch.as_tensor(_DevArr(w.d_sub_ids, (nh,), "<i4"), device="cuda").to(torch.int64) & M32
             q = torch.as_tensor(_DevArr(w.d_qos, (nh,), "|u1"), device="cuda").to(torch.int64) & 3
@@ -445,6 +447,18 @@ def device_digests(r, batch, n, retain, formats=True, topic_ids=None, qos=None):
             if fmt == capi.RGR_FORMAT_RUNS:
                 runs_pt = info["runs_per_topic"]
             del d
+    if retain and formats:
+        # the retained path's position form: tuples carry positions of the epoch's preorder value array, resolved through the host mirror
+        batch.set_retain_positions(True)
+        batch.begin()
+        while batch.next_window() is not None:
+            pass
+        vals = torch.from_numpy(batch.retain_vals()["topic_id"].astype(np.int64)).cuda()
+        d, ok_s, _ = gpu_digests(batch, n, True, capi.RGR_FORMAT_TUPLE, retain_vals_dev=vals)
+        batch.set_retain_positions(False)
+        struct["positions"] = ok_s
+        fmt_ok["positions"] = "ok" if (bool((d == D).all()) and ok_s) else "MISMATCH"
+        del d, vals
     if topic_ids is not None:
         batch.set_topic_ids(topic_ids)
     return D, fmt_ok, {"structure_ok": struct, "windows": info0.get("windows", 0), "last_window": info0.get("last_window", (0, 0)),
@@ -1170,6 +1184,26 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
             except capi.RgrError as e:
                 rec["compact_formats"].append({"format": name, "error": str(e)})
         batch.set_format(capi.RGR_FORMAT_TUPLE)
+        if retain:
+            # the retained path answering with POSITIONS of the epoch's preorder value array (rgr_batch_set_retain_positions): the same 12-byte
+            # tuples, nothing read per hit — beside the headline, whose tuples carry the caller's topic ids
+            batch.set_retain_positions(True)
+            batch.run()
+            r.stats_reset()
+            torch.cuda.synchronize()
+            t = time.time()
+            for _ in range(steps):
+                h2, _ = batch.run()
+            dt = time.time() - t
+            s2 = r.stats()
+            batch.set_retain_positions(False)
+            rec["retain_positions"] = {"value": round(my_topics * steps / dt, 1), "unit": rec["unit"], "ms_per_step": round(dt * 1e3 / steps, 3),
+                                       "expand_avg_launch_ms": round(s2["expand_ms"] / max(1, s2["expand_launches"]), 4),
+                                       "expand_store_GBps": round(h2 * steps * 12 / max(1e-9, s2["expand_ms"] / 1e3) / 1e9, 1),
+                                       "frac_of_hbm_peak_stores_kernel": round(h2 * steps * 12 / max(1e-9, s2["expand_ms"] / 1e3) / 8.0e12, 3),
+                                       "speedup_vs_topic_ids": round((my_topics * steps / dt) / value, 3),
+                                       "what": "rgr_batch_set_retain_positions: rgr_tuple.sub_id = position in the epoch's preorder value array (topic id = "
+                                               "mirror[position], rgr_batch_retain_vals); a trailing '#' is a contiguous range of it, so the expansion reads nothing per hit"}
     # ---- PCIe-inclusive rate: the same pass with every window copied into pinned host memory (bounded prefix:
     # at config-3 fan-out a publish carries 178 KB of tuples, the full batch would be 1.8 TB over the link)
     if world == 1 and not args.no_d2h and deliver < 0:
@@ -1281,6 +1315,17 @@ def attach_traffic(rec, phase, pmc, cal):
                             "algorithmic bytes (20 B/hit) over the same time; it exceeds frac, and 1, on the expansion because its 8 B/hit READ term never "
                             "reaches HBM: 64 filters produce 98 % of config 3's hits, their subscriber runs stay in L2 / Infinity Cache (the counters see "
                             "0.25 B fetched per hit).  frac_stores_only = the 12 B/hit of tuple stores alone, the floor no cache can remove."})
+    if phase["retain"] and cls == "expand" and rf.get("frac_stores_only") is not None:
+        # the retained path's value array (40 MB at BASELINE configs[4]) is served by the Infinity Cache: FETCH_SIZE counts those reads although
+        # they never reach HBM (MI355X guide, HBM section), and `traffic`-based frac came out above the ~6.3 TB/s HBM can sustain (round 5: 0.905).
+        # The physical HBM figure of this kernel is its stores: frac = frac_stores_only, the counter-inclusive one is kept beside it.
+        rf["frac_counters_incl_infinity_cache_reads"] = rf["frac"]
+        rf["achieved_counters_incl_infinity_cache_reads"] = rf["achieved"]
+        rf["frac"] = rf["frac_stores_only"]
+        rf["achieved"] = round(rf["frac_stores_only"] * HBM_PEAK_GBS, 1)
+        rf["frac_note"] = ("frac = the tuple STORES alone (WRITE_SIZE) / HIP-event time / 8 TB/s: the reads of this kernel (value entries, 4 B per hit from the "
+                           "packed side array) are served by the 256 MiB Infinity Cache, which the fabric-side FETCH_SIZE counter includes; "
+                           "frac_counters_incl_infinity_cache_reads is that figure")
     gc = cal.get("walk", {}).get("gather_ceiling_Ggathers_per_s")
     if cls == "walk" and gc and rf["avg_launch_ms"] > 0:
         # the walk's own yardstick: dependent random 32-byte gathers.  tools/membench.hip `calib` measures how many such
@@ -1511,9 +1556,12 @@ def _time_one_format(args, W, r, batch, name, ab_name, ab_values):
     import torch
     from rmqtt_amd import capi
     deliver = name in ("deliver", "deliver8")
-    fmt = capi.RGR_FORMAT_DELIVER8 if name == "deliver8" else capi.RGR_FORMAT_TUPLE if deliver else FORMAT_NAMES.index(name)
+    positions = name == "positions"                    # retained path: tuples with positions of the preorder value array (rgr_batch_set_retain_positions)
+    fmt = capi.RGR_FORMAT_DELIVER8 if name == "deliver8" else capi.RGR_FORMAT_TUPLE if (deliver or positions) else FORMAT_NAMES.index(name)
     batch.set_format(fmt)
-    bph = {"tuple": 12, "soa": 5, "packed": 4, "runs": 0, "ids24": 3, "deliver": 12, "deliver8": 8}[name]
+    if W["retain"]:
+        batch.set_retain_positions(positions)
+    bph = {"tuple": 12, "soa": 5, "packed": 4, "runs": 0, "ids24": 3, "deliver": 12, "deliver8": 8, "positions": 12}[name]
     results = []
     for val in ab_values:
         _set_variant(ab_name, val)
@@ -1541,7 +1589,7 @@ def _time_one_format(args, W, r, batch, name, ab_name, ab_values):
             rec["env"] = val
         results.append(rec)
         print(json.dumps(rec), flush=True)
-    if ab_name and len(ab_values) > 1 and not args.no_ab_check and fmt != capi.RGR_FORMAT_RUNS:
+    if ab_name and len(ab_values) > 1 and not args.no_ab_check and fmt != capi.RGR_FORMAT_RUNS and not positions:
         best = max(range(len(results)), key=lambda i: results[i]["value"])
         if best == 0:
             best = max(range(1, len(results)), key=lambda i: results[i]["value"])
@@ -1682,6 +1730,8 @@ def compact_record(r, top):
         out["compact_formats"] = cf if top else {e["format"]: e.get("value") for e in cf}
     if isinstance(r.get("pcie_inclusive_ranges"), dict):
         out["pcie_inclusive_ranges_matches_per_s"] = r["pcie_inclusive_ranges"].get("matches_per_s")
+    if isinstance(r.get("retain_positions"), dict):
+        out["retain_positions"] = _pick(r["retain_positions"], ["value", "ms_per_step", "expand_avg_launch_ms", "frac_of_hbm_peak_stores_kernel"])
     if isinstance(r.get("delivery_stage"), dict):
         out["delivery_stage"] = _pick(r["delivery_stage"], ["v5_fraction", "bytes_written_per_hit", "dedup_ms_per_step", "expand_store_GBps"])
         if isinstance(r["delivery_stage"].get("tuple12"), dict):

@@ -456,6 +456,16 @@ int32_t rgr_retain_match_ranges(rgr_handle* h, const uint8_t* filters_blob, cons
                                 rgr_retain_ranges* out);
 void rgr_retain_ranges_free(rgr_retain_ranges* r);
 
+/* Device-resident retain batches: answer with POSITIONS.  Later passes write, into rgr_tuple.sub_id, the position of the hit in the epoch's
+ * preorder value array instead of the topic id stored there: topic id = vals[position].topic_id, with `vals` the host mirror
+ * rgr_batch_retain_vals returns (the array rgr_retain_ranges.vals points at).  The expansion then reads nothing per hit — a trailing '#' is a
+ * contiguous range of that array (retain.rs:502-524), its hits are consecutive numbers.  rgr_tuple.qos_flags is 0 in this form: in two-tier
+ * mode the RGR_RETAIN_HIT_DEAD bit of a hit is vals[position].flags.  RGR_ESTATE inside a pass or on a publish batch. */
+int32_t rgr_batch_set_retain_positions(rgr_batch* b, int32_t on);
+/* Host mirror of the value array of the epoch (and tier) the batch's last rgr_batch_begin bound; valid until the next rgr_batch_begin /
+ * rgr_batch_destroy of this batch. */
+int32_t rgr_batch_retain_vals(const rgr_batch* b, const rgr_retain_val** vals, uint64_t* n);
+
 /* ---- multi-GPU sharding rule (host-side helper, no device work) -------------------------
  * Table and publishes shard by a hash of the first `key_levels` topic levels (SURVEY.md §8(e):
  * a first-level-only hash is far too skewed under Zipf level-0 tokens; 3 levels keep the

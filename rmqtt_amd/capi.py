@@ -32,7 +32,7 @@ SYMBOLS = [
     "rgr_sub_remove", "rgr_subscribe_bulk", "rgr_snapshot_save", "rgr_snapshot_load", "rgr_commit",
     "rgr_match_batch", "rgr_match_batch_deliver", "rgr_match_batch_deliver_grouped", "rgr_group_match_batch_deliver_grouped", "rgr_result_free", "rgr_match_filters", "rgr_match_filter_subs", "rgr_filters_result_free",
     "rgr_batch_create", "rgr_batch_create_from_publish", "rgr_batch_publish_info", "rgr_batch_destroy", "rgr_batch_status", "rgr_batch_set_publish_attrs",
-    "rgr_batch_set_format", "rgr_batch_set_topic_ids", "rgr_batch_begin", "rgr_batch_next_window",
+    "rgr_batch_set_format", "rgr_batch_set_topic_ids", "rgr_batch_set_retain_positions", "rgr_batch_retain_vals", "rgr_batch_begin", "rgr_batch_next_window",
     "rgr_window_to_host", "rgr_batch_run", "rgr_batch_run_to_host",
     "rgr_retain_topic_add", "rgr_retain_topic_remove", "rgr_retain_add_bulk", "rgr_retain_commit",
     "rgr_retain_match_batch", "rgr_retain_result_free", "rgr_retain_match_ranges", "rgr_retain_ranges_free", "rgr_retain_batch_create", "rgr_retain_batch_create_tier",
@@ -158,6 +158,8 @@ def lib():
         L.rgr_batch_begin.argtypes = [vp]
         L.rgr_batch_set_format.argtypes = [vp, u32]
         L.rgr_batch_set_topic_ids.argtypes = [vp, vp]
+        L.rgr_batch_set_retain_positions.argtypes = [vp, C.c_int32]
+        L.rgr_batch_retain_vals.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
         L.rgr_batch_next_window.argtypes = [vp, C.POINTER(Window)]
         L.rgr_window_to_host.argtypes = [vp, C.POINTER(Window), vp, vp]
         L.rgr_batch_run.argtypes = [vp, C.POINTER(u64), C.POINTER(u32)]
@@ -525,6 +527,16 @@ class Batch:
         """RGR_FORMAT_TUPLE (12 B/hit) | RGR_FORMAT_SOA (sub ids + qos bytes, 5 B/hit) | RGR_FORMAT_PACKED (4 B/hit) | RGR_FORMAT_RUNS |
         RGR_FORMAT_IDS24 (3-byte sub ids, 3 B/hit) | RGR_FORMAT_DELIVER8 (delivery passes: {sub_id, delivery word}, 8 B/hit)."""
         _check(lib().rgr_batch_set_format(self._b, fmt))
+
+    def set_retain_positions(self, on=True):
+        """Retain batches: tuples carry positions in the epoch's preorder value array instead of topic ids (see retain_vals)."""
+        _check(lib().rgr_batch_set_retain_positions(self._b, 1 if on else 0))
+
+    def retain_vals(self):
+        """Host mirror of the value array of the epoch the last begin() bound: structured array (topic_id, flags), a copy."""
+        p, n = C.c_void_p(), C.c_uint64(0)
+        _check(lib().rgr_batch_retain_vals(self._b, C.byref(p), C.byref(n)))
+        return _copy(p, int(n.value), RETAIN_VAL_DTYPE) if n.value else np.zeros(0, dtype=RETAIN_VAL_DTYPE)
 
     def run(self):
         """One full pass; tuples stay on the device.  -> (n_hits, n_windows)"""

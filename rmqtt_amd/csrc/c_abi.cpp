@@ -241,9 +241,11 @@ struct rgr_batch {
     DevBuf rf_filter[2], rf_node[2], r_cnt, r_payload, r_ecnt, r_e0, r_e1, r_out_off, r_epos, r_end, r_depth;   // retain frontier rounds
     // pass state
     bool retain = false;             // batch of SUBSCRIBE filters against the retained-topic trie
+    bool retain_positions = false;   // rgr_batch_set_retain_positions: tuples carry positions in the epoch's value array instead of topic ids
     uint32_t tier = 0;               // two-tier mode: 0 = base epoch, 1 = delta epoch
     std::shared_ptr<Epoch> epoch;
     std::shared_ptr<RetainEpoch> repoch;
+    std::shared_ptr<const std::vector<SubEntry>> retain_vals_pin;      // mirror handed out by rgr_batch_retain_vals
     bool in_pass = false;
     uint32_t cursor = 0;
     uint64_t hits_before = 0;        // hits emitted by earlier windows of this pass
@@ -1242,6 +1244,26 @@ int32_t rgr_batch_set_publish_attrs(rgr_batch* b, const rgr_publish_attr* attrs)
     });
 }
 
+int32_t rgr_batch_set_retain_positions(rgr_batch* b, int32_t on) {
+    if (!b) return fail(RGR_EINVAL, "rgr_batch_set_retain_positions: bad argument");
+    if (b->in_pass) return fail(RGR_ESTATE, "rgr_batch_set_retain_positions: inside a pass");
+    if (!b->retain) return fail(RGR_ESTATE, "rgr_batch_set_retain_positions: not a retain batch");
+    b->retain_positions = on != 0;
+    return RGR_OK;
+}
+
+int32_t rgr_batch_retain_vals(const rgr_batch* b, const rgr_retain_val** vals, uint64_t* n) {
+    if (!b || !vals || !n) return fail(RGR_EINVAL, "rgr_batch_retain_vals: bad argument");
+    if (!b->retain || !b->repoch) return fail(RGR_ESTATE, "rgr_batch_retain_vals: no retain pass has begun on this batch");
+    static_assert(sizeof(rgr_retain_val) == sizeof(SubEntry), "rgr_retain_val layout");
+    std::shared_ptr<const std::vector<SubEntry>> hv;
+    { std::lock_guard<std::mutex> g(b->h->epoch_mu); hv = b->repoch->h_vals; }
+    const_cast<rgr_batch*>(b)->retain_vals_pin = hv;        // (the two-tier commit replaces the epoch's mirror copy-on-write: keep the one handed out)
+    *vals = hv ? reinterpret_cast<const rgr_retain_val*>(hv->data()) : nullptr;
+    *n = hv ? hv->size() : 0;
+    return RGR_OK;
+}
+
 int32_t rgr_batch_set_topic_ids(rgr_batch* b, const uint32_t* ids) {
     return guarded([&]() -> int32_t {
         if (!b) return fail(RGR_EINVAL, "rgr_batch_set_topic_ids: bad argument");
@@ -1429,8 +1451,16 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
             }
             sp = b->span_begin(kSpanExpand);
             if (b->format == kFmtTuple || b->format == kFmtDeliver8)
+            {
+                // where the retained path's tuples take their ids from (kernels.hpp launch_expand): positions need no read at all; a single-tier
+                // epoch's entries carry no flags, so its packed 4-byte side array serves (RGR_RETAIN_PACKED_READS=0, read per window: the 8-byte
+                // entries as until r5)
+                int id_source = 0;
+                if (b->retain && b->retain_positions) id_source = 2;
+                else if (b->retain && !h->retain_tiered() && batch_view(b).subs_packed) { const char* e = std::getenv("RGR_RETAIN_PACKED_READS"); id_source = (e && e[0] == '0') ? 0 : 1; }
                 launch_expand(batch_view(b), ca, pair_lo, pair_hi, hit_lo, hit_hi, tile_recs, outbuf.as<Tuple>(), b->stream,
-                              (b->deliver && !b->retain) ? &da : nullptr, b->format == kFmtDeliver8);
+                              (b->deliver && !b->retain) ? &da : nullptr, b->format == kFmtDeliver8, id_source);
+            }
             else if (launch_expand_compact(batch_view(b), ca, pair_lo, pair_hi, hit_lo, hit_hi, tile_recs, b->format,
                                            outbuf.as<uint32_t>(), outbuf.as<uint8_t>() + ids_bytes, b->stream, next_tiles.out ? &next_tiles : nullptr))
                 b->tile_plan = next_plan;                      // the expansion wrote the next window's records as well

@@ -870,7 +870,7 @@ void launch_tiles(const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint
 }
 
 void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint64_t hit_hi,
-                   const TileRec* tile_first, Tuple* out, void* stream, const DeliverArgs* deliver, bool hits8) {
+                   const TileRec* tile_first, Tuple* out, void* stream, const DeliverArgs* deliver, bool hits8, int id_source) {
     if (hit_hi <= hit_lo) return;
     const uint32_t ntiles = uint32_t((hit_hi - hit_lo + kTile - 1) / kTile);
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -896,6 +896,8 @@ void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, ui
     else if (deliver && !(lean && lean[0] == '0')) expand_deliver_lean_kernel<kTile / 4, 4><<<ntiles, kTile / 4, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, *deliver);
     else if (deliver && !(early && early[0] == '0')) expand_deliver_early_kernel<kTile / 4, 4><<<ntiles, kTile / 4, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, *deliver);
     else if (deliver) expand_kernel<true, kTile / 4, 4><<<ntiles, kTile / 4, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, *deliver);
+    else if (id_source == 2) expand_kernel<false, kExpandThreads, kExpandPerThread, 2><<<ntiles, kExpandThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, DeliverArgs{}, nullptr);
+    else if (id_source == 1 && t.subs_packed) expand_kernel<false, kExpandThreads, kExpandPerThread, 1><<<ntiles, kExpandThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, DeliverArgs{}, t.subs_packed);
     else expand_kernel<false, kExpandThreads, kExpandPerThread><<<ntiles, kExpandThreads, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, DeliverArgs{});
 }
 

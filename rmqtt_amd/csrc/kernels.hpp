@@ -255,8 +255,10 @@ void launch_compact(const TrieView& t, const ChunkArrays& c, uint32_t topic_base
 struct alignas(16) TileRec { uint32_t first, src, topic, qr; };
 void launch_tiles(const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, TileRec* tile_first, void* stream);
 // hits8: `out` receives 8-byte hits {sub_id, delivery word} (delivery passes in RGR_FORMAT_DELIVER8; lean expansion only)
+// id_source (plain tuples): 0 = the 8-byte entries, 1 = t.subs_packed (entries without flags: the retained path's single-tier epochs),
+// 2 = the entry's index in subs[] (retained-path passes that answer with positions, rgr_batch_set_retain_positions)
 void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, uint64_t pair_hi, uint64_t hit_lo, uint64_t hit_hi,
-                   const TileRec* tile_first, Tuple* out, void* stream, const DeliverArgs* deliver = nullptr, bool hits8 = false);
+                   const TileRec* tile_first, Tuple* out, void* stream, const DeliverArgs* deliver = nullptr, bool hits8 = false, int id_source = 0);
 // compact result formats (rgr_batch_set_format): sub ids (+ a qos byte array) without the topic column
 constexpr int kFmtTuple = 0, kFmtSoa = 1, kFmtPacked = 2, kFmtRuns = 3, kFmtIds24 = 4, kFmtDeliver8 = 5;     // == RGR_FORMAT_*
 // packed[i] = subs[i].sub_id | (subs[i].qos_flags & 3) << 30 for i in [0, n)

@@ -177,6 +177,8 @@ extern "C" {
     pub fn rgr_batch_set_publish_attrs(b: *mut rgr_batch, attrs: *const rgr_publish_attr) -> i32;
     pub fn rgr_batch_set_topic_ids(b: *mut rgr_batch, ids: *const u32) -> i32;
     pub fn rgr_batch_set_format(b: *mut rgr_batch, format: u32) -> i32;
+    pub fn rgr_batch_set_retain_positions(b: *mut rgr_batch, on: i32) -> i32;
+    pub fn rgr_batch_retain_vals(b: *const rgr_batch, vals: *mut *const rgr_retain_val, n: *mut u64) -> i32;
     pub fn rgr_batch_begin(b: *mut rgr_batch) -> i32;
     pub fn rgr_batch_next_window(b: *mut rgr_batch, w: *mut rgr_window) -> i32;
     pub fn rgr_batch_run(b: *mut rgr_batch, n_hits: *mut u64, n_windows: *mut u32) -> i32;

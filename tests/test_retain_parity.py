@@ -282,3 +282,62 @@ def test_dense_range_answer_equals_the_hit_list():
     rg2 = r.retain_match_ranges(*pack(["brand/#", "#"]))
     assert rg2["topic_ids"][:1].tolist() == [999_999] and int(rg2["hit_offsets"][2] - rg2["hit_offsets"][1]) == int(eo[1] - eo[0]) + 1
     r.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("delta_max", [0, 50])
+def test_device_resident_windows_with_positions_and_packed_reads(delta_max, monkeypatch):
+    """(r6) Where the retained path's tuples take their ids from (kernels.hpp launch_expand): the 8-byte value entries (RGR_RETAIN_PACKED_READS=0,
+    as until round 5), the packed 4-byte side array of a single-tier epoch (the default there), or nothing at all — rgr_batch_set_retain_positions:
+    the tuple carries the hit's POSITION in the epoch's preorder value array and the caller resolves it through rgr_batch_retain_vals' mirror.
+    All three must describe the same hits, window for window; in two-tier mode (delta_max > 0) the dead bit of a position form hit is the
+    mirror's flag word."""
+    from rmqtt_amd import capi
+    c = wl.CONFIGS[5]
+    blob, offs = wl.gen_topics(40_000, wl.PUB_SEED + 5, 0.01, c["p_blank"], c["fixed_depth"], distinct=True)
+    fb, fo, _, _ = wl.gen_subs(600, wl.SUB_SEED + 5, c["p_plus"], c["p_hash"], c["p_sys"], 0, c["fixed_depth"], force_wildcard=True)
+    r = capi.Router(device=0, window_hits=30_000, retain_delta_max=delta_max)
+    ids = np.random.default_rng(3).permutation(40_000).astype(np.uint32) + 7          # caller ids: neither dense from 0 nor in preorder
+    r.retain_add_bulk(blob, offs, ids)
+    r.retain_commit()
+    if delta_max:                                   # some base topics replaced / removed after the base tier was compiled: dead entries
+        names = [bytes(blob[int(offs[i]):int(offs[i + 1])]).decode() for i in range(0, 280, 7)]          # (fewer than delta_max: no merge)
+        for k, nm in enumerate(names):
+            if k % 2:
+                r.retain_remove(nm)
+            else:
+                r.retain_add(nm, 1_000_000 + k)
+        r.retain_commit()
+
+    def windows(b):
+        out = []
+        b.begin()
+        while True:
+            w = b.next_window()
+            if w is None:
+                return out
+            t, o = b.window_to_host(w)
+            out.append((int(w.topic_begin), int(w.topic_end), o.copy(), t.copy()))
+    b = r.retain_batch(fb, fo, tier=0 if delta_max else None)
+    monkeypatch.setenv("RGR_RETAIN_PACKED_READS", "0")
+    ref = windows(b)
+    monkeypatch.delenv("RGR_RETAIN_PACKED_READS")
+    dflt = windows(b)
+    b.set_retain_positions(True)
+    pos = windows(b)
+    vals = b.retain_vals()
+    b.set_retain_positions(False)
+    again = windows(b)
+    assert sum(len(x[3]) for x in ref) > 100_000 and len(ref) > 3
+    seen_dead = False
+    for (tb0, te0, o0, t0), (tb1, te1, o1, t1), (tb2, te2, o2, t2), (_, _, _, t3) in zip(ref, dflt, pos, again):
+        assert (tb0, te0) == (tb1, te1) == (tb2, te2) and np.array_equal(o0, o1) and np.array_equal(o0, o2)
+        assert np.array_equal(t0, t1) and np.array_equal(t0, t3)
+        assert np.array_equal(t2["topic_idx"], t0["topic_idx"]) and not t2["qos_flags"].any()
+        assert np.array_equal(vals["topic_id"][t2["sub_id"]], t0["sub_id"]) and np.array_equal(vals["flags"][t2["sub_id"]], t0["qos_flags"])
+        seen_dead |= bool(t0["qos_flags"].any())
+    assert seen_dead == bool(delta_max)
+    bp = r.batch(*pack(["a/b"]))
+    with pytest.raises(capi.RgrError):
+        bp.set_retain_positions(True)               # a publish batch has no value array
+    bp.close(); b.close(); r.close()
