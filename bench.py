@@ -1420,6 +1420,9 @@ def measure_router_e2e(args, quick=False):
     L.hr_restore_bulk.argtypes = [vp, vp, vp, vp, vp, C.c_uint64]
     L.hr_e2e_run.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, vp, vp, vp, C.c_uint32, vp]
     L.hr_e2e_run_async.argtypes = [vp, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, vp, vp, vp, C.c_uint32, vp]
+    L.hr_restore_bulk_ex.argtypes = [vp, vp, vp, vp, vp, vp, C.c_uint64]
+    L.hr_forwards_run_async.argtypes = [vp, vp, vp, C.c_uint32, vp, vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_double, vp, vp, vp, C.c_uint32, vp]
+    legs = set(args.e2e_legs.split(","))
     cores = args.cpu_threads or os.cpu_count() or 1
     out = []
     for cfg in [int(x) for x in args.e2e_configs.split(",")]:
@@ -1429,6 +1432,15 @@ def measure_router_e2e(args, quick=False):
         tb = np.ascontiguousarray(tb, dtype=np.uint8); to = np.ascontiguousarray(to, dtype=np.uint64)
         blob = np.ascontiguousarray(W["blob"], dtype=np.uint8); offs = np.ascontiguousarray(W["offs"], dtype=np.uint64)
         client = np.ascontiguousarray(W["client"], dtype=np.uint32); qos = np.ascontiguousarray(W["qos"], dtype=np.uint8)
+        if "forwards" in legs:
+            # ---- Shared::forwards (shared.rs:735-820, 876-963) through GpuShared: one delivery pass per batch, delivery words -> sessions, no SubRelationsMap;
+            # beside it the oracle's _matches + collector + forwards_to pass on the same publishes (same table: 10 % MQTT v5 relations, same publishers)
+            frec = measure_forwards_e2e(args, L, W, cfg, n_t, tb, to, blob, offs, client, qos, cores, quick)
+            out.append(frec)
+            if not quick:
+                print(json.dumps(frec), flush=True)
+        if "matches" not in legs:
+            continue
         g = L.hr_new(1, 0)
         t = time.time()
         assert L.hr_restore_bulk(g, blob.ctypes.data, offs.ctypes.data, client.ctypes.data, qos.ctypes.data, W["n_sub"]) == 0
@@ -1503,6 +1515,70 @@ def measure_router_e2e(args, quick=False):
         if not quick:
             print(json.dumps(rec), flush=True)
     return out if quick else 0
+
+
+def measure_forwards_e2e(args, L, W, cfg, n_t, tb, to, blob, offs, client, qos, cores, quick):
+    """Shared::forwards end to end (the consumer of SURVEY 8(f)-1's delivery stage): publishes submitted asynchronously to the C++ twin of GpuShared
+    (rmqtt_amd/host/gpu_shared.*), every batch ONE device pass (rgr_group_match_batch_deliver with the publishes' qos / retain), every publish consumed
+    from delivery words on a pool thread — per recipient a Publish clone with qos' / retain' handed to the session's (counting) channel.  CPU side: the
+    oracle's DefaultRouter::forwards_shaped (_matches + v3 / v5 collector + forwards_to's transform) on all cores, same table, same publishes."""
+    import ctypes as C
+
+    from oracle import oracle as orc
+    flags = deliver_flags(W["n_sub"], DELIVER_SECONDARY_V5)
+    prng = np.random.default_rng(12)
+    from_client = np.ascontiguousarray(prng.choice(client, size=n_t), dtype=np.uint32)
+    qr = np.ascontiguousarray(prng.integers(0, 3, size=n_t) | (prng.integers(0, 2, size=n_t) << 2), dtype=np.uint8)
+    g = L.hr_new(1, 0)
+    t = time.time()
+    assert L.hr_restore_bulk_ex(g, blob.ctypes.data, offs.ctypes.data, client.ctypes.data, qos.ctypes.data, flags.ctypes.data, W["n_sub"]) == 0
+    log(f"forwards e2e config {cfg}: GpuRouter::restore of {W['n_sub']} relations (10 % v5) in {time.time() - t:.1f}s")
+    rec = {"metric": f"Shared::forwards publishes/sec, delivery words -> sessions (config {cfg}, v5 fraction {DELIVER_SECONDARY_V5})", "unit": "publishes/s", "threads": cores,
+           "config": {"workload": f"BASELINE.json configs[{cfg - 1}]: {W['n_sub']} subscriptions ({DELIVER_SECONDARY_V5:.0%} MQTT v5: No Local / RAP), {n_t} publishes cycled, "
+                                  f"publishers drawn from the subscribers", "batcher": {"max_batch": 4096, "max_delay_us": 200}},
+           "gpu_async": []}
+    shapes = [(args.e2e_submitters, args.e2e_outstanding, args.e2e_workers or max(8, min(64, cores // 4)), args.e2e_passes)]
+    if args.e2e_sweep:
+        shapes += [(8, 16384, 128, 3), (8, 65536, 64, 4), (4, 8192, 32, 2)]
+    for subm, outst, workers, passes in shapes:
+        res = (C.c_uint64 * 6)()
+        wall = C.c_double(0)
+        lat = np.zeros(200_000, dtype=np.float32)
+        nl = C.c_uint32(0)
+        L.hr_forwards_run_async(g, tb.ctypes.data, to.ctypes.data, n_t, from_client.ctypes.data, qr.ctypes.data, subm, outst, workers, passes, 4096, 200, 1.0, res, C.byref(wall), None, 0, None)      # warm
+        L.hr_forwards_run_async(g, tb.ctypes.data, to.ctypes.data, n_t, from_client.ctypes.data, qr.ctypes.data, subm, outst, workers, passes, 4096, 200, 3.0 if quick else 5.0, res,
+                                C.byref(wall), lat.ctypes.data, len(lat), C.byref(nl))
+        l = np.sort(lat[:nl.value])
+        rec["gpu_async"].append({"submitters": subm, "outstanding": outst, "workers": workers, "passes_in_flight": passes,
+                                 "value": round(res[0] / wall.value, 1), "recipients_per_s": round(res[1] / wall.value, 1), "device_passes": int(res[2]),
+                                 "publishes_per_pass": round(res[0] / max(1, res[2]), 1), "errors": int(res[3]), "host_path_publishes": int(res[4]), "wall_s": round(wall.value, 2),
+                                 "publishes": int(res[0]), "recipients": int(res[1]),
+                                 "latency_us": {"p50": round(float(l[len(l) // 2]), 1), "p99": round(float(l[int(len(l) * 0.99)]), 1)} if len(l) else None})
+        log(f"forwards e2e config {cfg}: {rec['gpu_async'][-1]}")
+    L.hr_free(g)
+    o = orc.DefaultRouter()
+    o.add_bulk_ex(W["blob"], W["offs"], W["client"], W["qos"], flags)
+    n_c = n_t if cfg == 2 else int(min(n_t, 60_000 * cores / 256 + 2000))
+    idx = np.arange(n_c)
+    cb, co = prefix(W, n_c)
+    o.forwards_timed(cb, co, from_client[idx], qr[idx], cores)
+    sec, rows, hits, reps = 0.0, 0, 0, 0
+    while sec < 2.0 and reps < 400:
+        s1, o1 = o.forwards_timed(cb, co, from_client[idx], qr[idx], cores)
+        sec += s1; rows += o1["rows"]; hits += o1["hits"]; reps += 1
+    rec["cpu_reference_port"] = {"value": round(n_c * reps / sec, 1), "recipients_per_s": round(rows / sec, 1), "relations_visited_per_s": round(hits / sec, 1), "threads": cores,
+                                 "kind": "port", "sample": n_c, "sweeps": reps,
+                                 "what": "oracle DefaultRouter::forwards_shaped: _matches with the v3 / v5 collector (router.rs:174-265, types.rs:510-540) + forwards_to's "
+                                         "per-recipient transform (shared.rs:886-908); rows are built and dropped, no channel"}
+    # the two sides reach the same recipients: per publish of the sample, rows delivered by the oracle == recipients counted by the device path
+    rec["recipients_per_publish"] = {"gpu": round(rec["gpu_async"][0]["recipients"] / max(1, rec["gpu_async"][0]["publishes"]), 2),
+                                     "cpu_port_sample": round(rows / max(1, reps * n_c), 2)}
+    best = max(x["value"] for x in rec["gpu_async"])
+    rec["value"] = best
+    rec["value_async_submit"] = best
+    rec["vs_cpu_port"] = round(best / rec["cpu_reference_port"]["value"], 2)
+    del o
+    return rec
 
 
 def time_format(args):
@@ -1812,6 +1888,7 @@ def main():
     ap.add_argument("--e2e-passes", type=int, default=3, help="device passes in flight")
     ap.add_argument("--e2e-sweep", action="store_true", help="--router-e2e: also run a few other (submitters, outstanding, workers, passes) shapes")
     ap.add_argument("--e2e-configs", default="2,3")
+    ap.add_argument("--e2e-legs", default="matches,forwards", help="--router-e2e: which consumers to time: Router::matches (SubRelationsMap per publish) and / or Shared::forwards (delivery words -> sessions)")
     ap.add_argument("--time-format", default=None, help="time passes of ONE result format only (or several, comma-separated: one table build) and exit (sweeps, kernel traces): " + ", ".join(FORMAT_NAMES) + "; or `deliver` alone: the delivery stage (--deliver V5FRAC, default 0.1)")
     ap.add_argument("--ab-env", default=None, help="with --time-format: 'A=1,A=2,A=2+B=7': time the same batch once per variant (comma-separated; '+' joins assignments) of environment switches the library reads per launch")
     ap.add_argument("--no-ab-check", action="store_true", help="with --ab-env: skip the full-pass digest comparison of the fastest value against the first")

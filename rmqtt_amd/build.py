@@ -86,8 +86,8 @@ def build_gpu(force=False, verbose=False):
 def build_host_router(force=False):
     """C++ mirror of the reference's Router trait over the C ABI + its test shim."""
     hdir = os.path.join(HERE, "host")
-    srcs = [os.path.join(hdir, f) for f in ("gpu_router.cpp", "gpu_retain.cpp", "raft_snapshot.cpp", "router_capi.cpp")]
-    deps = srcs + [os.path.join(hdir, f) for f in ("gpu_router.hpp", "gpu_retain.hpp", "raft_snapshot.hpp")] + [os.path.join(INCLUDE, "rmqtt_gpu_router.h"), GPU_LIB]
+    srcs = [os.path.join(hdir, f) for f in ("gpu_router.cpp", "gpu_shared.cpp", "gpu_retain.cpp", "raft_snapshot.cpp", "router_capi.cpp")]
+    deps = srcs + [os.path.join(hdir, f) for f in ("gpu_router.hpp", "gpu_shared.hpp", "gpu_retain.hpp", "raft_snapshot.hpp")] + [os.path.join(INCLUDE, "rmqtt_gpu_router.h"), GPU_LIB]
     if force or _stale(HOST_LIB, deps):
         with _build_lock():
             if force or _stale(HOST_LIB, deps):

@@ -487,6 +487,28 @@ Result<bool> GpuRouter::matches_batch_deliver(const std::vector<Id>& ids, const 
     return Result<bool>::Ok(true);
 }
 
+// The delivery stage as a pass of its own: see gpu_router.hpp.  The pass runs under the table's SHARED lock (several passes at once, like
+// filters_pass); a dirty table is committed first under the exclusive one.
+Result<bool> GpuRouter::deliver_pass(const std::string& blob, const std::vector<uint64_t>& offs, const Id* const* ids, const uint8_t* qos_retain, DeliverPass& pass) {
+    if (!g_) return Result<bool>::Err(create_error_);
+    const uint32_t n = uint32_t(offs.size() - 1);
+    auto run = [&]() -> Result<bool> {
+        std::vector<rgr_publish_attr> attrs(n);
+        for (uint32_t i = 0; i < n; ++i) attrs[i] = rgr_publish_attr{owners_.find(id_key(*ids[i])), uint32_t(qos_retain[i] & 7u)};
+        pass.epoch = mutation_epoch_.load(std::memory_order_acquire);
+        if (rgr_group_match_batch_deliver(g_, reinterpret_cast<const uint8_t*>(blob.data()), offs.data(), n, attrs.data(), &pass.res) != RGR_OK)
+            return Result<bool>::Err(rgr_last_error());
+        return Result<bool>::Ok(true);
+    };
+    if (!dirty_.load(std::memory_order_acquire)) {
+        std::shared_lock<std::shared_mutex> g(mu_);
+        if (!dirty_.load(std::memory_order_acquire)) return run();
+    }
+    std::unique_lock<std::shared_mutex> g(mu_);
+    if (commit_if_dirty() != RGR_OK) return Result<bool>::Err(rgr_last_error());
+    return run();
+}
+
 // router.rs:499-501
 Result<SubRelationsMap> GpuRouter::matches(const Id& id, const TopicName& topic) {
     std::vector<std::optional<SubRelationsMap>> out;
@@ -584,7 +606,7 @@ Batcher::~Batcher() {
 }
 
 void Batcher::enqueue(Req* req) {
-    Shard& sh = shards_[req->cb ? req->shard : shard_of_this_thread(kShards)];
+    Shard& sh = shards_[(req->cb || req->dcb) ? req->shard : shard_of_this_thread(kShards)];
     { std::lock_guard<std::mutex> lk(sh.m); sh.q.push_back(req); ++sh.requests; }      // (counted per shard, under the lock already held: one shared atomic less per publish)
     const size_t before = pending_.fetch_add(1, std::memory_order_seq_cst);
     // wake a driver for the first request of a batch and when the batch is full; everything in between rides on its deadline.  Only
@@ -616,6 +638,19 @@ void Batcher::submit(const Id& id, std::string_view topic, Callback cb, void* us
     if (!req) req = new Req;
     req->id = id; req->topic.assign(topic.data(), topic.size());      // (recycled objects: the strings' capacity is reused)
     req->cb = cb; req->user = user; req->tag = tag; req->shard = shard;
+    req->pass.reset(); req->err.clear(); req->done = false;
+    enqueue(req);
+}
+
+void Batcher::submit_deliver(const Id& from, std::string_view topic, uint8_t qos_retain, DeliverCallback cb, void* user, uint64_t tag) {
+    if (stop_.load(std::memory_order_acquire)) { const std::string e = "batcher stopped"; cb(user, tag, nullptr, 0, from, &e); return; }
+    const uint32_t shard = uint32_t(shard_of_this_thread(kShards));
+    Shard& sh = shards_[shard];
+    Req* req = nullptr;
+    { std::lock_guard<std::mutex> lk(sh.m); if (!sh.free.empty()) { req = sh.free.back(); sh.free.pop_back(); } }
+    if (!req) req = new Req;
+    req->id = from; req->topic.assign(topic.data(), topic.size());
+    req->cb = nullptr; req->dcb = cb; req->qos_retain = qos_retain; req->user = user; req->tag = tag; req->shard = shard;
     req->pass.reset(); req->err.clear(); req->done = false;
     enqueue(req);
 }
@@ -668,8 +703,17 @@ void Batcher::run() {
             for (size_t i = 0; i < reqs.size(); ++i) { blob += reqs[i]->topic; offs[i + 1] = blob.size(); }
         }
         auto pass = std::make_shared<GpuRouter::FilterPass>();
+        std::shared_ptr<GpuRouter::DeliverPass> dpass;
+        const bool deliver = reqs[0]->dcb != nullptr;            // (a batcher serves one kind of request)
         const auto t_pass = std::chrono::steady_clock::now();
-        auto res = router_.filters_pass(blob, offs, *pass);
+        Result<bool> res = Result<bool>::Ok(true);
+        if (deliver) {
+            dpass = std::make_shared<GpuRouter::DeliverPass>();
+            std::vector<const Id*> ids(reqs.size());
+            std::vector<uint8_t> qr(reqs.size());
+            for (size_t i = 0; i < reqs.size(); ++i) { ids[i] = &reqs[i]->id; qr[i] = reqs[i]->qos_retain; }
+            res = router_.deliver_pass(blob, offs, ids.data(), qr.data(), *dpass);
+        } else res = router_.filters_pass(blob, offs, *pass);
         const auto t_done = std::chrono::steady_clock::now();
         passes_.fetch_add(1, std::memory_order_relaxed);
         collect_ns_.fetch_add(uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(t_pass - t_collect).count()), std::memory_order_relaxed);
@@ -679,13 +723,20 @@ void Batcher::run() {
         std::vector<Req*> failed;
         auto flush = [&] {
             if (task.reqs.empty()) return;
-            task.pass = pass;
+            task.pass = pass; task.dpass = dpass;
             if (workers_.empty()) run_task(task);                 // no pool configured: complete on the driver
             else { { std::lock_guard<std::mutex> g(task_mu_); tasks_.push_back(std::move(task)); } task_cv_.notify_one(); }
             task = Task{};
         };
         for (size_t i = 0; i < reqs.size(); ++i) {
             Req* r = reqs[i];
+            if (r->dcb) {
+                if (!res.ok()) { r->dcb(r->user, r->tag, nullptr, 0, r->id, &res.error); failed.push_back(r); continue; }
+                r->index = i;
+                task.reqs.push_back(r);
+                if (task.reqs.size() >= kTaskRun) flush();
+                continue;
+            }
             if (r->cb) {
                 if (!res.ok()) { r->cb(r->user, r->tag, Result<SubRelationsMap>::Err(res.error)); failed.push_back(r); continue; }
                 r->index = i;
@@ -710,6 +761,11 @@ void Batcher::run_task(Task& t) {
         b->task_ns_.fetch_add(uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count()), std::memory_order_relaxed);
         b->tasks_run_.fetch_add(1, std::memory_order_relaxed); } } timed{this, t0};
     const size_t n = t.reqs.size();
+    if (t.dpass) {                                                // Shared::forwards requests: the completion consumes the delivery words itself
+        for (size_t i = 0; i < n; ++i) t.reqs[i]->dcb(t.reqs[i]->user, t.reqs[i]->tag, t.dpass, t.reqs[i]->index, t.reqs[i]->id, nullptr);
+        recycle(t.reqs);
+        return;
+    }
     std::vector<size_t> index(n);
     std::vector<const Id*> ids(n);
     std::vector<const TopicName*> topics(n);

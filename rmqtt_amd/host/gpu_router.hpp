@@ -188,6 +188,49 @@ class GpuRouter final : public Router {
     void expand_chunk(const FilterPass& pass, const size_t* index, const Id* const* ids, const TopicName* const* topics, size_t n,
                       std::vector<Result<SubRelationsMap>>& out);
     uint64_t stale_expansions() const { return stale_expansions_; }
+    // ---- the delivery stage as a pass of its own (r6): what Shared::forwards consumes WITHOUT a SubRelationsMap in between (gpu_shared.hpp).
+    // One device pass (rgr_group_match_batch_deliver) for a batch of publishes with their real qos / retain bits: per hit the device has
+    // already taken forwards_to's per-recipient decisions (shared.rs:886-903: qos' = min, Retain-As-Published) and _matches' (router.rs:196-201
+    // No Local; types.rs:524-539 first hit per v5 client).  `ids` are the publishers (No Local compares whole Ids).
+    struct DeliverPass {
+        rgr_result res{};
+        uint64_t epoch = 0;                 // mutation epoch the pass saw
+        DeliverPass() = default;
+        DeliverPass(const DeliverPass&) = delete;
+        DeliverPass& operator=(const DeliverPass&) = delete;
+        ~DeliverPass() { rgr_result_free(&res); }
+    };
+    Result<bool> deliver_pass(const std::string& blob, const std::vector<uint64_t>& offs, const Id* const* ids, const uint8_t* qos_retain, DeliverPass& pass);
+    // One recipient of one publish, as the device decided it; pointers into the router's relations map (valid while the visitor runs).
+    struct Delivery {
+        const ClientId* client_id; const TopicFilter* topic_filter; NodeId node_id;
+        uint8_t qos; bool retain;                      // shared.rs:886-902
+        bool is_v5;                                    // SubscriptionOptions::V5 (the collector treats v3 and v5 hits differently, types.rs:519-539)
+        uint32_t subscription_identifier;              // 0 = none; of THIS hit
+        bool v5_duplicate;                             // later hit of a v5 client already delivered to: only its identifier counts (types.rs:526-534)
+    };
+    enum class DeliverOutcome { Done, InvalidTopic, NeedsHostPath };      // NeedsHostPath: $share members among the hits, or the pass is older than the last
+                                                                          // removal (a recycled sub id): the caller takes the reference's own path for this publish
+    // Every hit of publish `t` of the pass that is not dropped by No Local, in TopicTree::matches order; `visit` returns nothing.  Holds the table's
+    // shared lock while it runs (like expand()).
+    template <class Visit> DeliverOutcome visit_deliveries(const DeliverPass& pass, size_t t, Visit&& visit) {
+        std::shared_lock<std::shared_mutex> g(mu_);
+        if (pass.epoch != mutation_epoch_.load(std::memory_order_acquire)) { stale_expansions_++; return DeliverOutcome::NeedsHostPath; }
+        if (pass.res.status[t] != RGR_TOPIC_OK) return DeliverOutcome::InvalidTopic;
+        const uint64_t lo = pass.res.hit_offsets[t], hi = pass.res.hit_offsets[t + 1];
+        if (shared_rels_)
+            for (uint64_t k = lo; k < hi; ++k) if ((pass.res.tuples[k].qos_flags >> 8) & RGR_SUB_SHARED) return DeliverOutcome::NeedsHostPath;
+        for (uint64_t k = lo; k < hi; ++k) {
+            const uint32_t w = pass.res.tuples[k].qos_flags;
+            if (w & RGR_HIT_NO_LOCAL) continue;
+            const Slot& sl = slab_[pass.res.tuples[k].sub_id];
+            const Rel& rel = *sl.rel;
+            visit(Delivery{&rel.id.client_id, sl.filter, bulk_loaded_ ? rel.id.node_id : nodes_[w >> 16], uint8_t(w & RGR_HIT_QOS_MASK), (w & RGR_HIT_RETAIN) != 0,
+                           rel.opts.v5, rel.opts.v5 ? rel.opts.subscription_identifier : 0u, (w & RGR_HIT_V5_DUP) != 0});
+        }
+        return DeliverOutcome::Done;
+    }
+    NodeId this_node() const { return this_node_; }
     bool is_online(NodeId node, const std::string& client) override { return is_online_ ? is_online_(node, client) : true; }   // session state lives in the broker
     std::vector<Route> gets(size_t limit) override;
     Result<std::vector<Route>> get(const std::string& topic) override;       // router.rs:157-170 (.unique())
@@ -273,6 +316,11 @@ class Batcher {
     ~Batcher();
     Result<SubRelationsMap> matches(const Id& id, const TopicName& topic);
     void submit(const Id& id, std::string_view topic, Callback cb, void* user, uint64_t tag);
+    // (r6) the same queueing for Shared::forwards (gpu_shared.hpp): a request carries the publish's qos / retain, its batch runs ONE delivery
+    // pass (GpuRouter::deliver_pass), and the completion — on a pool thread, or on the driver without a pool — receives the pass and the
+    // request's index in it instead of a SubRelationsMap (err != nullptr: the pass failed).  A batcher serves one kind of request.
+    using DeliverCallback = void (*)(void* user, uint64_t tag, const std::shared_ptr<GpuRouter::DeliverPass>& pass, size_t index, const Id& from, const std::string* err);
+    void submit_deliver(const Id& from, std::string_view topic, uint8_t qos_retain, DeliverCallback cb, void* user, uint64_t tag);
     uint64_t passes() const { return passes_; }
     uint64_t requests() const { uint64_t n = 0; for (const Shard& sh : shards_) { std::lock_guard<std::mutex> g(sh.m); n += sh.requests; } return n; }
     // where the drivers' and workers' time went (nanoseconds summed over threads): collecting a batch (incl. the deadline wait's tail
@@ -283,14 +331,14 @@ class Batcher {
    private:
     // blocking requests live on their caller's stack and are woken through their own condition variable (one shared cv made 256
     // callers fight for one mutex per pass); asynchronous ones are heap objects that end with their callback
-    struct Req { Id id; TopicName topic; Callback cb = nullptr; void* user = nullptr; uint64_t tag = 0; uint32_t shard = 0;
+    struct Req { Id id; TopicName topic; Callback cb = nullptr; DeliverCallback dcb = nullptr; uint8_t qos_retain = 0; void* user = nullptr; uint64_t tag = 0; uint32_t shard = 0;
                  std::shared_ptr<GpuRouter::FilterPass> pass; size_t index = 0; std::string err; bool done = false;
                  std::mutex m; std::condition_variable cv; };
     // a submitter sticks to one shard: its queue, and the free list its asynchronous requests are recycled through (a finished
     // request goes back to the shard it came from, so request objects — and the capacity of their strings — stay with their submitter
     // instead of crossing the allocator's arenas on every publish)
     struct alignas(64) Shard { mutable std::mutex m; std::vector<Req*> q; std::vector<Req*> free; uint64_t requests = 0; };
-    struct Task { std::shared_ptr<GpuRouter::FilterPass> pass; std::vector<Req*> reqs; };
+    struct Task { std::shared_ptr<GpuRouter::FilterPass> pass; std::shared_ptr<GpuRouter::DeliverPass> dpass; std::vector<Req*> reqs; };
     static constexpr size_t kShards = 16;      // submission queues (a submitter sticks to one)
     static constexpr size_t kTaskRun = 64;     // publishes per worker task
     GpuRouter& router_;

@@ -14,6 +14,7 @@
 
 #include "gpu_retain.hpp"
 #include "gpu_router.hpp"
+#include "gpu_shared.hpp"
 #include "raft_snapshot.hpp"
 
 using namespace rmqtt;
@@ -416,3 +417,199 @@ int64_t hr_topics(void* r) { return static_cast<GpuRouter*>(r)->topics().count; 
 int64_t hr_routes(void* r) { return static_cast<GpuRouter*>(r)->routes().count; }
 uint64_t hr_topics_tree(void* r) { return static_cast<GpuRouter*>(r)->topics_tree(); }
 }
+
+// ---------------------------------------------------------------------------------------------- Shared::forwards (gpu_shared.hpp)
+namespace {
+// a session whose channel writes into its Shared's log: "<client>\t<qos'>\t<retain'>\t<subscription ids in arrival order,|->"
+struct LogShared;
+struct LogTx final : Tx {
+    LogShared* owner; ClientId client; bool closed = false;
+    bool unbounded_send(const From&, Publish&& p) override;
+};
+struct LogShared {
+    Sessions sessions;
+    std::unique_ptr<DefaultShared> inner;
+    std::unique_ptr<GpuShared> gpu;
+    std::mutex m;
+    std::vector<std::string> log;
+};
+bool LogTx::unbounded_send(const From&, Publish&& p) {
+    if (closed) return false;
+    std::string ids = "-";
+    if (!p.subscription_ids.empty()) { ids.clear(); for (size_t i = 0; i < p.subscription_ids.size(); ++i) { if (i) ids.push_back(','); ids += std::to_string(p.subscription_ids[i]); } }
+    std::lock_guard<std::mutex> g(owner->m);
+    owner->log.push_back(client + "\t" + std::to_string(p.qos) + "\t" + std::to_string(int(p.retain)) + "\t" + ids + "\n");
+    return true;
+}
+// every recipient is reachable and only counted (the bench: what the oracle's forwards_shaped ends at is the row, not a channel)
+struct CountingTx final : Tx {
+    static constexpr uint32_t kLanes = 128;
+    struct alignas(64) Lane { std::atomic<uint64_t> n{0}, qos_sum{0}; char pad[48]; };
+    Lane lane[kLanes];
+    bool unbounded_send(const From&, Publish&& p) override {
+        static std::atomic<uint32_t> next{0};
+        thread_local const uint32_t mine = next.fetch_add(1, std::memory_order_relaxed) % kLanes;
+        lane[mine].n.fetch_add(1, std::memory_order_relaxed);
+        lane[mine].qos_sum.fetch_add(uint64_t(p.qos) + (p.retain ? 4u : 0u), std::memory_order_relaxed);
+        return true;
+    }
+    uint64_t total() const { uint64_t t = 0; for (const Lane& l : lane) t += l.n.load(); return t; }
+    uint64_t checksum() const { uint64_t t = 0; for (const Lane& l : lane) t += l.qos_sum.load(); return t; }
+};
+struct CountingShared final : Shared {
+    CountingTx sink;
+    Router& router;
+    explicit CountingShared(Router& r) : router(r) {}
+    Tx* tx(const ClientId&) override { return &sink; }
+    Result<ForwardedCount> forwards(const From& from, const Publish& publish, std::vector<Undelivered>*) override {      // the host path of a publish the device handed back
+        auto m = router.matches(from.id, *publish.topic);
+        ForwardedCount n = 0;
+        if (m.ok()) for (auto& kv : *m.value) for (auto& r : kv.second) { Publish p = publish; p.qos = std::min(p.qos, r.opts.qos); sink.unbounded_send(from, std::move(p)); ++n; }
+        return Result<ForwardedCount>::Ok(n);
+    }
+};
+}  // namespace
+
+extern "C" {
+// A Shared pair over router `r`: `inner` = the reference's forwards over Router::matches, `gpu` = GpuShared in front of it.
+void* hr_shared_new(void* r, uint64_t this_node, uint32_t max_batch, uint32_t max_delay_us) {
+    auto* router = static_cast<GpuRouter*>(r);
+    auto* s = new LogShared;
+    s->inner = std::make_unique<DefaultShared>(*router, s->sessions, this_node);
+    s->gpu = std::make_unique<GpuShared>(*router, *s->inner, max_batch ? max_batch : 64, std::chrono::microseconds(max_delay_us), 2, 0);
+    return s;
+}
+void hr_shared_free(void* sh) { delete static_cast<LogShared*>(sh); }
+// closed != 0: the session exists but its channel is closed ("Connection Tx is closed")
+void hr_shared_connect(void* sh, const char* client, uint32_t len, int closed) {
+    auto* s = static_cast<LogShared*>(sh);
+    auto tx = std::make_shared<LogTx>();
+    tx->owner = s; tx->client.assign(client, len); tx->closed = closed != 0;
+    s->sessions.connect(tx->client, tx);
+}
+void hr_shared_disconnect(void* sh, const char* client, uint32_t len) { static_cast<LogShared*>(sh)->sessions.disconnect(std::string(client, len)); }
+// One publish through Shared::forwards: use_gpu 0 = the reference path (DefaultShared over Router::matches), 1 = GpuShared.  Returns the sorted log of what the
+// sessions were sent, then "= <count>\n", then one "! <client>\t<reason>\n" per undelivered relation (sorted); NULL on Err.
+char* hr_shared_forwards(void* sh, int use_gpu, const hr_id* from_id, const char* topic, uint64_t len, uint8_t qos, uint8_t retain, const char* target, uint32_t target_len) {
+    auto* s = static_cast<LogShared*>(sh);
+    From from{mk_id(from_id)};
+    Publish p;
+    p.topic = std::make_shared<const TopicName>(topic, len);
+    p.qos = qos; p.retain = retain != 0; p.dup = true; p.packet_id = 77;
+    if (target) p.target_clientid = std::string(target, target_len);
+    { std::lock_guard<std::mutex> g(s->m); s->log.clear(); }
+    std::vector<Undelivered> errs;
+    Shared& which = use_gpu ? static_cast<Shared&>(*s->gpu) : static_cast<Shared&>(*s->inner);
+    auto r = which.forwards(from, p, &errs);
+    if (!r.ok()) return nullptr;
+    std::vector<std::string> log;
+    { std::lock_guard<std::mutex> g(s->m); log.swap(s->log); }
+    std::sort(log.begin(), log.end());
+    std::string out;
+    for (auto& l : log) out += l;
+    out += "= " + std::to_string(*r.value) + "\n";
+    std::vector<std::string> es;
+    for (auto& e : errs) es.push_back("! " + e.to) ;
+    for (size_t i = 0; i < errs.size(); ++i) es[i] += "\t" + errs[i].reason + "\n";
+    std::sort(es.begin(), es.end());
+    for (auto& e : es) out += e;
+    return dup_str(out);
+}
+void hr_shared_counters(void* sh, uint64_t* out /* [5] device_path, host_path, deliveries, remote, passes */) {
+    const auto c = static_cast<LogShared*>(sh)->gpu->counters();
+    out[0] = c.device_path; out[1] = c.host_path; out[2] = c.deliveries; out[3] = c.remote; out[4] = c.passes;
+}
+
+// hr_restore_bulk with the delivery stage's flags per relation (RGR_SUB_V5 | RGR_SUB_NO_LOCAL | RGR_SUB_RAP bits, bench.py deliver_flags)
+int hr_restore_bulk_ex(void* r, const uint8_t* blob, const uint64_t* offs, const uint32_t* client, const uint8_t* qos, const uint8_t* flags, uint64_t n) {
+    raft::Snapshot snap;
+    snap.relations.reserve(n);
+    for (uint64_t i = 0; i < n; ++i) {
+        raft::Relation rel;
+        rel.topic_filter.assign(reinterpret_cast<const char*>(blob) + offs[i], offs[i + 1] - offs[i]);
+        rel.client_id = "c" + std::to_string(client[i]);
+        rel.id.node_id = 1; rel.id.client_id = rel.client_id;
+        rel.opts.qos = qos ? qos[i] : 0;
+        if (flags) { rel.opts.v5 = (flags[i] & RGR_SUB_V5) != 0; rel.opts.no_local = rel.opts.v5 && (flags[i] & RGR_SUB_NO_LOCAL); rel.opts.retain_as_published = rel.opts.v5 && (flags[i] & RGR_SUB_RAP); }
+        snap.relations.push_back(std::move(rel));
+    }
+    return static_cast<GpuRouter*>(r)->restore(snap).ok() ? 0 : -1;
+}
+
+// Shared::forwards at its design point (the asynchronous shape of hr_e2e_run_async): `n_submitters` threads keep `outstanding` publishes in flight through
+// GpuShared::submit; every publish goes through ONE delivery pass of its batch and from delivery words straight to the (counting) sessions on `workers` pool
+// threads.  Publisher of topic i = client "c<from_client[i]>" of node 1, publish qos / retain = qos_retain[i] (bench.py's delivery workload).
+// out[0] = publishes completed, out[1] = recipients reached, out[2] = device passes, out[3] = errors, out[4] = publishes that took the host path,
+// out[5] = checksum of the delivered (qos', retain') pairs.
+int hr_forwards_run_async(void* r, const uint8_t* blob, const uint64_t* offs, uint32_t n, const uint32_t* from_client, const uint8_t* qos_retain, uint32_t n_submitters,
+                          uint32_t outstanding, uint32_t workers, uint32_t passes_in_flight, uint32_t max_batch, uint32_t max_delay_us, double seconds, uint64_t* out,
+                          double* wall_s, float* lat_us, uint32_t n_lat, uint32_t* n_lat_out) {
+    auto* router = static_cast<GpuRouter*>(r);
+    CountingShared inner(*router);
+    // the publishes and their publishers, built once (a broker holds them as it decodes them)
+    std::vector<Publish> pubs(n);
+    std::vector<From> froms(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        pubs[i].topic = std::make_shared<const TopicName>(reinterpret_cast<const char*>(blob) + offs[i], offs[i + 1] - offs[i]);
+        pubs[i].qos = qos_retain[i] & 3u; pubs[i].retain = (qos_retain[i] & 4u) != 0;
+        froms[i].id.node_id = from_client[i] == 0xFFFFFFFFu ? 0 : 1; froms[i].id.client_id = "c" + std::to_string(from_client[i]);
+    }
+    constexpr uint32_t kLanes = 128;
+    struct alignas(64) Lane { std::atomic<uint64_t> pubs{0}, rows{0}, errs{0}; char pad[40]; };
+    struct alignas(64) Ctx { Lane lane[kLanes]; float* lat = nullptr; uint32_t n_lat = 0; std::atomic<uint32_t> lat_n{0}; std::chrono::steady_clock::time_point t0;
+                             uint64_t done() const { uint64_t d = 0; for (const Lane& l : lane) d += l.pubs.load(std::memory_order_acquire); return d; } };
+    std::vector<std::unique_ptr<Ctx>> ctx;
+    for (uint32_t k = 0; k < n_submitters; ++k) ctx.push_back(std::make_unique<Ctx>());
+    const uint64_t cap = std::max<uint64_t>(1, outstanding / std::max(1u, n_submitters));
+    std::atomic<bool> stop{false};
+    const auto t0 = std::chrono::steady_clock::now();
+    for (auto& c : ctx) c->t0 = t0;
+    ctx[0]->lat = lat_us; ctx[0]->n_lat = lat_us ? n_lat : 0;
+    const GpuShared::Done done = [](void* user, uint64_t tag, ForwardedCount count, const std::string* err) {
+        static std::atomic<uint32_t> next_lane{0};
+        thread_local const uint32_t my_lane = next_lane.fetch_add(1, std::memory_order_relaxed) % kLanes;
+        Ctx& c = *static_cast<Ctx*>(user);
+        Lane& l = c.lane[my_lane];
+        if (err) l.errs.fetch_add(1, std::memory_order_relaxed);
+        if (count) l.rows.fetch_add(count, std::memory_order_relaxed);
+        if (c.lat) {
+            const uint32_t j = c.lat_n.fetch_add(1, std::memory_order_relaxed);
+            if (j < c.n_lat) c.lat[j] = float(double(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - c.t0).count() - int64_t(tag)) / 1e3);
+        }
+        l.pubs.fetch_add(1, std::memory_order_release);
+    };
+    double wall = 0;
+    GpuShared::Counters cnt{};
+    {
+        GpuShared gs(*router, inner, max_batch, std::chrono::microseconds(max_delay_us), passes_in_flight, workers);
+        std::vector<std::thread> th;
+        for (uint32_t k = 0; k < n_submitters; ++k)
+            th.emplace_back([&, k] {
+                Ctx& c = *ctx[k];
+                uint64_t submitted = 0, seen = 0;
+                for (uint64_t i = k; !stop.load(std::memory_order_relaxed); i += n_submitters) {
+                    while (submitted - seen >= cap) {
+                        seen = c.done();
+                        if (submitted - seen >= cap) { if (stop.load(std::memory_order_relaxed)) break; std::this_thread::yield(); }
+                    }
+                    const uint32_t t = uint32_t(i % n);
+                    const uint64_t tag = uint64_t(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count());
+                    gs.submit(&froms[t], &pubs[t], done, &c, tag);
+                    ++submitted;
+                }
+                while (c.done() < submitted) std::this_thread::yield();      // drain: every publish completes before the Shared goes away
+            });
+        std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
+        stop = true;
+        for (auto& t : th) t.join();
+        wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        cnt = gs.counters();
+    }
+    if (wall_s) *wall_s = wall;
+    uint64_t p = 0, rws = 0, errs = 0;
+    for (auto& c : ctx) for (const auto& l : c->lane) { p += l.pubs.load(); rws += l.rows.load(); errs += l.errs.load(); }
+    out[0] = p; out[1] = rws; out[2] = cnt.passes; out[3] = errs; out[4] = cnt.host_path; out[5] = inner.sink.checksum();
+    if (n_lat_out) *n_lat_out = std::min<uint32_t>(ctx[0]->lat_n.load(), ctx[0]->n_lat);
+    return 0;
+}
+}  // extern "C"

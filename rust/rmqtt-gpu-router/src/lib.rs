@@ -9,12 +9,14 @@
 //!   max_batch = 4096        publishes per device pass at most
 //!   max_delay_us = 150      micro-batcher deadline
 //!   retain = false          also serve retained-message wildcard queries from the GPU
+//!   forwards = true         install `GpuShared` too: `Shared::forwards` consumes the device's delivery stage directly (no SubRelationsMap)
 //! Environment variables of the same names in upper case with the `RMQTT_GPU_` prefix override the file (round 2 read only those).
 //! Source only — see Cargo.toml.
 mod batcher;
 mod ffi;
 mod retain;
 mod router;
+mod shared;
 
 use std::time::Duration;
 
@@ -26,12 +28,14 @@ use rmqtt::Result;
 
 pub use retain::{GpuRetainIndex, GpuRetainStorage};
 pub use router::GpuRouter;
+pub use shared::GpuShared;
 
 register!(GpuRouterPlugin::new);
 
 struct GpuRouterPlugin {
     scx: ServerContext,
     router: GpuRouter,
+    shared: Option<GpuShared>,
     retain: Option<std::sync::Arc<GpuRetainStorage>>,
 }
 
@@ -47,10 +51,11 @@ struct PluginConfig {
     max_batch: usize,
     max_delay_us: u64,
     retain: bool,
+    forwards: bool,
 }
 impl Default for PluginConfig {
     fn default() -> Self {
-        Self { devices: vec![0], max_batch: 4096, max_delay_us: 150, retain: false }
+        Self { devices: vec![0], max_batch: 4096, max_delay_us: 150, retain: false, forwards: true }
     }
 }
 
@@ -65,10 +70,12 @@ impl GpuRouterPlugin {
         cfg.max_batch = env_or("RMQTT_GPU_MAX_BATCH", cfg.max_batch);
         cfg.max_delay_us = env_or("RMQTT_GPU_MAX_DELAY_US", cfg.max_delay_us);
         cfg.retain = env_or("RMQTT_GPU_RETAIN", cfg.retain as u8) == 1;
+        cfg.forwards = env_or("RMQTT_GPU_FORWARDS", cfg.forwards as u8) == 1;
         log::info!("{name} config: {cfg:?}");
         let router = GpuRouter::new(scx.clone(), &cfg.devices, cfg.max_batch, Duration::from_micros(cfg.max_delay_us))?;
         let retain = if cfg.retain { Some(std::sync::Arc::new(GpuRetainStorage::new(cfg.devices[0])?)) } else { None };
-        Ok(Self { scx, router, retain })
+        let shared = if cfg.forwards { Some(GpuShared::new(scx.clone(), router.clone(), cfg.max_batch, Duration::from_micros(cfg.max_delay_us))) } else { None };
+        Ok(Self { scx, router, shared, retain })
     }
 }
 
@@ -79,6 +86,10 @@ impl Plugin for GpuRouterPlugin {
     async fn start(&mut self) -> Result<()> {
         // rmqtt/src/extend.rs:135 — the router slot is an RwLock<Box<dyn Router>>
         *self.scx.extends.router_mut().await = Box::new(self.router.clone());
+        if let Some(s) = &self.shared {
+            // rmqtt/src/extend.rs:123 — the shared slot, replaced the way rmqtt-cluster-broadcast/src/lib.rs:141 replaces it
+            *self.scx.extends.shared_mut().await = Box::new(s.clone());
+        }
         if let Some(r) = &self.retain {
             // rmqtt/src/extend.rs:71 — the retain slot, as rmqtt-retainer/src/lib.rs:191 fills it
             *self.scx.extends.retain_mut().await = Box::new(RetainHandle(r.clone()));

@@ -98,6 +98,14 @@ struct Slab {
     node_idx: HashMap<NodeId, u16>,
 }
 
+/// Read guard over the sub id slab for `GpuShared`: sub id -> (filter, client, Id) of the relation.
+pub(crate) struct SlabRead<'a>(std::sync::RwLockReadGuard<'a, Slab>);
+impl SlabRead<'_> {
+    pub(crate) fn relation(&self, sub_id: u32) -> Option<&(TopicFilter, ClientId, Id)> {
+        self.0.slots.get(sub_id as usize).and_then(|x| x.as_ref())
+    }
+}
+
 #[derive(Clone)]
 pub struct GpuRouter {
     scx: ServerContext,
@@ -195,6 +203,21 @@ impl GpuRouter {
 
     pub fn _inner(&self) -> &DefaultRouter {
         &self.inner
+    }
+
+    // ---- what `crate::shared::GpuShared` (the consumer of the delivery stage) needs from the router ---------------------------------
+    pub(crate) fn group_ptr(&self) -> GroupPtr { GroupPtr(self.g.0) }
+    /// The same "epoch, then commit what is pending" step the match batcher runs before a pass (see `committer`).
+    pub(crate) fn pass_committer(&self) -> impl Fn() -> std::result::Result<u64, String> + Send + Sync + Clone + 'static {
+        Self::committer(GroupPtr(self.g.0), self.dirty.clone(), self.epoch.clone(), self.slab.clone(), self.commit_lock.clone())
+    }
+    pub(crate) fn mutation_epoch(&self) -> u64 { self.epoch.get() }
+    pub(crate) fn slab_read(&self) -> SlabRead<'_> { SlabRead(self.slab.read().unwrap()) }
+    /// Dense id of the publisher's `Id` (No Local compares whole Ids, router.rs:198); RGR_ID_NONE when it holds no subscription.
+    pub(crate) fn owner_id_of(&self, id: &Id) -> u32 { self.slab.read().unwrap().owners.find(id) }
+    /// The relation's v5 subscription identifier, from the source of truth (`inner.relations`).
+    pub(crate) fn subscription_identifier_of(&self, filter: &TopicFilter, client_id: &ClientId) -> Option<SubscriptionIdentifier> {
+        self.inner.relations.get(filter).and_then(|rels| rels.get(client_id).and_then(|(_, opts)| opts.subscription_identifier()))
     }
 
     /// Mirror one relation into the device table (after `inner.add` accepted it).

@@ -468,3 +468,102 @@ def test_matches_while_the_table_changes(hr):
         stop.set()
         th.join()
     hr.hr_free(g)
+
+
+# ---------------------------------------------------------------------------------------------- Shared::forwards (rmqtt_amd/host/gpu_shared.*)
+def _shared_api(L):
+    vp = C.c_void_p
+    L.hr_shared_new.restype = vp; L.hr_shared_new.argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32]
+    L.hr_shared_free.argtypes = [vp]
+    L.hr_shared_connect.argtypes = [vp, C.c_char_p, C.c_uint32, C.c_int]
+    L.hr_shared_disconnect.argtypes = [vp, C.c_char_p, C.c_uint32]
+    L.hr_shared_forwards.restype = vp
+    L.hr_shared_forwards.argtypes = [vp, C.c_int, C.POINTER(HrId), C.c_char_p, C.c_uint64, C.c_uint8, C.c_uint8, C.c_char_p, C.c_uint32]
+    L.hr_shared_counters.argtypes = [vp, C.POINTER(C.c_uint64)]
+
+
+def _expected_sends(dump, node, connected, closed):
+    """The oracle's forwards dump ("N <node>" sections of "<client>\\t<filter>\\t<qos'>\\t<retain'>\\t<ids>" rows) -> what the sessions of `node` are sent:
+    sorted "<client>\\t<qos'>\\t<retain'>\\t<ids>" rows of the connected clients, the number of recipients reached, the sorted undelivered ones."""
+    rows, errs, cur = [], [], None
+    for ln in dump.splitlines():
+        if ln.startswith("N "):
+            cur = int(ln[2:])
+            continue
+        if cur != node:
+            continue
+        client, _filt, q, rt, ids = ln.split("\t")[:5]
+        if client in closed:
+            errs.append(f"! {client}\tConnection Tx is closed\n")
+        elif client not in connected:
+            errs.append(f"! {client}\tthe client has disconnected\n")
+        else:
+            rows.append(f"{client}\t{q}\t{rt}\t{ids}\n")
+    return "".join(sorted(rows)) + f"= {len(rows)}\n" + "".join(sorted(errs))
+
+
+def test_shared_forwards_from_delivery_words_equals_the_reference_path(hr):
+    """Shared::forwards (shared.rs:735-820, 876-963) three ways for the same publishes: the oracle's _matches + collector + forwards_to dump, the C++
+    restatement of the reference path (DefaultShared over Router::matches) and GpuShared — one delivery pass of the device, delivery words straight into
+    the sessions' channels, no SubRelationsMap.  v3 and v5 relations, No Local publishers, Retain As Published, subscription identifiers collected
+    across a v5 client's overlapping filters, relations of other nodes (not sent by a single-node Shared), disconnected clients and a closed channel;
+    publishes that meet $share members and `target_clientid` publishes must take the reference's path unchanged."""
+    _shared_api(hr)
+    g = hr.hr_new(1, 0)
+    assert g
+    o = orc.DefaultRouter()
+    hr.hr_set_shared_policy(g, 1); o.set_shared_policy(1)
+    rng = random.Random(23)
+    levels = ["a", "b", "c", ""]
+    filters = ["a/#", "a/b", "a/+", "+/b", "#", "a/b/c", "+/+/c", "b/#", "a/b/#", "$SYS/#"]
+    clients = [f"cl{i}" for i in range(60)]
+    node_of = {c: rng.choice([1, 1, 1, 2]) for c in clients}
+    for i in range(700):
+        f = rng.choice(filters)
+        client = rng.choice(clients)
+        v5 = rng.random() < 0.55
+        opts = dict(qos=rng.randint(0, 2), v5=v5, no_local=v5 and rng.random() < 0.4, rap=v5 and rng.random() < 0.5, sub_ident=rng.randint(1, 40) if v5 and rng.random() < 0.6 else 0)
+        hid, oid = _id(node_of[client], client)
+        ho = HrOpts(int(opts["v5"]), opts["qos"], int(opts["no_local"]), int(opts["rap"]), 0, opts["sub_ident"])
+        assert hr.hr_add(g, f.encode(), len(f.encode()), C.byref(hid), C.byref(ho)) == o.add(f, oid, orc.mk_opts(**opts), rel_id=i)
+    for i in range(8):                                 # $share members on one filter only
+        client = f"sh{i}"
+        node_of[client] = 1
+        hid, oid = _id(1, client)
+        sg = b"g1"
+        ho = HrOpts(0, 1, 0, 0, 0, 0, sg, len(sg))
+        assert hr.hr_add(g, b"b/x", 3, C.byref(hid), C.byref(ho)) == o.add("b/x", oid, orc.mk_opts(qos=1, shared_group="g1"), rel_id=900 + i)
+    sh = hr.hr_shared_new(g, 1, 16, 100)
+    connected = set(c for c in list(node_of) if rng.random() < 0.85)
+    closed = {"cl7"}
+    connected.add("cl9")
+    connected -= closed
+    for c in connected:
+        hr.hr_shared_connect(sh, c.encode(), len(c.encode()), 0)
+    hr.hr_shared_connect(sh, b"cl7", 3, 1)
+    topics = ["a/b", "a/b/c", "a", "b/x", "b/y", "$SYS/x", "a//c", "x/y/z", "a/#/b", "c/b"]
+    n_device = n_host = 0
+    for k in range(160):
+        t = rng.choice(topics)
+        pub = rng.choice(clients + ["stranger"])
+        hid, oid = _id(node_of.get(pub, 1), pub)
+        q, rt = rng.randint(0, 2), int(rng.random() < 0.5)
+        ref = _take(hr, hr.hr_shared_forwards(sh, 0, C.byref(hid), t.encode(), len(t.encode()), q, rt, None, 0))
+        got = _take(hr, hr.hr_shared_forwards(sh, 1, C.byref(hid), t.encode(), len(t.encode()), q, rt, None, 0))
+        assert got == ref, (t, pub, q, rt)
+        dump = o.forwards(oid, t, q, bool(rt))
+        if dump is None:
+            assert got == "= 0\n"                        # Topic::from_str Err: logged, nobody is sent anything (shared.rs:774-777)
+        elif t != "b/x":                                # (the $share publish: the chosen member's row is in the dump; counts expand the group, shared.rs:945-956)
+            assert got == _expected_sends(dump, 1, connected, closed), (t, pub)
+    cnt = (C.c_uint64 * 5)()
+    hr.hr_shared_counters(sh, cnt)
+    n_device, n_host = int(cnt[0]), int(cnt[1])
+    assert n_device > 100 and n_host > 3 and int(cnt[3]) > 0          # device path taken, $share publishes handed back, other nodes' relations met
+    # target_clientid: no matching at all (shared.rs:744-770)
+    hid, _ = _id(1, "cl1")
+    a = _take(hr, hr.hr_shared_forwards(sh, 0, C.byref(hid), b"a/b", 3, 2, 1, b"cl9", 3))
+    b = _take(hr, hr.hr_shared_forwards(sh, 1, C.byref(hid), b"a/b", 3, 2, 1, b"cl9", 3))
+    assert a == b and a.endswith("= 1\n")
+    hr.hr_shared_free(sh)
+    hr.hr_free(g)
