@@ -250,6 +250,13 @@ def gpu_digests(batch, n_topics, retain, fmt=0, subs_len=0, topic_ids_dev=None, 
     batch.begin()
     expect_begin = 0
     M32 = 0xFFFFFFFF
+    # a batch in walk order (rgr_batch_set_order): windows enumerate walk positions; order_dev[k] = batch topic walked k-th, inv_dev its inverse
+    perm = None if retain else batch.topic_order()
+    order_dev = inv_dev = None
+    if perm is not None:
+        order_dev = torch.from_numpy(perm.astype(np.int64)).cuda()
+        inv_dev = torch.empty_like(order_dev)
+        inv_dev[order_dev] = torch.arange(n_topics, dtype=torch.int64, device="cuda")
     while True:
         w = batch.next_window()
         if w is None:
@@ -267,9 +274,12 @@ def gpu_digests(batch, n_topics, retain, fmt=0, subs_len=0, topic_ids_dev=None, 
         structure_ok &= int(d_off[0]) == 0 and int(d_off[-1]) == nh
         start, end = d_off[:-1], d_off[1:]
         cnt = end - start
+        rows = order_dev[tb_:te_] if order_dev is not None else None          # batch topics of the window's positions
+        if order_dev is not None:
+            structure_ok &= bool(w.d_topic_order) and bool((torch.as_tensor(_DevArr(w.d_topic_order, (nt,), "<i4"), device="cuda").to(torch.int64) == rows).all())
         if fmt == capi.RGR_FORMAT_TUPLE:
             t = torch.as_tensor(_DevArr(w.d_tuples, (nh, 3), "<i4"), device="cuda")
-            owner = torch.repeat_interleave(torch.arange(tb_, te_, dtype=torch.int32, device="cuda"), cnt)
+            owner = torch.repeat_interleave(rows.to(torch.int32) if rows is not None else torch.arange(tb_, te_, dtype=torch.int32, device="cuda"), cnt)
             if topic_ids_dev is not None:              # sharded batch (rgr_batch_set_topic_ids): the column carries the GLOBAL publish index
                 owner = topic_ids_dev[owner.to(torch.int64)]
             structure_ok &= bool((t[:, 0] == owner).all())       # tuple i names the topic whose CSR range holds position i
@@ -296,12 +306,15 @@ def gpu_digests(batch, n_topics, retain, fmt=0, subs_len=0, topic_ids_dev=None, 
             roff = torch.as_tensor(_DevArr(w.d_run_off, (nr + 1,), "<i8"), device="cuda") - int(w.offsets_bias)
             lens = roff[1:] - roff[:-1]
             structure_ok &= int(roff[0]) == 0 and int(roff[-1]) == nh and bool((lens > 0).all())
-            loc = rtp - tb_
+            loc = (inv_dev[rtp] if inv_dev is not None else rtp) - tb_
             if bool(((loc < 0) | (loc >= nt)).any()):
                 structure_ok = False
                 continue
             structure_ok &= bool(((roff[:-1] >= start[loc]) & (roff[1:] <= end[loc])).all())     # a run lies inside its topic's range
-            runs_per_topic[tb_:te_] += torch.bincount(loc, minlength=nt).to(torch.int32)
+            if rows is not None:
+                runs_per_topic[rows] += torch.bincount(loc, minlength=nt).to(torch.int32)
+            else:
+                runs_per_topic[tb_:te_] += torch.bincount(loc, minlength=nt).to(torch.int32)
             idx = torch.repeat_interleave(src - roff[:-1], lens) + torch.arange(nh, dtype=torch.int64, device="cuda")
             hi = int(idx.max()) + 1
             e = torch.as_tensor(_DevArr(w.d_subs, (max(hi, subs_len),), "<i8"), device="cuda")[idx]
@@ -313,7 +326,7 @@ def gpu_digests(batch, n_topics, retain, fmt=0, subs_len=0, topic_ids_dev=None, 
             hi_ = torch.where(end > 0, cs[(end - 1).clamp(min=0)], torch.zeros_like(end))
             lo_ = torch.where(start > 0, cs[(start - 1).clamp(min=0)], torch.zeros_like(start))
             return hi_ - lo_
-        acc = out[tb_:te_]
+        acc = torch.zeros((nt, ncol), dtype=torch.int64, device="cuda") if rows is not None else out[tb_:te_]
         acc[:, 0] = cnt
         if retain:
             acc[:, 1] = seg(sid)
@@ -325,6 +338,8 @@ def gpu_digests(batch, n_topics, retain, fmt=0, subs_len=0, topic_ids_dev=None, 
             acc[:, 2] = seg(torch.arange(1, nh + 1, dtype=torch.int64, device="cuda") * v) - start * s1     # sum (k+1) v_k, k = position in the topic
             acc[:, 3] = seg(v * v)
             del v, s1
+        if rows is not None:
+            out[rows] = acc
         del sid, q, d_off, start, end, cnt
         torch.cuda.synchronize()                    # torch's reads of the window must finish before the library expands the next one into the same buffer
     structure_ok &= expect_begin == n_topics
@@ -667,7 +682,7 @@ def run_pmc_children(args, phases, world=1, rank=0):
             cmd = [rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(work, counter), "-o", "pmc", "--",
                    sys.executable, os.path.abspath(__file__), "--pmc-child", meta, "--pmc-phases", ",".join(phases),
                    "--config", str(args.config), "--scale", str(args.scale), "--pmc-topics", str(args.pmc_topics),
-                   "--pmc-world", str(world), "--pmc-rank", str(rank), "--deliver-format", args.deliver_format]
+                   "--pmc-world", str(world), "--pmc-rank", str(rank), "--deliver-format", args.deliver_format, "--topic-order", args.topic_order]
             if args.window_hits:
                 cmd += ["--window-hits", str(args.window_hits)]
             t = time.time()
@@ -732,6 +747,8 @@ def pmc_child(args):
         n = min(n_mine, args.pmc_topics)
         sb, so = shard.take(tb_r, to_r, np.arange(n)) if n < n_mine else (tb_r, to_r)
         b = r.retain_batch(sb, so) if W["retain"] else r.batch(sb, so)
+        if args.topic_order == "walk" and not W["retain"] and not deliver:
+            b.set_order(True)
         if deliver:
             pa = np.zeros(n, dtype=capi.PUBLISH_ATTR_DTYPE)
             prng = np.random.default_rng(12)
@@ -788,8 +805,12 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
             f"{st0['table_bytes_device'] / 2**30:.2f} GiB in HBM, built in {build_s:.1f}s (rejected {rej})", rank)
     t = time.time()
     batch = r.retain_batch(tb_r, to_r) if retain else r.batch(tb_r, to_r)
+    walk_order = args.topic_order == "walk" and not retain and deliver < 0
+    if walk_order:
+        # the library sorts the batch by its leading tokens and walks it in that order (rgr_batch_set_order): part of preparing the batch, like the tokeniser
+        batch.set_order(True)
     batch_create_s = time.time() - t
-    log(f"config {cfg}: batch: {my_topics} topics tokenised + uploaded in {batch_create_s:.1f}s", rank)
+    log(f"config {cfg}: batch: {my_topics} topics tokenised + uploaded{' + sorted into walk order' if walk_order else ''} in {batch_create_s:.1f}s", rank)
     dfmt = capi.RGR_FORMAT_TUPLE
     if deliver >= 0:
         pa = np.zeros(my_topics, dtype=capi.PUBLISH_ATTR_DTYPE)
@@ -1048,6 +1069,7 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
                                 f"BASELINE.json configs[{cfg - 1}]: {n_sub} subscriptions (p_plus/level {c['p_plus']}, p_hash {c['p_hash']}, "
                                 f"Zipf tokens s=1.1, Zipf clients s=1.0), {n_pub} publish topics, seeds 0x{wl.SUB_SEED + cfg:X}/0x{wl.PUB_SEED + cfg:X}"),
                    "subscriptions": n_sub, "publishes": n_pub, "sharding": f"hash of the first {shard.KEY_LEVELS} levels x{world}" if world > 1 else "none",
+                   "topic_order": "walk order: the library sorts the batch by its leading level tokens (rgr_batch_set_order); tuples name the caller's index" if walk_order else "caller order",
                    "gather": args.gather if world > 1 else "n/a", "collective": collective,
                    "rccl_ranks": comm_info["ranks"] if comm_info and comm_info["transport"] == "rccl" else None,
                    "dist_backend": args.dist_backend if world > 1 else "n/a", "windows_per_step": int(nwin),
@@ -1599,6 +1621,8 @@ def time_format(args):
     v5 = (args.deliver if args.deliver >= 0 else DELIVER_SECONDARY_V5) if deliver else -1.0
     build_table(r, W, W["blob"], W["offs"], np.arange(W["n_sub"], dtype=np.uint32), W["qos"], deliver_frac=v5)
     batch = r.retain_batch(W["tb"], W["to"]) if W["retain"] else r.batch(W["tb"], W["to"])
+    if args.topic_order == "walk" and not W["retain"] and not deliver:
+        batch.set_order(True)
     W["publish_attrs"] = None
     if deliver:
         pa = np.zeros(W["n_pub"], dtype=capi.PUBLISH_ATTR_DTYPE)
@@ -1651,6 +1675,7 @@ def _time_one_format(args, W, r, batch, name, ab_name, ab_values):
         dt = time.time() - t
         st = r.stats()
         rec = {"format": name, "config": args.config, "scale": args.scale, "window_hits": args.window_hits or "default",
+               "topic_order": args.topic_order if (not W["retain"] and not deliver) else "caller",
                "value": round(W["n_pub"] * args.steps / dt, 1), "ms_per_step": round(dt * 1e3 / args.steps, 3), "windows_per_step": int(nwin),
                "hits_per_step": int(hits), "kernel_ms_per_step": {"walk": round(st["walk_ms"] / args.steps, 3), "scan_compact_tiles": round(st["scan_ms"] / args.steps, 3),
                                                                    "expand": round(st["expand_ms"] / args.steps, 3)},
@@ -1879,6 +1904,9 @@ def main():
     ap.add_argument("--deliver", type=float, default=-1.0, metavar="V5FRAC",
                     help="also run the delivery stage (SURVEY 8(f)-1): this fraction of the subscriptions is MQTT v5 "
                          "(No Local / RAP / per-client dedup); 0 = v3 only. Not the headline metric.")
+    ap.add_argument("--topic-order", choices=["walk", "caller"], default="walk",
+                    help="order in which the timed publish batch is walked: `walk` = sorted by the leading level tokens inside the library (rgr_batch_set_order; "
+                         "results per topic are identical, windows enumerate walk positions), `caller` = as handed over (rounds 1-5)")
     ap.add_argument("--deliver-format", choices=["hits8", "tuple12"], default="hits8",
                     help="answer format of the delivery stage's records: 8-byte hits {sub_id, delivery word} (RGR_FORMAT_DELIVER8; the 12-byte form is timed "
                          "beside it) or 12-byte tuples only")

@@ -220,6 +220,9 @@ typedef struct rgr_window {
     const uint64_t* d_subs;           /* the epoch's subscriber entries, 8 bytes each    */
     const uint8_t* d_ids24;           /* [3 * n_hits] RGR_FORMAT_IDS24: sub ids as 3 little-endian bytes each; NULL otherwise */
     const rgr_hit8* d_hits8;          /* [n_hits] RGR_FORMAT_DELIVER8 (delivery passes): {sub_id, delivery word}; NULL otherwise */
+    const uint32_t* d_topic_order;    /* batches in walk order (rgr_batch_set_order): [topic_end - topic_begin] the BATCH index of the window's k-th
+                                         topic — topic_begin / topic_end then count walk positions, d_hit_offsets[k] belongs to batch topic
+                                         d_topic_order[k]; tuples name the batch index as ever.  NULL: k-th topic = topic_begin + k */
 } rgr_window;
 
 /* Result format of a device-resident batch.  The 12-byte tuple is BASELINE.json's (topic_idx, subscriber_id,
@@ -373,6 +376,15 @@ int32_t rgr_batch_set_publish_attrs(rgr_batch* b, const rgr_publish_attr* attrs)
  * Costs nothing per hit (the id is attached per (topic, filter) pair at compaction).  RGR_ESTATE inside a pass
  * or together with publish attributes. */
 int32_t rgr_batch_set_topic_ids(rgr_batch* b, const uint32_t* ids);
+/* Order in which later passes walk the batch's topics.  RGR_ORDER_WALK: the library sorts the topics by their leading level tokens (two device
+ * radix sorts per batch, repeated when a grown dictionary re-tokenises it): neighbouring lanes of the walk then share their upper trie levels
+ * and hot subscriber runs (walk -16..-24 %, profiles/r06g_*).  Nothing changes per topic — same hits, same order inside a topic, rgr_tuple.topic_idx
+ * still the batch index (or rgr_batch_set_topic_ids' id) — but windows enumerate topics in walk order: see rgr_window.d_topic_order;
+ * rgr_batch_topic_order returns the whole permutation ([n], host pointer valid until the next rgr_batch_set_order / rgr_batch_begin / destroy;
+ * NULL in caller order).  Device-resident publish batches without publish attributes only (RGR_ESTATE otherwise, or inside a pass). */
+enum { RGR_ORDER_CALLER = 0, RGR_ORDER_WALK = 1 };
+int32_t rgr_batch_set_order(rgr_batch* b, uint32_t order);
+const uint32_t* rgr_batch_topic_order(const rgr_batch* b);
 /* Choose the result format of later passes (RGR_FORMAT_*).  RGR_ESTATE inside a pass; with publish attributes attached only
  * RGR_FORMAT_TUPLE and RGR_FORMAT_DELIVER8 carry the delivery word (RGR_FORMAT_DELIVER8 without them is RGR_ESTATE as well;
  * detaching the attributes returns such a batch to RGR_FORMAT_TUPLE). */

@@ -21,7 +21,7 @@ GPU_LIB = os.path.join(HERE, "librmqtt_gpu_router.so")
 WL_LIB = os.path.join(HERE, "librmqtt_workload.so")
 HOST_LIB = os.path.join(HERE, "librmqtt_host_router.so")
 
-GPU_SRCS = ["c_abi.cpp", "table.cpp", "retain.cpp", "kernels.hip"]
+GPU_SRCS = ["c_abi.cpp", "table.cpp", "retain.cpp", "kernels.hip", "order.hip"]
 GPU_HDRS = ["table.hpp", "topic.hpp", "device.hpp", "kernels.hpp", "retain.hpp", "retain_abi.inc", "group_abi.inc", "match_core.hpp", "expand_compact.inc", "dedup.inc", "expand_tuple.inc", "prep_batched.inc"]
 
 

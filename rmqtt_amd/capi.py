@@ -32,7 +32,7 @@ SYMBOLS = [
     "rgr_sub_remove", "rgr_subscribe_bulk", "rgr_snapshot_save", "rgr_snapshot_load", "rgr_commit",
     "rgr_match_batch", "rgr_match_batch_deliver", "rgr_match_batch_deliver_grouped", "rgr_group_match_batch_deliver_grouped", "rgr_result_free", "rgr_match_filters", "rgr_match_filter_subs", "rgr_filters_result_free",
     "rgr_batch_create", "rgr_batch_create_from_publish", "rgr_batch_publish_info", "rgr_batch_destroy", "rgr_batch_status", "rgr_batch_set_publish_attrs",
-    "rgr_batch_set_format", "rgr_batch_set_topic_ids", "rgr_batch_set_retain_positions", "rgr_batch_retain_vals", "rgr_batch_begin", "rgr_batch_next_window",
+    "rgr_batch_set_format", "rgr_batch_set_topic_ids", "rgr_batch_set_retain_positions", "rgr_batch_retain_vals", "rgr_batch_set_order", "rgr_batch_topic_order", "rgr_batch_begin", "rgr_batch_next_window",
     "rgr_window_to_host", "rgr_batch_run", "rgr_batch_run_to_host",
     "rgr_retain_topic_add", "rgr_retain_topic_remove", "rgr_retain_add_bulk", "rgr_retain_commit",
     "rgr_retain_match_batch", "rgr_retain_result_free", "rgr_retain_match_ranges", "rgr_retain_ranges_free", "rgr_retain_batch_create", "rgr_retain_batch_create_tier",
@@ -87,6 +87,7 @@ class RetainRanges(C.Structure):      # == rgr_retain_ranges
 RANGE_DTYPE = np.dtype([("begin", np.uint32), ("len", np.uint32)])               # == rgr_id_range
 RETAIN_VAL_DTYPE = np.dtype([("topic_id", np.uint32), ("flags", np.uint32)])     # == rgr_retain_val
 RGR_RETAIN_HIT_DEAD = 1
+RGR_ORDER_CALLER, RGR_ORDER_WALK = 0, 1
 
 
 class Window(C.Structure):
@@ -94,7 +95,7 @@ class Window(C.Structure):
                 ("hit_base", C.c_uint64), ("d_tuples", C.c_void_p), ("d_hit_offsets", C.c_void_p),
                 ("offsets_bias", C.c_uint64), ("d_sub_ids", C.c_void_p), ("d_qos", C.c_void_p),
                 ("n_runs", C.c_uint64), ("d_run_src", C.c_void_p), ("d_run_topic", C.c_void_p), ("d_run_off", C.c_void_p), ("d_subs", C.c_void_p),
-                ("d_ids24", C.c_void_p), ("d_hits8", C.c_void_p)]
+                ("d_ids24", C.c_void_p), ("d_hits8", C.c_void_p), ("d_topic_order", C.c_void_p)]
 
 
 class Stats(C.Structure):
@@ -158,6 +159,8 @@ def lib():
         L.rgr_batch_begin.argtypes = [vp]
         L.rgr_batch_set_format.argtypes = [vp, u32]
         L.rgr_batch_set_topic_ids.argtypes = [vp, vp]
+        L.rgr_batch_set_order.argtypes = [vp, u32]
+        L.rgr_batch_topic_order.argtypes = [vp]; L.rgr_batch_topic_order.restype = vp
         L.rgr_batch_set_retain_positions.argtypes = [vp, C.c_int32]
         L.rgr_batch_retain_vals.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
         L.rgr_batch_next_window.argtypes = [vp, C.POINTER(Window)]
@@ -527,6 +530,15 @@ class Batch:
         """RGR_FORMAT_TUPLE (12 B/hit) | RGR_FORMAT_SOA (sub ids + qos bytes, 5 B/hit) | RGR_FORMAT_PACKED (4 B/hit) | RGR_FORMAT_RUNS |
         RGR_FORMAT_IDS24 (3-byte sub ids, 3 B/hit) | RGR_FORMAT_DELIVER8 (delivery passes: {sub_id, delivery word}, 8 B/hit)."""
         _check(lib().rgr_batch_set_format(self._b, fmt))
+
+    def set_order(self, walk=True):
+        """RGR_ORDER_WALK: later passes walk the topics sorted by their leading tokens (windows then enumerate walk positions: Window.d_topic_order)."""
+        _check(lib().rgr_batch_set_order(self._b, RGR_ORDER_WALK if walk else RGR_ORDER_CALLER))
+
+    def topic_order(self):
+        """The permutation of a batch in walk order: order[k] = batch index of the topic walked k-th; None in caller order."""
+        p = lib().rgr_batch_topic_order(self._b)
+        return _copy(p, self.n, np.uint32) if p else None
 
     def set_retain_positions(self, on=True):
         """Retain batches: tuples carry positions in the epoch's preorder value array instead of topic ids (see retain_vals)."""

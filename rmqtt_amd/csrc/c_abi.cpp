@@ -172,6 +172,11 @@ struct rgr_batch {
     std::vector<int32_t> status;
     uint64_t total_tokens = 0, valid_levels = 0, valid_topics = 0;
     DevBuf d_tokens, d_tok_off, d_tflags, d_path;
+    // rgr_batch_set_order(RGR_ORDER_WALK): the token arrays once more, gathered into walk order (sorted by the leading tokens, order.hip); d_order[k] = batch
+    // index of the topic walked k-th.  The tokeniser keeps writing the caller-order arrays; apply_order() follows every (re)tokenisation.
+    bool ordered = false;
+    DevBuf s_tokens, s_tok_off, s_tflags, d_order, d_order_ids, order_tmp[4];
+    std::vector<uint32_t> h_order;
     DevBuf d_blob, d_offs, d_level_cnt;   // raw topics (device tokeniser)
     // rgr_batch_create_from_publish: raw PUBLISH packets, what the scan extracted, which packets the codec rejects
     bool from_publish = false;
@@ -424,12 +429,43 @@ void tokenize_batch_device(rgr_batch* b, const DictImage& dict) {
     b->local.tokenize_ms += now_ms() - t0;
 }
 
+// Walk order (rgr_batch_set_order): sort the batch's topics by their leading tokens and gather the token arrays into that order.  Runs after every
+// (re)tokenisation of an ordered batch; the stream is synchronised on return (the permutation is mirrored on the host for rgr_batch_topic_order).
+void apply_order(rgr_batch* b) {
+    const uint32_t n = b->n;
+    b->h_order.assign(n, 0);
+    if (!n) return;
+    const size_t temp_bytes = order_sort_temp_bytes(n);
+    b->order_tmp[0].ensure(size_t(n) * 8); b->order_tmp[1].ensure(size_t(n) * 8); b->order_tmp[2].ensure(size_t(n) * 4); b->order_tmp[3].ensure(std::max<size_t>(16, temp_bytes));
+    b->d_order.ensure(size_t(n) * 4);
+    if (launch_order_sort(b->d_tokens.as<uint32_t>(), b->d_tok_off.as<uint64_t>(), b->d_tflags.as<uint8_t>(), n, b->order_tmp[0].as<unsigned long long>(),
+                          b->order_tmp[1].as<unsigned long long>(), b->order_tmp[2].as<uint32_t>(), b->d_order.as<uint32_t>(), b->order_tmp[3].p, temp_bytes, b->stream) != 0)
+        throw std::runtime_error("rgr_batch_set_order: the radix sort failed");
+    // lengths in walk order -> offsets -> tokens / flags
+    b->s_tok_off.ensure((size_t(n) + 1) * 8);
+    b->s_tflags.ensure(n);
+    b->s_tokens.ensure(std::max<uint64_t>(1, b->total_tokens) * 4);
+    b->scan_tmp.ensure((size_t(n) / scan_block_topics() + 3) * 16);
+    uint32_t* len = b->order_tmp[2].as<uint32_t>();                      // (the sort is done with its index scratch)
+    launch_order_len(b->d_order.as<uint32_t>(), b->d_tok_off.as<uint64_t>(), n, len, b->stream);
+    launch_scan_u32(len, b->s_tok_off.as<uint64_t>(), n, b->scan_tmp.as<uint64_t>(), b->stream);
+    launch_order_gather(b->d_order.as<uint32_t>(), n, b->d_tok_off.as<uint64_t>(), b->d_tokens.as<uint32_t>(), b->d_tflags.as<uint8_t>(), b->s_tok_off.as<uint64_t>(),
+                        b->s_tokens.as<uint32_t>(), b->s_tflags.as<uint8_t>(), b->stream);
+    if (b->has_topic_ids) {
+        b->d_order_ids.ensure(size_t(n) * 4);
+        launch_order_compose(b->d_order.as<uint32_t>(), b->d_topic_ids.as<uint32_t>(), n, b->d_order_ids.as<uint32_t>(), b->stream);
+    }
+    RGR_HIP(hipMemcpyAsync(b->h_order.data(), b->d_order.p, size_t(n) * 4, hipMemcpyDeviceToHost, b->stream));
+    RGR_HIP(hipStreamSynchronize(b->stream));
+    RGR_HIP(hipGetLastError());
+}
+
 WalkArgs make_walk_args(rgr_batch* b, uint32_t n) {
     WalkArgs a{};
     Scalars* sc = b->c->scalars.as<Scalars>();
-    a.tokens = b->d_tokens.as<uint32_t>();
-    a.tok_off = b->d_tok_off.as<uint64_t>();
-    a.tflags = b->d_tflags.as<uint8_t>();
+    a.tokens = (b->ordered ? b->s_tokens : b->d_tokens).as<uint32_t>();
+    a.tok_off = (b->ordered ? b->s_tok_off : b->d_tok_off).as<uint64_t>();
+    a.tflags = (b->ordered ? b->s_tflags : b->d_tflags).as<uint8_t>();
     a.topic_base = b->c->begin;
     a.n = n;
     a.slot_cap = b->retain ? 0 : b->h->cfg.slot_cap;
@@ -467,6 +503,7 @@ ChunkArrays make_chunk_arrays(rgr_batch* b, uint32_t n) {
     c.pair_topic = b->c->pair_topic.as<uint32_t>();
     c.pair_off = b->c->pair_off.as<uint64_t>();
     if (b->deliver && !b->retain) { c.pub = b->d_pub.as<PublishAttr>(); c.pair_qr = b->c->pair_qr.as<uint8_t>(); }
+    else if (b->ordered) c.topic_ids = (b->has_topic_ids ? b->d_order_ids : b->d_order).as<uint32_t>();      // walk position -> the caller's index (or the caller's id of it)
     else if (b->has_topic_ids) c.topic_ids = b->d_topic_ids.as<uint32_t>();
     return c;
 }
@@ -1082,6 +1119,8 @@ static int32_t batch_create_impl(rgr_handle* h, const uint8_t* blob, const uint6
         b->retain = retain;
         b->tier = retain ? tier : 0;
         b->deliver = false;
+        b->ordered = false;
+        b->retain_positions = false;
         b->format = kFmtTuple;
         b->has_topic_ids = false;
         b->from_publish = false;
@@ -1234,6 +1273,7 @@ int32_t rgr_batch_set_publish_attrs(rgr_batch* b, const rgr_publish_attr* attrs)
         if (!attrs) { b->deliver = false; if (b->format == kFmtDeliver8) b->format = kFmtTuple; return RGR_OK; }
         if (b->format != kFmtTuple && b->format != kFmtDeliver8) return fail(RGR_ESTATE, "rgr_batch_set_publish_attrs: the delivery stage needs RGR_FORMAT_TUPLE or RGR_FORMAT_DELIVER8");
         if (b->has_topic_ids) return fail(RGR_ESTATE, "rgr_batch_set_publish_attrs: not together with rgr_batch_set_topic_ids");
+        if (b->ordered) return fail(RGR_ESTATE, "rgr_batch_set_publish_attrs: not on a batch in walk order (rgr_batch_set_order)");
         RGR_HIP(hipSetDevice(b->h->cfg.device));
         static_assert(sizeof(rgr_publish_attr) == sizeof(PublishAttr), "rgr_publish_attr layout");
         b->d_pub.ensure(std::max<size_t>(1, b->n) * sizeof(PublishAttr));
@@ -1243,6 +1283,24 @@ int32_t rgr_batch_set_publish_attrs(rgr_batch* b, const rgr_publish_attr* attrs)
         return RGR_OK;
     });
 }
+
+int32_t rgr_batch_set_order(rgr_batch* b, uint32_t order) {
+    return guarded([&]() -> int32_t {
+        if (!b || order > RGR_ORDER_WALK) return fail(RGR_EINVAL, "rgr_batch_set_order: bad argument");
+        if (b->in_pass) return fail(RGR_ESTATE, "rgr_batch_set_order: inside a pass");
+        if (order == RGR_ORDER_CALLER) { b->ordered = false; return RGR_OK; }
+        if (b->retain) return fail(RGR_ESTATE, "rgr_batch_set_order: not a publish batch");
+        if (b->deliver) return fail(RGR_ESTATE, "rgr_batch_set_order: not together with publish attributes (the delivery stage indexes them by batch position)");
+        RGR_HIP(hipSetDevice(b->h->cfg.device));
+        b->ordered = true;
+        struct Undo { rgr_batch* b; bool armed = true; ~Undo() { if (armed) b->ordered = false; } } undo{b};
+        apply_order(b);
+        undo.armed = false;
+        return RGR_OK;
+    });
+}
+
+const uint32_t* rgr_batch_topic_order(const rgr_batch* b) { return (b && b->ordered) ? b->h_order.data() : nullptr; }
 
 int32_t rgr_batch_set_retain_positions(rgr_batch* b, int32_t on) {
     if (!b) return fail(RGR_EINVAL, "rgr_batch_set_retain_positions: bad argument");
@@ -1273,8 +1331,12 @@ int32_t rgr_batch_set_topic_ids(rgr_batch* b, const uint32_t* ids) {
         RGR_HIP(hipSetDevice(b->h->cfg.device));
         b->d_topic_ids.ensure(std::max<size_t>(1, b->n) * 4);
         if (b->n) RGR_HIP(hipMemcpyAsync(b->d_topic_ids.p, ids, size_t(b->n) * 4, hipMemcpyHostToDevice, b->stream));
-        RGR_HIP(hipStreamSynchronize(b->stream));
         b->has_topic_ids = true;
+        if (b->ordered && b->n) {
+            b->d_order_ids.ensure(size_t(b->n) * 4);
+            launch_order_compose(b->d_order.as<uint32_t>(), b->d_topic_ids.as<uint32_t>(), b->n, b->d_order_ids.as<uint32_t>(), b->stream);
+        }
+        RGR_HIP(hipStreamSynchronize(b->stream));
         return RGR_OK;
     });
 }
@@ -1307,6 +1369,7 @@ int32_t rgr_batch_begin(rgr_batch* b) {
         if (want != b->dict_tokens) {      // the dictionary grew since this batch was tokenised
             if (b->host_tok) tokenize_batch(b->h, b, b->h_blob.data(), b->h_offs.data(), b->n);
             else tokenize_batch_device(b, b->retain ? b->repoch->dict : *b->epoch->dict);
+            if (b->ordered) apply_order(b);                  // (new token ids: a new order)
         }
         if (b->format == kFmtPacked && (b->retain ? b->repoch->max_id : b->epoch->max_sub_id) >= (1u << 30))
             return fail(RGR_ECAPACITY, "rgr_batch_begin: RGR_FORMAT_PACKED needs ids below 2^30");
@@ -1530,6 +1593,7 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
             w->d_qos = b->format == kFmtSoa && nh ? static_cast<const uint8_t*>(op) + ids_bytes : nullptr;
             w->d_ids24 = b->format == kFmtIds24 && nh ? static_cast<const uint8_t*>(op) : nullptr;
             w->d_hits8 = b->format == kFmtDeliver8 && nh ? static_cast<const rgr_hit8*>(op) : nullptr;
+            w->d_topic_order = b->ordered ? b->d_order.as<uint32_t>() + b->cursor : nullptr;
         }
         w->d_hit_offsets = b->c->hit_off.as<uint64_t>() + lc;
         w->offsets_bias = hit_lo;

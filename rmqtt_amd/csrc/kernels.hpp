@@ -295,6 +295,14 @@ void launch_node_groups(const Tuple* tuples, const uint64_t* hit_off, uint64_t h
 // run descriptors of a window packed for the exchange step (== rgr_run)
 struct RunDesc { uint32_t shard, src, len, topic; };
 void launch_pack_runs(const uint32_t* src, const uint32_t* topic, const uint64_t* off, uint64_t n, uint32_t shard, RunDesc* out, void* stream);
+// walk order of a publish batch (order.hip): sort by the first two level tokens, gather the token arrays into that order
+size_t order_sort_temp_bytes(uint32_t n);
+int launch_order_sort(const uint32_t* tokens, const uint64_t* tok_off, const uint8_t* tflags, uint32_t n, unsigned long long* keys, unsigned long long* keys_tmp,
+                      uint32_t* idx_tmp, uint32_t* perm, void* temp, size_t temp_bytes, void* stream);
+void launch_order_len(const uint32_t* perm, const uint64_t* tok_off, uint32_t n, uint32_t* len, void* stream);
+void launch_order_gather(const uint32_t* perm, uint32_t n, const uint64_t* off_old, const uint32_t* tok_old, const uint8_t* fl_old, const uint64_t* off_new, uint32_t* tok_new,
+                         uint8_t* fl_new, void* stream);
+void launch_order_compose(const uint32_t* perm, const uint32_t* ids, uint32_t n, uint32_t* out, void* stream);
 uint32_t expand_tile_hits();
 const char* expand_ids24_kernel_name();      // ... 3-byte-id windows by default (RGR_COMPACT_LP overrides per launch)
 const char* expand_tuple_kernel_name();      // which kernel expands plain 12-byte tuple windows (profilers see this name)

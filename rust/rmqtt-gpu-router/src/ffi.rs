@@ -121,6 +121,8 @@ pub const RGR_FORMAT_PACKED: u32 = 2;
 pub const RGR_FORMAT_RUNS: u32 = 3;
 pub const RGR_FORMAT_IDS24: u32 = 4;
 pub const RGR_FORMAT_DELIVER8: u32 = 5;
+pub const RGR_ORDER_CALLER: u32 = 0;
+pub const RGR_ORDER_WALK: u32 = 1;
 pub const RGR_TOPIC_INVALID: i32 = -2;
 pub const RGR_PACKET_MALFORMED: i32 = -8;
 pub const RGR_COMM_ID_BYTES: usize = 128;
@@ -143,6 +145,7 @@ pub struct rgr_window {
     pub d_subs: *const u64,
     pub d_ids24: *const u8,
     pub d_hits8: *const rgr_hit8,
+    pub d_topic_order: *const u32,
 }
 
 /// One hit of a delivery pass in RGR_FORMAT_DELIVER8: relation + delivery word (the topic is implied by the CSR offsets).
@@ -177,6 +180,8 @@ extern "C" {
     pub fn rgr_batch_set_publish_attrs(b: *mut rgr_batch, attrs: *const rgr_publish_attr) -> i32;
     pub fn rgr_batch_set_topic_ids(b: *mut rgr_batch, ids: *const u32) -> i32;
     pub fn rgr_batch_set_format(b: *mut rgr_batch, format: u32) -> i32;
+    pub fn rgr_batch_set_order(b: *mut rgr_batch, order: u32) -> i32;
+    pub fn rgr_batch_topic_order(b: *const rgr_batch) -> *const u32;
     pub fn rgr_batch_set_retain_positions(b: *mut rgr_batch, on: i32) -> i32;
     pub fn rgr_batch_retain_vals(b: *const rgr_batch, vals: *mut *const rgr_retain_val, n: *mut u64) -> i32;
     pub fn rgr_batch_begin(b: *mut rgr_batch) -> i32;

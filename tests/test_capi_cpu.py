@@ -53,7 +53,7 @@ def test_struct_layouts_match_header(tmp_path):
     sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     assert sizes == [C.sizeof(capi.Config), capi.TUPLE_DTYPE.itemsize, C.sizeof(capi.Window), C.sizeof(capi.Stats), C.sizeof(capi.Result),
                      C.sizeof(capi.FiltersResult), C.sizeof(capi.RetainResult), capi.PUBLISH_ATTR_DTYPE.itemsize]
-    assert sizes[:3] == [40, 12, 120]          # rgr_window grew by d_hits8 (RGR_FORMAT_DELIVER8, r6)
+    assert sizes[:3] == [40, 12, 128]          # rgr_window grew by d_hits8 (RGR_FORMAT_DELIVER8) and d_topic_order (rgr_batch_set_order), r6
 
 
 @pytest.mark.skipif(has_gpu(), reason="a GPU is present")

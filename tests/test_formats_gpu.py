@@ -315,3 +315,84 @@ def test_lane_held_expansion_equals_tile_kernel(window_hits, monkeypatch):
         assert np.array_equal(a, t["sub_id"]), "RGR_TILES_FUSED"
     monkeypatch.delenv("RGR_TILES_FUSED")
     batch.close(); r.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("window_hits", [0, 40_000])
+def test_walk_order_changes_nothing_per_topic(window_hits):
+    """rgr_batch_set_order(RGR_ORDER_WALK) (r6): the library sorts the batch's topics by their leading tokens and walks them in that order.  Per
+    topic nothing changes — the same tuples in the same order, naming the topic's BATCH index — but windows enumerate walk positions:
+    d_topic_order says which batch topic the k-th offset belongs to, rgr_batch_topic_order returns the permutation (a bijection, sorted by the
+    first four tokens).  Every format, caller topic ids composed with the order, and back to caller order."""
+    rng = np.random.default_rng(17)
+    c = wl.CONFIGS[3]
+    blob, offs, _, qos = wl.gen_subs(60_000, wl.SUB_SEED + 3, c["p_plus"], c["p_hash"], c["p_sys"])
+    tb, to = wl.gen_topics(9_000, wl.PUB_SEED + 3, 0.01, c["p_blank"])
+    r = capi.Router(device=0, window_hits=window_hits, chunk_topics=2_000)
+    assert r.subscribe_bulk(blob, offs, None, qos) == 0
+    r.commit()
+    b = r.batch(tb, to)
+    n = len(to) - 1
+
+    def per_topic(fmt, ids=None):
+        """{batch topic (or its caller id): payload of its hits} from every window of one pass"""
+        out = {}
+        b.set_format(fmt)
+        b.begin()
+        pos = 0
+        while True:
+            w = b.next_window()
+            if w is None:
+                break
+            nt = w.topic_end - w.topic_begin
+            assert w.topic_begin == pos
+            pos = w.topic_end
+            offs_ = np.zeros(nt + 1, dtype=np.uint64)
+            assert capi.lib().rgr_window_to_host(b._b, C.byref(w), None, offs_.ctypes.data) == 0
+            order = capi.device_to_host(w.d_topic_order, nt * 4).view(np.uint32) if w.d_topic_order else np.arange(w.topic_begin, w.topic_end, dtype=np.uint32)
+            nh = int(w.n_hits)
+            if fmt == capi.RGR_FORMAT_TUPLE:
+                t = capi.device_to_host(w.d_tuples, nh * 12).view(capi.TUPLE_DTYPE)
+            elif fmt == capi.RGR_FORMAT_PACKED:
+                t = capi.device_to_host(w.d_sub_ids, nh * 4).view(np.uint32)
+            else:
+                t = capi.device_to_host(w.d_ids24, nh * 3).reshape(-1, 3)
+            for k in range(nt):
+                a, e = int(offs_[k]), int(offs_[k + 1])
+                if fmt == capi.RGR_FORMAT_TUPLE and e > a:
+                    want = int(order[k]) if ids is None else int(ids[order[k]])
+                    assert (t["topic_idx"][a:e] == want).all()
+                out[int(order[k])] = t[a:e].copy()
+        assert pos == n
+        return out
+
+    ref = {f: per_topic(f) for f in (capi.RGR_FORMAT_TUPLE, capi.RGR_FORMAT_PACKED, capi.RGR_FORMAT_IDS24)}
+    assert b.topic_order() is None
+    b.set_order(True)
+    perm = b.topic_order()
+    assert sorted(perm.tolist()) == list(range(n))
+    strings = wl.strings(tb, to)
+    st = b.status()
+    lead = [tuple(strings[i].split("/")[:4]) for i in perm if st[i] == 0]
+    groups = [lead[0]] + [x for p_, x in zip(lead, lead[1:]) if x != p_]
+    assert len(groups) == len(set(groups)), "topics with the same four leading levels are contiguous in walk order"
+    for f in ref:
+        got = per_topic(f)
+        assert got.keys() == ref[f].keys()
+        for k in got:
+            assert np.array_equal(got[k], ref[f][k]), (f, k)
+    ids = rng.permutation(n).astype(np.uint32) + 1000
+    b.set_topic_ids(ids)
+    got = per_topic(capi.RGR_FORMAT_TUPLE, ids)
+    for k in got:
+        assert np.array_equal(got[k]["sub_id"], ref[capi.RGR_FORMAT_TUPLE][k]["sub_id"])
+    b.set_topic_ids(None)
+    b.set_order(False)
+    back = per_topic(capi.RGR_FORMAT_TUPLE)
+    for k in back:
+        assert np.array_equal(back[k], ref[capi.RGR_FORMAT_TUPLE][k])
+    attrs = np.zeros(n, dtype=capi.PUBLISH_ATTR_DTYPE)
+    b.set_order(True)
+    with pytest.raises(capi.RgrError):
+        b.set_publish_attrs(attrs)                  # the delivery stage indexes its attributes by batch position
+    b.close(); r.close()
