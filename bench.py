@@ -357,7 +357,10 @@ def _delivery_window_columns(w, fmt):
     if fmt == capi.RGR_FORMAT_DELIVER8:
         t = torch.as_tensor(_DevArr(w.d_hits8, (nh, 2), "<i4"), device="cuda")
         d_off = torch.as_tensor(_DevArr(w.d_hit_offsets, (te_ - tb_ + 1,), "<i8"), device="cuda") - int(w.offsets_bias)
-        topic = torch.repeat_interleave(torch.arange(tb_, te_, dtype=torch.int64, device="cuda"), d_off[1:] - d_off[:-1])
+        # (a batch in walk order: the window's k-th topic is batch topic d_topic_order[k])
+        tids = (torch.as_tensor(_DevArr(w.d_topic_order, (te_ - tb_,), "<i4"), device="cuda").to(torch.int64) if w.d_topic_order
+                else torch.arange(tb_, te_, dtype=torch.int64, device="cuda"))
+        topic = torch.repeat_interleave(tids, d_off[1:] - d_off[:-1])
         return topic, t[:, 0].to(torch.int64) & 0xFFFFFFFF, t[:, 1].to(torch.int64) & 0xFFFFFFFF
     t = torch.as_tensor(_DevArr(w.d_tuples, (nh, 3), "<i4"), device="cuda")
     return t[:, 0].to(torch.int64) & 0xFFFFFFFF, t[:, 1].to(torch.int64) & 0xFFFFFFFF, t[:, 2].to(torch.int64) & 0xFFFFFFFF
@@ -407,7 +410,7 @@ def delivery_parity(batch, W, pa, n_windows_wanted=3, fmt=0):
         drop = is5 & ((fl & capi.RGR_SUB_NO_LOCAL) != 0) & (client[sid] == p_from[topic])
         exp = exp | torch.where(drop, capi.RGR_HIT_NO_LOCAL, 0)
         cand = torch.nonzero(is5 & ~drop).squeeze(1)
-        key = (topic[cand] - int(w.topic_begin)) * (int(client.max()) + 1) + client[sid[cand]]
+        key = topic[cand] * (int(client.max()) + 1) + client[sid[cand]]
         uk, inv = torch.unique(key, return_inverse=True)
         first = torch.full((uk.numel(),), nh, dtype=torch.int64, device="cuda").scatter_reduce(0, inv, cand, reduce="amin")
         dup = first[inv] != cand
@@ -569,12 +572,15 @@ def delivery_oracle_sample(o, W, batch, pa, threads, seed=20260923, fmt=0):
             hi_ = torch.where(end > 0, cs[(end - 1).clamp(min=0)], torch.zeros_like(end))
             lo_ = torch.where(start > 0, cs[(start - 1).clamp(min=0)], torch.zeros_like(start))
             return hi_ - lo_
-        acc = D[tb_:te_]
+        rows = torch.as_tensor(_DevArr(w.d_topic_order, (te_ - tb_,), "<i4"), device="cuda").to(torch.int64) if w.d_topic_order else None
+        acc = torch.zeros((te_ - tb_, 4), dtype=torch.int64, device="cuda") if rows is not None else D[tb_:te_]
         acc[:, 0] = end - start
         s1 = seg(x)
         acc[:, 1] = s1
         acc[:, 2] = seg(torch.arange(1, nh + 1, dtype=torch.int64, device="cuda") * x) - start * s1
         acc[:, 3] = seg(x * x)
+        if rows is not None:
+            D[rows] = acc
         del t, x, s1, d_off, start, end
         torch.cuda.synchronize()
     gpu_s = time.time() - t0
@@ -747,7 +753,7 @@ def pmc_child(args):
         n = min(n_mine, args.pmc_topics)
         sb, so = shard.take(tb_r, to_r, np.arange(n)) if n < n_mine else (tb_r, to_r)
         b = r.retain_batch(sb, so) if W["retain"] else r.batch(sb, so)
-        if args.topic_order == "walk" and not W["retain"] and not deliver:
+        if args.topic_order == "walk" and not W["retain"] and (not deliver or args.deliver_format == "hits8"):
             b.set_order(True)
         if deliver:
             pa = np.zeros(n, dtype=capi.PUBLISH_ATTR_DTYPE)
@@ -805,7 +811,7 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
             f"{st0['table_bytes_device'] / 2**30:.2f} GiB in HBM, built in {build_s:.1f}s (rejected {rej})", rank)
     t = time.time()
     batch = r.retain_batch(tb_r, to_r) if retain else r.batch(tb_r, to_r)
-    walk_order = args.topic_order == "walk" and not retain and deliver < 0
+    walk_order = args.topic_order == "walk" and not retain and (deliver < 0 or args.deliver_format == "hits8")
     if walk_order:
         # the library sorts the batch by its leading tokens and walks it in that order (rgr_batch_set_order): part of preparing the batch, like the tokeniser
         batch.set_order(True)
@@ -1124,7 +1130,9 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
                                  "frac_of_hbm_peak_stores_kernel": round(total_hits * K * bph / max(1e-9, st["expand_ms"] / 1e3) / 8.0e12, 3)}
         roofline["bytes_written_per_hit"] = bph
         if dfmt == capi.RGR_FORMAT_DELIVER8:
-            # the same batch, same table, in the 12-byte tuple form (what rounds 2-5 reported as the delivery record)
+            # the same batch, same table, in the 12-byte tuple form and in the caller's topic order (what rounds 2-5 reported as the delivery record)
+            if walk_order:
+                batch.set_order(False)
             batch.set_format(capi.RGR_FORMAT_TUPLE)
             batch.run()
             r.stats_reset()
@@ -1137,16 +1145,22 @@ def measure(args, cfg, scale, steps, warmup, primary, rank=0, world=1, local_ran
             rec["delivery_stage"]["tuple12"] = {"value": round(my_topics * steps / dt, 1), "unit": rec["unit"], "ms_per_step": round(dt * 1e3 / steps, 3),
                                                 "expand_avg_launch_ms": round(s12["expand_ms"] / max(1, s12["expand_launches"]), 4),
                                                 "dedup_ms_per_step": round(s12["dedup_ms"] / steps, 3),
-                                                "expand_store_GBps": round(total_hits * steps * 12 / max(1e-9, s12["expand_ms"] / 1e3) / 1e9, 1)}
+                                                "expand_store_GBps": round(total_hits * steps * 12 / max(1e-9, s12["expand_ms"] / 1e3) / 1e9, 1), "topic_order": "caller"}
             batch.set_format(dfmt)
+            if walk_order:
+                batch.set_order(True)
         if not args.no_parity:
             rec["parity_sample"] = delivery_parity(batch, W, pa, fmt=dfmt)
             log(f"config {cfg}: delivery parity {rec['parity_sample']}", 0)
             if dfmt == capi.RGR_FORMAT_DELIVER8:
+                if walk_order:
+                    batch.set_order(False)
                 p12 = delivery_parity(batch, W, pa, fmt=capi.RGR_FORMAT_TUPLE)
                 rec["parity_sample"]["tuple12"] = _pick(p12, ["ok", "windows_checked", "of_windows", "hits", "mismatching_words"])
                 rec["parity_sample"]["ok"] = bool(rec["parity_sample"]["ok"] and p12["ok"])
                 batch.set_format(dfmt)
+                if walk_order:
+                    batch.set_order(True)
         if args.cpu_sample != 0 and world == 1:
             # the oracle's side of the delivery record: its own delivery verdicts for a stratified sample of publishes (digests of the
             # per-hit words in canonical order, DefaultRouter::deliver_digest) against the device's, and the reference-shaped
@@ -1621,8 +1635,6 @@ def time_format(args):
     v5 = (args.deliver if args.deliver >= 0 else DELIVER_SECONDARY_V5) if deliver else -1.0
     build_table(r, W, W["blob"], W["offs"], np.arange(W["n_sub"], dtype=np.uint32), W["qos"], deliver_frac=v5)
     batch = r.retain_batch(W["tb"], W["to"]) if W["retain"] else r.batch(W["tb"], W["to"])
-    if args.topic_order == "walk" and not W["retain"] and not deliver:
-        batch.set_order(True)
     W["publish_attrs"] = None
     if deliver:
         pa = np.zeros(W["n_pub"], dtype=capi.PUBLISH_ATTR_DTYPE)
@@ -1658,7 +1670,12 @@ def _time_one_format(args, W, r, batch, name, ab_name, ab_values):
     deliver = name in ("deliver", "deliver8")
     positions = name == "positions"                    # retained path: tuples with positions of the preorder value array (rgr_batch_set_retain_positions)
     fmt = capi.RGR_FORMAT_DELIVER8 if name == "deliver8" else capi.RGR_FORMAT_TUPLE if (deliver or positions) else FORMAT_NAMES.index(name)
+    want_order = args.topic_order == "walk" and not W["retain"] and name != "deliver"          # (12-byte delivery tuples: caller order only)
+    if not W["retain"] and not want_order:
+        batch.set_order(False)
     batch.set_format(fmt)
+    if want_order:
+        batch.set_order(True)
     if W["retain"]:
         batch.set_retain_positions(positions)
     bph = {"tuple": 12, "soa": 5, "packed": 4, "runs": 0, "ids24": 3, "deliver": 12, "deliver8": 8, "positions": 12}[name]
@@ -1675,7 +1692,7 @@ def _time_one_format(args, W, r, batch, name, ab_name, ab_values):
         dt = time.time() - t
         st = r.stats()
         rec = {"format": name, "config": args.config, "scale": args.scale, "window_hits": args.window_hits or "default",
-               "topic_order": args.topic_order if (not W["retain"] and not deliver) else "caller",
+               "topic_order": "walk" if want_order else "caller",
                "value": round(W["n_pub"] * args.steps / dt, 1), "ms_per_step": round(dt * 1e3 / args.steps, 3), "windows_per_step": int(nwin),
                "hits_per_step": int(hits), "kernel_ms_per_step": {"walk": round(st["walk_ms"] / args.steps, 3), "scan_compact_tiles": round(st["scan_ms"] / args.steps, 3),
                                                                    "expand": round(st["expand_ms"] / args.steps, 3)},
@@ -1718,6 +1735,8 @@ def _time_one_format(args, W, r, batch, name, ab_name, ab_values):
                           "what": "per-topic digests (hits, sum, order-weighted sum, sum of squares) of every window of a full pass, reduced on the device, under both values"}),
               flush=True)
         del d0, d1
+    if not W["retain"]:
+        batch.set_order(False)
     batch.set_format(capi.RGR_FORMAT_TUPLE)
 
 

@@ -381,7 +381,9 @@ int32_t rgr_batch_set_topic_ids(rgr_batch* b, const uint32_t* ids);
  * and hot subscriber runs (walk -16..-24 %, profiles/r06g_*).  Nothing changes per topic — same hits, same order inside a topic, rgr_tuple.topic_idx
  * still the batch index (or rgr_batch_set_topic_ids' id) — but windows enumerate topics in walk order: see rgr_window.d_topic_order;
  * rgr_batch_topic_order returns the whole permutation ([n], host pointer valid until the next rgr_batch_set_order / rgr_batch_begin / destroy;
- * NULL in caller order).  Device-resident publish batches without publish attributes only (RGR_ESTATE otherwise, or inside a pass). */
+ * NULL in caller order).  Device-resident publish batches (RGR_ESTATE on a retain batch or inside a pass).  With publish attributes attached the
+ * delivery stage indexes them by walk position (the library gathers them) and answers in RGR_FORMAT_DELIVER8 only — the 12-byte delivery
+ * tuple's topic column would name walk positions: rgr_batch_begin refuses that combination. */
 enum { RGR_ORDER_CALLER = 0, RGR_ORDER_WALK = 1 };
 int32_t rgr_batch_set_order(rgr_batch* b, uint32_t order);
 const uint32_t* rgr_batch_topic_order(const rgr_batch* b);

@@ -242,6 +242,7 @@ struct rgr_batch {
     int format = kFmtTuple;              // rgr_batch_set_format
     bool has_topic_ids = false;          // rgr_batch_set_topic_ids
     DevBuf d_topic_ids;
+    DevBuf d_pub_in;                     // the attributes as the caller gave them (batch order); d_pub is what the kernels index: the same, or gathered into walk order
     DevBuf d_pub, cand, cand_count, dedup_items, dedup_scalars;   // dedup_scalars: u64 candidates of the pass, u32 work-item count
     DevBuf rf_filter[2], rf_node[2], r_cnt, r_payload, r_ecnt, r_e0, r_e1, r_out_off, r_epos, r_end, r_depth;   // retain frontier rounds
     // pass state
@@ -454,6 +455,10 @@ void apply_order(rgr_batch* b) {
     if (b->has_topic_ids) {
         b->d_order_ids.ensure(size_t(n) * 4);
         launch_order_compose(b->d_order.as<uint32_t>(), b->d_topic_ids.as<uint32_t>(), n, b->d_order_ids.as<uint32_t>(), b->stream);
+    }
+    if (b->deliver && b->d_pub_in.p) {           // the delivery stage indexes its attributes by walk position
+        b->d_pub.ensure(size_t(n) * sizeof(PublishAttr));
+        launch_order_gather_attrs(b->d_order.as<uint32_t>(), b->d_pub_in.as<PublishAttr>(), n, b->d_pub.as<PublishAttr>(), b->stream);
     }
     RGR_HIP(hipMemcpyAsync(b->h_order.data(), b->d_order.p, size_t(n) * 4, hipMemcpyDeviceToHost, b->stream));
     RGR_HIP(hipStreamSynchronize(b->stream));
@@ -1273,11 +1278,16 @@ int32_t rgr_batch_set_publish_attrs(rgr_batch* b, const rgr_publish_attr* attrs)
         if (!attrs) { b->deliver = false; if (b->format == kFmtDeliver8) b->format = kFmtTuple; return RGR_OK; }
         if (b->format != kFmtTuple && b->format != kFmtDeliver8) return fail(RGR_ESTATE, "rgr_batch_set_publish_attrs: the delivery stage needs RGR_FORMAT_TUPLE or RGR_FORMAT_DELIVER8");
         if (b->has_topic_ids) return fail(RGR_ESTATE, "rgr_batch_set_publish_attrs: not together with rgr_batch_set_topic_ids");
-        if (b->ordered) return fail(RGR_ESTATE, "rgr_batch_set_publish_attrs: not on a batch in walk order (rgr_batch_set_order)");
         RGR_HIP(hipSetDevice(b->h->cfg.device));
         static_assert(sizeof(rgr_publish_attr) == sizeof(PublishAttr), "rgr_publish_attr layout");
         b->d_pub.ensure(std::max<size_t>(1, b->n) * sizeof(PublishAttr));
-        if (b->n) RGR_HIP(hipMemcpyAsync(b->d_pub.p, attrs, size_t(b->n) * sizeof(PublishAttr), hipMemcpyHostToDevice, b->stream));
+        b->d_pub_in.ensure(std::max<size_t>(1, b->n) * sizeof(PublishAttr));
+        if (b->n) {
+            RGR_HIP(hipMemcpyAsync(b->d_pub_in.p, attrs, size_t(b->n) * sizeof(PublishAttr), hipMemcpyHostToDevice, b->stream));
+            // a batch in walk order (rgr_batch_set_order): the delivery stage indexes its attributes by walk position
+            if (b->ordered) launch_order_gather_attrs(b->d_order.as<uint32_t>(), b->d_pub_in.as<PublishAttr>(), b->n, b->d_pub.as<PublishAttr>(), b->stream);
+            else RGR_HIP(hipMemcpyAsync(b->d_pub.p, b->d_pub_in.p, size_t(b->n) * sizeof(PublishAttr), hipMemcpyDeviceToDevice, b->stream));
+        }
         RGR_HIP(hipStreamSynchronize(b->stream));
         b->deliver = true;
         return RGR_OK;
@@ -1288,10 +1298,17 @@ int32_t rgr_batch_set_order(rgr_batch* b, uint32_t order) {
     return guarded([&]() -> int32_t {
         if (!b || order > RGR_ORDER_WALK) return fail(RGR_EINVAL, "rgr_batch_set_order: bad argument");
         if (b->in_pass) return fail(RGR_ESTATE, "rgr_batch_set_order: inside a pass");
-        if (order == RGR_ORDER_CALLER) { b->ordered = false; return RGR_OK; }
-        if (b->retain) return fail(RGR_ESTATE, "rgr_batch_set_order: not a publish batch");
-        if (b->deliver) return fail(RGR_ESTATE, "rgr_batch_set_order: not together with publish attributes (the delivery stage indexes them by batch position)");
         RGR_HIP(hipSetDevice(b->h->cfg.device));
+        if (order == RGR_ORDER_CALLER) {
+            if (b->ordered && b->deliver && b->d_pub_in.p && b->n) {        // the kernels index the attributes by batch position again
+                RGR_HIP(hipMemcpyAsync(b->d_pub.p, b->d_pub_in.p, size_t(b->n) * sizeof(PublishAttr), hipMemcpyDeviceToDevice, b->stream));
+                RGR_HIP(hipStreamSynchronize(b->stream));
+            }
+            b->ordered = false;
+            return RGR_OK;
+        }
+        if (b->retain) return fail(RGR_ESTATE, "rgr_batch_set_order: not a publish batch");
+        if (b->deliver && b->from_publish) return fail(RGR_ESTATE, "rgr_batch_set_order: not on a PUBLISH-packet batch that carries its own attributes");
         b->ordered = true;
         struct Undo { rgr_batch* b; bool armed = true; ~Undo() { if (armed) b->ordered = false; } } undo{b};
         apply_order(b);
@@ -1371,6 +1388,8 @@ int32_t rgr_batch_begin(rgr_batch* b) {
             else tokenize_batch_device(b, b->retain ? b->repoch->dict : *b->epoch->dict);
             if (b->ordered) apply_order(b);                  // (new token ids: a new order)
         }
+        if (b->deliver && b->ordered && b->format != kFmtDeliver8)
+            return fail(RGR_ESTATE, "rgr_batch_begin: a delivery pass in walk order answers in RGR_FORMAT_DELIVER8 (the 12-byte tuple's topic column would name walk positions)");
         if (b->format == kFmtPacked && (b->retain ? b->repoch->max_id : b->epoch->max_sub_id) >= (1u << 30))
             return fail(RGR_ECAPACITY, "rgr_batch_begin: RGR_FORMAT_PACKED needs ids below 2^30");
         if (b->format == kFmtIds24 && (b->retain ? b->repoch->max_id : b->epoch->max_sub_id) >= (1u << 24))

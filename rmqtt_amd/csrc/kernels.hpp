@@ -303,6 +303,7 @@ void launch_order_len(const uint32_t* perm, const uint64_t* tok_off, uint32_t n,
 void launch_order_gather(const uint32_t* perm, uint32_t n, const uint64_t* off_old, const uint32_t* tok_old, const uint8_t* fl_old, const uint64_t* off_new, uint32_t* tok_new,
                          uint8_t* fl_new, void* stream);
 void launch_order_compose(const uint32_t* perm, const uint32_t* ids, uint32_t n, uint32_t* out, void* stream);
+void launch_order_gather_attrs(const uint32_t* perm, const PublishAttr* in, uint32_t n, PublishAttr* out, void* stream);
 uint32_t expand_tile_hits();
 const char* expand_ids24_kernel_name();      // ... 3-byte-id windows by default (RGR_COMPACT_LP overrides per launch)
 const char* expand_tuple_kernel_name();      // which kernel expands plain 12-byte tuple windows (profilers see this name)

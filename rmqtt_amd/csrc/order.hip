@@ -55,6 +55,11 @@ __global__ __launch_bounds__(256) void order_compose_kernel(const uint32_t* __re
     if (k < n) out[k] = ids[perm[k]];
 }
 
+__global__ __launch_bounds__(256) void order_compose_kernel64(const uint32_t* __restrict__ perm, const unsigned long long* __restrict__ in, uint32_t n, unsigned long long* __restrict__ out) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k < n) out[k] = in[perm[k]];
+}
+
 }  // namespace
 
 size_t order_sort_temp_bytes(uint32_t n) {
@@ -86,6 +91,12 @@ void launch_order_len(const uint32_t* perm, const uint64_t* tok_off, uint32_t n,
 void launch_order_gather(const uint32_t* perm, uint32_t n, const uint64_t* off_old, const uint32_t* tok_old, const uint8_t* fl_old, const uint64_t* off_new, uint32_t* tok_new,
                          uint8_t* fl_new, void* stream) {
     if (n) order_gather_kernel<<<(n + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(perm, n, off_old, tok_old, fl_old, off_new, tok_new, fl_new);
+}
+
+// publish attributes (8 bytes each) into walk order
+void launch_order_gather_attrs(const uint32_t* perm, const PublishAttr* in, uint32_t n, PublishAttr* out, void* stream) {
+    static_assert(sizeof(PublishAttr) == 8, "gathered as 64-bit words");
+    if (n) order_compose_kernel64<<<(n + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(perm, reinterpret_cast<const unsigned long long*>(in), n, reinterpret_cast<unsigned long long*>(out));
 }
 
 void launch_order_compose(const uint32_t* perm, const uint32_t* ids, uint32_t n, uint32_t* out, void* stream) {

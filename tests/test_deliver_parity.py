@@ -523,6 +523,24 @@ def test_deliver8_windows_equal_the_delivery_tuples(window_hits):
             seen_dup |= bool((h["word"] & capi.RGR_HIT_V5_DUP).any()); seen_drop |= bool((h["word"] & capi.RGR_HIT_NO_LOCAL).any())
     assert seen_dup
     del seen_drop            # (a No Local drop needs the publisher among the subscribers: not guaranteed by this draw)
+    # the same pass in walk order (rgr_batch_set_order): the attributes follow their topics, every topic's hits are what they were
+    per_topic = {}
+    for tb1, te1, _, o1, h in got:
+        for k in range(te1 - tb1):
+            per_topic[tb1 + k] = h[int(o1[k]):int(o1[k + 1])] if h is not None else np.zeros(0, dtype=np.dtype([("sub_id", np.uint32), ("word", np.uint32)]))
+    b.set_format(capi.RGR_FORMAT_DELIVER8)
+    b.set_order(True)
+    perm = b.topic_order()
+    assert sorted(perm.tolist()) == list(range(len(topics)))
+    walked = windows(capi.RGR_FORMAT_DELIVER8)
+    seen = 0
+    for tb1, te1, _, o1, h in walked:
+        for k in range(te1 - tb1):
+            a, e = int(o1[k]), int(o1[k + 1])
+            assert np.array_equal(h[a:e] if h is not None else per_topic[int(perm[tb1 + k])][:0], per_topic[int(perm[tb1 + k])]), (tb1 + k, perm[tb1 + k])
+            seen += 1
+    assert seen == len(topics)
+    b.set_order(False)
     with pytest.raises(capi.RgrError):
         b.set_format(capi.RGR_FORMAT_PACKED)                 # plain compact formats carry no delivery word
     b.set_publish_attrs(None)                                # detaching the attributes: back to tuples

@@ -393,6 +393,7 @@ def test_walk_order_changes_nothing_per_topic(window_hits):
         assert np.array_equal(back[k], ref[capi.RGR_FORMAT_TUPLE][k])
     attrs = np.zeros(n, dtype=capi.PUBLISH_ATTR_DTYPE)
     b.set_order(True)
+    b.set_publish_attrs(attrs)                      # the delivery stage in walk order answers with 8-byte hits only (tests/test_deliver_parity.py) ...
     with pytest.raises(capi.RgrError):
-        b.set_publish_attrs(attrs)                  # the delivery stage indexes its attributes by batch position
+        b.begin()                                   # ... a 12-byte tuple's topic column would name walk positions
     b.close(); r.close()
