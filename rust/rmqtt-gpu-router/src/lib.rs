@@ -14,6 +14,7 @@
 //! Source only — see Cargo.toml.
 mod batcher;
 mod ffi;
+mod message_index;
 mod retain;
 mod router;
 mod shared;
@@ -26,6 +27,7 @@ use rmqtt::plugin::{PackageInfo, Plugin};
 use rmqtt::register;
 use rmqtt::Result;
 
+pub use message_index::GpuMessageIndex;
 pub use retain::{GpuRetainIndex, GpuRetainStorage};
 pub use router::GpuRouter;
 pub use shared::GpuShared;
