@@ -1573,9 +1573,12 @@ def measure_forwards_e2e(args, L, W, cfg, n_t, tb, to, blob, offs, client, qos, 
            "config": {"workload": f"BASELINE.json configs[{cfg - 1}]: {W['n_sub']} subscriptions ({DELIVER_SECONDARY_V5:.0%} MQTT v5: No Local / RAP), {n_t} publishes cycled, "
                                   f"publishers drawn from the subscribers", "batcher": {"max_batch": 4096, "max_delay_us": 200}},
            "gpu_async": []}
-    shapes = [(args.e2e_submitters, args.e2e_outstanding, args.e2e_workers or max(8, min(64, cores // 4)), args.e2e_passes)]
+    # (the shape that measured best at both configs, profiles/r06f_*: 4 submitters, 8 k publishes outstanding, 32 completion threads, 2 passes in flight — a
+    # delivery pass carries 12 bytes per HIT to the host, so fewer, fuller passes and less outstanding work than the filter-id form of Router::matches)
+    shapes = [(4, 8192, 32, 2)] if (args.e2e_submitters, args.e2e_outstanding, args.e2e_workers, args.e2e_passes) == (8, 16384, 0, 3) else \
+             [(args.e2e_submitters, args.e2e_outstanding, args.e2e_workers or max(8, min(64, cores // 4)), args.e2e_passes)]
     if args.e2e_sweep:
-        shapes += [(8, 16384, 128, 3), (8, 65536, 64, 4), (4, 8192, 32, 2)]
+        shapes += [(8, 16384, 64, 3), (8, 65536, 64, 4), (8, 16384, 128, 3)]
     for subm, outst, workers, passes in shapes:
         res = (C.c_uint64 * 6)()
         wall = C.c_double(0)
