@@ -591,6 +591,15 @@ int32_t rgr_group_batch_gather_runs(rgr_group_batch* gb, uint32_t consumer_shard
 /* Device pointer to shard `holder`'s replica of shard `of`'s subs[] (valid until the next rgr_group_batch_gather_runs after a commit). */
 int32_t rgr_group_peer_subs(rgr_group* g, uint32_t holder, uint32_t of, const uint64_t** d_subs, uint64_t* n_entries);
 
+/* The retained-message twin over the group: retained topics live on the shard their key levels hash to; a SUBSCRIBE filter whose
+ * key levels are literal asks that one shard, a filter with a wildcard among them asks every shard and the answers are concatenated (shard order).
+ * Same meaning as the single-handle calls (RetainTree insert / remove / matches, rmqtt/src/retain.rs:373-413, 450-526). */
+int32_t rgr_group_retain_topic_add(rgr_group* g, const char* topic, uint32_t len, uint32_t topic_id);
+int32_t rgr_group_retain_topic_remove(rgr_group* g, const char* topic, uint32_t len);
+int32_t rgr_group_retain_add_bulk(rgr_group* g, const uint8_t* blob, const uint64_t* offsets, uint64_t n, const uint32_t* topic_ids, uint64_t* n_rejected);
+int32_t rgr_group_retain_commit(rgr_group* g);
+int32_t rgr_group_retain_match_batch(rgr_group* g, const uint8_t* filters_blob, const uint64_t* filter_offsets, uint32_t n, rgr_retain_result* out);
+
 /* ---- observability ------------------------------------------------------------------------ */
 int32_t rgr_stats_get(rgr_handle* h, rgr_stats* out);
 int32_t rgr_stats_reset(rgr_handle* h);

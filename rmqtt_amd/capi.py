@@ -42,6 +42,7 @@ SYMBOLS = [
     "rgr_group_create", "rgr_group_destroy", "rgr_group_size", "rgr_group_set_key_levels", "rgr_group_handle", "rgr_group_comm", "rgr_group_uses_rccl",
     "rgr_group_subscribe_bulk", "rgr_group_sub_attrs_bulk", "rgr_group_subscribe", "rgr_group_subscribe_ex", "rgr_group_unsubscribe", "rgr_group_commit",
     "rgr_group_match_batch", "rgr_group_match_batch_deliver", "rgr_group_match_filter_subs",
+    "rgr_group_retain_topic_add", "rgr_group_retain_topic_remove", "rgr_group_retain_add_bulk", "rgr_group_retain_commit", "rgr_group_retain_match_batch",
     "rgr_group_batch_create", "rgr_group_batch_destroy", "rgr_group_batch_shard", "rgr_group_batch_run", "rgr_group_batch_gather",
 ]
 GATHER_CONSUMER = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_uint32, C.c_uint64)
@@ -196,6 +197,11 @@ def lib():
         L.rgr_group_subscribe.argtypes = [vp, C.c_char_p, u32, u32, u8, u8]
         L.rgr_group_unsubscribe.argtypes = [vp, C.c_char_p, u32, u32, i32]
         L.rgr_group_commit.argtypes = [vp]
+        L.rgr_group_retain_topic_add.argtypes = [vp, C.c_char_p, u32, u32]
+        L.rgr_group_retain_topic_remove.argtypes = [vp, C.c_char_p, u32]
+        L.rgr_group_retain_add_bulk.argtypes = [vp, vp, vp, u64, vp, C.POINTER(u64)]
+        L.rgr_group_retain_commit.argtypes = [vp]
+        L.rgr_group_retain_match_batch.argtypes = [vp, vp, vp, u32, C.POINTER(RetainResult)]
         L.rgr_group_match_batch.argtypes = [vp, vp, vp, u32, C.POINTER(Result)]
         L.rgr_group_batch_create.argtypes = [vp, vp, vp, u32, C.POINTER(vp)]
         L.rgr_group_batch_destroy.argtypes = [vp]; L.rgr_group_batch_destroy.restype = None
@@ -721,6 +727,38 @@ class Group:
 
     def commit(self):
         _check(lib().rgr_group_commit(self._g))
+
+    # ---- the retained-message twin over the group (rgr_group_retain_*)
+    def retain_add(self, topic, topic_id):
+        t = _b(topic)
+        return lib().rgr_group_retain_topic_add(self._g, t, len(t), topic_id)
+
+    def retain_remove(self, topic):
+        t = _b(topic)
+        return lib().rgr_group_retain_topic_remove(self._g, t, len(t))
+
+    def retain_add_bulk(self, blob, offsets, topic_ids=None):
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        ids = None if topic_ids is None else np.ascontiguousarray(topic_ids, dtype=np.uint32)
+        rej = C.c_uint64(0)
+        bp, bk = _blob_ptr(blob)
+        _check(lib().rgr_group_retain_add_bulk(self._g, bp, offsets.ctypes.data, len(offsets) - 1, None if ids is None else ids.ctypes.data, C.byref(rej)))
+        return int(rej.value)
+
+    def retain_commit(self):
+        _check(lib().rgr_group_retain_commit(self._g))
+
+    def retain_match_batch(self, blob, offsets):
+        n = len(offsets) - 1
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        r = RetainResult()
+        bp, bk = _blob_ptr(blob)
+        _check(lib().rgr_group_retain_match_batch(self._g, bp, offsets.ctypes.data, n, C.byref(r)))
+        try:
+            return dict(status=_copy(r.status, n, np.int32), hit_offsets=_copy(r.hit_offsets, n + 1, np.uint64),
+                        topic_ids=_copy(r.topic_ids, r.n_hits, np.uint32))
+        finally:
+            lib().rgr_retain_result_free(C.byref(r))
 
     def match_batch(self, blob, offsets):
         n = len(offsets) - 1

@@ -12,6 +12,8 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <cstdlib>
+
 #include "kernels.hpp"
 
 namespace rgr {
@@ -77,11 +79,19 @@ int launch_order_sort(const uint32_t* tokens, const uint64_t* tok_off, const uin
     if (!n) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint32_t nb = (n + 255) / 256;
-    order_keys_kernel<<<nb, 256, 0, s>>>(tokens, tok_off, tflags, n, 2u, nullptr, keys, idx_tmp);                  // levels 2, 3 of topic k; idx_tmp = identity
-    int rc = int(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, keys_tmp, idx_tmp, perm, int(n), 0, 64, s));
-    if (rc) return rc;
-    order_keys_kernel<<<nb, 256, 0, s>>>(tokens, tok_off, tflags, n, 0u, perm, keys, idx_tmp);                     // levels 0, 1 of the topic at position k; idx_tmp = perm
-    return int(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, keys_tmp, idx_tmp, perm, int(n), 0, 64, s));
+    // RGR_ORDER_LEVELS (A/B switch, read per sort): how many leading levels order the batch (2, 4 (default), 6, 8): one stable sort per pair of levels,
+    // the least significant pair first
+    uint32_t levels = 4;
+    if (const char* e = std::getenv("RGR_ORDER_LEVELS")) { const int v = std::atoi(e); if (v >= 2 && v <= 16) levels = uint32_t(v) & ~1u; }
+    bool first = true;
+    for (uint32_t lv = levels; lv >= 2; lv -= 2) {
+        // keys of levels lv - 2, lv - 1: of topic k on the first pass (idx_tmp = identity), of the topic at position k afterwards (idx_tmp = perm so far)
+        order_keys_kernel<<<nb, 256, 0, s>>>(tokens, tok_off, tflags, n, lv - 2, first ? nullptr : perm, keys, idx_tmp);
+        const int rc = int(hipcub::DeviceRadixSort::SortPairs(temp, temp_bytes, keys, keys_tmp, idx_tmp, perm, int(n), 0, 64, s));
+        if (rc) return rc;
+        first = false;
+    }
+    return 0;
 }
 
 void launch_order_len(const uint32_t* perm, const uint64_t* tok_off, uint32_t n, uint32_t* len, void* stream) {

@@ -102,6 +102,11 @@ extern "C" {
                                     flags: *const u8, n_rejected: *mut u64) -> i32;
     pub fn rgr_group_sub_attrs_bulk(g: *mut rgr_group, sub_ids: *const u32, owner_ids: *const u32, client_idx: *const u32, n: u64) -> i32;
     pub fn rgr_group_commit(g: *mut rgr_group) -> i32;
+    pub fn rgr_group_retain_topic_add(g: *mut rgr_group, topic: *const c_char, len: u32, topic_id: u32) -> i32;
+    pub fn rgr_group_retain_topic_remove(g: *mut rgr_group, topic: *const c_char, len: u32) -> i32;
+    pub fn rgr_group_retain_add_bulk(g: *mut rgr_group, blob: *const u8, offsets: *const u64, n: u64, topic_ids: *const u32, n_rejected: *mut u64) -> i32;
+    pub fn rgr_group_retain_commit(g: *mut rgr_group) -> i32;
+    pub fn rgr_group_retain_match_batch(g: *mut rgr_group, filters_blob: *const u8, filter_offsets: *const u64, n: u32, out: *mut rgr_retain_result) -> i32;
     pub fn rgr_group_match_batch(g: *mut rgr_group, blob: *const u8, offsets: *const u64, n: u32, out: *mut rgr_result) -> i32;
     pub fn rgr_group_match_batch_deliver(g: *mut rgr_group, blob: *const u8, offsets: *const u64, n: u32, attrs: *const rgr_publish_attr,
                                          out: *mut rgr_result) -> i32;

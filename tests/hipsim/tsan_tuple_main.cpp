@@ -64,5 +64,19 @@ int main() {
                     (unsigned long long)dw, (unsigned long long)hits, (unsigned long long)dc, ntiles, (unsigned long long)dn);
         bad += rc != 0 || dw || dc || dn;
     }
+    // (r6) the lean variants writing 8-byte hits {sub_id, delivery word} (RGR_FORMAT_DELIVER8) into a buffer of exactly hits * 8 bytes: the same words
+    // and sub ids as the tuples, the same candidate sets and count words
+    for (int variant : {5, 6}) {
+        std::vector<unsigned long long> o8(hits, 0);
+        c.assign(size_t(ntiles) * kTile, Cand{kNone, kNone}); n.assign(ntiles, 0xDEADBEEFu); r.assign(2 * size_t(ntiles), 0xDEADBEEFu);
+        const int rc = sim_expand_tuple(variant, subs.data(), attrs.data(), pub.data(), src.data(), ptopic.data(), off.data(), qr.data(), 0, np, topic_lo,
+                                        reinterpret_cast<Tuple*>(o8.data()), c.data(), n.data(), r.data());
+        uint64_t dw = 0, dn = 0;
+        for (uint64_t i = 0; i < hits; ++i) dw += uint32_t(o8[i]) != o1[i].sub_id || uint32_t(o8[i] >> 32) != o1[i].qos_flags;
+        for (uint32_t t = 0; t < ntiles; ++t) dn += n[t] != n1[t];
+        std::printf("variant %d (8-byte hits) vs expand_kernel<true>: rc %d, %llu of %llu hits differ, %llu count words differ\n", variant, rc, (unsigned long long)dw,
+                    (unsigned long long)hits, (unsigned long long)dn);
+        bad += rc != 0 || dw || dn;
+    }
     return bad ? 1 : 0;
 }

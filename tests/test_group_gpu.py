@@ -126,3 +126,53 @@ def test_rccl_communicator_world_of_one():
     assert np.array_equal(sid, exp["sub_ids"])
     assert np.array_equal(np.repeat(runs["topic"], runs["len"]), np.repeat((n - 1 - np.arange(n)).astype(np.uint32), np.diff(ho)))
     b.close(); c.close(); r.close()
+
+
+@pytest.mark.parametrize("shards,key_levels", [(1, 0), (2, 0), (3, 1)])
+def test_group_retained_path_matches_the_unsharded_oracle(shards, key_levels):
+    """(r6) The retained-message twin over the group (rgr_group_retain_*): retained topics sharded by the hash of their key levels,
+    a filter with literal key levels asks its one shard, a filter with a wildcard among them asks every shard and the answers are concatenated.
+    Against the oracle's RetainTree on the UNSHARDED set (as sets per filter: the reference's own order is hash-map order), with removals and
+    replacements between commits; one shard = the single-handle answer, order included."""
+    from tests.parity import pack
+    c = wl.CONFIGS[5]
+    blob, offs = wl.gen_topics(30_000, wl.PUB_SEED + 5, 0.01, c["p_blank"], c["fixed_depth"], distinct=True)
+    fb, fo, _, _ = wl.gen_subs(800, wl.SUB_SEED + 5, c["p_plus"], c["p_hash"], c["p_sys"], 0, c["fixed_depth"], force_wildcard=True)
+    extra = pack(["#", "+/#", "$SYS/#", "l0x0/#", "l0x0/l1x0/#", "l0x0/l1x0/l2x0/#", "+/+/+", "l0x0/+/l2x0", "bad/#/x", "nope/#", "/#", "l0x1/l1x3/l2x1/l3x7"])
+    g = capi.Group([0] * shards, window_hits=50_000)
+    if key_levels:
+        g.set_key_levels(key_levels)
+    t = orc.RetainTree()
+    assert g.retain_add_bulk(blob, offs) == t.insert_bulk(blob, offs)
+    g.retain_commit()
+
+    def check():
+        for b_, o_ in ((fb, fo), extra):
+            got = g.retain_match_batch(b_, o_)
+            st, eo, ev, _ = t.match_batch(b_, o_)
+            assert np.array_equal(st < 0, got["status"] < 0) and np.array_equal(eo, got["hit_offsets"])
+            for a, e in zip(eo[:-1], eo[1:]):
+                assert sorted(got["topic_ids"][int(a):int(e)].tolist()) == sorted(ev[int(a):int(e)].tolist())
+        return got
+    last = check()
+    if shards == 1:                                  # one shard IS the single handle
+        r = capi.Router(device=0, window_hits=50_000)
+        r.retain_add_bulk(blob, offs)
+        r.retain_commit()
+        ref = r.retain_match_batch(*extra)
+        assert np.array_equal(ref["topic_ids"], last["topic_ids"])
+        r.close()
+    names = [bytes(blob[int(offs[i]):int(offs[i + 1])]).decode() for i in range(0, 3000, 7)]
+    for k, nm in enumerate(names):
+        if k % 3 == 0:
+            assert g.retain_remove(nm) == 0 and t.remove(nm)[0] == 1
+        elif k % 3 == 1:
+            assert g.retain_add(nm, 500_000 + k) == 0
+            t.insert(nm, 500_000 + k)
+    assert g.retain_add("brand/new/topic", 999_999) == 0
+    t.insert("brand/new/topic", 999_999)
+    g.retain_commit()
+    check()
+    got = g.retain_match_batch(*pack(["brand/#", "brand/new/+"]))
+    assert got["topic_ids"].tolist() == [999_999, 999_999]
+    g.close()
