@@ -376,7 +376,7 @@ int32_t rgr_batch_set_publish_attrs(rgr_batch* b, const rgr_publish_attr* attrs)
  * Costs nothing per hit (the id is attached per (topic, filter) pair at compaction).  RGR_ESTATE inside a pass
  * or together with publish attributes. */
 int32_t rgr_batch_set_topic_ids(rgr_batch* b, const uint32_t* ids);
-/* Order in which later passes walk the batch's topics.  RGR_ORDER_WALK: the library sorts the topics by their leading level tokens (two device
+/* Order in which later passes walk the batch's topics.  RGR_ORDER_WALK: the library sorts the topics by their leading level tokens (three device
  * radix sorts per batch, repeated when a grown dictionary re-tokenises it): neighbouring lanes of the walk then share their upper trie levels
  * and hot subscriber runs (walk -16..-24 %, profiles/r06g_*).  Nothing changes per topic — same hits, same order inside a topic, rgr_tuple.topic_idx
  * still the batch index (or rgr_batch_set_topic_ids' id) — but windows enumerate topics in walk order: see rgr_window.d_topic_order;

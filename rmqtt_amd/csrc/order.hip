@@ -5,7 +5,7 @@
 // by its leading tokens the lanes of a wave walk the same upper trie levels and the same hot subscriber runs at the same time — measured through
 // the product API on topics sorted on the host (tools/walk_order_lab.py, profiles/r06g_*): walk -16 % at BASELINE configs[1] (1 997 -> 2 263 M
 // topics/s), walk -24 %, count / compact -29 %, expansion -3.6 % at configs[2] (3/10 scale).  Here the library does the reordering itself:
-// keys = the first four level tokens of every topic, two stable radix sorts of (key, batch index) pairs (rocPRIM through hipCUB — a library primitive for a
+// keys = the first six level tokens of every topic, three stable radix sorts of (key, batch index) pairs (rocPRIM through hipCUB — a library primitive for a
 // once-per-batch preprocessing step; nothing of the hot path), then the token arrays are gathered into that order.  Tuples still name the
 // caller's topic index (the permutation rides on the topic-id indirection of the compaction: no cost per hit); windows enumerate topics in walk
 // order and rgr_window.d_topic_order says which.
@@ -71,7 +71,7 @@ size_t order_sort_temp_bytes(uint32_t n) {
     return bytes;
 }
 
-// perm[k] = batch index of the topic walked k-th: topics sorted by their first FOUR level tokens, ties in batch order — two stable radix sorts,
+// perm[k] = batch index of the topic walked k-th: topics sorted by their first SIX level tokens, ties in batch order — three stable radix sorts,
 // least significant pair of levels first (two levels: 2.02 -> 2.17 G topics/s at BASELINE configs[1]; sorted by the whole string on the host: 2.26 G,
 // profiles/r06g_*, r06h_*).  keys / keys_tmp: [n] u64 scratch, idx_tmp: [n] u32 scratch, temp: order_sort_temp_bytes(n).
 int launch_order_sort(const uint32_t* tokens, const uint64_t* tok_off, const uint8_t* tflags, uint32_t n, unsigned long long* keys, unsigned long long* keys_tmp,
@@ -79,9 +79,10 @@ int launch_order_sort(const uint32_t* tokens, const uint64_t* tok_off, const uin
     if (!n) return 0;
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint32_t nb = (n + 255) / 256;
-    // RGR_ORDER_LEVELS (A/B switch, read per sort): how many leading levels order the batch (2, 4 (default), 6, 8): one stable sort per pair of levels,
-    // the least significant pair first
-    uint32_t levels = 4;
+    // RGR_ORDER_LEVELS (A/B switch, read per sort): how many leading levels order the batch: one stable sort per pair of levels, the least significant
+    // pair first.  Measured (profiles/r06n_*): 4 / 6 / 8 levels -> walk 5.58 / 4.89 / 4.94 ms per 10 M topics at BASELINE configs[2], configs[1] 2.29 / 2.45 /
+    // 2.43 G topics/s, runs 946 / 999 / 993 M; tuples and ids24 within +-1 %.  Six.
+    uint32_t levels = 6;
     if (const char* e = std::getenv("RGR_ORDER_LEVELS")) { const int v = std::atoi(e); if (v >= 2 && v <= 16) levels = uint32_t(v) & ~1u; }
     bool first = true;
     for (uint32_t lv = levels; lv >= 2; lv -= 2) {

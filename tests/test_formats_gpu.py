@@ -323,7 +323,7 @@ def test_walk_order_changes_nothing_per_topic(window_hits):
     """rgr_batch_set_order(RGR_ORDER_WALK) (r6): the library sorts the batch's topics by their leading tokens and walks them in that order.  Per
     topic nothing changes — the same tuples in the same order, naming the topic's BATCH index — but windows enumerate walk positions:
     d_topic_order says which batch topic the k-th offset belongs to, rgr_batch_topic_order returns the permutation (a bijection, sorted by the
-    first four tokens).  Every format, caller topic ids composed with the order, and back to caller order."""
+    first six tokens).  Every format, caller topic ids composed with the order, and back to caller order."""
     rng = np.random.default_rng(17)
     c = wl.CONFIGS[3]
     blob, offs, _, qos = wl.gen_subs(60_000, wl.SUB_SEED + 3, c["p_plus"], c["p_hash"], c["p_sys"])
@@ -373,9 +373,9 @@ def test_walk_order_changes_nothing_per_topic(window_hits):
     assert sorted(perm.tolist()) == list(range(n))
     strings = wl.strings(tb, to)
     st = b.status()
-    lead = [tuple(strings[i].split("/")[:4]) for i in perm if st[i] == 0]
+    lead = [tuple(strings[i].split("/")[:6]) for i in perm if st[i] == 0]
     groups = [lead[0]] + [x for p_, x in zip(lead, lead[1:]) if x != p_]
-    assert len(groups) == len(set(groups)), "topics with the same four leading levels are contiguous in walk order"
+    assert len(groups) == len(set(groups)), "topics with the same six leading levels are contiguous in walk order"
     for f in ref:
         got = per_topic(f)
         assert got.keys() == ref[f].keys()
