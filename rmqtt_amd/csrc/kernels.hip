@@ -398,6 +398,9 @@ __global__ __launch_bounds__(256) void count_kernel(TrieView tv, ChunkArrays c) 
 
 // Long pair lists (a retained-path '+' over a wide node emits one descriptor per child; a hot
 // publish topic can match hundreds of filters): one block per topic instead of one lane.
+// (r6) eight descriptors per thread and step, all in flight together: a retained-path filter like `+/+/+/#` owns a list of 10^5 - 10^6 descriptors, walked by
+// ONE block — at one gather per thread and step its 4 000 dependent rounds were the whole kernel (1.78 ms per launch at BASELINE configs[4]).
+constexpr int kBigPer = 8;
 __global__ __launch_bounds__(256) void count_big_kernel(TrieView tv, ChunkArrays c) {
     __shared__ unsigned long long s_a[4], s_b[4];
     const uint32_t nb = *c.big_count;
@@ -409,9 +412,12 @@ __global__ __launch_bounds__(256) void count_big_kernel(TrieView tv, ChunkArrays
             continue;
         }
         unsigned long long hits = 0, live = 0;
-        for (uint32_t j = threadIdx.x; j < cnt; j += 256) {
-            const uint32_t n = tv.filt[pair_fid(c, t, cnt, j)].count;
-            hits += n; live += n != 0;
+        for (uint32_t j0 = threadIdx.x; j0 < cnt; j0 += 256 * kBigPer) {
+            uint32_t n[kBigPer];
+#pragma unroll
+            for (int k = 0; k < kBigPer; ++k) { const uint32_t j = j0 + uint32_t(k) * 256; n[k] = j < cnt ? tv.filt[pair_fid(c, t, cnt, j)].count : 0u; }
+#pragma unroll
+            for (int k = 0; k < kBigPer; ++k) { hits += n[k]; live += n[k] != 0; }
         }
         hits = wave_sum(hits); live = wave_sum(live);
         if ((threadIdx.x & 63) == 0) { s_a[threadIdx.x >> 6] = hits; s_b[threadIdx.x >> 6] = live; }
@@ -586,8 +592,9 @@ __global__ __launch_bounds__(kCompactWave) void compact_kernel(TrieView tv, Chun
     }
 }
 
-// Order-preserving compaction of one long pair list by a whole block: 256 pairs per step, block
-// exclusive scan of (live, count), carried across steps.
+// Order-preserving compaction of one long pair list by a whole block: 256 x kBigPer pairs per step (a thread owns kBigPer CONSECUTIVE pairs, their
+// descriptors gathered together), block exclusive scan of the threads' (live, count) totals, carried across steps.  (r6: one pair per thread and step —
+// two barriers and a dependent gather per 256 pairs — made the 10^5 - 10^6-descriptor lists of the retained path 3.98 ms per launch.)
 __global__ __launch_bounds__(256) void compact_big_kernel(TrieView tv, ChunkArrays c, uint32_t topic_base) {
     __shared__ unsigned long long s_l[4], s_c[4];
     const uint32_t nb = *c.big_count;
@@ -597,12 +604,17 @@ __global__ __launch_bounds__(256) void compact_big_kernel(TrieView tv, ChunkArra
         const uint32_t cnt = c.pair_cnt[t];
         if (c.pair_live[t] == 0) continue;      // nothing to emit — also every topic count_big_kernel refused (list beyond the arena)
         uint64_t p0 = c.pair_base[t], o0 = c.hit_off[t];
-        for (uint32_t j0 = 0; j0 < cnt; j0 += 256) {
-            const uint32_t j = j0 + threadIdx.x;
-            FilterDesc fd{0, 0};
-            if (j < cnt) fd = tv.filt[pair_fid(c, t, cnt, j)];
-            unsigned long long xl = fd.count != 0, xc = fd.count;
-            const unsigned long long ml = xl, mc = xc;
+        const uint32_t topic_val = c.topic_ids ? c.topic_ids[topic_base + t] : topic_base + t;
+        const uint8_t qr = c.pair_qr ? uint8_t(c.pub[topic_base + t].qos_retain) : uint8_t(0);
+        for (uint32_t j0 = 0; j0 < cnt; j0 += 256 * kBigPer) {
+            const uint32_t jt = j0 + threadIdx.x * kBigPer;
+            FilterDesc fd[kBigPer];
+#pragma unroll
+            for (int k = 0; k < kBigPer; ++k) fd[k] = jt + k < cnt ? tv.filt[pair_fid(c, t, cnt, jt + k)] : FilterDesc{0, 0};
+            unsigned long long ml = 0, mc = 0;                    // this thread's live pairs / hits
+#pragma unroll
+            for (int k = 0; k < kBigPer; ++k) { ml += fd[k].count != 0; mc += fd[k].count; }
+            unsigned long long xl = ml, xc = mc;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
                 const unsigned long long yl = __shfl_up(xl, o, 64), yc = __shfl_up(xc, o, 64);
@@ -612,13 +624,16 @@ __global__ __launch_bounds__(256) void compact_big_kernel(TrieView tv, ChunkArra
             __syncthreads();
             unsigned long long pl = 0, pc = 0, tl = 0, tc = 0;
             for (int i = 0; i < 4; ++i) { if (i < w) { pl += s_l[i]; pc += s_c[i]; } tl += s_l[i]; tc += s_c[i]; }
-            if (ml) {
-                const uint64_t p = p0 + pl + (xl - ml);
-                c.pair_src[p] = fd.begin;
-                c.pair_topic[p] = c.topic_ids ? c.topic_ids[topic_base + t] : topic_base + t;
-                if (c.pair_qr) c.pair_qr[p] = uint8_t(c.pub[topic_base + t].qos_retain);
-                c.pair_off[p] = o0 + pc + (xc - mc);
-            }
+            uint64_t p = p0 + pl + (xl - ml), o = o0 + pc + (xc - mc);
+#pragma unroll
+            for (int k = 0; k < kBigPer; ++k)
+                if (fd[k].count) {
+                    c.pair_src[p] = fd[k].begin;
+                    c.pair_topic[p] = topic_val;
+                    if (c.pair_qr) c.pair_qr[p] = qr;
+                    c.pair_off[p] = o;
+                    ++p; o += fd[k].count;
+                }
             p0 += tl; o0 += tc;
             __syncthreads();
         }
