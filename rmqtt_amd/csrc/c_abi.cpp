@@ -243,7 +243,9 @@ struct rgr_batch {
     bool has_topic_ids = false;          // rgr_batch_set_topic_ids
     DevBuf d_topic_ids;
     DevBuf d_pub_in;                     // the attributes as the caller gave them (batch order); d_pub is what the kernels index: the same, or gathered into walk order
-    DevBuf d_pub, cand, cand_count, dedup_items, dedup_scalars;   // dedup_scalars: u64 candidates of the pass, u32 work-item count
+    // dedup_scalars: [0] unused, [1] the two work-item counters; dedup_stat: candidates seen, one u64 per block of the tile pass (kDedupStatSlots of them:
+    // a block adds to ITS slot with a plain read-modify-write — launches are stream-ordered — instead of 2 048 atomics on one address per window)
+    DevBuf d_pub, cand, cand_count, dedup_items, dedup_scalars, dedup_stat;
     DevBuf rf_filter[2], rf_node[2], r_cnt, r_payload, r_ecnt, r_e0, r_e1, r_out_off, r_epos, r_end, r_depth;   // retain frontier rounds
     // pass state
     bool retain = false;             // batch of SUBSCRIBE filters against the retained-topic trie
@@ -1400,6 +1402,7 @@ int32_t rgr_batch_begin(rgr_batch* b) {
         }
         b->c = &b->cs[0];
         if (b->dedup_scalars.p) RGR_HIP(hipMemsetAsync(b->dedup_scalars.p, 0, 16, b->stream));     // (a pass abandoned midway leaves its count behind)
+        if (b->dedup_stat.p) RGR_HIP(hipMemsetAsync(b->dedup_stat.p, 0, size_t(dedup_stat_slots()) * 8, b->stream));
         b->in_pass = true;
         b->cursor = 0;
         b->hits_before = 0;
@@ -1422,11 +1425,14 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
         RGR_HIP(hipSetDevice(h->cfg.device));
         if (b->cursor >= b->n) {
             unsigned long long n_cand = 0;
-            if (b->dedup_scalars.p) {                 // candidates the pass's dedup kernels saw (accumulated on the device)
-                RGR_HIP(hipMemcpyAsync(&n_cand, b->dedup_scalars.p, 8, hipMemcpyDeviceToHost, b->stream));
-                RGR_HIP(hipMemsetAsync(b->dedup_scalars.p, 0, 8, b->stream));
+            std::vector<unsigned long long> per_block;
+            if (b->dedup_stat.p) {                    // candidates the pass's dedup kernels saw (accumulated on the device, one slot per block of the tile pass)
+                per_block.assign(dedup_stat_slots(), 0);
+                RGR_HIP(hipMemcpyAsync(per_block.data(), b->dedup_stat.p, per_block.size() * 8, hipMemcpyDeviceToHost, b->stream));
+                RGR_HIP(hipMemsetAsync(b->dedup_stat.p, 0, per_block.size() * 8, b->stream));
             }
             RGR_HIP(hipStreamSynchronize(b->stream));
+            for (unsigned long long v : per_block) n_cand += v;
             b->local.dedup_candidates += n_cand;
             RGR_HIP(hipGetLastError());
             b->resolve_spans();
@@ -1525,6 +1531,7 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
                     b->cand_count.ensure(ntl * 4 * 3);                   // per-tile counts (every tile writes its own), then the tiles' topic ranges
                     b->dedup_items.ensure((size_t(nt) + nh / dedup_topic_cap() + 2) * sizeof(DedupItem));
                     if (!b->dedup_scalars.p) { b->dedup_scalars.ensure(16); RGR_HIP(hipMemsetAsync(b->dedup_scalars.p, 0, 16, b->stream)); }
+                    if (!b->dedup_stat.p) { b->dedup_stat.ensure(size_t(dedup_stat_slots()) * 8); RGR_HIP(hipMemsetAsync(b->dedup_stat.p, 0, size_t(dedup_stat_slots()) * 8, b->stream)); }
                     da.cand = b->cand.as<Cand>();
                     da.tile_ncand = b->cand_count.as<uint32_t>();
                     da.tile_trange = b->cand_count.as<uint32_t>() + ntl;
@@ -1556,7 +1563,7 @@ int32_t rgr_batch_next_window(rgr_batch* b, rgr_window* w) {
                 sp = b->span_begin(kSpanDedup);
                 launch_dedup(b->cand.as<Cand>(), b->cand_count.as<uint32_t>(), b->cand_count.as<uint32_t>() + (nh + T - 1) / T, uint32_t((nh + T - 1) / T),
                              b->format == kFmtDeliver8 ? hit8_words(outbuf.p) : tuple_words(outbuf.as<Tuple>()), le - lc, b->c->hit_off.as<uint64_t>() + lc, hit_lo, b->dedup_items.as<DedupItem>(),
-                             reinterpret_cast<uint32_t*>(b->dedup_scalars.as<unsigned long long>() + 1), b->dedup_seq & 1u, b->dedup_scalars.as<unsigned long long>(), b->stream);
+                             reinterpret_cast<uint32_t*>(b->dedup_scalars.as<unsigned long long>() + 1), b->dedup_seq & 1u, b->dedup_stat.as<unsigned long long>(), b->stream);
                 b->dedup_seq++;            // (its own counter, advanced exactly where a launch consumed the parity: ADVICE r5)
                 b->span_end(sp);
                 b->local.dedup_launches++;

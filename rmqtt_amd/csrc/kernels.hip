@@ -171,6 +171,7 @@ template <bool OVF>
 __global__ __launch_bounds__(kWalkThreads) void walk_kernel(TrieView tv, WalkArgs a) {
     __shared__ uint32_t s_tok[OVF ? 1 : kWalkWindow];
     __shared__ uint32_t s_path[OVF ? 1 : kWalkWindow];
+    __shared__ unsigned long long s_visited;         // (statistics only) the block's visited nodes: ONE global atomic per block, not per wave
 
     const int tid = threadIdx.x;
     uint32_t tl;            // chunk-local topic index
@@ -192,6 +193,7 @@ __global__ __launch_bounds__(kWalkThreads) void walk_kernel(TrieView tv, WalkArg
         const uint64_t span = win_end - win_base;
         staged = span < uint64_t(kWalkWindow) ? uint32_t(span) : uint32_t(kWalkWindow);
         for (uint32_t i = tid; i < staged; i += kWalkThreads) s_tok[i] = a.tokens[win_base + i];   // coalesced
+        if (tid == 0) s_visited = 0;
         __syncthreads();
     }
 
@@ -245,8 +247,11 @@ __global__ __launch_bounds__(kWalkThreads) void walk_kernel(TrieView tv, WalkArg
         }
     }
     if (a.visited && !OVF) {
+        // (r6: per WAVE this was 156 k atomics on one address per 10 M topics — 0.7 ms of a 5.6 ms walk when the caller asks for the statistic)
         const unsigned long long v = wave_sum(visited);
-        if ((tid & 63) == 0 && v) atomicAdd(a.visited, v);
+        if ((tid & 63) == 0 && v) atomicAdd(&s_visited, v);
+        __syncthreads();
+        if (tid == 0 && s_visited) atomicAdd(a.visited, s_visited);
     }
 }
 
@@ -1000,6 +1005,7 @@ void launch_node_groups(const Tuple* tuples, const uint64_t* hit_off, uint64_t h
 }
 
 uint32_t dedup_topic_cap() { return kDedupTopicCap; }
+uint32_t dedup_stat_slots() { return 2048; }
 
 void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, const uint32_t* tile_trange, uint32_t ntiles, HitWords tuples, uint32_t nt,
                   const uint64_t* hit_off, uint64_t hit_lo, DedupItem* items, uint32_t* item_counts, uint32_t parity, unsigned long long* stat, void* stream) {
@@ -1008,12 +1014,10 @@ void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, const uint32_t* 
     const uint32_t slots = uint32_t(kDedupTopicSlots);
     // tile pass + classification in one launch (dedup.inc); item_counts[parity] is this window's item counter
 #ifdef RGR_DIAG_TILE_BLOCKS_PER        /* diagnostic builds (r5x): tiles per block of the tile pass instead of a fixed grid of 2 048 blocks */
-    const uint32_t tile_blocks = std::max<uint32_t>(1u, (ntiles + RGR_DIAG_TILE_BLOCKS_PER - 1) / RGR_DIAG_TILE_BLOCKS_PER);
+    const uint32_t tile_blocks = std::min<uint32_t>(dedup_stat_slots(), std::max<uint32_t>(1u, (ntiles + RGR_DIAG_TILE_BLOCKS_PER - 1) / RGR_DIAG_TILE_BLOCKS_PER));
 #else
     const uint32_t tile_blocks = std::min<uint32_t>(ntiles, 2048u);
 #endif
-    dedup_tile_kernel<<<tile_blocks + (nt + 255) / 256, 256, 0, s>>>(cand, tile_ncand, tile_trange, ntiles, hit_off, hit_lo, nt, tuples, stat, tile_blocks, items, item_counts, parity);
-    uint32_t* item_count = item_counts + parity;
     // RGR_DEDUP_TEST_SLOTS (tests only): a smaller table, so that parts overflow and the re-split path runs on ordinary inputs
     // (read on every launch — it is one getenv — so that a test can set it after other tests of the same process have launched)
     const uint32_t max_slots = [&] {
@@ -1022,14 +1026,16 @@ void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, const uint32_t* 
         while (p2 < v && p2 < slots) p2 <<= 1;
         return v ? p2 : slots;
     }();
+    dedup_tile_kernel<<<tile_blocks + (nt + 255) / 256, 256, 0, s>>>(cand, tile_ncand, tile_trange, ntiles, hit_off, hit_lo, nt, tuples, stat, tile_blocks, items, item_counts, parity, max_slots);
+    uint32_t* item_count = item_counts + parity;
     // the item count stays on the device: a fixed grid of persistent blocks (4 per CU fit) strides over the items.
     // RGR_DEDUP_PROBE=0 (A/B switch, read per launch): linear probing and 8-byte table clears, the topic pass as it was until r5f
     // (0.396 -> 0.358 ms per 2^28-hit window with double hashing + 16-byte clears; template parameter — as a kernel argument the same
     // instructions cost 0.515 ms)
     const char* pe = std::getenv("RGR_DEDUP_PROBE");
     const uint32_t grid = kDedupTopicThreads >= 512 ? 1024 : 1280;
-    if (pe && pe[0] == '0') dedup_topic_kernel<0><<<grid, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, hit_off, hit_lo, items, item_count, tuples, max_slots);
-    else dedup_topic_kernel<3><<<grid, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, hit_off, hit_lo, items, item_count, tuples, max_slots);
+    if (pe && pe[0] == '0') dedup_topic_kernel<0><<<grid, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, items, item_count, tuples);
+    else dedup_topic_kernel<3><<<grid, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, items, item_count, tuples);
 }
 
 }  // namespace rgr

@@ -272,9 +272,11 @@ bool launch_expand_compact(const TrieView& t, const ChunkArrays& c, uint64_t pai
 // v5 per-client dedup over a window's candidates (match_core.hpp: LDS tile tables + LDS topic tables): first position per
 // (topic, client) wins, every other candidate gets kHitV5Dup.  hit_off points at the window's first topic (chunk-local
 // offsets, hit_lo = the window's first position); nt = topics of the window; items must hold
-// nt + n_hits / dedup_topic_cap() + 1 entries; *stat accumulates the candidate count.  Everything is stream-ordered: no host sync.
+// nt + n_hits / dedup_topic_cap() + 1 entries; stat[dedup_stat_slots()] accumulates the candidate count (block i of the tile pass adds to stat[i]).  Everything is stream-ordered: no host sync.
 // work item of the topic pass: part `part` of `parts` of window topic `topic` (nc candidates in total)
-struct DedupItem { uint32_t topic, part, parts, nc; };
+// (r6: the item carries the topic's window-relative hit range itself — the topic pass used to fetch it through the topic index, one more dependent
+// round trip per item of a pass that is bound by exactly those)
+struct DedupItem { uint32_t h0, h1, part, parts_slots; };      // hits [h0, h1) of the window; parts_slots = parts | log2(table slots of a part) << 24
 // where the delivery word of window position p lives: the third word of a 12-byte tuple, or the second of an 8-byte hit (RGR_FORMAT_DELIVER8)
 struct HitWords {
     uint32_t* first; uint32_t stride;        // in 32-bit words
@@ -286,6 +288,7 @@ void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, const uint32_t* 
                   const uint64_t* hit_off, uint64_t hit_lo, DedupItem* items, uint32_t* item_counts /* two words, zero when the pass begins */,
                   uint32_t parity /* dedup launches so far in the pass & 1 */, unsigned long long* stat, void* stream);
 uint32_t dedup_topic_cap();
+uint32_t dedup_stat_slots();         // u64 slots of launch_dedup's `stat` array (one per block of the tile pass)
 // Delivery results grouped by node (SubRelationsMap's shape, types.rs:486-497): stable partition of every topic's tuples by
 // one byte (`shift` = 16 or 24) of the delivery word's node index; then the directory of the node groups — called twice: with
 // group_node == null it writes group_cnt[t], with the scanned offsets it writes (node, first position + begin_bias) per group.

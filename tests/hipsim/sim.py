@@ -152,7 +152,9 @@ def dedup(variant, hit_off, cand_pos, cand_client, tile=2048, grid_topic=1024, m
         lo, hi = tl * tile, min(nh, (tl + 1) * tile)
         t_first = int(np.searchsorted(rel, lo, side="right") - 1)
         t_last = int(np.searchsorted(rel, hi - 1, side="right") - 1)
-        whole = t_first != t_last or (rel[t_first] >= lo and rel[t_first + 1] <= lo + tile)
+        # the expansion's flag (expand_tuple.inc tile_whole_topic_flag): two topics meeting in the tile count only when one of them is whole
+        first_whole, last_whole = rel[t_first] >= lo, rel[t_last + 1] <= lo + tile
+        whole = (first_whole and last_whole) if t_first == t_last else (first_whole or last_whole) if t_last - t_first == 1 else True
         if ncand[tl] >= 2 and whole:
             ncand[tl] |= 1 << 31
             trange[2 * tl], trange[2 * tl + 1] = t_first, t_last
