@@ -671,6 +671,12 @@ __global__ __launch_bounds__(256) void pack_subs_kernel(const SubEntry* __restri
     if (i < n) { const SubEntry e = subs[i]; packed[i] = e.sub_id | ((e.qos_flags & 3u) << 30); }
 }
 
+// (r6y) the delivery stage's packed side array (TrieView::subs_dpacked): the whole entry — id, node index, flags, qos — in 4 bytes
+__global__ __launch_bounds__(256) void pack_subs_deliver_kernel(const SubEntry* __restrict__ subs, uint64_t n, uint32_t* __restrict__ packed, uint32_t sb, uint32_t nb) {
+    const uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i < n) { const SubEntry e = subs[i]; packed[i] = e.sub_id | ((e.qos_flags >> 16) << sb) | (((e.qos_flags >> 8) & 0xFFu) << (sb + nb)) | ((e.qos_flags & 3u) << 30); }
+}
+
 #include "expand_compact.inc"
 
 #include "dedup.inc"
@@ -896,7 +902,12 @@ void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, ui
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (deliver && hits8) {          // RGR_FORMAT_DELIVER8 (r6): the lean expansion writing {sub_id, word} per hit
         const char* g = std::getenv("RGR_DELIVER_LEAN");
+        // (r6y) the entries from the 4-byte delivery-packed side array when the table has one (RGR_DELIVER_PACKED_READS=0, read per launch: the 8-byte entries)
+        const char* pk = std::getenv("RGR_DELIVER_PACKED_READS");
+        DeliverArgs da = *deliver;
+        if (t.subs_dpacked && !(pk && pk[0] == '0')) { da.dpacked = t.subs_dpacked; da.dp_sb = t.dp_sb; da.dp_nb = t.dp_nb; }
         if (g && g[0] == '2') expand_deliver_lean_kernel<kTile / 8, 8, true><<<ntiles, kTile / 8, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, *deliver);
+        else if (da.dpacked) expand_deliver_lean_kernel<kTile / 4, 4, true, true><<<ntiles, kTile / 4, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, da);
         else expand_deliver_lean_kernel<kTile / 4, 4, true><<<ntiles, kTile / 4, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, *deliver);
         return;
     }
@@ -987,6 +998,10 @@ void launch_pack_subs(const SubEntry* subs, uint64_t n, uint32_t* packed, void* 
     if (n) pack_subs_kernel<<<uint32_t((n + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(subs, n, packed);
 }
 
+void launch_pack_subs_deliver(const SubEntry* subs, uint64_t n, uint32_t* packed, uint32_t sb, uint32_t nb, void* stream) {
+    if (n) pack_subs_deliver_kernel<<<uint32_t((n + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(subs, n, packed, sb, nb);
+}
+
 void launch_pack_runs(const uint32_t* src, const uint32_t* topic, const uint64_t* off, uint64_t n, uint32_t shard, RunDesc* out, void* stream) {
     if (n) pack_runs_kernel<<<uint32_t((n + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(src, topic, off, n, shard, out);
 }
@@ -1026,7 +1041,10 @@ void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, const uint32_t* 
         while (p2 < v && p2 < slots) p2 <<= 1;
         return v ? p2 : slots;
     }();
-    dedup_tile_kernel<<<tile_blocks + (nt + 255) / 256, 256, 0, s>>>(cand, tile_ncand, tile_trange, ntiles, hit_off, hit_lo, nt, tuples, stat, tile_blocks, items, item_counts, parity, max_slots);
+    // RGR_DEDUP_SLOT_FACTOR (A/B, r6t): table slots per candidate of a part (2: load factor 0.25-0.5; 4: 0.125-0.25, capped by the 32 KiB table)
+    const char* sf = std::getenv("RGR_DEDUP_SLOT_FACTOR");
+    const uint32_t slot_factor = sf && std::atoi(sf) >= 2 && std::atoi(sf) <= 16 ? uint32_t(std::atoi(sf)) : 2u;
+    dedup_tile_kernel<<<tile_blocks + (nt + 255) / 256, 256, 0, s>>>(cand, tile_ncand, tile_trange, ntiles, hit_off, hit_lo, nt, tuples, stat, tile_blocks, items, item_counts, parity, max_slots, slot_factor);
     uint32_t* item_count = item_counts + parity;
     // the item count stays on the device: a fixed grid of persistent blocks (4 per CU fit) strides over the items.
     // RGR_DEDUP_PROBE=0 (A/B switch, read per launch): linear probing and 8-byte table clears, the topic pass as it was until r5f
@@ -1034,8 +1052,12 @@ void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, const uint32_t* 
     // instructions cost 0.515 ms)
     const char* pe = std::getenv("RGR_DEDUP_PROBE");
     const uint32_t grid = kDedupTopicThreads >= 512 ? 1024 : 1280;
+    // RGR_DEDUP_PROBE=3: the lists read 64 entries at a time, as until r6s (=7, the default: the first 256 entries of a tile's list in one request,
+    // 0.1404 -> 0.1289 ms of dedup per window); =a: the form that also fetches the next item ahead (slower: 0.152, profiles/r06t_*)
     if (pe && pe[0] == '0') dedup_topic_kernel<0><<<grid, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, items, item_count, tuples);
-    else dedup_topic_kernel<3><<<grid, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, items, item_count, tuples);
+    else if (pe && pe[0] == '3') dedup_topic_kernel<3><<<grid, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, items, item_count, tuples);
+    else if (pe && pe[0] == 'a') dedup_topic_ahead_kernel<<<grid, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, items, item_count, tuples);
+    else dedup_topic_kernel<7><<<grid, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, items, item_count, tuples);
 }
 
 }  // namespace rgr

@@ -537,8 +537,8 @@ RGR_HD inline bool dedup_topic_is_dup(uint32_t client, uint32_t pos, uint32_t ma
     }
 }
 // Slots a part's table uses: a power of two >= 2 x its expected candidates (+ slack), within [64, max_slots].
-RGR_HD inline uint32_t dedup_topic_slots(uint32_t nc, uint32_t parts, uint32_t max_slots) {
-    const uint32_t want = 2u * ((nc + parts - 1) / parts) + 16u;
+RGR_HD inline uint32_t dedup_topic_slots(uint32_t nc, uint32_t parts, uint32_t max_slots, uint32_t factor = 2u) {
+    const uint32_t want = factor * ((nc + parts - 1) / parts) + 16u;
     uint32_t len = 64;
     while (len < want && len < max_slots) len <<= 1;
     return len;
