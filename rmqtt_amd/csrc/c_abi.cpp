@@ -77,9 +77,7 @@ struct EdgeImage { DevBuf buf; uint64_t cap = 0; std::vector<uint32_t> pending; 
 struct FiltImage { DevBuf buf; uint64_t cap = 0; std::vector<uint32_t> pending; bool need_full = true; };
 // attr_buf: SubAttr parallel to buf; packed_buf: sub_id | qos << 30 parallel to buf (TrieView::subs_packed), filled on the device
 // for every range of entries a commit uploads
-// dpacked_buf (r6y): the delivery stage's 4-byte entries (TrieView::subs_dpacked), built with the attributes; dp_sb / dp_nb / dp_fb: the bit widths of
-// id / node index / flags chosen when the pool was (re)built — a commit whose table no longer fits them rebuilds the pool (the maxima only grow)
-struct SubsPool { DevBuf buf, attr_buf, packed_buf, dpacked_buf; uint64_t used = 0, cap = 0; bool has_attrs = false; bool dp_ok = false; uint32_t dp_sb = 0, dp_nb = 0, dp_fb = 0; };
+struct SubsPool { DevBuf buf, attr_buf, packed_buf; uint64_t used = 0, cap = 0; bool has_attrs = false; };
 
 struct Epoch {
     std::shared_ptr<DictImage> dict;
@@ -1011,14 +1009,8 @@ int32_t rgr_commit(rgr_handle* h) {
                 for (size_t i = 0; i < run.size(); ++i) at[i] = h->table.sub_attr(run[i].sub_id);
                 return at;
             };
-            auto bits = [](uint32_t v) { uint32_t b = 0; while (v >> b) ++b; return b; };            // bits needed for values 0 .. v
-            const uint32_t need_nb = bits(h->table.max_node_idx()), need_fb = bits(h->table.flags_or());
-            auto dp_fits = [&](const SubsPool& sp) {
-                return need_nb <= sp.dp_nb && need_fb <= sp.dp_fb && h->table.max_qos() < 4 && (sp.dp_sb >= 32 || h->table.max_sub_id() < (1ull << sp.dp_sb));
-            };
             bool rebuild = !h->sub_pool || h->sub_pool->used + add > h->sub_pool->cap || h->sub_pool->used + add > 0xFFFFFF00ull ||
-                           h->pool_garbage > h->table.n_subs() + (1u << 16) || attrs_dirty || (want_attrs && !h->sub_pool->has_attrs) ||
-                           (h->sub_pool->dp_ok && !dp_fits(*h->sub_pool));
+                           h->pool_garbage > h->table.n_subs() + (1u << 16) || attrs_dirty || (want_attrs && !h->sub_pool->has_attrs);
             if (rebuild) {
                 std::vector<FilterDesc> filt;
                 std::vector<SubEntry> subs;
@@ -1035,15 +1027,6 @@ int32_t rgr_commit(rgr_handle* h) {
                     const auto at = gather_attrs(subs);
                     if (!at.empty()) RGR_HIP(hipMemcpy(np->attr_buf.p, at.data(), at.size() * sizeof(SubAttr), hipMemcpyHostToDevice));
                     np->has_attrs = true;
-                    // the delivery-packed entries: widths from what the table holds today, every spare bit to the ids
-                    if (need_nb + need_fb < 30 && h->table.max_qos() < 4) {
-                        np->dp_nb = need_nb; np->dp_fb = need_fb; np->dp_sb = 30 - need_nb - need_fb;
-                        if (h->table.max_sub_id() < (1ull << np->dp_sb)) {
-                            np->dpacked_buf.ensure((np->cap + kPackedPad) * 4);
-                            launch_pack_subs_deliver(np->buf.as<SubEntry>(), np->used, np->dpacked_buf.as<uint32_t>(), np->dp_sb, np->dp_nb, nullptr);
-                            np->dp_ok = true;
-                        }
-                    }
                 }
                 h->sub_pool = np;
                 h->host_desc = filt;
@@ -1063,9 +1046,6 @@ int32_t rgr_commit(rgr_handle* h) {
                 {
                     RGR_HIP(hipMemcpy(h->sub_pool->buf.as<SubEntry>() + h->sub_pool->used, stage.data(), stage.size() * sizeof(SubEntry), hipMemcpyHostToDevice));
                     launch_pack_subs(h->sub_pool->buf.as<SubEntry>() + h->sub_pool->used, stage.size(), h->sub_pool->packed_buf.as<uint32_t>() + h->sub_pool->used, nullptr);
-                    if (h->sub_pool->dp_ok)
-                        launch_pack_subs_deliver(h->sub_pool->buf.as<SubEntry>() + h->sub_pool->used, stage.size(), h->sub_pool->dpacked_buf.as<uint32_t>() + h->sub_pool->used,
-                                                 h->sub_pool->dp_sb, h->sub_pool->dp_nb, nullptr);
                 }
                 if (!stage.empty() && h->sub_pool->has_attrs) {
                     const auto at = gather_attrs(stage);
@@ -1108,15 +1088,13 @@ int32_t rgr_commit(rgr_handle* h) {
             ep->n_v5 = h->table.n_v5_subs();
             ep->max_sub_id = h->table.max_sub_id();
             ep->view.subs_packed = ep->max_sub_id < (1u << 30) ? h->sub_pool->packed_buf.as<uint32_t>() : nullptr;
-            ep->view.subs_dpacked = h->sub_pool->dp_ok ? h->sub_pool->dpacked_buf.as<uint32_t>() : nullptr;
-            ep->view.dp_sb = h->sub_pool->dp_sb; ep->view.dp_nb = h->sub_pool->dp_nb;
             RGR_HIP(hipDeviceSynchronize());            // (the pack kernels above ran on the null stream; the epoch is published below)
             ep->max_node_idx = h->table.max_node_idx();
             ep->n_filters = h->table.n_filters();
             ep->n_subs = h->table.n_subs();
             ep->n_nodes = h->table.n_nodes();
             ep->edge_slots = edges.size();
-            ep->bytes = ei.buf.bytes + fi.buf.bytes + h->sub_pool->buf.bytes + h->sub_pool->attr_buf.bytes + h->sub_pool->packed_buf.bytes + h->sub_pool->dpacked_buf.bytes;
+            ep->bytes = ei.buf.bytes + fi.buf.bytes + h->sub_pool->buf.bytes + h->sub_pool->attr_buf.bytes + h->sub_pool->packed_buf.bytes;
         }
         recover.armed = false;
         std::lock_guard<std::mutex> g(h->epoch_mu);

@@ -671,12 +671,6 @@ __global__ __launch_bounds__(256) void pack_subs_kernel(const SubEntry* __restri
     if (i < n) { const SubEntry e = subs[i]; packed[i] = e.sub_id | ((e.qos_flags & 3u) << 30); }
 }
 
-// (r6y) the delivery stage's packed side array (TrieView::subs_dpacked): the whole entry — id, node index, flags, qos — in 4 bytes
-__global__ __launch_bounds__(256) void pack_subs_deliver_kernel(const SubEntry* __restrict__ subs, uint64_t n, uint32_t* __restrict__ packed, uint32_t sb, uint32_t nb) {
-    const uint64_t i = uint64_t(blockIdx.x) * 256 + threadIdx.x;
-    if (i < n) { const SubEntry e = subs[i]; packed[i] = e.sub_id | ((e.qos_flags >> 16) << sb) | (((e.qos_flags >> 8) & 0xFFu) << (sb + nb)) | ((e.qos_flags & 3u) << 30); }
-}
-
 #include "expand_compact.inc"
 
 #include "dedup.inc"
@@ -902,12 +896,7 @@ void launch_expand(const TrieView& t, const ChunkArrays& c, uint64_t pair_lo, ui
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (deliver && hits8) {          // RGR_FORMAT_DELIVER8 (r6): the lean expansion writing {sub_id, word} per hit
         const char* g = std::getenv("RGR_DELIVER_LEAN");
-        // (r6y) the entries from the 4-byte delivery-packed side array when the table has one (RGR_DELIVER_PACKED_READS=0, read per launch: the 8-byte entries)
-        const char* pk = std::getenv("RGR_DELIVER_PACKED_READS");
-        DeliverArgs da = *deliver;
-        if (t.subs_dpacked && !(pk && pk[0] == '0')) { da.dpacked = t.subs_dpacked; da.dp_sb = t.dp_sb; da.dp_nb = t.dp_nb; }
         if (g && g[0] == '2') expand_deliver_lean_kernel<kTile / 8, 8, true><<<ntiles, kTile / 8, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, *deliver);
-        else if (da.dpacked) expand_deliver_lean_kernel<kTile / 4, 4, true, true><<<ntiles, kTile / 4, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, da);
         else expand_deliver_lean_kernel<kTile / 4, 4, true><<<ntiles, kTile / 4, 0, s>>>(t.subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tile_first, ntiles, out, *deliver);
         return;
     }
@@ -996,10 +985,6 @@ bool launch_expand_compact(const TrieView& t, const ChunkArrays& c, uint64_t pai
 
 void launch_pack_subs(const SubEntry* subs, uint64_t n, uint32_t* packed, void* stream) {
     if (n) pack_subs_kernel<<<uint32_t((n + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(subs, n, packed);
-}
-
-void launch_pack_subs_deliver(const SubEntry* subs, uint64_t n, uint32_t* packed, uint32_t sb, uint32_t nb, void* stream) {
-    if (n) pack_subs_deliver_kernel<<<uint32_t((n + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(subs, n, packed, sb, nb);
 }
 
 void launch_pack_runs(const uint32_t* src, const uint32_t* topic, const uint64_t* off, uint64_t n, uint32_t shard, RunDesc* out, void* stream) {

@@ -84,8 +84,6 @@ struct DeliverArgs {
     uint32_t* tile_trange;       // [2 * tiles] window-relative first / last topic with hits in the tile (written with the tile's flag: bounds the
                                  // tile-local dedup's search for a candidate's topic)
     uint32_t topic_lo;           // first topic of the window (batch-global index)
-    const uint32_t* dpacked = nullptr;   // TrieView::subs_dpacked (set by launch_expand for the kernels that read it)
-    uint32_t dp_sb = 0, dp_nb = 0;
 };
 
 // Level-string dictionary image (host: table.cpp StringDict; device: one copy per epoch).
@@ -133,11 +131,6 @@ struct TrieView {
     // parallel to subs: sub_id | (qos & 3) << 30, 4 bytes per entry (null when some id needs 31+ bits or the array was not built).
     // What RGR_FORMAT_PACKED writes per hit, and RGR_FORMAT_IDS24 after masking: those expansions read 4 bytes per hit instead of 8.
     const uint32_t* subs_packed = nullptr;
-    // (r6y) parallel to subs, for the delivery stage: sub_id | node_idx << dp_sb | flags << (dp_sb + dp_nb) | qos << 30 — the whole 8-byte entry in
-    // 4 bytes when the table's ids, node indices and flag bits fit 30 bits together and every qos is < 4 (null otherwise).  The delivery expansion
-    // moves as many bytes from the Infinity Cache as it writes to HBM; this halves the first.
-    const uint32_t* subs_dpacked = nullptr;
-    uint32_t dp_sb = 0, dp_nb = 0;
 };
 
 // ---- RetainTree twin (rmqtt/src/retain.rs): trie of concrete retained topics, nodes numbered
@@ -304,7 +297,6 @@ void launch_node_groups(const Tuple* tuples, const uint64_t* hit_off, uint64_t h
                         uint32_t* group_node, uint64_t* group_begin, uint64_t begin_bias, void* stream);
 // run descriptors of a window packed for the exchange step (== rgr_run)
 struct RunDesc { uint32_t shard, src, len, topic; };
-void launch_pack_subs_deliver(const SubEntry* subs, uint64_t n, uint32_t* packed, uint32_t sb, uint32_t nb, void* stream);
 void launch_pack_runs(const uint32_t* src, const uint32_t* topic, const uint64_t* off, uint64_t n, uint32_t shard, RunDesc* out, void* stream);
 // walk order of a publish batch (order.hip): sort by the first two level tokens, gather the token arrays into that order
 size_t order_sort_temp_bytes(uint32_t n);

@@ -313,8 +313,6 @@ int32_t HostTable::sub_add(uint32_t fid, uint32_t sub_id, uint8_t qos, uint8_t f
     const uint64_t is_v5 = (flags & kSubV5) ? 1 : 0;
     if (sub_id > max_sub_id_) max_sub_id_ = sub_id;
     if (node_idx > max_node_idx_) max_node_idx_ = node_idx;
-    flags_or_ |= flags;
-    if (qos > max_qos_) max_qos_ = qos;
     if (v.empty() || v.back().sub_id < sub_id) { v.push_back(e); n_subs_++; n_v5_ += is_v5; return RGR_OK; }
     auto it = std::lower_bound(v.begin(), v.end(), sub_id, [](const SubEntry& a, uint32_t b) { return a.sub_id < b; });
     if (it != v.end() && it->sub_id == sub_id) {                             // re-subscribe: options replaced
@@ -757,21 +755,15 @@ bool HostTable::load(const std::string& path, std::string* err) {
     uint64_t used = 0, live = 0, n_v5 = 0, live_filters = 0;
     for (const EdgeEntry& e : t.edges_) { if (e.parent == kEdgeEmpty) continue; used++; if (e.parent != kEdgeTomb) live++; }
     for (uint64_t i = 0; i < nf; ++i) if (fnode[i] != kNone) live_filters++;
-    uint32_t max_sub = 0, max_node = 0, flags_or = 0, max_qos = 0;
-    for (const SubEntry& se : subs) {
-        if ((se.qos_flags >> 8) & kSubV5) n_v5++;
-        if (se.sub_id > max_sub) max_sub = se.sub_id;
-        if ((se.qos_flags >> 16) > max_node) max_node = se.qos_flags >> 16;
-        flags_or |= (se.qos_flags >> 8) & 0xFFu;
-        if ((se.qos_flags & 0xFFu) > max_qos) max_qos = se.qos_flags & 0xFFu;
-    }
+    uint32_t max_sub = 0, max_node = 0;
+    for (const SubEntry& se : subs) { if ((se.qos_flags >> 8) & kSubV5) n_v5++; if (se.sub_id > max_sub) max_sub = se.sub_id; if ((se.qos_flags >> 16) > max_node) max_node = se.qos_flags >> 16; }
     const uint64_t n_nodes = t.nodes_.size() - t.free_nodes_.size();
     if (used * 2 > t.edges_.size()) return bad("edge table over its load limit");
     if (t.free_nodes_.size() >= t.nodes_.size() || live + 1 != n_nodes) return bad("trie node count mismatch");
     if (h.edge_used != used || h.edge_live != live || h.n_nodes != n_nodes || h.n_filters != live_filters || h.n_v5 != n_v5 ||
         t.free_fids_.size() + live_filters != nf)
         return bad("header counters do not match the arrays");
-    t.n_filters_ = live_filters; t.n_subs_ = total; t.n_nodes_ = n_nodes; t.n_v5_ = n_v5; t.max_sub_id_ = max_sub; t.max_node_idx_ = max_node; t.flags_or_ = flags_or; t.max_qos_ = max_qos;
+    t.n_filters_ = live_filters; t.n_subs_ = total; t.n_nodes_ = n_nodes; t.n_v5_ = n_v5; t.max_sub_id_ = max_sub; t.max_node_idx_ = max_node;
     t.edge_used_ = used; t.edge_live_ = live;
     if (h.version == 1) t.rebuild_child_bitmaps();
     t.has_attrs_ = ha != 0;

@@ -132,8 +132,6 @@ class HostTable {
     uint64_t n_v5_subs() const { return n_v5_; }
     uint32_t max_sub_id() const { return max_sub_id_; }   // upper bound of the sub ids ever added
     uint32_t max_node_idx() const { return max_node_idx_; }   // upper bound of the node indices ever added (rgr_sub_add_ex)
-    uint32_t flags_or() const { return flags_or_; }           // OR of the RGR_SUB_* flag bytes ever added
-    uint32_t max_qos() const { return max_qos_; }             // upper bound of the qos bytes ever added
     int32_t sub_remove(uint32_t fid, uint32_t sub_id);
     // Restore / bulk path (rmqtt-cluster-raft/src/router.rs:557-566 re-inserts every filter after a
     // snapshot): filter_add + sub_add for n subscriptions.  Tokenises on `threads` threads, sorts the
@@ -202,7 +200,6 @@ class HostTable {
     uint64_t n_filters_ = 0, n_subs_ = 0, n_nodes_ = 1, n_v5_ = 0;
     uint32_t max_sub_id_ = 0;
     uint32_t max_node_idx_ = 0;
-    uint32_t flags_or_ = 0, max_qos_ = 0;
     std::vector<SubAttr> attrs_;
     bool has_attrs_ = false, attrs_all_dirty_ = false;
     uint64_t dict_gen_ = 0;

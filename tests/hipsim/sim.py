@@ -206,7 +206,7 @@ def expand_tuple(variant, subs, attrs, pub, pair_src, pair_topic, pair_off, pair
     pair_qr = np.ascontiguousarray(pair_qr, dtype=np.uint8)
     nh = int(pair_off[pair_hi] - pair_off[pair_lo])
     ntiles = (nh + tile - 1) // tile
-    hits8 = variant in (5, 6, 7)                     # 8-byte hits {sub_id, word}: the buffer is sized for them and guarded right behind
+    hits8 = variant in (5, 6)                       # 8-byte hits {sub_id, word}: the buffer is sized for them and guarded right behind
     out = np.zeros(nh + 1, dtype=HIT8_DTYPE if hits8 else TUPLE_DTYPE)
     out[nh] = (0xA5A5A5A5, 0xA5A5A5A5) if hits8 else (0xA5A5A5A5, 0xA5A5A5A5, 0xA5A5A5A5)
     deliver = variant != 0

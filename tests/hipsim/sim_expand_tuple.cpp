@@ -3,9 +3,6 @@
 // (RGR_DELIVER_EARLY).  tests/test_hipsim_expand_tuple.py compares with a numpy restatement of the per-hit rules.
 #include "hipsim.hpp"
 
-#include <algorithm>
-#include <vector>
-
 #include "kernels.hpp"
 #include "match_core.hpp"
 
@@ -23,8 +20,7 @@ using namespace rgr;
 extern "C" {
 
 // variant 0: expand_kernel<false, 1024, 2> (tuples only), 1: expand_kernel<true, 512, 4>, 2: expand_deliver_early_kernel<512, 4>,
-// 3: expand_deliver_lean_kernel<512, 4> (r5: v5 hits compacted per wave), 4: expand_deliver_lean_kernel<256, 8>, 5 / 6: the same two with 8-byte hits,
-// 7: 5 reading its entries from the 4-byte delivery-packed side array (-5: the entries do not fit 30 bits).
+// 3: expand_deliver_lean_kernel<512, 4> (r5: v5 hits compacted per wave), 4: expand_deliver_lean_kernel<256, 8>, 5 / 6: the same two with 8-byte hits.
 // cand / tile_ncand / tile_trange may be null (an epoch without v5 subscriptions).  Returns 0, -1 unknown variant, -2 divergence.
 int32_t sim_expand_tuple(int32_t variant, const SubEntry* subs, const SubAttr* attrs, const PublishAttr* pub, const uint32_t* pair_src,
                          const uint32_t* pair_topic, const uint64_t* pair_off, const uint8_t* pair_qr, uint64_t pair_lo, uint64_t pair_hi, uint32_t topic_lo,
@@ -52,27 +48,6 @@ int32_t sim_expand_tuple(int32_t variant, const SubEntry* subs, const SubAttr* a
     // 5 / 6: the lean variants writing 8-byte hits {sub_id, delivery word} (RGR_FORMAT_DELIVER8) into the same buffer
     else if (variant == 5) ok = hipsim::run(ntiles, 512, [&] { expand_deliver_lean_kernel<512, 4, true>(subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tf, ntiles, out, da); });
     else if (variant == 6) ok = hipsim::run(ntiles, 256, [&] { expand_deliver_lean_kernel<256, 8, true>(subs, c, pair_lo, pair_hi, hit_lo, hit_hi, tf, ntiles, out, da); });
-    else if (variant == 7) {
-        // (r6y) 5 with the entries read from the 4-byte delivery-packed side array (TrieView::subs_dpacked), built here the way rgr_commit builds it:
-        // widths from what the entries hold, every spare bit to the ids; exactly as long as the pool the window's pairs reach
-        uint64_t n = 0;
-        for (uint64_t p = pair_lo; p < pair_hi; ++p) n = std::max<uint64_t>(n, pair_src[p] + (pair_off[p + 1] - pair_off[p]));
-        uint32_t max_id = 0, max_node = 0, flags_or = 0, max_qos = 0;
-        for (uint64_t i = 0; i < n; ++i) {
-            max_id = std::max(max_id, subs[i].sub_id); max_node = std::max(max_node, subs[i].qos_flags >> 16);
-            flags_or |= (subs[i].qos_flags >> 8) & 0xFFu; max_qos = std::max(max_qos, subs[i].qos_flags & 0xFFu);
-        }
-        auto bits = [](uint32_t v) { uint32_t b = 0; while (v >> b) ++b; return b; };
-        const uint32_t nb = bits(max_node), fb = bits(flags_or);
-        if (nb + fb >= 30 || max_qos > 3) return -5;
-        const uint32_t sb = 30 - nb - fb;
-        if (max_id >> sb) return -5;
-        std::vector<uint32_t> dp(n);
-        for (uint64_t i = 0; i < n; ++i)
-            dp[i] = subs[i].sub_id | ((subs[i].qos_flags >> 16) << sb) | (((subs[i].qos_flags >> 8) & 0xFFu) << (sb + nb)) | ((subs[i].qos_flags & 3u) << 30);
-        da.dpacked = dp.data(); da.dp_sb = sb; da.dp_nb = nb;
-        ok = hipsim::run(ntiles, 512, [&] { expand_deliver_lean_kernel<512, 4, true, true>(nullptr, c, pair_lo, pair_hi, hit_lo, hit_hi, tf, ntiles, out, da); });
-    }
     else return -1;
     return ok ? 0 : -2;
 }

@@ -78,24 +78,5 @@ int main() {
                     (unsigned long long)hits, (unsigned long long)dn);
         bad += rc != 0 || dw || dn;
     }
-    // (r6y) the 8-byte-hit kernel reading its entries from the 4-byte delivery-packed side array (exactly as long as the pool): ids cut to the 20 bits
-    // that 30 leave beside 6 bits of node index and 4 of flags, variant 7 against variant 5 on the same entries
-    {
-        std::vector<SubEntry> subs20 = subs;
-        for (auto& e : subs20) e.sub_id &= (1u << 20) - 1u;
-        std::vector<unsigned long long> o5(hits, 0), o7(hits, 0);
-        std::vector<Cand> c5(size_t(ntiles) * kTile, Cand{kNone, kNone}), c7 = c5;
-        std::vector<uint32_t> n5(ntiles, 0xDEADBEEFu), n7 = n5, r5(2 * size_t(ntiles), 0xDEADBEEFu), r7 = r5;
-        const int rc5 = sim_expand_tuple(5, subs20.data(), attrs.data(), pub.data(), src.data(), ptopic.data(), off.data(), qr.data(), 0, np, topic_lo,
-                                         reinterpret_cast<Tuple*>(o5.data()), c5.data(), n5.data(), r5.data());
-        const int rc7 = sim_expand_tuple(7, subs20.data(), attrs.data(), pub.data(), src.data(), ptopic.data(), off.data(), qr.data(), 0, np, topic_lo,
-                                         reinterpret_cast<Tuple*>(o7.data()), c7.data(), n7.data(), r7.data());
-        uint64_t dw = 0, dn = 0;
-        for (uint64_t i = 0; i < hits; ++i) dw += o5[i] != o7[i];
-        for (uint32_t t = 0; t < ntiles; ++t) dn += n5[t] != n7[t];
-        std::printf("variant 7 (entries from 4 bytes) vs variant 5: rc %d / %d, %llu of %llu hits differ, %llu count words differ\n", rc5, rc7, (unsigned long long)dw,
-                    (unsigned long long)hits, (unsigned long long)dn);
-        bad += rc5 != 0 || rc7 != 0 || dw || dn;
-    }
     return bad ? 1 : 0;
 }

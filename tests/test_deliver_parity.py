@@ -555,77 +555,3 @@ def test_deliver8_windows_equal_the_delivery_tuples(window_hits):
         pass
     b.close(); r.close()
 
-
-@pytest.mark.gpu
-def test_deliver8_entries_from_four_bytes_follow_the_table(monkeypatch):
-    """(r6y) The 8-byte-hit expansion reads its entries from a 4-byte side array — id, node index, flags and qos packed into 30 + 2 bits — whenever the
-    table's ids / node indices / flag bits fit; rgr_commit chooses the widths when it (re)builds the pool and rebuilds when an appended subscription
-    no longer fits them, and a table that cannot fit at all answers from the 8-byte entries.  Every stage of such a table's life: the 8-byte hits equal
-    the delivery tuples (whose kernel reads the 8-byte entries), with the packed reads on and off."""
-    rng = np.random.default_rng(11)
-    r = capi.Router(device=0, window_hits=1 << 14)
-    fids = [r.filter_add(f) for f in ["a/#", "a/b/c", "+/+/+", "#"]]
-    sid = [0]
-
-    def add(fid, n, id_base=0, node=lambda c: c % 3, flag_extra=0):
-        for c in rng.choice(6000, size=n, replace=False):
-            v5 = rng.random() < 0.5
-            flags = (capi.RGR_SUB_V5 | (capi.RGR_SUB_NO_LOCAL if rng.random() < 0.3 else 0) | (capi.RGR_SUB_RAP if rng.random() < 0.5 else 0)) if v5 else 0
-            r.sub_add_ex(fid, id_base + sid[0], int(rng.integers(0, 3)), flags | flag_extra, int(node(int(c))), int(c), int(c))
-            sid[0] += 1
-    topics = ["a/b/c", "x/y", "a/b", "a/b/c", "q/r/s", "a/b/c/d"] * 4
-    blob, offs = pack(topics)
-    attrs = np.zeros(len(topics), dtype=capi.PUBLISH_ATTR_DTYPE)
-    attrs["from_id"] = rng.integers(0, 6000, size=len(topics))
-    attrs["qos_retain"] = rng.integers(0, 3, size=len(topics)) | (rng.integers(0, 2, size=len(topics)) << 2)
-
-    def hits(fmt):
-        b = r.batch(blob, offs)
-        b.set_publish_attrs(attrs)
-        b.set_format(fmt)
-        b.begin()
-        out = []
-        while True:
-            w = b.next_window()
-            if w is None:
-                return out
-            nh = int(w.n_hits)
-            o = np.zeros(w.topic_end - w.topic_begin + 1, dtype=np.uint64)
-            assert capi.lib().rgr_window_to_host(b._b, C.byref(w), None, o.ctypes.data) == 0
-            if not nh:
-                continue
-            if fmt == capi.RGR_FORMAT_DELIVER8:
-                h = capi.device_to_host(w.d_hits8, nh * 8).view(np.dtype([("sub_id", np.uint32), ("word", np.uint32)]))
-                out.append((h["sub_id"].copy(), h["word"].copy()))
-            else:
-                t = capi.device_to_host(w.d_tuples, nh * 12).view(capi.TUPLE_DTYPE)
-                out.append((t["sub_id"].copy(), t["qos_flags"].copy()))
-
-    def check(min_hits):
-        ref = hits(capi.RGR_FORMAT_TUPLE)
-        assert sum(len(x[0]) for x in ref) >= min_hits
-        for packed_reads in ("1", "0"):
-            monkeypatch.setenv("RGR_DELIVER_PACKED_READS", packed_reads)
-            got = hits(capi.RGR_FORMAT_DELIVER8)
-            assert len(got) == len(ref)
-            for (s0, w0), (s1, w1) in zip(ref, got):
-                assert np.array_equal(s0, s1) and np.array_equal(w0, w1), packed_reads
-        monkeypatch.delenv("RGR_DELIVER_PACKED_READS")
-    # 1. small ids, three nodes, four flag bits: packed with room to spare
-    add(fids[0], 3000); add(fids[1], 2500); add(fids[2], 1500)
-    r.commit()
-    check(60000)
-    # 2. appended runs that still fit the widths chosen at the build (an id of 23 bits beside 2 + 4)
-    add(fids[3], 40, id_base=1 << 22)
-    r.commit()
-    check(60000)
-    # 3. a node index of 10 bits and a table nibble (8 flag bits): the appended run no longer fits -> the pool is rebuilt with new widths (12 bits of
-    # id are not enough for the ids above: this table answers from the 8-byte entries)
-    add(fids[1], 30, node=lambda c: 700 + c % 5, flag_extra=0x30)
-    r.commit()
-    check(60000)
-    # 4. ids that need all 32 bits: never packable
-    add(fids[0], 20, id_base=0xFFFF0000)
-    r.commit()
-    check(60000)
-    r.close()

@@ -137,16 +137,6 @@ def test_tuple_expansions_source_on_host(case):
         h8, l8, n8, r8 = sim.expand_tuple(lean + 2, *args)
         assert np.array_equal(h8["sub_id"], t1["sub_id"]) and np.array_equal(h8["word"], t1["qos_flags"])
         assert l8 == l1 and np.array_equal(n8, n1) and np.array_equal(r8.reshape(-1, 2)[flagged], r1.reshape(-1, 2)[flagged])
-    # ... and (r6y) the 8-byte-hit kernel reading its entries from the 4-byte delivery-packed side array: ids cut to what 30 bits leave beside the
-    # node indices (< 40: 6 bits) and the flag nibble, then the same hits, candidate sets and count words as from the 8-byte entries
-    Wp = dict(W)
-    Wp["subs"] = W["subs"].copy()
-    Wp["subs"]["sub_id"] &= (1 << 20) - 1
-    argsp = (Wp["subs"],) + tuple(args[1:])
-    h5, l5, n5, r5 = sim.expand_tuple(5, *argsp)
-    h7, l7, n7, r7 = sim.expand_tuple(7, *argsp)
-    assert np.array_equal(h7, h5) and l7 == l5 and np.array_equal(n7, n5) and np.array_equal(r7, r5)
-    assert np.array_equal(h5["word"], t1["qos_flags"])            # (the words do not depend on the ids)
 
 
 # ---- property: ANY window (topics of 0 .. 12 runs of 1 .. 5 000 hits, any v5 fraction) through the lean delivery expansion equals the
