@@ -1038,10 +1038,9 @@ void launch_dedup(const Cand* cand, const uint32_t* tile_ncand, const uint32_t* 
     const char* pe = std::getenv("RGR_DEDUP_PROBE");
     const uint32_t grid = kDedupTopicThreads >= 512 ? 1024 : 1280;
     // RGR_DEDUP_PROBE=3: the lists read 64 entries at a time, as until r6s (=7, the default: the first 256 entries of a tile's list in one request,
-    // 0.1404 -> 0.1289 ms of dedup per window); =a: the form that also fetches the next item ahead (slower: 0.152, profiles/r06t_*)
+    // 0.1404 -> 0.1289 ms of dedup per window, profiles/r06s_*)
     if (pe && pe[0] == '0') dedup_topic_kernel<0><<<grid, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, items, item_count, tuples);
     else if (pe && pe[0] == '3') dedup_topic_kernel<3><<<grid, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, items, item_count, tuples);
-    else if (pe && pe[0] == 'a') dedup_topic_ahead_kernel<<<grid, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, items, item_count, tuples);
     else dedup_topic_kernel<7><<<grid, kDedupTopicThreads, 0, s>>>(cand, tile_ncand, items, item_count, tuples);
 }
 

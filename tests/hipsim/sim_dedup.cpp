@@ -30,9 +30,8 @@ int32_t sim_dedup(int32_t variant, uint32_t grid_topic, uint32_t max_slots, cons
     ok &= hipsim::run(tile_blocks + (nt + 255) / 256, 256, [&] { dedup_tile_kernel(cand, tile_ncand, tile_trange, ntiles, hit_off, hit_lo, nt, tuple_words(tuples), stat, tile_blocks, items.data(), item_counts, 1u, max_slots, 2u); });
     if (item_counts[0] != 0) return -4;          // the next window's counter was not zeroed
     uint32_t& item_count = item_counts[1];
-    if (variant != 0 && variant != 3 && variant != 7 && variant != 11) return -3;        // variant = the topic pass's probe_mode (bit 0: double hashing, bit 1: 16-byte clears)
+    if (variant != 0 && variant != 3 && variant != 7) return -3;        // variant = the topic pass's probe_mode (bit 0: double hashing, bit 1: 16-byte clears)
     if (variant == 7) ok &= hipsim::run(grid_topic, kDedupTopicThreads, [&] { dedup_topic_kernel<7>(cand, tile_ncand, items.data(), &item_count, tuple_words(tuples)); });
-    else if (variant == 11) ok &= hipsim::run(grid_topic, kDedupTopicThreads, [&] { dedup_topic_ahead_kernel(cand, tile_ncand, items.data(), &item_count, tuple_words(tuples)); });
     else if (variant == 3) ok &= hipsim::run(grid_topic, kDedupTopicThreads, [&] { dedup_topic_kernel<3>(cand, tile_ncand, items.data(), &item_count, tuple_words(tuples)); });
     else ok &= hipsim::run(grid_topic, kDedupTopicThreads, [&] { dedup_topic_kernel<0>(cand, tile_ncand, items.data(), &item_count, tuple_words(tuples)); });
     if (n_items_out) *n_items_out = item_count;

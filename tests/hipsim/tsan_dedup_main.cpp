@@ -1,7 +1,6 @@
 // TEST INFRASTRUCTURE ONLY — the v5 dedup passes of rmqtt_amd/csrc/dedup.inc on the host under ThreadSanitizer and AddressSanitizer
-// (tools/hipsim_sanitizers.sh).  TSAN: the topic pass clears, fills and re-clears ONE table in LDS between block barriers, and the
-// prefetching form (r6) runs on two barriers per item with an overflow flag that alternates between two words — a clear that overtakes a
-// probe, or a flag reset before every thread has read it, is a data race between the OS threads that stand for GPU threads.  ASAN: the
+// (tools/hipsim_sanitizers.sh).  TSAN: the topic pass clears, fills and re-clears ONE table in LDS between block barriers — a clear that overtakes a
+// probe, or the overflow flag reset before every thread has read it, is a data race between the OS threads that stand for GPU threads.  ASAN: the
 // candidate slices have exactly kTile entries per tile (the list heads are read past a tile's count, never past its slice), the item
 // array its exact upper bound.  Also compares every form's flags with a first-position map.
 #include "sim_dedup.cpp"
@@ -52,7 +51,7 @@ int main() {
             if (ncand[tl] >= 2 && whole) { ncand[tl] |= 1u << 31; trange[2 * tl] = tf; trange[2 * tl + 1] = tlast; }
         }
         std::sort(want.begin(), want.end());
-        for (int variant : {3, 7, 11}) {
+        for (int variant : {3, 7}) {
             std::vector<Tuple> tuples(nh, Tuple{0, 0, 0});
             uint32_t n_items = 0;
             const int rc = sim_dedup(variant, w.grid, w.slots, cand.data(), ncand.data(), trange.data(), ntiles, tuples.data(), nt, hit_off.data(), hit_lo, &n_items);

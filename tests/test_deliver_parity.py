@@ -298,10 +298,8 @@ SWITCH_SETS = {
     "lean_256x8": {"RGR_DELIVER_LEAN": "2"},
     # measured and not adopted: 2^30-hit delivery windows
     "large_windows": {"RGR_DELIVER_WINDOW_HITS": str(1 << 30)},
-    # (r6) the topic pass of the v5 dedup as it was until r6s (lists read 64 entries at a time), and the form that fetches the next item ahead on
-    # emptier tables (measured slower, kept behind the switch)
-    "topic_pass_r5": {"RGR_DEDUP_PROBE": "3"},
-    "topic_pass_ahead": {"RGR_DEDUP_PROBE": "a", "RGR_DEDUP_SLOT_FACTOR": "4"},
+    # (r6) the topic pass of the v5 dedup as it was until r6s (lists read 64 entries at a time), on emptier tables
+    "topic_pass_r5": {"RGR_DEDUP_PROBE": "3", "RGR_DEDUP_SLOT_FACTOR": "4"},
 }
 
 

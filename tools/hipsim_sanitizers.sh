@@ -17,7 +17,7 @@ for san in thread address; do
   TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0" ASAN_OPTIONS="detect_leaks=0" /tmp/hipsim_tuple_$san > /tmp/hipsim_tuple_$san.log 2>&1 || echo "# exit status $?"
   grep -v "^$" /tmp/hipsim_tuple_$san.log | head -60
   echo "# sanitizer reports, tuple expansions ($san): $(grep -c 'WARNING: ThreadSanitizer\|ERROR: AddressSanitizer' /tmp/hipsim_tuple_$san.log || true)"
-  # (r6) the v5 dedup passes: tile pass + classification, the topic pass (double hashing; lists fetched 256 entries at a time; the form that fetches the next item ahead)
+  # (r6) the v5 dedup passes: tile pass + classification, the topic pass (double hashing; lists fetched 256 entries at a time)
   $CC -O1 -g -std=c++17 -pthread -fsanitize=$san -I include -I rmqtt_amd/csrc -I tests/hipsim tests/hipsim/tsan_dedup_main.cpp -o /tmp/hipsim_dedup_$san
   echo "# $CC -O1 -g -fsanitize=$san tests/hipsim/tsan_dedup_main.cpp  (rmqtt_amd/csrc/dedup.inc on the host)"
   TSAN_OPTIONS="halt_on_error=0 report_signal_unsafe=0" ASAN_OPTIONS="detect_leaks=0" /tmp/hipsim_dedup_$san > /tmp/hipsim_dedup_$san.log 2>&1 || echo "# exit status $?"
