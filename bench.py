@@ -1575,12 +1575,15 @@ def measure_forwards_e2e(args, L, W, cfg, n_t, tb, to, blob, offs, client, qos, 
            "gpu_async": []}
     # (the shape that measured best at both configs, profiles/r06f_*: 4 submitters, 8 k publishes outstanding, 32 completion threads, 2 passes in flight — a
     # delivery pass carries 12 bytes per HIT to the host, so fewer, fuller passes and less outstanding work than the filter-id form of Router::matches)
-    shapes = [(4, 8192, 32, 2)] if (args.e2e_submitters, args.e2e_outstanding, args.e2e_workers, args.e2e_passes) == (8, 16384, 0, 3) else \
+    # (r7: at config 2 — half a recipient per publish, the passes are bound by their host round trips — 8 submitters / 16 k outstanding / 3 passes in
+    # flight measure best since the completions take the table's lock once per run: profiles/r07d_*, r07f_*)
+    best = (4, 8192, 32, 2) if cfg != 2 else (8, 16384, max(32, min(128, cores // 2)), 3)
+    shapes = [best] if (args.e2e_submitters, args.e2e_outstanding, args.e2e_workers, args.e2e_passes) == (8, 16384, 0, 3) else \
              [(args.e2e_submitters, args.e2e_outstanding, args.e2e_workers or max(8, min(64, cores // 4)), args.e2e_passes)]
     if args.e2e_sweep:
-        shapes += [(8, 16384, 64, 3), (8, 65536, 64, 4), (8, 16384, 128, 3)]
+        shapes += [x for x in [(4, 8192, 32, 2), (8, 16384, 64, 3), (8, 65536, 64, 4), (8, 16384, 128, 3), (12, 32768, 128, 4)] if x != best]
     for subm, outst, workers, passes in shapes:
-        res = (C.c_uint64 * 6)()
+        res = (C.c_uint64 * 12)()
         wall = C.c_double(0)
         lat = np.zeros(200_000, dtype=np.float32)
         nl = C.c_uint32(0)
@@ -1592,6 +1595,9 @@ def measure_forwards_e2e(args, L, W, cfg, n_t, tb, to, blob, offs, client, qos, 
                                  "value": round(res[0] / wall.value, 1), "recipients_per_s": round(res[1] / wall.value, 1), "device_passes": int(res[2]),
                                  "publishes_per_pass": round(res[0] / max(1, res[2]), 1), "errors": int(res[3]), "host_path_publishes": int(res[4]), "wall_s": round(wall.value, 2),
                                  "publishes": int(res[0]), "recipients": int(res[1]),
+                                 "batcher_ms_per_pass": {"collect": round(res[6] / max(1, res[2]) / 1e6, 3), "device_pass": round(res[7] / max(1, res[2]) / 1e6, 3),
+                                                         "dispatch": round(res[8] / max(1, res[2]) / 1e6, 3)},
+                                 "worker_task_us": round(res[9] / max(1, res[10]) / 1e3, 1), "worker_tasks": int(res[10]), "max_task_queue": int(res[11]),
                                  "latency_us": {"p50": round(float(l[len(l) // 2]), 1), "p99": round(float(l[int(len(l) * 0.99)]), 1)} if len(l) else None})
         log(f"forwards e2e config {cfg}: {rec['gpu_async'][-1]}")
     L.hr_free(g)

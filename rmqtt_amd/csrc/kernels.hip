@@ -96,17 +96,38 @@ __global__ __launch_bounds__(256) void tok_count_kernel(const uint8_t* __restric
     const uint32_t t = blockIdx.x * 256 + threadIdx.x;
     if (t >= n) return;
     if (force_invalid && force_invalid[t]) { level_cnt[t] = 0; tflags[t] = kTopicInvalid; return; }
-    uint8_t fl;
-    level_cnt[t] = topic_level_count(blob + offs[t], offs[t + 1] - offs[t], &fl);
-    tflags[t] = fl;
+    bool meta;
+    const int64_t nl = scan_topic_at(WordBytes(blob + offs[t]), offs[t + 1] - offs[t], &meta, [](int64_t, uint64_t, uint32_t, uint64_t, int) {});
+    level_cnt[t] = nl < 0 ? 0u : uint32_t(nl);
+    tflags[t] = nl < 0 ? kTopicInvalid : meta ? kTopicMeta : 0;
 }
 
-__global__ __launch_bounds__(256) void tok_fill_kernel(DictView d, const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offs,
-                                                       uint32_t n, const uint64_t* __restrict__ tok_off,
-                                                       const uint8_t* __restrict__ tflags, uint32_t* __restrict__ tokens) {
-    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+// (r7g) Two phases per lane.  One pass that looks a level up the moment its '/' is met makes the 64 lanes of a wave — whose levels end at different bytes —
+// run the dictionary probe (dependent loads: slot, entry, the stored string's bytes) once per DISTINCT level-end position of the wave, ~30 times for
+// topics of 7 levels: 171 us for a batch of 2 600 topics (profiles/r07e_*), the largest kernel of a micro-batch pass.  Now the byte scan only records
+// each level's (start, length, hash) in LDS, and the probes run level by level, all lanes on their k-th level together.
+constexpr int kTokFillThreads = 128, kTokFillLevels = 16;          // levels held in LDS per lane (32 KiB per block); deeper levels are looked up in the scan
+__global__ __launch_bounds__(kTokFillThreads) void tok_fill_kernel(DictView d, const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offs,
+                                                                   uint32_t n, const uint64_t* __restrict__ tok_off,
+                                                                   const uint8_t* __restrict__ tflags, uint32_t* __restrict__ tokens) {
+    __shared__ uint32_t s_seg[kTokFillLevels][kTokFillThreads], s_len[kTokFillLevels][kTokFillThreads];
+    __shared__ uint64_t s_hash[kTokFillLevels][kTokFillThreads];
+    const uint32_t t = blockIdx.x * kTokFillThreads + threadIdx.x;
     if (t >= n || (tflags[t] & kTopicInvalid)) return;
-    topic_tokens(d, blob + offs[t], offs[t + 1] - offs[t], tokens + tok_off[t]);
+    const uint8_t* s = blob + offs[t];
+    uint32_t* out = tokens + tok_off[t];
+    bool meta;
+    const int64_t nlev = scan_topic_at(WordBytes(s), offs[t + 1] - offs[t], &meta, [&](int64_t idx, uint64_t seg, uint32_t sl, uint64_t h, int kind) {
+        if (kind) out[idx] = kind == 1 ? kTokPlus : kTokHash;
+        else if (idx < kTokFillLevels) { s_seg[idx][threadIdx.x] = uint32_t(seg); s_len[idx][threadIdx.x] = sl; s_hash[idx][threadIdx.x] = h; }
+        else out[idx] = dict_find(d, s + seg, sl, h);
+        if (kind && idx < kTokFillLevels) s_len[idx][threadIdx.x] = 0xFFFFFFFFu;      // (a wildcard level: nothing to look up)
+    });
+    const int held = nlev < kTokFillLevels ? int(nlev) : kTokFillLevels;
+    for (int k = 0; k < held; ++k) {
+        const uint32_t sl = s_len[k][threadIdx.x];
+        if (sl != 0xFFFFFFFFu) out[k] = dict_find(d, s + s_seg[k][threadIdx.x], sl, s_hash[k][threadIdx.x]);
+    }
 }
 
 // PUBLISH packets: lane per packet (match_core.hpp publish_scan); then the topic-name fields are gathered into a
@@ -808,7 +829,7 @@ void launch_scan_u32(const uint32_t* in, uint64_t* out, uint32_t n, uint64_t* bl
 
 void launch_tok_fill(const DictView& d, const uint8_t* blob, const uint64_t* offs, uint32_t n, const uint64_t* tok_off,
                      const uint8_t* tflags, uint32_t* tokens, void* stream) {
-    if (n) tok_fill_kernel<<<(n + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(d, blob, offs, n, tok_off, tflags, tokens);
+    if (n) tok_fill_kernel<<<(n + kTokFillThreads - 1) / kTokFillThreads, kTokFillThreads, 0, static_cast<hipStream_t>(stream)>>>(d, blob, offs, n, tok_off, tflags, tokens);
 }
 
 void launch_walk(const TrieView& t, const WalkArgs& a, bool overflow_pass, void* stream) {

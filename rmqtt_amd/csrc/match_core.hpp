@@ -33,31 +33,57 @@ RGR_HD inline uint32_t dict_find(const DictView& d, const uint8_t* s, uint32_t l
 // level with (seg_ptr, seg_len, fnv_hash_of_segment, kind) where kind: 0 literal, 1 '+', 2 '#'.
 // Returns the level count, or -1 when Topic::from_str would fail; *meta = first level starts
 // with '$' (Level::Metadata).
-template <class OnLevel> RGR_HD inline int64_t scan_topic(const uint8_t* s, uint64_t len, bool* meta, OnLevel on_level) {
+// (r7h) The scan reads its bytes through `at(i)` (every index at most once, in ascending order — the device kernels hand in a source that holds the
+// aligned 8-byte word around the last index, one load per eight bytes instead of eight) and reports a level as (index, start, length, hash, kind).
+template <class At, class OnLevel> RGR_HD inline int64_t scan_topic_at(At&& at, uint64_t len, bool* meta, OnLevel on_level) {
+    // One outer iteration per LEVEL, a tight inner loop over its bytes (hash + "contains a wildcard character"); everything Topic::from_str decides
+    // is decided where a level ends.  (Until r7h one flat loop carried all of it per byte: ~60 instructions per byte on the device, where a micro-batch
+    // has one wave per SIMD and every instruction costs its full latency — 40 us to count the levels of 2 600 topics.)
     int64_t levels = 0;
-    uint64_t seg = 0, h = kFnvBasis;
-    bool hash_seen = false, seg_wild = false;
+    bool hash_seen = false;
     *meta = false;
-    for (uint64_t i = 0; i <= len; ++i) {
-        if (i == len || s[i] == '/') {
-            if (hash_seen) return -1;                               // '#' was not the last level
-            const uint64_t sl = i - seg;
-            int kind = 0;
-            if (sl == 1 && s[seg] == '+') kind = 1;
-            else if (sl == 1 && s[seg] == '#') { kind = 2; hash_seen = true; }
-            else if (seg_wild) return -1;                           // level merely contains '+'/'#'
-            else if (sl > 0 && s[seg] == '$') { if (levels != 0) return -1; *meta = true; }
-            on_level(levels, s + seg, uint32_t(sl), dict_hash_finish(h), kind);
-            ++levels;
-            seg = i + 1; h = kFnvBasis; seg_wild = false;
-        } else {
-            const uint8_t c = s[i];
-            if (c == '+' || c == '#') seg_wild = true;
+    uint64_t i = 0;
+    for (;;) {
+        const uint64_t seg = i;
+        uint64_t h = kFnvBasis;
+        bool wild = false, more = false;                            // more: the level ended at a '/', another level follows
+        const uint8_t first = i < len ? at(i) : uint8_t(0);         // the level's first byte (looked at only when the level has one)
+        while (i < len) {
+            const uint8_t c = at(i);
+            ++i;
+            if (c == '/') { more = true; break; }
+            wild |= (c == '+') | (c == '#');
             h ^= c; h *= kFnvPrime;
         }
+        const uint64_t sl = (more ? i - 1 : i) - seg;
+        if (hash_seen) return -1;                                   // '#' was not the last level
+        int kind = 0;
+        if (sl == 1 && first == '+') kind = 1;
+        else if (sl == 1 && first == '#') { kind = 2; hash_seen = true; }
+        else if (wild) return -1;                                   // level merely contains '+'/'#'
+        else if (sl > 0 && first == '$') { if (levels != 0) return -1; *meta = true; }
+        on_level(levels, seg, uint32_t(sl), dict_hash_finish(h), kind);
+        ++levels;
+        if (!more) break;
     }
     return levels;
 }
+template <class OnLevel> RGR_HD inline int64_t scan_topic(const uint8_t* s, uint64_t len, bool* meta, OnLevel on_level) {
+    return scan_topic_at([&](uint64_t i) { return s[i]; }, len, meta,
+                         [&](int64_t idx, uint64_t seg, uint32_t sl, uint64_t h, int kind) { on_level(idx, s + seg, sl, h, kind); });
+}
+// Byte source over aligned 8-byte words (device kernels): the words around a topic lie inside its blob's allocation — the blob starts at an
+// allocation's first byte and the allocation is padded to a multiple of eight (c_abi.cpp).
+struct WordBytes {
+    const uint8_t* s;
+    uint64_t base = ~0ull, w = 0;
+    RGR_HD explicit WordBytes(const uint8_t* p) : s(p) {}
+    RGR_HD uint8_t operator()(uint64_t i) {
+        const uint64_t a = reinterpret_cast<uint64_t>(s) + i, al = a & ~7ull;
+        if (al != base) { w = *reinterpret_cast<const uint64_t*>(al); base = al; }
+        return uint8_t(w >> ((a & 7ull) * 8));
+    }
+};
 
 RGR_HD inline uint32_t topic_level_count(const uint8_t* s, uint64_t len, uint8_t* flags) {
     bool meta;

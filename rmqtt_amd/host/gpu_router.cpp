@@ -13,12 +13,6 @@ uint8_t flags_of(const SubscriptionOptions& o) {
     return uint8_t((o.v5 ? RGR_SUB_V5 : 0) | (o.v5 && o.no_local ? RGR_SUB_NO_LOCAL : 0) | (o.v5 && o.retain_as_published ? RGR_SUB_RAP : 0) |
                    (o.shared_group ? RGR_SUB_SHARED : 0));
 }
-// Every field Id equality looks at (types.rs:1841-1851), unambiguously joined.
-std::string id_key(const Id& id) {
-    std::string k = std::to_string(id.node_id) + '|' + std::to_string(id.lid) + '|' + std::to_string(id.create_time);
-    for (const std::string* f : {&id.local_addr, &id.remote_addr, &id.client_id, &id.username}) { k += '|'; k += std::to_string(f->size()); k += ':'; k += *f; }
-    return k;
-}
 std::string client_key(NodeId node, const ClientId& c) { return std::to_string(node) + '|' + c; }
 }  // namespace
 
@@ -98,7 +92,7 @@ Result<bool> GpuRouter::add(const std::string& topic_filter, const Id& id, const
     auto& rels = it->second.rels;
     auto old = rels.find(id.client_id);
     uint32_t sub_id;
-    const uint32_t owner_id = owners_.acquire(id_key(id));
+    const uint32_t owner_id = owners_.acquire(id);
     if (opts.shared_group) shared_rels_++;
     if (old != rels.end() && old->second.opts.shared_group) shared_rels_--;
     if (old == rels.end()) {
@@ -108,7 +102,7 @@ Result<bool> GpuRouter::add(const std::string& topic_filter, const Id& id, const
         old = rels.emplace(id.client_id, Rel{id, opts, sub_id, owner_id}).first;
     } else {
         sub_id = old->second.sub_id;
-        owners_.release(id_key(old->second.id));
+        owners_.release(old->second.id);
         clients_.release(client_key(old->second.id.node_id, old->second.id.client_id));
         old->second = Rel{id, opts, sub_id, owner_id};              // HashMap::insert replaces (router.rs:447)
     }
@@ -142,7 +136,8 @@ Result<bool> GpuRouter::restore(const raft::Snapshot& snap) {
     std::unordered_map<TopicFilter, FilterEntry> relations;
     for (auto& r : snap.relations) relations[r.topic_filter].rels[r.client_id] = Rel{r.id, r.opts, 0, 0};   // HashMap::insert: the later entry wins
     std::vector<Slot> slab;
-    Dense owners, clients;
+    OwnerIndex owners;
+    Dense clients;
     std::string blob;
     std::vector<uint64_t> offs{0};
     std::vector<uint32_t> sub_ids, owner_ids, client_idx;
@@ -151,7 +146,7 @@ Result<bool> GpuRouter::restore(const raft::Snapshot& snap) {
         for (auto& rel : kv.second.rels) {
             Rel& x = rel.second;
             x.sub_id = uint32_t(slab.size());
-            x.owner_id = owners.acquire(id_key(x.id));
+            x.owner_id = owners.acquire(x.id);
             slab.push_back(Slot{&kv.first, &x, &kv.second});
             blob += kv.first;
             offs.push_back(blob.size());
@@ -202,7 +197,7 @@ Result<bool> GpuRouter::remove(const std::string& topic_filter, const Id& id) {
     if (r->second.opts.shared_group) shared_rels_--;
     slab_[sub_id] = Slot{};
     quarantined_sub_ids_.push_back(sub_id);          // reusable after the next commit (see mu_)
-    owners_.release(id_key(r->second.id));
+    owners_.release(r->second.id);
     clients_.release(client_key(r->second.id.node_id, r->second.id.client_id));
     rels.erase(r);
     relations_count_.dec();
@@ -400,7 +395,7 @@ Result<bool> GpuRouter::matches_batch_deliver(const std::vector<Id>& ids, const 
     for (size_t i = 0; i < topics.size(); ++i) { blob += topics[i]; offs[i + 1] = blob.size(); }
     // publish attributes: who publishes (for No Local); qos 2 / retain 0 leave the subscription's own qos in the word
     std::vector<rgr_publish_attr> attrs(topics.size());
-    for (size_t i = 0; i < topics.size(); ++i) attrs[i] = rgr_publish_attr{owners_.find(id_key(ids[i])), 2u};
+    for (size_t i = 0; i < topics.size(); ++i) attrs[i] = rgr_publish_attr{owners_.find(ids[i]), 2u};
     rgr_result res{};
     // Without $share members the grouping by node (router.rs:258-261: one collector per node) is done on the device: every
     // topic's tuples arrive partitioned by node index, one slice per collector.  ($share picks are added where their filter's
@@ -494,7 +489,7 @@ Result<bool> GpuRouter::deliver_pass(const std::string& blob, const std::vector<
     const uint32_t n = uint32_t(offs.size() - 1);
     auto run = [&]() -> Result<bool> {
         std::vector<rgr_publish_attr> attrs(n);
-        for (uint32_t i = 0; i < n; ++i) attrs[i] = rgr_publish_attr{owners_.find(id_key(*ids[i])), uint32_t(qos_retain[i] & 7u)};
+        for (uint32_t i = 0; i < n; ++i) attrs[i] = rgr_publish_attr{owners_.find(*ids[i]), uint32_t(qos_retain[i] & 7u)};
         pass.epoch = mutation_epoch_.load(std::memory_order_acquire);
         if (rgr_group_match_batch_deliver(g_, reinterpret_cast<const uint8_t*>(blob.data()), offs.data(), n, attrs.data(), &pass.res) != RGR_OK)
             return Result<bool>::Err(rgr_last_error());
@@ -762,6 +757,7 @@ void Batcher::run_task(Task& t) {
         b->tasks_run_.fetch_add(1, std::memory_order_relaxed); } } timed{this, t0};
     const size_t n = t.reqs.size();
     if (t.dpass) {                                                // Shared::forwards requests: the completion consumes the delivery words itself
+        GpuRouter::SharedHold hold(router_);                      // (one shared-lock acquisition per run, as for the expansions below)
         for (size_t i = 0; i < n; ++i) t.reqs[i]->dcb(t.reqs[i]->user, t.reqs[i]->tag, t.dpass, t.reqs[i]->index, t.reqs[i]->id, nullptr);
         recycle(t.reqs);
         return;

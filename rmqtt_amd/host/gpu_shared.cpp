@@ -100,6 +100,7 @@ void GpuShared::on_pass(void* user, uint64_t tag, const std::shared_ptr<GpuRoute
     const auto outcome = self->deliver(*pass, index, *p->from, *p->publish, count, nullptr);
     if (outcome == GpuRouter::DeliverOutcome::NeedsHostPath) {
         self->host_path_++;
+        GpuRouter::SharedPause pause(self->router_);          // (the worker's run holds the table's shared lock; the host path takes it itself)
         auto r = self->inner_.forwards(*p->from, *p->publish, nullptr);
         if (r.ok()) p->done(p->user, tag, *r.value, nullptr); else p->done(p->user, tag, 0, &r.error);
         return;

@@ -95,6 +95,7 @@ class GpuShared : public Shared {
                                       std::vector<Undelivered>* errs);
     struct Counters { uint64_t device_path, host_path, deliveries, remote, passes; };
     Counters counters() const { return Counters{device_path_, host_path_, deliveries_, remote_, batcher_.passes()}; }
+    Batcher::Timing timing() const { return batcher_.timing(); }        // where the batcher's threads spent their time (ns summed over threads)
 
    private:
     struct Pending { GpuShared* self; const From* from; const Publish* publish; Done done; void* user; };

@@ -580,6 +580,7 @@ int hr_forwards_run_async(void* r, const uint8_t* blob, const uint64_t* offs, ui
     };
     double wall = 0;
     GpuShared::Counters cnt{};
+    Batcher::Timing tm{};
     {
         GpuShared gs(*router, inner, max_batch, std::chrono::microseconds(max_delay_us), passes_in_flight, workers);
         std::vector<std::thread> th;
@@ -604,11 +605,14 @@ int hr_forwards_run_async(void* r, const uint8_t* blob, const uint64_t* offs, ui
         for (auto& t : th) t.join();
         wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         cnt = gs.counters();
+        tm = gs.timing();
     }
     if (wall_s) *wall_s = wall;
     uint64_t p = 0, rws = 0, errs = 0;
     for (auto& c : ctx) for (const auto& l : c->lane) { p += l.pubs.load(); rws += l.rows.load(); errs += l.errs.load(); }
     out[0] = p; out[1] = rws; out[2] = cnt.passes; out[3] = errs; out[4] = cnt.host_path; out[5] = inner.sink.checksum();
+    // out[6..11]: the batcher's clocks, as hr_e2e_run_async reports them
+    out[6] = tm.collect_ns; out[7] = tm.pass_ns; out[8] = tm.dispatch_ns; out[9] = tm.task_ns; out[10] = tm.tasks; out[11] = tm.max_task_queue;
     if (n_lat_out) *n_lat_out = std::min<uint32_t>(ctx[0]->lat_n.load(), ctx[0]->n_lat);
     return 0;
 }
