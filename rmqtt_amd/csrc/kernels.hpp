@@ -68,6 +68,12 @@ struct alignas(8) Cand { uint32_t pos, client_idx; };
 #else
 #define RGR_DIAG_CAND_STRIDE kTile
 #endif
+// The other timing diagnostics (expand_tuple.inc RGR_DIAG_LEAN_*: the lean delivery expansion without its stores / entry reads / v5 path / dependent
+// gathers, with the tile record or the pair list synthesised; dedup.inc RGR_DIAG_NO_DEDUP_STAT) also give wrong results by construction.
+#if (defined(RGR_DIAG_LEAN_NO_STORE) || defined(RGR_DIAG_LEAN_NO_LOAD) || defined(RGR_DIAG_LEAN_NO_V5) || defined(RGR_DIAG_LEAN_NO_ATTR) || \
+     defined(RGR_DIAG_LEAN_WARM) || defined(RGR_DIAG_LEAN_FAKE_REC) || defined(RGR_DIAG_LEAN_FAKE_PAIRS)) && !defined(RGR_DIAG_BUILD)
+#error "RGR_DIAG_LEAN_* builds give wrong results by construction: add -DRGR_DIAG_BUILD to say the build is a timing diagnostic"
+#endif
 constexpr uint32_t kSubV5 = 1u << 0, kSubNoLocal = 1u << 1, kSubShared = 1u << 2, kSubRap = 1u << 3;   // RGR_SUB_*
 constexpr uint32_t kHitRetain = 1u << 2, kHitNoLocal = 1u << 3, kHitV5Dup = 1u << 4;                    // RGR_HIT_*
 RGR_HD inline uint32_t mix32(uint32_t x) {           // bijective
