@@ -172,6 +172,7 @@ struct rgr_batch {
     std::vector<int32_t> status;
     uint64_t total_tokens = 0, valid_levels = 0, valid_topics = 0;
     DevBuf d_tokens, d_tok_off, d_tflags, d_path;
+    uint64_t blob_bytes = 0;          // bytes of the topic strings in d_blob (device tokeniser: bounds the token count of a micro-batch)
     // rgr_batch_set_order(RGR_ORDER_WALK): the token arrays once more, gathered into walk order (sorted by the leading tokens, order.hip); d_order[k] = batch
     // index of the topic walked k-th.  The tokeniser keeps writing the caller-order arrays; apply_order() follows every (re)tokenisation.
     bool ordered = false;
@@ -411,12 +412,24 @@ void tokenize_batch_device(rgr_batch* b, const DictImage& dict) {
     launch_scan_u32(b->d_level_cnt.as<uint32_t>(), b->d_tok_off.as<uint64_t>(), n, b->scan_tmp.as<uint64_t>(), b->stream);
     uint64_t total = 0;
     std::vector<uint8_t> flags(n);
-    RGR_HIP(hipMemcpyAsync(&total, b->d_tok_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
-    if (n) RGR_HIP(hipMemcpyAsync(flags.data(), b->d_tflags.p, n, hipMemcpyDeviceToHost, b->stream));
-    RGR_HIP(hipStreamSynchronize(b->stream));
-    b->d_tokens.ensure(std::max<uint64_t>(1, total) * 4);
-    b->d_path.ensure(std::max<uint64_t>(1, total) * (b->retain ? 8 : 4));
+    // (r7) A micro-batch does not wait for its token count between the two kernels: a topic of b bytes has at most b + 1 levels, so the arrays are
+    // sized by that bound and count, scan and fill run back to back — one host round trip less in a pass that is made of them (a few thousand
+    // publishes: 7.5 synchronisations per pass, profiles/r07e_*).  Larger batches keep the exact size (10 M topics: 0.3 GB instead of 2 GB).
+    const uint64_t bound = (b->blob_bytes) + n;
+    const bool small = n != 0 && bound * 12 <= (64ull << 20);
+    if (!small) {
+        RGR_HIP(hipMemcpyAsync(&total, b->d_tok_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
+        if (n) RGR_HIP(hipMemcpyAsync(flags.data(), b->d_tflags.p, n, hipMemcpyDeviceToHost, b->stream));
+        RGR_HIP(hipStreamSynchronize(b->stream));
+    }
+    const uint64_t cap_tokens = small ? bound : total;
+    b->d_tokens.ensure(std::max<uint64_t>(1, cap_tokens) * 4);
+    b->d_path.ensure(std::max<uint64_t>(1, cap_tokens) * (b->retain ? 8 : 4));
     launch_tok_fill(dict.view, blob, offs, n, b->d_tok_off.as<uint64_t>(), b->d_tflags.as<uint8_t>(), b->d_tokens.as<uint32_t>(), b->stream);
+    if (small) {
+        RGR_HIP(hipMemcpyAsync(&total, b->d_tok_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
+        RGR_HIP(hipMemcpyAsync(flags.data(), b->d_tflags.p, n, hipMemcpyDeviceToHost, b->stream));
+    }
     RGR_HIP(hipStreamSynchronize(b->stream));
     RGR_HIP(hipGetLastError());
     b->status.assign(n, RGR_TOPIC_OK);
@@ -1155,10 +1168,12 @@ static int32_t batch_create_impl(rgr_handle* h, const uint8_t* blob, const uint6
             if (offs[i] > offs[i + 1]) return fail(RGR_EINVAL, "rgr_batch_create_from_publish: packet_offsets are not monotonic");
         for (uint32_t i = 0; i <= n && n; ++i) rel[i] = offs[i] - offs[0];
             b->d_blob.ensure(std::max<uint64_t>(16, nbytes + 16));
+            b->blob_bytes = nbytes;
             b->d_offs.ensure((size_t(n) + 1) * 8);
             if (nbytes) RGR_HIP(hipMemcpyAsync(b->d_blob.p, blob + offs[0], nbytes, hipMemcpyHostToDevice, b->stream));
             RGR_HIP(hipMemcpyAsync(b->d_offs.p, rel.data(), (size_t(n) + 1) * 8, hipMemcpyHostToDevice, b->stream));
-            RGR_HIP(hipStreamSynchronize(b->stream));
+            // (no synchronisation here since r7: `rel` and the caller's blob outlive tokenize_batch_device below, which synchronises the stream before
+            // it returns; a micro-batch pass is made of such round trips.  h2d_ms is what the copies cost the HOST; their device time is in tokenize_ms.)
             b->local.h2d_ms += now_ms() - t1;
             if (retain) {
                 std::shared_ptr<RetainEpoch> ep;
@@ -1225,6 +1240,7 @@ int32_t rgr_batch_create_from_publish(rgr_handle* h, const uint8_t* packets, con
         if (n) RGR_HIP(hipMemcpyAsync(b->pub_info.data(), b->d_pubinfo.p, size_t(n) * sizeof(PubInfo), hipMemcpyDeviceToHost, b->stream));
         RGR_HIP(hipStreamSynchronize(b->stream));
         b->d_blob.ensure(std::max<uint64_t>(16, topic_bytes + 16));
+        b->blob_bytes = topic_bytes;
         launch_publish_topics(b->d_pkts.as<uint8_t>(), b->d_pubinfo.as<PubInfo>(), n, b->d_offs.as<uint64_t>(), b->d_blob.as<uint8_t>(), b->stream);
         RGR_HIP(hipGetLastError());
         b->local.tokenize_ms += now_ms() - t2;
