@@ -205,10 +205,11 @@ __global__ __launch_bounds__(kWalkThreads) void walk_kernel(TrieView tv, WalkArg
         active = i < min(*a.ovf_count, a.n);
         tl = active ? a.ovf_list[i] : 0;
     } else {
-        const uint32_t t0 = blockIdx.x * kWalkThreads;
-        tl = t0 + tid;
-        active = tl < a.n;
-        const uint32_t t1 = min(t0 + uint32_t(kWalkThreads), a.n);
+        const uint32_t per_block = uint32_t(kWalkThreads) >> a.lane_shift;
+        const uint32_t t0 = blockIdx.x * per_block;
+        tl = t0 + (uint32_t(tid) >> a.lane_shift);
+        active = (uint32_t(tid) & ((1u << a.lane_shift) - 1u)) == 0 && tl < a.n;
+        const uint32_t t1 = min(t0 + per_block, a.n);
         win_base = a.tok_off[a.topic_base + t0];
         const uint64_t win_end = a.tok_off[a.topic_base + t1];
         const uint64_t span = win_end - win_base;
@@ -837,7 +838,19 @@ void launch_walk(const TrieView& t, const WalkArgs& a, bool overflow_pass, void*
     if (a.n == 0) return;
     // The overflow pass does not know the overflow count on the host: it is launched over the
     // whole chunk and every block beyond *ovf_count exits at once.
-    if (!overflow_pass) walk_kernel<false><<<(a.n + kWalkThreads - 1) / kWalkThreads, kWalkThreads, 0, s>>>(t, a);
+    if (!overflow_pass) {
+        // (r7m) A micro-batch — a few thousand publishes of the host router's batcher — was 41 waves of 64 walks: a wave runs as long as its LONGEST walk
+        // (every step a dependent 32-byte gather) while 1 000 SIMDs idle beside it.  A chunk that cannot fill the chip spreads its walks over more
+        // waves — 2^-shift of the lanes walk, up to 2 048 waves: 2 600 topics in 116 us with 64 walks per wave, 89 with 16, 64 with 4
+        // (profiles/r07m_*, r07n_*).  RGR_WALK_LANE_SHIFT (0 .. 6; read per launch) overrides the choice.
+        WalkArgs w = a;
+        const char* e = std::getenv("RGR_WALK_LANE_SHIFT");
+        uint32_t shift = 0;
+        while (shift < 6u && (uint64_t(a.n) << (shift + 1)) <= 131072ull) ++shift;
+        w.lane_shift = e ? uint32_t(std::min(6, std::max(0, std::atoi(e)))) : shift;
+        const uint32_t per_block = uint32_t(kWalkThreads) >> w.lane_shift;
+        walk_kernel<false><<<(a.n + per_block - 1) / per_block, kWalkThreads, 0, s>>>(t, w);
+    }
     else walk_kernel<true><<<(a.n + kOvfThreads - 1) / kOvfThreads, kOvfThreads, 0, s>>>(t, a);
 }
 

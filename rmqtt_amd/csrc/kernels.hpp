@@ -182,6 +182,8 @@ struct WalkArgs {
     unsigned long long* ovf_cursor;
     uint32_t* ovf_arena;
     uint64_t ovf_arena_cap;
+    // (r7m) main pass of a SMALL chunk: only every 2^lane_shift-th lane of a block walks a topic (set by launch_walk, see there)
+    uint32_t lane_shift = 0;
 };
 
 struct ChunkArrays {
