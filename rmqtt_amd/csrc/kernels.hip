@@ -92,8 +92,10 @@ __global__ __launch_bounds__(256) void scatter_desc_kernel(FilterDesc* __restric
 // per kernel (count, then fill after the exclusive scan of the level counts).
 __global__ __launch_bounds__(256) void tok_count_kernel(const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offs, uint32_t n,
                                                         uint32_t* __restrict__ level_cnt, uint8_t* __restrict__ tflags,
-                                                        const uint8_t* __restrict__ force_invalid) {
-    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+                                                        const uint8_t* __restrict__ force_invalid, uint32_t lane_shift) {
+    // (lane_shift: a batch that cannot fill the chip uses every 2^shift-th lane — a wave runs as long as its longest topic; see launch_walk)
+    if (threadIdx.x & ((1u << lane_shift) - 1u)) return;
+    const uint32_t t = (blockIdx.x * 256 + threadIdx.x) >> lane_shift;
     if (t >= n) return;
     if (force_invalid && force_invalid[t]) { level_cnt[t] = 0; tflags[t] = kTopicInvalid; return; }
     bool meta;
@@ -109,10 +111,11 @@ __global__ __launch_bounds__(256) void tok_count_kernel(const uint8_t* __restric
 constexpr int kTokFillThreads = 128, kTokFillLevels = 16;          // levels held in LDS per lane (32 KiB per block); deeper levels are looked up in the scan
 __global__ __launch_bounds__(kTokFillThreads) void tok_fill_kernel(DictView d, const uint8_t* __restrict__ blob, const uint64_t* __restrict__ offs,
                                                                    uint32_t n, const uint64_t* __restrict__ tok_off,
-                                                                   const uint8_t* __restrict__ tflags, uint32_t* __restrict__ tokens) {
+                                                                   const uint8_t* __restrict__ tflags, uint32_t* __restrict__ tokens, uint32_t lane_shift) {
     __shared__ uint32_t s_seg[kTokFillLevels][kTokFillThreads], s_len[kTokFillLevels][kTokFillThreads];
     __shared__ uint64_t s_hash[kTokFillLevels][kTokFillThreads];
-    const uint32_t t = blockIdx.x * kTokFillThreads + threadIdx.x;
+    if (threadIdx.x & ((1u << lane_shift) - 1u)) return;
+    const uint32_t t = (blockIdx.x * kTokFillThreads + threadIdx.x) >> lane_shift;
     if (t >= n || (tflags[t] & kTopicInvalid)) return;
     const uint8_t* s = blob + offs[t];
     uint32_t* out = tokens + tok_off[t];
@@ -800,6 +803,19 @@ const char* expand_tuple_kernel_name() { return "expand_kernel"; }
 
 uint32_t scan_block_topics() { return kScanBlock; }
 
+// Lane-per-item kernels whose wave runs as long as its longest item (walk, tokeniser): a batch that cannot fill the chip uses 2^-shift of the lanes, up to
+// 2 048 waves.  RGR_WALK_LANE_SHIFT (0 .. 6; read per launch) overrides the choice.
+static uint32_t small_batch_lane_shift(uint32_t n, uint64_t lane_budget = 131072ull) {
+    const char* e = std::getenv("RGR_WALK_LANE_SHIFT");
+    if (e) return uint32_t(std::min(6, std::max(0, std::atoi(e))));
+    uint32_t shift = 0;
+    while (shift < 6u && (uint64_t(n) << (shift + 1)) <= lane_budget) ++shift;
+    return shift;
+}
+// (the tokeniser's kernels gain less from it — their waves are short either way — and lose a little once the batch has a few hundred waves of its own:
+// 300 topics 0.140 -> 0.110 ms of tokenising, 2 600 0.163 -> 0.152, 20 000 0.189 -> 0.202 with the walk's budget: profiles/r07p_*)
+constexpr uint64_t kTokLaneBudget = 32768;
+
 void launch_scatter_edges(EdgeEntry* dst, const uint32_t* slots, const EdgeEntry* recs, uint32_t n, void* stream) {
     if (n) scatter_edges_kernel<<<(n + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(dst, slots, recs, n);
 }
@@ -809,7 +825,9 @@ void launch_scatter_desc(FilterDesc* dst, const uint32_t* fids, const FilterDesc
 
 void launch_tok_count(const uint8_t* blob, const uint64_t* offs, uint32_t n, uint32_t* level_cnt, uint8_t* tflags, void* stream,
                       const uint8_t* force_invalid) {
-    if (n) tok_count_kernel<<<(n + 255) / 256, 256, 0, static_cast<hipStream_t>(stream)>>>(blob, offs, n, level_cnt, tflags, force_invalid);
+    if (!n) return;
+    const uint32_t sh = small_batch_lane_shift(n, kTokLaneBudget);
+    tok_count_kernel<<<uint32_t(((uint64_t(n) << sh) + 255) / 256), 256, 0, static_cast<hipStream_t>(stream)>>>(blob, offs, n, level_cnt, tflags, force_invalid, sh);
 }
 void launch_publish_scan(const uint8_t* pkts, const uint64_t* pkt_offs, uint32_t n, int version, PubInfo* info, uint32_t* topic_len, uint8_t* bad,
                          const uint32_t* from_ids, PublishAttr* attrs, void* stream) {
@@ -830,7 +848,9 @@ void launch_scan_u32(const uint32_t* in, uint64_t* out, uint32_t n, uint64_t* bl
 
 void launch_tok_fill(const DictView& d, const uint8_t* blob, const uint64_t* offs, uint32_t n, const uint64_t* tok_off,
                      const uint8_t* tflags, uint32_t* tokens, void* stream) {
-    if (n) tok_fill_kernel<<<(n + kTokFillThreads - 1) / kTokFillThreads, kTokFillThreads, 0, static_cast<hipStream_t>(stream)>>>(d, blob, offs, n, tok_off, tflags, tokens);
+    if (!n) return;
+    const uint32_t sh = small_batch_lane_shift(n, kTokLaneBudget);
+    tok_fill_kernel<<<uint32_t(((uint64_t(n) << sh) + kTokFillThreads - 1) / kTokFillThreads), kTokFillThreads, 0, static_cast<hipStream_t>(stream)>>>(d, blob, offs, n, tok_off, tflags, tokens, sh);
 }
 
 void launch_walk(const TrieView& t, const WalkArgs& a, bool overflow_pass, void* stream) {
@@ -842,12 +862,9 @@ void launch_walk(const TrieView& t, const WalkArgs& a, bool overflow_pass, void*
         // (r7m) A micro-batch — a few thousand publishes of the host router's batcher — was 41 waves of 64 walks: a wave runs as long as its LONGEST walk
         // (every step a dependent 32-byte gather) while 1 000 SIMDs idle beside it.  A chunk that cannot fill the chip spreads its walks over more
         // waves — 2^-shift of the lanes walk, up to 2 048 waves: 2 600 topics in 116 us with 64 walks per wave, 89 with 16, 64 with 4
-        // (profiles/r07m_*, r07n_*).  RGR_WALK_LANE_SHIFT (0 .. 6; read per launch) overrides the choice.
+        // (profiles/r07m_*, r07n_*; small_batch_lane_shift above — the tokeniser's kernels use it too).
         WalkArgs w = a;
-        const char* e = std::getenv("RGR_WALK_LANE_SHIFT");
-        uint32_t shift = 0;
-        while (shift < 6u && (uint64_t(a.n) << (shift + 1)) <= 131072ull) ++shift;
-        w.lane_shift = e ? uint32_t(std::min(6, std::max(0, std::atoi(e)))) : shift;
+        w.lane_shift = small_batch_lane_shift(a.n);
         const uint32_t per_block = uint32_t(kWalkThreads) >> w.lane_shift;
         walk_kernel<false><<<(a.n + per_block - 1) / per_block, kWalkThreads, 0, s>>>(t, w);
     }
