@@ -1575,9 +1575,10 @@ def measure_forwards_e2e(args, L, W, cfg, n_t, tb, to, blob, offs, client, qos, 
            "gpu_async": []}
     # (the shape that measured best at both configs, profiles/r06f_*: 4 submitters, 8 k publishes outstanding, 32 completion threads, 2 passes in flight — a
     # delivery pass carries 12 bytes per HIT to the host, so fewer, fuller passes and less outstanding work than the filter-id form of Router::matches)
-    # (r7: at config 2 — half a recipient per publish, the passes are bound by their host round trips — 8 submitters / 16 k outstanding / 3 passes in
-    # flight measure best since the completions take the table's lock once per run: profiles/r07d_*, r07f_*)
-    best = (4, 8192, 32, 2) if cfg != 2 else (8, 16384, max(32, min(128, cores // 2)), 3)
+    # (r7: once the publisher's owner id travels with its From and the completions take the table's lock once per run, FEWER threads measure best at both
+    # configs — 4 submitters / 8 k outstanding / 32 completion threads / 2 passes in flight: 4.6 M publishes/s with p99 1.4 ms at config 2, against
+    # 3.4-3.8 M with p99 20-50 ms for the larger shapes: profiles/r07t_*)
+    best = (4, 8192, 32, 2)
     shapes = [best] if (args.e2e_submitters, args.e2e_outstanding, args.e2e_workers, args.e2e_passes) == (8, 16384, 0, 3) else \
              [(args.e2e_submitters, args.e2e_outstanding, args.e2e_workers or max(8, min(64, cores // 4)), args.e2e_passes)]
     if args.e2e_sweep:

@@ -247,6 +247,7 @@ struct rgr_batch {
     // dedup_scalars: [0] unused, [1] the two work-item counters; dedup_stat: candidates seen, one u64 per block of the tile pass (kDedupStatSlots of them:
     // a block adds to ITS slot with a plain read-modify-write — launches are stream-ordered — instead of 2 048 atomics on one address per window)
     DevBuf d_pub, cand, cand_count, dedup_items, dedup_scalars, dedup_stat;
+    PinnedBuf h_pub_stage;             // rgr_batch_set_publish_attrs of a small batch: the caller's array, staged for an upload nobody waits for
     DevBuf rf_filter[2], rf_node[2], r_cnt, r_payload, r_ecnt, r_e0, r_e1, r_out_off, r_epos, r_end, r_depth;   // retain frontier rounds
     // pass state
     bool retain = false;             // batch of SUBSCRIBE filters against the retained-topic trie
@@ -689,6 +690,12 @@ void prepare_chunk(rgr_batch* b, uint32_t begin, bool walk_only) {
         RGR_HIP(hipMemcpyAsync(b->c->h_scalars.p, b->c->scalars.p, sizeof(Scalars), hipMemcpyDeviceToHost, b->stream));
         RGR_HIP(hipMemcpyAsync(&tot[0], b->c->hit_off.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
         RGR_HIP(hipMemcpyAsync(&tot[1], b->c->pair_base.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, b->stream));
+        // (r7) a small chunk whose caller wants the offsets on the host anyway (the host-staged calls) takes them in THIS round trip
+        const bool arrays_now = b->want_host_offsets && n <= 65536u;
+        if (arrays_now) {
+            RGR_HIP(hipMemcpyAsync(b->c->h_hit_off.p, b->c->hit_off.p, (size_t(n) + 1) * 8, hipMemcpyDeviceToHost, b->stream));
+            RGR_HIP(hipMemcpyAsync(b->c->h_pair_base.p, b->c->pair_base.p, (size_t(n) + 1) * 8, hipMemcpyDeviceToHost, b->stream));
+        }
         RGR_HIP(hipStreamSynchronize(b->stream));
         RGR_HIP(hipGetLastError());
         b->resolve_spans();
@@ -700,7 +707,7 @@ void prepare_chunk(rgr_batch* b, uint32_t begin, bool walk_only) {
         }
         const uint64_t H = tot[0], P = tot[1];
         b->c->total_hits = H; b->c->total_pairs = P;
-        b->c->host_arrays = false;
+        b->c->host_arrays = arrays_now;
         if (H > b->window_cap() || b->want_host_offsets) fetch_host_arrays(b);
         b->c->pair_src.ensure(std::max<uint64_t>(1, P) * 4);
         b->c->pair_topic.ensure(std::max<uint64_t>(1, P) * 4);
@@ -1301,12 +1308,22 @@ int32_t rgr_batch_set_publish_attrs(rgr_batch* b, const rgr_publish_attr* attrs)
         b->d_pub.ensure(std::max<size_t>(1, b->n) * sizeof(PublishAttr));
         b->d_pub_in.ensure(std::max<size_t>(1, b->n) * sizeof(PublishAttr));
         if (b->n) {
-            RGR_HIP(hipMemcpyAsync(b->d_pub_in.p, attrs, size_t(b->n) * sizeof(PublishAttr), hipMemcpyHostToDevice, b->stream));
+            // (r7) a small batch stages the caller's array in pinned memory of its own and does not wait for the upload: the pass's kernels are ordered
+            // behind it on the stream, and a micro-batch pass is made of host round trips
+            const bool staged = size_t(b->n) * sizeof(PublishAttr) <= (1u << 20);
+            const void* src = attrs;
+            if (staged) {
+                if (b->h_pub_stage.p) RGR_HIP(hipStreamSynchronize(b->stream));          // (an earlier upload from this buffer may still be reading it)
+                b->h_pub_stage.ensure(size_t(b->n) * sizeof(PublishAttr));
+                std::memcpy(b->h_pub_stage.p, attrs, size_t(b->n) * sizeof(PublishAttr));
+                src = b->h_pub_stage.p;
+            }
+            RGR_HIP(hipMemcpyAsync(b->d_pub_in.p, src, size_t(b->n) * sizeof(PublishAttr), hipMemcpyHostToDevice, b->stream));
             // a batch in walk order (rgr_batch_set_order): the delivery stage indexes its attributes by walk position
             if (b->ordered) launch_order_gather_attrs(b->d_order.as<uint32_t>(), b->d_pub_in.as<PublishAttr>(), b->n, b->d_pub.as<PublishAttr>(), b->stream);
             else RGR_HIP(hipMemcpyAsync(b->d_pub.p, b->d_pub_in.p, size_t(b->n) * sizeof(PublishAttr), hipMemcpyDeviceToDevice, b->stream));
+            if (!staged) RGR_HIP(hipStreamSynchronize(b->stream));
         }
-        RGR_HIP(hipStreamSynchronize(b->stream));
         b->deliver = true;
         return RGR_OK;
     });

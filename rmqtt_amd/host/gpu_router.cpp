@@ -93,6 +93,7 @@ Result<bool> GpuRouter::add(const std::string& topic_filter, const Id& id, const
     auto old = rels.find(id.client_id);
     uint32_t sub_id;
     const uint32_t owner_id = owners_.acquire(id);
+    struct PublishOwners { GpuRouter* r; ~PublishOwners() { r->owners_epoch_.store(r->owners_.changes, std::memory_order_release); } } publish_owners{this};
     if (opts.shared_group) shared_rels_++;
     if (old != rels.end() && old->second.opts.shared_group) shared_rels_--;
     if (old == rels.end()) {
@@ -169,7 +170,9 @@ Result<bool> GpuRouter::restore(const raft::Snapshot& snap) {
     slab_ = std::move(slab);
     free_sub_ids_.clear();
     quarantined_sub_ids_.clear();
+    owners.changes += owners_.changes + 1;              // (a restore replaces every owner id)
     owners_ = std::move(owners);
+    owners_epoch_.store(owners_.changes, std::memory_order_release);
     clients_ = std::move(clients);
     bulk_loaded_ = true;
     shared_rels_ = 0;
@@ -198,6 +201,7 @@ Result<bool> GpuRouter::remove(const std::string& topic_filter, const Id& id) {
     slab_[sub_id] = Slot{};
     quarantined_sub_ids_.push_back(sub_id);          // reusable after the next commit (see mu_)
     owners_.release(r->second.id);
+    owners_epoch_.store(owners_.changes, std::memory_order_release);
     clients_.release(client_key(r->second.id.node_id, r->second.id.client_id));
     rels.erase(r);
     relations_count_.dec();
@@ -484,13 +488,16 @@ Result<bool> GpuRouter::matches_batch_deliver(const std::vector<Id>& ids, const 
 
 // The delivery stage as a pass of its own: see gpu_router.hpp.  The pass runs under the table's SHARED lock (several passes at once, like
 // filters_pass); a dirty table is committed first under the exclusive one.
-Result<bool> GpuRouter::deliver_pass(const std::string& blob, const std::vector<uint64_t>& offs, const Id* const* ids, const uint8_t* qos_retain, DeliverPass& pass) {
+Result<bool> GpuRouter::deliver_pass(const std::string& blob, const std::vector<uint64_t>& offs, const Id* const* ids, const uint8_t* qos_retain, DeliverPass& pass,
+                                     const OwnerHint* hints) {
     if (!g_) return Result<bool>::Err(create_error_);
     const uint32_t n = uint32_t(offs.size() - 1);
     auto run = [&]() -> Result<bool> {
         std::vector<rgr_publish_attr> attrs(n);
-        for (uint32_t i = 0; i < n; ++i) attrs[i] = rgr_publish_attr{owners_.find(*ids[i]), uint32_t(qos_retain[i] & 7u)};
         pass.epoch = mutation_epoch_.load(std::memory_order_acquire);
+        const uint64_t oe = owners_epoch_.load(std::memory_order_acquire);
+        for (uint32_t i = 0; i < n; ++i)
+            attrs[i] = rgr_publish_attr{hints && hints[i].epoch == oe ? hints[i].owner : owners_.find(*ids[i]), uint32_t(qos_retain[i] & 7u)};
         if (rgr_group_match_batch_deliver(g_, reinterpret_cast<const uint8_t*>(blob.data()), offs.data(), n, attrs.data(), &pass.res) != RGR_OK)
             return Result<bool>::Err(rgr_last_error());
         return Result<bool>::Ok(true);
@@ -637,7 +644,7 @@ void Batcher::submit(const Id& id, std::string_view topic, Callback cb, void* us
     enqueue(req);
 }
 
-void Batcher::submit_deliver(const Id& from, std::string_view topic, uint8_t qos_retain, DeliverCallback cb, void* user, uint64_t tag) {
+void Batcher::submit_deliver(const Id& from, std::string_view topic, uint8_t qos_retain, DeliverCallback cb, void* user, uint64_t tag, const GpuRouter::OwnerHint* hint) {
     if (stop_.load(std::memory_order_acquire)) { const std::string e = "batcher stopped"; cb(user, tag, nullptr, 0, from, &e); return; }
     const uint32_t shard = uint32_t(shard_of_this_thread(kShards));
     Shard& sh = shards_[shard];
@@ -645,6 +652,7 @@ void Batcher::submit_deliver(const Id& from, std::string_view topic, uint8_t qos
     { std::lock_guard<std::mutex> lk(sh.m); if (!sh.free.empty()) { req = sh.free.back(); sh.free.pop_back(); } }
     if (!req) req = new Req;
     req->id = from; req->topic.assign(topic.data(), topic.size());
+    req->owner = hint && hint->epoch == router_.owners_epoch() ? *hint : router_.owner_hint(from);
     req->cb = nullptr; req->dcb = cb; req->qos_retain = qos_retain; req->user = user; req->tag = tag; req->shard = shard;
     req->pass.reset(); req->err.clear(); req->done = false;
     enqueue(req);
@@ -706,8 +714,9 @@ void Batcher::run() {
             dpass = std::make_shared<GpuRouter::DeliverPass>();
             std::vector<const Id*> ids(reqs.size());
             std::vector<uint8_t> qr(reqs.size());
-            for (size_t i = 0; i < reqs.size(); ++i) { ids[i] = &reqs[i]->id; qr[i] = reqs[i]->qos_retain; }
-            res = router_.deliver_pass(blob, offs, ids.data(), qr.data(), *dpass);
+            std::vector<GpuRouter::OwnerHint> hints(reqs.size());
+            for (size_t i = 0; i < reqs.size(); ++i) { ids[i] = &reqs[i]->id; qr[i] = reqs[i]->qos_retain; hints[i] = reqs[i]->owner; }
+            res = router_.deliver_pass(blob, offs, ids.data(), qr.data(), *dpass, hints.data());
         } else res = router_.filters_pass(blob, offs, *pass);
         const auto t_done = std::chrono::steady_clock::now();
         passes_.fetch_add(1, std::memory_order_relaxed);

@@ -200,7 +200,18 @@ class GpuRouter final : public Router {
         DeliverPass& operator=(const DeliverPass&) = delete;
         ~DeliverPass() { rgr_result_free(&res); }
     };
-    Result<bool> deliver_pass(const std::string& blob, const std::vector<uint64_t>& offs, const Id* const* ids, const uint8_t* qos_retain, DeliverPass& pass);
+    // A publisher's dense owner id, looked up where the publish is SUBMITTED (many threads) instead of once per publish inside the pass (one driver
+    // thread: 0.5 ms of a pass of 3 600 publishes) — or not at all: a session keeps the hint of its own Id (gpu_shared.hpp `From`).  The hint carries
+    // the epoch of the owner index it was read at (bumped whenever an Id gets or loses its owner id): deliver_pass looks the Id up again when the
+    // index has changed since, so a recycled or newly assigned owner id is never missed.
+    struct OwnerHint { uint32_t owner = RGR_ID_NONE; uint64_t epoch = ~0ull; };
+    uint64_t owners_epoch() const { return owners_epoch_.load(std::memory_order_acquire); }
+    Result<bool> deliver_pass(const std::string& blob, const std::vector<uint64_t>& offs, const Id* const* ids, const uint8_t* qos_retain, DeliverPass& pass,
+                              const OwnerHint* hints = nullptr);
+    OwnerHint owner_hint(const Id& id) {
+        std::shared_lock<std::shared_mutex> g(mu_);
+        return OwnerHint{owners_.find(id), owners_epoch_.load(std::memory_order_acquire)};
+    }
     // One recipient of one publish, as the device decided it; pointers into the router's relations map (valid while the visitor runs).
     struct Delivery {
         const ClientId* client_id; const TopicFilter* topic_filter; NodeId node_id;
@@ -321,22 +332,25 @@ class GpuRouter final : public Router {
         std::unordered_map<Id, std::pair<uint32_t, uint32_t>, IdHash> ids;
         std::vector<uint32_t> free;
         uint32_t next = 0;
+        uint64_t changes = 0;            // keys that appeared or disappeared (published as GpuRouter::owners_epoch_: what a cached OwnerHint is checked against)
         uint32_t acquire(const Id& k) {
             auto it = ids.find(k);
             if (it != ids.end()) { it->second.second++; return it->second.first; }
             uint32_t id;
             if (!free.empty()) { id = free.back(); free.pop_back(); } else id = next++;
             ids.emplace(k, std::make_pair(id, 1u));
+            ++changes;
             return id;
         }
         void release(const Id& k) {
             auto it = ids.find(k);
             if (it == ids.end()) return;
-            if (--it->second.second == 0) { free.push_back(it->second.first); ids.erase(it); }
+            if (--it->second.second == 0) { free.push_back(it->second.first); ids.erase(it); ++changes; }
         }
         uint32_t find(const Id& k) const { auto it = ids.find(k); return it == ids.end() ? RGR_ID_NONE : it->second.first; }
     };
     OwnerIndex owners_;
+    std::atomic<uint64_t> owners_epoch_{0};      // owners_.changes, published after every mutation (add / remove / restore hold mu_ exclusively)
     Dense clients_;                      // (node, ClientId) -> client_idx
     std::vector<NodeId> nodes_;          // node_idx -> NodeId
     std::unordered_map<NodeId, uint16_t> node_idx_;
@@ -375,7 +389,8 @@ class Batcher {
     // pass (GpuRouter::deliver_pass), and the completion — on a pool thread, or on the driver without a pool — receives the pass and the
     // request's index in it instead of a SubRelationsMap (err != nullptr: the pass failed).  A batcher serves one kind of request.
     using DeliverCallback = void (*)(void* user, uint64_t tag, const std::shared_ptr<GpuRouter::DeliverPass>& pass, size_t index, const Id& from, const std::string* err);
-    void submit_deliver(const Id& from, std::string_view topic, uint8_t qos_retain, DeliverCallback cb, void* user, uint64_t tag);
+    // hint: the publisher's cached OwnerHint (checked against the owner index's epoch here and again inside the pass); null = looked up here
+    void submit_deliver(const Id& from, std::string_view topic, uint8_t qos_retain, DeliverCallback cb, void* user, uint64_t tag, const GpuRouter::OwnerHint* hint = nullptr);
     uint64_t passes() const { return passes_; }
     uint64_t requests() const { uint64_t n = 0; for (const Shard& sh : shards_) { std::lock_guard<std::mutex> g(sh.m); n += sh.requests; } return n; }
     // where the drivers' and workers' time went (nanoseconds summed over threads): collecting a batch (incl. the deadline wait's tail
@@ -387,6 +402,7 @@ class Batcher {
     // blocking requests live on their caller's stack and are woken through their own condition variable (one shared cv made 256
     // callers fight for one mutex per pass); asynchronous ones are heap objects that end with their callback
     struct Req { Id id; TopicName topic; Callback cb = nullptr; DeliverCallback dcb = nullptr; uint8_t qos_retain = 0; void* user = nullptr; uint64_t tag = 0; uint32_t shard = 0;
+                 GpuRouter::OwnerHint owner;
                  std::shared_ptr<GpuRouter::FilterPass> pass; size_t index = 0; std::string err; bool done = false;
                  std::mutex m; std::condition_variable cv; };
     // a submitter sticks to one shard: its queue, and the free list its asynchronous requests are recycled through (a finished

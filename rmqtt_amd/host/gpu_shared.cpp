@@ -117,7 +117,17 @@ void GpuShared::submit(const From* from, const Publish* publish, Done done, void
         return;
     }
     auto* p = new Pending{this, from, publish, done, user};
-    batcher_.submit_deliver(from->id, *publish->topic, uint8_t((publish->qos & 3u) | (publish->retain ? 4u : 0u)), &GpuShared::on_pass, p, tag);
+    // the publisher's cached owner id (From::owner_hint), refreshed when the owner index has changed since it was read
+    const uint64_t oe = router_.owners_epoch();
+    uint64_t packed = from->owner_hint.load(std::memory_order_relaxed);
+    GpuRouter::OwnerHint hint;
+    if (packed != 0 && uint32_t(packed) == uint32_t(oe)) hint = GpuRouter::OwnerHint{uint32_t(packed >> 32), oe};
+    else {
+        hint = router_.owner_hint(from->id);
+        // (0 means "never looked up": an epoch whose low word is 0 is simply not cached)
+        if (uint32_t(hint.epoch) != 0) from->owner_hint.store(uint64_t(hint.owner) << 32 | uint32_t(hint.epoch), std::memory_order_relaxed);
+    }
+    batcher_.submit_deliver(from->id, *publish->topic, uint8_t((publish->qos & 3u) | (publish->retain ? 4u : 0u)), &GpuShared::on_pass, p, tag, &hint);
 }
 
 Result<ForwardedCount> GpuShared::forwards(const From& from, const Publish& publish, std::vector<Undelivered>* errs) {

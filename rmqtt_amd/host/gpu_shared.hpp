@@ -24,7 +24,16 @@
 
 namespace rmqtt {
 
-struct From { Id id; };                                     // types.rs From: the publisher's Id (+ kind)
+struct From {                                               // types.rs From: the publisher's Id (+ kind)
+    Id id;
+    // the publisher's owner id in the device table, kept by whoever keeps the From (a session keeps its own): owner << 32 | low 32 bits of the owner
+    // index's epoch it was read at.  GpuShared refreshes it when the index has changed; 0 = never looked up (epoch 0 hints are re-checked in the pass).
+    mutable std::atomic<uint64_t> owner_hint{0};
+    From() = default;
+    explicit From(Id i) : id(std::move(i)) {}
+    From(const From& o) : id(o.id), owner_hint(o.owner_hint.load(std::memory_order_relaxed)) {}
+    From& operator=(const From& o) { id = o.id; owner_hint.store(o.owner_hint.load(std::memory_order_relaxed), std::memory_order_relaxed); return *this; }
+};
 struct Publish {                                            // types.rs Publish: the fields forwards / forwards_to read or rewrite
     std::shared_ptr<const TopicName> topic;                 // ByteString: shared, a clone per recipient (shared.rs:899) bumps a count, copies nothing
     uint8_t qos = 0;

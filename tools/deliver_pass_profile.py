@@ -1,6 +1,8 @@
 """Where a SMALL host-staged delivery pass spends its time (the pass GpuShared's batcher issues: a few thousand publishes of config 2 per call).
 rgr_match_batch (plain) and rgr_match_batch_deliver on the same topics, wall clock per call beside the library's own stage clocks (rgr_stats).
-   python3 tools/deliver_pass_profile.py [publishes per call] [calls]"""
+   python3 tools/deliver_pass_profile.py [publishes per call] [calls] [threads]
+With threads > 1 the delivery pass is also timed from that many host threads at once (ctypes releases the GIL): what one pass costs when the
+batcher keeps several in flight."""
 import sys, time
 import numpy as np
 import os
@@ -9,6 +11,7 @@ from rmqtt_amd import capi, workload as wl
 
 n_call = int(sys.argv[1]) if len(sys.argv) > 1 else 2600
 calls = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+n_threads = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 n_subs = 1_000_000
 blob, offs, client, qos = wl.gen_subs(n_subs, wl.SUB_SEED + 2, p_plus=0.028, p_hash=0.0, n_clients=n_subs // 10)
 rng = np.random.default_rng(7)
@@ -38,3 +41,20 @@ for name in ("plain", "deliver", "plain", "deliver"):
     st = r.stats()
     print(f"{name:8s} {n_call} publishes per call: {wall:.3f} ms per call (python included); library clocks per call: " +
           ", ".join(f"{k} {st[k] / calls:.3f}" for k in KEYS) + f"; launches per call: walk {st['walk_launches'] / calls:.1f} expand {st['expand_launches'] / calls:.1f} dedup {st['dedup_launches'] / calls:.1f}; hits per call {st['hits'] / calls:.0f}")
+
+if n_threads > 1:
+    import threading
+    for nt in range(1, n_threads + 1):
+        bs = [batch(k) for k in range(calls)]
+        walls = [0.0] * nt
+        def work(i):
+            t0 = time.perf_counter()
+            for b, o in bs[i::nt]:
+                r.match_batch_deliver(b, o, pa)
+            walls[i] = (time.perf_counter() - t0) / max(1, len(bs[i::nt])) * 1e3
+        th = [threading.Thread(target=work, args=(i,)) for i in range(nt)]
+        t0 = time.perf_counter()
+        for t in th: t.start()
+        for t in th: t.join()
+        tot = time.perf_counter() - t0
+        print(f"{nt} host threads: {sum(walls) / nt:.3f} ms per delivery pass of {n_call} publishes seen by a thread, {calls / tot:.0f} passes/s = {calls * n_call / tot / 1e6:.2f} M publishes/s in all")
