@@ -109,6 +109,17 @@ void GpuShared::on_pass(void* user, uint64_t tag, const std::shared_ptr<GpuRoute
     p->done(p->user, tag, count, nullptr);              // InvalidTopic: nobody matched (the reference logs the Err and forwards to nobody)
 }
 
+// the publisher's cached owner id (From::owner_hint), refreshed when the owner index has changed since it was read
+GpuRouter::OwnerHint GpuShared::owner_hint_of(const From& from) {
+    const uint64_t oe = router_.owners_epoch();
+    const uint64_t packed = from.owner_hint.load(std::memory_order_relaxed);
+    if (packed != 0 && uint32_t(packed) == uint32_t(oe)) return GpuRouter::OwnerHint{uint32_t(packed >> 32), oe};
+    const GpuRouter::OwnerHint hint = router_.owner_hint(from.id);
+    // (0 means "never looked up": an epoch whose low word is 0 is simply not cached)
+    if (uint32_t(hint.epoch) != 0) from.owner_hint.store(uint64_t(hint.owner) << 32 | uint32_t(hint.epoch), std::memory_order_relaxed);
+    return hint;
+}
+
 void GpuShared::submit(const From* from, const Publish* publish, Done done, void* user, uint64_t tag) {
     if (publish->target_clientid) {                     // shared.rs:744: no matching involved
         host_path_++;
@@ -117,16 +128,7 @@ void GpuShared::submit(const From* from, const Publish* publish, Done done, void
         return;
     }
     auto* p = new Pending{this, from, publish, done, user};
-    // the publisher's cached owner id (From::owner_hint), refreshed when the owner index has changed since it was read
-    const uint64_t oe = router_.owners_epoch();
-    uint64_t packed = from->owner_hint.load(std::memory_order_relaxed);
-    GpuRouter::OwnerHint hint;
-    if (packed != 0 && uint32_t(packed) == uint32_t(oe)) hint = GpuRouter::OwnerHint{uint32_t(packed >> 32), oe};
-    else {
-        hint = router_.owner_hint(from->id);
-        // (0 means "never looked up": an epoch whose low word is 0 is simply not cached)
-        if (uint32_t(hint.epoch) != 0) from->owner_hint.store(uint64_t(hint.owner) << 32 | uint32_t(hint.epoch), std::memory_order_relaxed);
-    }
+    const GpuRouter::OwnerHint hint = owner_hint_of(*from);
     batcher_.submit_deliver(from->id, *publish->topic, uint8_t((publish->qos & 3u) | (publish->retain ? 4u : 0u)), &GpuShared::on_pass, p, tag, &hint);
 }
 
@@ -134,6 +136,7 @@ Result<ForwardedCount> GpuShared::forwards(const From& from, const Publish& publ
     if (publish.target_clientid) { host_path_++; return inner_.forwards(from, publish, errs); }
     // the blocking caller consumes its publish itself (so that `errs` can be filled): a pass of its own request through the batcher
     struct Wait { std::mutex m; std::condition_variable cv; bool done = false; std::shared_ptr<GpuRouter::DeliverPass> pass; size_t index = 0; std::string err; } w;
+    const GpuRouter::OwnerHint hint = owner_hint_of(from);
     batcher_.submit_deliver(from.id, *publish.topic, uint8_t((publish.qos & 3u) | (publish.retain ? 4u : 0u)),
                             [](void* user, uint64_t, const std::shared_ptr<GpuRouter::DeliverPass>& pass, size_t index, const Id&, const std::string* err) {
                                 auto* w = static_cast<Wait*>(user);
@@ -141,7 +144,7 @@ Result<ForwardedCount> GpuShared::forwards(const From& from, const Publish& publ
                                 if (err) w->err = *err; else { w->pass = pass; w->index = index; }
                                 w->done = true;
                                 w->cv.notify_one();
-                            }, &w, 0);
+                            }, &w, 0, &hint);
     { std::unique_lock<std::mutex> lk(w.m); w.cv.wait(lk, [&] { return w.done; }); }
     if (!w.err.empty()) return Result<ForwardedCount>::Err(w.err);
     ForwardedCount count = 0;

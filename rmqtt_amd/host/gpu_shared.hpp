@@ -102,6 +102,7 @@ class GpuShared : public Shared {
     // One publish of a finished pass: delivery words -> sessions (forwards_to without the map).  count: recipients reached.
     GpuRouter::DeliverOutcome deliver(const GpuRouter::DeliverPass& pass, size_t index, const From& from, const Publish& publish, ForwardedCount& count,
                                       std::vector<Undelivered>* errs);
+    GpuRouter::OwnerHint owner_hint_of(const From& from);       // From::owner_hint, refreshed against the owner index's epoch
     struct Counters { uint64_t device_path, host_path, deliveries, remote, passes; };
     Counters counters() const { return Counters{device_path_, host_path_, deliveries_, remote_, batcher_.passes()}; }
     Batcher::Timing timing() const { return batcher_.timing(); }        // where the batcher's threads spent their time (ns summed over threads)

@@ -8,6 +8,7 @@
 #include <mutex>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <thread>
 #include <memory>
@@ -432,6 +433,17 @@ struct LogShared {
     std::unique_ptr<GpuShared> gpu;
     std::mutex m;
     std::vector<std::string> log;
+    // one From per publisher for as long as the Shared lives, as a session keeps its own: the owner id cached in it (From::owner_hint) has to survive
+    // the publisher's own subscribes / unsubscribes between two publishes (tests/test_host_router.py)
+    std::mutex from_m;
+    std::map<std::string, std::unique_ptr<From>> froms;
+    const From& from_of(const Id& id) {
+        std::string key = std::to_string(id.node_id) + '|' + std::to_string(id.lid) + '|' + std::to_string(id.create_time) + '|' + id.client_id + '|' + id.username + '|' + id.local_addr + '|' + id.remote_addr;
+        std::lock_guard<std::mutex> g(from_m);
+        auto& f = froms[key];
+        if (!f) f = std::make_unique<From>(id);
+        return *f;
+    }
 };
 bool LogTx::unbounded_send(const From&, Publish&& p) {
     if (closed) return false;
@@ -492,7 +504,7 @@ void hr_shared_disconnect(void* sh, const char* client, uint32_t len) { static_c
 // sessions were sent, then "= <count>\n", then one "! <client>\t<reason>\n" per undelivered relation (sorted); NULL on Err.
 char* hr_shared_forwards(void* sh, int use_gpu, const hr_id* from_id, const char* topic, uint64_t len, uint8_t qos, uint8_t retain, const char* target, uint32_t target_len) {
     auto* s = static_cast<LogShared*>(sh);
-    From from{mk_id(from_id)};
+    const From& from = s->from_of(mk_id(from_id));
     Publish p;
     p.topic = std::make_shared<const TopicName>(topic, len);
     p.qos = qos; p.retain = retain != 0; p.dup = true; p.packet_id = 77;

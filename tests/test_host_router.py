@@ -560,6 +560,36 @@ def test_shared_forwards_from_delivery_words_equals_the_reference_path(hr):
     hr.hr_shared_counters(sh, cnt)
     n_device, n_host = int(cnt[0]), int(cnt[1])
     assert n_device > 100 and n_host > 3 and int(cnt[3]) > 0          # device path taken, $share publishes handed back, other nodes' relations met
+    # (r7) the publisher's owner id is cached with its From and checked against the owner index's epoch: a publisher that had no subscription when it
+    # first published ("stranger": no owner id at all) subscribes with No Local, publishes, unsubscribes, publishes; other clients come and go in
+    # between so that owner ids are recycled — every publish equals the reference path
+    def both(pub, t, q=1, rt=0):
+        hid, oid = _id(node_of.get(pub, 1), pub)
+        ref = _take(hr, hr.hr_shared_forwards(sh, 0, C.byref(hid), t.encode(), len(t.encode()), q, rt, None, 0))
+        got = _take(hr, hr.hr_shared_forwards(sh, 1, C.byref(hid), t.encode(), len(t.encode()), q, rt, None, 0))
+        assert got == ref, (pub, t)
+        dump = o.forwards(oid, t, q, bool(rt))
+        assert got == _expected_sends(dump, 1, connected, closed), (pub, t)
+        return got
+    hr.hr_shared_connect(sh, b"stranger", 8, 0); connected.add("stranger")
+    before = both("stranger", "a/b")
+    assert "stranger\t" not in before
+    sid, soid = _id(1, "stranger")
+    nl = HrOpts(1, 2, 1, 0, 0, 0)                        # v5, qos 2, No Local
+    assert hr.hr_add(g, b"a/b", 3, C.byref(sid), C.byref(nl)) == o.add("a/b", soid, orc.mk_opts(qos=2, v5=True, no_local=True), rel_id=5000)
+    assert "stranger\t" not in both("stranger", "a/b")              # its own publish: dropped by No Local, on the device
+    assert "stranger\t" in both("cl3", "a/b")                       # anybody else's reaches it
+    for k, c in enumerate(["cl11", "cl12", "cl13"]):                # owner ids leave and come back
+        for f in filters:
+            hid, oid = _id(node_of[c], c)
+            assert (hr.hr_remove(g, f.encode(), len(f.encode()), C.byref(hid)) == 0) == (o.remove(f, oid) == 0)
+        both("stranger", "a/b"); both(c, "a/b")
+        hid, oid = _id(node_of[c], c)
+        ho = HrOpts(1, 1, 1, 0, 0, 0)
+        assert hr.hr_add(g, b"a/#", 3, C.byref(hid), C.byref(ho)) == o.add("a/#", oid, orc.mk_opts(qos=1, v5=True, no_local=True), rel_id=6000 + k)
+        both(c, "a/b"); both("stranger", "a/b/c")
+    assert (hr.hr_remove(g, b"a/b", 3, C.byref(sid)) == 0) == (o.remove("a/b", soid) == 0)
+    both("stranger", "a/b"); both("cl3", "a/b")
     # target_clientid: no matching at all (shared.rs:744-770)
     hid, _ = _id(1, "cl1")
     a = _take(hr, hr.hr_shared_forwards(sh, 0, C.byref(hid), b"a/b", 3, 2, 1, b"cl9", 3))
