@@ -1584,22 +1584,56 @@ def measure_forwards_e2e(args, L, W, cfg, n_t, tb, to, blob, offs, client, qos, 
     if args.e2e_sweep:
         shapes += [x for x in [(4, 8192, 32, 2), (8, 16384, 64, 3), (8, 65536, 64, 4), (8, 16384, 128, 3), (12, 32768, 128, 4)] if x != best]
     for subm, outst, workers, passes in shapes:
-        res = (C.c_uint64 * 12)()
+        res = (C.c_uint64 * 13)()
         wall = C.c_double(0)
         lat = np.zeros(200_000, dtype=np.float32)
         nl = C.c_uint32(0)
         L.hr_forwards_run_async(g, tb.ctypes.data, to.ctypes.data, n_t, from_client.ctypes.data, qr.ctypes.data, subm, outst, workers, passes, 4096, 200, 1.0, res, C.byref(wall), None, 0, None)      # warm
+        churn = None
+        if getattr(args, "e2e_churn", False):
+            # a subscriber thread beside the publishes: one relation added and removed over and over (Router::add / remove take the table's lock
+            # exclusively, the passes and the completions hold it shared) — how long a subscribe waits under full publish load
+            import threading
+
+            class HrId(C.Structure):
+                _fields_ = [("node_id", C.c_uint64), ("client_id", C.c_char_p), ("client_len", C.c_uint32), ("create_time", C.c_int64), ("lid", C.c_uint16)]
+
+            class HrOpts(C.Structure):
+                _fields_ = [("v5", C.c_uint8), ("qos", C.c_uint8), ("no_local", C.c_uint8), ("rap", C.c_uint8), ("rh", C.c_uint8), ("sub_ident", C.c_uint32),
+                            ("shared_group", C.c_char_p), ("shared_group_len", C.c_uint32)]
+            L.hr_add.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.POINTER(HrId), C.POINTER(HrOpts)]
+            L.hr_remove.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.POINTER(HrId)]
+            stop_churn, lat_add, lat_rm = threading.Event(), [], []
+
+            def churner():
+                cid = b"churner"
+                hid, ho, f = HrId(1, cid, len(cid), 0, 0), HrOpts(1, 1, 0, 0, 0, 0, None, 0), b"churn/+/x"
+                while not stop_churn.is_set():
+                    t0 = time.perf_counter(); L.hr_add(g, f, len(f), C.byref(hid), C.byref(ho)); lat_add.append(time.perf_counter() - t0)
+                    t0 = time.perf_counter(); L.hr_remove(g, f, len(f), C.byref(hid)); lat_rm.append(time.perf_counter() - t0)
+                    time.sleep(0.002)
+            churn = threading.Thread(target=churner)
+            churn.start()
         L.hr_forwards_run_async(g, tb.ctypes.data, to.ctypes.data, n_t, from_client.ctypes.data, qr.ctypes.data, subm, outst, workers, passes, 4096, 200, 3.0 if quick else 5.0, res,
                                 C.byref(wall), lat.ctypes.data, len(lat), C.byref(nl))
+        churn_rec = None
+        if churn is not None:
+            stop_churn.set(); churn.join()
+            q = lambda a, f: round(float(np.quantile(np.asarray(a), f)) * 1e3, 3) if a else None
+            churn_rec = {"adds": len(lat_add), "removes": len(lat_rm), "add_ms": {"p50": q(lat_add, 0.5), "p99": q(lat_add, 0.99), "max": q(lat_add, 1.0)},
+                         "remove_ms": {"p50": q(lat_rm, 0.5), "p99": q(lat_rm, 0.99), "max": q(lat_rm, 1.0)},
+                         "what": "one relation added and removed in a loop (2 ms apart) by another thread during the timed run: Router::add / remove wait for the table's exclusive lock"}
         l = np.sort(lat[:nl.value])
         rec["gpu_async"].append({"submitters": subm, "outstanding": outst, "workers": workers, "passes_in_flight": passes,
                                  "value": round(res[0] / wall.value, 1), "recipients_per_s": round(res[1] / wall.value, 1), "device_passes": int(res[2]),
-                                 "publishes_per_pass": round(res[0] / max(1, res[2]), 1), "errors": int(res[3]), "host_path_publishes": int(res[4]), "wall_s": round(wall.value, 2),
+                                 "publishes_per_pass": round(res[0] / max(1, res[2]), 1), "errors": int(res[3]), "host_path_publishes": int(res[4]), "resubmitted_publishes": int(res[12]), "wall_s": round(wall.value, 2),
                                  "publishes": int(res[0]), "recipients": int(res[1]),
                                  "batcher_ms_per_pass": {"collect": round(res[6] / max(1, res[2]) / 1e6, 3), "device_pass": round(res[7] / max(1, res[2]) / 1e6, 3),
                                                          "dispatch": round(res[8] / max(1, res[2]) / 1e6, 3)},
                                  "worker_task_us": round(res[9] / max(1, res[10]) / 1e3, 1), "worker_tasks": int(res[10]), "max_task_queue": int(res[11]),
                                  "latency_us": {"p50": round(float(l[len(l) // 2]), 1), "p99": round(float(l[int(len(l) * 0.99)]), 1)} if len(l) else None})
+        if churn_rec:
+            rec["gpu_async"][-1]["subscribe_churn_under_load"] = churn_rec
         log(f"forwards e2e config {cfg}: {rec['gpu_async'][-1]}")
     L.hr_free(g)
     o = orc.DefaultRouter()
@@ -1943,6 +1977,7 @@ def main():
     ap.add_argument("--e2e-outstanding", type=int, default=16384)
     ap.add_argument("--e2e-workers", type=int, default=0, help="completion pool threads (0 = cores / 4, at most 64)")
     ap.add_argument("--e2e-passes", type=int, default=3, help="device passes in flight")
+    ap.add_argument("--e2e-churn", action="store_true", help="--router-e2e, forwards leg: a thread subscribing / unsubscribing beside the publishes; its add / remove latencies are reported")
     ap.add_argument("--e2e-sweep", action="store_true", help="--router-e2e: also run a few other (submitters, outstanding, workers, passes) shapes")
     ap.add_argument("--e2e-configs", default="2,3")
     ap.add_argument("--e2e-legs", default="matches,forwards", help="--router-e2e: which consumers to time: Router::matches (SubRelationsMap per publish) and / or Shared::forwards (delivery words -> sessions)")

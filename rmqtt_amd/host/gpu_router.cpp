@@ -51,9 +51,14 @@ int32_t GpuRouter::commit_if_dirty() {
     int32_t rc = rgr_group_commit(g_);
     if (rc == RGR_OK) {
         dirty_ = false;
-        // the device table no longer holds the ids removed before this commit: they may be handed out again
-        free_sub_ids_.insert(free_sub_ids_.end(), quarantined_sub_ids_.begin(), quarantined_sub_ids_.end());
-        quarantined_sub_ids_.clear();
+        // the device table no longer holds the ids removed before this commit.  Those of the PREVIOUS generation may be handed out again once no delivery
+        // pass of that generation lives; then this commit also ends the current generation (gpu_router.hpp, limbo_).
+        const unsigned old = 1u - unsigned(pass_generation_ & 1u);
+        if (live_passes_[old].load(std::memory_order_acquire) == 0) {
+            free_sub_ids_.insert(free_sub_ids_.end(), limbo_[old].begin(), limbo_[old].end());
+            limbo_[old].clear();
+            ++pass_generation_;
+        }
     }
     return rc;
 }
@@ -80,7 +85,7 @@ static bool valid_topic(const std::string& s) {
 Result<bool> GpuRouter::add(const std::string& topic_filter, const Id& id, const SubscriptionOptions& opts) {
     if (!g_) return Result<bool>::Err(create_error_);
     if (!valid_topic(topic_filter)) return Result<bool>::Err("invalid topic filter `" + topic_filter + "`");   // router.rs:436 (`?`)
-    std::unique_lock<std::shared_mutex> g(mu_);
+    std::unique_lock<TableMutex> g(mu_);
     // (no epoch bump: an add cannot make a sub id held by a pass in flight resolve to another relation — ids are recycled only out of
     // the quarantine that remove() fills, and remove() bumps.  Bumping here sent every batched publish through the exclusive re-match
     // path under ordinary subscribe churn: round-3 advisor.)
@@ -128,7 +133,7 @@ Result<bool> GpuRouter::restore(const raft::Snapshot& snap) {
     for (auto& r : snap.relations)
         if (!valid_topic(r.topic_filter)) return Result<bool>::Err("invalid topic filter `" + r.topic_filter + "`");   // router.rs:559
     if (snap.relations.size() >= RGR_ID_NONE) return Result<bool>::Err("snapshot holds more relations than sub ids");
-    std::unique_lock<std::shared_mutex> g(mu_);
+    std::unique_lock<TableMutex> g(mu_);
     mutation_epoch_++;
     // relations.clear() (router.rs:557): a fresh device table takes the place of the old one
     rgr_group* fresh = nullptr;
@@ -169,7 +174,8 @@ Result<bool> GpuRouter::restore(const raft::Snapshot& snap) {
     relations_ = std::move(relations);      // node-based map: the slab's pointers into it stay valid
     slab_ = std::move(slab);
     free_sub_ids_.clear();
-    quarantined_sub_ids_.clear();
+    limbo_[0].clear(); limbo_[1].clear();
+    restore_epoch_++;                            // every id was renumbered: delivery passes in flight are stale
     owners.changes += owners_.changes + 1;              // (a restore replaces every owner id)
     owners_ = std::move(owners);
     owners_epoch_.store(owners_.changes, std::memory_order_release);
@@ -186,7 +192,7 @@ Result<bool> GpuRouter::restore(const raft::Snapshot& snap) {
 // router.rs:456-496
 Result<bool> GpuRouter::remove(const std::string& topic_filter, const Id& id) {
     if (!g_) return Result<bool>::Err(create_error_);
-    std::unique_lock<std::shared_mutex> g(mu_);
+    std::unique_lock<TableMutex> g(mu_);
     auto it = relations_.find(topic_filter);
     if (it == relations_.end()) return Result<bool>::Ok(false);
     auto& rels = it->second.rels;
@@ -199,7 +205,7 @@ Result<bool> GpuRouter::remove(const std::string& topic_filter, const Id& id) {
     mutation_epoch_++;
     if (r->second.opts.shared_group) shared_rels_--;
     slab_[sub_id] = Slot{};
-    quarantined_sub_ids_.push_back(sub_id);          // reusable after the next commit (see mu_)
+    limbo_[pass_generation_ & 1u].push_back(sub_id);  // reusable when the device table has dropped it and no delivery pass that may hold it lives (limbo_)
     owners_.release(r->second.id);
     owners_epoch_.store(owners_.changes, std::memory_order_release);
     clients_.release(client_key(r->second.id.node_id, r->second.id.client_id));
@@ -255,13 +261,13 @@ Result<bool> GpuRouter::filters_pass(const std::string& blob, const std::vector<
     // after a few rounds the pass simply runs under the exclusive lock (no live-lock under subscribe churn: r3c).
     for (int attempt = 0; attempt < 3; ++attempt) {
         {
-            std::shared_lock<std::shared_mutex> sh(mu_);
+            std::shared_lock<TableMutex> sh(mu_);
             if (!dirty_) return device_pass(blob, offs, pass);
         }
-        std::unique_lock<std::shared_mutex> x(mu_);
+        std::unique_lock<TableMutex> x(mu_);
         if (commit_if_dirty() != RGR_OK) return Result<bool>::Err(rgr_last_error());
     }
-    std::unique_lock<std::shared_mutex> x(mu_);
+    std::unique_lock<TableMutex> x(mu_);
     return filters_pass_locked(blob, offs, pass);
 }
 
@@ -322,7 +328,7 @@ std::optional<SubRelationsMap> GpuRouter::expand_locked(const rgr_filters_result
 
 Result<SubRelationsMap> GpuRouter::expand(const FilterPass& pass, size_t t, const Id& id, const TopicName& topic) {
     {
-        std::shared_lock<std::shared_mutex> g(mu_);
+        std::shared_lock<TableMutex> g(mu_);
         if (pass.epoch == mutation_epoch_) {
             uint64_t hits = 0;
             auto m = expand_locked(pass.res, t, id, topic, &hits);
@@ -341,7 +347,7 @@ Result<SubRelationsMap> GpuRouter::rematch(const Id& id, const TopicName& topic)
     stale_expansions_++;
     FilterPass fresh;
     const std::vector<uint64_t> offs{0, topic.size()};
-    std::unique_lock<std::shared_mutex> x(mu_);
+    std::unique_lock<TableMutex> x(mu_);
     auto r = filters_pass_locked(topic, offs, fresh);
     if (!r.ok()) return Result<SubRelationsMap>::Err(r.error);
     auto m = expand_locked(fresh.res, 0, id, topic, nullptr);
@@ -357,7 +363,7 @@ void GpuRouter::expand_chunk(const FilterPass& pass, const size_t* index, const 
     out.reserve(n);
     bool current;
     {
-        std::shared_lock<std::shared_mutex> g(mu_);
+        std::shared_lock<TableMutex> g(mu_);
         current = pass.epoch == mutation_epoch_;
         if (current) {
             uint64_t hits = 0, h = 0;
@@ -392,7 +398,7 @@ Result<bool> GpuRouter::matches_batch(const std::vector<Id>& ids, const std::vec
 // ---- Deliver path: 12-byte tuples with the device's delivery words
 Result<bool> GpuRouter::matches_batch_deliver(const std::vector<Id>& ids, const std::vector<TopicName>& topics,
                                               std::vector<std::optional<SubRelationsMap>>& out) {
-    std::unique_lock<std::shared_mutex> g(mu_);
+    std::unique_lock<TableMutex> g(mu_);
     if (commit_if_dirty() != RGR_OK) return Result<bool>::Err(rgr_last_error());
     std::string blob;
     std::vector<uint64_t> offs(topics.size() + 1, 0);
@@ -494,7 +500,8 @@ Result<bool> GpuRouter::deliver_pass(const std::string& blob, const std::vector<
     const uint32_t n = uint32_t(offs.size() - 1);
     auto run = [&]() -> Result<bool> {
         std::vector<rgr_publish_attr> attrs(n);
-        pass.epoch = mutation_epoch_.load(std::memory_order_acquire);
+        pass.epoch = restore_epoch_.load(std::memory_order_acquire);
+        if (!pass.lease_of) { pass.lease_of = this; pass.lease_parity = unsigned(pass_generation_ & 1u); live_passes_[pass.lease_parity].fetch_add(1, std::memory_order_acq_rel); }
         const uint64_t oe = owners_epoch_.load(std::memory_order_acquire);
         for (uint32_t i = 0; i < n; ++i)
             attrs[i] = rgr_publish_attr{hints && hints[i].epoch == oe ? hints[i].owner : owners_.find(*ids[i]), uint32_t(qos_retain[i] & 7u)};
@@ -502,11 +509,18 @@ Result<bool> GpuRouter::deliver_pass(const std::string& blob, const std::vector<
             return Result<bool>::Err(rgr_last_error());
         return Result<bool>::Ok(true);
     };
-    if (!dirty_.load(std::memory_order_acquire)) {
-        std::shared_lock<std::shared_mutex> g(mu_);
-        if (!dirty_.load(std::memory_order_acquire)) return run();
+    // As filters_pass: the pass itself runs under the SHARED lock; pending changes are committed first under the exclusive one, and a writer slipping in
+    // between the two sends us round again (a few times: then the pass runs under the exclusive lock).  (Until r7z a dirty table meant the whole pass
+    // under the exclusive lock — under subscribe churn that kept the completion threads out for the length of every other pass.)
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        {
+            std::shared_lock<TableMutex> g(mu_);
+            if (!dirty_.load(std::memory_order_acquire)) return run();
+        }
+        std::unique_lock<TableMutex> g(mu_);
+        if (commit_if_dirty() != RGR_OK) return Result<bool>::Err(rgr_last_error());
     }
-    std::unique_lock<std::shared_mutex> g(mu_);
+    std::unique_lock<TableMutex> g(mu_);
     if (commit_if_dirty() != RGR_OK) return Result<bool>::Err(rgr_last_error());
     return run();
 }
@@ -524,7 +538,7 @@ Result<SubRelationsMap> GpuRouter::matches(const Id& id, const TopicName& topic)
 // relation (it leaves with its last one, router.rs:484-490), so the filters of the hits ARE the matched filters.
 Result<std::vector<Route>> GpuRouter::get(const std::string& topic) {
     if (!g_) return Result<std::vector<Route>>::Err(create_error_);
-    std::unique_lock<std::shared_mutex> g(mu_);
+    std::unique_lock<TableMutex> g(mu_);
     if (commit_if_dirty() != RGR_OK) return Result<std::vector<Route>>::Err(rgr_last_error());
     const uint64_t offs[2] = {0, topic.size()};
     rgr_result res{};
@@ -552,7 +566,7 @@ Result<bool> GpuRouter::has_matches(const std::string& topic) {
 }
 
 std::vector<Route> GpuRouter::gets(size_t limit) {   // router.rs:514-541: unique (node, filter) pairs
-    std::shared_lock<std::shared_mutex> g(mu_);
+    std::shared_lock<TableMutex> g(mu_);
     std::vector<Route> out;
     for (auto& kv : relations_) {
         std::vector<NodeId> seen;
@@ -567,12 +581,12 @@ std::vector<Route> GpuRouter::gets(size_t limit) {   // router.rs:514-541: uniqu
 }
 
 size_t GpuRouter::topics_tree() {
-    std::shared_lock<std::shared_mutex> g(mu_);
+    std::shared_lock<TableMutex> g(mu_);
     return relations_.size();      // one trie value per distinct filter (router.rs:571-574)
 }
 
 std::vector<std::string> GpuRouter::list_topics(size_t top) {
-    std::shared_lock<std::shared_mutex> g(mu_);
+    std::shared_lock<TableMutex> g(mu_);
     std::vector<std::string> v;
     for (auto& kv : relations_) { if (v.size() >= top) break; v.push_back(kv.first); }
     return v;

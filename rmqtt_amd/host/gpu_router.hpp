@@ -64,6 +64,24 @@ struct Id {
     bool operator!=(const Id& o) const { return !(*this == o); }
 };
 
+// The table's reader / writer lock.  std::shared_mutex is pthread_rwlock with glibc's default: readers are preferred, and a writer waits until NO reader
+// holds the lock — with two passes in flight and 32 completion threads taking it in turns that is practically never: measured at full publish load
+// (bench.py --router-e2e --e2e-churn, profiles/r07x_*) a subscribe waited 1.1 s.  Here a waiting writer stops NEW readers (they yield until it has
+// been through), so it gets the lock as soon as the current holders are done.  No thread takes the lock shared twice (GpuRouter::SharedHold).
+class TableMutex {
+   public:
+    void lock() { writers_.fetch_add(1, std::memory_order_acq_rel); m_.lock(); writers_.fetch_sub(1, std::memory_order_acq_rel); }
+    bool try_lock() { return m_.try_lock(); }
+    void unlock() { m_.unlock(); }
+    void lock_shared() { while (writers_.load(std::memory_order_acquire) > 0) std::this_thread::yield(); m_.lock_shared(); }
+    bool try_lock_shared() { return writers_.load(std::memory_order_acquire) == 0 && m_.try_lock_shared(); }
+    void unlock_shared() { m_.unlock_shared(); }
+
+   private:
+    std::shared_mutex m_;
+    std::atomic<int> writers_{0};
+};
+
 // types.rs:607-827 (fields the matching path carries).
 struct SubscriptionOptions {
     bool v5 = false;
@@ -194,11 +212,13 @@ class GpuRouter final : public Router {
     // No Local; types.rs:524-539 first hit per v5 client).  `ids` are the publishers (No Local compares whole Ids).
     struct DeliverPass {
         rgr_result res{};
-        uint64_t epoch = 0;                 // mutation epoch the pass saw
+        uint64_t epoch = 0;                 // restore epoch the pass saw (a removal does NOT make a delivery pass stale: see limbo_ below)
+        GpuRouter* lease_of = nullptr;      // the router whose generation counter this pass is counted in while it lives (set by deliver_pass)
+        unsigned lease_parity = 0;
         DeliverPass() = default;
         DeliverPass(const DeliverPass&) = delete;
         DeliverPass& operator=(const DeliverPass&) = delete;
-        ~DeliverPass() { rgr_result_free(&res); }
+        ~DeliverPass() { if (lease_of) lease_of->live_passes_[lease_parity].fetch_sub(1, std::memory_order_acq_rel); rgr_result_free(&res); }
     };
     // A publisher's dense owner id, looked up where the publish is SUBMITTED (many threads) instead of once per publish inside the pass (one driver
     // thread: 0.5 ms of a pass of 3 600 publishes) — or not at all: a session keeps the hint of its own Id (gpu_shared.hpp `From`).  The hint carries
@@ -209,7 +229,8 @@ class GpuRouter final : public Router {
     Result<bool> deliver_pass(const std::string& blob, const std::vector<uint64_t>& offs, const Id* const* ids, const uint8_t* qos_retain, DeliverPass& pass,
                               const OwnerHint* hints = nullptr);
     OwnerHint owner_hint(const Id& id) {
-        std::shared_lock<std::shared_mutex> g(mu_);
+        std::shared_lock<TableMutex> g(mu_, std::defer_lock);
+        if (held_by_this_thread() != this) g.lock();                  // (a resubmission from inside a worker's SharedHold)
         return OwnerHint{owners_.find(id), owners_epoch_.load(std::memory_order_acquire)};
     }
     // One recipient of one publish, as the device decided it; pointers into the router's relations map (valid while the visitor runs).
@@ -220,14 +241,15 @@ class GpuRouter final : public Router {
         uint32_t subscription_identifier;              // 0 = none; of THIS hit
         bool v5_duplicate;                             // later hit of a v5 client already delivered to: only its identifier counts (types.rs:526-534)
     };
-    enum class DeliverOutcome { Done, InvalidTopic, NeedsHostPath };      // NeedsHostPath: $share members among the hits, or the pass is older than the last
-                                                                          // removal (a recycled sub id): the caller takes the reference's own path for this publish
+    // NeedsHostPath: $share members among the hits — the caller takes the reference's own path for this publish.  Stale: the pass is older than the last
+    // removal (a sub id may have been recycled): the publish has to be matched again — through another batch (GpuShared resubmits it), not one by one.
+    enum class DeliverOutcome { Done, InvalidTopic, NeedsHostPath, Stale };
     // Every hit of publish `t` of the pass that is not dropped by No Local, in TopicTree::matches order; `visit` returns nothing.  Holds the table's
     // shared lock while it runs (like expand()).
     template <class Visit> DeliverOutcome visit_deliveries(const DeliverPass& pass, size_t t, Visit&& visit) {
-        std::shared_lock<std::shared_mutex> g(mu_, std::defer_lock);
+        std::shared_lock<TableMutex> g(mu_, std::defer_lock);
         if (held_by_this_thread() != this) g.lock();              // (a worker's run of publishes holds it once: SharedHold)
-        if (pass.epoch != mutation_epoch_.load(std::memory_order_acquire)) { stale_expansions_++; return DeliverOutcome::NeedsHostPath; }
+        if (pass.epoch != restore_epoch_.load(std::memory_order_acquire)) { stale_expansions_++; return DeliverOutcome::Stale; }
         if (pass.res.status[t] != RGR_TOPIC_OK) return DeliverOutcome::InvalidTopic;
         const uint64_t lo = pass.res.hit_offsets[t], hi = pass.res.hit_offsets[t + 1];
         if (shared_rels_)
@@ -236,6 +258,7 @@ class GpuRouter final : public Router {
             const uint32_t w = pass.res.tuples[k].qos_flags;
             if (w & RGR_HIT_NO_LOCAL) continue;
             const Slot& sl = slab_[pass.res.tuples[k].sub_id];
+            if (!sl.rel) continue;                                    // the relation was removed after the pass matched it: nobody to deliver to (its id is not reused while this pass lives)
             const Rel& rel = *sl.rel;
             visit(Delivery{&rel.id.client_id, sl.filter, bulk_loaded_ ? rel.id.node_id : nodes_[w >> 16], uint8_t(w & RGR_HIT_QOS_MASK), (w & RGR_HIT_RETAIN) != 0,
                            rel.opts.v5, rel.opts.v5 ? rel.opts.subscription_identifier : 0u, (w & RGR_HIT_V5_DUP) != 0});
@@ -306,13 +329,22 @@ class GpuRouter final : public Router {
     bool bulk_loaded_ = false;           // relations loaded by restore(): the tuples' node bits are not populated
     // add / remove / restore / commit: exclusive; a device pass and the host expansion of its result: shared (the reference:
     // DashMap + a trie RwLock) — so several passes walk the same committed table at once.  A sub id freed by remove() is
-    // quarantined until the next commit has dropped it from the device table, and a pass remembers the mutation epoch it ran at
-    // (bumped by remove / restore only: an add never recycles an id a pass in flight may hold): expand() re-runs a publish whose
-    // pass is older than the last removal, so a recycled id can never resolve to a relation the device did not match.
-    std::shared_mutex mu_;
+    // kept out of circulation until the device table has dropped it AND no pass that may hold it lives (limbo_ below); a FILTER pass remembers the
+    // mutation epoch it ran at (bumped by remove / restore only: an add never recycles an id a pass in flight may hold): expand() re-runs a publish
+    // whose pass is older than the last removal, so a recycled id can never resolve to a relation the device did not match.
+    // (r7z) DELIVERY passes carry one sub id per hit, so a removal does not invalidate them: a hit whose relation is gone is skipped, and a freed sub id
+    // is not handed out again while a delivery pass that may hold it lives.  Two generations: removals go to limbo_[current]; a delivery pass is counted
+    // in live_passes_[generation it started in]; a successful commit with no pass of the PREVIOUS generation alive frees that generation's limbo (those
+    // ids left the device table at the commit that ended it, and every pass that started before is gone) and starts a new generation.  Only restore()
+    // — which renumbers everything — makes delivery passes stale (restore_epoch_).  With the epoch rule alone 410 unsubscribes a second sent a quarter
+    // of 4 M publishes/s round again (profiles/r07y_*).  Filter passes keep the mutation epoch: their ids stand for whole filters.
+    TableMutex mu_;
     std::atomic<uint64_t> mutation_epoch_{0};
+    std::atomic<uint64_t> restore_epoch_{0};
     std::atomic<uint64_t> stale_expansions_{0};
-    std::vector<uint32_t> quarantined_sub_ids_;
+    std::vector<uint32_t> limbo_[2];
+    uint64_t pass_generation_ = 0;               // (changed under the exclusive lock only; passes read it under the shared lock)
+    std::atomic<int64_t> live_passes_[2] = {{0}, {0}};
     MatchMode mode_ = MatchMode::Auto;
     std::atomic<double> mean_hits_{1e9};         // running mean of hits per publish (Auto)
     std::unordered_map<TopicFilter, FilterEntry> relations_;   // AllRelationsMap

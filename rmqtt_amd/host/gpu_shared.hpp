@@ -103,12 +103,14 @@ class GpuShared : public Shared {
     GpuRouter::DeliverOutcome deliver(const GpuRouter::DeliverPass& pass, size_t index, const From& from, const Publish& publish, ForwardedCount& count,
                                       std::vector<Undelivered>* errs);
     GpuRouter::OwnerHint owner_hint_of(const From& from);       // From::owner_hint, refreshed against the owner index's epoch
-    struct Counters { uint64_t device_path, host_path, deliveries, remote, passes; };
-    Counters counters() const { return Counters{device_path_, host_path_, deliveries_, remote_, batcher_.passes()}; }
+    struct Counters { uint64_t device_path, host_path, deliveries, remote, passes, resubmitted; };
+    Counters counters() const { return Counters{device_path_, host_path_, deliveries_, remote_, batcher_.passes(), resubmitted_}; }
     Batcher::Timing timing() const { return batcher_.timing(); }        // where the batcher's threads spent their time (ns summed over threads)
 
    private:
-    struct Pending { GpuShared* self; const From* from; const Publish* publish; Done done; void* user; };
+    struct Pending { GpuShared* self; const From* from; const Publish* publish; Done done; void* user; unsigned tries = 0; };
+    static constexpr unsigned kMaxResubmits = 3;        // a publish whose pass a removal overtook joins another batch; after that many, the host path
+    std::atomic<uint64_t> resubmitted_{0};
     static void on_pass(void* user, uint64_t tag, const std::shared_ptr<GpuRouter::DeliverPass>& pass, size_t index, const Id& from, const std::string* err);
     GpuRouter& router_;
     Shared& inner_;

@@ -527,7 +527,7 @@ char* hr_shared_forwards(void* sh, int use_gpu, const hr_id* from_id, const char
     for (auto& e : es) out += e;
     return dup_str(out);
 }
-void hr_shared_counters(void* sh, uint64_t* out /* [5] device_path, host_path, deliveries, remote, passes */) {
+void hr_shared_counters(void* sh, uint64_t* out /* [5] device_path, host_path, deliveries, remote, passes (resubmissions: hr_forwards_run_async out[12]) */) {
     const auto c = static_cast<LogShared*>(sh)->gpu->counters();
     out[0] = c.device_path; out[1] = c.host_path; out[2] = c.deliveries; out[3] = c.remote; out[4] = c.passes;
 }
@@ -625,6 +625,7 @@ int hr_forwards_run_async(void* r, const uint8_t* blob, const uint64_t* offs, ui
     out[0] = p; out[1] = rws; out[2] = cnt.passes; out[3] = errs; out[4] = cnt.host_path; out[5] = inner.sink.checksum();
     // out[6..11]: the batcher's clocks, as hr_e2e_run_async reports them
     out[6] = tm.collect_ns; out[7] = tm.pass_ns; out[8] = tm.dispatch_ns; out[9] = tm.task_ns; out[10] = tm.tasks; out[11] = tm.max_task_queue;
+    out[12] = cnt.resubmitted;      // publishes that joined another batch because a removal overtook their pass
     if (n_lat_out) *n_lat_out = std::min<uint32_t>(ctx[0]->lat_n.load(), ctx[0]->n_lat);
     return 0;
 }

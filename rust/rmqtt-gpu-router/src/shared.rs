@@ -143,8 +143,9 @@ impl GpuShared {
         Self { inner: DefaultShared::new(Some(scx.clone())), scx, router, batcher: Arc::new(batcher) }
     }
 
-    /// `forwards_to` (shared.rs:876-963) from delivery words.  `None`: the publish has to take the reference's path.
-    fn deliver(&self, from: &From, publish: &Publish, hits: &DeliverHits) -> Option<(ForwardedRecipients, Vec<(To, From, Publish, Reason)>)> {
+    /// `forwards_to` (shared.rs:876-963) from delivery words.  `Err(stale)`: the publish cannot be finished from these hits — `stale` = a removal overtook
+    /// the pass (it joins another batch), otherwise `$share` members are among the hits (the reference's own path).
+    fn deliver(&self, from: &From, publish: &Publish, hits: &DeliverHits) -> std::result::Result<(ForwardedRecipients, Vec<(To, From, Publish, Reason)>), bool> {
         let this_node = self.scx.node.id();
         let mut ok: ForwardedRecipients = Vec::new();
         let mut errs = Vec::new();
@@ -177,16 +178,16 @@ impl GpuShared {
         {
             let slab = self.router.slab_read();
             if self.router.mutation_epoch() != hits.epoch {
-                return None; // a removal since the pass: a sub id may have been recycled
+                return Err(true); // a removal since the pass: a sub id may have been recycled
             }
             for (sub_id, w) in hits.hits.iter().copied() {
                 if (w >> 8) & (RGR_SUB_SHARED as u32) != 0 {
-                    return None; // $share members: SharedSubscription::choice is the broker's
+                    return Err(false); // $share members: SharedSubscription::choice is the broker's
                 }
                 if w & RGR_HIT_NO_LOCAL != 0 {
                     continue; // router.rs:196-201, decided on the device
                 }
-                let Some((filter, client_id, id)) = slab.relation(sub_id) else { return None };
+                let Some((filter, client_id, id)) = slab.relation(sub_id) else { return Err(true) };
                 if id.node_id != this_node {
                     continue; // shared.rs:809-815: a single-node Shared only warns about other nodes' relations
                 }
@@ -216,7 +217,7 @@ impl GpuShared {
         for (client_id, qos, retain, ids) in rows5 {
             send(client_id, qos, retain, if ids.is_empty() { None } else { Some(ids) });
         }
-        Some((ok, errs))
+        Ok((ok, errs))
     }
 }
 
@@ -236,17 +237,25 @@ impl Shared for GpuShared {
             return self.inner.forwards(msg_id, from, publish).await; // shared.rs:744-770: no matching involved
         }
         let qos_retain = (publish.qos.value() as u32 & 3) | if publish.retain { 4 } else { 0 };
-        let from_owner = self.router.owner_id_of(&from.id);
-        let hits = match self.batcher.deliver(&publish.topic, from_owner, qos_retain).await {
-            Ok(h) => h,
-            Err(e) => {
-                // shared.rs:774-777: an Err of `matches` is logged and nobody is forwarded to
-                log::warn!("forwards, from:{:?}, topic:{:?}, error: {:?}", from, publish.topic, e);
-                return Ok(0);
+        // A publish whose pass a removal overtook joins another batch (a few times) instead of taking the reference's path, which would run a device pass
+        // of ONE publish through `Router::matches`: measured on the C++ twin, two removals a second took Shared::forwards from 4.1 M to 1.5 M publishes/s
+        // that way (profiles/r07x_*).  (The C++ twin goes further — rmqtt_amd/host/gpu_router.hpp `limbo_`: its delivery passes survive removals.)
+        let mut tries = 0;
+        let (recipients, errs) = loop {
+            let from_owner = self.router.owner_id_of(&from.id);
+            let hits = match self.batcher.deliver(&publish.topic, from_owner, qos_retain).await {
+                Ok(h) => h,
+                Err(e) => {
+                    // shared.rs:774-777: an Err of `matches` is logged and nobody is forwarded to
+                    log::warn!("forwards, from:{:?}, topic:{:?}, error: {:?}", from, publish.topic, e);
+                    return Ok(0);
+                }
+            };
+            match self.deliver(&from, &publish, &hits) {
+                Ok(done) => break done,
+                Err(true) if tries < 3 => tries += 1,
+                Err(_) => return self.inner.forwards(msg_id, from, publish).await, // $share members (or a table that will not hold still): the reference's own path
             }
-        };
-        let Some((recipients, errs)) = self.deliver(&from, &publish, &hits) else {
-            return self.inner.forwards(msg_id, from, publish).await; // $share members / stale pass: the reference's own path
         };
         let recipients_count = recipients.len();
         #[cfg(feature = "msgstore")]

@@ -597,3 +597,60 @@ def test_shared_forwards_from_delivery_words_equals_the_reference_path(hr):
     assert a == b and a.endswith("= 1\n")
     hr.hr_shared_free(sh)
     hr.hr_free(g)
+
+
+def test_forwards_while_the_table_changes(hr):
+    """(r7z) Shared::forwards from delivery words while another thread subscribes and unsubscribes.  A removal no longer makes a delivery pass stale: a hit
+    whose relation is gone is skipped, and a freed sub id stays out of circulation until the device table has dropped it and no delivery pass that may
+    hold it lives (gpu_router.hpp, limbo_).  So: the relations nobody touches are ALWAYS delivered to, the clients that only ever subscribe to filters
+    the published topics cannot match are NEVER delivered to — although their relations take the sub ids the churning matchers free — and the device
+    path is taken throughout (no publish falls back to the host path because of a removal)."""
+    import threading
+    import time
+    _shared_api(hr)
+    g = hr.hr_new(1, 0)
+    stable = [("t/+/x", "keep1"), ("t/#", "keep2"), ("t/a/x", "keep3")]
+    for f, c in stable:
+        hid, _ = _id(1, c)
+        assert hr.hr_add(g, f.encode(), len(f), C.byref(hid), C.byref(HrOpts())) == 0
+    sh = hr.hr_shared_new(g, 1, 64, 100)
+    everybody = [c for _, c in stable] + [f"churn{i}" for i in range(7)] + [f"never{i}" for i in range(7)]
+    for c in everybody:
+        hr.hr_shared_connect(sh, c.encode(), len(c.encode()), 0)
+    stop = threading.Event()
+
+    def churn():
+        k = 0
+        while not stop.is_set():
+            f = ["t/+/x", "t/#", "t/a/+", "+/a/x", "t/a/x"][k % 5]               # matches the published topics
+            hid, _ = _id(1, f"churn{k % 7}")
+            hr.hr_add(g, f.encode(), len(f), C.byref(hid), C.byref(HrOpts()))
+            nf = ["o/+/y", "o/#", "u/+"][k % 3]                                  # cannot match them: takes the ids the removals below free
+            nid, _ = _id(1, f"never{(k * 3) % 7}")
+            hr.hr_add(g, nf.encode(), len(nf), C.byref(nid), C.byref(HrOpts()))
+            if k % 4:
+                hr.hr_remove(g, f.encode(), len(f), C.byref(hid))
+            if k % 3 == 0:
+                hr.hr_remove(g, nf.encode(), len(nf), C.byref(nid))
+            k += 1
+            if k % 8 == 0:
+                time.sleep(0.0005)
+    th = threading.Thread(target=churn)
+    th.start()
+    try:
+        pid, _ = _id(1, "publisher")
+        for k in range(1500):
+            t = ["t/a/x", "t/b/x"][k % 2]
+            got = _take(hr, hr.hr_shared_forwards(sh, 1, C.byref(pid), t.encode(), len(t.encode()), 1, 0, None, 0))
+            clients = {ln.split("\t")[0] for ln in got.splitlines() if ln and ln[0] not in "=!"}
+            want = {"keep1", "keep2"} | ({"keep3"} if t == "t/a/x" else set())
+            assert want <= clients, (k, t, got)
+            assert not any(c.startswith("never") for c in clients), (k, t, got)
+    finally:
+        stop.set()
+        th.join()
+    cnt = (C.c_uint64 * 5)()
+    hr.hr_shared_counters(sh, cnt)
+    assert int(cnt[0]) == 1500 and int(cnt[1]) == 0                            # every publish finished on the device path
+    hr.hr_shared_free(sh)
+    hr.hr_free(g)
