@@ -1509,21 +1509,25 @@ def measure_router_e2e(args, quick=False):
         if args.e2e_sweep:
             shapes += [(4, 8192, 32, 2), (8, 32768, 64, 3), (16, 65536, 96, 4), (8, 16384, 32, 1)]
         for subm, outst, workers, passes in shapes:
-            res = (C.c_uint64 * 10)()
+            res = (C.c_uint64 * 11)()
             wall = C.c_double(0)
             lat = np.zeros(400_000, dtype=np.float32)
             nl = C.c_uint32(0)
             L.hr_e2e_run_async(g, tb.ctypes.data, to.ctypes.data, n_t, subm, outst, workers, passes, 4096, 200, 1.0, res, C.byref(wall), None, 0, None)      # warm
+            churn = start_churn(L, g) if getattr(args, "e2e_churn", False) else None
             L.hr_e2e_run_async(g, tb.ctypes.data, to.ctypes.data, n_t, subm, outst, workers, passes, 4096, 200, 4.0 if quick else (5.0 if cfg == 2 else 4.0), res, C.byref(wall),
                                lat.ctypes.data, len(lat), C.byref(nl))
+            churn_rec = stop_churn(churn)
             l = np.sort(lat[:nl.value])
             rec["gpu_async"].append({"submitters": subm, "outstanding": outst, "workers": workers, "passes_in_flight": passes,
                                      "value": round(res[0] / wall.value, 1), "rows_per_s": round(res[1] / wall.value, 1), "device_passes": int(res[2]),
                                      "publishes_per_pass": round(res[0] / max(1, res[2]), 1), "errors": int(res[3]), "wall_s": round(wall.value, 2),
                                      "batcher_ms_per_pass": {"collect": round(res[4] / max(1, res[2]) / 1e6, 3), "device_pass": round(res[5] / max(1, res[2]) / 1e6, 3),
                                                              "dispatch": round(res[6] / max(1, res[2]) / 1e6, 3)},
-                                     "worker_task_us": round(res[7] / max(1, res[8]) / 1e3, 1), "worker_tasks": int(res[8]), "max_task_queue": int(res[9]),
+                                     "worker_task_us": round(res[7] / max(1, res[8]) / 1e3, 1), "worker_tasks": int(res[8]), "max_task_queue": int(res[9]), "requeued_publishes": int(res[10]),
                                      "latency_us": {"p50": round(float(l[len(l) // 2]), 1), "p99": round(float(l[int(len(l) * 0.99)]), 1)} if len(l) else None})
+            if churn_rec:
+                rec["gpu_async"][-1]["subscribe_churn_under_load"] = churn_rec
             log(f"router e2e config {cfg} async: {rec['gpu_async'][-1]}")
         L.hr_free(g)
         o = orc.DefaultRouter()
@@ -1551,6 +1555,45 @@ def measure_router_e2e(args, quick=False):
         if not quick:
             print(json.dumps(rec), flush=True)
     return out if quick else 0
+
+
+def start_churn(L, g):
+    """A subscriber thread beside the publishes of an e2e leg (--e2e-churn): one relation added and removed over and over (Router::add / remove take the
+    table's lock exclusively, the passes and the completions hold it shared) — how long a subscribe waits under full publish load, and what it does to it."""
+    import ctypes as C
+    import threading
+
+    class HrId(C.Structure):
+        _fields_ = [("node_id", C.c_uint64), ("client_id", C.c_char_p), ("client_len", C.c_uint32), ("create_time", C.c_int64), ("lid", C.c_uint16)]
+
+    class HrOpts(C.Structure):
+        _fields_ = [("v5", C.c_uint8), ("qos", C.c_uint8), ("no_local", C.c_uint8), ("rap", C.c_uint8), ("rh", C.c_uint8), ("sub_ident", C.c_uint32),
+                    ("shared_group", C.c_char_p), ("shared_group_len", C.c_uint32)]
+    L.hr_add.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.POINTER(HrId), C.POINTER(HrOpts)]
+    L.hr_remove.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.POINTER(HrId)]
+    stop, lat_add, lat_rm = threading.Event(), [], []
+
+    def churner():
+        cid = b"churner"
+        hid, ho, f = HrId(1, cid, len(cid), 0, 0), HrOpts(1, 1, 0, 0, 0, 0, None, 0), b"churn/+/x"
+        while not stop.is_set():
+            t0 = time.perf_counter(); L.hr_add(g, f, len(f), C.byref(hid), C.byref(ho)); lat_add.append(time.perf_counter() - t0)
+            t0 = time.perf_counter(); L.hr_remove(g, f, len(f), C.byref(hid)); lat_rm.append(time.perf_counter() - t0)
+            time.sleep(0.002)
+    th = threading.Thread(target=churner)
+    th.start()
+    return th, stop, lat_add, lat_rm
+
+
+def stop_churn(churn):
+    if churn is None:
+        return None
+    th, stop, lat_add, lat_rm = churn
+    stop.set(); th.join()
+    q = lambda a, f: round(float(np.quantile(np.asarray(a), f)) * 1e3, 3) if a else None
+    return {"adds": len(lat_add), "removes": len(lat_rm), "add_ms": {"p50": q(lat_add, 0.5), "p99": q(lat_add, 0.99), "max": q(lat_add, 1.0)},
+            "remove_ms": {"p50": q(lat_rm, 0.5), "p99": q(lat_rm, 0.99), "max": q(lat_rm, 1.0)},
+            "what": "one relation added and removed in a loop (2 ms apart) by another thread during the timed run: Router::add / remove wait for the table's exclusive lock"}
 
 
 def measure_forwards_e2e(args, L, W, cfg, n_t, tb, to, blob, offs, client, qos, cores, quick):
@@ -1589,40 +1632,10 @@ def measure_forwards_e2e(args, L, W, cfg, n_t, tb, to, blob, offs, client, qos, 
         lat = np.zeros(200_000, dtype=np.float32)
         nl = C.c_uint32(0)
         L.hr_forwards_run_async(g, tb.ctypes.data, to.ctypes.data, n_t, from_client.ctypes.data, qr.ctypes.data, subm, outst, workers, passes, 4096, 200, 1.0, res, C.byref(wall), None, 0, None)      # warm
-        churn = None
-        if getattr(args, "e2e_churn", False):
-            # a subscriber thread beside the publishes: one relation added and removed over and over (Router::add / remove take the table's lock
-            # exclusively, the passes and the completions hold it shared) — how long a subscribe waits under full publish load
-            import threading
-
-            class HrId(C.Structure):
-                _fields_ = [("node_id", C.c_uint64), ("client_id", C.c_char_p), ("client_len", C.c_uint32), ("create_time", C.c_int64), ("lid", C.c_uint16)]
-
-            class HrOpts(C.Structure):
-                _fields_ = [("v5", C.c_uint8), ("qos", C.c_uint8), ("no_local", C.c_uint8), ("rap", C.c_uint8), ("rh", C.c_uint8), ("sub_ident", C.c_uint32),
-                            ("shared_group", C.c_char_p), ("shared_group_len", C.c_uint32)]
-            L.hr_add.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.POINTER(HrId), C.POINTER(HrOpts)]
-            L.hr_remove.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.POINTER(HrId)]
-            stop_churn, lat_add, lat_rm = threading.Event(), [], []
-
-            def churner():
-                cid = b"churner"
-                hid, ho, f = HrId(1, cid, len(cid), 0, 0), HrOpts(1, 1, 0, 0, 0, 0, None, 0), b"churn/+/x"
-                while not stop_churn.is_set():
-                    t0 = time.perf_counter(); L.hr_add(g, f, len(f), C.byref(hid), C.byref(ho)); lat_add.append(time.perf_counter() - t0)
-                    t0 = time.perf_counter(); L.hr_remove(g, f, len(f), C.byref(hid)); lat_rm.append(time.perf_counter() - t0)
-                    time.sleep(0.002)
-            churn = threading.Thread(target=churner)
-            churn.start()
+        churn = start_churn(L, g) if getattr(args, "e2e_churn", False) else None
         L.hr_forwards_run_async(g, tb.ctypes.data, to.ctypes.data, n_t, from_client.ctypes.data, qr.ctypes.data, subm, outst, workers, passes, 4096, 200, 3.0 if quick else 5.0, res,
                                 C.byref(wall), lat.ctypes.data, len(lat), C.byref(nl))
-        churn_rec = None
-        if churn is not None:
-            stop_churn.set(); churn.join()
-            q = lambda a, f: round(float(np.quantile(np.asarray(a), f)) * 1e3, 3) if a else None
-            churn_rec = {"adds": len(lat_add), "removes": len(lat_rm), "add_ms": {"p50": q(lat_add, 0.5), "p99": q(lat_add, 0.99), "max": q(lat_add, 1.0)},
-                         "remove_ms": {"p50": q(lat_rm, 0.5), "p99": q(lat_rm, 0.99), "max": q(lat_rm, 1.0)},
-                         "what": "one relation added and removed in a loop (2 ms apart) by another thread during the timed run: Router::add / remove wait for the table's exclusive lock"}
+        churn_rec = stop_churn(churn)
         l = np.sort(lat[:nl.value])
         rec["gpu_async"].append({"submitters": subm, "outstanding": outst, "workers": workers, "passes_in_flight": passes,
                                  "value": round(res[0] / wall.value, 1), "recipients_per_s": round(res[1] / wall.value, 1), "device_passes": int(res[2]),

@@ -358,7 +358,7 @@ Result<SubRelationsMap> GpuRouter::rematch(const Id& id, const TopicName& topic)
 // A run of publishes of ONE pass expanded under one acquisition of the shared lock (the Batcher's workers: a shared_mutex taken
 // once per publish by dozens of threads is itself a hot cache line).
 void GpuRouter::expand_chunk(const FilterPass& pass, const size_t* index, const Id* const* ids, const TopicName* const* topics, size_t n,
-                             std::vector<Result<SubRelationsMap>>& out) {
+                             std::vector<Result<SubRelationsMap>>& out, bool* stale) {
     out.clear();
     out.reserve(n);
     bool current;
@@ -375,6 +375,7 @@ void GpuRouter::expand_chunk(const FilterPass& pass, const size_t* index, const 
             if (n) mean_hits_ = 0.9 * std::min(mean_hits_.load(), 1e8) + 0.1 * double(hits) / double(n);
         }
     }
+    if (!current && stale) { *stale = true; return; }            // (the caller sends the run through another batch)
     if (!current) for (size_t i = 0; i < n; ++i) out.push_back(rematch(*ids[i], *topics[i]));
 }
 
@@ -654,7 +655,7 @@ void Batcher::submit(const Id& id, std::string_view topic, Callback cb, void* us
     if (!req) req = new Req;
     req->id = id; req->topic.assign(topic.data(), topic.size());      // (recycled objects: the strings' capacity is reused)
     req->cb = cb; req->user = user; req->tag = tag; req->shard = shard;
-    req->pass.reset(); req->err.clear(); req->done = false;
+    req->pass.reset(); req->err.clear(); req->done = false; req->tries = 0;
     enqueue(req);
 }
 
@@ -668,7 +669,7 @@ void Batcher::submit_deliver(const Id& from, std::string_view topic, uint8_t qos
     req->id = from; req->topic.assign(topic.data(), topic.size());
     req->owner = hint && hint->epoch == router_.owners_epoch() ? *hint : router_.owner_hint(from);
     req->cb = nullptr; req->dcb = cb; req->qos_retain = qos_retain; req->user = user; req->tag = tag; req->shard = shard;
-    req->pass.reset(); req->err.clear(); req->done = false;
+    req->pass.reset(); req->err.clear(); req->done = false; req->tries = 0;
     enqueue(req);
 }
 
@@ -790,7 +791,20 @@ void Batcher::run_task(Task& t) {
     std::vector<const TopicName*> topics(n);
     for (size_t i = 0; i < n; ++i) { index[i] = t.reqs[i]->index; ids[i] = &t.reqs[i]->id; topics[i] = &t.reqs[i]->topic; }
     std::vector<Result<SubRelationsMap>> out;
-    router_.expand_chunk(*t.pass, index.data(), ids.data(), topics.data(), n, out);
+    bool stale = false;
+    router_.expand_chunk(*t.pass, index.data(), ids.data(), topics.data(), n, out, &stale);
+    if (stale) {
+        // a removal overtook the pass: the run joins another batch (up to kMaxRequeues times per publish, then the one-publish re-match) — re-matching
+        // each publish on its own, a device pass of one, is what made the rate collapse under unsubscribe churn (profiles/r07x_*)
+        std::vector<Req*> done;
+        for (Req* r : t.reqs) {
+            if (r->tries < kMaxRequeues && !stop_.load(std::memory_order_acquire)) { r->tries++; r->pass.reset(); requeued_.fetch_add(1, std::memory_order_relaxed); enqueue(r); }
+            else { r->cb(r->user, r->tag, router_.rematch_public(r->id, r->topic)); done.push_back(r); }
+        }
+        if (!done.empty()) recycle(done);
+        t.reqs.clear();
+        return;
+    }
     for (size_t i = 0; i < n; ++i) t.reqs[i]->cb(t.reqs[i]->user, t.reqs[i]->tag, std::move(out[i]));
     recycle(t.reqs);
 }

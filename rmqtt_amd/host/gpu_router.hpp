@@ -204,7 +204,8 @@ class GpuRouter final : public Router {
     Result<SubRelationsMap> expand(const FilterPass& pass, size_t t, const Id& id, const TopicName& topic);
     // n publishes of one pass (index[i] = position inside the pass) under ONE acquisition of the table lock
     void expand_chunk(const FilterPass& pass, const size_t* index, const Id* const* ids, const TopicName* const* topics, size_t n,
-                      std::vector<Result<SubRelationsMap>>& out);
+                      std::vector<Result<SubRelationsMap>>& out, bool* stale = nullptr);      // stale (optional): set instead of re-matching one by one when a removal overtook the pass
+    Result<SubRelationsMap> rematch_public(const Id& id, const TopicName& topic) { return rematch(id, topic); }
     uint64_t stale_expansions() const { return stale_expansions_; }
     // ---- the delivery stage as a pass of its own (r6): what Shared::forwards consumes WITHOUT a SubRelationsMap in between (gpu_shared.hpp).
     // One device pass (rgr_group_match_batch_deliver) for a batch of publishes with their real qos / retain bits: per hit the device has
@@ -427,14 +428,14 @@ class Batcher {
     uint64_t requests() const { uint64_t n = 0; for (const Shard& sh : shards_) { std::lock_guard<std::mutex> g(sh.m); n += sh.requests; } return n; }
     // where the drivers' and workers' time went (nanoseconds summed over threads): collecting a batch (incl. the deadline wait's tail
     // and packing the topics), the device pass (GpuRouter::filters_pass), handing the results on, and the workers' expansion tasks
-    struct Timing { uint64_t collect_ns, pass_ns, dispatch_ns, task_ns, tasks, max_task_queue; };
-    Timing timing() const { return Timing{collect_ns_, pass_ns_, dispatch_ns_, task_ns_, tasks_run_, max_task_queue_}; }
+    struct Timing { uint64_t collect_ns, pass_ns, dispatch_ns, task_ns, tasks, max_task_queue, requeued; };
+    Timing timing() const { return Timing{collect_ns_, pass_ns_, dispatch_ns_, task_ns_, tasks_run_, max_task_queue_, requeued_}; }
 
    private:
     // blocking requests live on their caller's stack and are woken through their own condition variable (one shared cv made 256
     // callers fight for one mutex per pass); asynchronous ones are heap objects that end with their callback
     struct Req { Id id; TopicName topic; Callback cb = nullptr; DeliverCallback dcb = nullptr; uint8_t qos_retain = 0; void* user = nullptr; uint64_t tag = 0; uint32_t shard = 0;
-                 GpuRouter::OwnerHint owner;
+                 GpuRouter::OwnerHint owner; unsigned tries = 0;
                  std::shared_ptr<GpuRouter::FilterPass> pass; size_t index = 0; std::string err; bool done = false;
                  std::mutex m; std::condition_variable cv; };
     // a submitter sticks to one shard: its queue, and the free list its asynchronous requests are recycled through (a finished
@@ -444,6 +445,8 @@ class Batcher {
     struct Task { std::shared_ptr<GpuRouter::FilterPass> pass; std::shared_ptr<GpuRouter::DeliverPass> dpass; std::vector<Req*> reqs; };
     static constexpr size_t kShards = 16;      // submission queues (a submitter sticks to one)
     static constexpr size_t kTaskRun = 64;     // publishes per worker task
+    static constexpr unsigned kMaxRequeues = 8;  // a publish whose FILTER pass a removal overtook joins another batch that many times at most (then the one-publish re-match)
+    std::atomic<uint64_t> requeued_{0};
     GpuRouter& router_;
     size_t max_batch_;
     std::chrono::microseconds max_delay_;

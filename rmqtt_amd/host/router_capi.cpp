@@ -223,8 +223,8 @@ int hr_e2e_run_async(void* r, const uint8_t* blob, const uint64_t* offs, uint32_
         for (auto& c : ctx) while (c->done() < c->submitted) std::this_thread::sleep_for(std::chrono::microseconds(100));
         wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         passes = b.passes();
-        const Batcher::Timing tm = b.timing();      // out[4..9]: where the batcher's threads spent their time (ns summed over threads)
-        out[4] = tm.collect_ns; out[5] = tm.pass_ns; out[6] = tm.dispatch_ns; out[7] = tm.task_ns; out[8] = tm.tasks; out[9] = tm.max_task_queue;
+        const Batcher::Timing tm = b.timing();      // out[4..10]: where the batcher's threads spent their time (ns summed over threads); publishes that joined another batch (stale filter pass)
+        out[4] = tm.collect_ns; out[5] = tm.pass_ns; out[6] = tm.dispatch_ns; out[7] = tm.task_ns; out[8] = tm.tasks; out[9] = tm.max_task_queue; out[10] = tm.requeued;
     }
     if (wall_s) *wall_s = wall;
     out[0] = out[1] = out[3] = 0;
