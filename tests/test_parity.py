@@ -258,6 +258,24 @@ def test_seeded_workloads_small(kind, cfg, n_sub, n_pub):
         assert exp["stats"]["hits"] > 0
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("shift", ["0", "3", "6"])
+def test_small_batches_under_every_lane_mapping(shift, monkeypatch):
+    """(r7) A chunk that cannot fill the chip spreads its walks — and a small batch its tokeniser kernels — over more waves: only every 2^shift-th lane
+    takes an item (kernels.hip small_batch_lane_shift; the rule picks the shift by size).  Every test of a few thousand topics runs under the rule's
+    choice; this one pins the other mappings — all 64 lanes (what a large chunk uses), every 8th, one item per wave — on batches of 1, 63, 257 and
+    20 000 topics (parser edge cases included) against the oracle."""
+    monkeypatch.setenv("RGR_WALK_LANE_SHIFT", shift)
+    (blob, offs, client, qos), (tb, to) = parity.workload(2, 30_000, 20_000)
+    p = Pair("hip")
+    p.add_bulk(blob, offs, client, qos)
+    for n in (1, 63, 257, 20_000):
+        p.check(tb[:int(to[n])], to[:n + 1], what=f"lane shift {shift}, {n} topics")
+    odd = ["", "/", "a//b", "+/x", "a/#/b", "$SYS/x", "a/b/c/d/e/f/g/h/i/j/k/l/m/n/o/p/q/r/s/t", "x" * 300] * 9
+    ob, oo = pack(odd)
+    p.check(ob, oo, what=f"lane shift {shift}, parser edge cases")
+
+
 def test_several_tables_in_one_pass(kind):
     """the reference matches every publish against more `TopicTree`s than the
     router's — e.g. the egress bridges' `TopicTree<(BridgeName, EntryIndex)>`
