@@ -86,15 +86,14 @@ Result<bool> GpuRouter::add(const std::string& topic_filter, const Id& id, const
     if (!g_) return Result<bool>::Err(create_error_);
     if (!valid_topic(topic_filter)) return Result<bool>::Err("invalid topic filter `" + topic_filter + "`");   // router.rs:436 (`?`)
     std::unique_lock<TableMutex> g(mu_);
-    // (no epoch bump: an add cannot make a sub id held by a pass in flight resolve to another relation — ids are recycled only out of
-    // the quarantine that remove() fills, and remove() bumps.  Bumping here sent every batched publish through the exclusive re-match
-    // path under ordinary subscribe churn: round-3 advisor.)
+    // (an add cannot make a sub id held by a pass in flight resolve to another relation: ids are handed out again only out of the limbo that
+    // remove() fills, when no pass that may hold them lives — gpu_router.hpp limbo_)
     auto it = relations_.find(topic_filter);
     if (it == relations_.end()) {
         topics_count_.inc();
-        it = relations_.emplace(topic_filter, FilterEntry{{}}).first;
+        it = relations_.emplace(topic_filter, std::make_shared<FilterEntry>(FilterEntry{topic_filter, {}})).first;
     }
-    auto& rels = it->second.rels;
+    auto& rels = it->second->rels;
     auto old = rels.find(id.client_id);
     uint32_t sub_id;
     const uint32_t owner_id = owners_.acquire(id);
@@ -119,7 +118,7 @@ Result<bool> GpuRouter::add(const std::string& topic_filter, const Id& id, const
         ni = node_idx_.emplace(id.node_id, uint16_t(nodes_.size())).first;
         nodes_.push_back(id.node_id);
     }
-    slab_[sub_id] = Slot{&it->first, &old->second, &it->second};
+    slab_[sub_id] = Slot{&it->second->filter, &old->second, it->second};
     if (rgr_group_subscribe_ex(g_, topic_filter.data(), uint32_t(topic_filter.size()), sub_id, opts.qos, flags_of(opts), ni->second, owner_id,
                                client_idx) != RGR_OK)
         return Result<bool>::Err(rgr_last_error());
@@ -134,13 +133,16 @@ Result<bool> GpuRouter::restore(const raft::Snapshot& snap) {
         if (!valid_topic(r.topic_filter)) return Result<bool>::Err("invalid topic filter `" + r.topic_filter + "`");   // router.rs:559
     if (snap.relations.size() >= RGR_ID_NONE) return Result<bool>::Err("snapshot holds more relations than sub ids");
     std::unique_lock<TableMutex> g(mu_);
-    mutation_epoch_++;
     // relations.clear() (router.rs:557): a fresh device table takes the place of the old one
     rgr_group* fresh = nullptr;
     rgr_config cfg{};
     if (rgr_group_create(&cfg, devices_.data(), uint32_t(devices_.size()), &fresh) != RGR_OK) return Result<bool>::Err(rgr_last_error());
-    std::unordered_map<TopicFilter, FilterEntry> relations;
-    for (auto& r : snap.relations) relations[r.topic_filter].rels[r.client_id] = Rel{r.id, r.opts, 0, 0};   // HashMap::insert: the later entry wins
+    std::unordered_map<TopicFilter, std::shared_ptr<FilterEntry>> relations;
+    for (auto& r : snap.relations) {                                                                        // HashMap::insert: the later entry wins
+        auto& e = relations[r.topic_filter];
+        if (!e) e = std::make_shared<FilterEntry>(FilterEntry{r.topic_filter, {}});
+        e->rels[r.client_id] = Rel{r.id, r.opts, 0, 0};
+    }
     std::vector<Slot> slab;
     OwnerIndex owners;
     Dense clients;
@@ -149,11 +151,11 @@ Result<bool> GpuRouter::restore(const raft::Snapshot& snap) {
     std::vector<uint32_t> sub_ids, owner_ids, client_idx;
     std::vector<uint8_t> qos, flags;
     for (auto& kv : relations)
-        for (auto& rel : kv.second.rels) {
+        for (auto& rel : kv.second->rels) {
             Rel& x = rel.second;
             x.sub_id = uint32_t(slab.size());
             x.owner_id = owners.acquire(x.id);
-            slab.push_back(Slot{&kv.first, &x, &kv.second});
+            slab.push_back(Slot{&kv.second->filter, &x, kv.second});
             blob += kv.first;
             offs.push_back(blob.size());
             sub_ids.push_back(x.sub_id);
@@ -182,7 +184,7 @@ Result<bool> GpuRouter::restore(const raft::Snapshot& snap) {
     clients_ = std::move(clients);
     bulk_loaded_ = true;
     shared_rels_ = 0;
-    for (auto& kv : relations_) for (auto& rel : kv.second.rels) shared_rels_ += rel.second.opts.shared_group ? 1 : 0;
+    for (auto& kv : relations_) for (auto& rel : kv.second->rels) shared_rels_ += rel.second.opts.shared_group ? 1 : 0;
     topics_count_ = Counter{snap.topics_count.count, snap.topics_count.max};             // router.rs:555
     relations_count_ = Counter{snap.relations_count.count, snap.relations_count.max};   // router.rs:568
     dirty_ = true;
@@ -195,16 +197,15 @@ Result<bool> GpuRouter::remove(const std::string& topic_filter, const Id& id) {
     std::unique_lock<TableMutex> g(mu_);
     auto it = relations_.find(topic_filter);
     if (it == relations_.end()) return Result<bool>::Ok(false);
-    auto& rels = it->second.rels;
+    auto& rels = it->second->rels;
     auto r = rels.find(id.client_id);
     if (r == rels.end() || r->second.id != id) return Result<bool>::Ok(false);   // router.rs:460-467
     const uint32_t sub_id = r->second.sub_id;
     const bool last = rels.size() == 1;                              // router.rs:484-490: the filter leaves the trie with its last relation
     if (rgr_group_unsubscribe(g_, topic_filter.data(), uint32_t(topic_filter.size()), sub_id, last ? 1 : 0) != RGR_OK)
         return Result<bool>::Err(rgr_last_error());
-    mutation_epoch_++;
     if (r->second.opts.shared_group) shared_rels_--;
-    slab_[sub_id] = Slot{};
+    slab_[sub_id].rel = nullptr;                      // (the slot keeps its filter's entry until it is handed out again: gpu_router.hpp Slot)
     limbo_[pass_generation_ & 1u].push_back(sub_id);  // reusable when the device table has dropped it and no delivery pass that may hold it lives (limbo_)
     owners_.release(r->second.id);
     owners_epoch_.store(owners_.changes, std::memory_order_release);
@@ -273,7 +274,8 @@ Result<bool> GpuRouter::filters_pass(const std::string& blob, const std::vector<
 
 // caller holds mu_ (shared or exclusive) and the table is committed
 Result<bool> GpuRouter::device_pass(const std::string& blob, const std::vector<uint64_t>& offs, FilterPass& pass) {
-    pass.epoch = mutation_epoch_;
+    pass.epoch = restore_epoch_.load(std::memory_order_acquire);
+    if (!pass.lease_of) { pass.lease_of = this; pass.lease_parity = unsigned(pass_generation_ & 1u); live_passes_[pass.lease_parity].fetch_add(1, std::memory_order_acq_rel); }
     rgr_filters_result_free(&pass.res);
     if (rgr_group_match_filter_subs(g_, reinterpret_cast<const uint8_t*>(blob.data()), offs.data(), uint32_t(offs.size() - 1), &pass.res) != RGR_OK)
         return Result<bool>::Err(rgr_last_error());
@@ -329,7 +331,7 @@ std::optional<SubRelationsMap> GpuRouter::expand_locked(const rgr_filters_result
 Result<SubRelationsMap> GpuRouter::expand(const FilterPass& pass, size_t t, const Id& id, const TopicName& topic) {
     {
         std::shared_lock<TableMutex> g(mu_);
-        if (pass.epoch == mutation_epoch_) {
+        if (pass.epoch == restore_epoch_.load(std::memory_order_acquire)) {
             uint64_t hits = 0;
             auto m = expand_locked(pass.res, t, id, topic, &hits);
             mean_hits_ = 0.9 * std::min(mean_hits_.load(), 1e8) + 0.1 * double(hits);
@@ -364,7 +366,7 @@ void GpuRouter::expand_chunk(const FilterPass& pass, const size_t* index, const 
     bool current;
     {
         std::shared_lock<TableMutex> g(mu_);
-        current = pass.epoch == mutation_epoch_;
+        current = pass.epoch == restore_epoch_.load(std::memory_order_acquire);
         if (current) {
             uint64_t hits = 0, h = 0;
             for (size_t i = 0; i < n; ++i) {
@@ -571,7 +573,7 @@ std::vector<Route> GpuRouter::gets(size_t limit) {   // router.rs:514-541: uniqu
     std::vector<Route> out;
     for (auto& kv : relations_) {
         std::vector<NodeId> seen;
-        for (auto& r : kv.second.rels) {
+        for (auto& r : kv.second->rels) {
             if (out.size() >= limit) return out;
             if (std::find(seen.begin(), seen.end(), r.second.id.node_id) != seen.end()) continue;
             seen.push_back(r.second.id.node_id);

@@ -192,11 +192,13 @@ class GpuRouter final : public Router {
     // tokio worker does in the reference): one device pass for the whole batch, then expand() per publish on any thread.
     struct FilterPass {
         rgr_filters_result res{};
-        uint64_t epoch = 0;                 // mutation epoch the pass saw
+        uint64_t epoch = 0;                 // restore epoch the pass saw (removals do not make it stale since r8j: Slot / limbo_)
+        GpuRouter* lease_of = nullptr;      // counted in the router's pass generation while it lives (set by device_pass)
+        unsigned lease_parity = 0;
         FilterPass() = default;
         FilterPass(const FilterPass&) = delete;
         FilterPass& operator=(const FilterPass&) = delete;
-        ~FilterPass() { rgr_filters_result_free(&res); }
+        ~FilterPass() { if (lease_of) lease_of->live_passes_[lease_parity].fetch_sub(1, std::memory_order_acq_rel); rgr_filters_result_free(&res); }
     };
     Result<bool> filters_pass(const std::vector<TopicName>& topics, FilterPass& pass);
     Result<bool> filters_pass(const std::string& blob, const std::vector<uint64_t>& offs, FilterPass& pass);      // topics already packed
@@ -316,8 +318,11 @@ class GpuRouter final : public Router {
         void release(const std::string& k);
         uint32_t find(const std::string& k) const;                             // RGR_ID_NONE if absent
     };
-    struct FilterEntry { std::unordered_map<ClientId, Rel> rels; };
-    struct Slot { const std::string* filter = nullptr; const Rel* rel = nullptr; const FilterEntry* entry = nullptr; };
+    // A filter's relations.  Shared: a slot whose relation has been removed keeps its filter's entry (and through it the filter string) until the slot
+    // is handed out again — so a FILTER pass that holds the id of a removed relation as its filter's representative still expands the filter's
+    // CURRENT relations instead of going stale (r8j; ids are not handed out again while a pass that may hold them lives: limbo_).
+    struct FilterEntry { std::string filter; std::unordered_map<ClientId, Rel> rels; };
+    struct Slot { const std::string* filter = nullptr; const Rel* rel = nullptr; std::shared_ptr<const FilterEntry> entry; };      // filter = &entry->filter
 
     rgr_group* g_ = nullptr;
     std::shared_ptr<SharedSubscription> shared_;
@@ -330,17 +335,15 @@ class GpuRouter final : public Router {
     bool bulk_loaded_ = false;           // relations loaded by restore(): the tuples' node bits are not populated
     // add / remove / restore / commit: exclusive; a device pass and the host expansion of its result: shared (the reference:
     // DashMap + a trie RwLock) — so several passes walk the same committed table at once.  A sub id freed by remove() is
-    // kept out of circulation until the device table has dropped it AND no pass that may hold it lives (limbo_ below); a FILTER pass remembers the
-    // mutation epoch it ran at (bumped by remove / restore only: an add never recycles an id a pass in flight may hold): expand() re-runs a publish
-    // whose pass is older than the last removal, so a recycled id can never resolve to a relation the device did not match.
+    // kept out of circulation until the device table has dropped it AND no pass that may hold it lives (limbo_ below), so a recycled id can never
+    // resolve to a relation the device did not match; only restore() — which renumbers everything — makes a pass stale: expand() re-runs its publishes.
     // (r7z) DELIVERY passes carry one sub id per hit, so a removal does not invalidate them: a hit whose relation is gone is skipped, and a freed sub id
     // is not handed out again while a delivery pass that may hold it lives.  Two generations: removals go to limbo_[current]; a delivery pass is counted
     // in live_passes_[generation it started in]; a successful commit with no pass of the PREVIOUS generation alive frees that generation's limbo (those
     // ids left the device table at the commit that ended it, and every pass that started before is gone) and starts a new generation.  Only restore()
-    // — which renumbers everything — makes delivery passes stale (restore_epoch_).  With the epoch rule alone 410 unsubscribes a second sent a quarter
-    // of 4 M publishes/s round again (profiles/r07y_*).  Filter passes keep the mutation epoch: their ids stand for whole filters.
+    // — which renumbers everything — makes passes stale (restore_epoch_).  With the epoch rule alone 410 unsubscribes a second sent a quarter
+    // of 4 M publishes/s round again (profiles/r07y_*).  Filter passes (their ids stand for whole filters) live by the same rule since r8j: Slot.
     TableMutex mu_;
-    std::atomic<uint64_t> mutation_epoch_{0};
     std::atomic<uint64_t> restore_epoch_{0};
     std::atomic<uint64_t> stale_expansions_{0};
     std::vector<uint32_t> limbo_[2];
@@ -348,7 +351,7 @@ class GpuRouter final : public Router {
     std::atomic<int64_t> live_passes_[2] = {{0}, {0}};
     MatchMode mode_ = MatchMode::Auto;
     std::atomic<double> mean_hits_{1e9};         // running mean of hits per publish (Auto)
-    std::unordered_map<TopicFilter, FilterEntry> relations_;   // AllRelationsMap
+    std::unordered_map<TopicFilter, std::shared_ptr<FilterEntry>> relations_;   // AllRelationsMap
     std::vector<Slot> slab_;           // sub_id -> relation
     std::vector<uint32_t> free_sub_ids_;
     // Id -> owner_id, keyed by the Id itself (every field Id equality looks at, types.rs:1841-1851): the publisher of EVERY publish of a delivery
