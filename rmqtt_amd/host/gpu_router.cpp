@@ -37,6 +37,7 @@ uint32_t GpuRouter::Dense::find(const std::string& k) const {
 GpuRouter::GpuRouter(NodeId this_node, int device) : GpuRouter(this_node, std::vector<int>{device}) {}
 
 GpuRouter::GpuRouter(NodeId this_node, const std::vector<int>& devices) : this_node_(this_node) {
+    for (auto& e : owner_bucket_epoch_) e.store(1, std::memory_order_relaxed);
     rgr_config cfg{};
     devices_.assign(devices.begin(), devices.end());
     if (rgr_group_create(&cfg, devices_.data(), uint32_t(devices_.size()), &g_) != RGR_OK) { g_ = nullptr; create_error_ = rgr_last_error(); }
@@ -96,8 +97,9 @@ Result<bool> GpuRouter::add(const std::string& topic_filter, const Id& id, const
     auto& rels = it->second->rels;
     auto old = rels.find(id.client_id);
     uint32_t sub_id;
-    const uint32_t owner_id = owners_.acquire(id);
-    struct PublishOwners { GpuRouter* r; ~PublishOwners() { r->owners_epoch_.store(r->owners_.changes, std::memory_order_release); } } publish_owners{this};
+    bool owner_appeared = false;
+    const uint32_t owner_id = owners_.acquire(id, &owner_appeared);
+    if (owner_appeared) bump_owner_bucket(id);
     if (opts.shared_group) shared_rels_++;
     if (old != rels.end() && old->second.opts.shared_group) shared_rels_--;
     if (old == rels.end()) {
@@ -107,7 +109,9 @@ Result<bool> GpuRouter::add(const std::string& topic_filter, const Id& id, const
         old = rels.emplace(id.client_id, Rel{id, opts, sub_id, owner_id}).first;
     } else {
         sub_id = old->second.sub_id;
-        owners_.release(old->second.id);
+        bool owner_left = false;
+        owners_.release(old->second.id, &owner_left);
+        if (owner_left) bump_owner_bucket(old->second.id);
         clients_.release(client_key(old->second.id.node_id, old->second.id.client_id));
         old->second = Rel{id, opts, sub_id, owner_id};              // HashMap::insert replaces (router.rs:447)
     }
@@ -178,9 +182,8 @@ Result<bool> GpuRouter::restore(const raft::Snapshot& snap) {
     free_sub_ids_.clear();
     limbo_[0].clear(); limbo_[1].clear();
     restore_epoch_++;                            // every id was renumbered: delivery passes in flight are stale
-    owners.changes += owners_.changes + 1;              // (a restore replaces every owner id)
     owners_ = std::move(owners);
-    owners_epoch_.store(owners_.changes, std::memory_order_release);
+    for (auto& e : owner_bucket_epoch_) e.fetch_add(1, std::memory_order_acq_rel);      // (a restore replaces every owner id)
     clients_ = std::move(clients);
     bulk_loaded_ = true;
     shared_rels_ = 0;
@@ -207,8 +210,9 @@ Result<bool> GpuRouter::remove(const std::string& topic_filter, const Id& id) {
     if (r->second.opts.shared_group) shared_rels_--;
     slab_[sub_id].rel = nullptr;                      // (the slot keeps its filter's entry until it is handed out again: gpu_router.hpp Slot)
     limbo_[pass_generation_ & 1u].push_back(sub_id);  // reusable when the device table has dropped it and no delivery pass that may hold it lives (limbo_)
-    owners_.release(r->second.id);
-    owners_epoch_.store(owners_.changes, std::memory_order_release);
+    bool owner_left = false;
+    owners_.release(r->second.id, &owner_left);
+    if (owner_left) bump_owner_bucket(r->second.id);
     clients_.release(client_key(r->second.id.node_id, r->second.id.client_id));
     rels.erase(r);
     relations_count_.dec();
@@ -505,9 +509,8 @@ Result<bool> GpuRouter::deliver_pass(const std::string& blob, const std::vector<
         std::vector<rgr_publish_attr> attrs(n);
         pass.epoch = restore_epoch_.load(std::memory_order_acquire);
         if (!pass.lease_of) { pass.lease_of = this; pass.lease_parity = unsigned(pass_generation_ & 1u); live_passes_[pass.lease_parity].fetch_add(1, std::memory_order_acq_rel); }
-        const uint64_t oe = owners_epoch_.load(std::memory_order_acquire);
         for (uint32_t i = 0; i < n; ++i)
-            attrs[i] = rgr_publish_attr{hints && hints[i].epoch == oe ? hints[i].owner : owners_.find(*ids[i]), uint32_t(qos_retain[i] & 7u)};
+            attrs[i] = rgr_publish_attr{hints && owner_hint_current(hints[i]) ? hints[i].owner : owners_.find(*ids[i]), uint32_t(qos_retain[i] & 7u)};
         if (rgr_group_match_batch_deliver(g_, reinterpret_cast<const uint8_t*>(blob.data()), offs.data(), n, attrs.data(), &pass.res) != RGR_OK)
             return Result<bool>::Err(rgr_last_error());
         return Result<bool>::Ok(true);
@@ -669,7 +672,7 @@ void Batcher::submit_deliver(const Id& from, std::string_view topic, uint8_t qos
     { std::lock_guard<std::mutex> lk(sh.m); if (!sh.free.empty()) { req = sh.free.back(); sh.free.pop_back(); } }
     if (!req) req = new Req;
     req->id = from; req->topic.assign(topic.data(), topic.size());
-    req->owner = hint && hint->epoch == router_.owners_epoch() ? *hint : router_.owner_hint(from);
+    req->owner = hint && router_.owner_hint_current(*hint) ? *hint : router_.owner_hint(from);
     req->cb = nullptr; req->dcb = cb; req->qos_retain = qos_retain; req->user = user; req->tag = tag; req->shard = shard;
     req->pass.reset(); req->err.clear(); req->done = false; req->tries = 0;
     enqueue(req);

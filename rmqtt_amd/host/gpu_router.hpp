@@ -227,14 +227,21 @@ class GpuRouter final : public Router {
     // thread: 0.5 ms of a pass of 3 600 publishes) — or not at all: a session keeps the hint of its own Id (gpu_shared.hpp `From`).  The hint carries
     // the epoch of the owner index it was read at (bumped whenever an Id gets or loses its owner id): deliver_pass looks the Id up again when the
     // index has changed since, so a recycled or newly assigned owner id is never missed.
-    struct OwnerHint { uint32_t owner = RGR_ID_NONE; uint64_t epoch = ~0ull; };
-    uint64_t owners_epoch() const { return owners_epoch_.load(std::memory_order_acquire); }
+    // (r8k) The epoch is PER BUCKET of the Id's hash (kOwnerBuckets of them): one client's first subscribe or last unsubscribe invalidates the cached
+    // hints of 1 / 4 096 of the publishers, not of all of them — with one global epoch a subscriber coming and going 420 times a second sent every
+    // publish of 4 M/s back to the locked lookup (profiles/r08j_*: 1.6 M).  `bucket` travels with the hint (the hash of an Id never changes).
+    static constexpr uint32_t kOwnerBuckets = 4096;
+    struct OwnerHint { uint32_t owner = RGR_ID_NONE; uint32_t bucket = 0; uint64_t epoch = ~0ull; };
+    static uint32_t owner_bucket_of(const Id& id) { return uint32_t(IdHash{}(id) >> 7) % kOwnerBuckets; }
+    uint64_t owners_epoch(uint32_t bucket) const { return owner_bucket_epoch_[bucket].load(std::memory_order_acquire); }
+    bool owner_hint_current(const OwnerHint& h) const { return h.bucket < kOwnerBuckets && h.epoch == owners_epoch(h.bucket); }
     Result<bool> deliver_pass(const std::string& blob, const std::vector<uint64_t>& offs, const Id* const* ids, const uint8_t* qos_retain, DeliverPass& pass,
                               const OwnerHint* hints = nullptr);
     OwnerHint owner_hint(const Id& id) {
         std::shared_lock<TableMutex> g(mu_, std::defer_lock);
         if (held_by_this_thread() != this) g.lock();                  // (a resubmission from inside a worker's SharedHold)
-        return OwnerHint{owners_.find(id), owners_epoch_.load(std::memory_order_acquire)};
+        const uint32_t b = owner_bucket_of(id);
+        return OwnerHint{owners_.find(id), b, owners_epoch(b)};
     }
     // One recipient of one publish, as the device decided it; pointers into the router's relations map (valid while the visitor runs).
     struct Delivery {
@@ -368,25 +375,27 @@ class GpuRouter final : public Router {
         std::unordered_map<Id, std::pair<uint32_t, uint32_t>, IdHash> ids;
         std::vector<uint32_t> free;
         uint32_t next = 0;
-        uint64_t changes = 0;            // keys that appeared or disappeared (published as GpuRouter::owners_epoch_: what a cached OwnerHint is checked against)
-        uint32_t acquire(const Id& k) {
+        // changed (optional): set when the key appeared / disappeared — the caller bumps the epoch of the key's bucket (GpuRouter::owner_bucket_epoch_)
+        uint32_t acquire(const Id& k, bool* changed = nullptr) {
             auto it = ids.find(k);
             if (it != ids.end()) { it->second.second++; return it->second.first; }
             uint32_t id;
             if (!free.empty()) { id = free.back(); free.pop_back(); } else id = next++;
             ids.emplace(k, std::make_pair(id, 1u));
-            ++changes;
+            if (changed) *changed = true;
             return id;
         }
-        void release(const Id& k) {
+        void release(const Id& k, bool* changed = nullptr) {
             auto it = ids.find(k);
             if (it == ids.end()) return;
-            if (--it->second.second == 0) { free.push_back(it->second.first); ids.erase(it); ++changes; }
+            if (--it->second.second == 0) { free.push_back(it->second.first); ids.erase(it); if (changed) *changed = true; }
         }
         uint32_t find(const Id& k) const { auto it = ids.find(k); return it == ids.end() ? RGR_ID_NONE : it->second.first; }
     };
     OwnerIndex owners_;
-    std::atomic<uint64_t> owners_epoch_{0};      // owners_.changes, published after every mutation (add / remove / restore hold mu_ exclusively)
+    // bumped (under the exclusive lock) when an Id of the bucket gets or loses its owner id; restore() bumps every bucket.  Starts at 1: 0 = "never read".
+    std::atomic<uint64_t> owner_bucket_epoch_[kOwnerBuckets];
+    void bump_owner_bucket(const Id& id) { owner_bucket_epoch_[owner_bucket_of(id)].fetch_add(1, std::memory_order_acq_rel); }
     Dense clients_;                      // (node, ClientId) -> client_idx
     std::vector<NodeId> nodes_;          // node_idx -> NodeId
     std::unordered_map<NodeId, uint16_t> node_idx_;

@@ -121,9 +121,11 @@ void GpuShared::on_pass(void* user, uint64_t tag, const std::shared_ptr<GpuRoute
 
 // the publisher's cached owner id (From::owner_hint), refreshed when the owner index has changed since it was read
 GpuRouter::OwnerHint GpuShared::owner_hint_of(const From& from) {
-    const uint64_t oe = router_.owners_epoch();
+    uint32_t bucket = from.owner_bucket.load(std::memory_order_relaxed);
+    if (bucket == 0xFFFFFFFFu) { bucket = GpuRouter::owner_bucket_of(from.id); from.owner_bucket.store(bucket, std::memory_order_relaxed); }
+    const uint64_t oe = router_.owners_epoch(bucket);
     const uint64_t packed = from.owner_hint.load(std::memory_order_relaxed);
-    if (packed != 0 && uint32_t(packed) == uint32_t(oe)) return GpuRouter::OwnerHint{uint32_t(packed >> 32), oe};
+    if (packed != 0 && uint32_t(packed) == uint32_t(oe)) return GpuRouter::OwnerHint{uint32_t(packed >> 32), bucket, oe};
     const GpuRouter::OwnerHint hint = router_.owner_hint(from.id);
     // (0 means "never looked up": an epoch whose low word is 0 is simply not cached)
     if (uint32_t(hint.epoch) != 0) from.owner_hint.store(uint64_t(hint.owner) << 32 | uint32_t(hint.epoch), std::memory_order_relaxed);

@@ -26,13 +26,20 @@ namespace rmqtt {
 
 struct From {                                               // types.rs From: the publisher's Id (+ kind)
     Id id;
-    // the publisher's owner id in the device table, kept by whoever keeps the From (a session keeps its own): owner << 32 | low 32 bits of the owner
-    // index's epoch it was read at.  GpuShared refreshes it when the index has changed; 0 = never looked up (epoch 0 hints are re-checked in the pass).
+    // the publisher's owner id in the device table, kept by whoever keeps the From (a session keeps its own): owner << 32 | low 32 bits of the epoch of
+    // the Id's bucket of the owner index it was read at (0 = never looked up: bucket epochs start at 1), and the bucket itself (the hash of an Id never
+    // changes).  GpuShared refreshes the hint when the bucket's epoch has moved.
     mutable std::atomic<uint64_t> owner_hint{0};
+    mutable std::atomic<uint32_t> owner_bucket{0xFFFFFFFFu};
     From() = default;
     explicit From(Id i) : id(std::move(i)) {}
-    From(const From& o) : id(o.id), owner_hint(o.owner_hint.load(std::memory_order_relaxed)) {}
-    From& operator=(const From& o) { id = o.id; owner_hint.store(o.owner_hint.load(std::memory_order_relaxed), std::memory_order_relaxed); return *this; }
+    From(const From& o) : id(o.id), owner_hint(o.owner_hint.load(std::memory_order_relaxed)), owner_bucket(o.owner_bucket.load(std::memory_order_relaxed)) {}
+    From& operator=(const From& o) {
+        id = o.id;
+        owner_hint.store(o.owner_hint.load(std::memory_order_relaxed), std::memory_order_relaxed);
+        owner_bucket.store(o.owner_bucket.load(std::memory_order_relaxed), std::memory_order_relaxed);
+        return *this;
+    }
 };
 struct Publish {                                            // types.rs Publish: the fields forwards / forwards_to read or rewrite
     std::shared_ptr<const TopicName> topic;                 // ByteString: shared, a clone per recipient (shared.rs:899) bumps a count, copies nothing
