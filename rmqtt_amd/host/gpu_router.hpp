@@ -26,6 +26,7 @@
 // pass (the twin of rust/rmqtt-gpu-router/src/batcher.rs).
 #pragma once
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <cstdint>
@@ -73,7 +74,13 @@ class TableMutex {
     void lock() { writers_.fetch_add(1, std::memory_order_acq_rel); m_.lock(); writers_.fetch_sub(1, std::memory_order_acq_rel); }
     bool try_lock() { return m_.try_lock(); }
     void unlock() { m_.unlock(); }
-    void lock_shared() { while (writers_.load(std::memory_order_acquire) > 0) std::this_thread::yield(); m_.lock_shared(); }
+    void lock_shared() {
+        // (a writer is usually through in a fraction of a millisecond — an add, a remove, a commit; behind a long one (restore) the readers sleep instead of spinning)
+        for (unsigned spins = 0; writers_.load(std::memory_order_acquire) > 0; ++spins) {
+            if (spins < 256) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(100));
+        }
+        m_.lock_shared();
+    }
     bool try_lock_shared() { return writers_.load(std::memory_order_acquire) == 0 && m_.try_lock_shared(); }
     void unlock_shared() { m_.unlock_shared(); }
 
