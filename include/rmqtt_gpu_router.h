@@ -119,7 +119,8 @@ typedef struct rgr_config {
                                    arena is used (0 = default 64)                       */
     uint64_t window_hits;       /* capacity of one expansion window in hits.  0 = default: 2^30 (12 GiB of
                                    tuples) for device-resident passes, 2^28 for passes that stage windows on the
-                                   host, 2^27 for device-resident passes of the delivery stage (measured, round 5).
+                                   host; device-resident passes of the delivery stage: 2^28 in 8-byte hits (RGR_FORMAT_DELIVER8), 2^27 as
+                                   tuples (measured, rounds 5 and 6).
                                    A non-zero value is used as given.                                       */
     uint32_t chunk_topics;      /* topics walked per pass (0 = default 2^21)            */
     uint32_t host_threads;      /* tokeniser threads (0 = hardware concurrency)         */

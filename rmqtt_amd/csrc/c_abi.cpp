@@ -222,7 +222,9 @@ struct rgr_batch {
             // r5q / r5r: 2^27 — the delivery expansion runs 0.328 ms per 2^27-hit window against 0.733 per 2^28 (its tile records, count
             // words and candidate slices of a window stay closer to L2), the dedup's four launches per window cost 0.187 against 0.352:
             // 16.31 -> 16.84 M matches/s; 2^26: 15.0 M, 2^29: 15.4 M, 2^30: 15.0 M (profiles/r05r_*, r05q_*, r05i_*)
-            return std::min<uint64_t>(c, 1ull << 27);
+            // r8o: with this round's dedup passes (0.188 -> 0.129 ms per 2^27-hit window) and 8-byte hits the balance moved: 2^28-hit windows run the
+            // 8-byte form at 21.42 M against 21.04 M (2^29: 20.65, 2^30: 20.03; profiles/r08o_*).  12-byte delivery tuples keep 2^27.
+            return std::min<uint64_t>(c, format == kFmtDeliver8 ? 1ull << 28 : 1ull << 27);
         }
         return (host_out || deliver) ? std::min<uint64_t>(c, h->cfg_window_explicit ? c : (1ull << 28)) : c;
     }
